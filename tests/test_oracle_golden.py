@@ -242,3 +242,87 @@ def test_error_conventions():
     L.p, L.i, L.x = [0, 1], [0], [0.0]
     with pytest.raises(ZeroDivisionError):
         O.cs_lsolve(L, [1.0])
+
+
+# ---- the plain-C oracle must agree bit for bit with the pinned Python oracle ----
+import c_oracle as CO  # noqa: E402
+
+
+def _arr(A):
+    nnz = A.p[A.n]
+    return (np.asarray(A.p, dtype=np.int32), np.asarray(A.i[:nnz], dtype=np.int32),
+            None if A.x is None else np.asarray(A.x[:nnz], dtype=np.float64))
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_c_oracle_kernels(name, meta):
+    g = golden(name)
+    A = unpack(O, g, "A")
+    Ap, Ai, Ax = _arr(A)
+    y = CO.gaxpy(A.m, A.n, Ap, Ai, Ax, g["gaxpy_x"], g["gaxpy_y0"])
+    assert y.tobytes() == g["gaxpy_y"].tobytes()
+    Tp, Ti, Tx = CO.transpose(A.m, A.n, Ap, Ai, Ax)
+    assert Tp.tolist() == g["AT_p"].tolist() and Ti.tolist() == g["AT_i"].tolist()
+    assert Tx.tobytes() == g["AT_x"].tobytes()
+    Cp, Ci, Cx = CO.multiply(A.m, A.n, A.m, Ap, Ai, Ax, Tp, Ti, Tx)
+    mm = meta[name]["AAT"]
+    assert sha(Cp, np.int64) == mm["sha_p"] and sha(Ci, np.int64) == mm["sha_i"]
+    assert sha(Cx, np.float64) == mm["sha_x"]
+    Pp, Pi, Px = CO.multiply(A.m, A.n, A.m, Ap, Ai, None, Tp, Ti, Tx)
+    assert Px is None and Pi.tolist() == Ci.tolist()
+    if "x_lsolve" in g:
+        Lp, Li, Lx = _arr(unpack(O, g, "Lo"))
+        Up, Ui, Ux = _arr(unpack(O, g, "Up"))
+        n = A.n
+        assert CO.lsolve(n, Lp, Li, Lx, g["b"]).tobytes() == g["x_lsolve"].tobytes()
+        assert CO.ltsolve(n, Lp, Li, Lx, g["b"]).tobytes() == g["x_ltsolve"].tobytes()
+        assert CO.usolve(n, Up, Ui, Ux, g["b"]).tobytes() == g["x_usolve"].tobytes()
+        assert CO.utsolve(n, Up, Ui, Ux, g["b"]).tobytes() == g["x_utsolve"].tobytes()
+    if "refL" in g:
+        Lp, Li, Lx = _arr(unpack(O, g, "refL"))
+        Up, Ui, Ux = _arr(unpack(O, g, "refU"))
+        yv = CO.lsolve(A.n, Lp, Li, Lx, g["ref_lu_pb"])
+        assert yv.tobytes() == g["ref_lu_y"].tobytes()
+        assert CO.usolve(A.n, Up, Ui, Ux, yv).tobytes() == g["ref_lu_x"].tobytes()
+
+
+@pytest.mark.parametrize("name", ["bcsstk01", "bcsstk16"])
+def test_c_oracle_cholesky(name):
+    g = golden(name)
+    C = unpack(O, g, "C")
+    n = C.n
+    Cp, Ci, Cx = _arr(C)
+    parent, cp = CO.schol(n, Cp, Ci)
+    S = O.cs_schol(0, C)
+    assert parent.tolist() == S.parent and cp.tolist() == S.cp
+    if name == "bcsstk01":
+        N = O.cs_chol(C, S)
+        Lp, Li, Lx = CO.chol(n, Cp, Ci, Cx, parent, cp)
+        assert Lp.tolist() == N.L.p and Li.tolist() == N.L.i
+        assert Lx.tobytes() == np.asarray(N.L.x).tobytes()
+        bad = Cx.copy()
+        bad[[p for j in range(n) for p in range(Cp[j], Cp[j + 1]) if Ci[p] == j][3]] = -1.0
+        assert CO.chol(n, Cp, Ci, bad, parent, cp) is None
+        Cbad = unpack(O, g, "C")
+        Cbad.x = [float(v) for v in bad]
+        assert O.cs_chol(Cbad, S) is None
+    else:
+        Lp, Li, Lx = CO.chol(n, Cp, Ci, Cx, parent, cp)
+        assert Lp[n] == 610800
+        b = g["b"]
+        x = CO.ltsolve(n, Lp, Li, Lx, CO.lsolve(n, Lp, Li, Lx, b))
+        # csparse_test.py:528-533: ||x||_inf = 1.9998 +- 1e-3
+        assert np.max(np.abs(x)) == pytest.approx(1.9998, abs=1e-3)
+        r = CO.gaxpy(n, n, Cp, Ci, Cx, x, -b)
+        assert np.max(np.abs(r)) / (O.cs_norm(C) * np.max(np.abs(x)) + np.max(np.abs(b))) < 1e-14
+
+
+def test_c_oracle_perm_and_zero_pivot():
+    g = golden("synthetic_20240601")
+    assert CO.ipvec(g["perm"], g["perm_b"]).tolist() == g["ipvec"].tolist()
+    assert CO.pvec(g["perm"], g["perm_b"]).tolist() == g["pvec"].tolist()
+    assert CO.ipvec(None, g["perm_b"]).tolist() == g["perm_b"].tolist()
+    with pytest.raises(ZeroDivisionError):
+        CO.lsolve(1, [0, 1], [0], [0.0], [1.0])
+    with pytest.raises(ZeroDivisionError):
+        CO.usolve(1, [0, 1], [0], [-0.0], [1.0])
