@@ -1,0 +1,179 @@
+"""ctypes binding of libcsx.so (include/csx.h).  Thin on purpose: prototypes,
+status -> exception mapping, numpy <-> pointer helpers.  There is no CPU
+fallback: if the HIP library or a GPU is missing, calls raise."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcsx.so")
+
+OK, EINVAL, EZEROPIVOT, ENOTSPD, ERUNTIME = 0, 1, 2, 3, 4
+TRI_L, TRI_LT, TRI_U, TRI_UT = 0, 1, 2, 3
+GAXPY_AUTO, GAXPY_EXACT, GAXPY_WAVE, GAXPY_TILED, GAXPY_ATOMIC = 0, 1, 2, 3, 4
+
+H = C.c_uint64
+_i32p = C.POINTER(C.c_int32)
+_f64p = C.POINTER(C.c_double)
+_vp = C.c_void_p
+
+_PROTOS = {
+    "csx_init": [C.c_int],
+    "csx_finalize": [],
+    "csx_sync": [],
+    "csx_set_stream": [_vp],
+    "csx_device_info": [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)],
+    "csx_timer_start": [],
+    "csx_timer_stop": [_f64p],
+    "csx_csc_upload": [C.c_int32, C.c_int32, _i32p, _i32p, _f64p, C.POINTER(H)],
+    "csx_csc_alloc": [C.c_int32, C.c_int32, C.c_int32, C.c_int, C.POINTER(H)],
+    "csx_csc_wrap": [C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, C.POINTER(H)],
+    "csx_csc_info": [H, _i32p, _i32p, _i32p, C.POINTER(C.c_int)],
+    "csx_csc_download": [H, _i32p, _i32p, _f64p],
+    "csx_csc_ptrs": [H, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)],
+    "csx_free": [H],
+    "csx_vec_alloc": [C.c_int64, C.POINTER(H)],
+    "csx_vec_upload": [_f64p, C.c_int64, C.POINTER(H)],
+    "csx_vec_wrap": [_vp, C.c_int64, C.POINTER(H)],
+    "csx_vec_download": [H, _f64p, C.c_int64],
+    "csx_vec_write": [H, _f64p, C.c_int64],
+    "csx_vec_fill": [H, C.c_double],
+    "csx_vec_copy": [H, H],
+    "csx_vec_ptr": [H, C.POINTER(_vp), C.POINTER(C.c_int64)],
+    "csx_ivec_upload": [_i32p, C.c_int64, C.POINTER(H)],
+    "csx_ivec_download": [H, _i32p, C.c_int64],
+    "csx_gaxpy": [H, H, H, C.c_int],
+    "csx_gaxpy_prepare": [H, C.c_int],
+    "csx_transpose": [H, C.c_int, C.POINTER(H)],
+    "csx_cumsum": [H, H, C.c_int64, C.POINTER(C.c_int64)],
+    "csx_multiply": [H, H, C.POINTER(H)],
+    "csx_tri_analyse": [H, C.c_int, C.POINTER(H)],
+    "csx_tri_info": [H, _i32p, _i32p, _i32p],
+    "csx_tri_solve": [H, H, C.c_int32],
+    "csx_permute_vec": [H, H, H, C.c_int32, C.c_int32, C.c_int],
+    "csx_schol_host": [C.c_int32, _i32p, _i32p, _i32p, _i32p],
+    "csx_chol": [H, _i32p, _i32p, _i32p, C.POINTER(H)],
+    "csx_cholsol_plan": [H, _i32p, C.POINTER(H)],
+    "csx_cholsol_solve": [H, H, C.c_int32],
+    "csx_gen_grand": [C.c_int32, C.c_int32, C.c_uint64, C.POINTER(H)],
+    "csx_gen_gspd": [C.c_int32, C.c_int32, C.c_uint64, C.POINTER(H)],
+    "csx_gen_vec": [C.c_int64, C.c_uint64, C.c_double, C.c_double, C.POINTER(H)],
+    "csx_gen_rhs": [C.c_int32, C.c_int32, C.c_int32, C.POINTER(H)],
+}
+
+_lib = None
+_ready = False
+
+
+class CsxError(RuntimeError):
+    pass
+
+
+class NotPositiveDefinite(ArithmeticError):
+    pass
+
+
+def load():
+    """dlopen libcsx.so and set prototypes (no GPU needed for this)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libcsx.so is not built: run `python csparse.py_amd/build.py` "
+                              "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        lib = C.CDLL(LIB_PATH)
+        for name, args in _PROTOS.items():
+            fn = getattr(lib, name)
+            fn.argtypes = args
+            fn.restype = C.c_int
+        lib.csx_last_error.restype = C.c_char_p
+        lib.csx_last_error.argtypes = []
+        _lib = lib
+    return _lib
+
+
+def exported_symbols():
+    return sorted(list(_PROTOS) + ["csx_last_error"])
+
+
+def check(status, what=""):
+    if status == OK:
+        return
+    if status == EZEROPIVOT:
+        raise ZeroDivisionError("float division by zero")
+    if status == ENOTSPD:
+        raise NotPositiveDefinite(what or "matrix is not positive definite")
+    if status == EINVAL:
+        raise ValueError("libcsx: bad argument" + (" in " + what if what else ""))
+    raise CsxError("libcsx %s: %s" % (what, load().csx_last_error().decode("utf-8", "replace")))
+
+
+def init(device=None):
+    """Bind this process to one GPU (LOCAL_RANK by default) and create the context."""
+    global _ready
+    lib = load()
+    if not _ready:
+        if device is None:
+            device = int(os.environ.get("CSX_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        st = lib.csx_init(int(device))
+        if st != OK:
+            raise CsxError("csx_init(%d) failed: %s -- the MI355X path has no CPU fallback"
+                           % (device, lib.csx_last_error().decode("utf-8", "replace")))
+        _ready = True
+    return lib
+
+
+def lib():
+    return init()
+
+
+def i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def pi(a):
+    return None if a is None else a.ctypes.data_as(_i32p)
+
+
+def pd(a):
+    return None if a is None else a.ctypes.data_as(_f64p)
+
+
+def new_handle():
+    return H(0)
+
+
+def free(h):
+    if h and _lib is not None and _ready:
+        _lib.csx_free(h)
+
+
+def sync():
+    check(lib().csx_sync(), "csx_sync")
+
+
+def device_info():
+    name = C.create_string_buffer(256)
+    cus = C.c_int(0)
+    mem = C.c_int64(0)
+    check(lib().csx_device_info(name, 256, C.byref(cus), C.byref(mem)), "csx_device_info")
+    return name.value.decode(), cus.value, mem.value
+
+
+class Timer(object):
+    """HIP-event timer on the library's stream (the stream the kernels run on)."""
+
+    def __enter__(self):
+        check(lib().csx_timer_start(), "csx_timer_start")
+        self.ms = None
+        return self
+
+    def __exit__(self, *exc):
+        ms = C.c_double(0.0)
+        check(lib().csx_timer_stop(C.byref(ms)), "csx_timer_stop")
+        self.ms = ms.value
+        return False

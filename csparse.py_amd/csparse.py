@@ -1,0 +1,691 @@
+"""csparse -- drop-in for rwl/CSparse.py's sparse-direct hot path on AMD MI355X.
+
+Same names, same positional signatures, same `cs` objects (CSC: p, i, x; nz ==
+-1) and the same error conventions as the reference module
+(/root/reference/csparse.py, cited as csparse.py:N): bad arguments give False /
+None / -1, a zero pivot in a triangular solve raises ZeroDivisionError, vectors
+are updated in place, matrix results are new `cs` objects.
+
+What runs where
+  * The loops of the hot path -- cs_gaxpy, cs_transpose, cs_multiply,
+    cs_lsolve / cs_ltsolve / cs_usolve / cs_utsolve, the numeric part of cs_chol,
+    and the permute/solve sequence of cs_cholsol / cs_lusol -- run as hand-written
+    HIP kernels (gfx950) behind the C ABI of libcsx.so (include/csx.h), reached
+    through ctypes (_csx.py).  There is no CPU fallback: without the library or a
+    GPU these functions raise.
+  * List-based calls behave exactly like the reference: inputs are uploaded,
+    the result is written back into the caller's list.  For these calls the
+    kernels keep the reference's order of floating-point operations, so y / x
+    come back bit-identical.
+  * Large problems stay on the device: `cs_pin(A)` keeps a matrix resident (and
+    caches its analysis), `dvec` is a device-resident vector / n-by-k block that
+    every function here accepts in place of a list, and results of
+    cs_transpose / cs_multiply on pinned inputs are device-backed `cs` objects
+    whose p / i / x are only copied to the host when read.
+  * Host-side glue that the reference also does in Python (triplet assembly,
+    cs_cumsum, cs_scatter on lists, permutation of a single list) stays Python.
+"""
+import os
+import weakref
+
+import numpy as np
+
+import _csx
+from _csx import (GAXPY_ATOMIC, GAXPY_AUTO, GAXPY_EXACT, GAXPY_TILED,  # noqa: F401
+                  GAXPY_WAVE, TRI_L, TRI_LT, TRI_U, TRI_UT)
+
+CS_VER = 1
+CS_SUBVER = 0
+CS_SUBSUB = 0
+CS_DATE = "May 14, 2012"
+CS_COPYRIGHT = "Copyright (C) Timothy A. Davis, 2006-2011"
+
+
+# --------------------------------------------------------------- containers --
+
+class _DevMatrix(object):
+    """Owner of a libcsx CSC handle (+ cached triangular-solve plans)."""
+
+    def __init__(self, handle):
+        self.handle = handle
+        self.plans = {}
+        self._fin = weakref.finalize(self, _DevMatrix._release, handle, self.plans)
+
+    @staticmethod
+    def _release(handle, plans):
+        for h in plans.values():
+            _csx.free(h)
+        _csx.free(handle)
+
+    def info(self):
+        m, n, nnz, hv = (_csx.C.c_int32(), _csx.C.c_int32(), _csx.C.c_int32(), _csx.C.c_int())
+        _csx.check(_csx.lib().csx_csc_info(self.handle, m, n, nnz, hv), "csx_csc_info")
+        return m.value, n.value, nnz.value, bool(hv.value)
+
+
+class cs(object):
+    """Matrix in compressed-column or triplet form (csparse.py:37-54).
+
+    p, i, x behave as plain attributes.  A matrix produced on the device keeps
+    them there until they are first read."""
+
+    def __init__(self):
+        self.nzmax = 0
+        self.m = 0
+        self.n = 0
+        self._p = []
+        self._i = []
+        self._x = []
+        self.nz = 0
+        self._dev = None       # _DevMatrix when a device copy exists
+        self._lazy = False     # True: host lists not materialised yet
+        self._pinned = False
+
+    def _materialise(self):
+        if self._lazy:
+            m, n, nnz, hv = self._dev.info()
+            p = np.empty(n + 1, dtype=np.int32)
+            i = np.empty(max(nnz, 1), dtype=np.int32)
+            x = np.empty(max(nnz, 1), dtype=np.float64) if hv else None
+            _csx.check(_csx.lib().csx_csc_download(self._dev.handle, _csx.pi(p), _csx.pi(i), _csx.pd(x)),
+                       "csx_csc_download")
+            keep = self.nzmax
+            self._p = p.tolist()
+            self._i = i[:nnz].tolist() + [0] * (keep - nnz)
+            self._x = None if x is None else x[:nnz].tolist() + [0.0] * (keep - nnz)
+            self._lazy = False
+
+    def _touch(self):
+        # host data assigned: a non-pinned device copy is stale
+        if self._dev is not None and not self._lazy:
+            self._dev = None
+            self._pinned = False
+
+    @property
+    def p(self):
+        self._materialise()
+        return self._p
+
+    @p.setter
+    def p(self, v):
+        self._materialise()
+        self._p = v
+        self._touch()
+
+    @property
+    def i(self):
+        self._materialise()
+        return self._i
+
+    @i.setter
+    def i(self, v):
+        self._materialise()
+        self._i = v
+        self._touch()
+
+    @property
+    def x(self):
+        self._materialise()
+        return self._x
+
+    @x.setter
+    def x(self, v):
+        self._materialise()
+        self._x = v
+        self._touch()
+
+
+class css(object):
+    """Symbolic Cholesky / LU / QR analysis (csparse.py:57-76)."""
+
+    def __init__(self):
+        self.pinv = []
+        self.q = []
+        self.parent = []
+        self.cp = []
+        self.leftmost = []
+        self.m2 = 0
+        self.lnz = 0
+        self.unz = 0
+
+
+class csn(object):
+    """Numeric Cholesky / LU / QR factorisation (csparse.py:79-90)."""
+
+    def __init__(self):
+        self.L = None
+        self.U = None
+        self.pinv = []
+        self.B = []
+
+
+class dvec(object):
+    """Device-resident float64 vector (k == 1) or n-by-k row-major block.
+
+    dvec(data)            upload a sequence / numpy array (2-D arrays keep their shape)
+    dvec(n, k=1)          zeros
+    Accepted wherever the reference takes a list x / y / b."""
+
+    def __init__(self, data, k=None, _handle=None):
+        if _handle is not None:
+            self.handle, self.n, self.k = _handle, int(data), int(k or 1)
+        elif isinstance(data, (int, np.integer)):
+            self.n, self.k = int(data), int(k or 1)
+            h = _csx.new_handle()
+            _csx.check(_csx.lib().csx_vec_alloc(self.n * self.k, h), "csx_vec_alloc")
+            self.handle = h
+        else:
+            a = _csx.f64(data)
+            self.n = a.shape[0]
+            self.k = 1 if a.ndim == 1 else int(np.prod(a.shape[1:]))
+            h = _csx.new_handle()
+            _csx.check(_csx.lib().csx_vec_upload(_csx.pd(a), a.size, h), "csx_vec_upload")
+            self.handle = h
+        self._fin = weakref.finalize(self, _csx.free, self.handle)
+
+    def __len__(self):
+        return self.n
+
+    def numpy(self):
+        out = np.empty(self.n * self.k, dtype=np.float64)
+        _csx.check(_csx.lib().csx_vec_download(self.handle, _csx.pd(out), out.size), "csx_vec_download")
+        return out if self.k == 1 else out.reshape(self.n, self.k)
+
+    def tolist(self):
+        return self.numpy().tolist()
+
+    def assign(self, data):
+        a = _csx.f64(data)
+        _csx.check(_csx.lib().csx_vec_write(self.handle, _csx.pd(a), a.size), "csx_vec_write")
+
+    def fill(self, value):
+        _csx.check(_csx.lib().csx_vec_fill(self.handle, float(value)), "csx_vec_fill")
+
+    def copy(self):
+        out = dvec(self.n, self.k)
+        _csx.check(_csx.lib().csx_vec_copy(self.handle, out.handle), "csx_vec_copy")
+        return out
+
+    def device_ptr(self):
+        p = _csx.C.c_void_p()
+        ln = _csx.C.c_int64()
+        _csx.check(_csx.lib().csx_vec_ptr(self.handle, p, ln), "csx_vec_ptr")
+        return p.value
+
+
+# ------------------------------------------------------- predicates, alloc --
+
+def CS_CSC(A):
+    """True if A is compressed-column (csparse.py:113-119)."""
+    return A is not None and A.nz == -1
+
+
+def CS_TRIPLET(A):
+    """True if A is a triplet matrix (csparse.py:122-128)."""
+    return A is not None and A.nz >= 0
+
+
+def ialloc(n):
+    return [0] * n
+
+
+def xalloc(n):
+    return [0.0] * n
+
+
+def cs_spalloc(m, n, nzmax, values, triplet):
+    """Allocate a CSC or triplet matrix (csparse.py:2388-2406)."""
+    A = cs()
+    A.m = m
+    A.n = n
+    A.nzmax = nzmax = max(nzmax, 1)
+    A.nz = 0 if triplet else -1
+    A.p = ialloc(nzmax) if triplet else ialloc(n + 1)
+    A.i = ialloc(nzmax)
+    A.x = xalloc(nzmax) if values else None
+    return A
+
+
+def cs_sprealloc(A, nzmax):
+    """Resize i / x (and p of a triplet); nzmax <= 0 trims (csparse.py:2414-2440)."""
+    if A is None:
+        return False
+    if nzmax <= 0:
+        nzmax = A.p[A.n] if CS_CSC(A) else A.nz
+    A.i = (list(A.i) + [0] * nzmax)[:nzmax]
+    if CS_TRIPLET(A):
+        A.p = (list(A.p) + [0] * nzmax)[:nzmax]
+    if A.x is not None:
+        A.x = (list(A.x) + [0.0] * nzmax)[:nzmax]
+    A.nzmax = nzmax
+    return True
+
+
+# ------------------------------------------- host glue (Python in the reference too) --
+
+def cs_entry(T, i, j, x):
+    """Append one triplet (csparse.py:1068-1091)."""
+    if not CS_TRIPLET(T) or i < 0 or j < 0:
+        return False
+    if T.nz >= T.nzmax:
+        cs_sprealloc(T, 2 * T.nzmax)
+    if T.x is not None:
+        T.x[T.nz] = x
+    T.i[T.nz] = i
+    T.p[T.nz] = j
+    T.nz += 1
+    T.m = max(T.m, i + 1)
+    T.n = max(T.n, j + 1)
+    return True
+
+
+def cs_load(filename, base=0):
+    """Read 'i j aij' lines into a triplet matrix (csparse.py:1307-1327)."""
+    T = cs_spalloc(0, 0, 1, True, True)
+    with open(filename, "rb") as fd:
+        for line in fd:
+            tok = line.split()
+            if len(tok) != 3:
+                return None
+            if not cs_entry(T, int(tok[0]) - base, int(tok[1]) - base, float(tok[2])):
+                return None
+    return T
+
+
+def cs_compress(T):
+    """Triplet -> CSC, a stable sort by column (csparse.py:647-673), done with numpy."""
+    if not CS_TRIPLET(T):
+        return None
+    nz = T.nz
+    C = cs_spalloc(T.m, T.n, nz, T.x is not None, False)
+    cols = np.asarray(T.p[:nz], dtype=np.int64)
+    order = np.argsort(cols, kind="stable")
+    counts = np.bincount(cols, minlength=T.n) if nz else np.zeros(T.n, dtype=np.int64)
+    C.p = [0] + np.cumsum(counts).tolist()
+    pad = C.nzmax - nz
+    C.i = np.asarray(T.i[:nz], dtype=np.int64)[order].tolist() + [0] * pad
+    if T.x is not None:
+        C.x = np.asarray(T.x[:nz], dtype=np.float64)[order].tolist() + [0.0] * pad
+    return C
+
+
+def cs_cumsum(p, c, n):
+    """p[0..n] = exclusive prefix sums of c; c[0..n-1] = p[0..n-1] (csparse.py:767-784)."""
+    if p is None or c is None:
+        return -1
+    total = 0
+    for k in range(n):
+        p[k] = total
+        total += c[k]
+        c[k] = p[k]
+    p[n] = total
+    return total
+
+
+def cs_scatter(A, j, beta, w, x, mark, C, nz):
+    """x += beta * A(:,j) on host lists, new rows appended to C.i (csparse.py:1961-1989).
+    The device SpGEMM (cs_multiply) carries its own accumulator; this is the
+    list-level primitive for callers that use it directly."""
+    if not CS_CSC(A) or w is None or not CS_CSC(C):
+        return -1
+    Ai, Ax, Ci = A.i, A.x, C.i
+    for p in range(A.p[j], A.p[j + 1]):
+        r = Ai[p]
+        if w[r] < mark:
+            w[r] = mark
+            Ci[nz] = r
+            nz += 1
+            if x is not None:
+                x[r] = beta * Ax[p]
+        elif x is not None:
+            x[r] += beta * Ax[p]
+    return nz
+
+
+def cs_norm(A):
+    """1-norm = largest column sum of |a| (csparse.py:1647-1663)."""
+    if not CS_CSC(A) or A.x is None:
+        return -1
+    best = 0
+    for j in range(A.n):
+        s = 0
+        for p in range(A.p[j], A.p[j + 1]):
+            s += abs(A.x[p])
+        best = max(best, s)
+    return best
+
+
+def cs_pinv(p, n):
+    """Inverse permutation (csparse.py:1696-1708)."""
+    if p is None:
+        return None
+    inv = [0] * n
+    for k in range(n):
+        inv[p[k]] = k
+    return inv
+
+
+# ------------------------------------------------------------ device plumbing --
+
+def _upload(A):
+    """Host lists of a CSC `cs` -> libcsx handle.  IndexError for indices the
+    reference would have tripped over."""
+    n = A.n
+    p = _csx.i32(A.p[:n + 1])
+    nnz = int(p[n]) if n >= 0 and len(p) == n + 1 else -1
+    if nnz < 0 or len(A.i) < nnz or (A.x is not None and len(A.x) < nnz):
+        raise IndexError("list index out of range")
+    i = _csx.i32(A.i[:nnz])
+    x = None if A.x is None else _csx.f64(A.x[:nnz])
+    h = _csx.new_handle()
+    st = _csx.lib().csx_csc_upload(A.m, n, _csx.pi(p), _csx.pi(i), _csx.pd(x), h)
+    if st == _csx.EINVAL:
+        raise IndexError("list index out of range")
+    _csx.check(st, "csx_csc_upload")
+    return h
+
+
+class _Resident(object):
+    """Context manager: a device handle for A, temporary unless A is pinned."""
+
+    def __init__(self, A):
+        self.A = A
+        self.temp = None
+
+    def __enter__(self):
+        A = self.A
+        if A._dev is not None:
+            return A._dev
+        dev = _DevMatrix(_upload(A))
+        if A._pinned:
+            A._dev = dev
+        else:
+            self.temp = dev
+        return dev
+
+    def __exit__(self, *exc):
+        if self.temp is not None:
+            self.temp._fin()
+        return False
+
+
+def cs_pin(A):
+    """Keep A resident on the device (and cache its analyses) until cs_unpin /
+    its host lists are reassigned.  In-place edits of A.p / A.i / A.x after
+    pinning are not seen: call cs_invalidate(A)."""
+    if not CS_CSC(A):
+        return None
+    if A._dev is None:
+        A._dev = _DevMatrix(_upload(A))
+    A._pinned = True
+    return A
+
+
+def cs_invalidate(A):
+    if A is not None and not A._lazy:
+        A._dev = None
+    return A
+
+
+def cs_unpin(A):
+    if A is not None:
+        A._pinned = False
+        if not A._lazy:
+            A._dev = None
+    return A
+
+
+def _from_device(handle, nzmax_rule):
+    """Wrap a device result as a lazily materialised `cs`."""
+    dev = _DevMatrix(handle)
+    m, n, nnz, hv = dev.info()
+    C = cs()
+    C.m, C.n, C.nz = m, n, -1
+    C.nzmax = nzmax_rule(nnz)
+    C._dev = dev
+    C._lazy = True
+    C._pinned = True
+    return C
+
+
+def _vec_in(v, need, what):
+    """list / numpy / dvec -> (dvec, writeback)"""
+    if isinstance(v, dvec):
+        if v.n * v.k < need:
+            raise IndexError("list index out of range")
+        return v, None
+    if len(v) < need:
+        raise IndexError("list index out of range")
+    return dvec(np.asarray(v, dtype=np.float64)), v
+
+
+def _write_back(host, d, count):
+    if host is not None:
+        out = d.numpy().reshape(-1)[:count]
+        if isinstance(host, np.ndarray):
+            host.reshape(-1)[:count] = out
+        else:
+            host[:count] = out.tolist()
+
+
+# -------------------------------------------------------------- hot path ----
+
+def cs_gaxpy(A, x, y, mode=None):
+    """y = A*x + y (csparse.py:1199-1213).  True on success, False on bad input.
+
+    Lists: y is updated in place with the reference's exact summation order.
+    dvec x / y: stays on the device; `mode` picks the kernel (default: exact for
+    list calls, the matrix's best plan for device calls)."""
+    if not CS_CSC(A) or x is None or y is None:
+        return False
+    if A.x is None:
+        raise TypeError("'NoneType' object is not subscriptable")
+    dx, _ = _vec_in(x, A.n, "x")
+    dy, yhost = _vec_in(y, A.m, "y")
+    if mode is None:
+        mode = GAXPY_EXACT if (yhost is not None or not isinstance(x, dvec)) else GAXPY_AUTO
+    with _Resident(A) as dA:
+        _csx.check(_csx.lib().csx_gaxpy(dA.handle, dx.handle, dy.handle, mode), "csx_gaxpy")
+    _write_back(yhost, dy, A.m)
+    return True
+
+
+def cs_gaxpy_prepare(A, mode=GAXPY_AUTO):
+    """Build the SpMV plan of a pinned matrix ahead of time (outside timed regions)."""
+    cs_pin(A)
+    _csx.check(_csx.lib().csx_gaxpy_prepare(A._dev.handle, mode), "csx_gaxpy_prepare")
+    return True
+
+
+def cs_transpose(A, values):
+    """C = A' (csparse.py:2292-2315); None if A is not CSC."""
+    if not CS_CSC(A):
+        return None
+    with _Resident(A) as dA:
+        h = _csx.new_handle()
+        _csx.check(_csx.lib().csx_transpose(dA.handle, 1 if values else 0, h), "csx_transpose")
+    C = _from_device(h, lambda nnz: max(nnz, 1))
+    if not A._pinned:
+        C._materialise()
+        C._dev = None
+        C._pinned = False
+    return C
+
+
+def cs_multiply(A, B):
+    """C = A*B (csparse.py:1608-1642): columns in first-touch order, trimmed to nnz."""
+    if not CS_CSC(A) or not CS_CSC(B):
+        return None
+    if A.n != B.m:
+        return None
+    with _Resident(A) as dA, _Resident(B) as dB:
+        h = _csx.new_handle()
+        _csx.check(_csx.lib().csx_multiply(dA.handle, dB.handle, h), "csx_multiply")
+    C = _from_device(h, lambda nnz: nnz)
+    if not (A._pinned and B._pinned):
+        C._materialise()
+        C._i = C._i[:C.nzmax]
+        if C._x is not None:
+            C._x = C._x[:C.nzmax]
+        C._dev = None
+        C._pinned = False
+    return C
+
+
+def _plan(dT, kind):
+    h = dT.plans.get(kind)
+    if h is None:
+        h = _csx.new_handle()
+        _csx.check(_csx.lib().csx_tri_analyse(dT.handle, kind, h), "csx_tri_analyse")
+        dT.plans[kind] = h
+    return h
+
+
+def _trisolve(T, x, kind):
+    if not CS_CSC(T) or x is None:
+        return False
+    if T.x is None:
+        raise TypeError("'NoneType' object is not subscriptable")
+    if T.m != T.n:
+        raise IndexError("list index out of range")
+    dx, xhost = _vec_in(x, T.n, "x")
+    nrhs = dx.k
+    with _Resident(T) as dT:
+        plan = _plan(dT, kind)
+        _csx.check(_csx.lib().csx_tri_solve(plan, dx.handle, nrhs), "csx_tri_solve")
+    _write_back(xhost, dx, T.n * nrhs)
+    return True
+
+
+def cs_lsolve(L, x):
+    """Solve L x = b in place, diagonal first in each column (csparse.py:1330-1345)."""
+    return _trisolve(L, x, TRI_L)
+
+
+def cs_ltsolve(L, x):
+    """Solve L' x = b in place (csparse.py:1348-1365)."""
+    return _trisolve(L, x, TRI_LT)
+
+
+def cs_usolve(U, x):
+    """Solve U x = b in place, diagonal last in each column (csparse.py:2368-2385)."""
+    return _trisolve(U, x, TRI_U)
+
+
+def cs_utsolve(U, x):
+    """Solve U' x = b in place (csparse.py:2460-2475)."""
+    return _trisolve(U, x, TRI_UT)
+
+
+def _perm_handle(p, n):
+    if p is None:
+        return _csx.H(0), None
+    a = _csx.i32(p[:n])
+    h = _csx.new_handle()
+    _csx.check(_csx.lib().csx_ivec_upload(_csx.pi(a), n, h), "csx_ivec_upload")
+    return h, h
+
+
+def _permute(p, b, x, n, inverse):
+    if x is None or b is None:
+        return False
+    if isinstance(b, dvec) and isinstance(x, dvec):
+        h, tmp = _perm_handle(p, n)
+        try:
+            _csx.check(_csx.lib().csx_permute_vec(h, b.handle, x.handle, n, b.k, inverse), "csx_permute_vec")
+        finally:
+            _csx.free(tmp)
+        return True
+    # a single host list: the reference's own loop is the whole job
+    if inverse:
+        for k in range(n):
+            x[p[k] if p is not None else k] = b[k]
+    else:
+        for k in range(n):
+            x[k] = b[p[k] if p is not None else k]
+    return True
+
+
+def cs_ipvec(p, b, x, n):
+    """x(p) = b (csparse.py:1264-1277); p None is the identity."""
+    return _permute(p, b, x, n, 1)
+
+
+def cs_pvec(p, b, x, n):
+    """x = b(p) (csparse.py:1779-1792); p None is the identity."""
+    return _permute(p, b, x, n, 0)
+
+
+# ------------------------------------------------------------- Cholesky ----
+
+def cs_schol(order, A):
+    """Symbolic Cholesky analysis (csparse.py:2051-2072): etree, postorder, column
+    counts -- host C++ inside libcsx.  Only the natural ordering (order 0) is
+    defined: the reference's cs_amd never yields a permutation."""
+    if not CS_CSC(A) or order != 0:
+        return None
+    n = A.n
+    p = _csx.i32(A.p[:n + 1])
+    i = _csx.i32(A.i[:int(p[n])])
+    parent = np.empty(max(n, 1), dtype=np.int32)
+    cp = np.empty(n + 1, dtype=np.int32)
+    st = _csx.load().csx_schol_host(n, _csx.pi(p), _csx.pi(i), _csx.pi(parent), _csx.pi(cp))
+    if st != _csx.OK:
+        return None
+    S = css()
+    S.pinv = None
+    S.q = None
+    S.parent = parent[:n].tolist()
+    S.cp = cp.tolist()
+    S.unz = S.lnz = S.cp[n]
+    return S
+
+
+def cs_chol(A, S):
+    """Numeric Cholesky L L' = P A P' (csparse.py:561-619); None if A is not
+    positive definite.  The returned csn holds L as a device-backed `cs`."""
+    if not CS_CSC(A) or S is None or S.cp is None or S.parent is None:
+        return None
+    n = A.n
+    parent = _csx.i32(S.parent)
+    cp = _csx.i32(S.cp)
+    pinv = None if S.pinv is None else _csx.i32(S.pinv)
+    with _Resident(A) as dA:
+        h = _csx.new_handle()
+        st = _csx.lib().csx_chol(dA.handle, _csx.pi(parent), _csx.pi(cp), _csx.pi(pinv), h)
+    if st == _csx.ENOTSPD:
+        return None
+    _csx.check(st, "csx_chol")
+    N = csn()
+    N.L = _from_device(h, lambda nnz: max(nnz, 1))
+    N.U = None
+    N.pinv = None
+    N.B = None
+    return N
+
+
+def cs_cholsol(order, A, b):
+    """Solve A x = b, A symmetric positive definite, upper triangle used; b is
+    overwritten (csparse.py:622-644).  b may be a list (one system) or a dvec
+    n-by-k block (k systems, factor once)."""
+    if not CS_CSC(A) or b is None:
+        return False
+    n = A.n
+    S = cs_schol(order, A)
+    N = cs_chol(A, S) if S is not None else None
+    if S is None or N is None:
+        return False
+    db, bhost = _vec_in(b, n, "b")
+    pinv = None if S.pinv is None else _csx.i32(S.pinv)
+    plan = _csx.new_handle()
+    _csx.check(_csx.lib().csx_cholsol_plan(N.L._dev.handle, _csx.pi(pinv), plan), "csx_cholsol_plan")
+    try:
+        _csx.check(_csx.lib().csx_cholsol_solve(plan, db.handle, db.k), "csx_cholsol_solve")
+    finally:
+        _csx.free(plan)
+    _write_back(bhost, db, n * db.k)
+    return True
+
+
+def device_name():
+    return _csx.device_info()

@@ -1,0 +1,415 @@
+// Context, handles, host<->device transfers, timers.
+#include <cstdarg>
+#include <cstring>
+#include <mutex>
+
+#include "csx_internal.h"
+
+namespace csx {
+
+static thread_local std::string g_error;
+static Context g_ctx;
+
+void set_error(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_error = buf;
+}
+
+Context &ctx() { return g_ctx; }
+
+int require_ready() {
+    if (!g_ctx.ready) {
+        set_error("csx_init() has not been called");
+        return CSX_ERUNTIME;
+    }
+    return CSX_OK;
+}
+
+csx_handle_t put(Kind k, void *ptr) {
+    auto &objs = g_ctx.objects;
+    for (size_t i = 0; i < objs.size(); i++)
+        if (objs[i].kind == K_FREE) {
+            objs[i] = {k, ptr};
+            return (csx_handle_t)(i + 1);
+        }
+    objs.push_back({k, ptr});
+    return (csx_handle_t)objs.size();
+}
+
+void *get(csx_handle_t h, Kind k) {
+    auto &objs = g_ctx.objects;
+    if (h == 0 || h > objs.size()) return nullptr;
+    Object &o = objs[h - 1];
+    return o.kind == k ? o.ptr : nullptr;
+}
+
+int dmalloc(void **p, size_t bytes) {
+    *p = nullptr;
+    CSX_HIP(hipMalloc(p, bytes ? bytes : 16));
+    return CSX_OK;
+}
+
+void dfree(void *p) {
+    if (p) (void)hipFree(p);
+}
+
+void free_gather(Gather *g) {
+    if (!g) return;
+    dfree(g->ptr);
+    dfree(g->idx);
+    dfree(g->val);
+    delete g;
+}
+
+void free_tiled(TiledPlan *t) {
+    if (!t) return;
+    dfree(t->tile_ptr);
+    dfree(t->tile_key);
+    dfree(t->tile_val);
+    dfree(t->partial);
+    dfree(t->queue);
+    delete t;
+}
+
+void free_csc(Csc *A) {
+    if (!A) return;
+    if (A->owns) {
+        dfree(A->p);
+        dfree(A->i);
+        dfree(A->x);
+    }
+    free_gather(A->rows);
+    free_tiled(A->tiled);
+    delete A;
+}
+
+static void free_vec(Vec *v) {
+    if (!v) return;
+    if (v->owns) dfree(v->d);
+    delete v;
+}
+
+static void free_object(Object &o) {
+    switch (o.kind) {
+        case K_CSC: free_csc((Csc *)o.ptr); break;
+        case K_VEC:
+        case K_IVEC: free_vec((Vec *)o.ptr); break;
+        case K_TRIPLAN: free_triplan((TriPlan *)o.ptr); break;
+        case K_CHOLPLAN: free_cholplan((CholPlan *)o.ptr); break;
+        default: break;
+    }
+    o = {K_FREE, nullptr};
+}
+
+__global__ void k_fill_f64(double *p, int64_t n, double v) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = v;
+}
+
+}  // namespace csx
+
+using namespace csx;
+
+extern "C" {
+
+int csx_init(int device) {
+    Context &c = ctx();
+    if (c.ready) {
+        if (c.device == device) return CSX_OK;
+        set_error("csx_init: context already bound to device %d", c.device);
+        return CSX_EINVAL;
+    }
+    int count = 0;
+    CSX_HIP(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) {
+        set_error("csx_init: device %d out of range (%d visible)", device, count);
+        return CSX_EINVAL;
+    }
+    CSX_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    CSX_HIP(hipGetDeviceProperties(&prop, device));
+    c.cus = prop.multiProcessorCount;
+    CSX_HIP(hipStreamCreateWithFlags(&c.own_stream, hipStreamNonBlocking));
+    c.stream = c.own_stream;
+    CSX_HIP(hipEventCreate(&c.ev0));
+    CSX_HIP(hipEventCreate(&c.ev1));
+    c.device = device;
+    c.ready = true;
+    return CSX_OK;
+}
+
+int csx_finalize(void) {
+    Context &c = ctx();
+    if (!c.ready) return CSX_OK;
+    (void)hipStreamSynchronize(c.stream);
+    for (auto &o : c.objects) free_object(o);
+    c.objects.clear();
+    (void)hipEventDestroy(c.ev0);
+    (void)hipEventDestroy(c.ev1);
+    (void)hipStreamDestroy(c.own_stream);
+    c = Context();
+    return CSX_OK;
+}
+
+const char *csx_last_error(void) { return g_error.c_str(); }
+
+int csx_sync(void) {
+    CSX_TRY(require_ready());
+    CSX_HIP(hipStreamSynchronize(ctx().stream));
+    return CSX_OK;
+}
+
+int csx_set_stream(void *hip_stream) {
+    CSX_TRY(require_ready());
+    CSX_HIP(hipStreamSynchronize(ctx().stream));
+    ctx().stream = hip_stream ? (hipStream_t)hip_stream : ctx().own_stream;
+    return CSX_OK;
+}
+
+int csx_device_info(char *name, int name_cap, int *compute_units, int64_t *hbm_bytes) {
+    CSX_TRY(require_ready());
+    hipDeviceProp_t prop;
+    CSX_HIP(hipGetDeviceProperties(&prop, ctx().device));
+    if (name && name_cap > 0) {
+        std::snprintf(name, (size_t)name_cap, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    return CSX_OK;
+}
+
+int csx_timer_start(void) {
+    CSX_TRY(require_ready());
+    CSX_HIP(hipEventRecord(ctx().ev0, ctx().stream));
+    return CSX_OK;
+}
+
+int csx_timer_stop(double *ms) {
+    CSX_TRY(require_ready());
+    CSX_HIP(hipEventRecord(ctx().ev1, ctx().stream));
+    CSX_HIP(hipEventSynchronize(ctx().ev1));
+    float t = 0.f;
+    CSX_HIP(hipEventElapsedTime(&t, ctx().ev0, ctx().ev1));
+    if (ms) *ms = (double)t;
+    return CSX_OK;
+}
+
+// ---- CSC ----------------------------------------------------------------
+
+int csx_csc_alloc(int32_t m, int32_t n, int32_t nnz, int values, csx_handle_t *out) {
+    CSX_TRY(require_ready());
+    if (m < 0 || n < 0 || nnz < 0 || !out) return CSX_EINVAL;
+    Csc *A = new Csc();
+    A->m = m;
+    A->n = n;
+    A->nnz = nnz;
+    int st = dalloc(&A->p, (size_t)n + 1);
+    if (st == CSX_OK) st = dalloc(&A->i, (size_t)nnz);
+    if (st == CSX_OK && values) st = dalloc(&A->x, (size_t)nnz);
+    if (st != CSX_OK) {
+        free_csc(A);
+        return st;
+    }
+    *out = put(K_CSC, A);
+    return CSX_OK;
+}
+
+int csx_csc_upload(int32_t m, int32_t n, const int32_t *p, const int32_t *i, const double *x,
+                   csx_handle_t *out) {
+    CSX_TRY(require_ready());
+    if (m < 0 || n < 0 || !p || !out) return CSX_EINVAL;
+    int32_t nnz = p[n];
+    if (nnz < 0 || p[0] != 0 || (nnz > 0 && !i)) return CSX_EINVAL;
+    for (int32_t j = 0; j < n; j++)
+        if (p[j] > p[j + 1]) return CSX_EINVAL;
+    for (int32_t q = 0; q < nnz; q++)
+        if (i[q] < 0 || i[q] >= m) return CSX_EINVAL;  // the reference would raise IndexError
+    csx_handle_t h;
+    CSX_TRY(csx_csc_alloc(m, n, nnz, x != nullptr, &h));
+    Csc *A = csc(h);
+    hipStream_t s = ctx().stream;
+    CSX_HIP(hipMemcpyAsync(A->p, p, ((size_t)n + 1) * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    if (nnz) CSX_HIP(hipMemcpyAsync(A->i, i, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    if (nnz && x) CSX_HIP(hipMemcpyAsync(A->x, x, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice, s));
+    CSX_HIP(hipStreamSynchronize(s));
+    *out = h;
+    return CSX_OK;
+}
+
+int csx_csc_wrap(int32_t m, int32_t n, int32_t nnz, void *d_p, void *d_i, void *d_x, csx_handle_t *out) {
+    CSX_TRY(require_ready());
+    if (m < 0 || n < 0 || nnz < 0 || !d_p || (nnz > 0 && !d_i) || !out) return CSX_EINVAL;
+    Csc *A = new Csc();
+    A->m = m;
+    A->n = n;
+    A->nnz = nnz;
+    A->p = (int32_t *)d_p;
+    A->i = (int32_t *)d_i;
+    A->x = (double *)d_x;
+    A->owns = false;
+    *out = put(K_CSC, A);
+    return CSX_OK;
+}
+
+int csx_csc_info(csx_handle_t h, int32_t *m, int32_t *n, int32_t *nnz, int *has_values) {
+    Csc *A = csc(h);
+    if (!A) return CSX_EINVAL;
+    if (m) *m = A->m;
+    if (n) *n = A->n;
+    if (nnz) *nnz = A->nnz;
+    if (has_values) *has_values = A->x != nullptr;
+    return CSX_OK;
+}
+
+int csx_csc_download(csx_handle_t h, int32_t *p, int32_t *i, double *x) {
+    CSX_TRY(require_ready());
+    Csc *A = csc(h);
+    if (!A) return CSX_EINVAL;
+    hipStream_t s = ctx().stream;
+    if (p) CSX_HIP(hipMemcpyAsync(p, A->p, ((size_t)A->n + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (i && A->nnz) CSX_HIP(hipMemcpyAsync(i, A->i, (size_t)A->nnz * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (x && A->x && A->nnz)
+        CSX_HIP(hipMemcpyAsync(x, A->x, (size_t)A->nnz * sizeof(double), hipMemcpyDeviceToHost, s));
+    CSX_HIP(hipStreamSynchronize(s));
+    return CSX_OK;
+}
+
+int csx_csc_ptrs(csx_handle_t h, void **d_p, void **d_i, void **d_x) {
+    Csc *A = csc(h);
+    if (!A) return CSX_EINVAL;
+    if (d_p) *d_p = A->p;
+    if (d_i) *d_i = A->i;
+    if (d_x) *d_x = A->x;
+    return CSX_OK;
+}
+
+int csx_free(csx_handle_t h) {
+    auto &objs = ctx().objects;
+    if (h == 0 || h > objs.size() || objs[h - 1].kind == K_FREE) return CSX_EINVAL;
+    if (ctx().ready) (void)hipStreamSynchronize(ctx().stream);
+    free_object(objs[h - 1]);
+    return CSX_OK;
+}
+
+// ---- vectors ------------------------------------------------------------
+
+static int vec_new(Kind k, int64_t len, size_t elem, csx_handle_t *out, Vec **pv) {
+    CSX_TRY(require_ready());
+    if (len < 0 || !out) return CSX_EINVAL;
+    Vec *v = new Vec();
+    v->len = len;
+    int st = dmalloc(&v->d, (size_t)len * elem);
+    if (st != CSX_OK) {
+        delete v;
+        return st;
+    }
+    *out = put(k, v);
+    *pv = v;
+    return CSX_OK;
+}
+
+int csx_vec_alloc(int64_t len, csx_handle_t *out) {
+    Vec *v;
+    CSX_TRY(vec_new(K_VEC, len, sizeof(double), out, &v));
+    CSX_HIP(hipMemsetAsync(v->d, 0, (size_t)len * sizeof(double), ctx().stream));
+    return CSX_OK;
+}
+
+int csx_vec_upload(const double *src, int64_t len, csx_handle_t *out) {
+    if (!src && len > 0) return CSX_EINVAL;
+    Vec *v;
+    CSX_TRY(vec_new(K_VEC, len, sizeof(double), out, &v));
+    if (len) {
+        CSX_HIP(hipMemcpyAsync(v->d, src, (size_t)len * sizeof(double), hipMemcpyHostToDevice, ctx().stream));
+        CSX_HIP(hipStreamSynchronize(ctx().stream));
+    }
+    return CSX_OK;
+}
+
+int csx_vec_wrap(void *d_ptr, int64_t len, csx_handle_t *out) {
+    CSX_TRY(require_ready());
+    if (len < 0 || (!d_ptr && len > 0) || !out) return CSX_EINVAL;
+    Vec *v = new Vec();
+    v->len = len;
+    v->d = d_ptr;
+    v->owns = false;
+    *out = put(K_VEC, v);
+    return CSX_OK;
+}
+
+int csx_vec_download(csx_handle_t h, double *dst, int64_t len) {
+    CSX_TRY(require_ready());
+    Vec *v = vec(h);
+    if (!v || len < 0 || len > v->len || (!dst && len > 0)) return CSX_EINVAL;
+    if (len) CSX_HIP(hipMemcpyAsync(dst, v->d, (size_t)len * sizeof(double), hipMemcpyDeviceToHost, ctx().stream));
+    CSX_HIP(hipStreamSynchronize(ctx().stream));
+    return CSX_OK;
+}
+
+int csx_vec_write(csx_handle_t h, const double *src, int64_t len) {
+    CSX_TRY(require_ready());
+    Vec *v = vec(h);
+    if (!v || len < 0 || len > v->len || (!src && len > 0)) return CSX_EINVAL;
+    if (len) {
+        CSX_HIP(hipMemcpyAsync(v->d, src, (size_t)len * sizeof(double), hipMemcpyHostToDevice, ctx().stream));
+        CSX_HIP(hipStreamSynchronize(ctx().stream));
+    }
+    return CSX_OK;
+}
+
+int csx_vec_fill(csx_handle_t h, double value) {
+    CSX_TRY(require_ready());
+    Vec *v = vec(h);
+    if (!v) return CSX_EINVAL;
+    if (v->len == 0) return CSX_OK;
+    int64_t blocks = (v->len + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_fill_f64, dim3((unsigned)blocks), dim3(256), 0, ctx().stream, (double *)v->d, v->len, value);
+    CSX_LAUNCH_CHECK();
+    return CSX_OK;
+}
+
+int csx_vec_copy(csx_handle_t hs, csx_handle_t hd) {
+    CSX_TRY(require_ready());
+    Vec *s = vec(hs), *d = vec(hd);
+    if (!s || !d || d->len < s->len) return CSX_EINVAL;
+    if (s->len)
+        CSX_HIP(hipMemcpyAsync(d->d, s->d, (size_t)s->len * sizeof(double), hipMemcpyDeviceToDevice, ctx().stream));
+    return CSX_OK;
+}
+
+int csx_vec_ptr(csx_handle_t h, void **d_ptr, int64_t *len) {
+    Vec *v = vec(h);
+    if (!v) v = ivec(h);
+    if (!v) return CSX_EINVAL;
+    if (d_ptr) *d_ptr = v->d;
+    if (len) *len = v->len;
+    return CSX_OK;
+}
+
+int csx_ivec_upload(const int32_t *src, int64_t len, csx_handle_t *out) {
+    if (!src && len > 0) return CSX_EINVAL;
+    Vec *v;
+    CSX_TRY(vec_new(K_IVEC, len, sizeof(int32_t), out, &v));
+    if (len) {
+        CSX_HIP(hipMemcpyAsync(v->d, src, (size_t)len * sizeof(int32_t), hipMemcpyHostToDevice, ctx().stream));
+        CSX_HIP(hipStreamSynchronize(ctx().stream));
+    }
+    return CSX_OK;
+}
+
+int csx_ivec_download(csx_handle_t h, int32_t *dst, int64_t len) {
+    CSX_TRY(require_ready());
+    Vec *v = ivec(h);
+    if (!v || len < 0 || len > v->len || (!dst && len > 0)) return CSX_EINVAL;
+    if (len) CSX_HIP(hipMemcpyAsync(dst, v->d, (size_t)len * sizeof(int32_t), hipMemcpyDeviceToHost, ctx().stream));
+    CSX_HIP(hipStreamSynchronize(ctx().stream));
+    return CSX_OK;
+}
+
+}  // extern "C"

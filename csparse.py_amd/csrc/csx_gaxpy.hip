@@ -1,0 +1,147 @@
+// cs_gaxpy (csparse.py:1199-1213): y += A x, A in CSC.
+//
+// The reference walks the columns and scatters  y[Ai[p]] += Ax[p] * x[j]
+// (:1211-1212).  A scatter needs atomics on the device; the plans below turn it
+// into gathers over a cached, stably transposed copy of A ("rows": the entries
+// of row r in ascending (column, position) order = the order in which the
+// reference adds them into y[r]).
+//
+//   EXACT   one thread per row, the reference's summation order, multiply and
+//           add rounded separately (no FMA): bit-identical y.
+//   WAVE    one wavefront (or a 4/8/16/32-lane group) per row: coalesced loads
+//           of idx[]/val[], gathered x, shuffle tree reduction.  Deterministic,
+//           differs from the reference only by summation order.
+//   ATOMIC  straight CSC scatter, one wavefront per column, fp64 atomics; no
+//           plan needed.  Order of additions is not deterministic.
+//   TILED   see csx_gaxpy_tiled.hip (matrices whose rows share no columns).
+//
+// Algorithmic bytes per call: 12 nnz + 4(n+1) + 8 n + 16 m  (SURVEY.md 8d).
+#include "csx_internal.h"
+
+namespace csx {
+
+int gaxpy_tiled_prepare(Csc *A);                                 // csx_gaxpy_tiled.hip
+int gaxpy_tiled_run(const Csc *A, const double *x, double *y);   // csx_gaxpy_tiled.hip
+
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(256) void k_gaxpy_exact(int32_t rows, const int32_t *__restrict__ ptr,
+                                                     const int32_t *__restrict__ idx, const double *__restrict__ val,
+                                                     const double *__restrict__ x, double *__restrict__ y) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    double acc = y[r];
+    const int32_t e = ptr[r + 1];
+    for (int32_t q = ptr[r]; q < e; q++) {
+        double t = val[q] * x[idx[q]];
+        acc = acc + t;
+    }
+    y[r] = acc;
+}
+#pragma clang fp contract(fast)
+
+template <int G>
+__global__ __launch_bounds__(256) void k_gaxpy_rows(int32_t rows, const int32_t *__restrict__ ptr,
+                                                    const int32_t *__restrict__ idx, const double *__restrict__ val,
+                                                    const double *__restrict__ x, double *__restrict__ y) {
+    const int sub = threadIdx.x & (G - 1);
+    int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) / G;
+    for (int64_t r = group; r < rows; r += ngroups) {
+        const int32_t b = ptr[r], e = ptr[r + 1];
+        double acc = 0.0;
+        for (int32_t q = b + sub; q < e; q += G) acc = fma(val[q], x[idx[q]], acc);
+#pragma unroll
+        for (int d = G >> 1; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
+        if (sub == 0 && e > b) y[r] += acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gaxpy_atomic(int32_t n, const int32_t *__restrict__ Ap,
+                                                      const int32_t *__restrict__ Ai, const double *__restrict__ Ax,
+                                                      const double *__restrict__ x, double *y) {
+    const int lane = threadIdx.x & 63;
+    int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t j = wave; j < n; j += nwaves) {
+        const int32_t b = Ap[j], e = Ap[j + 1];
+        const double xj = x[j];
+        for (int32_t p = b + lane; p < e; p += 64) unsafeAtomicAdd(&y[Ai[p]], Ax[p] * xj);
+    }
+}
+
+static int run_rows(const Gather *g, int64_t nnz, const double *x, double *y) {
+    hipStream_t s = ctx().stream;
+    if (g->rows == 0) return CSX_OK;
+    const double avg = (double)nnz / (double)g->rows;
+    const int64_t cap = (int64_t)ctx().cus * 32;  // workgroups of 256: 8 per CU x 4 rounds
+#define CSX_ROWS(G)                                                                                     \
+    {                                                                                                   \
+        int64_t blocks = ((int64_t)g->rows * G + 255) / 256;                                            \
+        if (blocks > cap) blocks = cap;                                                                 \
+        hipLaunchKernelGGL(k_gaxpy_rows<G>, dim3((unsigned)blocks), dim3(256), 0, s, g->rows, g->ptr, g->idx, \
+                           g->val, x, y);                                                               \
+    }
+    if (avg > 48) CSX_ROWS(64)
+    else if (avg > 24) CSX_ROWS(32)
+    else if (avg > 12) CSX_ROWS(16)
+    else if (avg > 6) CSX_ROWS(8)
+    else CSX_ROWS(4)
+#undef CSX_ROWS
+    CSX_LAUNCH_CHECK();
+    return CSX_OK;
+}
+
+}  // namespace csx
+
+using namespace csx;
+
+extern "C" int csx_gaxpy_prepare(csx_handle_t hA, int mode) {
+    CSX_TRY(require_ready());
+    Csc *A = csc(hA);
+    if (!A || !A->x) return CSX_EINVAL;
+    switch (mode) {
+        case CSX_GAXPY_ATOMIC: return CSX_OK;
+        case CSX_GAXPY_TILED: return gaxpy_tiled_prepare(A);
+        case CSX_GAXPY_AUTO:
+        case CSX_GAXPY_EXACT:
+        case CSX_GAXPY_WAVE: return build_row_gather(A);
+        default: return CSX_EINVAL;
+    }
+}
+
+extern "C" int csx_gaxpy(csx_handle_t hA, csx_handle_t hx, csx_handle_t hy, int mode) {
+    CSX_TRY(require_ready());
+    Csc *A = csc(hA);
+    Vec *x = vec(hx), *y = vec(hy);
+    if (!A || !x || !y || !A->x || x->len < A->n || y->len < A->m) return CSX_EINVAL;
+    if (A->nnz == 0 || A->m == 0) return CSX_OK;
+    hipStream_t s = ctx().stream;
+    const double *xd = (const double *)x->d;
+    double *yd = (double *)y->d;
+    if (mode == CSX_GAXPY_AUTO) mode = A->tiled ? CSX_GAXPY_TILED : CSX_GAXPY_WAVE;
+    switch (mode) {
+        case CSX_GAXPY_EXACT: {
+            CSX_TRY(build_row_gather(A));
+            int64_t blocks = ((int64_t)A->m + 255) / 256;
+            hipLaunchKernelGGL(k_gaxpy_exact, dim3((unsigned)blocks), dim3(256), 0, s, A->rows->rows, A->rows->ptr,
+                               A->rows->idx, A->rows->val, xd, yd);
+            CSX_LAUNCH_CHECK();
+            return CSX_OK;
+        }
+        case CSX_GAXPY_WAVE:
+            CSX_TRY(build_row_gather(A));
+            return run_rows(A->rows, A->nnz, xd, yd);
+        case CSX_GAXPY_TILED:
+            CSX_TRY(gaxpy_tiled_prepare(A));
+            return gaxpy_tiled_run(A, xd, yd);
+        case CSX_GAXPY_ATOMIC: {
+            int64_t blocks = ((int64_t)A->n + 3) / 4;
+            const int64_t cap = (int64_t)ctx().cus * 32;
+            if (blocks > cap) blocks = cap;
+            hipLaunchKernelGGL(k_gaxpy_atomic, dim3((unsigned)blocks), dim3(256), 0, s, A->n, A->p, A->i, A->x, xd, yd);
+            CSX_LAUNCH_CHECK();
+            return CSX_OK;
+        }
+        default: return CSX_EINVAL;
+    }
+}

@@ -1,0 +1,139 @@
+// Internal declarations shared by the libcsx translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/csx.h"
+
+namespace csx {
+
+void set_error(const char *fmt, ...);
+
+#define CSX_HIP(call)                                                                      \
+    do {                                                                                   \
+        hipError_t _e = (call);                                                            \
+        if (_e != hipSuccess) {                                                            \
+            csx::set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(_e)); \
+            return CSX_ERUNTIME;                                                           \
+        }                                                                                  \
+    } while (0)
+
+#define CSX_TRY(call)            \
+    do {                         \
+        int _s = (call);         \
+        if (_s != CSX_OK) return _s; \
+    } while (0)
+
+#define CSX_LAUNCH_CHECK() CSX_HIP(hipGetLastError())
+
+enum Kind : int { K_FREE = 0, K_CSC, K_VEC, K_IVEC, K_TRIPLAN, K_CHOLPLAN };
+
+struct Csc;
+
+// Row-gather layout used by the wave/exact SpMV and the triangular solves:
+// for row r, entries [ptr[r], ptr[r+1]) hold (idx, val) in the order the
+// reference updates that row.
+struct Gather {
+    int32_t rows = 0;
+    int32_t *ptr = nullptr;
+    int32_t *idx = nullptr;
+    double *val = nullptr;
+};
+
+// LDS-tiled SpMV plan (csx_gaxpy.hip): entries regrouped into tiles of
+// (column slab, row block); within a tile entries stay in column order.
+struct TiledPlan {
+    int32_t row_block = 0;     // rows per LDS tile
+    int32_t nrb = 0;           // number of row blocks
+    int32_t nslab = 0;         // number of column slabs
+    int32_t slab_cols = 0;     // columns per slab
+    int32_t ngroup = 0;        // slab groups (partial-y buffers)
+    int32_t *tile_ptr = nullptr;   // [nslab*nrb + 1], tile t = slab*nrb + rb
+    uint32_t *tile_key = nullptr;  // packed (local col << rb_bits) | local row
+    double *tile_val = nullptr;
+    double *partial = nullptr;     // [ngroup][nrb*row_block]
+    int32_t *queue = nullptr;      // work counters
+    int rb_bits = 0;
+};
+
+struct Csc {
+    int32_t m = 0, n = 0, nnz = 0;
+    int32_t *p = nullptr;
+    int32_t *i = nullptr;
+    double *x = nullptr;  // nullptr: pattern only
+    bool owns = true;
+    // cached plans (built on demand, freed with the matrix)
+    Gather *rows = nullptr;   // stable transpose = rows of A in ascending column order
+    TiledPlan *tiled = nullptr;
+};
+
+struct Vec {
+    int64_t len = 0;
+    void *d = nullptr;
+    bool owns = true;
+};
+
+struct TriPlan;   // csx_trisolve.hip
+struct CholPlan;  // csx_chol.hip
+
+struct Object {
+    Kind kind = K_FREE;
+    void *ptr = nullptr;
+};
+
+struct Context {
+    bool ready = false;
+    int device = -1;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int cus = 0;
+    std::vector<Object> objects;  // handle = index + 1
+};
+
+Context &ctx();
+int require_ready();
+csx_handle_t put(Kind k, void *ptr);
+void *get(csx_handle_t h, Kind k);
+inline Csc *csc(csx_handle_t h) { return (Csc *)get(h, K_CSC); }
+inline Vec *vec(csx_handle_t h) { return (Vec *)get(h, K_VEC); }
+inline Vec *ivec(csx_handle_t h) { return (Vec *)get(h, K_IVEC); }
+
+// device allocation helpers (bytes may be 0 -> still returns a valid pointer)
+int dmalloc(void **p, size_t bytes);
+template <class T>
+inline int dalloc(T **p, size_t count) { return dmalloc((void **)p, count * sizeof(T)); }
+void dfree(void *p);
+
+void free_gather(Gather *g);
+void free_tiled(TiledPlan *t);
+void free_csc(Csc *A);
+void free_triplan(TriPlan *t);
+void free_cholplan(CholPlan *t);
+
+// ---- device primitives (csx_scan.hip, csx_sort.hip) ----
+// out[k] = sum(in[0..k-1]) for k in [0, n]; out has n+1 slots; in may alias out
+// (then the last slot is written too).  total (host) optional.
+int scan_exclusive_i32(const int32_t *in, int32_t *out, int64_t n, int64_t *total_host);
+// col[p] = j for p in [Ap[j], Ap[j+1])
+int expand_columns(const int32_t *Ap, int32_t n, int32_t nnz, int32_t *col);
+// Stable sort of `count` records by key in [0, key_limit).  a = 32-bit payload,
+// v = 64-bit payload (nullptr: none).  Inputs are not modified; outputs may not
+// alias inputs.  out_key may be nullptr.
+int stable_sort_by_key(const uint32_t *key, const uint32_t *a, const double *v, int64_t count,
+                       uint32_t key_limit, uint32_t *out_key, uint32_t *out_a, double *out_v);
+// ptr[r] = first position q with sorted_key[q] >= r, r in [0, nkeys]; ptr has nkeys+1 slots
+int boundaries_from_sorted(const uint32_t *sorted_key, int64_t count, int32_t nkeys, int32_t *ptr);
+
+// ---- building blocks shared across files ----
+int build_row_gather(Csc *A);   // fills A->rows (values required)
+int transpose_device(const Csc *A, bool values, Csc *C);  // C fields allocated here
+
+// sizes
+constexpr int WAVE = 64;
+
+}  // namespace csx

@@ -1,0 +1,148 @@
+/* csx.h -- C ABI of libcsx.so, the MI355X (gfx950) implementation of the
+ * CSparse.py sparse-direct hot path.
+ *
+ * The reference (rwl/CSparse.py) is one pure-Python module with no FFI: its
+ * "plugin interface" for this path is the module namespace (cs_gaxpy, cs_multiply,
+ * cs_transpose, cs_lsolve ... called as `csparse.cs_gaxpy(A, x, y)`,
+ * csparse_test.py:24,146,262).  This header is the C boundary the drop-in module
+ * csparse.py_amd/csparse.py binds with ctypes; every compute entry point names the
+ * reference function (csparse.py:LINE) whose loop it replaces.  INTEGRATION.md
+ * shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - extern "C", plain C types only.  Indices are int32_t, values are double
+ *     (IEEE binary64, what a Python float is); nnz < 2^31.
+ *   - Host buffers belong to the caller.  Device buffers belong to the library,
+ *     behind opaque 64-bit handles, unless created with a *_wrap call (then the
+ *     caller keeps ownership of the device memory: torch tensors can be passed
+ *     as raw device pointers this way).
+ *   - Dense right-hand-side blocks are n-by-k, row-major (element (i, r) at
+ *     i*k + r): the k values of one matrix row are contiguous.
+ *   - Every function returns a status.  No exceptions, no exit().  On
+ *     CSX_ERUNTIME the message is in csx_last_error().
+ *   - One context per process (one process per GPU).  Calls are serialised on
+ *     the context's HIP stream; results are complete after the call returns only
+ *     for functions that copy to host, otherwise after csx_sync().
+ */
+#ifndef CSX_H
+#define CSX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint64_t csx_handle_t;
+
+enum {
+    CSX_OK = 0,
+    CSX_EINVAL = 1,     /* bad argument: the Python layer returns False / None / -1 */
+    CSX_EZEROPIVOT = 2, /* zero diagonal in a triangular solve: Python raises ZeroDivisionError */
+    CSX_ENOTSPD = 3,    /* non-positive pivot in cs_chol: Python returns None (csparse.py:612) */
+    CSX_ERUNTIME = 4    /* HIP runtime failure; see csx_last_error() */
+};
+
+/* triangular-solve kinds (csparse.py:1330, :1348, :2368, :2460) */
+enum { CSX_TRI_L = 0, CSX_TRI_LT = 1, CSX_TRI_U = 2, CSX_TRI_UT = 3 };
+
+/* cs_gaxpy execution modes */
+enum {
+    CSX_GAXPY_AUTO = 0,  /* best available plan for the matrix */
+    CSX_GAXPY_EXACT = 1, /* reference summation order, no FMA: bit-identical to csparse.py:1211-1212 */
+    CSX_GAXPY_WAVE = 2,  /* one wavefront (or sub-wave group) per row of the cached transpose */
+    CSX_GAXPY_TILED = 3, /* LDS-tiled plan for matrices without locality (G-rand) */
+    CSX_GAXPY_ATOMIC = 4 /* direct CSC scatter with fp64 atomics, no plan */
+};
+
+/* ---- context ---------------------------------------------------------- */
+int csx_init(int device);                 /* idempotent; selects the HIP device, creates the stream */
+int csx_finalize(void);                   /* frees every handle and the stream */
+const char *csx_last_error(void);
+int csx_sync(void);                       /* wait for the context's stream */
+int csx_set_stream(void *hip_stream);     /* run on a caller-provided hipStream_t (NULL: own stream) */
+int csx_device_info(char *name, int name_cap, int *compute_units, int64_t *hbm_bytes);
+int csx_timer_start(void);                /* hipEvent on the context's stream */
+int csx_timer_stop(double *ms);           /* second hipEvent, synchronises, elapsed ms */
+
+/* ---- CSC matrices: the reference's `cs` object with nz == -1 (csparse.py:37-54) ---- */
+int csx_csc_upload(int32_t m, int32_t n, const int32_t *p, const int32_t *i, const double *x /* or NULL */,
+                   csx_handle_t *out);
+int csx_csc_alloc(int32_t m, int32_t n, int32_t nnz, int values, csx_handle_t *out);
+int csx_csc_wrap(int32_t m, int32_t n, int32_t nnz, void *d_p, void *d_i, void *d_x /* or NULL */,
+                 csx_handle_t *out);
+int csx_csc_info(csx_handle_t A, int32_t *m, int32_t *n, int32_t *nnz, int *has_values);
+int csx_csc_download(csx_handle_t A, int32_t *p, int32_t *i, double *x /* or NULL */);
+int csx_csc_ptrs(csx_handle_t A, void **d_p, void **d_i, void **d_x);
+int csx_free(csx_handle_t h);             /* any handle kind */
+
+/* ---- dense vectors / row-major blocks (float64) and index vectors (int32) ---- */
+int csx_vec_alloc(int64_t len, csx_handle_t *out);          /* zero-filled */
+int csx_vec_upload(const double *src, int64_t len, csx_handle_t *out);
+int csx_vec_wrap(void *d_ptr, int64_t len, csx_handle_t *out);
+int csx_vec_download(csx_handle_t v, double *dst, int64_t len);
+int csx_vec_write(csx_handle_t v, const double *src, int64_t len);
+int csx_vec_fill(csx_handle_t v, double value);
+int csx_vec_copy(csx_handle_t src, csx_handle_t dst);
+int csx_vec_ptr(csx_handle_t v, void **d_ptr, int64_t *len);
+int csx_ivec_upload(const int32_t *src, int64_t len, csx_handle_t *out);
+int csx_ivec_download(csx_handle_t v, int32_t *dst, int64_t len);
+
+/* ---- hot path --------------------------------------------------------- */
+
+/* cs_gaxpy, csparse.py:1199-1213: y += A x.  x has >= n, y >= m entries. */
+int csx_gaxpy(csx_handle_t A, csx_handle_t x, csx_handle_t y, int mode);
+/* Build (and cache on A) the plan `mode` needs, outside any timed region. */
+int csx_gaxpy_prepare(csx_handle_t A, int mode);
+
+/* cs_transpose, csparse.py:2292-2315: stable counting sort by row. */
+int csx_transpose(csx_handle_t A, int values, csx_handle_t *out);
+
+/* cs_cumsum, csparse.py:767-784, on int32 device vectors: p[0..n] = exclusive
+ * scan of c[0..n-1], c overwritten with p[0..n-1]; *total = sum. */
+int csx_cumsum(csx_handle_t p, csx_handle_t c, int64_t n, int64_t *total);
+
+/* cs_multiply (+ cs_scatter), csparse.py:1608-1642, :1961-1989: C = A*B with
+ * each column of C in first-touch order; pattern only if A or B has no values. */
+int csx_multiply(csx_handle_t A, csx_handle_t B, csx_handle_t *out);
+
+/* cs_lsolve / cs_ltsolve / cs_usolve / cs_utsolve, csparse.py:1330-1365,
+ * :2368-2385, :2460-2475.  Analyse once (level sets, gather layout in the
+ * reference's update order, zero-pivot check), then solve any number of
+ * right-hand sides in place: X is n-by-nrhs, row-major. */
+int csx_tri_analyse(csx_handle_t T, int kind, csx_handle_t *plan);
+int csx_tri_info(csx_handle_t plan, int32_t *n, int32_t *levels, int32_t *sequential);
+int csx_tri_solve(csx_handle_t plan, csx_handle_t X, int32_t nrhs);
+
+/* cs_ipvec / cs_pvec, csparse.py:1264-1277, :1779-1792, on n-by-nrhs blocks:
+ * inverse != 0: x[p[k], :] = b[k, :] (ipvec); else x[k, :] = b[p[k], :] (pvec).
+ * p == 0 is the identity permutation. */
+int csx_permute_vec(csx_handle_t p, csx_handle_t b, csx_handle_t x, int32_t n, int32_t nrhs, int inverse);
+
+/* cs_schol (natural order), csparse.py:2051-2072: host C++ symbolic analysis of
+ * the upper triangle of a host CSC pattern.  parent[n], cp[n+1]. */
+int csx_schol_host(int32_t n, const int32_t *Ap, const int32_t *Ai, int32_t *parent, int32_t *cp);
+
+/* cs_chol numeric, csparse.py:561-619.  A: device CSC (upper triangle used);
+ * parent/cp: host arrays from csx_schol_host; pinv: host permutation or NULL.
+ * Output L (device CSC, diagonal first, rows ascending). */
+int csx_chol(csx_handle_t A, const int32_t *parent, const int32_t *cp, const int32_t *pinv,
+             csx_handle_t *L);
+
+/* The solve phase of cs_cholsol, csparse.py:640-643, for nrhs right-hand sides:
+ * B (n-by-nrhs, row-major) is overwritten with the solutions. */
+int csx_cholsol_plan(csx_handle_t L, const int32_t *pinv /* host, or NULL */, csx_handle_t *plan);
+int csx_cholsol_solve(csx_handle_t plan, csx_handle_t B, int32_t nrhs);
+
+/* ---- synthetic inputs of the benchmark configs, generated on
+ * the device from a counter-based hash so host and device agree bit for bit ---- */
+int csx_gen_grand(int32_t n, int32_t per_col, uint64_t seed, csx_handle_t *out);
+int csx_gen_gspd(int32_t nblocks, int32_t bs, uint64_t seed, csx_handle_t *out);
+int csx_gen_vec(int64_t len, uint64_t seed, double lo, double hi, csx_handle_t *out);
+int csx_gen_rhs(int32_t n, int32_t nrhs, int32_t col0, csx_handle_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSX_H */

@@ -1,0 +1,66 @@
+"""Host (numpy) twins of the device generators in csparse.py_amd/csrc/csx_gen.hip:
+same counter-based hash, same operation order, bit-identical output."""
+import numpy as np
+
+_M1 = np.uint64(0x9E3779B97F4A7C15)
+_M2 = np.uint64(0xBF58476D1CE4E5B9)
+_M3 = np.uint64(0x94D049BB133111EB)
+
+
+def mix64(z):
+    with np.errstate(over="ignore"):
+        z = (np.asarray(z, dtype=np.uint64) + _M1)
+        z = (z ^ (z >> np.uint64(30))) * _M2
+        z = (z ^ (z >> np.uint64(27))) * _M3
+        return z ^ (z >> np.uint64(31))
+
+
+def hash2(seed, c):
+    return mix64(np.uint64(seed) ^ mix64(c))
+
+
+def unit(h):
+    return (h >> np.uint64(11)).astype(np.float64) * 2.0 ** -53
+
+
+def grand(n, per_col, seed):
+    """G-rand: (Ap, Ai, Ax) int32/int32/float64."""
+    nnz = n * per_col
+    e = np.arange(nnz, dtype=np.uint64)
+    k = (e % np.uint64(per_col)).astype(np.int64)
+    W = n // per_col
+    Wk = np.where(k == per_col - 1, n - (per_col - 1) * W, W).astype(np.uint64)
+    Ai = (k * W + (hash2(seed, e) % Wk).astype(np.int64)).astype(np.int32)
+    Ax = 0.5 + unit(hash2(seed + 1, e))
+    Ap = (np.arange(n + 1, dtype=np.int64) * per_col).astype(np.int32)
+    return Ap, Ai, Ax
+
+
+def gspd(nblocks, bs, seed):
+    """G-spd: block-diagonal SPD, dense bs-by-bs blocks."""
+    n = nblocks * bs
+    c = np.arange(nblocks * bs * bs, dtype=np.uint64)
+    R = (-1.0 + 2.0 * unit(hash2(seed, c))).reshape(nblocks, bs, bs)   # R[b][r][k]
+    acc = np.zeros((nblocks, bs, bs))
+    for k in range(bs):  # ascending k, separately rounded multiply and add
+        acc = acc + R[:, :, k][:, :, None] * R[:, :, k][:, None, :]
+    B = acc / float(bs)
+    idx = np.arange(bs)
+    B[:, idx, idx] = B[:, idx, idx] + float(bs)
+    # column-major inside each block: entry q = ((b*bs + c)*bs + r) holds B[b][r][c]
+    Ax = np.ascontiguousarray(np.transpose(B, (0, 2, 1))).reshape(-1)
+    Ai = (np.arange(nblocks)[:, None, None] * bs + np.arange(bs)[None, None, :] +
+          np.zeros((1, bs, 1), dtype=np.int64)).astype(np.int32).reshape(-1)
+    Ap = (np.arange(n + 1, dtype=np.int64) * bs).astype(np.int32)
+    return Ap, Ai, Ax
+
+
+def vec(length, seed, lo, hi):
+    i = np.arange(length, dtype=np.uint64)
+    return lo + (hi - lo) * unit(hash2(seed, i))
+
+
+def rhs(n, nrhs, col0=0):
+    i = np.arange(n, dtype=np.float64)[:, None]
+    r = np.arange(nrhs, dtype=np.float64)[None, :]
+    return 1.0 + (i + col0 + r) / float(n)
