@@ -56,6 +56,9 @@ _PROTOS = {
     "csx_chol": [H, _i32p, _i32p, _i32p, C.POINTER(H)],
     "csx_cholsol_plan": [H, _i32p, C.POINTER(H)],
     "csx_cholsol_solve": [H, H, C.c_int32],
+    "csx_cholsol_info": [H, _i32p, _i32p, _i32p],
+    "csx_lu_host": [C.c_int32, _i32p, _i32p, _f64p, C.c_double, C.POINTER(_i32p), C.POINTER(_i32p),
+                    C.POINTER(_f64p), C.POINTER(_i32p), C.POINTER(_i32p), C.POINTER(_f64p), _i32p],
     "csx_gen_grand": [C.c_int32, C.c_int32, C.c_uint64, C.POINTER(H)],
     "csx_gen_gspd": [C.c_int32, C.c_int32, C.c_uint64, C.POINTER(H)],
     "csx_gen_vec": [C.c_int64, C.c_uint64, C.c_double, C.c_double, C.POINTER(H)],
@@ -88,12 +91,14 @@ def load():
             fn.restype = C.c_int
         lib.csx_last_error.restype = C.c_char_p
         lib.csx_last_error.argtypes = []
+        lib.csx_host_free.restype = None
+        lib.csx_host_free.argtypes = [_vp]
         _lib = lib
     return _lib
 
 
 def exported_symbols():
-    return sorted(list(_PROTOS) + ["csx_last_error"])
+    return sorted(list(_PROTOS) + ["csx_last_error", "csx_host_free"])
 
 
 def check(status, what=""):

@@ -687,5 +687,119 @@ def cs_cholsol(order, A, b):
     return True
 
 
+def cholsol_factor(A, order=0):
+    """Factor once for many solves: returns a solver `solve(b)` where b is a list or a
+    dvec n-by-k block (overwritten).  The batched form of cs_cholsol (csparse.py:622-644)."""
+    S = cs_schol(order, A)
+    N = cs_chol(A, S) if S is not None else None
+    if N is None:
+        return None
+    pinv = None if S.pinv is None else _csx.i32(S.pinv)
+    plan = _csx.new_handle()
+    _csx.check(_csx.lib().csx_cholsol_plan(N.L._dev.handle, _csx.pi(pinv), plan), "csx_cholsol_plan")
+    n = A.n
+
+    class _Solver(object):
+        L = N.L
+        symbolic = S
+
+        def __init__(self):
+            self._fin = weakref.finalize(self, _csx.free, plan)
+
+        def info(self):
+            a, b, c = _csx.C.c_int32(), _csx.C.c_int32(), _csx.C.c_int32()
+            _csx.check(_csx.lib().csx_cholsol_info(plan, a, b, c), "csx_cholsol_info")
+            return {"fused_local": bool(a.value), "trees": b.value, "max_nodes": c.value}
+
+        def solve(self, b):
+            db, bhost = _vec_in(b, n, "b")
+            _csx.check(_csx.lib().csx_cholsol_solve(plan, db.handle, db.k), "csx_cholsol_solve")
+            _write_back(bhost, db, n * db.k)
+            return True
+
+    return _Solver()
+
+
+# -------------------------------------------------------------------- LU ----
+
+def cs_sqr(order, A, qr):
+    """Symbolic analysis for LU (csparse.py:2187-2217): natural ordering only, with the
+    reference's size guesses.  QR analysis is outside the hot path."""
+    if not CS_CSC(A) or order != 0 or qr:
+        return None
+    S = css()
+    S.q = None
+    S.pinv = None
+    S.unz = S.lnz = 4 * A.p[A.n] + A.n
+    return S
+
+
+def _cs_from_arrays(m, n, p, i, x):
+    C = cs_spalloc(m, n, len(i), True, False)
+    C.p, C.i, C.x = p, i if i else [0], x if x else [0.0]
+    C.nzmax = max(len(i), 1) if i else 0
+    return C
+
+
+def cs_lu(A, S, tol):
+    """Sparse LU with threshold partial pivoting, P A = L U (csparse.py:1370-1451).
+    Host C++ (csx_lu_host): pivot search is serial and data dependent.  L has its unit
+    diagonal first in every column, U its diagonal last -- what cs_lsolve / cs_usolve need."""
+    if not CS_CSC(A) or S is None:
+        return None
+    if A.x is None:
+        raise TypeError("'NoneType' object is not subscriptable")
+    n = A.n
+    if A.m != n:
+        raise IndexError("list index out of range")
+    p = _csx.i32(A.p[:n + 1])
+    nnz = int(p[n])
+    i, x = _csx.i32(A.i[:nnz]), _csx.f64(A.x[:nnz])
+    C = _csx.C
+    out = [C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)(), C.POINTER(C.c_double)(),
+           C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)(), C.POINTER(C.c_double)()]
+    pinv = np.empty(max(n, 1), dtype=np.int32)
+    lib = _csx.load()
+    st = lib.csx_lu_host(n, _csx.pi(p), _csx.pi(i), _csx.pd(x), float(tol), *[C.byref(o) for o in out], _csx.pi(pinv))
+    if st == _csx.ENOTSPD:
+        return None
+    _csx.check(st, "csx_lu_host")
+    try:
+        Lp = np.ctypeslib.as_array(out[0], shape=(n + 1,)).tolist()
+        Up = np.ctypeslib.as_array(out[3], shape=(n + 1,)).tolist()
+        lnz, unz = Lp[n], Up[n]
+        Li = np.ctypeslib.as_array(out[1], shape=(max(lnz, 1),))[:lnz].tolist()
+        Lx = np.ctypeslib.as_array(out[2], shape=(max(lnz, 1),))[:lnz].tolist()
+        Ui = np.ctypeslib.as_array(out[4], shape=(max(unz, 1),))[:unz].tolist()
+        Ux = np.ctypeslib.as_array(out[5], shape=(max(unz, 1),))[:unz].tolist()
+    finally:
+        for o in out:
+            lib.csx_host_free(C.cast(o, C.c_void_p))
+    N = csn()
+    N.L = _cs_from_arrays(n, n, Lp, Li, Lx)
+    N.U = _cs_from_arrays(n, n, Up, Ui, Ux)
+    N.pinv = pinv[:n].tolist()
+    N.B = None
+    return N
+
+
+def cs_lusol(order, A, b, tol):
+    """Solve A x = b by LU; b is overwritten (csparse.py:1456-1478): host factorisation, then
+    x = b(p); L\\x; U\\x; b(q) = x with the triangular solves on the device."""
+    if not CS_CSC(A) or b is None:
+        return False
+    n = A.n
+    S = cs_sqr(order, A, False)
+    N = cs_lu(A, S, tol) if S is not None else None
+    if S is None or N is None:
+        return False
+    x = xalloc(n)
+    cs_ipvec(N.pinv, b, x, n)
+    cs_lsolve(N.L, x)
+    cs_usolve(N.U, x)
+    cs_ipvec(S.q, x, b, n)
+    return True
+
+
 def device_name():
     return _csx.device_info()

@@ -1,0 +1,609 @@
+// cs_chol numeric (csparse.py:561-619) and the solve phase of cs_cholsol
+// (csparse.py:640-643) on the device.
+//
+// The reference factors row by row (up-looking): row k of L is a sparse triangular
+// solve against the rows above it, one interpreted loop nest.  The factor itself
+// is unique, so the device computes the SAME L column by column (left-looking):
+//     L(j:n, j) = ( C(j:n, j) - sum_{k<j, L(j,k)!=0} L(j,k) * L(j:n, k) ) / sqrt(...)
+// where the pattern of every column (diagonal first, rows ascending: the order
+// cs_chol emits, :606-617) and, per row j, the list of columns k with L(j,k) != 0
+// are produced by the host symbolic phase (csx_host.cpp, from cs_ereach walks).
+// L.p / L.i are therefore bit-identical to the reference restatement; L.x differs
+// by summation order only (<= 1e-10 relative).
+//
+// Scheduling follows the elimination tree (S.parent):
+//   * a forest of SMALL trees (block-diagonal matrices, batches of independent
+//     matrices): one wavefront per tree walks its columns in ascending order, the
+//     tree's part of L stays in L1/L2;
+//   * big trees: columns grouped by height in the tree (all columns of a level are
+//     independent), one wavefront per column, one launch per level; runs of
+//     narrow levels are walked by ONE workgroup with a barrier per level.
+// A column's running sums live in LDS (wave-private), the finished columns it
+// reads are streamed from L2/HBM with coalesced loads.
+//
+// Solve phase for many right-hand sides (B is n-by-k, row-major, overwritten):
+//   x = P b; L y = x; L' z = y; b = P' z        (csparse.py:640-643)
+// generic path: device permutation + the level-scheduled triangular solves of
+// csx_trisolve.hip.  Forest-of-small-trees path: ONE fused kernel; a workgroup
+// takes a tree and 64 right-hand sides per wave, keeps those unknowns in LDS,
+// runs forward and backward substitution there (one lane per right-hand side, the
+// reference's operation order, so every solution is bit-identical to the
+// reference's cs_lsolve + cs_ltsolve on the same L) and writes the result back:
+// B is read once and written once, L is read once.
+#include <algorithm>
+#include <cmath>
+
+#include "csx_internal.h"
+
+namespace csx {
+
+// csx_host.cpp
+void upper_pattern(int32_t n, const int32_t *Ap, const int32_t *Ai, const int32_t *pinv, std::vector<int32_t> &up_ptr,
+                   std::vector<int32_t> &up_idx);
+int symbolic_fill(int32_t n, const std::vector<int32_t> &up_ptr, const std::vector<int32_t> &up_idx,
+                  const int32_t *parent, const int32_t *cp, std::vector<int32_t> &Li, std::vector<int32_t> &row_ptr,
+                  std::vector<int32_t> &row_col, std::vector<int32_t> &row_pos);
+// csx_trisolve.hip
+struct TriPlan;
+int tri_solve_raw(TriPlan *P, double *X, int32_t nrhs);
+int tri_analyse_raw(const Csc *T, int kind, TriPlan **out);
+void tri_gather_arrays(const TriPlan *P, const int32_t **ptr, const int32_t **idx, const double **val,
+                       const double **diag);
+
+constexpr int CH_ACC = 1024;        // column entries kept in LDS per wave
+constexpr int CH_WAVES = 4;         // waves per workgroup in the column kernels
+constexpr int CH_SMALL_TREE = 512;  // trees up to this many columns go to the tree kernel
+constexpr int CH_NARROW = 8;        // levels with <= this many columns join a one-workgroup run
+
+struct Tree {
+    int32_t first, count;  // into tree_cols
+};
+
+// ---- scatter of C = upper(P A P') into the pattern of L ------------------------------------
+__device__ __forceinline__ int32_t find_row(const int32_t *rows, int32_t len, int32_t r) {
+    int32_t lo = 0, hi = len - 1;
+    while (lo < hi) {
+        const int32_t mid = (lo + hi) >> 1;
+        if (rows[mid] < r) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// the reference scatters x[Ci[p]] = Cx[p] in storage order: of duplicate entries the last wins
+__global__ __launch_bounds__(256) void k_chol_winner(int32_t n, const int32_t *__restrict__ Ap,
+                                                     const int32_t *__restrict__ Ai, const int32_t *__restrict__ pinv,
+                                                     const int32_t *__restrict__ Lp, const int32_t *__restrict__ Li,
+                                                     int32_t *win, int *bad) {
+    const int lane = threadIdx.x & 63;
+    const int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (j >= n) return;
+    const int32_t j2 = pinv ? pinv[j] : (int32_t)j;
+    for (int32_t p = Ap[j] + lane; p < Ap[j + 1]; p += 64) {
+        const int32_t i = Ai[p];
+        if (i > j) continue;
+        const int32_t i2 = pinv ? pinv[i] : i;
+        const int32_t c = min(i2, j2), r = max(i2, j2);
+        const int32_t b = Lp[c], len = Lp[c + 1] - b;
+        const int32_t t = find_row(Li + b, len, r);
+        if (Li[b + t] != r) {
+            *bad = 1;  // the symbolic pattern does not contain this entry
+            continue;
+        }
+        atomicMax(&win[b + t], p);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_chol_init(int64_t lnz, const int32_t *__restrict__ win,
+                                                   const double *__restrict__ Ax, double *__restrict__ Lx) {
+    int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < lnz) Lx[q] = win[q] >= 0 ? Ax[win[q]] : 0.0;
+}
+
+// ---- one column ---------------------------------------------------------------------------------
+// acc_v / acc_r: wave-private LDS (CH_ACC doubles / ints).  Columns longer than CH_ACC keep their
+// sums in Lx itself (global), the row search then runs on Li in global memory.
+__device__ __forceinline__ void chol_column(int32_t j, const int32_t *__restrict__ Lp, const int32_t *__restrict__ Li,
+                                            double *Lx, const int32_t *__restrict__ row_ptr,
+                                            const int32_t *__restrict__ row_col, const int32_t *__restrict__ row_pos,
+                                            double *acc_v, int32_t *acc_r, int lane, int *notspd) {
+    const int32_t base = Lp[j], len = Lp[j + 1] - base;
+    const bool in_lds = len <= CH_ACC;
+    if (in_lds) {
+        for (int32_t t = lane; t < len; t += 64) {
+            acc_v[t] = Lx[base + t];
+            acc_r[t] = Li[base + t];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int32_t qe = row_ptr[j + 1];
+    for (int32_t q = row_ptr[j]; q < qe; q++) {
+        const int32_t k = row_col[q], pos = row_pos[q];
+        const double ljk = Lx[pos];
+        const int32_t kend = Lp[k + 1];
+        for (int32_t p = pos + lane; p < kend; p += 64) {
+            const int32_t r = Li[p];
+            const double v = Lx[p] * ljk;
+            if (in_lds) {
+                acc_v[find_row(acc_r, len, r)] -= v;
+            } else {
+                Lx[base + find_row(Li + base, len, r)] -= v;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    const double d = in_lds ? acc_v[0] : Lx[base];
+    if (d <= 0.0 && lane == 0) atomicMin(notspd, j);  // csparse.py:612: not positive definite
+    const double ljj = sqrt(d);
+    __builtin_amdgcn_wave_barrier();
+    for (int32_t t = lane; t < len; t += 64) {
+        const double v = in_lds ? acc_v[t] : Lx[base + t];
+        Lx[base + t] = t == 0 ? ljj : v / ljj;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+#define CH_SHARED                                              \
+    __shared__ double s_acc_v[CH_WAVES][CH_ACC];               \
+    __shared__ int32_t s_acc_r[CH_WAVES][CH_ACC];
+
+// one wave per column of a level
+__global__ __launch_bounds__(64 * CH_WAVES) void k_chol_level(const int32_t *__restrict__ cols, int32_t count,
+                                                             const int32_t *__restrict__ Lp,
+                                                             const int32_t *__restrict__ Li, double *Lx,
+                                                             const int32_t *__restrict__ row_ptr,
+                                                             const int32_t *__restrict__ row_col,
+                                                             const int32_t *__restrict__ row_pos, int *notspd) {
+    CH_SHARED
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t c = (int64_t)blockIdx.x * CH_WAVES + w;
+    if (c >= count) return;
+    chol_column(cols[c], Lp, Li, Lx, row_ptr, row_col, row_pos, s_acc_v[w], s_acc_r[w], lane, notspd);
+}
+
+// one workgroup walks levels [l0, l1), a barrier after each
+__global__ __launch_bounds__(64 * CH_WAVES) void k_chol_levels_one_wg(const int32_t *__restrict__ cols,
+                                                                     const int32_t *__restrict__ level_ptr, int32_t l0,
+                                                                     int32_t l1, const int32_t *__restrict__ Lp,
+                                                                     const int32_t *__restrict__ Li, double *Lx,
+                                                                     const int32_t *__restrict__ row_ptr,
+                                                                     const int32_t *__restrict__ row_col,
+                                                                     const int32_t *__restrict__ row_pos, int *notspd) {
+    CH_SHARED
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int32_t l = l0; l < l1; l++) {
+        const int32_t first = level_ptr[l], count = level_ptr[l + 1] - first;
+        for (int32_t c = w; c < count; c += CH_WAVES)
+            chol_column(cols[first + c], Lp, Li, Lx, row_ptr, row_col, row_pos, s_acc_v[w], s_acc_r[w], lane, notspd);
+        __syncthreads();
+    }
+}
+
+// one wave per small tree: its columns in ascending order (children before parents)
+__global__ __launch_bounds__(64 * CH_WAVES) void k_chol_trees(const Tree *__restrict__ trees, int32_t ntrees,
+                                                             const int32_t *__restrict__ tree_cols,
+                                                             const int32_t *__restrict__ Lp,
+                                                             const int32_t *__restrict__ Li, double *Lx,
+                                                             const int32_t *__restrict__ row_ptr,
+                                                             const int32_t *__restrict__ row_col,
+                                                             const int32_t *__restrict__ row_pos, int *notspd) {
+    CH_SHARED
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t t = (int64_t)blockIdx.x * CH_WAVES + w;
+    if (t >= ntrees) return;
+    const Tree tr = trees[t];
+    for (int32_t c = 0; c < tr.count; c++)
+        chol_column(tree_cols[tr.first + c], Lp, Li, Lx, row_ptr, row_col, row_pos, s_acc_v[w], s_acc_r[w], lane,
+                    notspd);
+}
+
+template <class T>
+static int upload(T **d, const std::vector<T> &h) {
+    CSX_TRY(dalloc(d, h.size()));
+    if (!h.empty())
+        CSX_HIP(hipMemcpyAsync(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, ctx().stream));
+    return CSX_OK;
+}
+
+struct Forest {
+    std::vector<Tree> small;             // trees handled by the tree kernel
+    std::vector<int32_t> small_cols;     // their columns, ascending inside a tree
+    std::vector<int32_t> level_cols;     // columns of big trees sorted by level
+    std::vector<int32_t> level_ptr;
+    int32_t max_tree = 0;
+};
+
+// Partition the elimination forest (parent[]) into small trees and level sets of the big ones.
+static void partition_forest(int32_t n, const int32_t *parent, Forest &F) {
+    std::vector<int32_t> root((size_t)n), size((size_t)n, 0);
+    for (int32_t j = n - 1; j >= 0; j--) root[(size_t)j] = parent[j] < 0 ? j : root[(size_t)parent[j]];
+    for (int32_t j = 0; j < n; j++) size[(size_t)root[(size_t)j]]++;
+    std::vector<int32_t> slot((size_t)n, -1);
+    for (int32_t j = 0; j < n; j++) {
+        if (parent[j] >= 0) continue;
+        F.max_tree = std::max(F.max_tree, size[(size_t)j]);
+        if (size[(size_t)j] <= CH_SMALL_TREE) {
+            slot[(size_t)j] = (int32_t)F.small.size();
+            F.small.push_back({0, size[(size_t)j]});
+        }
+    }
+    int32_t run = 0;
+    for (auto &t : F.small) {
+        t.first = run;
+        run += t.count;
+        t.count = 0;
+    }
+    F.small_cols.assign((size_t)run, 0);
+    std::vector<int32_t> level((size_t)n, 0);
+    int32_t nlev = 0;
+    for (int32_t j = 0; j < n; j++) {
+        const int32_t s = slot[(size_t)root[(size_t)j]];
+        if (s >= 0) {
+            Tree &t = F.small[(size_t)s];
+            F.small_cols[(size_t)(t.first + t.count++)] = j;
+        } else {
+            nlev = std::max(nlev, level[(size_t)j] + 1);
+            if (parent[j] >= 0) level[(size_t)parent[j]] = std::max(level[(size_t)parent[j]], level[(size_t)j] + 1);
+        }
+    }
+    F.level_ptr.assign((size_t)nlev + 1, 0);
+    for (int32_t j = 0; j < n; j++)
+        if (slot[(size_t)root[(size_t)j]] < 0) F.level_ptr[(size_t)level[(size_t)j] + 1]++;
+    for (int32_t l = 0; l < nlev; l++) F.level_ptr[(size_t)l + 1] += F.level_ptr[(size_t)l];
+    F.level_cols.assign((size_t)F.level_ptr[(size_t)nlev], 0);
+    std::vector<int32_t> fill(F.level_ptr.begin(), F.level_ptr.end() - 1);
+    for (int32_t j = 0; j < n; j++)
+        if (slot[(size_t)root[(size_t)j]] < 0) F.level_cols[(size_t)fill[(size_t)level[(size_t)j]]++] = j;
+}
+
+static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, const int32_t *pinv, Csc *L) {
+    hipStream_t s = ctx().stream;
+    const int32_t n = A->n;
+    L->m = L->n = n;
+    L->nnz = cp[n];
+    L->owns = true;
+    if (n == 0) {
+        CSX_TRY(dalloc(&L->p, 1));
+        CSX_HIP(hipMemsetAsync(L->p, 0, sizeof(int32_t), s));
+        CSX_TRY(dalloc(&L->i, 0));
+        CSX_TRY(dalloc(&L->x, 0));
+        return CSX_OK;
+    }
+    // host: pattern of A -> pattern of L and its row view
+    std::vector<int32_t> hAp((size_t)n + 1), hAi((size_t)A->nnz);
+    CSX_HIP(hipMemcpyAsync(hAp.data(), A->p, hAp.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (A->nnz) CSX_HIP(hipMemcpyAsync(hAi.data(), A->i, hAi.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    CSX_HIP(hipStreamSynchronize(s));
+    std::vector<int32_t> up_ptr, up_idx, hLi, row_ptr, row_col, row_pos;
+    upper_pattern(n, hAp.data(), hAi.data(), pinv, up_ptr, up_idx);
+    CSX_TRY(symbolic_fill(n, up_ptr, up_idx, parent, cp, hLi, row_ptr, row_col, row_pos));
+    Forest F;
+    partition_forest(n, parent, F);
+
+    int32_t *d_rp = nullptr, *d_rc = nullptr, *d_rpos = nullptr, *d_pinv = nullptr, *d_win = nullptr;
+    int32_t *d_small_cols = nullptr, *d_level_cols = nullptr, *d_level_ptr = nullptr;
+    Tree *d_trees = nullptr;
+    int *d_flags = nullptr;
+    std::vector<int32_t> hcp(cp, cp + n + 1), hpinv;
+    if (pinv) hpinv.assign(pinv, pinv + n);
+    int st = upload(&L->p, hcp);
+    if (st == CSX_OK) st = upload(&L->i, hLi);
+    if (st == CSX_OK) st = dalloc(&L->x, (size_t)L->nnz);
+    if (st == CSX_OK) st = upload(&d_rp, row_ptr);
+    if (st == CSX_OK) st = upload(&d_rc, row_col);
+    if (st == CSX_OK) st = upload(&d_rpos, row_pos);
+    if (st == CSX_OK && pinv) st = upload(&d_pinv, hpinv);
+    if (st == CSX_OK) st = dalloc(&d_win, (size_t)L->nnz);
+    if (st == CSX_OK) st = dalloc(&d_flags, 2);
+    if (st == CSX_OK) st = upload(&d_trees, F.small);
+    if (st == CSX_OK) st = upload(&d_small_cols, F.small_cols);
+    if (st == CSX_OK) st = upload(&d_level_cols, F.level_cols);
+    if (st == CSX_OK) st = upload(&d_level_ptr, F.level_ptr);
+    int hflags[2] = {0, 0x7fffffff};
+    if (st == CSX_OK) {
+        (void)hipMemsetAsync(d_win, 0xff, (size_t)L->nnz * sizeof(int32_t), s);
+        (void)hipMemcpyAsync(d_flags, hflags, sizeof hflags, hipMemcpyHostToDevice, s);
+        hipLaunchKernelGGL(k_chol_winner, dim3((unsigned)(((int64_t)n + 3) / 4)), dim3(256), 0, s, n, A->p, A->i, d_pinv,
+                           L->p, L->i, d_win, d_flags);
+        hipLaunchKernelGGL(k_chol_init, dim3((unsigned)(((int64_t)L->nnz + 255) / 256)), dim3(256), 0, s,
+                           (int64_t)L->nnz, d_win, A->x, L->x);
+        const int32_t nt = (int32_t)F.small.size();
+        if (nt > 0)
+            hipLaunchKernelGGL(k_chol_trees, dim3((unsigned)((nt + CH_WAVES - 1) / CH_WAVES)), dim3(64 * CH_WAVES), 0, s,
+                               d_trees, nt, d_small_cols, L->p, L->i, L->x, d_rp, d_rc, d_rpos, d_flags + 1);
+        const int32_t nlev = (int32_t)F.level_ptr.size() - 1;
+        int32_t l = 0;
+        while (l < nlev) {
+            const int32_t cnt = F.level_ptr[(size_t)l + 1] - F.level_ptr[(size_t)l];
+            if (cnt > CH_NARROW) {
+                hipLaunchKernelGGL(k_chol_level, dim3((unsigned)((cnt + CH_WAVES - 1) / CH_WAVES)), dim3(64 * CH_WAVES), 0,
+                                   s, d_level_cols + F.level_ptr[(size_t)l], cnt, L->p, L->i, L->x, d_rp, d_rc, d_rpos,
+                                   d_flags + 1);
+                l++;
+                continue;
+            }
+            int32_t e = l + 1;
+            while (e < nlev && F.level_ptr[(size_t)e + 1] - F.level_ptr[(size_t)e] <= CH_NARROW) e++;
+            hipLaunchKernelGGL(k_chol_levels_one_wg, dim3(1), dim3(64 * CH_WAVES), 0, s, d_level_cols, d_level_ptr, l, e,
+                               L->p, L->i, L->x, d_rp, d_rc, d_rpos, d_flags + 1);
+            l = e;
+        }
+        if (hipGetLastError() != hipSuccess ||
+            hipMemcpyAsync(hflags, d_flags, sizeof hflags, hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess) {
+            set_error("cs_chol: %s", hipGetErrorString(hipGetLastError()));
+            st = CSX_ERUNTIME;
+        }
+    }
+    dfree(d_rp);
+    dfree(d_rc);
+    dfree(d_rpos);
+    dfree(d_pinv);
+    dfree(d_win);
+    dfree(d_flags);
+    dfree(d_trees);
+    dfree(d_small_cols);
+    dfree(d_level_cols);
+    dfree(d_level_ptr);
+    if (st != CSX_OK) return st;
+    if (hflags[0]) return CSX_EINVAL;                 // S.cp / S.parent do not belong to A
+    if (hflags[1] != 0x7fffffff) return CSX_ENOTSPD;  // some pivot d <= 0
+    return CSX_OK;
+}
+
+// ---- solve phase ----------------------------------------------------------------------------------
+struct CholPlan {
+    int32_t n = 0;
+    const Csc *L = nullptr;  // not owned; must outlive the plan
+    TriPlan *fwd = nullptr, *bwd = nullptr;
+    int32_t *perm = nullptr;    // device: x[j] = b[perm[j]]  (perm = inverse of pinv), nullptr = identity
+    double *scratch = nullptr;  // n * scratch_rhs doubles for the permuted block (generic path)
+    int64_t scratch_len = 0;
+    // forest-of-small-trees fast path
+    bool local = false;
+    int32_t ntrees = 0, max_nodes = 0;
+    Tree *trees = nullptr;
+    int32_t *tree_nodes = nullptr, *local_id = nullptr;
+};
+
+void free_cholplan(CholPlan *P) {
+    if (!P) return;
+    free_triplan(P->fwd);
+    free_triplan(P->bwd);
+    dfree(P->perm);
+    dfree(P->scratch);
+    dfree(P->trees);
+    dfree(P->tree_nodes);
+    dfree(P->local_id);
+    delete P;
+}
+
+__global__ __launch_bounds__(256) void k_parent_of_sorted_L(int32_t n, const int32_t *__restrict__ Lp,
+                                                            const int32_t *__restrict__ Li, int32_t *parent,
+                                                            int *unsorted) {
+    const int lane = threadIdx.x & 63;
+    const int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (j >= n) return;
+    const int32_t b = Lp[j], e = Lp[j + 1];
+    if (lane == 0) parent[j] = e - b > 1 ? Li[b + 1] : -1;
+    for (int32_t p = b + lane; p < e; p += 64) {
+        const int32_t r = Li[p];
+        if ((p == b && r != j) || (p > b && r <= Li[p - 1])) *unsorted = 1;
+    }
+}
+
+// One wave = one tree x 64 right-hand sides.  X tile in LDS: [node][lane].
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(64 * CH_WAVES) void k_cholsol_local(
+    const Tree *__restrict__ trees, int32_t ntrees, const int32_t *__restrict__ nodes,
+    const int32_t *__restrict__ local_id, const int32_t *__restrict__ perm, const int32_t *__restrict__ Lp,
+    const int32_t *__restrict__ Li, const double *__restrict__ Lx, const int32_t *__restrict__ Gp,
+    const int32_t *__restrict__ Gi, const double *__restrict__ Gx, double *B, int32_t nrhs, int32_t chunks,
+    int32_t max_nodes, int32_t waves_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) double xt[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (w >= waves_per_wg) return;
+    const int64_t task = (int64_t)blockIdx.x * waves_per_wg + w;
+    if (task >= (int64_t)ntrees * chunks) return;
+    const int32_t t = (int32_t)(task / chunks), h = (int32_t)(task % chunks);
+    const Tree tr = trees[t];
+    const int32_t rhs = h * 64 + lane;
+    const bool live = rhs < nrhs;
+    double *X = xt + (size_t)w * max_nodes * 64;
+    for (int32_t a = 0; a < tr.count; a++) {
+        const int32_t j = nodes[tr.first + a];
+        const int64_t src = (int64_t)(perm ? perm[j] : j) * nrhs + rhs;
+        X[a * 64 + lane] = live ? B[src] : 0.0;
+    }
+    // forward: L y = x, rows ascending, terms in ascending column order (the reference's push order)
+    for (int32_t a = 0; a < tr.count; a++) {
+        const int32_t j = nodes[tr.first + a];
+        double acc = X[a * 64 + lane];
+        const int32_t qe = Gp[j + 1];
+        for (int32_t q = Gp[j]; q < qe; q++) {
+            const double tt = Gx[q] * X[local_id[Gi[q]] * 64 + lane];
+            acc = acc - tt;
+        }
+        X[a * 64 + lane] = acc / Lx[Lp[j]];
+    }
+    // backward: L' z = y, rows descending, the column of L in storage order
+    for (int32_t a = tr.count - 1; a >= 0; a--) {
+        const int32_t j = nodes[tr.first + a];
+        double acc = X[a * 64 + lane];
+        const int32_t pe = Lp[j + 1];
+        for (int32_t p = Lp[j] + 1; p < pe; p++) {
+            const double tt = Lx[p] * X[local_id[Li[p]] * 64 + lane];
+            acc = acc - tt;
+        }
+        X[a * 64 + lane] = acc / Lx[Lp[j]];
+    }
+    if (live) {
+        for (int32_t a = 0; a < tr.count; a++) {
+            const int32_t j = nodes[tr.first + a];
+            B[(int64_t)(perm ? perm[j] : j) * nrhs + rhs] = X[a * 64 + lane];
+        }
+    }
+}
+#pragma clang fp contract(fast)
+
+__global__ __launch_bounds__(256) void k_perm_rows(const int32_t *__restrict__ perm, const double *__restrict__ src,
+                                                   double *__restrict__ dst, int32_t n, int32_t nrhs, int to_x) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)n * nrhs) return;
+    const int64_t j = t / nrhs, r = t % nrhs;
+    const int64_t k = perm[j];
+    if (to_x) dst[t] = src[k * nrhs + r];        // x[j] = b[perm[j]]
+    else dst[k * nrhs + r] = src[t];             // b[perm[j]] = x[j]
+}
+
+static int cholsol_plan(const Csc *L, const int32_t *pinv, CholPlan **out) {
+    hipStream_t s = ctx().stream;
+    CholPlan *P = new CholPlan();
+    *out = P;
+    const int32_t n = L->n;
+    P->n = n;
+    P->L = L;
+    if (pinv) {
+        std::vector<int32_t> perm((size_t)n);
+        for (int32_t k = 0; k < n; k++) {
+            if (pinv[k] < 0 || pinv[k] >= n) return CSX_EINVAL;
+            perm[(size_t)pinv[k]] = k;
+        }
+        CSX_TRY(upload(&P->perm, perm));
+    }
+    CSX_TRY(tri_analyse_raw(L, CSX_TRI_L, &P->fwd));
+    CSX_TRY(tri_analyse_raw(L, CSX_TRI_LT, &P->bwd));
+    if (n == 0) return CSX_OK;
+    // forest of small trees?  (needs a Cholesky-shaped L: diagonal first, rows ascending)
+    int32_t *d_parent = nullptr;
+    int *d_flag = nullptr;
+    CSX_TRY(dalloc(&d_parent, (size_t)n));
+    CSX_TRY(dalloc(&d_flag, 1));
+    CSX_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), s));
+    hipLaunchKernelGGL(k_parent_of_sorted_L, dim3((unsigned)(((int64_t)n + 3) / 4)), dim3(256), 0, s, n, L->p, L->i,
+                       d_parent, d_flag);
+    std::vector<int32_t> parent((size_t)n);
+    int unsorted = 0;
+    CSX_HIP(hipMemcpyAsync(parent.data(), d_parent, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    CSX_HIP(hipMemcpyAsync(&unsorted, d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    CSX_HIP(hipStreamSynchronize(s));
+    dfree(d_parent);
+    dfree(d_flag);
+    if (unsorted) return CSX_OK;
+    Forest F;
+    partition_forest(n, parent.data(), F);
+    if (!F.level_cols.empty() || F.max_tree > 256) return CSX_OK;  // some tree is too big for LDS
+    std::vector<int32_t> local((size_t)n, 0);
+    for (const Tree &t : F.small)
+        for (int32_t a = 0; a < t.count; a++) local[(size_t)F.small_cols[(size_t)(t.first + a)]] = a;
+    CSX_TRY(upload(&P->trees, F.small));
+    CSX_TRY(upload(&P->tree_nodes, F.small_cols));
+    CSX_TRY(upload(&P->local_id, local));
+    CSX_HIP(hipStreamSynchronize(s));
+    P->ntrees = (int32_t)F.small.size();
+    P->max_nodes = F.max_tree;
+    P->local = true;
+    return CSX_OK;
+}
+
+static int cholsol_solve(CholPlan *P, double *B, int32_t nrhs) {
+    hipStream_t s = ctx().stream;
+    const int32_t n = P->n;
+    if (n == 0 || nrhs == 0) return CSX_OK;
+    const int32_t *Gp, *Gi;
+    const double *Gx, *Gd;
+    tri_gather_arrays(P->fwd, &Gp, &Gi, &Gx, &Gd);
+    if (P->local && Gd != nullptr) {
+        int zero = 0;
+        (void)zero;
+        // zero pivots were detected by the analysis; report like the reference (ZeroDivisionError)
+        int st = tri_solve_raw(P->fwd, B, 0);
+        if (st != CSX_OK) return st;
+        const size_t per_wave = (size_t)P->max_nodes * 64 * sizeof(double);
+        int waves = (int)std::min<size_t>(CH_WAVES, (128 * 1024) / per_wave);
+        if (waves < 1) waves = 1;
+        const int32_t chunks = (nrhs + 63) / 64;
+        const int64_t tasks = (int64_t)P->ntrees * chunks;
+        const size_t lds = per_wave * (size_t)waves;
+        CSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cholsol_local),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+        hipLaunchKernelGGL(k_cholsol_local, dim3((unsigned)((tasks + waves - 1) / waves)), dim3(64 * CH_WAVES), lds, s,
+                           P->trees, P->ntrees, P->tree_nodes, P->local_id, P->perm, P->L->p, P->L->i, P->L->x, Gp, Gi,
+                           Gx, B, nrhs, chunks, P->max_nodes, waves);
+        CSX_LAUNCH_CHECK();
+        return CSX_OK;
+    }
+    double *X = B;
+    if (P->perm) {
+        const int64_t need = (int64_t)n * nrhs;
+        if (P->scratch_len < need) {
+            dfree(P->scratch);
+            P->scratch = nullptr;
+            P->scratch_len = 0;
+            CSX_TRY(dalloc(&P->scratch, (size_t)need));
+            P->scratch_len = need;
+        }
+        X = P->scratch;
+        hipLaunchKernelGGL(k_perm_rows, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, s, P->perm, B, X, n, nrhs, 1);
+    }
+    CSX_TRY(tri_solve_raw(P->fwd, X, nrhs));
+    CSX_TRY(tri_solve_raw(P->bwd, X, nrhs));
+    if (P->perm) {
+        const int64_t need = (int64_t)n * nrhs;
+        hipLaunchKernelGGL(k_perm_rows, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, s, P->perm, X, B, n, nrhs, 0);
+    }
+    CSX_LAUNCH_CHECK();
+    return CSX_OK;
+}
+
+}  // namespace csx
+
+using namespace csx;
+
+extern "C" int csx_chol(csx_handle_t hA, const int32_t *parent, const int32_t *cp, const int32_t *pinv,
+                        csx_handle_t *out) {
+    CSX_TRY(require_ready());
+    Csc *A = csc(hA);
+    if (!A || !A->x || A->m != A->n || !parent || !cp || !out) return CSX_EINVAL;
+    if (cp[0] != 0 || cp[A->n] < A->n) return CSX_EINVAL;
+    Csc *L = new Csc();
+    int st = chol_device(A, parent, cp, pinv, L);
+    if (st != CSX_OK) {
+        free_csc(L);
+        return st;
+    }
+    *out = put(K_CSC, L);
+    return CSX_OK;
+}
+
+extern "C" int csx_cholsol_plan(csx_handle_t hL, const int32_t *pinv, csx_handle_t *out) {
+    CSX_TRY(require_ready());
+    Csc *L = csc(hL);
+    if (!L || !L->x || L->m != L->n || !out) return CSX_EINVAL;
+    CholPlan *P = nullptr;
+    int st = cholsol_plan(L, pinv, &P);
+    if (st != CSX_OK) {
+        free_cholplan(P);
+        return st;
+    }
+    *out = put(K_CHOLPLAN, P);
+    return CSX_OK;
+}
+
+extern "C" int csx_cholsol_info(csx_handle_t h, int32_t *local, int32_t *ntrees, int32_t *max_nodes) {
+    CholPlan *P = (CholPlan *)get(h, K_CHOLPLAN);
+    if (!P) return CSX_EINVAL;
+    if (local) *local = P->local ? 1 : 0;
+    if (ntrees) *ntrees = P->ntrees;
+    if (max_nodes) *max_nodes = P->max_nodes;
+    return CSX_OK;
+}
+
+extern "C" int csx_cholsol_solve(csx_handle_t h, csx_handle_t hB, int32_t nrhs) {
+    CSX_TRY(require_ready());
+    CholPlan *P = (CholPlan *)get(h, K_CHOLPLAN);
+    Vec *B = vec(hB);
+    if (!P || !B || nrhs < 0 || B->len < (int64_t)P->n * nrhs) return CSX_EINVAL;
+    return cholsol_solve(P, (double *)B->d, nrhs);
+}

@@ -68,6 +68,7 @@ void free_gather(Gather *g) {
 void free_tiled(TiledPlan *t) {
     if (!t) return;
     dfree(t->tile_ptr);
+    dfree(t->tile_len);
     dfree(t->tile_key);
     dfree(t->tile_val);
     dfree(t->partial);

@@ -1,4 +1,4 @@
-// cs_gaxpy (csparse.py:1199-1213), LDS-tiled plan for matrices whose rows share
+// cs_gaxpy (csparse.py:1199-1213), LDS-resident plan for matrices whose rows share
 // no columns (uniformly random structure, the "G-rand" benchmark input).
 //
 // Why: with y and x of 40 MB each (n = 5e6) every one of the 3.2e8 entries of A
@@ -7,23 +7,27 @@
 // into y needs memory-side atomics.  Both run far below the HBM rate.
 //
 // Plan: regroup the entries once (stable radix sort, csx_sort.hip) into tiles
-//      tile(s, b) = { A(i, j) : j in column slab s, i in row block b }
-// kept in column order inside a tile.  A row block is 2^RB rows, so its slice of
-// y lives in LDS (128 KiB at RB = 14) and takes the random accumulation as
-// ds_add_f64; a column slab is <= 2.5 MB of x, so it stays in the 4 MiB L2 of
-// the XCD that works on it, and because the tile is column-sorted neighbouring
-// lanes hit the same 128-byte lines of x.  The entry stream itself (4-byte
-// packed (col,row) key + 8-byte value = the same 12 bytes/entry as CSC) is read
-// once, coalesced.  Each (slab, row block) tile then writes its y slice to a
-// per-slab partial buffer, and a second kernel adds the slabs' partials to y in
-// slab order.
+//      tile(b, s) = { A(i, j) : i in row block b, j in column slab s },
+// row-block-major, column order kept inside a tile.
+//   * One workgroup owns one row block for the whole kernel: its slice of y
+//     (m / 256 rows, up to 156 KiB) is loaded into LDS once, takes every random
+//     accumulation as ds_add_f64, and is written back once.  No partial sums in
+//     memory, no second kernel, no inter-workgroup communication.
+//   * All workgroups walk the column slabs in the same order and at the same
+//     pace (equal work per tile for a random matrix), so the slab of x in use
+//     (<= 1 MiB) is shared through each XCD's L2.
+//   * Entries are stored in groups of 256 (tiles padded to a multiple of 256),
+//     INTERLEAVED so that the 16-byte key load of lane l returns entries
+//     l, l+64, l+128, l+192 of the group: the k-th gather instruction of a wave
+//     then covers 64 CONSECUTIVE entries of the column-sorted tile, i.e. ~16
+//     cache lines of x instead of 64.  Measured: the texture addresser handles
+//     about one distinct line per clock, and with 4 consecutive entries per lane
+//     the gathers alone cost 0.6 ms of a 1.3 ms kernel (profiles/ablation_r01.md).
+//   * The entry stream (4-byte packed (col,row) key + 8-byte value = the same 12
+//     bytes per entry as CSC) is read once, coalesced, non-temporal, one group
+//     ahead of the gathers.
 //
-// XCD awareness: slab s is served by work queue s % 8; a workgroup reads its
-// XCC id and drains "its" queue first, then helps the others, so placement only
-// affects speed, never the result.  Counters are zeroed before every launch.
-//
-// HBM bytes per call: 12 nnz (entries) + 2 * 8 * m * nslab (partials, written
-// then read) + 16 m (y) + 8 n (x)  -- the partials are the price of the plan.
+// HBM bytes per call ~ 12 nnz (+0.4 % padding) + 16 m + 8 n * (#XCDs that read x).
 #include <cstdlib>
 
 #include "csx_internal.h"
@@ -31,149 +35,225 @@
 namespace csx {
 
 constexpr int TL_THREADS = 1024;
-constexpr int TL_QUEUES = 8;
-
-__device__ __forceinline__ unsigned xcc_id() {
-    // s_getreg_b32 HW_REG_XCC_ID (id 20), bits [3:0]; only used as a queue preference
-    return __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;
-}
+constexpr int TL_WAVES = TL_THREADS / 64;
+constexpr int TL_GROUP = 256;                   // entries per group = 64 lanes x 4
+constexpr int TL_LDS_BYTES = 160 * 1024 - 256;  // leave a little headroom below the CU's 160 KiB
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(256) void k_tile_keys(int64_t nnz, const int32_t *__restrict__ Ai,
-                                                   const int32_t *__restrict__ col, int rb_bits, int32_t slab_cols,
-                                                   int32_t nrb, uint32_t *__restrict__ tile_id,
+                                                   const int32_t *__restrict__ col, int rb_bits, int32_t row_block,
+                                                   int32_t slab_cols, int32_t nslab, uint32_t *__restrict__ tile_id,
                                                    uint32_t *__restrict__ packed) {
     int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= nnz) return;
     const uint32_t i = (uint32_t)Ai[p], j = (uint32_t)col[p];
     const uint32_t s = j / (uint32_t)slab_cols, lc = j - s * (uint32_t)slab_cols;
-    const uint32_t b = i >> rb_bits, lr = i & ((1u << rb_bits) - 1u);
-    tile_id[p] = s * (uint32_t)nrb + b;
+    const uint32_t b = i / (uint32_t)row_block, lr = i - b * (uint32_t)row_block;
+    tile_id[p] = b * (uint32_t)nslab + s;
     packed[p] = (lc << rb_bits) | lr;
 }
 
-template <int RB_BITS>
-__global__ __launch_bounds__(TL_THREADS) void k_gaxpy_tiled(const int32_t *__restrict__ tile_ptr,
+__global__ __launch_bounds__(256) void k_padded_lengths(int64_t ntiles, const int32_t *__restrict__ sptr,
+                                                        int32_t *__restrict__ ngroups) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < ntiles) ngroups[t] = (sptr[t + 1] - sptr[t] + TL_GROUP - 1) / TL_GROUP;
+}
+
+// group_info[g] = (slab << 9) | entries in the group (1..256)
+__global__ __launch_bounds__(256) void k_group_info(int64_t ntiles, int32_t nslab, const int32_t *__restrict__ sptr,
+                                                    const int32_t *__restrict__ gptr, uint32_t *__restrict__ info) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntiles) return;
+    const int32_t len = sptr[t + 1] - sptr[t];
+    const uint32_t slab = (uint32_t)(t % nslab);
+    int32_t g = gptr[t];
+    for (int32_t left = len; left > 0; left -= TL_GROUP, g++) info[g] = (slab << 9) | (uint32_t)min(left, TL_GROUP);
+}
+
+// sorted position q (tile t, rank e inside the tile) -> interleaved slot
+__global__ __launch_bounds__(256) void k_interleave(int64_t nnz, const uint32_t *__restrict__ stid,
+                                                    const int32_t *__restrict__ sptr, const int32_t *__restrict__ gptr,
+                                                    const uint32_t *__restrict__ skey, const double *__restrict__ sval,
+                                                    uint32_t *__restrict__ okey, double *__restrict__ oval) {
+    int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nnz) return;
+    const uint32_t t = stid[q];
+    const int32_t e = (int32_t)(q - sptr[t]);
+    const int32_t g = e / TL_GROUP, w = e % TL_GROUP;
+    const int64_t pos = ((int64_t)gptr[t] + g) * TL_GROUP + (w & 63) * 4 + (w >> 6);
+    okey[pos] = skey[q];
+    oval[pos] = sval[q];
+}
+
+struct GroupRegs {
+    u32x4 kk;
+    f64x2 v0, v1;
+    uint32_t info;
+};
+
+__device__ __forceinline__ GroupRegs load_group(const uint32_t *__restrict__ key, const double *__restrict__ val,
+                                                const uint32_t *__restrict__ info, int32_t g, int lane) {
+    GroupRegs r;
+    const int64_t pos = (int64_t)g * TL_GROUP + 4 * lane;
+    r.kk = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(key + pos));
+    r.v0 = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(val + pos));
+    r.v1 = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(val + pos + 2));
+    r.info = info[g];
+    return r;
+}
+
+// VARIANT bits (timing experiments only; results are wrong unless VARIANT == 0):
+//   1 = skip the x gather, 2 = skip the LDS accumulation
+template <int VARIANT>
+__global__ __launch_bounds__(TL_THREADS) void k_gaxpy_tiled(const int32_t *__restrict__ rb_gptr,
+                                                            const uint32_t *__restrict__ group_info,
                                                             const uint32_t *__restrict__ tile_key,
                                                             const double *__restrict__ tile_val,
-                                                            const double *__restrict__ x, double *__restrict__ partial,
-                                                            int32_t *queue, int32_t nrb, int32_t nslab,
-                                                            int32_t slab_cols, int64_t mpad) {
-    constexpr int RB = 1 << RB_BITS;
-    // all LDS in the dynamic region (16-byte aligned base): RB doubles + one work-item word
-    extern __shared__ __attribute__((aligned(16))) double ytile[];
-    int &s_item = *reinterpret_cast<int *>(ytile + RB);
-    const unsigned home = xcc_id();
-    for (int hop = 0; hop < TL_QUEUES; hop++) {
-        const int qid = (int)((home + hop) & (TL_QUEUES - 1));
-        // queue qid serves slabs qid, qid + 8, ...: all row blocks of one slab before the next
-        const int nslab_q = (nslab - qid + TL_QUEUES - 1) / TL_QUEUES;
-        const int items = nslab_q > 0 ? nslab_q * nrb : 0;
-        for (;;) {
-            __syncthreads();
-            if (threadIdx.x == 0) s_item = items > 0 ? atomicAdd(&queue[qid], 1) : items;
-            __syncthreads();
-            const int t = s_item;
-            if (t >= items) break;
-            const int slab = qid + TL_QUEUES * (t / nrb);
-            const int rb = t % nrb;
-            for (int k = threadIdx.x; k < RB; k += TL_THREADS) ytile[k] = 0.0;
-            __syncthreads();
-            const int tile = slab * nrb + rb;
-            const int32_t b = tile_ptr[tile], e = tile_ptr[tile + 1];
-            const double *xs = x + (int64_t)slab * slab_cols;
-            // two entries per lane per step; b may be odd, so peel to an even position
-            int32_t q = b + 2 * (int32_t)threadIdx.x;
-            const int32_t b2 = (b + 1) & ~1;
-            if (b2 != b && b < e) {
-                if (threadIdx.x == 0) {
-                    const uint32_t kk = tile_key[b];
-                    unsafeAtomicAdd(&ytile[kk & (RB - 1)], tile_val[b] * xs[kk >> RB_BITS]);
-                }
-                q = b2 + 2 * (int32_t)threadIdx.x;
+                                                            const double *__restrict__ x, double *__restrict__ y,
+                                                            int32_t m, int32_t nrb, int32_t row_block,
+                                                            int32_t slab_cols, int rb_bits) {
+    extern __shared__ __attribute__((aligned(16))) double ytile[];  // row_block doubles
+    constexpr bool GATHER = !(VARIANT & 1), ATOMIC = !(VARIANT & 2);
+    const uint32_t rmask = (1u << rb_bits) - 1u;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double sink = 0.0;
+    for (int32_t rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
+        const int64_t row0 = (int64_t)rb * row_block;
+        const int32_t rows = (int32_t)((row0 + row_block <= m) ? row_block : (m - row0));
+        for (int k = threadIdx.x; k < rows; k += TL_THREADS) ytile[k] = y[row0 + k];
+        __syncthreads();
+        const int32_t gend = rb_gptr[rb + 1];
+        int32_t g = rb_gptr[rb] + wave;
+        GroupRegs cur;
+        if (g < gend) cur = load_group(tile_key, tile_val, group_info, g, lane);
+        while (g < gend) {
+            const int32_t gn = g + TL_WAVES;
+            const uint32_t cnt = cur.info & 511u;
+            const double *xs = x + (int64_t)(cur.info >> 9) * slab_cols;
+            // entry index inside the group of component k is k*64 + lane
+            const bool ok0 = (uint32_t)lane < cnt, ok1 = (uint32_t)(64 + lane) < cnt;
+            const bool ok2 = (uint32_t)(128 + lane) < cnt, ok3 = (uint32_t)(192 + lane) < cnt;
+            double x0 = 1.0, x1 = 1.0, x2 = 1.0, x3 = 1.0;
+            if (GATHER) {  // padding slots carry key 0: a valid address, result unused
+                x0 = xs[cur.kk.x >> rb_bits];
+                x1 = xs[cur.kk.y >> rb_bits];
+                x2 = xs[cur.kk.z >> rb_bits];
+                x3 = xs[cur.kk.w >> rb_bits];
             }
-            for (; q + 1 < e; q += 2 * TL_THREADS) {
-                const uint2 kk = *reinterpret_cast<const uint2 *>(tile_key + q);
-                const double2 vv = *reinterpret_cast<const double2 *>(tile_val + q);
-                const double x0 = xs[kk.x >> RB_BITS], x1 = xs[kk.y >> RB_BITS];
-                unsafeAtomicAdd(&ytile[kk.x & (RB - 1)], vv.x * x0);
-                unsafeAtomicAdd(&ytile[kk.y & (RB - 1)], vv.y * x1);
+            GroupRegs nxt = cur;
+            if (gn < gend) nxt = load_group(tile_key, tile_val, group_info, gn, lane);  // behind the gathers
+            if (ATOMIC) {
+                if (ok0) unsafeAtomicAdd(&ytile[cur.kk.x & rmask], cur.v0.x * x0);
+                if (ok1) unsafeAtomicAdd(&ytile[cur.kk.y & rmask], cur.v0.y * x1);
+                if (ok2) unsafeAtomicAdd(&ytile[cur.kk.z & rmask], cur.v1.x * x2);
+                if (ok3) unsafeAtomicAdd(&ytile[cur.kk.w & rmask], cur.v1.y * x3);
+            } else {
+                sink += cur.v0.x * x0 + cur.v0.y * x1 + cur.v1.x * x2 + cur.v1.y * x3 +
+                        (double)((cur.kk.x ^ cur.kk.y ^ cur.kk.z ^ cur.kk.w) & 1u);
             }
-            if (q < e) {  // odd tail
-                const uint32_t kk = tile_key[q];
-                unsafeAtomicAdd(&ytile[kk & (RB - 1)], tile_val[q] * xs[kk >> RB_BITS]);
-            }
-            __syncthreads();
-            double2 *dst = reinterpret_cast<double2 *>(partial + (int64_t)slab * mpad + (int64_t)rb * RB);
-            const double2 *src = reinterpret_cast<const double2 *>(ytile);
-            for (int k = threadIdx.x; k < RB / 2; k += TL_THREADS) dst[k] = src[k];
+            g = gn;
+            cur = nxt;
         }
+        __syncthreads();
+        if (!ATOMIC && sink == 12345.678) ytile[0] = sink;  // keep the ablated arithmetic alive
+        for (int k = threadIdx.x; k < rows; k += TL_THREADS) y[row0 + k] = ytile[k];
+        __syncthreads();
     }
 }
 
-__global__ __launch_bounds__(256) void k_reduce_partials(int64_t m, int32_t nslab, int64_t mpad,
-                                                         const double *__restrict__ partial, double *__restrict__ y) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
-    double acc = y[i];
-    for (int s = 0; s < nslab; s++) acc += partial[(int64_t)s * mpad + i];
-    y[i] = acc;
+__global__ __launch_bounds__(256) void k_rb_group_ptr(int32_t nrb, int32_t nslab, const int32_t *__restrict__ gptr,
+                                                      int32_t *__restrict__ rb_gptr) {
+    int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b <= nrb) rb_gptr[b] = gptr[(int64_t)b * nslab];
 }
 
 int gaxpy_tiled_prepare(Csc *A) {
     if (A->tiled) return CSX_OK;
     if (!A->x) return CSX_EINVAL;
     hipStream_t s = ctx().stream;
-    int rb_bits = 14;
-    if (const char *e = std::getenv("CSX_TILED_RB_BITS")) rb_bits = std::atoi(e) == 13 ? 13 : 14;
-    double slab_mb = 2.5;
-    if (const char *e = std::getenv("CSX_TILED_SLAB_MB")) slab_mb = std::atof(e) > 0.1 ? std::atof(e) : slab_mb;
+    // one row block per workgroup, one workgroup per CU; more rounds only if a block would not fit LDS
+    const int32_t nwg = ctx().cus > 0 ? ctx().cus : 256;
+    const int32_t cap = TL_LDS_BYTES / 8;
+    int32_t rounds = 1;
+    int32_t row_block;
+    for (;;) {
+        const int64_t nrb_try = (int64_t)nwg * rounds;
+        row_block = (int32_t)(((int64_t)A->m + nrb_try - 1) / nrb_try);
+        if (row_block <= cap) break;
+        rounds++;
+    }
+    if (row_block < 1) row_block = 1;
+    const int32_t nrb = (int32_t)(((int64_t)A->m + row_block - 1) / row_block);
+    int rb_bits = 1;
+    while ((1 << rb_bits) < row_block) rb_bits++;
+    double slab_kb = 1024.0;
+    if (const char *e = std::getenv("CSX_TILED_SLAB_KB")) slab_kb = std::atof(e) >= 8.0 ? std::atof(e) : slab_kb;
+    int64_t slab_cols = (int64_t)(slab_kb * 1024 / 8);
     const int64_t max_cols_key = 1ll << (32 - rb_bits);
-    int64_t max_cols = (int64_t)(slab_mb * 1024 * 1024 / 8);
-    if (max_cols > max_cols_key) max_cols = max_cols_key;
-    int nslab = TL_QUEUES;
-    while (((int64_t)A->n + nslab - 1) / nslab > max_cols) nslab += TL_QUEUES;
-    int32_t slab_cols = (int32_t)(((int64_t)A->n + nslab - 1) / nslab);
-    if (slab_cols < 1) slab_cols = 1;
-    nslab = (int)(((int64_t)A->n + slab_cols - 1) / slab_cols);
+    if (slab_cols > max_cols_key) slab_cols = max_cols_key;
+    if (slab_cols > A->n) slab_cols = A->n > 0 ? A->n : 1;
+    int32_t nslab = (int32_t)(((int64_t)A->n + slab_cols - 1) / slab_cols);
     if (nslab < 1) nslab = 1;
-    const int32_t rb = 1 << rb_bits;
-    const int32_t nrb = (int32_t)(((int64_t)A->m + rb - 1) / rb);
+    const int64_t ntiles = (int64_t)nrb * nslab;
+    if (ntiles > 0x3fffffffll || nslab >= (1 << 22)) return CSX_EINVAL;
 
     TiledPlan *t = new TiledPlan();
     t->rb_bits = rb_bits;
-    t->row_block = rb;
+    t->row_block = row_block;
     t->nrb = nrb;
     t->nslab = nslab;
-    t->slab_cols = slab_cols;
-    t->ngroup = nslab;
-    const int64_t ntiles = (int64_t)nslab * nrb;
-    const int64_t mpad = (int64_t)nrb * rb;
-    int32_t *col = nullptr;
-    uint32_t *tid = nullptr, *packed = nullptr, *stid = nullptr;
-    int st = dalloc(&t->tile_ptr, (size_t)ntiles + 1);
-    if (st == CSX_OK) st = dalloc(&t->tile_key, (size_t)A->nnz + 2);
-    if (st == CSX_OK) st = dalloc(&t->tile_val, (size_t)A->nnz + 2);
-    if (st == CSX_OK) st = dalloc(&t->partial, (size_t)(mpad * nslab));
-    if (st == CSX_OK) st = dalloc(&t->queue, (size_t)TL_QUEUES);
-    if (st == CSX_OK) st = dalloc(&col, (size_t)A->nnz);
+    t->slab_cols = (int32_t)slab_cols;
+    int32_t *col = nullptr, *sptr = nullptr, *gptr = nullptr;
+    uint32_t *tid = nullptr, *packed = nullptr, *stid = nullptr, *skey = nullptr;
+    double *sval = nullptr;
+    int64_t ngroups = 0;
+    int st = dalloc(&col, (size_t)A->nnz);
     if (st == CSX_OK) st = dalloc(&tid, (size_t)A->nnz);
     if (st == CSX_OK) st = dalloc(&packed, (size_t)A->nnz);
     if (st == CSX_OK) st = dalloc(&stid, (size_t)A->nnz);
+    if (st == CSX_OK) st = dalloc(&skey, (size_t)A->nnz);
+    if (st == CSX_OK) st = dalloc(&sval, (size_t)A->nnz);
+    if (st == CSX_OK) st = dalloc(&sptr, (size_t)ntiles + 1);
+    if (st == CSX_OK) st = dalloc(&gptr, (size_t)ntiles + 1);
+    if (st == CSX_OK) st = dalloc(&t->tile_ptr, (size_t)nrb + 1);
     if (st == CSX_OK) st = expand_columns(A->p, A->n, A->nnz, col);
     if (st == CSX_OK && A->nnz > 0) {
         int64_t blocks = ((int64_t)A->nnz + 255) / 256;
         hipLaunchKernelGGL(k_tile_keys, dim3((unsigned)blocks), dim3(256), 0, s, (int64_t)A->nnz, A->i, col, rb_bits,
-                           slab_cols, nrb, tid, packed);
+                           row_block, t->slab_cols, t->nslab, tid, packed);
         if (hipGetLastError() != hipSuccess) st = CSX_ERUNTIME;
     }
-    if (st == CSX_OK)
-        st = stable_sort_by_key(tid, packed, A->x, A->nnz, (uint32_t)ntiles, stid, t->tile_key, t->tile_val);
-    if (st == CSX_OK) st = boundaries_from_sorted(stid, A->nnz, (int32_t)ntiles, t->tile_ptr);
-    if (st == CSX_OK && hipStreamSynchronize(s) != hipSuccess) st = CSX_ERUNTIME;
+    if (st == CSX_OK) st = stable_sort_by_key(tid, packed, A->x, A->nnz, (uint32_t)ntiles, stid, skey, sval);
+    if (st == CSX_OK) st = boundaries_from_sorted(stid, A->nnz, (int32_t)ntiles, sptr);
+    const unsigned tb = (unsigned)((ntiles + 256) / 256);
+    if (st == CSX_OK) {
+        hipLaunchKernelGGL(k_padded_lengths, dim3(tb), dim3(256), 0, s, ntiles, sptr, gptr);
+        st = scan_exclusive_i32(gptr, gptr, ntiles, &ngroups);
+    }
+    if (st == CSX_OK) st = dalloc(&t->tile_len, (size_t)ngroups);  // group_info
+    if (st == CSX_OK) st = dalloc(&t->tile_key, (size_t)ngroups * TL_GROUP);
+    if (st == CSX_OK) st = dalloc(&t->tile_val, (size_t)ngroups * TL_GROUP);
+    if (st == CSX_OK && ngroups > 0) {
+        (void)hipMemsetAsync(t->tile_key, 0, (size_t)ngroups * TL_GROUP * sizeof(uint32_t), s);
+        (void)hipMemsetAsync(t->tile_val, 0, (size_t)ngroups * TL_GROUP * sizeof(double), s);
+        hipLaunchKernelGGL(k_group_info, dim3(tb), dim3(256), 0, s, ntiles, nslab, sptr, gptr, (uint32_t *)t->tile_len);
+        hipLaunchKernelGGL(k_interleave, dim3((unsigned)(((int64_t)A->nnz + 255) / 256)), dim3(256), 0, s,
+                           (int64_t)A->nnz, stid, sptr, gptr, skey, sval, t->tile_key, t->tile_val);
+    }
+    if (st == CSX_OK) {
+        hipLaunchKernelGGL(k_rb_group_ptr, dim3((unsigned)((nrb + 256) / 256)), dim3(256), 0, s, nrb, nslab, gptr,
+                           t->tile_ptr);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) st = CSX_ERUNTIME;
+    }
     dfree(col);
     dfree(tid);
     dfree(packed);
     dfree(stid);
+    dfree(skey);
+    dfree(sval);
+    dfree(sptr);
+    dfree(gptr);
     if (st != CSX_OK) {
         free_tiled(t);
         return st;
@@ -185,29 +265,26 @@ int gaxpy_tiled_prepare(Csc *A) {
 int gaxpy_tiled_run(const Csc *A, const double *x, double *y) {
     const TiledPlan *t = A->tiled;
     hipStream_t s = ctx().stream;
-    CSX_HIP(hipMemsetAsync(t->queue, 0, TL_QUEUES * sizeof(int32_t), s));
-    const int64_t mpad = (int64_t)t->nrb * t->row_block;
-    const size_t lds = (size_t)t->row_block * sizeof(double) + 16;
-    static bool attr_set = false;
-    if (!attr_set) {  // > 64 KiB of dynamic LDS has to be requested explicitly
-        CSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gaxpy_tiled<13>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (1 << 13) * 8 + 16));
-        CSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gaxpy_tiled<14>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (1 << 14) * 8 + 16));
-        attr_set = true;
+    const size_t lds = (((size_t)t->row_block * sizeof(double)) + 15) & ~(size_t)15;
+    int variant = 0;
+    if (const char *e = std::getenv("CSX_TILED_VARIANT")) variant = std::atoi(e) & 3;
+    const int32_t nwg = ctx().cus > 0 ? ctx().cus : 256;
+    const unsigned grid = (unsigned)(t->nrb < nwg ? t->nrb : nwg);
+#define CSX_TILED_LAUNCH(V)                                                                                          \
+    case V: {                                                                                                        \
+        CSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gaxpy_tiled<V>),                               \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, TL_LDS_BYTES));                      \
+        hipLaunchKernelGGL(k_gaxpy_tiled<V>, dim3(grid), dim3(TL_THREADS), lds, s, t->tile_ptr,                      \
+                           (const uint32_t *)t->tile_len, t->tile_key, t->tile_val, x, y, A->m, t->nrb, t->row_block, \
+                           t->slab_cols, t->rb_bits);                                                                \
+    } break;
+    switch (variant) {
+        CSX_TILED_LAUNCH(0)
+        CSX_TILED_LAUNCH(1)
+        CSX_TILED_LAUNCH(2)
+        CSX_TILED_LAUNCH(3)
     }
-    const int wg_per_cu = t->rb_bits == 13 ? 2 : 1;
-    const unsigned grid = (unsigned)(ctx().cus * wg_per_cu);
-    if (t->rb_bits == 13)
-        hipLaunchKernelGGL(k_gaxpy_tiled<13>, dim3(grid), dim3(TL_THREADS), lds, s, t->tile_ptr, t->tile_key,
-                           t->tile_val, x, t->partial, t->queue, t->nrb, t->nslab, t->slab_cols, mpad);
-    else
-        hipLaunchKernelGGL(k_gaxpy_tiled<14>, dim3(grid), dim3(TL_THREADS), lds, s, t->tile_ptr, t->tile_key,
-                           t->tile_val, x, t->partial, t->queue, t->nrb, t->nslab, t->slab_cols, mpad);
-    CSX_LAUNCH_CHECK();
-    int64_t blocks = ((int64_t)A->m + 255) / 256;
-    hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)blocks), dim3(256), 0, s, (int64_t)A->m, t->nslab, mpad,
-                       t->partial, y);
+#undef CSX_TILED_LAUNCH
     CSX_LAUNCH_CHECK();
     return CSX_OK;
 }

@@ -1,0 +1,274 @@
+// Host-side (CPU, C++) steps that feed the device hot path.  These are the
+// integer / data-dependent phases the reference also runs before its hot loops:
+//   csx_schol_host   cs_schol, natural order          (csparse.py:2051-2072)
+//   symbolic_fill    pattern of L from cs_ereach walks (csparse.py:1094-1131, 606-617)
+//   csx_lu_host      cs_lu with partial pivoting       (csparse.py:1370-1451, 2078-2113)
+// They are written from the algorithms, not transcribed: the elimination tree
+// uses the same ancestor path compression idea, the column counts come from the
+// row-pattern walk (O(|L|)) that the numeric phase needs anyway.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "csx_internal.h"
+
+namespace csx {
+
+// Elimination tree of the symmetric matrix whose upper triangle is (Ap, Ai)
+// (entries with row > col are ignored).  With a permutation, node ids are the
+// permuted ones: entry (i, j) of A is entry (min, max) of (pinv[i], pinv[j]).
+// up_ptr/up_idx receive the upper-triangular pattern of the permuted matrix by column.
+void upper_pattern(int32_t n, const int32_t *Ap, const int32_t *Ai, const int32_t *pinv, std::vector<int32_t> &up_ptr,
+                   std::vector<int32_t> &up_idx) {
+    up_ptr.assign((size_t)n + 1, 0);
+    for (int32_t j = 0; j < n; j++) {
+        const int32_t j2 = pinv ? pinv[j] : j;
+        for (int32_t p = Ap[j]; p < Ap[j + 1]; p++) {
+            const int32_t i = Ai[p];
+            if (i > j) continue;
+            const int32_t i2 = pinv ? pinv[i] : i;
+            up_ptr[(size_t)std::max(i2, j2) + 1]++;
+        }
+    }
+    for (int32_t j = 0; j < n; j++) up_ptr[(size_t)j + 1] += up_ptr[(size_t)j];
+    up_idx.resize((size_t)up_ptr[(size_t)n]);
+    std::vector<int32_t> fill(up_ptr.begin(), up_ptr.end() - 1);
+    for (int32_t j = 0; j < n; j++) {
+        const int32_t j2 = pinv ? pinv[j] : j;
+        for (int32_t p = Ap[j]; p < Ap[j + 1]; p++) {
+            const int32_t i = Ai[p];
+            if (i > j) continue;
+            const int32_t i2 = pinv ? pinv[i] : i;
+            up_idx[(size_t)fill[(size_t)std::max(i2, j2)]++] = std::min(i2, j2);
+        }
+    }
+}
+
+void etree_of_upper(int32_t n, const std::vector<int32_t> &up_ptr, const std::vector<int32_t> &up_idx,
+                    std::vector<int32_t> &parent) {
+    parent.assign((size_t)n, -1);
+    std::vector<int32_t> anc((size_t)n, -1);
+    for (int32_t k = 0; k < n; k++) {
+        for (int32_t p = up_ptr[(size_t)k]; p < up_ptr[(size_t)k + 1]; p++) {
+            int32_t i = up_idx[(size_t)p];
+            while (i != -1 && i < k) {
+                const int32_t next = anc[(size_t)i];
+                anc[(size_t)i] = k;
+                if (next == -1) parent[(size_t)i] = k;
+                i = next;
+            }
+        }
+    }
+}
+
+// Row patterns of L below the diagonal: for row k the columns i < k with L(k,i) != 0 are
+// the nodes on the etree paths from the entries of column k of the upper pattern up to k.
+// visit(k, i) is called once per such pair, k ascending.
+template <class Visit>
+static void walk_row_patterns(int32_t n, const std::vector<int32_t> &up_ptr, const std::vector<int32_t> &up_idx,
+                              const int32_t *parent, Visit visit) {
+    std::vector<int32_t> mark((size_t)n, -1);
+    for (int32_t k = 0; k < n; k++) {
+        mark[(size_t)k] = k;
+        for (int32_t p = up_ptr[(size_t)k]; p < up_ptr[(size_t)k + 1]; p++) {
+            for (int32_t i = up_idx[(size_t)p]; i != -1 && i < k && mark[(size_t)i] != k; i = parent[i]) {
+                mark[(size_t)i] = k;
+                visit(k, i);
+            }
+        }
+    }
+}
+
+// Pattern of L (diagonal first, then rows ascending: the order cs_chol emits, csparse.py:606-617)
+// plus the row view used by the device kernels: for row k the list of (column i, position of
+// L(k,i) in Li/Lx), columns ascending.
+int symbolic_fill(int32_t n, const std::vector<int32_t> &up_ptr, const std::vector<int32_t> &up_idx,
+                  const int32_t *parent, const int32_t *cp, std::vector<int32_t> &Li, std::vector<int32_t> &row_ptr,
+                  std::vector<int32_t> &row_col, std::vector<int32_t> &row_pos) {
+    const size_t lnz = (size_t)cp[n];
+    Li.assign(lnz, 0);
+    std::vector<int32_t> next(cp, cp + n);
+    row_ptr.assign((size_t)n + 1, 0);
+    row_col.assign(lnz - (size_t)n, 0);
+    row_pos.assign(lnz - (size_t)n, 0);
+    for (int32_t j = 0; j < n; j++) {
+        if (cp[j + 1] - cp[j] < 1) return CSX_EINVAL;
+        Li[(size_t)next[(size_t)j]++] = j;
+    }
+    bool ok = true;
+    int32_t last_row = -1;
+    size_t rc = 0;
+    walk_row_patterns(n, up_ptr, up_idx, parent, [&](int32_t k, int32_t i) {
+        while (last_row < k) row_ptr[(size_t)++last_row] = (int32_t)rc;
+        if (next[(size_t)i] >= cp[i + 1] || rc >= row_col.size()) {
+            ok = false;
+            return;
+        }
+        const int32_t pos = next[(size_t)i]++;
+        Li[(size_t)pos] = k;
+        row_col[rc] = i;
+        row_pos[rc] = pos;
+        rc++;
+    });
+    while (last_row < n) row_ptr[(size_t)++last_row] = (int32_t)rc;
+    if (!ok || rc != row_col.size()) return CSX_EINVAL;  // cp does not describe chol(A)
+    // columns ascending inside each row (the walk visits them in path order)
+    std::vector<std::pair<int32_t, int32_t>> tmp;
+    for (int32_t k = 0; k < n; k++) {
+        const int32_t b = row_ptr[(size_t)k], e = row_ptr[(size_t)k + 1];
+        if (e - b < 2) continue;
+        tmp.resize((size_t)(e - b));
+        for (int32_t q = b; q < e; q++) tmp[(size_t)(q - b)] = {row_col[(size_t)q], row_pos[(size_t)q]};
+        std::sort(tmp.begin(), tmp.end());
+        for (int32_t q = b; q < e; q++) {
+            row_col[(size_t)q] = tmp[(size_t)(q - b)].first;
+            row_pos[(size_t)q] = tmp[(size_t)(q - b)].second;
+        }
+    }
+    return CSX_OK;
+}
+
+}  // namespace csx
+
+using namespace csx;
+
+extern "C" int csx_schol_host(int32_t n, const int32_t *Ap, const int32_t *Ai, int32_t *parent, int32_t *cp) {
+    if (n < 0 || !Ap || (!Ai && Ap[n] > 0) || !parent || !cp) return CSX_EINVAL;
+    for (int32_t j = 0; j < n; j++)
+        for (int32_t p = Ap[j]; p < Ap[j + 1]; p++)
+            if (Ai[p] < 0 || Ai[p] >= n) return CSX_EINVAL;
+    std::vector<int32_t> up_ptr, up_idx, par;
+    upper_pattern(n, Ap, Ai, nullptr, up_ptr, up_idx);
+    etree_of_upper(n, up_ptr, up_idx, par);
+    std::vector<int32_t> count((size_t)n, 1);  // the diagonal
+    walk_row_patterns(n, up_ptr, up_idx, par.data(), [&](int32_t, int32_t i) { count[(size_t)i]++; });
+    int64_t run = 0;
+    for (int32_t j = 0; j < n; j++) {
+        parent[j] = par[(size_t)j];
+        cp[j] = (int32_t)run;
+        run += count[(size_t)j];
+        if (run > 2147483647ll) return CSX_EINVAL;
+    }
+    cp[n] = (int32_t)run;
+    return CSX_OK;
+}
+
+// ---- LU, left-looking, threshold partial pivoting, natural column order -----------------
+// Output: L (unit diagonal first in each column, row indices in pivot order), U (diagonal last),
+// pinv (row i of A is row pinv[i] of L U).  Arrays are malloc'ed; free with csx_host_free.
+extern "C" int csx_lu_host(int32_t n, const int32_t *Ap, const int32_t *Ai, const double *Ax, double tol,
+                           int32_t **Lp_out, int32_t **Li_out, double **Lx_out, int32_t **Up_out, int32_t **Ui_out,
+                           double **Ux_out, int32_t *pinv) {
+    if (n < 0 || !Ap || !Ai || !Ax || !Lp_out || !Li_out || !Lx_out || !Up_out || !Ui_out || !Ux_out || !pinv)
+        return CSX_EINVAL;
+    std::vector<int32_t> Lp((size_t)n + 1, 0), Up((size_t)n + 1, 0), Li, Ui;
+    std::vector<double> Lx, Ux, x((size_t)n, 0.0);
+    std::vector<int32_t> reach((size_t)n), stack((size_t)n), pos((size_t)n);
+    std::vector<char> seen((size_t)n, 0);
+    for (int32_t i = 0; i < n; i++) pinv[i] = -1;
+    for (int32_t k = 0; k < n; k++) {
+        Lp[(size_t)k] = (int32_t)Li.size();
+        Up[(size_t)k] = (int32_t)Ui.size();
+        // reach of A(:,k) in the graph of L (rows already pivotal map to columns of L): DFS,
+        // topological order in reach[top..n-1]
+        int32_t top = n;
+        for (int32_t p = Ap[k]; p < Ap[k + 1]; p++) {
+            if (seen[(size_t)Ai[p]]) continue;
+            int32_t head = 0;
+            stack[0] = Ai[p];
+            while (head >= 0) {
+                const int32_t j = stack[(size_t)head];
+                const int32_t col = pinv[j];
+                if (!seen[(size_t)j]) {
+                    seen[(size_t)j] = 1;
+                    pos[(size_t)head] = col < 0 ? 0 : Lp[(size_t)col];
+                }
+                bool done = true;
+                const int32_t end = col < 0 ? 0 : (col == k ? (int32_t)Li.size() : Lp[(size_t)col + 1]);
+                for (int32_t q = pos[(size_t)head]; q < end; q++) {
+                    const int32_t i = Li[(size_t)q];
+                    if (seen[(size_t)i]) continue;
+                    pos[(size_t)head] = q;
+                    stack[(size_t)++head] = i;
+                    done = false;
+                    break;
+                }
+                if (done) {
+                    head--;
+                    reach[(size_t)--top] = j;
+                }
+            }
+        }
+        for (int32_t p = top; p < n; p++) {
+            seen[(size_t)reach[(size_t)p]] = 0;
+            x[(size_t)reach[(size_t)p]] = 0.0;
+        }
+        for (int32_t p = Ap[k]; p < Ap[k + 1]; p++) x[(size_t)Ai[p]] = Ax[p];
+        // sparse triangular solve x = L \ A(:,k) along the reach
+        for (int32_t px = top; px < n; px++) {
+            const int32_t j = reach[(size_t)px], col = pinv[j];
+            if (col < 0) continue;
+            x[(size_t)j] /= Lx[(size_t)Lp[(size_t)col]];
+            const double xj = x[(size_t)j];
+            for (int32_t q = Lp[(size_t)col] + 1; q < Lp[(size_t)col + 1]; q++) x[(size_t)Li[(size_t)q]] -= Lx[(size_t)q] * xj;
+        }
+        // pivot search among non-pivotal rows; pivotal rows go to U
+        int32_t ipiv = -1;
+        double a = -1.0;
+        for (int32_t p = top; p < n; p++) {
+            const int32_t i = reach[(size_t)p];
+            if (pinv[i] < 0) {
+                const double t = std::fabs(x[(size_t)i]);
+                if (t > a) {
+                    a = t;
+                    ipiv = i;
+                }
+            } else {
+                Ui.push_back(pinv[i]);
+                Ux.push_back(x[(size_t)i]);
+            }
+        }
+        if (ipiv == -1 || a <= 0) return CSX_ENOTSPD;  // singular: the reference returns None (csparse.py:1423)
+        if (pinv[k] < 0 && std::fabs(x[(size_t)k]) >= a * tol) ipiv = k;
+        const double pivot = x[(size_t)ipiv];
+        Ui.push_back(k);
+        Ux.push_back(pivot);
+        pinv[ipiv] = k;
+        Li.push_back(ipiv);
+        Lx.push_back(1.0);
+        for (int32_t p = top; p < n; p++) {
+            const int32_t i = reach[(size_t)p];
+            if (pinv[i] < 0) {
+                Li.push_back(i);
+                Lx.push_back(x[(size_t)i] / pivot);
+            }
+            x[(size_t)i] = 0.0;
+        }
+        // L's column k is complete only now; DFS above used Li.size() as its end while building
+        Lp[(size_t)k + 1] = (int32_t)Li.size();
+    }
+    Lp[(size_t)n] = (int32_t)Li.size();
+    Up[(size_t)n] = (int32_t)Ui.size();
+    for (auto &r : Li) r = pinv[r];
+    auto dup_i = [](const std::vector<int32_t> &v) {
+        int32_t *p = (int32_t *)std::malloc((v.size() + 1) * sizeof(int32_t));
+        if (!v.empty()) std::memcpy(p, v.data(), v.size() * sizeof(int32_t));
+        return p;
+    };
+    auto dup_d = [](const std::vector<double> &v) {
+        double *p = (double *)std::malloc((v.size() + 1) * sizeof(double));
+        if (!v.empty()) std::memcpy(p, v.data(), v.size() * sizeof(double));
+        return p;
+    };
+    *Lp_out = dup_i(Lp);
+    *Li_out = dup_i(Li);
+    *Lx_out = dup_d(Lx);
+    *Up_out = dup_i(Up);
+    *Ui_out = dup_i(Ui);
+    *Ux_out = dup_d(Ux);
+    return CSX_OK;
+}
+
+extern "C" void csx_host_free(void *p) { std::free(p); }

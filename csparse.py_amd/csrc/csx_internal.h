@@ -52,7 +52,8 @@ struct TiledPlan {
     int32_t nslab = 0;         // number of column slabs
     int32_t slab_cols = 0;     // columns per slab
     int32_t ngroup = 0;        // slab groups (partial-y buffers)
-    int32_t *tile_ptr = nullptr;   // [nslab*nrb + 1], tile t = slab*nrb + rb
+    int32_t *tile_ptr = nullptr;   // [ntiles + 1] padded start of every tile (multiple of the group size)
+    int32_t *tile_len = nullptr;   // [ntiles] true number of entries
     uint32_t *tile_key = nullptr;  // packed (local col << rb_bits) | local row
     double *tile_val = nullptr;
     double *partial = nullptr;     // [ngroup][nrb*row_block]

@@ -1,0 +1,465 @@
+// cs_lsolve / cs_ltsolve / cs_usolve / cs_utsolve (csparse.py:1330-1345, :1348-1365,
+// :2368-2385, :2460-2475) and cs_ipvec / cs_pvec (:1264-1277, :1779-1792) on the
+// device, for n-by-nrhs row-major blocks of right-hand sides.
+//
+// Every solve is executed in GATHER form, one unknown at a time:
+//     x[r] = ( x[r] - sum_q val[q] * x[idx[q]] ) / diag[r]
+// with the terms q in exactly the order in which the reference updates x[r]:
+//   L  (forward, column push):  ascending source column, then storage order
+//        -> stable transpose of L with the first entry of every column removed
+//   U  (backward, column push): descending source column, then storage order
+//        -> stable transpose of U with the last entry of every column removed
+//           and the columns taken in reverse
+//   LT / UT (column gather):    the column itself, storage order, no copy
+// Each (unknown, right-hand side) pair is one lane running that loop with the
+// multiply and the subtract rounded separately, so the result is bit-identical
+// to the reference for every right-hand side; lanes of a wavefront hold
+// neighbouring right-hand sides (row-major X => coalesced).
+//
+// Scheduling: level sets (unknowns whose inputs are all in earlier levels).
+// Wide levels are one launch each; runs of narrow levels are executed by ONE
+// workgroup that walks them with a workgroup barrier in between, so a chain
+// (thousands of one-row levels) costs one launch, not thousands.
+//
+// Structures the reference would mis-solve (an entry above the diagonal in L,
+// ...) are run by a literal one-lane-per-right-hand-side transcription of the
+// reference loop, so the answer matches even then.
+#include <algorithm>
+
+#include "csx_internal.h"
+
+namespace csx {
+
+struct Segment {
+    int32_t l0, l1;   // levels [l0, l1)
+    bool one_wg;
+};
+
+struct TriPlan {
+    int kind = 0;
+    int32_t n = 0, nlevels = 0;
+    bool sequential = false, zero_pivot = false;
+    bool owns_g = false;
+    int skip_first = 0, skip_last = 0;
+    int32_t *ptr = nullptr, *idx = nullptr;
+    double *val = nullptr;
+    double *diag = nullptr;
+    int32_t *order = nullptr, *level_ptr = nullptr;  // device
+    std::vector<int32_t> level_ptr_h;
+    std::vector<Segment> segs;
+    const int32_t *Tp = nullptr, *Ti = nullptr;  // the analysed matrix (not owned)
+    const double *Tx = nullptr;
+};
+
+void free_triplan(TriPlan *t) {
+    if (!t) return;
+    if (t->owns_g) {
+        dfree(t->ptr);
+        dfree(t->idx);
+        dfree(t->val);
+    }
+    dfree(t->diag);
+    dfree(t->order);
+    dfree(t->level_ptr);
+    delete t;
+}
+
+constexpr int NARROW = 2048;  // (rows in level) * nrhs at or below this: level joins a one-workgroup run
+
+// ---- building the gather layout ----------------------------------------------
+__global__ __launch_bounds__(256) void k_check_columns(int32_t n, const int32_t *Tp, int *bad) {
+    int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n && Tp[j + 1] <= Tp[j]) *bad = 1;
+}
+
+// out = T without the first entry of each column (same column order)
+__global__ __launch_bounds__(256) void k_strip_first(int32_t n, const int32_t *Tp, const int32_t *Ti, const double *Tx,
+                                                     int32_t *op, int32_t *oi, double *ox, double *diag) {
+    const int lane = threadIdx.x & 63;
+    int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t j = wave; j <= n; j += nwaves) {
+        if (j == n) {
+            if (lane == 0) op[n] = Tp[n] - n;
+            continue;
+        }
+        const int32_t b = Tp[j], e = Tp[j + 1], ob = b - (int32_t)j;
+        if (lane == 0) {
+            op[j] = ob;
+            diag[j] = Tx[b];
+        }
+        for (int32_t p = b + 1 + lane; p < e; p += 64) {
+            oi[ob + (p - b - 1)] = Ti[p];
+            ox[ob + (p - b - 1)] = Tx[p];
+        }
+    }
+}
+
+// out column c = column n-1-c of T without its last entry
+__global__ __launch_bounds__(256) void k_strip_last_reverse(int32_t n, const int32_t *Tp, const int32_t *Ti,
+                                                            const double *Tx, int32_t *op, int32_t *oi, double *ox,
+                                                            double *diag) {
+    const int lane = threadIdx.x & 63;
+    int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int32_t nnz = Tp[n];
+    for (int64_t c = wave; c <= n; c += nwaves) {
+        const int32_t ob = nnz - Tp[n - c] - (int32_t)c;
+        if (c == n) {
+            if (lane == 0) op[n] = ob;
+            continue;
+        }
+        const int32_t j = n - 1 - (int32_t)c, b = Tp[j], e = Tp[j + 1];
+        if (lane == 0) {
+            op[c] = ob;
+            diag[j] = Tx[e - 1];
+        }
+        for (int32_t p = b + lane; p < e - 1; p += 64) {
+            oi[ob + (p - b)] = Ti[p];
+            ox[ob + (p - b)] = Tx[p];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_diag_direct(int32_t n, const int32_t *Tp, const double *Tx, int last,
+                                                     double *diag) {
+    int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) diag[j] = last ? Tx[Tp[j + 1] - 1] : Tx[Tp[j]];
+}
+
+__global__ __launch_bounds__(256) void k_reverse_index(int64_t count, int32_t n, int32_t *idx) {
+    int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < count) idx[q] = n - 1 - idx[q];
+}
+
+__global__ __launch_bounds__(256) void k_any_zero(int32_t n, const double *diag, int *flag) {
+    int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n && diag[j] == 0.0) *flag = 1;
+}
+
+// ---- solve kernels ---------------------------------------------------------------
+#pragma clang fp contract(off)
+
+__device__ __forceinline__ void solve_one(int32_t row, int r, int nrhs, const int32_t *__restrict__ ptr,
+                                          const int32_t *__restrict__ idx, const double *__restrict__ val,
+                                          const double *__restrict__ diag, int skip_first, int skip_last, double *X) {
+    const int32_t b = ptr[row] + skip_first, e = ptr[row + 1] - skip_last;
+    double acc = X[(int64_t)row * nrhs + r];
+    for (int32_t q = b; q < e; q++) {
+        double t = val[q] * X[(int64_t)idx[q] * nrhs + r];
+        acc = acc - t;
+    }
+    X[(int64_t)row * nrhs + r] = acc / diag[row];
+}
+
+__global__ __launch_bounds__(256) void k_tri_level(const int32_t *__restrict__ order, int32_t first, int32_t count,
+                                                   const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx,
+                                                   const double *__restrict__ val, const double *__restrict__ diag,
+                                                   int skip_first, int skip_last, double *X, int nrhs) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)count * nrhs) return;
+    solve_one(order[first + t / nrhs], (int)(t % nrhs), nrhs, ptr, idx, val, diag, skip_first, skip_last, X);
+}
+
+__global__ __launch_bounds__(1024) void k_tri_levels_one_wg(const int32_t *__restrict__ order,
+                                                            const int32_t *__restrict__ level_ptr, int32_t l0,
+                                                            int32_t l1, const int32_t *__restrict__ ptr,
+                                                            const int32_t *__restrict__ idx,
+                                                            const double *__restrict__ val,
+                                                            const double *__restrict__ diag, int skip_first,
+                                                            int skip_last, double *X, int nrhs) {
+    for (int32_t l = l0; l < l1; l++) {
+        const int32_t first = level_ptr[l], count = level_ptr[l + 1] - first;
+        for (int32_t t = threadIdx.x; t < count * nrhs; t += 1024)
+            solve_one(order[first + t / nrhs], t % nrhs, nrhs, ptr, idx, val, diag, skip_first, skip_last, X);
+        __syncthreads();  // workgroup-scope release/acquire: the next level reads these x
+    }
+}
+
+// literal transcriptions of the reference loops, one lane per right-hand side
+__global__ __launch_bounds__(64) void k_tri_sequential(int kind, int32_t n, const int32_t *Tp, const int32_t *Ti,
+                                                       const double *Tx, double *X, int nrhs) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrhs) return;
+#define XV(i) X[(int64_t)(i) * nrhs + r]
+    if (kind == CSX_TRI_L) {
+        for (int32_t j = 0; j < n; j++) {
+            XV(j) = XV(j) / Tx[Tp[j]];
+            const double xj = XV(j);
+            for (int32_t p = Tp[j] + 1; p < Tp[j + 1]; p++) {
+                double t = Tx[p] * xj;
+                XV(Ti[p]) = XV(Ti[p]) - t;
+            }
+        }
+    } else if (kind == CSX_TRI_LT) {
+        for (int32_t j = n - 1; j >= 0; j--) {
+            for (int32_t p = Tp[j] + 1; p < Tp[j + 1]; p++) {
+                double t = Tx[p] * XV(Ti[p]);
+                XV(j) = XV(j) - t;
+            }
+            XV(j) = XV(j) / Tx[Tp[j]];
+        }
+    } else if (kind == CSX_TRI_U) {
+        for (int32_t j = n - 1; j >= 0; j--) {
+            XV(j) = XV(j) / Tx[Tp[j + 1] - 1];
+            const double xj = XV(j);
+            for (int32_t p = Tp[j]; p < Tp[j + 1] - 1; p++) {
+                double t = Tx[p] * xj;
+                XV(Ti[p]) = XV(Ti[p]) - t;
+            }
+        }
+    } else {
+        for (int32_t j = 0; j < n; j++) {
+            for (int32_t p = Tp[j]; p < Tp[j + 1] - 1; p++) {
+                double t = Tx[p] * XV(Ti[p]);
+                XV(j) = XV(j) - t;
+            }
+            XV(j) = XV(j) / Tx[Tp[j + 1] - 1];
+        }
+    }
+#undef XV
+}
+
+#pragma clang fp contract(fast)
+
+__global__ __launch_bounds__(256) void k_permute(const int32_t *__restrict__ p, const double *__restrict__ b,
+                                                 double *__restrict__ x, int32_t n, int nrhs, int inverse) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)n * nrhs) return;
+    const int64_t k = t / nrhs, r = t % nrhs;
+    const int64_t pk = p ? p[k] : k;
+    if (inverse) x[pk * nrhs + r] = b[t];
+    else x[t] = b[pk * nrhs + r];
+}
+
+// ---- analysis ---------------------------------------------------------------------
+static int download_i32(std::vector<int32_t> &h, const int32_t *d, size_t count) {
+    h.resize(count);
+    if (count) CSX_HIP(hipMemcpyAsync(h.data(), d, count * sizeof(int32_t), hipMemcpyDeviceToHost, ctx().stream));
+    CSX_HIP(hipStreamSynchronize(ctx().stream));
+    return CSX_OK;
+}
+
+// Level of every unknown from the gather structure.  forward: inputs have smaller
+// index.  Returns false if some input does not precede its unknown (malformed).
+static bool compute_levels(int32_t n, const std::vector<int32_t> &ptr, const std::vector<int32_t> &idx, int sf, int sl,
+                           bool forward, std::vector<int32_t> &level, int32_t &nlevels) {
+    level.assign((size_t)n, 0);
+    nlevels = 0;
+    for (int32_t s = 0; s < n; s++) {
+        const int32_t r = forward ? s : n - 1 - s;
+        int32_t lv = 0;
+        for (int32_t q = ptr[r] + sf; q < ptr[r + 1] - sl; q++) {
+            const int32_t j = idx[q];
+            if (forward ? j >= r : j <= r) return false;
+            lv = std::max(lv, level[j] + 1);
+        }
+        level[r] = lv;
+        nlevels = std::max(nlevels, lv + 1);
+    }
+    return true;
+}
+
+static int analyse(const Csc *T, int kind, TriPlan **out) {
+    hipStream_t s = ctx().stream;
+    const int32_t n = T->n;
+    TriPlan *P = new TriPlan();
+    *out = P;
+    P->kind = kind;
+    P->n = n;
+    P->Tp = T->p;
+    P->Ti = T->i;
+    P->Tx = T->x;
+    if (n == 0) return CSX_OK;
+    int *flag = nullptr;
+    CSX_TRY(dalloc(&flag, 2));
+    CSX_HIP(hipMemsetAsync(flag, 0, 2 * sizeof(int), s));
+    const unsigned nb = (unsigned)(((int64_t)n + 255) / 256);
+    hipLaunchKernelGGL(k_check_columns, dim3(nb), dim3(256), 0, s, n, T->p, flag);
+    int hflag[2] = {0, 0};
+    CSX_HIP(hipMemcpyAsync(hflag, flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    CSX_HIP(hipStreamSynchronize(s));
+    if (hflag[0]) {  // a column without entries has no diagonal: the reference would index past it
+        dfree(flag);
+        return CSX_EINVAL;
+    }
+    CSX_TRY(dalloc(&P->diag, (size_t)n));
+    const bool forward = (kind == CSX_TRI_L || kind == CSX_TRI_UT);
+    std::vector<int32_t> hptr, hidx;
+    if (kind == CSX_TRI_LT || kind == CSX_TRI_UT) {
+        P->ptr = T->p;
+        P->idx = T->i;
+        P->val = T->x;
+        P->skip_first = kind == CSX_TRI_LT ? 1 : 0;
+        P->skip_last = kind == CSX_TRI_UT ? 1 : 0;
+        hipLaunchKernelGGL(k_diag_direct, dim3(nb), dim3(256), 0, s, n, T->p, T->x, kind == CSX_TRI_UT ? 1 : 0, P->diag);
+    } else {
+        Csc S;  // stripped copy
+        S.m = S.n = n;
+        S.nnz = T->nnz - n;
+        int st = dalloc(&S.p, (size_t)n + 1);
+        if (st == CSX_OK) st = dalloc(&S.i, (size_t)S.nnz);
+        if (st == CSX_OK) st = dalloc(&S.x, (size_t)S.nnz);
+        if (st == CSX_OK) {
+            int64_t blocks = std::min<int64_t>(((int64_t)n + 4) / 4, 65536);
+            if (kind == CSX_TRI_L)
+                hipLaunchKernelGGL(k_strip_first, dim3((unsigned)blocks), dim3(256), 0, s, n, T->p, T->i, T->x, S.p, S.i,
+                                   S.x, P->diag);
+            else
+                hipLaunchKernelGGL(k_strip_last_reverse, dim3((unsigned)blocks), dim3(256), 0, s, n, T->p, T->i, T->x,
+                                   S.p, S.i, S.x, P->diag);
+            if (hipGetLastError() != hipSuccess) st = CSX_ERUNTIME;
+        }
+        Csc G;
+        if (st == CSX_OK) st = transpose_device(&S, true, &G);
+        dfree(S.p);
+        dfree(S.i);
+        dfree(S.x);
+        if (st != CSX_OK) {
+            dfree(G.p);
+            dfree(G.i);
+            dfree(G.x);
+            dfree(flag);
+            return st;
+        }
+        P->ptr = G.p;
+        P->idx = G.i;
+        P->val = G.x;
+        P->owns_g = true;
+        if (kind == CSX_TRI_U && G.nnz > 0) {
+            hipLaunchKernelGGL(k_reverse_index, dim3((unsigned)(((int64_t)G.nnz + 255) / 256)), dim3(256), 0, s,
+                               (int64_t)G.nnz, n, P->idx);
+        }
+    }
+    hipLaunchKernelGGL(k_any_zero, dim3(nb), dim3(256), 0, s, n, P->diag, flag + 1);
+    CSX_HIP(hipMemcpyAsync(hflag, flag, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+    CSX_HIP(hipStreamSynchronize(s));
+    dfree(flag);
+    P->zero_pivot = hflag[1] != 0;
+    const int32_t gnnz = (kind == CSX_TRI_LT || kind == CSX_TRI_UT) ? T->nnz : T->nnz - n;
+    CSX_TRY(download_i32(hptr, P->ptr, (size_t)n + 1));
+    CSX_TRY(download_i32(hidx, P->idx, (size_t)gnnz));
+    std::vector<int32_t> level;
+    if (!compute_levels(n, hptr, hidx, P->skip_first, P->skip_last, forward, level, P->nlevels)) {
+        P->sequential = true;
+        P->nlevels = n;
+        return CSX_OK;
+    }
+    // rows sorted by level (counting sort; inside a level ascending row)
+    P->level_ptr_h.assign((size_t)P->nlevels + 1, 0);
+    for (int32_t r = 0; r < n; r++) P->level_ptr_h[(size_t)level[r] + 1]++;
+    for (int32_t l = 0; l < P->nlevels; l++) P->level_ptr_h[(size_t)l + 1] += P->level_ptr_h[(size_t)l];
+    std::vector<int32_t> order((size_t)n), fill(P->level_ptr_h.begin(), P->level_ptr_h.end() - 1);
+    for (int32_t r = 0; r < n; r++) order[(size_t)fill[(size_t)level[r]]++] = r;
+    CSX_TRY(dalloc(&P->order, (size_t)n));
+    CSX_TRY(dalloc(&P->level_ptr, (size_t)P->nlevels + 1));
+    CSX_HIP(hipMemcpyAsync(P->order, order.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    CSX_HIP(hipMemcpyAsync(P->level_ptr, P->level_ptr_h.data(), ((size_t)P->nlevels + 1) * sizeof(int32_t),
+                           hipMemcpyHostToDevice, s));
+    CSX_HIP(hipStreamSynchronize(s));
+    return CSX_OK;
+}
+
+static void make_segments(TriPlan *P, int nrhs) {
+    P->segs.clear();
+    int32_t l = 0;
+    while (l < P->nlevels) {
+        const int64_t w = (int64_t)(P->level_ptr_h[(size_t)l + 1] - P->level_ptr_h[(size_t)l]) * nrhs;
+        if (w > NARROW) {
+            P->segs.push_back({l, l + 1, false});
+            l++;
+            continue;
+        }
+        int32_t e = l + 1;
+        while (e < P->nlevels && (int64_t)(P->level_ptr_h[(size_t)e + 1] - P->level_ptr_h[(size_t)e]) * nrhs <= NARROW) e++;
+        P->segs.push_back({l, e, true});
+        l = e;
+    }
+}
+
+int tri_solve_raw(TriPlan *P, double *X, int32_t nrhs) {
+    hipStream_t s = ctx().stream;
+    if (P->zero_pivot) return CSX_EZEROPIVOT;
+    if (P->n == 0 || nrhs == 0) return CSX_OK;
+    if (P->sequential) {
+        hipLaunchKernelGGL(k_tri_sequential, dim3((unsigned)((nrhs + 63) / 64)), dim3(64), 0, s, P->kind, P->n, P->Tp,
+                           P->Ti, P->Tx, X, nrhs);
+        CSX_LAUNCH_CHECK();
+        return CSX_OK;
+    }
+    make_segments(P, nrhs);
+    for (const Segment &g : P->segs) {
+        if (g.one_wg) {
+            hipLaunchKernelGGL(k_tri_levels_one_wg, dim3(1), dim3(1024), 0, s, P->order, P->level_ptr, g.l0, g.l1, P->ptr,
+                               P->idx, P->val, P->diag, P->skip_first, P->skip_last, X, nrhs);
+        } else {
+            const int32_t first = P->level_ptr_h[(size_t)g.l0];
+            const int32_t count = P->level_ptr_h[(size_t)g.l0 + 1] - first;
+            const int64_t threads = (int64_t)count * nrhs;
+            hipLaunchKernelGGL(k_tri_level, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, P->order, first,
+                               count, P->ptr, P->idx, P->val, P->diag, P->skip_first, P->skip_last, X, nrhs);
+        }
+    }
+    CSX_LAUNCH_CHECK();
+    return CSX_OK;
+}
+
+int tri_analyse_raw(const Csc *T, int kind, TriPlan **out) { return analyse(T, kind, out); }
+
+void tri_gather_arrays(const TriPlan *P, const int32_t **ptr, const int32_t **idx, const double **val,
+                       const double **diag) {
+    *ptr = P->ptr;
+    *idx = P->idx;
+    *val = P->val;
+    *diag = P->diag;
+}
+
+}  // namespace csx
+
+using namespace csx;
+
+extern "C" int csx_tri_analyse(csx_handle_t hT, int kind, csx_handle_t *out) {
+    CSX_TRY(require_ready());
+    Csc *T = csc(hT);
+    if (!T || !out || !T->x || T->m != T->n || kind < 0 || kind > 3) return CSX_EINVAL;
+    TriPlan *P = nullptr;
+    int st = analyse(T, kind, &P);
+    if (st != CSX_OK) {
+        free_triplan(P);
+        return st;
+    }
+    *out = put(K_TRIPLAN, P);
+    return CSX_OK;
+}
+
+extern "C" int csx_tri_info(csx_handle_t h, int32_t *n, int32_t *levels, int32_t *sequential) {
+    TriPlan *P = (TriPlan *)get(h, K_TRIPLAN);
+    if (!P) return CSX_EINVAL;
+    if (n) *n = P->n;
+    if (levels) *levels = P->nlevels;
+    if (sequential) *sequential = P->sequential ? 1 : 0;
+    return CSX_OK;
+}
+
+extern "C" int csx_tri_solve(csx_handle_t h, csx_handle_t hX, int32_t nrhs) {
+    CSX_TRY(require_ready());
+    TriPlan *P = (TriPlan *)get(h, K_TRIPLAN);
+    Vec *X = vec(hX);
+    if (!P || !X || nrhs < 0 || X->len < (int64_t)P->n * nrhs) return CSX_EINVAL;
+    return tri_solve_raw(P, (double *)X->d, nrhs);
+}
+
+extern "C" int csx_permute_vec(csx_handle_t hp, csx_handle_t hb, csx_handle_t hx, int32_t n, int32_t nrhs,
+                               int inverse) {
+    CSX_TRY(require_ready());
+    Vec *b = vec(hb), *x = vec(hx);
+    Vec *p = hp ? ivec(hp) : nullptr;
+    if (!b || !x || n < 0 || nrhs < 0 || (hp && (!p || p->len < n))) return CSX_EINVAL;
+    if (b->len < (int64_t)n * nrhs || x->len < (int64_t)n * nrhs || b->d == x->d) return CSX_EINVAL;
+    const int64_t total = (int64_t)n * nrhs;
+    if (total == 0) return CSX_OK;
+    hipLaunchKernelGGL(k_permute, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx().stream,
+                       p ? (const int32_t *)p->d : nullptr, (const double *)b->d, (double *)x->d, n, nrhs, inverse);
+    CSX_LAUNCH_CHECK();
+    return CSX_OK;
+}

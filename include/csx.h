@@ -133,7 +133,18 @@ int csx_chol(csx_handle_t A, const int32_t *parent, const int32_t *cp, const int
 /* The solve phase of cs_cholsol, csparse.py:640-643, for nrhs right-hand sides:
  * B (n-by-nrhs, row-major) is overwritten with the solutions. */
 int csx_cholsol_plan(csx_handle_t L, const int32_t *pinv /* host, or NULL */, csx_handle_t *plan);
+int csx_cholsol_info(csx_handle_t plan, int32_t *fused_local, int32_t *ntrees, int32_t *max_nodes);
 int csx_cholsol_solve(csx_handle_t plan, csx_handle_t B, int32_t nrhs);
+
+/* cs_lu, csparse.py:1370-1451 (+ cs_spsolve :2078-2113), natural column order: host C++
+ * left-looking LU with threshold partial pivoting.  It produces the L (unit diagonal first)
+ * and U (diagonal last) that cs_lsolve / cs_usolve consume in cs_lusol (csparse.py:1474-1477).
+ * Output arrays are malloc'ed here; release each with csx_host_free.  Returns CSX_ENOTSPD for a
+ * singular matrix (the reference returns None, csparse.py:1423). */
+int csx_lu_host(int32_t n, const int32_t *Ap, const int32_t *Ai, const double *Ax, double tol,
+                int32_t **Lp, int32_t **Li, double **Lx, int32_t **Up, int32_t **Ui, double **Ux,
+                int32_t *pinv);
+void csx_host_free(void *p);
 
 /* ---- synthetic inputs of the benchmark configs, generated on
  * the device from a counter-based hash so host and device agree bit for bit ---- */

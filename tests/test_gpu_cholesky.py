@@ -1,0 +1,153 @@
+"""cs_chol / cs_cholsol / cs_lusol on the device against the oracle (needs an MI355X).
+The reference cannot run cs_chol: parity is against the restatement, which is
+pinned by the reference's own cs_lusol answers and the L L' = C residual (test_oracle_golden)."""
+import numpy as np
+import pytest
+
+import c_oracle as CO
+import csparse_oracle as O
+import synth
+from conftest import golden, unpack
+from test_gpu_parity import RTOL, _host_cs, cs  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+def _arr(A):
+    nnz = A.p[A.n]
+    return (np.asarray(A.p, np.int32), np.asarray(A.i[:nnz], np.int32), np.asarray(A.x[:nnz], np.float64))
+
+
+@pytest.mark.parametrize("name", ["bcsstk01", "bcsstk16"])
+def test_chol_and_cholsol_reference_matrices(cs, name):
+    g = golden(name)
+    C = unpack(cs, g, "C")
+    n = C.n
+    S = cs.cs_schol(0, C)
+    N = cs.cs_chol(C, S)
+    L = N.L
+    Cp, Ci, Cx = _arr(C)
+    parent, cp = CO.schol(n, Cp, Ci)
+    Lp, Li, Lx = CO.chol(n, Cp, Ci, Cx, parent, cp)
+    assert L.p == S.cp == Lp.tolist()
+    assert L.i[:Lp[n]] == Li.tolist()                      # structure: bit-exact
+    got = np.asarray(L.x[:Lp[n]])
+    assert np.max(np.abs(got - Lx) / np.abs(Lx).max()) < 1e-13
+    small = np.abs(Lx) > 1e-6 * np.abs(Lx).max()
+    assert np.max(np.abs(got[small] - Lx[small]) / np.abs(Lx[small])) < RTOL
+    # the driver: b overwritten in place, True returned
+    b = g["b"].tolist()
+    alias = b
+    assert cs.cs_cholsol(0, C, b) is True and alias is b
+    ref = CO.ltsolve(n, Lp, Li, Lx, CO.lsolve(n, Lp, Li, Lx, g["b"]))
+    assert np.max(np.abs(np.asarray(b) - ref) / np.abs(ref)) < 1e-9
+    if name == "bcsstk01":
+        # csparse_test.py:505-516 (0.0005) and the unmodified reference's own LU answer
+        assert max(abs(v) for v in b) == pytest.approx(0.0005, abs=1e-4)
+        assert np.max(np.abs(np.asarray(b) - g["x_lusol"]) / np.abs(g["x_lusol"])) < RTOL
+    else:
+        assert max(abs(v) for v in b) == pytest.approx(1.9998, abs=1e-3)  # csparse_test.py:528-533
+    # the reference's solve sequence on the build's L reproduces the driver bit for bit
+    gLp, gLi, gLx = _arr(L)
+    seq = CO.ltsolve(n, gLp, gLi, gLx, CO.lsolve(n, gLp, gLi, gLx, g["b"]))
+    assert np.asarray(b).tobytes() == seq.tobytes()
+
+
+def test_chol_not_positive_definite(cs):
+    g = golden("bcsstk01")
+    C = unpack(cs, g, "C")
+    S = cs.cs_schol(0, C)
+    diag = [p for j in range(C.n) for p in range(C.p[j], C.p[j + 1]) if C.i[p] == j]
+    x = list(C.x)
+    x[diag[5]] = -1.0
+    C.x = x
+    assert cs.cs_chol(C, S) is None
+    assert cs.cs_cholsol(0, C, g["b"].tolist()) is False
+    assert cs.cs_chol(C, None) is None
+
+
+def test_chol_with_permutation(cs):
+    g = golden("bcsstk01")
+    C = unpack(cs, g, "C")
+    Co = unpack(O, g, "C")
+    n = C.n
+    rng = np.random.default_rng(11)
+    pinv = rng.permutation(n).tolist()
+    C2 = O.cs_symperm(Co, pinv, False)
+    So = O.css()
+    So.pinv = pinv
+    So.parent = O.cs_etree(C2, False)
+    So.cp = [0] * (n + 1)
+    So.lnz = O.cs_cumsum(So.cp, O.cs_counts(C2, So.parent, O.cs_post(So.parent, n), False), n)
+    No = O.cs_chol(Co, So)
+    S = cs.css()
+    S.pinv, S.parent, S.cp, S.lnz = pinv, So.parent, So.cp, So.lnz
+    N = cs.cs_chol(C, S)
+    assert N.L.p == No.L.p and N.L.i == No.L.i
+    np.testing.assert_allclose(N.L.x, No.L.x, rtol=1e-9, atol=1e-9 * max(abs(v) for v in No.L.x))
+    # batched solve through the permutation, generic (level-scheduled) path
+    b = g["b"].tolist()
+    xo = list(b)
+    y = [0.0] * n
+    O.cs_ipvec(pinv, xo, y, n)
+    O.cs_lsolve(No.L, y)
+    O.cs_ltsolve(No.L, y)
+    O.cs_pvec(pinv, y, xo, n)
+    np.testing.assert_allclose(xo, g["x_lusol"], rtol=1e-8)
+    import _csx
+    plan = _csx.new_handle()
+    _csx.check(_csx.lib().csx_cholsol_plan(N.L._dev.handle, _csx.pi(_csx.i32(pinv)), plan))
+    B = np.stack([g["b"], 2 * g["b"], g["b"] + 1.0], axis=1)
+    dB = cs.dvec(B)
+    _csx.check(_csx.lib().csx_cholsol_solve(plan, dB.handle, 3))
+    X = dB.numpy()
+    _csx.free(plan)
+    np.testing.assert_allclose(X[:, 0], xo, rtol=1e-9)
+    np.testing.assert_allclose(X[:, 1], 2 * np.asarray(xo), rtol=1e-9)
+
+
+@pytest.mark.parametrize("nblocks,bs,k", [(40, 64, 130), (300, 8, 5), (3, 32, 64)])
+def test_gspd_factor_and_batched_solve(cs, nblocks, bs, k):
+    """Block-diagonal SPD (the benchmark's G-spd shape): forest of small trees -> tree kernels
+    for the factorisation and the fused in-LDS solve for many right-hand sides."""
+    Ap, Ai, Ax = synth.gspd(nblocks, bs, 20240606)
+    n = nblocks * bs
+    A = cs.cs_pin(_host_cs(cs, n, n, Ap, Ai, Ax))
+    F = cs.cholsol_factor(A)
+    assert F.info() == {"fused_local": True, "trees": nblocks, "max_nodes": bs}
+    parent, cp = CO.schol(n, Ap, Ai)
+    assert F.symbolic.parent == parent.tolist() and F.symbolic.cp == cp.tolist()
+    Lp, Li, Lx = CO.chol(n, Ap, Ai, Ax, parent, cp)
+    L = F.L
+    assert L.p == Lp.tolist() and L.i[:Lp[n]] == Li.tolist()
+    got = np.asarray(L.x[:Lp[n]])
+    assert np.max(np.abs(got - Lx)) / np.abs(Lx).max() < 1e-13
+    B = synth.rhs(n, k, 0)
+    dB = cs.dvec(B)
+    assert F.solve(dB) is True
+    X = dB.numpy()
+    gLp, gLi, gLx = _arr(L)
+    for r in sorted(set([0, 1, k // 2, k - 1])):
+        ref = CO.ltsolve(n, gLp, gLi, gLx, CO.lsolve(n, gLp, gLi, gLx, B[:, r]))
+        assert X[:, r].tobytes() == ref.tobytes(), r            # bit-identical per right-hand side
+    # residual of the whole block against A (symmetric, full storage)
+    R = np.stack([CO.gaxpy(n, n, Ap, Ai, Ax, X[:, r], -B[:, r]) for r in (0, k - 1)], axis=1)
+    assert np.max(np.abs(R)) < 1e-12 * np.max(np.abs(B)) * bs
+    # one right-hand side as a list through the drop-in driver
+    b = B[:, 0].tolist()
+    assert cs.cs_cholsol(0, A, b) is True
+    assert np.asarray(b).tobytes() == X[:, 0].tobytes()
+
+
+@pytest.mark.parametrize("name", ["t1", "bcsstk01", "west0067", "fs_183_1"])
+def test_lusol_matches_reference(cs, name, meta):
+    g = golden(name)
+    C = unpack(cs, g, "C")
+    tol = 0.001 if meta[name]["sym"] else 1.0
+    b = g["b"].tolist()
+    assert cs.cs_lusol(0, C, b, tol) is True
+    ref = g["x_lusol"]  # unmodified reference cs_lusol(0, ...)
+    assert np.max(np.abs(np.asarray(b) - ref)) / np.max(np.abs(ref)) < RTOL
+    nz = np.abs(ref) > 1e-3 * np.max(np.abs(ref))
+    assert np.max(np.abs(np.asarray(b)[nz] - ref[nz]) / np.abs(ref[nz])) < 1e-9
+    assert max(abs(v) for v in b) == pytest.approx(meta[name]["lusol_norm_inf"], rel=1e-9)

@@ -1,0 +1,103 @@
+"""Parity of the device SpGEMM (cs_multiply) against the oracle and golden vectors:
+p[] and i[] bit-exact (first-touch column order), x[] within 1e-10."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import c_oracle as CO
+import synth
+from conftest import golden, unpack, same_csc
+from test_gpu_parity import ALL, SMALL, RTOL, _host_cs, cs, rel_err  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+def sha(a, dt):
+    return hashlib.sha256(np.asarray(a, dtype=dt).tobytes()).hexdigest()
+
+
+def check_product(C, Cp, Ci, Cx, Sx):
+    """C (product module) against oracle arrays; Sx = sum of |products| per entry (error scale)."""
+    nnz = int(Cp[-1])
+    assert C.p == Cp.tolist()
+    assert C.i[:nnz] == Ci.tolist()
+    assert C.nzmax == nnz and len(C.i) == nnz
+    if Cx is None:
+        assert C.x is None
+        return
+    assert rel_err(C.x, Cx, Sx) < RTOL
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_multiply_a_at_reference_matrices(cs, name, meta):
+    g = golden(name)
+    A = unpack(cs, g, "A")
+    AT = unpack(cs, g, "AT")
+    C = cs.cs_multiply(A, AT)
+    mm = meta[name]["AAT"]
+    nnz = C.p[C.n]
+    assert (C.m, C.n, nnz, C.nzmax, len(C.i)) == (mm["m"], mm["n"], mm["nnz"], mm["nzmax"], mm["leni"])
+    assert sha(C.p, np.int64) == mm["sha_p"] and sha(C.i[:nnz], np.int64) == mm["sha_i"]
+    ap, ai, ax = np.asarray(A.p, np.int32), np.asarray(A.i[:A.p[A.n]], np.int32), np.asarray(A.x[:A.p[A.n]])
+    tp, ti, tx = np.asarray(AT.p, np.int32), np.asarray(AT.i[:AT.p[AT.n]], np.int32), np.asarray(AT.x[:AT.p[AT.n]])
+    Cp, Ci, Cx = CO.multiply(A.m, A.n, AT.n, ap, ai, ax, tp, ti, tx)
+    _, _, Sx = CO.multiply(A.m, A.n, AT.n, ap, ai, np.abs(ax), tp, ti, np.abs(tx))
+    check_product(C, Cp, Ci, Cx, Sx)
+    if name in SMALL:
+        same_csc(C, g, "AAT", exact_x=False)
+        P = cs.cs_multiply(cs.cs_transpose(A, False), A)  # pattern only
+        same_csc(P, g, "ATA_pat")
+
+
+def test_multiply_edge_cases(cs):
+    g = golden("synthetic_20240601")
+    for c, (m, n, nnz) in enumerate(g["cases"]):
+        pre = "c%d_" % c
+        A, AT = unpack(cs, g, pre + "A"), unpack(cs, g, pre + "AT")
+        same_csc(cs.cs_multiply(A, AT), g, pre + "AAT", exact_x=False)
+        same_csc(cs.cs_multiply(AT, A), g, pre + "ATA", exact_x=False)
+        Ap = unpack(cs, g, pre + "A")
+        Ap.x = None
+        same_csc(cs.cs_multiply(Ap, AT), g, pre + "AAT_pat")
+        if m != n:
+            assert cs.cs_multiply(A, A) is None
+
+
+@pytest.mark.parametrize("n,per_col", [(20000, 32), (9000, 5), (70000, 12)])
+def test_multiply_hash_paths_against_c_oracle(cs, n, per_col):
+    """m > 8192 rows: the LDS hash accumulators (and, for the dense column below, the global one)."""
+    Ap, Ai, Ax = synth.grand(n, per_col, 31)
+    Tp, Ti, Tx = CO.transpose(n, n, Ap, Ai, Ax)
+    A = _host_cs(cs, n, n, Ap, Ai, Ax)
+    AT = _host_cs(cs, n, n, Tp, Ti, Tx)
+    Cp, Ci, Cx = CO.multiply(n, n, n, Ap, Ai, Ax, Tp, Ti, Tx)
+    _, _, Sx = CO.multiply(n, n, n, Ap, Ai, np.abs(Ax), Tp, Ti, np.abs(Tx))
+    check_product(cs.cs_multiply(A, AT), Cp, Ci, Cx, Sx)
+
+
+def test_multiply_one_huge_column_uses_global_accumulator(cs):
+    n = 30000
+    Ap, Ai, Ax = synth.grand(n, 8, 77)
+    # B: column 0 selects 3000 columns of A (24000 products > any LDS table), others are sparse
+    rng = np.random.default_rng(1)
+    sel = np.sort(rng.choice(n, 3000, replace=False)).astype(np.int32)
+    rest = rng.integers(0, n, size=(n - 1) * 2).astype(np.int32)
+    Bi = np.concatenate([sel, rest])
+    Bp = np.concatenate([[0], 3000 + 2 * np.arange(n)]).astype(np.int32)
+    Bx = rng.uniform(0.5, 1.5, len(Bi))
+    A = _host_cs(cs, n, n, Ap, Ai, Ax)
+    B = _host_cs(cs, n, n, Bp, Bi, Bx)
+    Cp, Ci, Cx = CO.multiply(n, n, n, Ap, Ai, Ax, Bp, Bi, Bx)
+    _, _, Sx = CO.multiply(n, n, n, Ap, Ai, np.abs(Ax), Bp, Bi, np.abs(Bx))
+    check_product(cs.cs_multiply(A, B), Cp, Ci, Cx, Sx)
+    # long B column (> one staging segment of 1024 entries) through the LDS-dense path
+    m2 = 500
+    Ap2, Ai2, Ax2 = synth.grand(m2, 5, 5)
+    Bi2 = rng.integers(0, m2, size=2500).astype(np.int32)
+    Bp2 = np.asarray([0, 2500], dtype=np.int32)
+    Bx2 = rng.uniform(-1, 1, 2500)
+    C2 = cs.cs_multiply(_host_cs(cs, m2, m2, Ap2, Ai2, Ax2), _host_cs(cs, m2, 1, Bp2, Bi2, Bx2))
+    Cp2, Ci2, Cx2 = CO.multiply(m2, m2, 1, Ap2, Ai2, Ax2, Bp2, Bi2, Bx2)
+    _, _, Sx2 = CO.multiply(m2, m2, 1, Ap2, Ai2, np.abs(Ax2), Bp2, Bi2, np.abs(Bx2))
+    check_product(C2, Cp2, Ci2, Cx2, Sx2)

@@ -1,0 +1,59 @@
+"""Host C++ steps inside libcsx (no GPU needed): cs_schol and cs_lu restated in C++
+against the pinned oracle."""
+import numpy as np
+import pytest
+
+import csparse_oracle as O
+import synth
+from conftest import golden, unpack
+
+
+@pytest.mark.parametrize("name", ["bcsstk01", "bcsstk16"])
+def test_schol_host_matches_oracle(name):
+    import csparse as cs
+    g = golden(name)
+    C = unpack(cs, g, "C")
+    S = cs.cs_schol(0, C)
+    R = O.cs_schol(0, unpack(O, g, "C"))
+    assert S.parent == R.parent and S.cp == R.cp and S.lnz == R.lnz and S.pinv is None
+    assert cs.cs_schol(1, C) is None  # the reference's cs_amd never yields an ordering
+
+
+def test_schol_host_block_diagonal():
+    import csparse as cs
+    Ap, Ai, Ax = synth.gspd(7, 8, 3)
+    A = cs.cs_spalloc(56, 56, len(Ai), True, False)
+    A.p, A.i, A.x = Ap.tolist(), Ai.tolist(), Ax.tolist()
+    S = cs.cs_schol(0, A)
+    assert S.lnz == 7 * 36
+    assert S.parent == [(-1 if j % 8 == 7 else j + 1) for j in range(56)]
+
+
+@pytest.mark.parametrize("name", ["t1", "bcsstk01", "west0067", "fs_183_1"])
+def test_lu_host_matches_oracle(name, meta):
+    import csparse as cs
+    g = golden(name)
+    tol = 0.001 if meta[name]["sym"] else 1.0
+    C = unpack(cs, g, "C")
+    N = cs.cs_lu(C, cs.cs_sqr(0, C, False), tol)
+    Co = unpack(O, g, "C")
+    R = O.cs_lu(Co, O.cs_sqr(0, Co, False), tol)
+    assert N.pinv == R.pinv
+    for got, ref in ((N.L, R.L), (N.U, R.U)):
+        assert got.p == ref.p and got.i == ref.i
+        assert np.asarray(got.x).tobytes() == np.asarray(ref.x).tobytes()
+    # diagonal first in L (unit), last in U: what cs_lsolve / cs_usolve rely on
+    n = C.n
+    assert all(N.L.i[N.L.p[j]] == j and N.L.x[N.L.p[j]] == 1.0 for j in range(n))
+    assert all(N.U.i[N.U.p[j + 1] - 1] == j for j in range(n))
+
+
+def test_lu_host_singular_and_bad_input():
+    import csparse as cs
+    A = cs.cs_spalloc(2, 2, 2, True, False)
+    A.p, A.i, A.x = [0, 1, 2], [0, 0], [1.0, 2.0]  # second row empty -> singular
+    assert cs.cs_lu(A, cs.cs_sqr(0, A, False), 1.0) is None
+    assert cs.cs_lusol(0, A, [1.0, 1.0], 1.0) is False
+    assert cs.cs_lu(A, None, 1.0) is None and cs.cs_sqr(2, A, False) is None
+    T = cs.cs_spalloc(2, 2, 2, True, True)
+    assert cs.cs_lusol(0, T, [1.0, 1.0], 1.0) is False and cs.cs_lusol(0, A, None, 1.0) is False
