@@ -97,15 +97,9 @@ def main():
     ap.add_argument("--skip-gspd", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    import shard
+    comm = shard.Comm()  # RCCL ("nccl") when launched by torch.distributed.run, no-op at N=1
+    rank, world, local = comm.rank, comm.world, comm.local
     import numpy as np
     import _csx
     import csparse as cs
@@ -113,19 +107,9 @@ def main():
     lib = _csx.lib()
 
     def barrier():
-        _csx.sync()
-        if dist is not None:
-            import torch
-            torch.cuda.synchronize()
-            dist.barrier()
+        comm.barrier(_csx.sync)
 
-    def max_over_ranks(v):
-        if dist is None:
-            return v
-        import torch
-        t = torch.tensor([v], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
+    max_over_ranks = comm.max
 
     n, per_col = args.n, args.per_col
     nnz = n * per_col
@@ -149,10 +133,7 @@ def main():
                 _csx.check(lib.csx_gaxpy(hA, hx, hy, modes[name]), "gaxpy " + name)
         trial[name] = {"ms": tm.ms / 3, "prepare_s": prep}
     chosen = min(trial, key=lambda k: trial[k]["ms"])
-    if dist is not None:  # all ranks must run the same kernel: rank 0 decides
-        obj = [chosen]
-        dist.broadcast_object_list(obj, src=0)
-        chosen = obj[0]
+    chosen = comm.broadcast_object(chosen)  # all ranks run the kernel rank 0 measured fastest
     mode = modes[chosen]
 
     _csx.check(lib.csx_vec_fill(hy, 0.0), "fill")
@@ -187,7 +168,11 @@ def main():
                    "n": n, "nnz": nnz, "kernel": "gaxpy_" + chosen, "algorithmic_bytes_per_step": by,
                    "parallelism": "independent matrices, 1 per GPU, no data-path collective"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes,
+                     # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes; profiles/r01_ablation.md).  Only
+                     # valid for the kernel and size it was measured on.
+                     "traffic": 5.6e9 if (chosen == "tiled" and n == 5000000 and per_col == 64) else None,
                      "step_ms_hip_events": round(step_ms_events, 4)},
         "gaxpy_trials_ms": {k: round(v["ms"], 4) for k, v in trial.items()},
         "gaxpy_prepare_s": {k: round(v["prepare_s"], 3) for k, v in trial.items()},
@@ -231,20 +216,72 @@ def main():
         out["cpu_baseline_c"] = c
     if rank == 0:
         print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    comm.close()
 
 
 def cholsol_section(args, lib, cs, hB, nb, bs, rank, world, barrier, max_over_ranks):
     """Batched cs_cholsol on G-spd: factor once per rank, solve nrhs right-hand sides per GPU."""
     import numpy as np
     import _csx
+    C = _csx.C
     n = nb * bs
-    if not hasattr(cs, "cs_chol_device"):
-        return None
-    return cs.bench_cholsol(lib, hB, n, nb, bs, args.nrhs, rank, world, args.steps, args.warmup, barrier,
-                            max_over_ranks, cholsol_bytes, HBM_PEAK_GBS)
+    nnz = n * bs
+    k = args.nrhs
+    # symbolic analysis on the host (cs_schol, natural order) from the matrix pattern
+    t0 = time.perf_counter()
+    p = np.empty(n + 1, dtype=np.int32)
+    i = np.empty(nnz, dtype=np.int32)
+    _csx.check(lib.csx_csc_download(hB, _csx.pi(p), _csx.pi(i), None), "download pattern")
+    parent = np.empty(n, dtype=np.int32)
+    cp = np.empty(n + 1, dtype=np.int32)
+    _csx.check(lib.csx_schol_host(n, _csx.pi(p), _csx.pi(i), _csx.pi(parent), _csx.pi(cp)), "schol")
+    del i
+    t_symbolic = time.perf_counter() - t0
+    lnz = int(cp[n])
+    # numeric factorisation on the device (includes the host pattern fill of L)
+    t0 = time.perf_counter()
+    hL = _csx.new_handle()
+    _csx.check(lib.csx_chol(hB, _csx.pi(parent), _csx.pi(cp), None, hL), "chol")
+    _csx.sync()
+    t_numeric = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    plan = _csx.new_handle()
+    _csx.check(lib.csx_cholsol_plan(hL, None, plan), "cholsol_plan")
+    _csx.sync()
+    t_plan = time.perf_counter() - t0
+    fused, trees, mx = C.c_int32(), C.c_int32(), C.c_int32()
+    _csx.check(lib.csx_cholsol_info(plan, fused, trees, mx), "cholsol_info")
+    # this rank's block of right-hand sides: columns [rank*k, (rank+1)*k) of the global B
+    hR = _csx.new_handle()
+    _csx.check(lib.csx_gen_rhs(n, k, rank * k, hR), "gen_rhs")
+    for _ in range(max(1, args.warmup)):
+        _csx.check(lib.csx_cholsol_solve(plan, hR, k), "cholsol_solve")
+    steps = min(args.steps, 40)
+    barrier()
+    t0 = time.perf_counter()
+    _csx.check(lib.csx_timer_start(), "timer")
+    for _ in range(steps):
+        _csx.check(lib.csx_cholsol_solve(plan, hR, k), "cholsol_solve")
+    ev = C.c_double(0.0)
+    _csx.check(lib.csx_timer_stop(ev), "timer")
+    barrier()
+    wall = max_over_ranks(time.perf_counter() - t0)
+    ms = max_over_ranks(ev.value / steps)
+    fused_bytes = 12 * lnz + 4 * (n + 1) + 16 * n * k  # L read once, B read once, X written once
+    out = {"workload": "batched cs_cholsol solve phase on G-spd (n=%d, lnz=%d): %d right-hand sides per GPU, "
+                       "factor once per GPU, row-major n x k block" % (n, lnz, k),
+           "solves_per_s": round(k * world * steps / wall, 1), "nrhs_per_gpu": k, "ms_per_batch": round(ms, 4),
+           "fused_in_lds": bool(fused.value), "trees": trees.value, "max_tree": mx.value,
+           "algorithmic_bytes_fused": fused_bytes,
+           "achieved_GBps_per_gpu": round(fused_bytes / (ms * 1e-3) / 1e9, 2),
+           "frac_of_peak": round(fused_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           "survey_bytes_unfused": cholsol_bytes(lnz, n, k),
+           "factor_s": {"symbolic_host": round(t_symbolic, 3), "numeric_incl_pattern_fill": round(t_numeric, 3),
+                        "solve_plan": round(t_plan, 3)}}
+    _csx.free(plan)
+    _csx.free(hR)
+    _csx.free(hL)
+    return out
 
 
 if __name__ == "__main__":

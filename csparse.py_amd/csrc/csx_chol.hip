@@ -364,6 +364,12 @@ struct CholPlan {
     int32_t ntrees = 0, max_nodes = 0;
     Tree *trees = nullptr;
     int32_t *tree_nodes = nullptr, *local_id = nullptr;
+    // per-tree solve programs, indexed by position k in tree_nodes (row a of tree t: k = first + a):
+    // forward terms [f_ptr[k], f_ptr[k+1]) and backward terms [b_ptr[k], b_ptr[k+1]) as
+    // (local row id, value) in the reference's update order, plus the diagonal of that row
+    int32_t *f_ptr = nullptr, *f_idx = nullptr, *b_ptr = nullptr, *b_idx = nullptr;
+    double *f_val = nullptr, *b_val = nullptr, *diagk = nullptr, *diagb = nullptr;
+    int32_t *rev_pos = nullptr;
 };
 
 void free_cholplan(CholPlan *P) {
@@ -375,6 +381,15 @@ void free_cholplan(CholPlan *P) {
     dfree(P->trees);
     dfree(P->tree_nodes);
     dfree(P->local_id);
+    dfree(P->f_ptr);
+    dfree(P->f_idx);
+    dfree(P->f_val);
+    dfree(P->b_ptr);
+    dfree(P->b_idx);
+    dfree(P->b_val);
+    dfree(P->diagk);
+    dfree(P->diagb);
+    dfree(P->rev_pos);
     delete P;
 }
 
@@ -392,14 +407,156 @@ __global__ __launch_bounds__(256) void k_parent_of_sorted_L(int32_t n, const int
     }
 }
 
-// One wave = one tree x 64 right-hand sides.  X tile in LDS: [node][lane].
+// ---- packing the per-tree programs (plan time) ----
+__global__ __launch_bounds__(256) void k_pack_len(int32_t n, const int32_t *__restrict__ nodes,
+                                                  const int32_t *__restrict__ rev_pos,
+                                                  const int32_t *__restrict__ Gp, const int32_t *__restrict__ Lp,
+                                                  int32_t *flen, int32_t *blen) {
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int32_t j = nodes[k];
+    flen[k] = Gp[j + 1] - Gp[j];
+    blen[rev_pos[k]] = Lp[j + 1] - Lp[j] - 1;  // the backward sweep visits a tree's rows in reverse
+}
+
+__global__ __launch_bounds__(256) void k_pack_fill(int32_t n, const int32_t *__restrict__ nodes,
+                                                   const int32_t *__restrict__ rev_pos,
+                                                   const int32_t *__restrict__ local_id,
+                                                   const int32_t *__restrict__ Gp, const int32_t *__restrict__ Gi,
+                                                   const double *__restrict__ Gx, const int32_t *__restrict__ Lp,
+                                                   const int32_t *__restrict__ Li, const double *__restrict__ Lx,
+                                                   const int32_t *__restrict__ f_ptr, int32_t *f_idx, double *f_val,
+                                                   const int32_t *__restrict__ b_ptr, int32_t *b_idx, double *b_val,
+                                                   double *diagf, double *diagb) {
+    const int lane = threadIdx.x & 63;
+    const int64_t k = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (k >= n) return;
+    const int32_t j = nodes[k], kb = rev_pos[k];
+    const int32_t gb = Gp[j], fl = Gp[j + 1] - gb, fo = f_ptr[k];
+    for (int32_t q = lane; q < fl; q += 64) {
+        f_idx[fo + q] = local_id[Gi[gb + q]] * 64;  // premultiplied: X tile is [node][64 lanes]
+        f_val[fo + q] = Gx[gb + q];
+    }
+    const int32_t lb = Lp[j] + 1, bl = Lp[j + 1] - lb, bo = b_ptr[kb];
+    for (int32_t q = lane; q < bl; q += 64) {
+        b_idx[bo + q] = local_id[Li[lb + q]] * 64;
+        b_val[bo + q] = Lx[lb + q];
+    }
+    if (lane == 0) {
+        diagf[k] = Lx[Lp[j]];
+        diagb[kb] = Lx[Lp[j]];
+    }
+}
+
+// One wave = one tree x 64 right-hand sides.  X tile in LDS: [node][lane].  The terms of a row
+// are loaded coalesced (one term per lane) and broadcast with v_readlane; each lane applies them
+// to its own right-hand side in the reference's order (multiply and subtract rounded
+// separately), so the result is bit-identical to cs_lsolve + cs_ltsolve on this L.
 #pragma clang fp contract(off)
+struct TermRegs {  // up to 64 terms of one row, one per lane
+    int32_t i;
+    double v;
+};
+
+__device__ __forceinline__ TermRegs load_terms(const int32_t *__restrict__ idx, const double *__restrict__ val,
+                                               int32_t q, int32_t qe, int lane) {
+    TermRegs t;
+    const bool in = q + lane < qe;
+    t.i = in ? idx[q + lane] : 0;
+    t.v = in ? val[q + lane] : 0.0;
+    return t;
+}
+
+__device__ __forceinline__ double bcast_f64(double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+// acc -= val[u] * X[idx[u] + lane] for the terms u0 <= u < u1 held one per lane in `t`, in order
+__device__ __forceinline__ double apply_terms(double acc, const TermRegs &t, int u0, int u1, const double *X,
+                                              int lane) {
+    int u = u0;
+    for (; u + 8 <= u1; u += 8) {  // 8 LDS reads in flight, then the (inherently serial) subtract chain
+        double xx[8], vv[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) xx[k] = X[__builtin_amdgcn_readlane(t.i, u + k) + lane];
+#pragma unroll
+        for (int k = 0; k < 8; k++) vv[k] = bcast_f64(t.v, u + k) * xx[k];
+#pragma unroll
+        for (int k = 0; k < 8; k++) acc = acc - vv[k];
+    }
+    for (; u < u1; u++) {
+        const double p = bcast_f64(t.v, u) * X[__builtin_amdgcn_readlane(t.i, u) + lane];
+        acc = acc - p;
+    }
+    return acc;
+}
+
+constexpr int SW_SLOTS = 32;  // 32 slots x 64 lanes = a window of 2048 terms in registers
+
+// One sweep over a tree's rows in sweep order (forward: rows ascending; backward: descending --
+// the backward program is packed in that order, so both sweeps stream their terms front to back).
+// A window of up to 2048 terms is requested with 64 back-to-back coalesced loads and then walked
+// row by row: term u of slot s is broadcast with v_readlane, every lane applies it to its own
+// right-hand side.  Memory latency is paid once per window, not per row or per term.
+template <bool FORWARD>
+__device__ __forceinline__ void sweep(const Tree tr, const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx,
+                                      const double *__restrict__ val, const double *__restrict__ diag, double *X,
+                                      int lane) {
+    const int32_t count = tr.count;
+    if (count == 0) return;
+    const int32_t tbase = ptr[tr.first], tend = ptr[tr.first + count];
+    // row ends and diagonals of 64 sweep positions at a time, handed out by v_readlane
+    int32_t c0 = 0;
+    int32_t pe_v = lane < count ? ptr[tr.first + lane + 1] : 0;
+    double dg_v = lane < count ? diag[tr.first + lane] : 1.0;
+    int32_t sp = 0;
+    int32_t rend = __builtin_amdgcn_readlane(pe_v, 0);
+    double acc = X[(FORWARD ? 0 : count - 1) * 64 + lane];
+#define CSX_FINALIZE_ROW                                                                  \
+    {                                                                                     \
+        X[(FORWARD ? sp : count - 1 - sp) * 64 + lane] = acc / bcast_f64(dg_v, sp - c0);  \
+        sp++;                                                                             \
+        if (sp < count) {                                                                 \
+            if (sp - c0 == 64) {                                                          \
+                c0 = sp;                                                                  \
+                pe_v = c0 + lane < count ? ptr[tr.first + c0 + lane + 1] : 0;             \
+                dg_v = c0 + lane < count ? diag[tr.first + c0 + lane] : 1.0;              \
+            }                                                                             \
+            acc = X[(FORWARD ? sp : count - 1 - sp) * 64 + lane];                         \
+            rend = __builtin_amdgcn_readlane(pe_v, sp - c0);                              \
+        } else {                                                                          \
+            rend = 0x7fffffff;                                                            \
+        }                                                                                 \
+    }
+    for (int32_t w0 = tbase; w0 < tend; w0 += 64 * SW_SLOTS) {
+        TermRegs T[SW_SLOTS];
+#pragma unroll
+        for (int sl = 0; sl < SW_SLOTS; sl++) T[sl] = load_terms(idx, val, w0 + 64 * sl, tend, lane);
+#pragma unroll
+        for (int sl = 0; sl < SW_SLOTS; sl++) {
+            const int32_t s0 = w0 + 64 * sl;
+            const int ulim = min(64, tend - s0);  // <= 0 past the end: nothing to do
+            int u = 0;
+            while (u < ulim) {
+                while (s0 + u == rend) CSX_FINALIZE_ROW
+                const int run = min(ulim, rend - s0);
+                acc = apply_terms(acc, T[sl], u, run, X, lane);
+                u = run;
+            }
+        }
+    }
+    while (sp < count) CSX_FINALIZE_ROW
+#undef CSX_FINALIZE_ROW
+}
+
 __global__ __launch_bounds__(64 * CH_WAVES) void k_cholsol_local(
     const Tree *__restrict__ trees, int32_t ntrees, const int32_t *__restrict__ nodes,
-    const int32_t *__restrict__ local_id, const int32_t *__restrict__ perm, const int32_t *__restrict__ Lp,
-    const int32_t *__restrict__ Li, const double *__restrict__ Lx, const int32_t *__restrict__ Gp,
-    const int32_t *__restrict__ Gi, const double *__restrict__ Gx, double *B, int32_t nrhs, int32_t chunks,
-    int32_t max_nodes, int32_t waves_per_wg) {
+    const int32_t *__restrict__ perm, const int32_t *__restrict__ f_ptr, const int32_t *__restrict__ f_idx,
+    const double *__restrict__ f_val, const int32_t *__restrict__ b_ptr, const int32_t *__restrict__ b_idx,
+    const double *__restrict__ b_val, const double *__restrict__ diagf, const double *__restrict__ diagb, double *B,
+    int32_t nrhs, int32_t chunks, int32_t max_nodes, int32_t waves_per_wg) {
     extern __shared__ __attribute__((aligned(16))) double xt[];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -411,37 +568,41 @@ __global__ __launch_bounds__(64 * CH_WAVES) void k_cholsol_local(
     const int32_t rhs = h * 64 + lane;
     const bool live = rhs < nrhs;
     double *X = xt + (size_t)w * max_nodes * 64;
-    for (int32_t a = 0; a < tr.count; a++) {
-        const int32_t j = nodes[tr.first + a];
-        const int64_t src = (int64_t)(perm ? perm[j] : j) * nrhs + rhs;
-        X[a * 64 + lane] = live ? B[src] : 0.0;
+    // rows of B owned by this tree: ids fetched coalesced (64 at a time), handed out by v_readlane;
+    // eight row loads are kept in flight
+    for (int32_t c0 = 0; c0 < tr.count; c0 += 64) {
+        const int32_t crow = min(64, tr.count - c0);
+        int32_t jrow = 0;
+        if (lane < crow) {
+            jrow = nodes[tr.first + c0 + lane];
+            if (perm) jrow = perm[jrow];
+        }
+        for (int32_t r0 = 0; r0 < crow; r0 += 8) {
+            double tmp[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int32_t row = __builtin_amdgcn_readlane(jrow, min(r0 + u, crow - 1));
+                tmp[u] = live ? B[(int64_t)row * nrhs + rhs] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (r0 + u < crow) X[(c0 + r0 + u) * 64 + lane] = tmp[u];
+        }
     }
     // forward: L y = x, rows ascending, terms in ascending column order (the reference's push order)
-    for (int32_t a = 0; a < tr.count; a++) {
-        const int32_t j = nodes[tr.first + a];
-        double acc = X[a * 64 + lane];
-        const int32_t qe = Gp[j + 1];
-        for (int32_t q = Gp[j]; q < qe; q++) {
-            const double tt = Gx[q] * X[local_id[Gi[q]] * 64 + lane];
-            acc = acc - tt;
-        }
-        X[a * 64 + lane] = acc / Lx[Lp[j]];
-    }
+    sweep<true>(tr, f_ptr, f_idx, f_val, diagf, X, lane);
     // backward: L' z = y, rows descending, the column of L in storage order
-    for (int32_t a = tr.count - 1; a >= 0; a--) {
-        const int32_t j = nodes[tr.first + a];
-        double acc = X[a * 64 + lane];
-        const int32_t pe = Lp[j + 1];
-        for (int32_t p = Lp[j] + 1; p < pe; p++) {
-            const double tt = Lx[p] * X[local_id[Li[p]] * 64 + lane];
-            acc = acc - tt;
+    sweep<false>(tr, b_ptr, b_idx, b_val, diagb, X, lane);
+    for (int32_t c0 = 0; c0 < tr.count; c0 += 64) {
+        const int32_t crow = min(64, tr.count - c0);
+        int32_t jrow = 0;
+        if (lane < crow) {
+            jrow = nodes[tr.first + c0 + lane];
+            if (perm) jrow = perm[jrow];
         }
-        X[a * 64 + lane] = acc / Lx[Lp[j]];
-    }
-    if (live) {
-        for (int32_t a = 0; a < tr.count; a++) {
-            const int32_t j = nodes[tr.first + a];
-            B[(int64_t)(perm ? perm[j] : j) * nrhs + rhs] = X[a * 64 + lane];
+        for (int32_t r = 0; r < crow; r++) {
+            const int32_t row = __builtin_amdgcn_readlane(jrow, r);
+            if (live) B[(int64_t)row * nrhs + rhs] = X[(c0 + r) * 64 + lane];
         }
     }
 }
@@ -500,6 +661,36 @@ static int cholsol_plan(const Csc *L, const int32_t *pinv, CholPlan **out) {
     CSX_TRY(upload(&P->trees, F.small));
     CSX_TRY(upload(&P->tree_nodes, F.small_cols));
     CSX_TRY(upload(&P->local_id, local));
+    std::vector<int32_t> rev((size_t)n, 0);
+    for (const Tree &t : F.small)
+        for (int32_t a = 0; a < t.count; a++) rev[(size_t)(t.first + a)] = t.first + t.count - 1 - a;
+    CSX_TRY(upload(&P->rev_pos, rev));
+    const int32_t *Gp, *Gi;
+    const double *Gx, *Gd;
+    tri_gather_arrays(P->fwd, &Gp, &Gi, &Gx, &Gd);
+    int32_t *flen = nullptr, *blen = nullptr;
+    CSX_TRY(dalloc(&flen, (size_t)n + 1));
+    CSX_TRY(dalloc(&blen, (size_t)n + 1));
+    CSX_TRY(dalloc(&P->f_ptr, (size_t)n + 1));
+    CSX_TRY(dalloc(&P->b_ptr, (size_t)n + 1));
+    CSX_TRY(dalloc(&P->diagk, (size_t)n));
+    CSX_TRY(dalloc(&P->diagb, (size_t)n));
+    const unsigned nb = (unsigned)(((int64_t)n + 255) / 256);
+    hipLaunchKernelGGL(k_pack_len, dim3(nb), dim3(256), 0, s, n, P->tree_nodes, P->rev_pos, Gp, L->p, flen, blen);
+    int64_t ftot = 0, btot = 0;
+    int st = scan_exclusive_i32(flen, P->f_ptr, n, &ftot);
+    if (st == CSX_OK) st = scan_exclusive_i32(blen, P->b_ptr, n, &btot);
+    dfree(flen);
+    dfree(blen);
+    CSX_TRY(st);
+    CSX_TRY(dalloc(&P->f_idx, (size_t)ftot + 8));
+    CSX_TRY(dalloc(&P->f_val, (size_t)ftot + 8));
+    CSX_TRY(dalloc(&P->b_idx, (size_t)btot + 8));
+    CSX_TRY(dalloc(&P->b_val, (size_t)btot + 8));
+    hipLaunchKernelGGL(k_pack_fill, dim3((unsigned)(((int64_t)n + 3) / 4)), dim3(256), 0, s, n, P->tree_nodes,
+                       P->rev_pos, P->local_id, Gp, Gi, Gx, L->p, L->i, L->x, P->f_ptr, P->f_idx, P->f_val, P->b_ptr,
+                       P->b_idx, P->b_val, P->diagk, P->diagb);
+    CSX_LAUNCH_CHECK();
     CSX_HIP(hipStreamSynchronize(s));
     P->ntrees = (int32_t)F.small.size();
     P->max_nodes = F.max_tree;
@@ -529,8 +720,8 @@ static int cholsol_solve(CholPlan *P, double *B, int32_t nrhs) {
         CSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cholsol_local),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
         hipLaunchKernelGGL(k_cholsol_local, dim3((unsigned)((tasks + waves - 1) / waves)), dim3(64 * CH_WAVES), lds, s,
-                           P->trees, P->ntrees, P->tree_nodes, P->local_id, P->perm, P->L->p, P->L->i, P->L->x, Gp, Gi,
-                           Gx, B, nrhs, chunks, P->max_nodes, waves);
+                           P->trees, P->ntrees, P->tree_nodes, P->perm, P->f_ptr, P->f_idx, P->f_val, P->b_ptr, P->b_idx,
+                           P->b_val, P->diagk, P->diagb, B, nrhs, chunks, P->max_nodes, waves);
         CSX_LAUNCH_CHECK();
         return CSX_OK;
     }

@@ -39,20 +39,48 @@ __global__ __launch_bounds__(256) void k_gaxpy_exact(int32_t rows, const int32_t
 }
 #pragma clang fp contract(fast)
 
-template <int G>
+// G lanes per row, U rows per group and step: the first G entries of the U rows are requested
+// back to back (U x 3 independent loads in flight per lane) before anything is consumed.
+template <int G, int U>
 __global__ __launch_bounds__(256) void k_gaxpy_rows(int32_t rows, const int32_t *__restrict__ ptr,
                                                     const int32_t *__restrict__ idx, const double *__restrict__ val,
                                                     const double *__restrict__ x, double *__restrict__ y) {
     const int sub = threadIdx.x & (G - 1);
-    int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) / G;
-    for (int64_t r = group; r < rows; r += ngroups) {
-        const int32_t b = ptr[r], e = ptr[r + 1];
-        double acc = 0.0;
-        for (int32_t q = b + sub; q < e; q += G) acc = fma(val[q], x[idx[q]], acc);
+    for (int64_t r0 = group * U; r0 < rows; r0 += ngroups * U) {
+        int32_t b[U], e[U], c[U];
+        double v[U], acc[U];
 #pragma unroll
-        for (int d = G >> 1; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
-        if (sub == 0 && e > b) y[r] += acc;
+        for (int u = 0; u < U; u++) {
+            const int64_t r = r0 + u < rows ? r0 + u : rows - 1;
+            b[u] = ptr[r];
+            e[u] = r0 + u < rows ? ptr[r + 1] : b[u];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int32_t q = b[u] + sub;
+            const bool in = q < e[u];
+            c[u] = in ? idx[q] : 0;
+            v[u] = in ? val[q] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const double xv = x[c[u]];
+            acc[u] = b[u] + sub < e[u] ? v[u] * xv : 0.0;  // lanes past the row end contribute nothing
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            for (int32_t q = b[u] + G + sub; q < e[u]; q += G) acc[u] = fma(val[q], x[idx[q]], acc[u]);
+#pragma unroll
+            for (int d = G >> 1; d > 0; d >>= 1) acc[u] += __shfl_xor(acc[u], d, 64);
+        }
+        if (sub < U && r0 + sub < rows) {
+            double a = acc[0];
+#pragma unroll
+            for (int u = 1; u < U; u++) a = sub == u ? acc[u] : a;
+            if (e[0] > b[0] || U > 1) y[r0 + sub] += a;
+        }
     }
 }
 
@@ -74,12 +102,12 @@ static int run_rows(const Gather *g, int64_t nnz, const double *x, double *y) {
     if (g->rows == 0) return CSX_OK;
     const double avg = (double)nnz / (double)g->rows;
     const int64_t cap = (int64_t)ctx().cus * 32;  // workgroups of 256: 8 per CU x 4 rounds
-#define CSX_ROWS(G)                                                                                     \
-    {                                                                                                   \
-        int64_t blocks = ((int64_t)g->rows * G + 255) / 256;                                            \
-        if (blocks > cap) blocks = cap;                                                                 \
-        hipLaunchKernelGGL(k_gaxpy_rows<G>, dim3((unsigned)blocks), dim3(256), 0, s, g->rows, g->ptr, g->idx, \
-                           g->val, x, y);                                                               \
+#define CSX_ROWS(G)                                                                                       \
+    {                                                                                                     \
+        int64_t blocks = (((int64_t)g->rows + 3) / 4 * G + 255) / 256;                                    \
+        if (blocks > cap) blocks = cap;                                                                   \
+        hipLaunchKernelGGL((k_gaxpy_rows<G, 4>), dim3((unsigned)blocks), dim3(256), 0, s, g->rows, g->ptr, \
+                           g->idx, g->val, x, y);                                                         \
     }
     if (avg > 48) CSX_ROWS(64)
     else if (avg > 24) CSX_ROWS(32)

@@ -104,7 +104,8 @@ __device__ __forceinline__ GroupRegs load_group(const uint32_t *__restrict__ key
 }
 
 // VARIANT bits (timing experiments only; results are wrong unless VARIANT == 0):
-//   1 = skip the x gather, 2 = skip the LDS accumulation
+//   1 = skip the x gather, 2 = skip the LDS accumulation, 4 = gather from a 2 KB footprint (L1 hits),
+//   5 = gather from a 256 KB footprint (L2 hits, L1 misses)
 template <int VARIANT>
 __global__ __launch_bounds__(TL_THREADS) void k_gaxpy_tiled(const int32_t *__restrict__ rb_gptr,
                                                             const uint32_t *__restrict__ group_info,
@@ -114,7 +115,8 @@ __global__ __launch_bounds__(TL_THREADS) void k_gaxpy_tiled(const int32_t *__res
                                                             int32_t m, int32_t nrb, int32_t row_block,
                                                             int32_t slab_cols, int rb_bits) {
     extern __shared__ __attribute__((aligned(16))) double ytile[];  // row_block doubles
-    constexpr bool GATHER = !(VARIANT & 1), ATOMIC = !(VARIANT & 2);
+    constexpr bool GATHER = !(VARIANT & 1) || VARIANT == 5, ATOMIC = !(VARIANT & 2);
+    constexpr uint32_t CMASK = VARIANT == 5 ? 32767u : ((VARIANT & 4) ? 255u : 0xffffffffu);
     const uint32_t rmask = (1u << rb_bits) - 1u;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double sink = 0.0;
@@ -124,37 +126,53 @@ __global__ __launch_bounds__(TL_THREADS) void k_gaxpy_tiled(const int32_t *__res
         for (int k = threadIdx.x; k < rows; k += TL_THREADS) ytile[k] = y[row0 + k];
         __syncthreads();
         const int32_t gend = rb_gptr[rb + 1];
+        // Each wave walks its groups two at a time (g and g + TL_WAVES): 8 gathers and the next
+        // pair's 6 stream loads are in flight per lane.
         int32_t g = rb_gptr[rb] + wave;
-        GroupRegs cur;
-        if (g < gend) cur = load_group(tile_key, tile_val, group_info, g, lane);
+        GroupRegs ca, cb;
+        if (g < gend) ca = load_group(tile_key, tile_val, group_info, g, lane);
+        if (g + TL_WAVES < gend) cb = load_group(tile_key, tile_val, group_info, g + TL_WAVES, lane);
+#define CSX_GATHER(c, xa, xb, xc, xd, xs)                    \
+    if (GATHER) {                                            \
+        xa = xs[(c.kk.x >> rb_bits) & CMASK];                \
+        xb = xs[(c.kk.y >> rb_bits) & CMASK];                \
+        xc = xs[(c.kk.z >> rb_bits) & CMASK];                \
+        xd = xs[(c.kk.w >> rb_bits) & CMASK];                \
+    }
+#define CSX_ACCUM(c, xa, xb, xc, xd)                                                                    \
+    {                                                                                                   \
+        const uint32_t cnt = c.info & 511u;                                                             \
+        if (ATOMIC) {                                                                                   \
+            if ((uint32_t)lane < cnt) unsafeAtomicAdd(&ytile[c.kk.x & rmask], c.v0.x * xa);             \
+            if ((uint32_t)(64 + lane) < cnt) unsafeAtomicAdd(&ytile[c.kk.y & rmask], c.v0.y * xb);      \
+            if ((uint32_t)(128 + lane) < cnt) unsafeAtomicAdd(&ytile[c.kk.z & rmask], c.v1.x * xc);     \
+            if ((uint32_t)(192 + lane) < cnt) unsafeAtomicAdd(&ytile[c.kk.w & rmask], c.v1.y * xd);     \
+        } else {                                                                                        \
+            sink += c.v0.x * xa + c.v0.y * xb + c.v1.x * xc + c.v1.y * xd +                             \
+                    (double)((c.kk.x ^ c.kk.y ^ c.kk.z ^ c.kk.w) & 1u);                                 \
+        }                                                                                               \
+    }
         while (g < gend) {
-            const int32_t gn = g + TL_WAVES;
-            const uint32_t cnt = cur.info & 511u;
-            const double *xs = x + (int64_t)(cur.info >> 9) * slab_cols;
-            // entry index inside the group of component k is k*64 + lane
-            const bool ok0 = (uint32_t)lane < cnt, ok1 = (uint32_t)(64 + lane) < cnt;
-            const bool ok2 = (uint32_t)(128 + lane) < cnt, ok3 = (uint32_t)(192 + lane) < cnt;
-            double x0 = 1.0, x1 = 1.0, x2 = 1.0, x3 = 1.0;
-            if (GATHER) {  // padding slots carry key 0: a valid address, result unused
-                x0 = xs[cur.kk.x >> rb_bits];
-                x1 = xs[cur.kk.y >> rb_bits];
-                x2 = xs[cur.kk.z >> rb_bits];
-                x3 = xs[cur.kk.w >> rb_bits];
+            const bool two = g + TL_WAVES < gend;
+            const int32_t gn = g + 2 * TL_WAVES;
+            const double *xsa = x + (int64_t)(ca.info >> 9) * slab_cols;
+            double a0 = 1.0, a1 = 1.0, a2 = 1.0, a3 = 1.0, b0 = 1.0, b1 = 1.0, b2 = 1.0, b3 = 1.0;
+            CSX_GATHER(ca, a0, a1, a2, a3, xsa)  // padding slots carry key 0: a valid address, result unused
+            if (two) {
+                const double *xsb = x + (int64_t)(cb.info >> 9) * slab_cols;
+                CSX_GATHER(cb, b0, b1, b2, b3, xsb)
             }
-            GroupRegs nxt = cur;
-            if (gn < gend) nxt = load_group(tile_key, tile_val, group_info, gn, lane);  // behind the gathers
-            if (ATOMIC) {
-                if (ok0) unsafeAtomicAdd(&ytile[cur.kk.x & rmask], cur.v0.x * x0);
-                if (ok1) unsafeAtomicAdd(&ytile[cur.kk.y & rmask], cur.v0.y * x1);
-                if (ok2) unsafeAtomicAdd(&ytile[cur.kk.z & rmask], cur.v1.x * x2);
-                if (ok3) unsafeAtomicAdd(&ytile[cur.kk.w & rmask], cur.v1.y * x3);
-            } else {
-                sink += cur.v0.x * x0 + cur.v0.y * x1 + cur.v1.x * x2 + cur.v1.y * x3 +
-                        (double)((cur.kk.x ^ cur.kk.y ^ cur.kk.z ^ cur.kk.w) & 1u);
-            }
+            GroupRegs na = ca, nb = cb;
+            if (gn < gend) na = load_group(tile_key, tile_val, group_info, gn, lane);  // behind the gathers
+            if (gn + TL_WAVES < gend) nb = load_group(tile_key, tile_val, group_info, gn + TL_WAVES, lane);
+            CSX_ACCUM(ca, a0, a1, a2, a3)
+            if (two) CSX_ACCUM(cb, b0, b1, b2, b3)
             g = gn;
-            cur = nxt;
+            ca = na;
+            cb = nb;
         }
+#undef CSX_GATHER
+#undef CSX_ACCUM
         __syncthreads();
         if (!ATOMIC && sink == 12345.678) ytile[0] = sink;  // keep the ablated arithmetic alive
         for (int k = threadIdx.x; k < rows; k += TL_THREADS) y[row0 + k] = ytile[k];
@@ -267,7 +285,7 @@ int gaxpy_tiled_run(const Csc *A, const double *x, double *y) {
     hipStream_t s = ctx().stream;
     const size_t lds = (((size_t)t->row_block * sizeof(double)) + 15) & ~(size_t)15;
     int variant = 0;
-    if (const char *e = std::getenv("CSX_TILED_VARIANT")) variant = std::atoi(e) & 3;
+    if (const char *e = std::getenv("CSX_TILED_VARIANT")) variant = std::atoi(e) & 7;
     const int32_t nwg = ctx().cus > 0 ? ctx().cus : 256;
     const unsigned grid = (unsigned)(t->nrb < nwg ? t->nrb : nwg);
 #define CSX_TILED_LAUNCH(V)                                                                                          \
@@ -283,6 +301,9 @@ int gaxpy_tiled_run(const Csc *A, const double *x, double *y) {
         CSX_TILED_LAUNCH(1)
         CSX_TILED_LAUNCH(2)
         CSX_TILED_LAUNCH(3)
+        CSX_TILED_LAUNCH(4)
+        CSX_TILED_LAUNCH(5)
+        default: return CSX_EINVAL;
     }
 #undef CSX_TILED_LAUNCH
     CSX_LAUNCH_CHECK();

@@ -39,6 +39,8 @@ struct TriPlan {
     int kind = 0;
     int32_t n = 0, nlevels = 0;
     bool sequential = false, zero_pivot = false;
+    bool scheduled = false, forward = true;  // level sets are computed on first use
+    int32_t gnnz = 0;
     bool owns_g = false;
     int skip_first = 0, skip_last = 0;
     int32_t *ptr = nullptr, *idx = nullptr;
@@ -285,7 +287,6 @@ static int analyse(const Csc *T, int kind, TriPlan **out) {
     }
     CSX_TRY(dalloc(&P->diag, (size_t)n));
     const bool forward = (kind == CSX_TRI_L || kind == CSX_TRI_UT);
-    std::vector<int32_t> hptr, hidx;
     if (kind == CSX_TRI_LT || kind == CSX_TRI_UT) {
         P->ptr = T->p;
         P->idx = T->i;
@@ -336,11 +337,23 @@ static int analyse(const Csc *T, int kind, TriPlan **out) {
     CSX_HIP(hipStreamSynchronize(s));
     dfree(flag);
     P->zero_pivot = hflag[1] != 0;
-    const int32_t gnnz = (kind == CSX_TRI_LT || kind == CSX_TRI_UT) ? T->nnz : T->nnz - n;
+    P->gnnz = (kind == CSX_TRI_LT || kind == CSX_TRI_UT) ? T->nnz : T->nnz - n;
+    P->forward = forward;
+    return CSX_OK;
+}
+
+// Level sets (host, O(nnz)): deferred until a level-scheduled solve needs them, so plans that
+// only feed the fused in-LDS cholsol kernel never pay for the download.
+static int ensure_schedule(TriPlan *P) {
+    if (P->scheduled || P->n == 0) return CSX_OK;
+    hipStream_t s = ctx().stream;
+    const int32_t n = P->n;
+    std::vector<int32_t> hptr, hidx;
     CSX_TRY(download_i32(hptr, P->ptr, (size_t)n + 1));
-    CSX_TRY(download_i32(hidx, P->idx, (size_t)gnnz));
+    CSX_TRY(download_i32(hidx, P->idx, (size_t)P->gnnz));
     std::vector<int32_t> level;
-    if (!compute_levels(n, hptr, hidx, P->skip_first, P->skip_last, forward, level, P->nlevels)) {
+    P->scheduled = true;
+    if (!compute_levels(n, hptr, hidx, P->skip_first, P->skip_last, P->forward, level, P->nlevels)) {
         P->sequential = true;
         P->nlevels = n;
         return CSX_OK;
@@ -381,6 +394,7 @@ int tri_solve_raw(TriPlan *P, double *X, int32_t nrhs) {
     hipStream_t s = ctx().stream;
     if (P->zero_pivot) return CSX_EZEROPIVOT;
     if (P->n == 0 || nrhs == 0) return CSX_OK;
+    CSX_TRY(ensure_schedule(P));
     if (P->sequential) {
         hipLaunchKernelGGL(k_tri_sequential, dim3((unsigned)((nrhs + 63) / 64)), dim3(64), 0, s, P->kind, P->n, P->Tp,
                            P->Ti, P->Tx, X, nrhs);
@@ -435,6 +449,7 @@ extern "C" int csx_tri_analyse(csx_handle_t hT, int kind, csx_handle_t *out) {
 extern "C" int csx_tri_info(csx_handle_t h, int32_t *n, int32_t *levels, int32_t *sequential) {
     TriPlan *P = (TriPlan *)get(h, K_TRIPLAN);
     if (!P) return CSX_EINVAL;
+    CSX_TRY(ensure_schedule(P));
     if (n) *n = P->n;
     if (levels) *levels = P->nlevels;
     if (sequential) *sequential = P->sequential ? 1 : 0;

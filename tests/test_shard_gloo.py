@@ -1,0 +1,98 @@
+"""The N > 1 path on CPU: two gloo ranks shard a batched cs_cholsol the way bench.py shards
+it across GPUs (one block of right-hand sides per rank, no data-path collective), with the
+oracle standing in for the device solver.  Checks the partition, the control collectives and
+that gathering the blocks reproduces the serial answer."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+from conftest import ROOT
+
+WORKER = textwrap.dedent("""
+    import os, sys, json
+    import numpy as np
+    sys.path[:0] = [os.path.join(r"{root}", "csparse.py_amd"), os.path.join(r"{root}", "oracle"),
+                    os.path.join(r"{root}", "tests")]
+    import shard, synth
+    import c_oracle as CO
+    comm = shard.Comm(backend="gloo")
+    assert comm.world == 2
+    nblocks, bs, per_rank = 6, 8, 3
+    n = nblocks * bs
+    Ap, Ai, Ax = synth.gspd(nblocks, bs, 5)              # every rank factors the same matrix
+    parent, cp = CO.schol(n, Ap, Ai)
+    Lp, Li, Lx = CO.chol(n, Ap, Ai, Ax, parent, cp)
+    col0, k = shard.weak_block(comm.rank, per_rank)
+    B = synth.rhs(n, k, col0)                             # this rank's block of the global RHS
+    X = np.stack([CO.ltsolve(n, Lp, Li, Lx, CO.lsolve(n, Lp, Li, Lx, B[:, r])) for r in range(k)], axis=1)
+    comm.barrier()
+    t = comm.max(1.0 + comm.rank)                         # slowest rank's time
+    total = comm.sum(k)
+    choice = comm.broadcast_object("tiled" if comm.rank == 0 else "wave")
+    full = comm.gather_blocks(X)
+    out = dict(rank=comm.rank, tmax=t, total=total, choice=choice, col0=col0,
+               strong=[shard.strong_block(r, 3, 10) for r in range(3)])
+    if comm.rank == 0:
+        out["full"] = np.asarray(full).tolist()
+    print("RESULT " + json.dumps(out))
+    comm.close()
+""")
+
+
+def test_two_rank_sharded_cholsol(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29653", WORLD_SIZE="2")
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=e, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=240) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+    import json
+    res = {}
+    for so, _ in outs:
+        line = [l for l in so.splitlines() if l.startswith("RESULT ")][0]
+        d = json.loads(line[7:])
+        res[d["rank"]] = d
+    assert res[0]["tmax"] == res[1]["tmax"] == 2.0
+    assert res[0]["total"] == res[1]["total"] == 6.0
+    assert res[0]["choice"] == res[1]["choice"] == "tiled"
+    assert (res[0]["col0"], res[1]["col0"]) == (0, 3)
+    assert res[0]["strong"] == [[0, 4], [4, 3], [7, 3]]
+    # the gathered block equals the serial solve of all six right-hand sides
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import c_oracle as CO
+    import synth
+    n = 48
+    Ap, Ai, Ax = synth.gspd(6, 8, 5)
+    parent, cp = CO.schol(n, Ap, Ai)
+    Lp, Li, Lx = CO.chol(n, Ap, Ai, Ax, parent, cp)
+    B = synth.rhs(n, 6, 0)
+    ref = np.stack([CO.ltsolve(n, Lp, Li, Lx, CO.lsolve(n, Lp, Li, Lx, B[:, r])) for r in range(6)], axis=1)
+    assert np.asarray(res[0]["full"]).tobytes() == ref.tobytes()
+
+
+def test_single_rank_comm_is_a_noop():
+    sys.path.insert(0, os.path.join(ROOT, "csparse.py_amd"))
+    import shard
+    old = {k: os.environ.pop(k, None) for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    try:
+        c = shard.Comm()
+        assert (c.rank, c.world) == (0, 1) and c.dist is None
+        assert c.max(3.5) == 3.5 and c.sum(2) == 2.0 and c.broadcast_object("x") == "x"
+        c.barrier()
+        blk = np.ones((2, 2))
+        assert c.gather_blocks(blk) is blk
+        c.close()
+    finally:
+        for k, v in old.items():
+            if v is not None:
+                os.environ[k] = v
+    assert shard.weak_block(3, 128) == (384, 128)
+    assert [shard.strong_block(r, 8, 1024) for r in (0, 7)] == [(0, 128), (896, 128)]
