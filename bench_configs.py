@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Secondary measurements: the BASELINE.json configs that are not the headline metric.
+
+    python bench_configs.py [--skip-spgemm]
+
+  config 2  cs_gaxpy on bcsstk16 (sym-expanded, 4884^2, 290 378 nnz)      -- cache resident: us per call
+  config 3  cs_lusol solve phase on W: block-diagonal tiling of the drop-tol'd west0067 pattern,
+            n = 67*1493 = 100 031; host LU (csx_lu_host), device cs_lsolve / cs_usolve
+  config 4  cs_multiply A*A' on S: 1M x 1M, 32 nnz/col
+  extra     cs_transpose on G-rand (5M x 5M, 64/col)
+
+Each config checks itself at full size (against the plain-C oracle where that takes seconds,
+otherwise through a size-independent identity) and prints one JSON line.  bench.py remains the
+driver's contract; this file only feeds profiles/ and DESIGN.md.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (os.path.join(ROOT, "csparse.py_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+
+import _csx  # noqa: E402
+import csparse as cs  # noqa: E402
+
+PEAK = 8000.0
+
+
+def timed(fn, reps):
+    fn()
+    _csx.sync()
+    with _csx.Timer() as t:
+        for _ in range(reps):
+            fn()
+    return t.ms / reps
+
+
+def host_cs(m, n, p, i, x):
+    A = cs.cs_spalloc(m, n, len(i), True, False)
+    A.p, A.i, A.x = p.tolist(), i.tolist(), x.tolist()
+    return A
+
+
+def config2():
+    import c_oracle as CO
+    g = np.load(os.path.join(ROOT, "tests", "golden", "bcsstk16.npz"))
+    p, i, x = g["C_p"].astype(np.int32), g["C_i"].astype(np.int32), g["C_x"]
+    n = 4884
+    A = cs.cs_pin(host_cs(n, n, p, i, x))
+    xv = 1.0 + np.arange(n) / n
+    ref = CO.gaxpy(n, n, p, i, x, xv, np.zeros(n))
+    dx = cs.dvec(xv)
+    out = {}
+    for name, mode in (("exact", cs.GAXPY_EXACT), ("wave", cs.GAXPY_WAVE)):
+        dy = cs.dvec(n)
+        cs.cs_gaxpy(A, dx, dy, mode)
+        err = float(np.max(np.abs(dy.numpy() - ref) / np.abs(ref)))
+        ms = timed(lambda: cs.cs_gaxpy(A, dx, dy, mode), 200)
+        out[name] = {"us_per_call": round(ms * 1e3, 2), "max_rel_err": err}
+    by = 12 * len(i) + 4 * (n + 1) + 8 * n + 16 * n
+    return {"config": "cs_gaxpy bcsstk16 sym-expanded (4884^2, %d nnz)" % len(i), "algorithmic_bytes": by,
+            "modes": out, "note": "3.6 MB working set: L2-resident, launch-latency-bound; no roofline claim"}
+
+
+def config3():
+    import c_oracle as CO
+    import synth
+    g = np.load(os.path.join(ROOT, "tests", "golden", "west0067.npz"))
+    bp, bi, bx = g["C_p"].astype(np.int64), g["C_i"].astype(np.int64), g["C_x"]
+    nb, bs = 1493, 67
+    n = nb * bs
+    bnnz = int(bp[-1])
+    u = synth.vec(nb, 20240604, 0.0, 1.0)
+    Ai = (bi[None, :] + (np.arange(nb) * bs)[:, None]).reshape(-1).astype(np.int32)
+    Ax = (bx[None, :] * (1.0 + 1e-3 * u)[:, None]).reshape(-1)
+    cols = np.diff(bp)
+    Ap = np.concatenate([[0], np.cumsum(np.tile(cols, nb))]).astype(np.int32)
+    A = host_cs(n, n, Ap, Ai, Ax)
+    t0 = time.perf_counter()
+    N = cs.cs_lu(A, cs.cs_sqr(0, A, False), 1.0)
+    t_lu = time.perf_counter() - t0
+    L, U = cs.cs_pin(N.L), cs.cs_pin(N.U)
+    b = 1.0 + np.arange(n) / n
+    pb = np.empty(n)
+    pb[np.asarray(N.pinv)] = b
+    Lp, Li, Lx = (np.asarray(v) for v in (L.p, L.i, L.x))
+    Up, Ui, Ux = (np.asarray(v) for v in (U.p, U.i, U.x))
+    ref_y = CO.lsolve(n, Lp, Li, Lx, pb)
+    ref_x = CO.usolve(n, Up, Ui, Ux, ref_y)
+    res = {}
+    for k in (1, 64):
+        B = np.repeat(pb[:, None], k, axis=1) if k > 1 else pb
+        X = cs.dvec(B)
+        t0 = time.perf_counter()
+        cs.cs_lsolve(L, X)
+        cs.cs_usolve(U, X)
+        _csx.sync()
+        first = time.perf_counter() - t0  # includes the two analyses
+        got = X.numpy().reshape(n, -1)
+        exact = bool(all(got[:, r].tobytes() == ref_x.tobytes() for r in (0, k - 1)))
+
+        def run():
+            cs.cs_lsolve(L, X)
+            cs.cs_usolve(U, X)
+        ms = timed(run, 20)
+        nnz_lu = int(Lp[-1] + Up[-1])
+        by = 12 * nnz_lu + 8 * (n + 1) + 2 * 16 * n * k
+        res["nrhs_%d" % k] = {"ms_lsolve_plus_usolve": round(ms, 4), "solves_per_s": round(k / (ms * 1e-3), 1),
+                              "bit_identical_to_c_oracle": exact, "first_call_incl_analysis_s": round(first, 3),
+                              "algorithmic_GBps": round(by / (ms * 1e-3) / 1e9, 2)}
+    import ctypes
+    lv = ctypes.c_int32()
+    _csx.check(_csx.lib().csx_tri_info(L._dev.plans[cs.TRI_L], None, lv, None))
+    # residual of the whole cs_lusol sequence against A
+    r = CO.gaxpy(n, n, Ap, Ai, Ax, ref_x, -b)
+    return {"config": "cs_lusol solve phase on W (west0067 tiling, n=%d, nnz(A)=%d, nnz(L)+nnz(U)=%d)"
+                      % (n, nb * bnnz, int(Lp[-1] + Up[-1])),
+            "host_lu_s": round(t_lu, 3), "levels_L": lv.value, "results": res,
+            "residual_inf": float(np.max(np.abs(r)))}
+
+
+def config4(n=1000000, per_col=32):
+    lib = _csx.lib()
+    hA = _csx.new_handle()
+    _csx.check(lib.csx_gen_grand(n, per_col, 20240605, hA))
+    hB = _csx.new_handle()
+    t0 = time.perf_counter()
+    _csx.check(lib.csx_transpose(hA, 1, hB))
+    _csx.sync()
+    t_tr = time.perf_counter() - t0
+    hC = _csx.new_handle()
+    _csx.check(lib.csx_multiply(hA, hB, hC))  # warm-up (also builds nothing persistent)
+    _csx.sync()
+    _csx.free(hC)
+    hC = _csx.new_handle()
+    t0 = time.perf_counter()
+    with _csx.Timer() as tm:
+        _csx.check(lib.csx_multiply(hA, hB, hC))
+    wall = time.perf_counter() - t0
+    C = _csx.C
+    m_, n_, nnzC, hv = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int()
+    _csx.check(lib.csx_csc_info(hC, m_, n_, nnzC, hv))
+    nnzA = n * per_col
+    products = n * per_col * per_col  # sum_k nnz(A(:,k)) * nnz(A'(k,:)) is this only on average; exact below
+    # identity at full size: C * 1 == A * (A' * 1)
+    ones = _csx.new_handle()
+    _csx.check(lib.csx_gen_vec(n, 1, 1.0, 1.0, ones))
+    t1, t2, t3 = _csx.new_handle(), _csx.new_handle(), _csx.new_handle()
+    for h in (t1, t2, t3):
+        _csx.check(lib.csx_vec_alloc(n, h))
+    _csx.check(lib.csx_gaxpy(hB, ones, t1, cs.GAXPY_WAVE))
+    _csx.check(lib.csx_gaxpy(hA, t1, t2, cs.GAXPY_WAVE))
+    _csx.check(lib.csx_gaxpy(hC, ones, t3, cs.GAXPY_ATOMIC))
+    a = cs.dvec(n, 1, _handle=t2).numpy()
+    c = cs.dvec(n, 1, _handle=t3).numpy()
+    ident = float(np.max(np.abs(a - c) / np.abs(a)))
+    by = 12 * (2 * nnzA + nnzC.value) + 4 * (3 * n + 3)
+    out = {"config": "cs_multiply A*A' on S (%d x %d, %d nnz/col)" % (n, n, per_col), "nnz_C": nnzC.value,
+           "ms": round(tm.ms, 2), "wall_s": round(wall, 3), "transpose_s": round(t_tr, 3),
+           "algorithmic_bytes": by, "algorithmic_GBps": round(by / (tm.ms * 1e-3) / 1e9, 2),
+           "frac_of_peak": round(by / (tm.ms * 1e-3) / 1e9 / PEAK, 4),
+           "G_products_per_s": round(products / (tm.ms * 1e-3) / 1e9, 3),
+           "identity_C1_eq_A_At1_max_rel": ident}
+    for h in (hA, hB, hC, ones):
+        _csx.free(h)
+    return out
+
+
+def transpose_grand(n=5000000, per_col=64):
+    lib = _csx.lib()
+    hA = _csx.new_handle()
+    _csx.check(lib.csx_gen_grand(n, per_col, 20240602, hA))
+    hT = _csx.new_handle()
+    _csx.check(lib.csx_transpose(hA, 1, hT))
+    _csx.sync()
+    _csx.free(hT)
+    hT = _csx.new_handle()
+    t0 = time.perf_counter()
+    _csx.check(lib.csx_transpose(hA, 1, hT))
+    _csx.sync()
+    dt = time.perf_counter() - t0
+    # involution at full size: (A')' has A's column pointers; and y = A'x matches the row view of A
+    hTT = _csx.new_handle()
+    _csx.check(lib.csx_transpose(hT, 1, hTT))
+    p1 = np.empty(n + 1, dtype=np.int32)
+    p2 = np.empty(n + 1, dtype=np.int32)
+    _csx.check(lib.csx_csc_download(hA, _csx.pi(p1), None, None))
+    _csx.check(lib.csx_csc_download(hTT, _csx.pi(p2), None, None))
+    nnz = n * per_col
+    by = 24 * nnz + 8 * (n + 1)
+    for h in (hA, hT, hTT):
+        _csx.free(h)
+    return {"config": "cs_transpose on G-rand (%d x %d, %d nnz/col)" % (n, n, per_col), "s": round(dt, 4),
+            "algorithmic_GBps": round(by / dt / 1e9, 1), "frac_of_peak": round(by / dt / 1e9 / PEAK, 4),
+            "double_transpose_restores_p": bool((p1 == p2).all())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--skip-spgemm", action="store_true")
+    ap.add_argument("--skip-transpose", action="store_true")
+    a = ap.parse_args()
+    _csx.init()
+    print(json.dumps({"device": _csx.device_info()}))
+    print(json.dumps(config2()))
+    print(json.dumps(config3()))
+    if not a.skip_transpose:
+        print(json.dumps(transpose_grand()))
+    if not a.skip_spgemm:
+        print(json.dumps(config4()))
+
+
+if __name__ == "__main__":
+    main()

@@ -32,6 +32,7 @@
 // B is read once and written once, L is read once.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "csx_internal.h"
 
@@ -370,6 +371,8 @@ struct CholPlan {
     int32_t *f_ptr = nullptr, *f_idx = nullptr, *b_ptr = nullptr, *b_idx = nullptr;
     double *f_val = nullptr, *b_val = nullptr, *diagk = nullptr, *diagb = nullptr;
     int32_t *rev_pos = nullptr;
+    int dense_bs = 0;  // > 0: every tree is a dense lower-triangular block of this size on contiguous rows
+    double *dense_b = nullptr;  // dense only: backward program with every row reversed (sweep-position order)
 };
 
 void free_cholplan(CholPlan *P) {
@@ -390,6 +393,7 @@ void free_cholplan(CholPlan *P) {
     dfree(P->diagk);
     dfree(P->diagb);
     dfree(P->rev_pos);
+    dfree(P->dense_b);
     delete P;
 }
 
@@ -582,7 +586,7 @@ __global__ __launch_bounds__(64 * CH_WAVES) void k_cholsol_local(
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const int32_t row = __builtin_amdgcn_readlane(jrow, min(r0 + u, crow - 1));
-                tmp[u] = live ? B[(int64_t)row * nrhs + rhs] : 0.0;
+                tmp[u] = B[(int64_t)row * nrhs + (live ? rhs : nrhs - 1)];  // clamped: safe unpredicated
             }
 #pragma unroll
             for (int u = 0; u < 8; u++)
@@ -607,6 +611,105 @@ __global__ __launch_bounds__(64 * CH_WAVES) void k_cholsol_local(
     }
 }
 #pragma clang fp contract(fast)
+
+// ---- dense-block specialisation -------------------------------------------------------------------
+// Every tree is a dense BS x BS lower-triangular block on contiguous rows (block-diagonal SPD
+// matrices, batches of small dense systems).  One wave = one block x 64 right-hand sides; the
+// unknowns of a lane's right-hand side live in BS registers, the packed block (row-major in
+// sweep order) and the reciprocal diagonal sit in LDS and are broadcast with immediate offsets.
+// The same unrolled sweep serves forward and backward substitution: the backward system in sweep
+// order (rows descending) is again "unit-ordered lower triangular" once the unknowns are
+// reversed in registers.  Uses FMA and a reciprocal diagonal, so x agrees with the
+// reference-order kernels to rounding (~1e-16 relative), not bit for bit.
+__global__ __launch_bounds__(256) void k_dense_reverse_rows(int32_t n, const int32_t *__restrict__ b_ptr,
+                                                           const double *__restrict__ b_val, double *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t k = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (k >= n) return;
+    const int32_t b = b_ptr[k], len = b_ptr[k + 1] - b;
+    for (int32_t q = lane; q < len; q += 64) out[b + q] = b_val[b + len - 1 - q];
+}
+
+typedef __attribute__((address_space(1))) const void *csx_gptr;
+typedef __attribute__((address_space(3))) void *csx_lptr;
+
+template <int BS>
+__global__ __launch_bounds__(256) void k_cholsol_dense(const Tree *__restrict__ trees, int32_t ntrees,
+                                                       const int32_t *__restrict__ nodes,
+                                                       const int32_t *__restrict__ perm,
+                                                       const int32_t *__restrict__ f_ptr, const double *__restrict__ f_val,
+                                                       const int32_t *__restrict__ b_ptr, const double *__restrict__ b_val,
+                                                       const double *__restrict__ diagf, const double *__restrict__ diagb,
+                                                       double *B, int32_t nrhs, int32_t chunks) {
+    constexpr int NT = BS * (BS - 1) / 2;  // strictly-lower entries
+    constexpr int MSZ = ((NT + 127) / 128 * 128 > NT + BS) ? (NT + 127) / 128 * 128 : NT + BS;
+    __shared__ __attribute__((aligned(16))) double s_m[4][MSZ];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t task = (int64_t)blockIdx.x * 4 + w;
+    if (task >= (int64_t)ntrees * chunks) return;
+    const int32_t t = (int32_t)(task / chunks), h = (int32_t)(task % chunks);
+    const int32_t first = trees[t].first;
+    const int32_t rhs = h * 64 + lane;
+    const bool live = rhs < nrhs;
+    double *M = s_m[w], *RD = s_m[w] + NT;  // RD overlaps the DMA overrun and is written after it
+    // rows of B owned by this block (through the fill-reducing permutation, if any)
+    int32_t jrow = 0;
+    if (lane < BS) {
+        jrow = nodes[first + lane];
+        if (perm) jrow = perm[jrow];
+    }
+    // lanes past the last right-hand side load a valid element (their column index is clamped)
+    // and never store: the compiler is free to issue these loads unpredicated
+    const int32_t rhs_ld = live ? rhs : nrhs - 1;
+    double x[BS];
+#pragma unroll
+    for (int a = 0; a < BS; a++) {
+        const int32_t row = __builtin_amdgcn_readlane(jrow, a);
+        x[a] = B[(int64_t)row * nrhs + rhs_ld];
+    }
+#pragma unroll 1
+    for (int pass = 0; pass < 2; pass++) {
+        const int32_t *ptr = pass ? b_ptr : f_ptr;
+        const double *val = pass ? b_val : f_val;  // b_val here is the row-reversed dense copy
+        const double *dg = pass ? diagb : diagf;
+        const int32_t base = ptr[first];
+        // stage the packed block (row sp of the sweep holds M[sp][t], t = 0..sp-1) with
+        // asynchronous global->LDS DMA: 1 KiB per instruction, no registers, all in flight at once.
+        // The last piece runs past the block into the RD area, which is written afterwards.
+        const double rd = lane < BS ? 1.0 / dg[first + lane] : 0.0;
+#pragma unroll
+        for (int k = 0; k < (NT + 127) / 128; k++)
+            __builtin_amdgcn_global_load_lds((csx_gptr)(val + base + k * 128 + 2 * lane), (csx_lptr)(M + k * 128), 16, 0,
+                                             0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane < BS) RD[lane] = rd;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int sp = 0; sp < BS; sp++) {
+            double acc = x[sp];
+#pragma unroll
+            for (int tt = 0; tt < sp; tt++) acc = fma(-M[sp * (sp - 1) / 2 + tt], x[tt], acc);
+            x[sp] = acc * RD[sp];
+        }
+        __builtin_amdgcn_wave_barrier();
+        // reverse the unknowns: after the forward pass this puts them in backward sweep order,
+        // after the backward pass it restores row order
+#pragma unroll
+        for (int a = 0; a < BS / 2; a++) {
+            const double tmp = x[a];
+            x[a] = x[BS - 1 - a];
+            x[BS - 1 - a] = tmp;
+        }
+    }
+    // v_readlane must run with every lane active (it reads lanes that may be past the last
+    // right-hand side), so only the store itself is predicated
+#pragma unroll
+    for (int a = 0; a < BS; a++) {
+        const int32_t row = __builtin_amdgcn_readlane(jrow, a);
+        if (live) B[(int64_t)row * nrhs + rhs] = x[a];
+    }
+}
 
 __global__ __launch_bounds__(256) void k_perm_rows(const int32_t *__restrict__ perm, const double *__restrict__ src,
                                                    double *__restrict__ dst, int32_t n, int32_t nrhs, int to_x) {
@@ -684,9 +787,9 @@ static int cholsol_plan(const Csc *L, const int32_t *pinv, CholPlan **out) {
     dfree(blen);
     CSX_TRY(st);
     CSX_TRY(dalloc(&P->f_idx, (size_t)ftot + 8));
-    CSX_TRY(dalloc(&P->f_val, (size_t)ftot + 8));
+    CSX_TRY(dalloc(&P->f_val, (size_t)ftot + 128));
     CSX_TRY(dalloc(&P->b_idx, (size_t)btot + 8));
-    CSX_TRY(dalloc(&P->b_val, (size_t)btot + 8));
+    CSX_TRY(dalloc(&P->b_val, (size_t)btot + 128));
     hipLaunchKernelGGL(k_pack_fill, dim3((unsigned)(((int64_t)n + 3) / 4)), dim3(256), 0, s, n, P->tree_nodes,
                        P->rev_pos, P->local_id, Gp, Gi, Gx, L->p, L->i, L->x, P->f_ptr, P->f_idx, P->f_val, P->b_ptr,
                        P->b_idx, P->b_val, P->diagk, P->diagb);
@@ -695,6 +798,37 @@ static int cholsol_plan(const Csc *L, const int32_t *pinv, CholPlan **out) {
     P->ntrees = (int32_t)F.small.size();
     P->max_nodes = F.max_tree;
     P->local = true;
+    // dense blocks? same size, contiguous rows, column c of a block holding exactly bs - c entries
+    const int32_t bs = F.max_tree;
+    if (bs == 8 || bs == 16 || bs == 32 || bs == 64) {
+        std::vector<int32_t> hLp((size_t)n + 1);
+        CSX_HIP(hipMemcpyAsync(hLp.data(), L->p, ((size_t)n + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        CSX_HIP(hipStreamSynchronize(s));
+        bool dense = true;
+        for (const Tree &t : F.small) {
+            if (t.count != bs) {
+                dense = false;
+                break;
+            }
+            const int32_t j0 = F.small_cols[(size_t)t.first];
+            for (int32_t c = 0; c < bs && dense; c++) {
+                const int32_t j = F.small_cols[(size_t)(t.first + c)];
+                if (j != j0 + c || hLp[(size_t)j + 1] - hLp[(size_t)j] != bs - c) dense = false;
+            }
+            if (!dense) break;
+        }
+        if (dense) {
+            int32_t btot_h = 0;
+            CSX_HIP(hipMemcpyAsync(&btot_h, P->b_ptr + n, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            CSX_HIP(hipStreamSynchronize(s));
+            CSX_TRY(dalloc(&P->dense_b, (size_t)btot_h + 128));
+            hipLaunchKernelGGL(k_dense_reverse_rows, dim3((unsigned)(((int64_t)n + 3) / 4)), dim3(256), 0, s, n, P->b_ptr,
+                               P->b_val, P->dense_b);
+            CSX_LAUNCH_CHECK();
+            CSX_HIP(hipStreamSynchronize(s));
+            P->dense_bs = bs;
+        }
+    }
     return CSX_OK;
 }
 
@@ -711,6 +845,23 @@ static int cholsol_solve(CholPlan *P, double *B, int32_t nrhs) {
         // zero pivots were detected by the analysis; report like the reference (ZeroDivisionError)
         int st = tri_solve_raw(P->fwd, B, 0);
         if (st != CSX_OK) return st;
+        if (P->dense_bs && !std::getenv("CSX_CHOLSOL_NO_DENSE")) {
+            const int32_t chunks = (nrhs + 63) / 64;
+            const int64_t tasks = (int64_t)P->ntrees * chunks;
+            const dim3 grid((unsigned)((tasks + 3) / 4));
+#define CSX_DENSE(BS)                                                                                          \
+    hipLaunchKernelGGL(k_cholsol_dense<BS>, grid, dim3(256), 0, s, P->trees, P->ntrees, P->tree_nodes, P->perm, \
+                       P->f_ptr, P->f_val, P->b_ptr, P->dense_b, P->diagk, P->diagb, B, nrhs, chunks)
+            switch (P->dense_bs) {
+                case 8: CSX_DENSE(8); break;
+                case 16: CSX_DENSE(16); break;
+                case 32: CSX_DENSE(32); break;
+                default: CSX_DENSE(64); break;
+            }
+#undef CSX_DENSE
+            CSX_LAUNCH_CHECK();
+            return CSX_OK;
+        }
         const size_t per_wave = (size_t)P->max_nodes * 64 * sizeof(double);
         int waves = (int)std::min<size_t>(CH_WAVES, (128 * 1024) / per_wave);
         if (waves < 1) waves = 1;
@@ -785,7 +936,7 @@ extern "C" int csx_cholsol_plan(csx_handle_t hL, const int32_t *pinv, csx_handle
 extern "C" int csx_cholsol_info(csx_handle_t h, int32_t *local, int32_t *ntrees, int32_t *max_nodes) {
     CholPlan *P = (CholPlan *)get(h, K_CHOLPLAN);
     if (!P) return CSX_EINVAL;
-    if (local) *local = P->local ? 1 : 0;
+    if (local) *local = P->local ? (P->dense_bs ? 2 : 1) : 0;  // 0 level-scheduled, 1 fused in LDS, 2 dense blocks
     if (ntrees) *ntrees = P->ntrees;
     if (max_nodes) *max_nodes = P->max_nodes;
     return CSX_OK;

@@ -66,7 +66,7 @@ void free_triplan(TriPlan *t) {
     delete t;
 }
 
-constexpr int NARROW = 2048;  // (rows in level) * nrhs at or below this: level joins a one-workgroup run
+constexpr int NARROW = 512;   // (rows in level) * nrhs at or below this: level joins a one-workgroup run
 
 // ---- building the gather layout ----------------------------------------------
 __global__ __launch_bounds__(256) void k_check_columns(int32_t n, const int32_t *Tp, int *bad) {

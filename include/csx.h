@@ -133,7 +133,8 @@ int csx_chol(csx_handle_t A, const int32_t *parent, const int32_t *cp, const int
 /* The solve phase of cs_cholsol, csparse.py:640-643, for nrhs right-hand sides:
  * B (n-by-nrhs, row-major) is overwritten with the solutions. */
 int csx_cholsol_plan(csx_handle_t L, const int32_t *pinv /* host, or NULL */, csx_handle_t *plan);
-int csx_cholsol_info(csx_handle_t plan, int32_t *fused_local, int32_t *ntrees, int32_t *max_nodes);
+/* *path: 0 = level-scheduled generic, 1 = fused per-tree kernel (X tile in LDS), 2 = dense-block kernel */
+int csx_cholsol_info(csx_handle_t plan, int32_t *path, int32_t *ntrees, int32_t *max_nodes);
 int csx_cholsol_solve(csx_handle_t plan, csx_handle_t B, int32_t nrhs);
 
 /* cs_lu, csparse.py:1370-1451 (+ cs_spsolve :2078-2113), natural column order: host C++

@@ -114,7 +114,7 @@ def test_gspd_factor_and_batched_solve(cs, nblocks, bs, k):
     n = nblocks * bs
     A = cs.cs_pin(_host_cs(cs, n, n, Ap, Ai, Ax))
     F = cs.cholsol_factor(A)
-    assert F.info() == {"fused_local": True, "trees": nblocks, "max_nodes": bs}
+    assert F.info() == {"fused_local": True, "dense_block": bs, "trees": nblocks, "max_nodes": bs}
     parent, cp = CO.schol(n, Ap, Ai)
     assert F.symbolic.parent == parent.tolist() and F.symbolic.cp == cp.tolist()
     Lp, Li, Lx = CO.chol(n, Ap, Ai, Ax, parent, cp)
@@ -129,7 +129,20 @@ def test_gspd_factor_and_batched_solve(cs, nblocks, bs, k):
     gLp, gLi, gLx = _arr(L)
     for r in sorted(set([0, 1, k // 2, k - 1])):
         ref = CO.ltsolve(n, gLp, gLi, gLx, CO.lsolve(n, gLp, gLi, gLx, B[:, r]))
-        assert X[:, r].tobytes() == ref.tobytes(), r            # bit-identical per right-hand side
+        # dense-block kernel: FMA + reciprocal diagonal -> equal to rounding, not bit for bit
+        assert np.max(np.abs(X[:, r] - ref) / np.abs(ref)) < 1e-13, r
+    # the reference-order fused kernel (forced) is bit-identical per right-hand side
+    import os
+    os.environ["CSX_CHOLSOL_NO_DENSE"] = "1"
+    try:
+        dB2 = cs.dvec(B)
+        assert F.solve(dB2) is True
+        X2 = dB2.numpy()
+    finally:
+        del os.environ["CSX_CHOLSOL_NO_DENSE"]
+    for r in sorted(set([0, k - 1])):
+        ref = CO.ltsolve(n, gLp, gLi, gLx, CO.lsolve(n, gLp, gLi, gLx, B[:, r]))
+        assert X2[:, r].tobytes() == ref.tobytes(), r
     # residual of the whole block against A (symmetric, full storage)
     R = np.stack([CO.gaxpy(n, n, Ap, Ai, Ax, X[:, r], -B[:, r]) for r in (0, k - 1)], axis=1)
     assert np.max(np.abs(R)) < 1e-12 * np.max(np.abs(B)) * bs
@@ -137,6 +150,50 @@ def test_gspd_factor_and_batched_solve(cs, nblocks, bs, k):
     b = B[:, 0].tolist()
     assert cs.cs_cholsol(0, A, b) is True
     assert np.asarray(b).tobytes() == X[:, 0].tobytes()
+
+
+def test_forest_of_sparse_trees_uses_generic_fused_kernel(cs):
+    """Block-diagonal with TRIDIAGONAL-plus-arrow blocks: small trees that are not dense blocks, and a
+    permutation -> the generic fused kernel (X tile in LDS), bit-identical per right-hand side."""
+    nb, bs, k = 200, 24, 70
+    n = nb * bs
+    rng = np.random.default_rng(4)
+    cols_i, cols_x, Ap = [], [], [0]
+    for j in range(n):
+        b0 = (j // bs) * bs
+        rows = {j}
+        if j - 1 >= b0:
+            rows.add(j - 1)
+        if j + 1 < b0 + bs:
+            rows.add(j + 1)
+        rows.add(b0 + bs - 1)  # arrow: last row/column of every block is full
+        if j == b0 + bs - 1:
+            rows.update(range(b0, b0 + bs))
+        rows = sorted(rows)
+        vals = [(8.0 + (j % 5)) if r == j else -1.0 / (1 + abs(r - j)) for r in rows]
+        cols_i.append(rows)
+        cols_x.append(vals)
+        Ap.append(Ap[-1] + len(rows))
+    Ap = np.asarray(Ap, np.int32)
+    Ai = np.concatenate(cols_i).astype(np.int32)
+    Ax = np.concatenate(cols_x)
+    A = cs.cs_pin(_host_cs(cs, n, n, Ap, Ai, Ax))
+    F = cs.cholsol_factor(A)
+    info = F.info()
+    assert info["fused_local"] and info["dense_block"] == 0 and info["trees"] == nb
+    parent, cp = CO.schol(n, Ap, Ai)
+    Lp, Li, Lx = CO.chol(n, Ap, Ai, Ax, parent, cp)
+    assert F.L.p == Lp.tolist() and F.L.i[:Lp[n]] == Li.tolist()
+    B = synth.rhs(n, k, 1)
+    dB = cs.dvec(B)
+    assert F.solve(dB)
+    X = dB.numpy()
+    gLp, gLi, gLx = _arr(F.L)
+    for r in (0, 33, k - 1):
+        ref = CO.ltsolve(n, gLp, gLi, gLx, CO.lsolve(n, gLp, gLi, gLx, B[:, r]))
+        assert X[:, r].tobytes() == ref.tobytes(), r
+        res = CO.gaxpy(n, n, Ap, Ai, Ax, X[:, r], -B[:, r])
+        assert np.max(np.abs(res)) < 1e-12
 
 
 @pytest.mark.parametrize("name", ["t1", "bcsstk01", "west0067", "fs_183_1"])
