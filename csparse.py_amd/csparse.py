@@ -27,6 +27,7 @@ What runs where
 """
 import os
 import weakref
+from math import sqrt
 
 import numpy as np
 
@@ -799,6 +800,337 @@ def cs_lusol(order, A, b, tol):
     cs_lsolve(N.L, x)
     cs_usolve(N.U, x)
     cs_ipvec(S.q, x, b, n)
+    return True
+
+
+# -------------------------------------------------------------------- QR ----
+# Host Python, like the reference: Householder QR is serial, data dependent and outside the
+# accelerated path.  It exists so that cs_qrsol -- the driver that reaches
+# cs_usolve / cs_utsolve from the least-squares side -- is a drop-in too.
+
+def cs_etree(A, ata):
+    """Elimination tree of A (ata False; upper triangle used) or of A'A (csparse.py:1136-1169)."""
+    if not CS_CSC(A):
+        return None
+    m, n = A.m, A.n
+    Ap, Ai = A.p, A.i
+    parent = [-1] * n
+    anc = [-1] * n
+    prev = [-1] * m if ata else None
+    for k in range(n):
+        for p in range(Ap[k], Ap[k + 1]):
+            i = prev[Ai[p]] if ata else Ai[p]
+            while i != -1 and i < k:
+                up = anc[i]
+                anc[i] = k
+                if up == -1:
+                    parent[i] = k
+                i = up
+            if ata:
+                prev[Ai[p]] = k
+    return parent
+
+
+def cs_post(parent, n):
+    """Postorder of a forest (csparse.py:1711-1742, :2258-2289)."""
+    if parent is None:
+        return None
+    first_child = [-1] * n
+    sibling = [-1] * n
+    for j in range(n - 1, -1, -1):
+        if parent[j] != -1:
+            sibling[j] = first_child[parent[j]]
+            first_child[parent[j]] = j
+    post = []
+    for root in range(n):
+        if parent[root] != -1:
+            continue
+        stack = [root]
+        while stack:
+            c = first_child[stack[-1]]
+            if c == -1:
+                post.append(stack.pop())
+            else:
+                first_child[stack[-1]] = sibling[c]
+                stack.append(c)
+    return post
+
+
+def _colcounts_ata(A, parent, post):
+    """Column counts of chol(A'A) (csparse.py:703-764 with :677-700): rows of A are grouped by the
+    postorder rank of their leftmost column, then the skeleton/leaf counting runs over those rows."""
+    m, n = A.m, A.n
+    AT = cs_transpose(A, False)
+    ATp, ATi = AT.p, AT.i
+    rank = [0] * n
+    for k in range(n):
+        rank[post[k]] = k
+    head = [-1] * (n + 1)
+    nxt = [-1] * m
+    for i in range(m):
+        k = n
+        for p in range(ATp[i], ATp[i + 1]):
+            k = min(k, rank[ATi[p]])
+        nxt[i] = head[k]
+        head[k] = i
+    delta = [0] * n
+    first = [-1] * n
+    maxfirst = [-1] * n
+    prevleaf = [-1] * n
+    for k in range(n):
+        j = post[k]
+        delta[j] = 1 if first[j] == -1 else 0
+        while j != -1 and first[j] == -1:
+            first[j] = k
+            j = parent[j]
+    anc = list(range(n))
+    for k in range(n):
+        j = post[k]
+        if parent[j] != -1:
+            delta[parent[j]] -= 1
+        J = head[k]
+        while J != -1:
+            for p in range(ATp[J], ATp[J + 1]):
+                i = ATi[p]
+                if i <= j or first[j] <= maxfirst[i]:
+                    continue
+                maxfirst[i] = first[j]
+                jprev = prevleaf[i]
+                prevleaf[i] = j
+                delta[j] += 1
+                if jprev != -1:
+                    q = jprev
+                    while q != anc[q]:
+                        q = anc[q]
+                    s = jprev
+                    while s != q:
+                        sp = anc[s]
+                        anc[s] = q
+                        s = sp
+                    delta[q] -= 1
+            J = nxt[J]
+        if parent[j] != -1:
+            anc[j] = parent[j]
+    for j in range(n):
+        if parent[j] != -1:
+            delta[parent[j]] += delta[j]
+    return delta
+
+
+def _vcount(A, S):
+    """nnz(V), the row permutation pinv, leftmost[] and m2 for QR (csparse.py:2118-2184).  Rows left
+    without a pivot are numbered from n upwards, as in CSparse; the reference's port restarts at
+    n - 1, which collides for m > n."""
+    m, n = A.m, A.n
+    parent = S.parent
+    pinv = [-1] * (m + n)
+    leftmost = [-1] * m
+    for k in range(n - 1, -1, -1):
+        for p in range(A.p[k], A.p[k + 1]):
+            leftmost[A.i[p]] = k
+    head = [-1] * n
+    tail = [-1] * n
+    count = [0] * n
+    nxt = [-1] * m
+    for i in range(m - 1, -1, -1):
+        k = leftmost[i]
+        if k == -1:
+            continue
+        if count[k] == 0:
+            tail[k] = i
+        count[k] += 1
+        nxt[i] = head[k]
+        head[k] = i
+    S.lnz = 0
+    S.m2 = m
+    for k in range(n):
+        i = head[k]
+        S.lnz += 1
+        if i < 0:
+            i = S.m2
+            S.m2 += 1
+        pinv[i] = k
+        count[k] -= 1
+        if count[k] <= 0:
+            continue
+        S.lnz += count[k]
+        pa = parent[k]
+        if pa != -1:
+            if count[pa] == 0:
+                tail[pa] = tail[k]
+            nxt[tail[k]] = head[pa]
+            head[pa] = nxt[i]
+            count[pa] += count[k]
+    k = n
+    for i in range(m):
+        if pinv[i] < 0:
+            pinv[i] = k
+            k += 1
+    S.pinv = pinv
+    S.leftmost = leftmost
+    return True
+
+
+def cs_sqr(order, A, qr):  # noqa: F811  (extends the LU-only version above)
+    """Symbolic ordering and analysis for QR or LU (csparse.py:2187-2217), natural ordering."""
+    if not CS_CSC(A) or order != 0:
+        return None
+    n = A.n
+    S = css()
+    S.q = None
+    S.pinv = None
+    if not qr:
+        S.unz = S.lnz = 4 * A.p[n] + n
+        return S
+    S.parent = cs_etree(A, True)
+    post = cs_post(S.parent, n)
+    S.cp = _colcounts_ata(A, S.parent, post)
+    _vcount(A, S)
+    S.unz = sum(S.cp)
+    return S
+
+
+def cs_house(x, x_offset, beta, n):
+    """Householder reflection (I - beta v v') x = s e1; x is overwritten with v (csparse.py:1238-1261)."""
+    if x is None or beta is None:
+        return -1
+    sigma = 0
+    for i in range(1, n):
+        sigma += x[x_offset + i] * x[x_offset + i]
+    x0 = x[x_offset]
+    if sigma == 0:
+        s = abs(x0)
+        beta[0] = 2.0 if x0 <= 0 else 0.0
+        x[x_offset] = 1
+    else:
+        s = sqrt(x0 * x0 + sigma)
+        x[x_offset] = x0 - s if x0 <= 0 else -sigma / (x0 + s)
+        beta[0] = -1.0 / (s * x[x_offset])
+    return s
+
+
+def cs_happly(V, i, beta, x):
+    """x = (I - beta v v') x with v = V(:, i) (csparse.py:1216-1235)."""
+    if not CS_CSC(V) or x is None:
+        return False
+    Vi, Vx = V.i, V.x
+    lo, hi = V.p[i], V.p[i + 1]
+    tau = 0
+    for p in range(lo, hi):
+        tau += Vx[p] * x[Vi[p]]
+    tau *= beta
+    for p in range(lo, hi):
+        x[Vi[p]] -= Vx[p] * tau
+    return True
+
+
+def cs_qr(A, S):
+    """Sparse Householder QR, A = Q R (csparse.py:1797-1870).  N.L = V, N.U = R (diagonal last in
+    every column), N.B = beta."""
+    if not CS_CSC(A) or S is None:
+        return None
+    n, Ap, Ai, Ax = A.n, A.p, A.i, A.x
+    q, parent, pinv, m2, leftmost = S.q, S.parent, S.pinv, S.m2, S.leftmost
+    mark = [-1] * m2
+    stack = [0] * n
+    x = [0.0] * m2
+    N = csn()
+    N.L = V = cs_spalloc(m2, n, S.lnz, True, False)
+    N.U = R = cs_spalloc(m2, n, S.unz, True, False)
+    N.B = Beta = [0.0] * n
+    N.pinv = None
+    Rp, Ri, Rx = R.p, R.i, R.x
+    Vp, Vi, Vx = V.p, V.i, V.x
+    rnz = vnz = 0
+    for k in range(n):
+        Rp[k] = rnz
+        Vp[k] = p1 = vnz
+        mark[k] = k
+        Vi[vnz] = k
+        vnz += 1
+        top = n
+        col = q[k] if q is not None else k
+        for p in range(Ap[col], Ap[col + 1]):
+            i = leftmost[Ai[p]]
+            length = 0
+            while mark[i] != k:
+                stack[length] = i
+                length += 1
+                mark[i] = k
+                i = parent[i]
+            while length > 0:
+                top -= 1
+                length -= 1
+                stack[top] = stack[length]
+            i = pinv[Ai[p]]
+            x[i] = Ax[p]
+            if i > k and mark[i] < k:
+                Vi[vnz] = i
+                vnz += 1
+                mark[i] = k
+        for p in range(top, n):
+            i = stack[p]
+            cs_happly(V, i, Beta[i], x)
+            Ri[rnz] = i
+            Rx[rnz] = x[i]
+            rnz += 1
+            x[i] = 0
+            if parent[i] == k:
+                vnz = cs_scatter(V, i, 0, mark, None, k, V, vnz)
+        for p in range(p1, vnz):
+            Vx[p] = x[Vi[p]]
+            x[Vi[p]] = 0
+        Ri[rnz] = k
+        b = [Beta[k]]
+        Rx[rnz] = cs_house(Vx, p1, b, vnz - p1)
+        rnz += 1
+        Beta[k] = b[0]
+    Rp[n] = rnz
+    Vp[n] = vnz
+    return N
+
+
+def _square_view(T):
+    """R from cs_qr is m2-by-n with nothing below row n: present it as n-by-n to the device solves."""
+    if T.m == T.n:
+        return T
+    V = cs()
+    V.m = V.n = T.n
+    V.nz, V.nzmax = -1, T.nzmax
+    V.p, V.i, V.x = T.p, T.i, T.x
+    return V
+
+
+def cs_qrsol(order, A, b):
+    """Least squares (m >= n) or minimum-norm solution (m < n) by QR; b (size max(m, n)) is
+    overwritten with x (csparse.py:1875-1912).  The factorisation and the Householder applications
+    run on the host, the triangular solves cs_usolve / cs_utsolve on the device."""
+    if not CS_CSC(A) or b is None:
+        return False
+    n, m = A.n, A.m
+    if m >= n:
+        S = cs_sqr(order, A, True)
+        N = cs_qr(A, S) if S is not None else None
+        if S is None or N is None:
+            return False
+        x = xalloc(S.m2)
+        cs_ipvec(S.pinv, b, x, m)
+        for k in range(n):
+            cs_happly(N.L, k, N.B[k], x)
+        cs_usolve(_square_view(N.U), x)
+        cs_ipvec(S.q, x, b, n)
+    else:
+        AT = cs_transpose(A, True)
+        S = cs_sqr(order, AT, True)
+        N = cs_qr(AT, S) if S is not None else None
+        if AT is None or S is None or N is None:
+            return False
+        x = xalloc(S.m2)
+        cs_pvec(S.q, b, x, m)
+        cs_utsolve(_square_view(N.U), x)
+        for k in range(m - 1, -1, -1):
+            cs_happly(N.L, k, N.B[k], x)
+        cs_pvec(S.pinv, x, b, n)
     return True
 
 

@@ -57,3 +57,4 @@ def test_lu_host_singular_and_bad_input():
     assert cs.cs_lu(A, None, 1.0) is None and cs.cs_sqr(2, A, False) is None
     T = cs.cs_spalloc(2, 2, 2, True, True)
     assert cs.cs_lusol(0, T, [1.0, 1.0], 1.0) is False and cs.cs_lusol(0, A, None, 1.0) is False
+
