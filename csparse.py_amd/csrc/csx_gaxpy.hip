@@ -16,6 +16,8 @@
 //   TILED   see csx_gaxpy_tiled.hip (matrices whose rows share no columns).
 //
 // Algorithmic bytes per call: 12 nnz + 4(n+1) + 8 n + 16 m  (SURVEY.md 8d).
+#include <cstdlib>
+
 #include "csx_internal.h"
 
 namespace csx {
@@ -57,6 +59,9 @@ __global__ __launch_bounds__(256) void k_gaxpy_rows(int32_t rows, const int32_t 
             b[u] = ptr[r];
             e[u] = r0 + u < rows ? ptr[r + 1] : b[u];
         }
+        // the y value this lane will update (lane u of the group owns row r0 + u): requested early
+        const bool owner = sub < U && r0 + sub < rows;
+        const double y_old = owner ? y[r0 + sub] : 0.0;
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int32_t q = b[u] + sub;
@@ -75,11 +80,11 @@ __global__ __launch_bounds__(256) void k_gaxpy_rows(int32_t rows, const int32_t 
 #pragma unroll
             for (int d = G >> 1; d > 0; d >>= 1) acc[u] += __shfl_xor(acc[u], d, 64);
         }
-        if (sub < U && r0 + sub < rows) {
+        if (owner) {
             double a = acc[0];
 #pragma unroll
             for (int u = 1; u < U; u++) a = sub == u ? acc[u] : a;
-            if (e[0] > b[0] || U > 1) y[r0 + sub] += a;
+            y[r0 + sub] = y_old + a;
         }
     }
 }
@@ -104,16 +109,28 @@ static int run_rows(const Gather *g, int64_t nnz, const double *x, double *y) {
     const int64_t cap = (int64_t)ctx().cus * 32;  // workgroups of 256: 8 per CU x 4 rounds
 #define CSX_ROWS(G)                                                                                       \
     {                                                                                                     \
-        int64_t blocks = (((int64_t)g->rows + 3) / 4 * G + 255) / 256;                                    \
+        int64_t blocks = (((int64_t)g->rows + RU - 1) / RU * G + 255) / 256;                              \
         if (blocks > cap) blocks = cap;                                                                   \
-        hipLaunchKernelGGL((k_gaxpy_rows<G, 4>), dim3((unsigned)blocks), dim3(256), 0, s, g->rows, g->ptr, \
+        hipLaunchKernelGGL((k_gaxpy_rows<G, RU>), dim3((unsigned)blocks), dim3(256), 0, s, g->rows, g->ptr, \
                            g->idx, g->val, x, y);                                                         \
     }
-    if (avg > 48) CSX_ROWS(64)
-    else if (avg > 24) CSX_ROWS(32)
-    else if (avg > 12) CSX_ROWS(16)
-    else if (avg > 6) CSX_ROWS(8)
-    else CSX_ROWS(4)
+    // 8 rows per group in flight measured 7 % faster than 4 on G-spd (0.94 vs 1.01 ms); rows with
+    // fewer than ~6 entries use 4-lane groups, which need U <= 4
+    static const int ru_env = std::getenv("CSX_ROWS_U") ? std::atoi(std::getenv("CSX_ROWS_U")) : 8;
+    if (ru_env == 8 && avg > 6) {
+        constexpr int RU = 8;
+        if (avg > 48) CSX_ROWS(64)
+        else if (avg > 24) CSX_ROWS(32)
+        else if (avg > 12) CSX_ROWS(16)
+        else CSX_ROWS(8)
+    } else {
+        constexpr int RU = 4;
+        if (avg > 48) CSX_ROWS(64)
+        else if (avg > 24) CSX_ROWS(32)
+        else if (avg > 12) CSX_ROWS(16)
+        else if (avg > 6) CSX_ROWS(8)
+        else CSX_ROWS(4)
+    }
 #undef CSX_ROWS
     CSX_LAUNCH_CHECK();
     return CSX_OK;

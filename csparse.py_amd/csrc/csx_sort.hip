@@ -157,18 +157,28 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint32_t *key, int
     hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
+// Stable scatter of one workgroup tile (4096 records).  Ranks follow (wave, round, lane) = source
+// order.  Records are first placed in LDS in their sorted order inside the tile, then written out
+// position by position: consecutive threads write consecutive slots of a bucket, so the stores are
+// runs of whole 64/128-byte pieces instead of 4/8-byte singles.
 template <bool HAS_A, bool HAS_V, bool WRITE_KEY>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint32_t *key, const uint32_t *a, const double *v,
                                                            int64_t count, int shift, uint32_t nblocks,
                                                            const int32_t *goff, uint32_t *okey, uint32_t *oa,
                                                            double *ov) {
     __shared__ int wh[RS_WAVES][RS_BINS];
+    __shared__ int gbase[RS_BINS];  // global slot of a bucket's first record minus its local start
+    __shared__ int wsum[RS_WAVES];
+    __shared__ uint32_t s_key[RS_TILE];
+    __shared__ uint32_t s_a[HAS_A ? RS_TILE : 1];
+    __shared__ double s_v[HAS_V ? RS_TILE : 1];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < RS_WAVES; k++) wh[k][threadIdx.x] = 0;
     __syncthreads();
     // wave w owns the contiguous sub-tile [w*64*ROUNDS, (w+1)*64*ROUNDS) of this workgroup's tile
-    const int64_t wbase = (int64_t)blockIdx.x * RS_TILE + (int64_t)w * 64 * RS_ROUNDS;
+    const int64_t tbase = (int64_t)blockIdx.x * RS_TILE;
+    const int64_t wbase = tbase + (int64_t)w * 64 * RS_ROUNDS;
 #pragma unroll 4
     for (int r = 0; r < RS_ROUNDS; r++) {
         int64_t idx = wbase + r * 64 + lane;
@@ -176,8 +186,25 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint32_t *key, 
     }
     __syncthreads();
     {
+        // digit d = threadIdx.x: local start of the bucket inside the tile = exclusive scan over digits
         const int d = threadIdx.x;
-        int run = goff[(size_t)d * nblocks + blockIdx.x];
+        int tot = 0;
+#pragma unroll
+        for (int k = 0; k < RS_WAVES; k++) tot += wh[k][d];
+        int inc = tot;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+            int t = __shfl_up(inc, dd, 64);
+            if (lane >= dd) inc += t;
+        }
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        int off = 0;
+#pragma unroll
+        for (int k = 0; k < RS_WAVES; k++)
+            if (k < w) off += wsum[k];
+        int run = off + inc - tot;  // local start of bucket d
+        gbase[d] = goff[(size_t)d * nblocks + blockIdx.x] - run;
 #pragma unroll
         for (int k = 0; k < RS_WAVES; k++) {
             int c = wh[k][d];
@@ -206,10 +233,19 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint32_t *key, 
         if (valid && rank == 0) wh[w][d] = pos + __popcll(peers);
         __builtin_amdgcn_wave_barrier();
         if (valid) {
-            if (WRITE_KEY) okey[pos] = k;
-            if (HAS_A) oa[pos] = a[idx];
-            if (HAS_V) ov[pos] = v[idx];
+            s_key[pos] = k;
+            if (HAS_A) s_a[pos] = a[idx];
+            if (HAS_V) s_v[pos] = v[idx];
         }
+    }
+    __syncthreads();
+    const int tcount = (int)((count - tbase) < RS_TILE ? (count - tbase) : RS_TILE);
+    for (int i = threadIdx.x; i < tcount; i += RS_THREADS) {
+        const uint32_t k = s_key[i];
+        const int64_t g = (int64_t)gbase[(k >> shift) & (RS_BINS - 1)] + i;
+        if (WRITE_KEY) okey[g] = k;
+        if (HAS_A) oa[g] = s_a[i];
+        if (HAS_V) ov[g] = s_v[i];
     }
 }
 
