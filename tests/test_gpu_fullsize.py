@@ -1,0 +1,147 @@
+"""BASELINE.json's full sizes, checked through size-independent properties (the oracle cannot run
+there in seconds): kernel-to-kernel agreement, linearity, transpose involution, A x = b residuals,
+C 1 = A (A' 1).  Inputs are generated on the device (csx_gen_*), whose bit-exact agreement with the
+host generators is covered by test_gpu_parity.py::test_generators_match_host_twins."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from test_gpu_parity import cs  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+def _vec(h, n, k=1):
+    import csparse
+    return csparse.dvec(n, k, _handle=h)
+
+
+@pytest.fixture(scope="module")
+def lib(cs):
+    import _csx
+    return _csx.lib()
+
+
+def test_gaxpy_5m_modes_agree_and_are_linear(cs, lib):
+    import _csx
+    n, per_col = 5000000, 64
+    hA = _csx.new_handle()
+    _csx.check(lib.csx_gen_grand(n, per_col, 20240602, hA))
+    hx = _csx.new_handle()
+    _csx.check(lib.csx_gen_vec(n, 7, 0.5, 1.5, hx))
+    x = _vec(hx, n)
+    results = {}
+    for name, mode in (("exact", cs.GAXPY_EXACT), ("wave", cs.GAXPY_WAVE), ("tiled", cs.GAXPY_TILED),
+                       ("atomic", cs.GAXPY_ATOMIC)):
+        y = cs.dvec(n)
+        _csx.check(lib.csx_gaxpy(hA, x.handle, y.handle, mode))
+        results[name] = y.numpy()
+    ref = results["exact"]  # reference summation order
+    assert np.all(np.isfinite(ref)) and ref.min() > 0          # all-positive data: every row sum positive
+    for name in ("wave", "tiled", "atomic"):
+        assert np.max(np.abs(results[name] - ref) / ref) < 1e-12, name
+    # total mass: 1' (A x) = sum_j x_j * colsum_j; column sums via y = A' 1 computed as gaxpy on the transpose
+    hT = _csx.new_handle()
+    _csx.check(lib.csx_transpose(hA, 1, hT))
+    hone = _csx.new_handle()
+    _csx.check(lib.csx_gen_vec(n, 1, 1.0, 1.0, hone))
+    cols = cs.dvec(n)
+    _csx.check(lib.csx_gaxpy(hT, hone, cols.handle, cs.GAXPY_WAVE))      # cols = A' 1
+    lhs = float(np.sum(ref))
+    rhs = float(np.dot(cols.numpy(), x.numpy()))
+    assert abs(lhs - rhs) / abs(rhs) < 1e-12
+    # linearity: A (2x) accumulated onto A x gives 3 A x (same kernel, y += semantics)
+    y = cs.dvec(ref)
+    x2 = cs.dvec(2.0 * x.numpy())
+    _csx.check(lib.csx_gaxpy(hA, x2.handle, y.handle, cs.GAXPY_TILED))
+    assert np.max(np.abs(y.numpy() - 3.0 * ref) / ref) < 1e-12
+    # transpose is an involution on p and a permutation of the entries
+    hTT = _csx.new_handle()
+    _csx.check(lib.csx_transpose(hT, 1, hTT))
+    p1, p2 = np.empty(n + 1, np.int32), np.empty(n + 1, np.int32)
+    nnz = n * per_col
+    i1, i2 = np.empty(nnz, np.int32), np.empty(nnz, np.int32)
+    _csx.check(lib.csx_csc_download(hA, _csx.pi(p1), _csx.pi(i1), None))
+    _csx.check(lib.csx_csc_download(hTT, _csx.pi(p2), _csx.pi(i2), None))
+    assert (p1 == p2).all() and (i1 == i2).all()               # generator rows are ascending: (A')' == A
+    tp = np.empty(n + 1, np.int32)
+    _csx.check(lib.csx_csc_download(hT, _csx.pi(tp), None, None))
+    assert tp[0] == 0 and tp[-1] == nnz and (np.diff(tp) >= 0).all()
+    for h in (hA, hT, hTT, hone):
+        _csx.free(h)
+
+
+def test_cholsol_5m_block_spd_residual(cs, lib):
+    import _csx
+    nb, bs, k = 78125, 64, 128
+    n = nb * bs
+    hA = _csx.new_handle()
+    _csx.check(lib.csx_gen_gspd(nb, bs, 20240606, hA))
+    p = np.empty(n + 1, np.int32)
+    i = np.empty(n * bs, np.int32)
+    _csx.check(lib.csx_csc_download(hA, _csx.pi(p), _csx.pi(i), None))
+    parent, cp = np.empty(n, np.int32), np.empty(n + 1, np.int32)
+    _csx.check(lib.csx_schol_host(n, _csx.pi(p), _csx.pi(i), _csx.pi(parent), _csx.pi(cp)))
+    assert int(cp[n]) == nb * bs * (bs + 1) // 2                # no fill: lnz = 78125 * 2080
+    hL = _csx.new_handle()
+    _csx.check(lib.csx_chol(hA, _csx.pi(parent), _csx.pi(cp), None, hL))
+    plan = _csx.new_handle()
+    _csx.check(lib.csx_cholsol_plan(hL, None, plan))
+    path, trees, mx = C.c_int32(), C.c_int32(), C.c_int32()
+    _csx.check(lib.csx_cholsol_info(plan, path, trees, mx))
+    assert (path.value, trees.value, mx.value) == (2, nb, bs)
+    hB = _csx.new_handle()
+    _csx.check(lib.csx_gen_rhs(n, k, 0, hB))
+    dB = _vec(hB, n, k)   # owns hB from here on (freed with the object)
+    B0 = dB.numpy().copy()
+    _csx.check(lib.csx_cholsol_solve(plan, hB, k))
+    X = dB.numpy()
+    # residual of three columns against the full symmetric matrix: A x - b
+    for r in (0, 63, 127):
+        xr = cs.dvec(np.ascontiguousarray(X[:, r]))
+        res = cs.dvec(-B0[:, r])
+        _csx.check(lib.csx_gaxpy(hA, xr.handle, res.handle, cs.GAXPY_WAVE))
+        assert np.max(np.abs(res.numpy())) < 1e-12 * np.max(np.abs(B0[:, r])) * bs
+    # the reference-order fused kernel agrees with the dense-block kernel to rounding
+    import os
+    os.environ["CSX_CHOLSOL_NO_DENSE"] = "1"
+    try:
+        hB2 = _csx.new_handle()
+        _csx.check(lib.csx_gen_rhs(n, k, 0, hB2))
+        dB2 = _vec(hB2, n, k)
+        _csx.check(lib.csx_cholsol_solve(plan, hB2, k))
+        X2 = dB2.numpy()
+    finally:
+        del os.environ["CSX_CHOLSOL_NO_DENSE"]
+    assert np.max(np.abs(X2 - X) / np.abs(X2)) < 1e-12
+    for h in (plan, hL, hA):
+        _csx.free(h)
+
+
+def test_multiply_1m_identity(cs, lib):
+    import _csx
+    n, per_col = 1000000, 32
+    hA = _csx.new_handle()
+    _csx.check(lib.csx_gen_grand(n, per_col, 20240605, hA))
+    hB = _csx.new_handle()
+    _csx.check(lib.csx_transpose(hA, 1, hB))
+    hC = _csx.new_handle()
+    _csx.check(lib.csx_multiply(hA, hB, hC))
+    m_, n_, nnzC, hv = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int()
+    _csx.check(lib.csx_csc_info(hC, m_, n_, nnzC, hv))
+    assert (m_.value, n_.value, hv.value) == (n, n, 1)
+    assert 0.9e9 < nnzC.value <= n * per_col * per_col           # <= number of products, few collisions
+    cp = np.empty(n + 1, np.int32)
+    _csx.check(lib.csx_csc_download(hC, _csx.pi(cp), None, None))
+    assert cp[0] == 0 and cp[-1] == nnzC.value and (np.diff(cp) > 0).all()
+    hone = _csx.new_handle()
+    _csx.check(lib.csx_gen_vec(n, 1, 1.0, 1.0, hone))
+    t1, t2, t3 = cs.dvec(n), cs.dvec(n), cs.dvec(n)
+    _csx.check(lib.csx_gaxpy(hB, hone, t1.handle, cs.GAXPY_WAVE))        # A' 1
+    _csx.check(lib.csx_gaxpy(hA, t1.handle, t2.handle, cs.GAXPY_WAVE))   # A (A' 1)
+    _csx.check(lib.csx_gaxpy(hC, hone, t3.handle, cs.GAXPY_ATOMIC))      # C 1
+    a, c = t2.numpy(), t3.numpy()
+    assert np.max(np.abs(a - c) / np.abs(a)) < 1e-12
+    for h in (hA, hB, hC, hone):
+        _csx.free(h)
