@@ -102,6 +102,47 @@ __global__ __launch_bounds__(256) void k_gaxpy_atomic(int32_t n, const int32_t *
     }
 }
 
+// Column locality probe for CSX_GAXPY_AUTO: mean over a sample of rows of (last column - first
+// column) of the row in the stable transpose (columns ascending).  A row-gather SpMV streams when
+// the x values a row needs sit close together; when rows span the whole of a vector that does not
+// fit an XCD's L2 the LDS-resident plan wins (csx_gaxpy_tiled.hip).
+__global__ __launch_bounds__(256) void k_row_span(int32_t rows, int32_t stride, const int32_t *__restrict__ ptr,
+                                                  const int32_t *__restrict__ idx, unsigned long long *sum,
+                                                  unsigned int *cnt) {
+    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * stride;
+    if (r >= rows) return;
+    const int32_t b = ptr[r], e = ptr[r + 1];
+    if (e - b < 2) return;
+    atomicAdd(sum, (unsigned long long)(idx[e - 1] - idx[b]));
+    atomicAdd(cnt, 1u);
+}
+
+static int wants_tiled(const Csc *A, bool *yes) {
+    *yes = false;
+    const Gather *g = A->rows;
+    // small problems: x and y live in L2 whatever the structure
+    if ((int64_t)A->n * 8 < (32ll << 20) || A->nnz < (1 << 24) || !g) return CSX_OK;
+    hipStream_t s = ctx().stream;
+    unsigned long long *d = nullptr;
+    CSX_TRY(dalloc(&d, 2));
+    CSX_HIP(hipMemsetAsync(d, 0, 16, s));
+    const int32_t stride = g->rows > (1 << 16) ? g->rows >> 16 : 1;
+    const int64_t samples = ((int64_t)g->rows + stride - 1) / stride;
+    hipLaunchKernelGGL(k_row_span, dim3((unsigned)((samples + 255) / 256)), dim3(256), 0, s, g->rows, stride, g->ptr,
+                       g->idx, d, (unsigned int *)(d + 1));
+    unsigned long long h[2] = {0, 0};
+    int st = CSX_OK;
+    if (hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+        st = CSX_ERUNTIME;
+    dfree(d);
+    CSX_TRY(st);
+    const unsigned int cnt = (unsigned int)(h[1] & 0xffffffffu);
+    if (!cnt) return CSX_OK;
+    const double mean_span_bytes = (double)h[0] / cnt * 8.0;
+    *yes = mean_span_bytes > (double)(4 << 20);  // a row reaches across more of x than one XCD's L2 holds
+    return CSX_OK;
+}
+
 static int run_rows(const Gather *g, int64_t nnz, const double *x, double *y) {
     hipStream_t s = ctx().stream;
     if (g->rows == 0) return CSX_OK;
@@ -147,7 +188,12 @@ extern "C" int csx_gaxpy_prepare(csx_handle_t hA, int mode) {
     switch (mode) {
         case CSX_GAXPY_ATOMIC: return CSX_OK;
         case CSX_GAXPY_TILED: return gaxpy_tiled_prepare(A);
-        case CSX_GAXPY_AUTO:
+        case CSX_GAXPY_AUTO: {
+            CSX_TRY(build_row_gather(A));
+            bool tiled = false;
+            CSX_TRY(wants_tiled(A, &tiled));
+            return tiled ? gaxpy_tiled_prepare(A) : CSX_OK;
+        }
         case CSX_GAXPY_EXACT:
         case CSX_GAXPY_WAVE: return build_row_gather(A);
         default: return CSX_EINVAL;
@@ -163,7 +209,10 @@ extern "C" int csx_gaxpy(csx_handle_t hA, csx_handle_t hx, csx_handle_t hy, int 
     hipStream_t s = ctx().stream;
     const double *xd = (const double *)x->d;
     double *yd = (double *)y->d;
-    if (mode == CSX_GAXPY_AUTO) mode = A->tiled ? CSX_GAXPY_TILED : CSX_GAXPY_WAVE;
+    if (mode == CSX_GAXPY_AUTO) {
+        if (!A->tiled && !A->rows) CSX_TRY(csx_gaxpy_prepare(hA, CSX_GAXPY_AUTO));  // first call: probe + plan
+        mode = A->tiled ? CSX_GAXPY_TILED : CSX_GAXPY_WAVE;
+    }
     switch (mode) {
         case CSX_GAXPY_EXACT: {
             CSX_TRY(build_row_gather(A));

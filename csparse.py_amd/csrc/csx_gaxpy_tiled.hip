@@ -103,9 +103,18 @@ __device__ __forceinline__ GroupRegs load_group(const uint32_t *__restrict__ key
     return r;
 }
 
+// how x is gathered: 0 plain (L1-allocating), 1 sc1 (agent-scope relaxed: bypasses L1), 2 non-temporal
+template <int HOW>
+__device__ __forceinline__ double load_x(const double *p) {
+    if (HOW == 1) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (HOW == 2) return __builtin_nontemporal_load(p);
+    return *p;
+}
+
 // VARIANT bits (timing experiments only; results are wrong unless VARIANT == 0):
 //   1 = skip the x gather, 2 = skip the LDS accumulation, 4 = gather from a 2 KB footprint (L1 hits),
 //   5 = gather from a 256 KB footprint (L2 hits, L1 misses)
+//   6 = full kernel, x gathered with L1-bypassing sc1 loads; 7 = same with nt loads (both compute y)
 template <int VARIANT>
 __global__ __launch_bounds__(TL_THREADS) void k_gaxpy_tiled(const int32_t *__restrict__ rb_gptr,
                                                             const uint32_t *__restrict__ group_info,
@@ -115,8 +124,9 @@ __global__ __launch_bounds__(TL_THREADS) void k_gaxpy_tiled(const int32_t *__res
                                                             int32_t m, int32_t nrb, int32_t row_block,
                                                             int32_t slab_cols, int rb_bits) {
     extern __shared__ __attribute__((aligned(16))) double ytile[];  // row_block doubles
-    constexpr bool GATHER = !(VARIANT & 1) || VARIANT == 5, ATOMIC = !(VARIANT & 2);
-    constexpr uint32_t CMASK = VARIANT == 5 ? 32767u : ((VARIANT & 4) ? 255u : 0xffffffffu);
+    constexpr bool GATHER = !(VARIANT & 1) || VARIANT >= 5, ATOMIC = !(VARIANT & 2) || VARIANT >= 6;
+    constexpr uint32_t CMASK = VARIANT == 5 ? 32767u : (VARIANT == 4 ? 255u : 0xffffffffu);
+    constexpr int XLOAD = VARIANT == 6 ? 1 : (VARIANT == 7 ? 2 : 0);
     const uint32_t rmask = (1u << rb_bits) - 1u;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double sink = 0.0;
@@ -134,10 +144,10 @@ __global__ __launch_bounds__(TL_THREADS) void k_gaxpy_tiled(const int32_t *__res
         if (g + TL_WAVES < gend) cb = load_group(tile_key, tile_val, group_info, g + TL_WAVES, lane);
 #define CSX_GATHER(c, xa, xb, xc, xd, xs)                    \
     if (GATHER) {                                            \
-        xa = xs[(c.kk.x >> rb_bits) & CMASK];                \
-        xb = xs[(c.kk.y >> rb_bits) & CMASK];                \
-        xc = xs[(c.kk.z >> rb_bits) & CMASK];                \
-        xd = xs[(c.kk.w >> rb_bits) & CMASK];                \
+        xa = load_x<XLOAD>(xs + ((c.kk.x >> rb_bits) & CMASK)); \
+        xb = load_x<XLOAD>(xs + ((c.kk.y >> rb_bits) & CMASK)); \
+        xc = load_x<XLOAD>(xs + ((c.kk.z >> rb_bits) & CMASK)); \
+        xd = load_x<XLOAD>(xs + ((c.kk.w >> rb_bits) & CMASK)); \
     }
 #define CSX_ACCUM(c, xa, xb, xc, xd)                                                                    \
     {                                                                                                   \
@@ -286,6 +296,7 @@ int gaxpy_tiled_run(const Csc *A, const double *x, double *y) {
     const size_t lds = (((size_t)t->row_block * sizeof(double)) + 15) & ~(size_t)15;
     int variant = 0;
     if (const char *e = std::getenv("CSX_TILED_VARIANT")) variant = std::atoi(e) & 7;
+    if (std::getenv("CSX_TILED_XLOAD")) variant = 5 + std::atoi(std::getenv("CSX_TILED_XLOAD"));  // 1 -> sc1, 2 -> nt
     const int32_t nwg = ctx().cus > 0 ? ctx().cus : 256;
     const unsigned grid = (unsigned)(t->nrb < nwg ? t->nrb : nwg);
 #define CSX_TILED_LAUNCH(V)                                                                                          \
@@ -303,6 +314,8 @@ int gaxpy_tiled_run(const Csc *A, const double *x, double *y) {
         CSX_TILED_LAUNCH(3)
         CSX_TILED_LAUNCH(4)
         CSX_TILED_LAUNCH(5)
+        CSX_TILED_LAUNCH(6)
+        CSX_TILED_LAUNCH(7)
         default: return CSX_EINVAL;
     }
 #undef CSX_TILED_LAUNCH

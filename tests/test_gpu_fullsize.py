@@ -33,13 +33,13 @@ def test_gaxpy_5m_modes_agree_and_are_linear(cs, lib):
     x = _vec(hx, n)
     results = {}
     for name, mode in (("exact", cs.GAXPY_EXACT), ("wave", cs.GAXPY_WAVE), ("tiled", cs.GAXPY_TILED),
-                       ("atomic", cs.GAXPY_ATOMIC)):
+                       ("atomic", cs.GAXPY_ATOMIC), ("auto", cs.GAXPY_AUTO)):
         y = cs.dvec(n)
         _csx.check(lib.csx_gaxpy(hA, x.handle, y.handle, mode))
         results[name] = y.numpy()
     ref = results["exact"]  # reference summation order
     assert np.all(np.isfinite(ref)) and ref.min() > 0          # all-positive data: every row sum positive
-    for name in ("wave", "tiled", "atomic"):
+    for name in ("wave", "tiled", "atomic", "auto"):
         assert np.max(np.abs(results[name] - ref) / ref) < 1e-12, name
     # total mass: 1' (A x) = sum_j x_j * colsum_j; column sums via y = A' 1 computed as gaxpy on the transpose
     hT = _csx.new_handle()
