@@ -71,8 +71,6 @@ void free_tiled(TiledPlan *t) {
     dfree(t->tile_len);
     dfree(t->tile_key);
     dfree(t->tile_val);
-    dfree(t->partial);
-    dfree(t->queue);
     delete t;
 }
 

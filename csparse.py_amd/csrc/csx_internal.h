@@ -44,20 +44,17 @@ struct Gather {
     double *val = nullptr;
 };
 
-// LDS-tiled SpMV plan (csx_gaxpy.hip): entries regrouped into tiles of
-// (column slab, row block); within a tile entries stay in column order.
+// LDS-resident SpMV plan (csx_gaxpy_tiled.hip): entries regrouped into (row block, column slab)
+// tiles, row-block-major, column order kept inside a tile, stored in interleaved groups of 256.
 struct TiledPlan {
-    int32_t row_block = 0;     // rows per LDS tile
-    int32_t nrb = 0;           // number of row blocks
-    int32_t nslab = 0;         // number of column slabs
-    int32_t slab_cols = 0;     // columns per slab
-    int32_t ngroup = 0;        // slab groups (partial-y buffers)
-    int32_t *tile_ptr = nullptr;   // [ntiles + 1] padded start of every tile (multiple of the group size)
-    int32_t *tile_len = nullptr;   // [ntiles] true number of entries
+    int32_t row_block = 0;         // rows per LDS tile (one tile per workgroup)
+    int32_t nrb = 0;               // number of row blocks
+    int32_t nslab = 0;             // number of column slabs
+    int32_t slab_cols = 0;         // columns per slab
+    int32_t *tile_ptr = nullptr;   // [nrb + 1] first group of every row block
+    int32_t *tile_len = nullptr;   // [ngroups] group info: (slab << 9) | entries in the group
     uint32_t *tile_key = nullptr;  // packed (local col << rb_bits) | local row
     double *tile_val = nullptr;
-    double *partial = nullptr;     // [ngroup][nrb*row_block]
-    int32_t *queue = nullptr;      // work counters
     int rb_bits = 0;
 };
 

@@ -179,8 +179,9 @@ __global__ __launch_bounds__(SG_THREADS) void k_spgemm(int kind, int slots, int3
                 // stage the segment: column ids, B values, lengths -> exclusive offsets
                 for (int k = threadIdx.x; k < nseg; k += SG_THREADS) {
                     const int32_t c = Bi[s0 + k];
-                    seg_col[k] = c;
-                    seg_off[k] = (uint32_t)(Ap[c + 1] - Ap[c]);
+                    const int32_t ab = Ap[c];
+                    seg_col[k] = ab;  // start of A(:, c): saves a dependent load per product
+                    seg_off[k] = (uint32_t)(Ap[c + 1] - ab);
                     if (VALUES) seg_bx[k] = Bx[s0 + k];
                 }
                 __syncthreads();
@@ -211,12 +212,16 @@ __global__ __launch_bounds__(SG_THREADS) void k_spgemm(int kind, int slots, int3
                 }
                 __syncthreads();
                 const uint32_t nprod = seg_off[SG_SEG];
-                for (uint32_t c0 = 0; c0 < nprod; c0 += SG_THREADS) {
-                    const uint32_t tl = c0 + threadIdx.x;
-                    const bool live = tl < nprod;
-                    uint32_t row = 0;
-                    double prod = 0.0;
-                    if (live) {
+                // four 256-wide chunks of products per step: their (row, value) loads are issued
+                // back to back (clamped indices, so no branch), then consumed in product order
+                constexpr int UN = 4;
+                for (uint32_t c0 = 0; c0 < nprod; c0 += UN * SG_THREADS) {
+                    uint32_t rows_[UN];
+                    double prods_[UN];
+#pragma unroll
+                    for (int u = 0; u < UN; u++) {
+                        uint32_t tl = c0 + u * SG_THREADS + threadIdx.x;
+                        if (tl >= nprod) tl = nprod - 1;
                         // which entry of the segment owns product tl: last k with seg_off[k] <= tl
                         int lo = 0, hi = nseg - 1;
                         while (lo < hi) {
@@ -224,37 +229,45 @@ __global__ __launch_bounds__(SG_THREADS) void k_spgemm(int kind, int slots, int3
                             if (seg_off[mid] <= tl) lo = mid;
                             else hi = mid - 1;
                         }
-                        const int32_t q = Ap[seg_col[lo]] + (int32_t)(tl - seg_off[lo]);
-                        row = (uint32_t)Ai[q];
-                        if (NUMERIC && VALUES && pass == 0) prod = seg_bx[lo] * Ax[q];
+                        const int32_t q = seg_col[lo] + (int32_t)(tl - seg_off[lo]);
+                        rows_[u] = (uint32_t)Ai[q];
+                        prods_[u] = (NUMERIC && VALUES && pass == 0) ? seg_bx[lo] * Ax[q] : 0.0;
                     }
-                    const uint32_t t = tbase + tl;
-                    if (reset_pass) {
-                        if (live) {
-                            a.tmin[row] = SG_UNSET;
-                            if (NUMERIC && VALUES) a.val[row] = 0.0;
+#pragma unroll
+                    for (int u = 0; u < UN; u++) {
+                        const uint32_t tl = c0 + u * SG_THREADS + threadIdx.x;
+                        if (c0 + u * SG_THREADS >= nprod) break;  // uniform
+                        const bool live = tl < nprod;
+                        const uint32_t row = rows_[u];
+                        const double prod = prods_[u];
+                        const uint32_t t = tbase + tl;
+                        if (reset_pass) {
+                            if (live) {
+                                a.tmin[row] = SG_UNSET;
+                                if (NUMERIC && VALUES) a.val[row] = 0.0;
+                            }
+                        } else if (pass == 0) {
+                            if (live) {
+                                const uint32_t slot = acc_slot(a, row);
+                                const uint32_t old = atomicMin(&a.tmin[slot], t);
+                                if (!NUMERIC && old == SG_UNSET) atomicAdd(&misc[8], 1);
+                                if (NUMERIC && VALUES) unsafeAtomicAdd(&a.val[slot], prod);
+                            }
+                        } else {  // pass B
+                            uint32_t slot = 0;
+                            bool first = false;
+                            if (live) {
+                                slot = acc_find(a, row);
+                                first = a.tmin[slot] == t;
+                            }
+                            int tot;
+                            const int pos = out_base + prefix_count(first, misc, &tot);
+                            if (first) {
+                                Ci[Cp[j] + pos] = (int32_t)row;
+                                if (VALUES) Cx[Cp[j] + pos] = a.val[slot];
+                            }
+                            out_base += tot;
                         }
-                    } else if (pass == 0) {
-                        if (live) {
-                            const uint32_t slot = acc_slot(a, row);
-                            const uint32_t old = atomicMin(&a.tmin[slot], t);
-                            if (!NUMERIC && old == SG_UNSET) atomicAdd(&misc[8], 1);
-                            if (NUMERIC && VALUES) unsafeAtomicAdd(&a.val[slot], prod);
-                        }
-                    } else {  // pass B
-                        uint32_t slot = 0;
-                        bool first = false;
-                        if (live) {
-                            slot = acc_find(a, row);
-                            first = a.tmin[slot] == t;
-                        }
-                        int tot;
-                        const int pos = out_base + prefix_count(first, misc, &tot);
-                        if (first) {
-                            Ci[Cp[j] + pos] = (int32_t)row;
-                            if (VALUES) Cx[Cp[j] + pos] = a.val[slot];
-                        }
-                        out_base += tot;
                     }
                 }
                 tbase += nprod;
