@@ -38,6 +38,7 @@ constexpr int TL_THREADS = 1024;
 constexpr int TL_WAVES = TL_THREADS / 64;
 constexpr int TL_GROUP = 256;                   // entries per group = 64 lanes x 4
 constexpr int TL_LDS_BYTES = 160 * 1024 - 256;  // leave a little headroom below the CU's 160 KiB
+constexpr int TL_LDS_ROWS = TL_LDS_BYTES / 8 - 2;  // y rows per tile (one slot is the padding dummy)
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
@@ -81,9 +82,21 @@ __global__ __launch_bounds__(256) void k_interleave(int64_t nnz, const uint32_t 
     const uint32_t t = stid[q];
     const int32_t e = (int32_t)(q - sptr[t]);
     const int32_t g = e / TL_GROUP, w = e % TL_GROUP;
-    const int64_t pos = ((int64_t)gptr[t] + g) * TL_GROUP + (w & 63) * 4 + (w >> 6);
-    okey[pos] = skey[q];
-    oval[pos] = sval[q];
+    // entry w of a group goes to lane l = w & 63, component k = w >> 6.  Keys: lane l's 16-byte
+    // word (slots 4l..4l+3).  Values: two planes of 128 doubles, plane k >> 1, lane l's 16-byte
+    // word (slots 2l, 2l+1) -- so that EACH value load instruction of a wave covers one contiguous
+    // 1 KiB (whole 128-byte lines).  With values at slots 4l..4l+3 each instruction touched only
+    // half of every line and issued twice as many (64-byte) requests.
+    const int64_t gbase = ((int64_t)gptr[t] + g) * TL_GROUP;
+    const int l = w & 63, k = w >> 6;
+    okey[gbase + l * 4 + k] = skey[q];
+    oval[gbase + (k >> 1) * 128 + l * 2 + (k & 1)] = sval[q];
+}
+
+__global__ __launch_bounds__(256) void k_fill_keys(uint32_t *p, int64_t n, uint32_t v) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = v;
 }
 
 struct GroupRegs {
@@ -92,13 +105,20 @@ struct GroupRegs {
     uint32_t info;
 };
 
-__device__ __forceinline__ GroupRegs load_group(const uint32_t *__restrict__ key, const double *__restrict__ val,
-                                                const uint32_t *__restrict__ info, int32_t g, int lane) {
+template <bool NT>
+__device__ __forceinline__ GroupRegs load_group_t(const uint32_t *__restrict__ key, const double *__restrict__ val,
+                                                  const uint32_t *__restrict__ info, int32_t g, int lane) {
     GroupRegs r;
-    const int64_t pos = (int64_t)g * TL_GROUP + 4 * lane;
-    r.kk = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(key + pos));
-    r.v0 = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(val + pos));
-    r.v1 = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(val + pos + 2));
+    const int64_t gb = (int64_t)g * TL_GROUP;
+    if (NT) {
+        r.kk = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(key + gb + 4 * lane));
+        r.v0 = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(val + gb + 2 * lane));
+        r.v1 = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(val + gb + 128 + 2 * lane));
+    } else {
+        r.kk = *reinterpret_cast<const u32x4 *>(key + gb + 4 * lane);
+        r.v0 = *reinterpret_cast<const f64x2 *>(val + gb + 2 * lane);
+        r.v1 = *reinterpret_cast<const f64x2 *>(val + gb + 128 + 2 * lane);
+    }
     r.info = info[g];
     return r;
 }
@@ -112,9 +132,11 @@ __device__ __forceinline__ double load_x(const double *p) {
 }
 
 // VARIANT bits (timing experiments only; results are wrong unless VARIANT == 0):
-//   1 = skip the x gather, 2 = skip the LDS accumulation, 4 = gather from a 2 KB footprint (L1 hits),
+//   1 = skip the x gather, 2 = full kernel with plain instead of nt stream loads, 3 = stream only,
+//   4 = gather from a 2 KB footprint (L1 hits),
 //   5 = gather from a 256 KB footprint (L2 hits, L1 misses)
-//   6 = full kernel, x gathered with L1-bypassing sc1 loads; 7 = same with nt loads (both compute y)
+//   6 = full kernel, x gathered with L1-bypassing sc1 loads (computes y)
+//   7 = real x gathers, but the entry stream re-reads the first 32 groups of the row block (L2-resident)
 template <int VARIANT>
 __global__ __launch_bounds__(TL_THREADS) void k_gaxpy_tiled(const int32_t *__restrict__ rb_gptr,
                                                             const uint32_t *__restrict__ group_info,
@@ -124,9 +146,12 @@ __global__ __launch_bounds__(TL_THREADS) void k_gaxpy_tiled(const int32_t *__res
                                                             int32_t m, int32_t nrb, int32_t row_block,
                                                             int32_t slab_cols, int rb_bits) {
     extern __shared__ __attribute__((aligned(16))) double ytile[];  // row_block doubles
-    constexpr bool GATHER = !(VARIANT & 1) || VARIANT >= 5, ATOMIC = !(VARIANT & 2) || VARIANT >= 6;
+    constexpr bool GATHER = !(VARIANT & 1) || VARIANT >= 5, ATOMIC = VARIANT != 3;
+    constexpr bool STREAM_NT = VARIANT != 2;  // variant 2: full kernel with plain (L1-allocating) stream loads
+#define load_group load_group_t<STREAM_NT>
     constexpr uint32_t CMASK = VARIANT == 5 ? 32767u : (VARIANT == 4 ? 255u : 0xffffffffu);
-    constexpr int XLOAD = VARIANT == 6 ? 1 : (VARIANT == 7 ? 2 : 0);
+    constexpr int XLOAD = VARIANT == 6 ? 1 : 0;
+    constexpr bool RING = VARIANT == 7;
     const uint32_t rmask = (1u << rb_bits) - 1u;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double sink = 0.0;
@@ -136,53 +161,69 @@ __global__ __launch_bounds__(TL_THREADS) void k_gaxpy_tiled(const int32_t *__res
         for (int k = threadIdx.x; k < rows; k += TL_THREADS) ytile[k] = y[row0 + k];
         __syncthreads();
         const int32_t gend = rb_gptr[rb + 1];
-        // Each wave walks its groups two at a time (g and g + TL_WAVES): 8 gathers and the next
-        // pair's 6 stream loads are in flight per lane.
-        int32_t g = rb_gptr[rb] + wave;
-        GroupRegs ca, cb;
-        if (g < gend) ca = load_group(tile_key, tile_val, group_info, g, lane);
-        if (g + TL_WAVES < gend) cb = load_group(tile_key, tile_val, group_info, g + TL_WAVES, lane);
-#define CSX_GATHER(c, xa, xb, xc, xd, xs)                    \
-    if (GATHER) {                                            \
-        xa = load_x<XLOAD>(xs + ((c.kk.x >> rb_bits) & CMASK)); \
-        xb = load_x<XLOAD>(xs + ((c.kk.y >> rb_bits) & CMASK)); \
-        xc = load_x<XLOAD>(xs + ((c.kk.z >> rb_bits) & CMASK)); \
-        xd = load_x<XLOAD>(xs + ((c.kk.w >> rb_bits) & CMASK)); \
+        const int32_t g0 = rb_gptr[rb];
+        // Each wave walks its groups two at a time (g and g + TL_WAVES) with two register sets
+        // used alternately (no copies): while set A is gathered and accumulated, set B's entries
+        // are in flight.  Prefetch indices are clamped to the last group instead of predicated,
+        // and padding entries point at a dummy LDS row, so the loop body is branch-free.
+#define CSX_GIDX(gg) (RING ? g0 + (((gg) - g0) & 31) : (gg))
+#define CSX_LOADPAIR(ra, rb2, gg)                                                                          \
+    {                                                                                                      \
+        const int32_t ga_ = (gg) < gend ? (gg) : gend - 1;                                                 \
+        const int32_t gb_ = (gg) + TL_WAVES < gend ? (gg) + TL_WAVES : gend - 1;                           \
+        ra = load_group(tile_key, tile_val, group_info, CSX_GIDX(ga_), lane);                              \
+        rb2 = load_group(tile_key, tile_val, group_info, CSX_GIDX(gb_), lane);                             \
     }
-#define CSX_ACCUM(c, xa, xb, xc, xd)                                                                    \
-    {                                                                                                   \
-        const uint32_t cnt = c.info & 511u;                                                             \
-        if (ATOMIC) {                                                                                   \
-            if ((uint32_t)lane < cnt) unsafeAtomicAdd(&ytile[c.kk.x & rmask], c.v0.x * xa);             \
-            if ((uint32_t)(64 + lane) < cnt) unsafeAtomicAdd(&ytile[c.kk.y & rmask], c.v0.y * xb);      \
-            if ((uint32_t)(128 + lane) < cnt) unsafeAtomicAdd(&ytile[c.kk.z & rmask], c.v1.x * xc);     \
-            if ((uint32_t)(192 + lane) < cnt) unsafeAtomicAdd(&ytile[c.kk.w & rmask], c.v1.y * xd);     \
-        } else {                                                                                        \
-            sink += c.v0.x * xa + c.v0.y * xb + c.v1.x * xc + c.v1.y * xd +                             \
-                    (double)((c.kk.x ^ c.kk.y ^ c.kk.z ^ c.kk.w) & 1u);                                 \
-        }                                                                                               \
+#define CSX_GATHER(c, xa, xb, xc, xd)                                    \
+    {                                                                    \
+        const double *xs_ = x + (int64_t)(c.info >> 9) * slab_cols;      \
+        if (GATHER) {                                                    \
+            xa = load_x<XLOAD>(xs_ + ((c.kk.x >> rb_bits) & CMASK));     \
+            xb = load_x<XLOAD>(xs_ + ((c.kk.y >> rb_bits) & CMASK));     \
+            xc = load_x<XLOAD>(xs_ + ((c.kk.z >> rb_bits) & CMASK));     \
+            xd = load_x<XLOAD>(xs_ + ((c.kk.w >> rb_bits) & CMASK));     \
+        }                                                                \
     }
-        while (g < gend) {
-            const bool two = g + TL_WAVES < gend;
-            const int32_t gn = g + 2 * TL_WAVES;
-            const double *xsa = x + (int64_t)(ca.info >> 9) * slab_cols;
-            double a0 = 1.0, a1 = 1.0, a2 = 1.0, a3 = 1.0, b0 = 1.0, b1 = 1.0, b2 = 1.0, b3 = 1.0;
-            CSX_GATHER(ca, a0, a1, a2, a3, xsa)  // padding slots carry key 0: a valid address, result unused
-            if (two) {
-                const double *xsb = x + (int64_t)(cb.info >> 9) * slab_cols;
-                CSX_GATHER(cb, b0, b1, b2, b3, xsb)
+#define CSX_ACCUM(c, xa, xb, xc, xd)                                                        \
+    {                                                                                       \
+        if (ATOMIC) {                                                                       \
+            unsafeAtomicAdd(&ytile[c.kk.x & rmask], c.v0.x * xa);                           \
+            unsafeAtomicAdd(&ytile[c.kk.y & rmask], c.v0.y * xb);                           \
+            unsafeAtomicAdd(&ytile[c.kk.z & rmask], c.v1.x * xc);                           \
+            unsafeAtomicAdd(&ytile[c.kk.w & rmask], c.v1.y * xd);                           \
+        } else {                                                                            \
+            sink += c.v0.x * xa + c.v0.y * xb + c.v1.x * xc + c.v1.y * xd +                 \
+                    (double)((c.kk.x ^ c.kk.y ^ c.kk.z ^ c.kk.w) & 1u);                     \
+        }                                                                                   \
+    }
+#define CSX_STEP(ca, cb, na, nb)                                                                          \
+    {                                                                                                     \
+        const bool two_ = g + TL_WAVES < gend;                                                            \
+        double a0 = 1.0, a1 = 1.0, a2 = 1.0, a3 = 1.0, b0 = 1.0, b1 = 1.0, b2 = 1.0, b3 = 1.0;            \
+        CSX_GATHER(ca, a0, a1, a2, a3)                                                                    \
+        if (two_) CSX_GATHER(cb, b0, b1, b2, b3)                                                          \
+        CSX_LOADPAIR(na, nb, g + 2 * TL_WAVES) /* behind the gathers */                                   \
+        CSX_ACCUM(ca, a0, a1, a2, a3)                                                                     \
+        if (two_) CSX_ACCUM(cb, b0, b1, b2, b3)                                                           \
+        g += 2 * TL_WAVES;                                                                                \
+    }
+        int32_t g = g0 + wave;
+        if (g < gend) {
+            GroupRegs pa, pb, qa, qb;
+            CSX_LOADPAIR(pa, pb, g)
+            for (;;) {
+                CSX_STEP(pa, pb, qa, qb)
+                if (g >= gend) break;
+                CSX_STEP(qa, qb, pa, pb)
+                if (g >= gend) break;
             }
-            GroupRegs na = ca, nb = cb;
-            if (gn < gend) na = load_group(tile_key, tile_val, group_info, gn, lane);  // behind the gathers
-            if (gn + TL_WAVES < gend) nb = load_group(tile_key, tile_val, group_info, gn + TL_WAVES, lane);
-            CSX_ACCUM(ca, a0, a1, a2, a3)
-            if (two) CSX_ACCUM(cb, b0, b1, b2, b3)
-            g = gn;
-            ca = na;
-            cb = nb;
         }
+#undef CSX_STEP
 #undef CSX_GATHER
 #undef CSX_ACCUM
+#undef CSX_LOADPAIR
+#undef CSX_GIDX
+#undef load_group
         __syncthreads();
         if (!ATOMIC && sink == 12345.678) ytile[0] = sink;  // keep the ablated arithmetic alive
         for (int k = threadIdx.x; k < rows; k += TL_THREADS) y[row0 + k] = ytile[k];
@@ -202,7 +243,7 @@ int gaxpy_tiled_prepare(Csc *A) {
     hipStream_t s = ctx().stream;
     // one row block per workgroup, one workgroup per CU; more rounds only if a block would not fit LDS
     const int32_t nwg = ctx().cus > 0 ? ctx().cus : 256;
-    const int32_t cap = TL_LDS_BYTES / 8;
+    const int32_t cap = TL_LDS_ROWS;
     int32_t rounds = 1;
     int32_t row_block;
     for (;;) {
@@ -214,7 +255,7 @@ int gaxpy_tiled_prepare(Csc *A) {
     if (row_block < 1) row_block = 1;
     const int32_t nrb = (int32_t)(((int64_t)A->m + row_block - 1) / row_block);
     int rb_bits = 1;
-    while ((1 << rb_bits) < row_block) rb_bits++;
+    while ((1 << rb_bits) <= row_block) rb_bits++;  // local row index row_block itself = dummy slot for padding
     double slab_kb = 1024.0;
     if (const char *e = std::getenv("CSX_TILED_SLAB_KB")) slab_kb = std::atof(e) >= 8.0 ? std::atof(e) : slab_kb;
     int64_t slab_cols = (int64_t)(slab_kb * 1024 / 8);
@@ -263,7 +304,9 @@ int gaxpy_tiled_prepare(Csc *A) {
     if (st == CSX_OK) st = dalloc(&t->tile_key, (size_t)ngroups * TL_GROUP);
     if (st == CSX_OK) st = dalloc(&t->tile_val, (size_t)ngroups * TL_GROUP);
     if (st == CSX_OK && ngroups > 0) {
-        (void)hipMemsetAsync(t->tile_key, 0, (size_t)ngroups * TL_GROUP * sizeof(uint32_t), s);
+        // padding slots: column 0 of the slab, dummy row, value 0 -> adds 0 * x into an unused LDS slot
+        hipLaunchKernelGGL(k_fill_keys, dim3(2048), dim3(256), 0, s, t->tile_key, (int64_t)ngroups * TL_GROUP,
+                           (uint32_t)row_block);
         (void)hipMemsetAsync(t->tile_val, 0, (size_t)ngroups * TL_GROUP * sizeof(double), s);
         hipLaunchKernelGGL(k_group_info, dim3(tb), dim3(256), 0, s, ntiles, nslab, sptr, gptr, (uint32_t *)t->tile_len);
         hipLaunchKernelGGL(k_interleave, dim3((unsigned)(((int64_t)A->nnz + 255) / 256)), dim3(256), 0, s,
@@ -293,7 +336,7 @@ int gaxpy_tiled_prepare(Csc *A) {
 int gaxpy_tiled_run(const Csc *A, const double *x, double *y) {
     const TiledPlan *t = A->tiled;
     hipStream_t s = ctx().stream;
-    const size_t lds = (((size_t)t->row_block * sizeof(double)) + 15) & ~(size_t)15;
+    const size_t lds = (((size_t)(t->row_block + 1) * sizeof(double)) + 15) & ~(size_t)15;  // + dummy row
     int variant = 0;
     if (const char *e = std::getenv("CSX_TILED_VARIANT")) variant = std::atoi(e) & 7;
     if (std::getenv("CSX_TILED_XLOAD")) variant = 5 + std::atoi(std::getenv("CSX_TILED_XLOAD"));  // 1 -> sc1, 2 -> nt
