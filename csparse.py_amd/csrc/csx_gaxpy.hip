@@ -50,14 +50,33 @@ __global__ __launch_bounds__(256) void k_gaxpy_rows(int32_t rows, const int32_t 
     const int sub = threadIdx.x & (G - 1);
     const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) / G;
+    // row pointers are fetched one step ahead (they head the dependent chain ptr -> idx/val -> x)
+    int32_t nb[U], ne[U];
+    {
+        const int64_t r0 = group * U;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int64_t r = r0 + u < rows ? r0 + u : rows - 1;
+            nb[u] = r0 < rows ? ptr[r] : 0;
+            ne[u] = (r0 < rows && r0 + u < rows) ? ptr[r + 1] : nb[u];
+        }
+    }
     for (int64_t r0 = group * U; r0 < rows; r0 += ngroups * U) {
         int32_t b[U], e[U], c[U];
         double v[U], acc[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const int64_t r = r0 + u < rows ? r0 + u : rows - 1;
-            b[u] = ptr[r];
-            e[u] = r0 + u < rows ? ptr[r + 1] : b[u];
+            b[u] = nb[u];
+            e[u] = ne[u];
+        }
+        {
+            const int64_t rn = r0 + ngroups * U;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int64_t r = rn + u < rows ? rn + u : rows - 1;
+                nb[u] = ptr[r];
+                ne[u] = rn + u < rows ? ptr[r + 1] : nb[u];
+            }
         }
         // the y value this lane will update (lane u of the group owns row r0 + u): requested early
         const bool owner = sub < U && r0 + sub < rows;

@@ -242,7 +242,9 @@ int gaxpy_tiled_prepare(Csc *A) {
     if (!A->x) return CSX_EINVAL;
     hipStream_t s = ctx().stream;
     // one row block per workgroup, one workgroup per CU; more rounds only if a block would not fit LDS
-    const int32_t nwg = ctx().cus > 0 ? ctx().cus : 256;
+    int wg_per_cu = 1;
+    if (const char *e = std::getenv("CSX_TILED_WG_PER_CU")) wg_per_cu = std::atoi(e) == 2 ? 2 : 1;
+    const int32_t nwg = (ctx().cus > 0 ? ctx().cus : 256) * wg_per_cu;
     const int32_t cap = TL_LDS_ROWS;
     int32_t rounds = 1;
     int32_t row_block;
@@ -340,7 +342,9 @@ int gaxpy_tiled_run(const Csc *A, const double *x, double *y) {
     int variant = 0;
     if (const char *e = std::getenv("CSX_TILED_VARIANT")) variant = std::atoi(e) & 7;
     if (std::getenv("CSX_TILED_XLOAD")) variant = 5 + std::atoi(std::getenv("CSX_TILED_XLOAD"));  // 1 -> sc1, 2 -> nt
-    const int32_t nwg = ctx().cus > 0 ? ctx().cus : 256;
+    int wg_per_cu = 1;
+    if (const char *e = std::getenv("CSX_TILED_WG_PER_CU")) wg_per_cu = std::atoi(e) == 2 ? 2 : 1;
+    const int32_t nwg = (ctx().cus > 0 ? ctx().cus : 256) * wg_per_cu;
     const unsigned grid = (unsigned)(t->nrb < nwg ? t->nrb : nwg);
 #define CSX_TILED_LAUNCH(V)                                                                                          \
     case V: {                                                                                                        \
