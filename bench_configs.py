@@ -204,15 +204,19 @@ def transpose_grand(n=5000000, per_col=64):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-spgemm", action="store_true")
+    ap.add_argument("--only", default=None, help="run one section: spmv | lusolve | spgemm | transpose")
     ap.add_argument("--skip-transpose", action="store_true")
     a = ap.parse_args()
     _csx.init()
     print(json.dumps({"device": _csx.device_info()}))
-    print(json.dumps(config2()))
-    print(json.dumps(config3()))
-    if not a.skip_transpose:
+    want = lambda name: a.only in (None, name)
+    if want("spmv"):
+        print(json.dumps(config2()))
+    if want("lusolve"):
+        print(json.dumps(config3()))
+    if want("transpose") and not a.skip_transpose:
         print(json.dumps(transpose_grand()))
-    if not a.skip_spgemm:
+    if want("spgemm") and not a.skip_spgemm:
         print(json.dumps(config4()))
 
 

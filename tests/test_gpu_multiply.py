@@ -101,3 +101,42 @@ def test_multiply_one_huge_column_uses_global_accumulator(cs):
     Cp2, Ci2, Cx2 = CO.multiply(m2, m2, 1, Ap2, Ai2, Ax2, Bp2, Bi2, Bx2)
     _, _, Sx2 = CO.multiply(m2, m2, 1, Ap2, Ai2, np.abs(Ax2), Bp2, Bi2, np.abs(Bx2))
     check_product(C2, Cp2, Ci2, Cx2, Sx2)
+
+
+def _ragged(rng, m, n, lens):
+    """CSC with the given column lengths; rows unsorted, duplicates within a column allowed."""
+    p = np.zeros(n + 1, np.int32)
+    p[1:] = np.cumsum(lens)
+    i = rng.integers(0, m, size=int(p[-1])).astype(np.int32)
+    x = rng.uniform(-1.0, 1.0, size=int(p[-1]))
+    return p, i, x
+
+
+@pytest.mark.parametrize("two_pass", [False, True])
+def test_multiply_ragged_columns_hash_bins(cs, two_pass, monkeypatch):
+    """m > 8192 with ragged shapes: A columns longer than one 32-lane chunk (and empty ones), B columns
+    longer than one staged segment, duplicate rows inside a column, all four hash table sizes.  Both the
+    one-pass kernel (bitmap ranking) and the two-pass kernel must reproduce the reference's column order."""
+    if two_pass:
+        monkeypatch.setenv("CSX_SPGEMM_TWO_PASS", "1")
+    rng = np.random.default_rng(20240611)
+    m, k, n = 12000, 3000, 400
+    alen = rng.integers(0, 90, size=k)
+    alen[rng.integers(0, k, size=200)] = 0
+    short = np.flatnonzero(alen <= 6)
+    Ap, Ai, Ax = _ragged(rng, m, k, alen)
+    blen = rng.integers(0, 40, size=n)
+    blen[:6] = [300, 280, 1, 0, 513, 2]
+    blen[6:11] = [70, 70, 60, 75, 130]                    # 2048 < P <= 4096 (largest table) and one global-bin column
+    Bp, Bi, Bx = _ragged(rng, k, n, blen)
+    for j in (0, 1, 4):                                   # long B columns name short A columns: P stays <= 4096
+        Bi[Bp[j]:Bp[j + 1]] = rng.choice(short, size=blen[j])
+    Cp, Ci, Cx = CO.multiply(m, k, n, Ap, Ai, Ax, Bp, Bi, Bx)
+    _, _, Sx = CO.multiply(m, k, n, Ap, Ai, np.abs(Ax), Bp, Bi, np.abs(Bx))
+    prods = np.array([int(np.sum(alen[Bi[Bp[j]:Bp[j + 1]]])) for j in range(n)])
+    assert ((prods > 2048) & (prods <= 4096)).any() and prods.max() > 4096 and (prods[[0, 1, 4]] > 0).all()
+    check_product(cs.cs_multiply(_host_cs(cs, m, k, Ap, Ai, Ax), _host_cs(cs, k, n, Bp, Bi, Bx)), Cp, Ci, Cx, Sx)
+    A0, B0 = _host_cs(cs, m, k, Ap, Ai, Ax), _host_cs(cs, k, n, Bp, Bi, Bx)
+    A0.x = None
+    C0 = cs.cs_multiply(A0, B0)                           # pattern only
+    assert C0.x is None and C0.p == Cp.tolist() and C0.i[:int(Cp[-1])] == Ci.tolist()
