@@ -24,6 +24,8 @@ _PROTOS = {
     "csx_sync": [],
     "csx_set_stream": [_vp],
     "csx_device_info": [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)],
+    "csx_mem_trim": [],
+    "csx_mem_info": [C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
     "csx_timer_start": [],
     "csx_timer_stop": [_f64p],
     "csx_csc_upload": [C.c_int32, C.c_int32, _i32p, _i32p, _f64p, C.POINTER(H)],

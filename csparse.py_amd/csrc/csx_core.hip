@@ -1,7 +1,10 @@
 // Context, handles, host<->device transfers, timers.
 #include <cstdarg>
+#include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
+#include <unordered_map>
 
 #include "csx_internal.h"
 
@@ -47,14 +50,116 @@ void *get(csx_handle_t h, Kind k) {
     return o.kind == k ? o.ptr : nullptr;
 }
 
+// ---- device memory: a caching allocator -------------------------------------------------------------
+// hipMalloc / hipFree of multi-GB blocks cost milliseconds and hipFree synchronises the device, which
+// would dominate the short operations here (a transpose or product allocates several work arrays).
+// Freed blocks are kept on a free list keyed by size and handed out again; every use of device memory in
+// this library is ordered on the context's single stream (csx_set_stream synchronises when it changes),
+// so a block can be reused as soon as the host has released it.  The cache is capped (default: a quarter
+// of the device's memory, CSX_POOL_LIMIT_MB overrides, CSX_NO_POOL=1 disables) and emptied when an
+// allocation fails.
+namespace {
+struct Pool {
+    std::mutex mu;
+    std::multimap<size_t, void *> idle;          // size -> block
+    std::unordered_map<void *, size_t> size_of;  // every block handed out or idle
+    size_t cached = 0, live = 0, limit = 0;
+    bool enabled = true, configured = false;
+};
+Pool g_pool;
+
+size_t pool_round(size_t bytes) {
+    if (bytes < 512) return 512;
+    if (bytes <= (1u << 20)) {
+        size_t r = 512;
+        while (r < bytes) r <<= 1;
+        return r;
+    }
+    const size_t g = (size_t)2 << 20;
+    return (bytes + g - 1) / g * g;
+}
+
+void pool_configure() {
+    if (g_pool.configured) return;
+    g_pool.configured = true;
+    g_pool.enabled = !getenv("CSX_NO_POOL");
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) total_b = (size_t)64 << 30;
+    g_pool.limit = total_b / 4;
+    if (const char *e = getenv("CSX_POOL_LIMIT_MB")) g_pool.limit = (size_t)strtoull(e, nullptr, 10) << 20;
+}
+
+void pool_release_locked() {
+    for (auto &kv : g_pool.idle) {
+        g_pool.size_of.erase(kv.second);
+        (void)hipFree(kv.second);
+    }
+    g_pool.idle.clear();
+    g_pool.cached = 0;
+}
+}  // namespace
+
+void pool_trim() {
+    std::lock_guard<std::mutex> lock(g_pool.mu);
+    pool_release_locked();
+}
+
+void pool_stats(size_t *cached, size_t *live) {
+    std::lock_guard<std::mutex> lock(g_pool.mu);
+    if (cached) *cached = g_pool.cached;
+    if (live) *live = g_pool.live;
+}
+
 int dmalloc(void **p, size_t bytes) {
     *p = nullptr;
-    CSX_HIP(hipMalloc(p, bytes ? bytes : 16));
+    std::lock_guard<std::mutex> lock(g_pool.mu);
+    pool_configure();
+    const size_t want = pool_round(bytes);
+    if (g_pool.enabled) {
+        auto it = g_pool.idle.lower_bound(want);
+        if (it != g_pool.idle.end() && it->first <= want + want / 4) {   // at most 25 % slack
+            *p = it->second;
+            g_pool.cached -= it->first;
+            g_pool.live += it->first;
+            g_pool.idle.erase(it);
+            return CSX_OK;
+        }
+    }
+    hipError_t e = hipMalloc(p, want);
+    if (e != hipSuccess && !g_pool.idle.empty()) {
+        (void)hipGetLastError();
+        (void)hipDeviceSynchronize();
+        pool_release_locked();
+        e = hipMalloc(p, want);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        *p = nullptr;
+        set_error("device allocation of %zu bytes failed: %s", want, hipGetErrorString(e));
+        return CSX_ERUNTIME;
+    }
+    g_pool.size_of[*p] = want;
+    g_pool.live += want;
     return CSX_OK;
 }
 
 void dfree(void *p) {
-    if (p) (void)hipFree(p);
+    if (!p) return;
+    std::lock_guard<std::mutex> lock(g_pool.mu);
+    auto it = g_pool.size_of.find(p);
+    if (it == g_pool.size_of.end()) {   // not ours (never happens for owned blocks); be safe
+        (void)hipFree(p);
+        return;
+    }
+    const size_t sz = it->second;
+    g_pool.live -= sz;
+    if (g_pool.enabled && g_pool.cached + sz <= g_pool.limit) {
+        g_pool.idle.emplace(sz, p);
+        g_pool.cached += sz;
+        return;
+    }
+    g_pool.size_of.erase(it);
+    (void)hipFree(p);
 }
 
 void free_gather(Gather *g) {
@@ -148,6 +253,7 @@ int csx_finalize(void) {
     (void)hipStreamSynchronize(c.stream);
     for (auto &o : c.objects) free_object(o);
     c.objects.clear();
+    pool_trim();
     (void)hipEventDestroy(c.ev0);
     (void)hipEventDestroy(c.ev1);
     (void)hipStreamDestroy(c.own_stream);
@@ -167,6 +273,24 @@ int csx_set_stream(void *hip_stream) {
     CSX_TRY(require_ready());
     CSX_HIP(hipStreamSynchronize(ctx().stream));
     ctx().stream = hip_stream ? (hipStream_t)hip_stream : ctx().own_stream;
+    return CSX_OK;
+}
+
+int csx_mem_trim(void) {
+    CSX_TRY(require_ready());
+    CSX_HIP(hipStreamSynchronize(ctx().stream));
+    pool_trim();
+    return CSX_OK;
+}
+
+int csx_mem_info(int64_t *cached_bytes, int64_t *live_bytes, int64_t *device_free_bytes) {
+    CSX_TRY(require_ready());
+    size_t c = 0, l = 0, f = 0, t = 0;
+    pool_stats(&c, &l);
+    CSX_HIP(hipMemGetInfo(&f, &t));
+    if (cached_bytes) *cached_bytes = (int64_t)c;
+    if (live_bytes) *live_bytes = (int64_t)l;
+    if (device_free_bytes) *device_free_bytes = (int64_t)f;
     return CSX_OK;
 }
 

@@ -106,6 +106,8 @@ int dmalloc(void **p, size_t bytes);
 template <class T>
 inline int dalloc(T **p, size_t count) { return dmalloc((void **)p, count * sizeof(T)); }
 void dfree(void *p);
+void pool_trim();                               // release every idle block to the driver
+void pool_stats(size_t *cached, size_t *live);  // bytes idle in the cache / handed out
 
 void free_gather(Gather *g);
 void free_tiled(TiledPlan *t);

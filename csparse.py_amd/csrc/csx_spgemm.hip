@@ -40,6 +40,13 @@ constexpr int SG_GLOBAL_WGS = 64;     // concurrent workgroups with global accum
 
 enum { ACC_LDS_DENSE = 0, ACC_LDS_HASH = 1, ACC_GLOBAL_DENSE = 2 };
 
+// column bins (sort key): dense LDS accumulator, eight LDS-hash bins by number of products, global accumulator
+constexpr int SG_BIN_DENSE = 0, SG_BIN_HASH0 = 1, SG_HASH_BINS = 8, SG_BIN_GLOBAL = 9, SG_BIN_EMPTY = 15, SG_NBINS = 16;
+constexpr int SG_HASH_MAXP = 4096;
+__host__ __device__ constexpr int sg_hash_limit(int hb) {   // products a column of hash bin hb may have
+    return hb == 0 ? 256 : hb == 1 ? 512 : hb == 2 ? 768 : hb == 3 ? 1024 : hb == 4 ? 1536 : hb == 5 ? 2048 : hb == 6 ? 3072 : 4096;
+}
+
 __global__ __launch_bounds__(256) void k_sg_products(int32_t n, const int32_t *__restrict__ Ap,
                                                      const int32_t *__restrict__ Bp, const int32_t *__restrict__ Bi,
                                                      int32_t m, uint32_t *__restrict__ bin, uint32_t *__restrict__ colid,
@@ -56,21 +63,28 @@ __global__ __launch_bounds__(256) void k_sg_products(int32_t n, const int32_t *_
     for (int d = 32; d > 0; d >>= 1) P += __shfl_xor(P, d, 64);
     if (lane == 0) {
         if (P > 0xFFFFFFF0ull) atomicAdd(too_big, 1ull);
-        const unsigned long long bound = P < (unsigned long long)m ? P : (unsigned long long)m;
         uint32_t b;
-        if (P == 0) b = 7;                       // nothing to do
-        else if (m <= SG_DENSE_MAX) b = 0;       // LDS dense
-        else if (bound <= 512) b = 1;            // hash 1024
-        else if (bound <= 1024) b = 2;           // hash 2048
-        else if (bound <= 2048) b = 3;           // hash 4096
-        else if (bound <= 4096) b = 4;           // hash 8192
-        else b = 5;                              // global dense
+        if (P == 0) b = SG_BIN_EMPTY;
+        else if (m <= SG_DENSE_MAX) b = SG_BIN_DENSE;
+        else if (P > (unsigned long long)SG_HASH_MAXP) b = SG_BIN_GLOBAL;
+        else {
+            b = SG_BIN_HASH0;
+            while ((unsigned long long)sg_hash_limit((int)(b - SG_BIN_HASH0)) < P) b++;
+        }
         bin[j] = b;
         colid[j] = (uint32_t)j;
-        const bool hashed = b >= 1 && b <= 4;
-        hprod[j] = hashed ? (int32_t)P : 0;      // one-pass path: slots reserved in the product-order buffer
-        if (hashed) atomicAdd(too_big + 1, P);
+        hprod[j] = (b >= SG_BIN_HASH0 && b < SG_BIN_HASH0 + SG_HASH_BINS) ? (int32_t)P : 0;
     }
+}
+
+// sum of a non-negative int32 array in 64 bits (few atomics: one per wave of a small grid)
+__global__ __launch_bounds__(256) void k_sum_i32(const int32_t *__restrict__ v, int64_t n, unsigned long long *out) {
+    unsigned long long acc = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        acc += (unsigned long long)v[i];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
 }
 
 struct Acc {
@@ -295,62 +309,105 @@ constexpr int H1_MAXP = 4096;   // products per column (bitmap bits)
 constexpr int H1_UN = 4;        // B entries in flight per 32-lane group
 
 template <bool VALUES>
-__device__ __forceinline__ void h1_insert(uint32_t *keys, uint32_t *tmin, double *val, uint32_t mask, int shift,
-                                          uint32_t row, uint32_t t, double v) {
-    uint32_t s = (row * 0x9E3779B1u) >> shift;
+__device__ __forceinline__ void h1_insert(uint32_t *keys, uint32_t *tmin, double *val, uint32_t slots, uint32_t row,
+                                          uint32_t t, double v) {
+    uint32_t s = __umulhi(row * 0x9E3779B1u, slots);
     for (;;) {
         const uint32_t prev = atomicCAS(&keys[s], SG_UNSET, row);
         if (prev == SG_UNSET || prev == row) break;
-        s = (s + 1) & mask;
+        s = s + 1 == slots ? 0u : s + 1;
     }
     atomicMin(&tmin[s], t);
     if (VALUES) unsafeAtomicAdd(&val[s], v);
 }
 
+// info[k] = (column j, Bp[j], Bp[j+1], offset of the column in the product-order buffer), in bin order
+__global__ __launch_bounds__(256) void k_sg_colinfo(const uint32_t *__restrict__ cols, int32_t ncols,
+                                                    const int32_t *__restrict__ Bp, const int32_t *__restrict__ toff,
+                                                    int4 *__restrict__ info) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ncols) return;
+    const int32_t j = (int32_t)cols[k];
+    info[k] = make_int4(j, Bp[j], Bp[j + 1], toff[j]);
+}
+
+// Persistent workgroups, columns ci = blockIdx.x, + gridDim.x, ...  The loads a column needs before its
+// products can be gathered (its descriptor, its B entries, the A column extents they name) are issued one and
+// two columns ahead and ride along with the current column's gathers, so the only exposed round trip per
+// column is the gather of A rows / values itself.
 template <bool VALUES>
-__global__ __launch_bounds__(256) void k_sg_hash1(int slots, const uint32_t *__restrict__ cols, int32_t ncols,
+__global__ __launch_bounds__(256) void k_sg_hash1(int slots_, const int4 *__restrict__ info, int32_t ncols,
                                                   const int32_t *__restrict__ Ap, const int32_t *__restrict__ Ai,
-                                                  const double *__restrict__ Ax, const int32_t *__restrict__ Bp,
-                                                  const int32_t *__restrict__ Bi, const double *__restrict__ Bx,
-                                                  const int32_t *__restrict__ toff, int32_t *__restrict__ count,
+                                                  const double *__restrict__ Ax, const int32_t *__restrict__ Bi,
+                                                  const double *__restrict__ Bx, int32_t *__restrict__ count,
                                                   int32_t *__restrict__ tmp_i, double *__restrict__ tmp_x) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t slots = (uint32_t)slots_;
     double *val = reinterpret_cast<double *>(smem);
     uint32_t *keys = reinterpret_cast<uint32_t *>(smem + (VALUES ? (size_t)slots * 8 : 0));
     uint32_t *tmin = keys + slots;
-    double *seg_bx = reinterpret_cast<double *>(tmin + slots);
+    double *seg_bx = reinterpret_cast<double *>(tmin + slots + (slots & 1));
     int32_t *seg_ab = reinterpret_cast<int32_t *>(seg_bx + H1_SEG);
     uint32_t *seg_len = reinterpret_cast<uint32_t *>(seg_ab + H1_SEG);
     uint32_t *seg_off = seg_len + H1_SEG;
     uint32_t *bitmap = seg_off + H1_SEG;        // H1_MAXP / 32 words
     uint32_t *wpre = bitmap + H1_MAXP / 32;     // exclusive popcount prefix per word
     uint32_t *misc = wpre + H1_MAXP / 32;       // [0..3] wave sums, [4] segment products, [5] column count
-    const uint32_t mask = (uint32_t)slots - 1u;
-    const int shift = 32 - (31 - __clz(slots));
+    uint16_t *inv = reinterpret_cast<uint16_t *>(misc + 16);   // position in the column -> slot (<= limit entries)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int grp = tid >> 5, gl = tid & 31;
-    for (int k = tid; k < slots; k += 256) {
+    const int32_t G = (int32_t)gridDim.x;
+    const int4 none = make_int4(-1, 0, 0, 0);
+    int32_t ci = blockIdx.x;                    // the host launches at most ncols workgroups
+    int4 cur = info[ci];
+    int4 nxt = ci + G < ncols ? info[ci + G] : none;
+    int32_t ab0 = 0;
+    uint32_t len0 = 0;
+    double bx0 = 0.0;
+    if (tid < min(H1_SEG, cur.z - cur.y)) {
+        const int32_t c = Bi[cur.y + tid];
+        ab0 = Ap[c];
+        len0 = (uint32_t)(Ap[c + 1] - ab0);
+        if (VALUES) bx0 = Bx[cur.y + tid];
+    }
+    for (uint32_t k = tid; k < slots; k += 256) {
         keys[k] = SG_UNSET;
         tmin[k] = SG_UNSET;
         if (VALUES) val[k] = 0.0;
     }
     if (tid < H1_MAXP / 32) bitmap[tid] = 0u;
     __syncthreads();
-    for (int32_t ci = blockIdx.x; ci < ncols; ci += gridDim.x) {
-        const int32_t j = (int32_t)cols[ci];
-        const int32_t bb = Bp[j], be = Bp[j + 1];
+    for (;;) {
+        // ---- prefetch: descriptor two columns ahead, B entries one column ahead ----
+        const int4 nn = ci + 2 * G < ncols ? info[ci + 2 * G] : none;
+        const int nseg1 = nxt.x >= 0 ? min(H1_SEG, nxt.z - nxt.y) : 0;
+        int32_t c1 = 0;
+        double bx1 = 0.0;
+        if (tid < nseg1) {
+            c1 = Bi[nxt.y + tid];
+            if (VALUES) bx1 = Bx[nxt.y + tid];
+        }
+        const int32_t j = cur.x, bb = cur.y, be = cur.z;
         uint32_t tbase = 0;
         for (int32_t s0 = bb; s0 < be; s0 += H1_SEG) {
             const int nseg = min(H1_SEG, be - s0);
-            // stage the segment and scan the lengths of the A columns it names
-            uint32_t len = 0;
+            // stage the segment (the first one was prefetched) and scan the lengths of the A columns it names
+            int32_t ab = ab0;
+            uint32_t len = len0;
+            double bx = bx0;
+            if (s0 != bb) {
+                len = 0;
+                if (tid < nseg) {
+                    const int32_t c = Bi[s0 + tid];
+                    ab = Ap[c];
+                    len = (uint32_t)(Ap[c + 1] - ab);
+                    if (VALUES) bx = Bx[s0 + tid];
+                }
+            }
             if (tid < nseg) {
-                const int32_t c = Bi[s0 + tid];
-                const int32_t ab = Ap[c];
-                len = (uint32_t)(Ap[c + 1] - ab);
                 seg_ab[tid] = ab;
                 seg_len[tid] = len;
-                if (VALUES) seg_bx[tid] = Bx[s0 + tid];
+                if (VALUES) seg_bx[tid] = bx;
             }
             uint32_t inc = len;
 #pragma unroll
@@ -387,56 +444,74 @@ __global__ __launch_bounds__(256) void k_sg_hash1(int slots, const uint32_t *__r
                 }
 #pragma unroll
                 for (int u = 0; u < H1_UN; u++) {
-                    if ((uint32_t)gl < lens_[u]) h1_insert<VALUES>(keys, tmin, val, mask, shift, rows_[u], ts_[u], bxs_[u] * vs_[u]);
+                    if ((uint32_t)gl < lens_[u]) h1_insert<VALUES>(keys, tmin, val, slots, rows_[u], ts_[u], bxs_[u] * vs_[u]);
                     for (uint32_t q = (uint32_t)gl + 32; q < lens_[u]; q += 32) {   // A columns longer than 32
                         const uint32_t row = (uint32_t)Ai[abs_[u] + (int32_t)q];
                         const double v = VALUES ? bxs_[u] * Ax[abs_[u] + (int32_t)q] : 0.0;
-                        h1_insert<VALUES>(keys, tmin, val, mask, shift, row, ts_[u] + (q - (uint32_t)gl), v);
+                        h1_insert<VALUES>(keys, tmin, val, slots, row, ts_[u] + (q - (uint32_t)gl), v);
                     }
                 }
             }
             tbase += misc[4];
             __syncthreads();
         }
+        // ---- prefetch, second half: extents of the A columns the next column names ----
+        int32_t ab1 = 0, e1 = 0;
+        if (tid < nseg1) {
+            ab1 = Ap[c1];
+            e1 = Ap[c1 + 1];
+        }
         // ---- read-out: mark first touches in product order, rank them, emit, and leave the table clean ----
-        for (int s = tid; s < slots; s += 256)
+        for (uint32_t s = tid; s < slots; s += 256)
             if (keys[s] != SG_UNSET) {
                 const uint32_t t = tmin[s];
                 atomicOr(&bitmap[t >> 5], 1u << (t & 31));
             }
         __syncthreads();
         if (tid < 64) {
-            const uint32_t c0 = __popc(bitmap[2 * tid]), c1 = __popc(bitmap[2 * tid + 1]);
-            uint32_t inc = c0 + c1;
+            const uint32_t c0 = __popc(bitmap[2 * tid]), c1w = __popc(bitmap[2 * tid + 1]);
+            uint32_t inc = c0 + c1w;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
                 const uint32_t up = __shfl_up(inc, d, 64);
                 if (tid >= d) inc += up;
             }
-            wpre[2 * tid] = inc - c0 - c1;
-            wpre[2 * tid + 1] = inc - c1;
+            wpre[2 * tid] = inc - c0 - c1w;
+            wpre[2 * tid + 1] = inc - c1w;
             if (tid == 63) misc[5] = inc;
         }
         __syncthreads();
-        const int64_t base = toff[j];
-        for (int s = tid; s < slots; s += 256) {
-            const uint32_t key = keys[s];
-            if (key != SG_UNSET) {
+        // inv[position] = slot, then a position-ordered (coalesced) copy-out that also clears the table
+        for (uint32_t s = tid; s < slots; s += 256)
+            if (keys[s] != SG_UNSET) {
                 const uint32_t t = tmin[s];
                 const uint32_t pos = wpre[t >> 5] + __popc(bitmap[t >> 5] & ((1u << (t & 31)) - 1u));
-                tmp_i[base + pos] = (int32_t)key;
-                keys[s] = SG_UNSET;
-                tmin[s] = SG_UNSET;
-                if (VALUES) {
-                    tmp_x[base + pos] = val[s];
-                    val[s] = 0.0;
-                }
+                inv[pos] = (uint16_t)s;
+            }
+        __syncthreads();
+        const int64_t base = cur.w;
+        const uint32_t cnt = misc[5];
+        for (uint32_t pos = tid; pos < cnt; pos += 256) {
+            const uint32_t s = inv[pos];
+            tmp_i[base + pos] = (int32_t)keys[s];
+            keys[s] = SG_UNSET;
+            tmin[s] = SG_UNSET;
+            if (VALUES) {
+                tmp_x[base + pos] = val[s];
+                val[s] = 0.0;
             }
         }
-        if (tid == 0) count[j] = (int32_t)misc[5];
+        if (tid == 0) count[j] = (int32_t)cnt;
         __syncthreads();
         if (tid < H1_MAXP / 32) bitmap[tid] = 0u;
         // the next column's first use of bitmap / misc / seg_* is behind the staging barriers above
+        ci += G;
+        if (ci >= ncols) break;
+        cur = nxt;
+        nxt = nn;
+        ab0 = ab1;
+        len0 = (uint32_t)(e1 - ab1);
+        bx0 = bx1;
     }
 }
 
@@ -457,22 +532,24 @@ __global__ __launch_bounds__(256) void k_sg_compact(const uint32_t *__restrict__
     }
 }
 
-static size_t h1_lds_bytes(int slots, bool values) {
-    return (size_t)slots * (values ? 16 : 8) + H1_SEG * (8 + 4 + 4 + 4) + (H1_MAXP / 32) * 8 + 64;
+static size_t h1_lds_bytes(int slots, bool values) {   // slots = 3/2 * (products allowed in the bin)
+    return (size_t)(slots + (slots & 1)) * (values ? 16 : 8) + H1_SEG * (8 + 4 + 4 + 4) + (H1_MAXP / 32) * 8 + 64 +
+           (size_t)(slots * 2 / 3) * 2 + 16;
 }
 
 template <bool VALUES>
-static int launch_hash1(int slots, const Csc *A, const Csc *B, const uint32_t *cols, int32_t ncols, const int32_t *toff,
-                        int32_t *count, int32_t *tmp_i, double *tmp_x) {
+static int launch_hash1(int slots, const Csc *A, const Csc *B, const int4 *info, int32_t ncols, int32_t *count,
+                        int32_t *tmp_i, double *tmp_x) {
     if (ncols <= 0) return CSX_OK;
     const size_t lds = h1_lds_bytes(slots, VALUES);
     auto kern = k_sg_hash1<VALUES>;
     CSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024 - 256));
-    const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(8, (160 * 1024) / (int64_t)(lds + 512)));
-    const int64_t grid = std::min<int64_t>(ncols, (int64_t)ctx().cus * per_cu * 2);
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, ctx().stream, slots, cols, ncols, A->p, A->i, A->x, B->p,
-                       B->i, B->x, toff, count, tmp_i, tmp_x);
+    // exactly the workgroups that are resident at once (LDS-limited, at most 8 x 4 waves per CU)
+    const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(8, (160 * 1024) / (int64_t)(lds + 256)));
+    const int64_t grid = std::min<int64_t>(ncols, (int64_t)ctx().cus * per_cu);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, ctx().stream, slots, info, ncols, A->p, A->i, A->x,
+                       B->i, B->x, count, tmp_i, tmp_x);
     CSX_LAUNCH_CHECK();
     return CSX_OK;
 }
@@ -510,13 +587,16 @@ static int launch_bin(int kind, int slots, const Csc *A, const Csc *B, const uin
 template <bool NUMERIC, bool VALUES>
 static int run_bins(const Csc *A, const Csc *B, const uint32_t *cols, const int32_t *bin_ptr, int32_t *count,
                     const int32_t *Cp, int32_t *Ci, double *Cx, uint32_t *g_tmin, double *g_val, bool skip_hash) {
-    static const int slots_of_bin[5] = {0, 1024, 2048, 4096, 8192};
-    for (int b = 0; b <= 5; b++) {
-        if (skip_hash && b >= 1 && b <= 4) continue;  // done by the one-pass kernel
+    for (int b = 0; b < SG_NBINS; b++) {
         const int32_t nb = bin_ptr[b + 1] - bin_ptr[b];
-        const int kind = b == 0 ? ACC_LDS_DENSE : (b == 5 ? ACC_GLOBAL_DENSE : ACC_LDS_HASH);
-        CSX_TRY((launch_bin<NUMERIC, VALUES>(kind, b >= 1 && b <= 4 ? slots_of_bin[b] : 0, A, B, cols + bin_ptr[b], nb,
-                                             count, Cp, Ci, Cx, g_tmin, g_val)));
+        const bool hashed = b >= SG_BIN_HASH0 && b < SG_BIN_HASH0 + SG_HASH_BINS;
+        if (b == SG_BIN_EMPTY || (hashed && skip_hash)) continue;  // hash bins: done by the one-pass kernel
+        if (!hashed && b != SG_BIN_DENSE && b != SG_BIN_GLOBAL) continue;
+        const int kind = b == SG_BIN_DENSE ? ACC_LDS_DENSE : (b == SG_BIN_GLOBAL ? ACC_GLOBAL_DENSE : ACC_LDS_HASH);
+        int slots = 0;  // two-pass hash tables: power of two, load <= 1/2
+        if (hashed)
+            for (slots = 1024; slots < 2 * sg_hash_limit(b - SG_BIN_HASH0); slots <<= 1) {}
+        CSX_TRY((launch_bin<NUMERIC, VALUES>(kind, slots, A, B, cols + bin_ptr[b], nb, count, Cp, Ci, Cx, g_tmin, g_val)));
     }
     return CSX_OK;
 }
@@ -538,40 +618,44 @@ static int multiply_device(const Csc *A, const Csc *B, Csc *C) {
     }
     uint32_t *bin = nullptr, *colid = nullptr, *sbin = nullptr, *scol = nullptr, *g_tmin = nullptr;
     int32_t *bin_ptr_d = nullptr, *count = nullptr, *hprod = nullptr, *toff = nullptr, *tmp_i = nullptr;
+    int4 *info = nullptr;
     double *g_val = nullptr, *tmp_x = nullptr;
     unsigned long long *too_big = nullptr;  // [0] columns with >= 2^32 products, [1] products in hash-bin columns
     int st = dalloc(&bin, (size_t)n);
     if (st == CSX_OK) st = dalloc(&colid, (size_t)n);
     if (st == CSX_OK) st = dalloc(&sbin, (size_t)n);
     if (st == CSX_OK) st = dalloc(&scol, (size_t)n);
-    if (st == CSX_OK) st = dalloc(&bin_ptr_d, 9);
+    if (st == CSX_OK) st = dalloc(&bin_ptr_d, SG_NBINS + 1);
     if (st == CSX_OK) st = dalloc(&count, (size_t)n + 1);
     if (st == CSX_OK) st = dalloc(&hprod, (size_t)n + 1);
     if (st == CSX_OK) st = dalloc(&too_big, 2);
-    int32_t bin_ptr[9] = {0};
+    int32_t bin_ptr[SG_NBINS + 1] = {0};
     unsigned long long big[2] = {0, 0};
     if (st == CSX_OK) {
         (void)hipMemsetAsync(too_big, 0, 2 * sizeof(unsigned long long), s);
         (void)hipMemsetAsync(count, 0, ((size_t)n + 1) * sizeof(int32_t), s);
         hipLaunchKernelGGL(k_sg_products, dim3((unsigned)(((int64_t)n + 3) / 4)), dim3(256), 0, s, n, A->p, B->p, B->i, m,
                            bin, colid, hprod, too_big);
+        hipLaunchKernelGGL(k_sum_i32, dim3(512), dim3(256), 0, s, hprod, (int64_t)n, too_big + 1);
         st = stable_sort_by_key(bin, colid, nullptr, n, 8, sbin, scol, nullptr);
     }
-    if (st == CSX_OK) st = boundaries_from_sorted(sbin, n, 8, bin_ptr_d);
+    if (st == CSX_OK) st = boundaries_from_sorted(sbin, n, SG_NBINS, bin_ptr_d);
     if (st == CSX_OK) {
-        if (hipMemcpyAsync(bin_ptr, bin_ptr_d, 9 * sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess ||
+        if (hipMemcpyAsync(bin_ptr, bin_ptr_d, (SG_NBINS + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess ||
             hipMemcpyAsync(big, too_big, sizeof big, hipMemcpyDeviceToHost, s) != hipSuccess ||
             hipStreamSynchronize(s) != hipSuccess)
             st = CSX_ERUNTIME;
     }
     if (st == CSX_OK && big[0]) st = CSX_EINVAL;  // a column with >= 2^32 products
     // one-pass path for the hash bins when its product-order buffer (12 B per product) is affordable
-    const int32_t nhash = bin_ptr[5] - bin_ptr[1];
+    const int32_t hash_lo = bin_ptr[SG_BIN_HASH0], nhash = bin_ptr[SG_BIN_HASH0 + SG_HASH_BINS] - hash_lo;
     bool onepass = false;
     if (st == CSX_OK && nhash > 0 && big[1] < 0x7FFFFFF0ull && !getenv("CSX_SPGEMM_TWO_PASS")) {
         size_t free_b = 0, total_b = 0;
         const size_t need = (size_t)big[1] * (values ? 12 : 4);
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need < free_b / 3) onepass = true;
+        size_t idle_b = 0;
+        pool_stats(&idle_b, nullptr);   // idle blocks of the caching allocator are reusable
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need < (free_b + idle_b) / 3) onepass = true;
     }
     if (st == CSX_OK && onepass) {
         st = dalloc(&toff, (size_t)n + 1);
@@ -579,14 +663,18 @@ static int multiply_device(const Csc *A, const Csc *B, Csc *C) {
         if (st == CSX_OK) st = scan_exclusive_i32(hprod, toff, n, &tot);
         if (st == CSX_OK) st = dalloc(&tmp_i, (size_t)big[1]);
         if (st == CSX_OK && values) st = dalloc(&tmp_x, (size_t)big[1]);
-        static const int slots_of_bin[5] = {0, 1024, 2048, 4096, 8192};
-        for (int b = 1; b <= 4 && st == CSX_OK; b++) {
-            const int32_t nb = bin_ptr[b + 1] - bin_ptr[b];
-            st = values ? launch_hash1<true>(slots_of_bin[b], A, B, scol + bin_ptr[b], nb, toff, count, tmp_i, tmp_x)
-                        : launch_hash1<false>(slots_of_bin[b], A, B, scol + bin_ptr[b], nb, toff, count, tmp_i, nullptr);
+        if (st == CSX_OK) st = dalloc(&info, (size_t)nhash);
+        if (st == CSX_OK)
+            hipLaunchKernelGGL(k_sg_colinfo, dim3((unsigned)((nhash + 255) / 256)), dim3(256), 0, s, scol + hash_lo, nhash,
+                               B->p, toff, info);
+        for (int hb = 0; hb < SG_HASH_BINS && st == CSX_OK; hb++) {
+            const int32_t lo = bin_ptr[SG_BIN_HASH0 + hb], nb = bin_ptr[SG_BIN_HASH0 + hb + 1] - lo;
+            const int slots = sg_hash_limit(hb) * 3 / 2;   // load factor <= 2/3
+            st = values ? launch_hash1<true>(slots, A, B, info + (lo - hash_lo), nb, count, tmp_i, tmp_x)
+                        : launch_hash1<false>(slots, A, B, info + (lo - hash_lo), nb, count, tmp_i, nullptr);
         }
     }
-    const int32_t nglobal = bin_ptr[6] - bin_ptr[5];
+    const int32_t nglobal = bin_ptr[SG_BIN_GLOBAL + 1] - bin_ptr[SG_BIN_GLOBAL];
     if (st == CSX_OK && nglobal > 0) {
         const size_t wgs = (size_t)std::min<int32_t>(nglobal, SG_GLOBAL_WGS);
         st = dalloc(&g_tmin, wgs * (size_t)m);
@@ -611,7 +699,7 @@ static int multiply_device(const Csc *A, const Csc *B, Csc *C) {
         if (st == CSX_OK && values) st = dalloc(&C->x, (size_t)total);
     }
     if (st == CSX_OK && onepass) {
-        hipLaunchKernelGGL(k_sg_compact, dim3((unsigned)(((int64_t)nhash + 3) / 4)), dim3(256), 0, s, scol + bin_ptr[1],
+        hipLaunchKernelGGL(k_sg_compact, dim3((unsigned)(((int64_t)nhash + 3) / 4)), dim3(256), 0, s, scol + hash_lo,
                            nhash, toff, C->p, tmp_i, tmp_x, C->i, C->x);
         if (hipGetLastError() != hipSuccess) st = CSX_ERUNTIME;
     }
@@ -627,6 +715,7 @@ static int multiply_device(const Csc *A, const Csc *B, Csc *C) {
     dfree(toff);
     dfree(tmp_i);
     dfree(tmp_x);
+    dfree(info);
     dfree(bin);
     dfree(colid);
     dfree(sbin);

@@ -63,6 +63,13 @@ const char *csx_last_error(void);
 int csx_sync(void);                       /* wait for the context's stream */
 int csx_set_stream(void *hip_stream);     /* run on a caller-provided hipStream_t (NULL: own stream) */
 int csx_device_info(char *name, int name_cap, int *compute_units, int64_t *hbm_bytes);
+/* Device memory is served by a caching allocator (freed blocks are reused instead of returned to the
+ * driver; cap = 1/4 of the device, CSX_POOL_LIMIT_MB / CSX_NO_POOL=1 override).  csx_mem_trim returns
+ * every idle block to the driver; csx_mem_info reports idle bytes, bytes in use, and hipMemGetInfo's free.
+ * Reuse is ordered on the context's stream: a block whose pointer was exported (csx_vec_ptr, csx_csc_ptrs)
+ * must not be freed while work on another stream still uses it (csx_free does not synchronise). */
+int csx_mem_trim(void);
+int csx_mem_info(int64_t *cached_bytes, int64_t *live_bytes, int64_t *device_free_bytes);
 int csx_timer_start(void);                /* hipEvent on the context's stream */
 int csx_timer_stop(double *ms);           /* second hipEvent, synchronises, elapsed ms */
 
