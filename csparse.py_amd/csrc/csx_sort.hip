@@ -139,7 +139,7 @@ int expand_columns(const int32_t *Ap, int32_t n, int32_t nnz, int32_t *col) {
 constexpr int RS_THREADS = 256;
 constexpr int RS_WAVES = RS_THREADS / 64;
 constexpr int RS_ROUNDS = 16;
-constexpr int RS_TILE = RS_THREADS * RS_ROUNDS;  // 4096 records per workgroup
+constexpr int RS_TILE = RS_THREADS * RS_ROUNDS;  // records per workgroup
 constexpr int RS_BINS = 256;
 
 __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint32_t *key, int64_t count, int shift,
@@ -165,7 +165,7 @@ template <bool HAS_A, bool HAS_V, bool WRITE_KEY>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint32_t *key, const uint32_t *a, const double *v,
                                                            int64_t count, int shift, uint32_t nblocks,
                                                            const int32_t *goff, uint32_t *okey, uint32_t *oa,
-                                                           double *ov) {
+                                                           double *ov, int getenv_flat) {
     __shared__ int wh[RS_WAVES][RS_BINS];
     __shared__ int gbase[RS_BINS];  // global slot of a bucket's first record minus its local start
     __shared__ int wsum[RS_WAVES];
@@ -176,13 +176,33 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint32_t *key, 
 #pragma unroll
     for (int k = 0; k < RS_WAVES; k++) wh[k][threadIdx.x] = 0;
     __syncthreads();
+    // Workgroups are dealt to the 8 XCDs round-robin; give each XCD a contiguous range of tiles, so that
+    // neighbouring tiles -- whose runs in a bucket are adjacent in memory -- meet in the same L2 and the
+    // partial lines at the run boundaries are merged there.
+    uint32_t tile = blockIdx.x;
+    if (!getenv_flat) {
+        const uint32_t q = nblocks >> 3, rem = nblocks & 7u, x = blockIdx.x & 7u, kk = blockIdx.x >> 3;
+        tile = x * q + (x < rem ? x : rem) + kk;
+    }
     // wave w owns the contiguous sub-tile [w*64*ROUNDS, (w+1)*64*ROUNDS) of this workgroup's tile
-    const int64_t tbase = (int64_t)blockIdx.x * RS_TILE;
+    const int64_t tbase = (int64_t)tile * RS_TILE;
     const int64_t wbase = tbase + (int64_t)w * 64 * RS_ROUNDS;
-#pragma unroll 4
+    // the whole sub-tile goes to registers first: every load of the tile is in flight before the
+    // (latency-bound) ranking rounds start, instead of one exposed round trip per round
+    uint32_t kreg[RS_ROUNDS], areg[HAS_A ? RS_ROUNDS : 1];
+    double vreg[HAS_V ? RS_ROUNDS : 1];
+#pragma unroll
     for (int r = 0; r < RS_ROUNDS; r++) {
-        int64_t idx = wbase + r * 64 + lane;
-        if (idx < count) atomicAdd(&wh[w][(key[idx] >> shift) & (RS_BINS - 1)], 1);
+        const int64_t idx = wbase + r * 64 + lane;
+        const int64_t cl = idx < count ? idx : count - 1;   // clamped: count > 0
+        kreg[r] = key[cl];
+        if (HAS_A) areg[r] = a[cl];
+        if (HAS_V) vreg[r] = v[cl];
+    }
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; r++) {
+        const int64_t idx = wbase + r * 64 + lane;
+        if (idx < count) atomicAdd(&wh[w][(kreg[r] >> shift) & (RS_BINS - 1)], 1);
     }
     __syncthreads();
     {
@@ -204,7 +224,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint32_t *key, 
         for (int k = 0; k < RS_WAVES; k++)
             if (k < w) off += wsum[k];
         int run = off + inc - tot;  // local start of bucket d
-        gbase[d] = goff[(size_t)d * nblocks + blockIdx.x] - run;
+        gbase[d] = goff[(size_t)d * nblocks + tile] - run;
 #pragma unroll
         for (int k = 0; k < RS_WAVES; k++) {
             int c = wh[k][d];
@@ -214,10 +234,11 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint32_t *key, 
     }
     __syncthreads();
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
     for (int r = 0; r < RS_ROUNDS; r++) {
         int64_t idx = wbase + r * 64 + lane;
         bool valid = idx < count;
-        uint32_t k = valid ? key[idx] : 0u;
+        uint32_t k = kreg[r];
         uint32_t d = (k >> shift) & (RS_BINS - 1);
         // lanes holding the same digit (multi-split by ballots, one per digit bit)
         unsigned long long peers = __ballot(valid);
@@ -234,8 +255,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint32_t *key, 
         __builtin_amdgcn_wave_barrier();
         if (valid) {
             s_key[pos] = k;
-            if (HAS_A) s_a[pos] = a[idx];
-            if (HAS_V) s_v[pos] = v[idx];
+            if (HAS_A) s_a[pos] = areg[r];
+            if (HAS_V) s_v[pos] = vreg[r];
         }
     }
     __syncthreads();
@@ -253,12 +274,13 @@ template <bool HAS_A, bool HAS_V>
 static int launch_scatter(bool write_key, dim3 grid, hipStream_t s, const uint32_t *key, const uint32_t *a,
                           const double *v, int64_t count, int shift, uint32_t nblocks, const int32_t *goff,
                           uint32_t *okey, uint32_t *oa, double *ov) {
+    const int flat = getenv("CSX_SORT_FLAT") ? 1 : 0;
     if (write_key)
         hipLaunchKernelGGL((k_rs_scatter<HAS_A, HAS_V, true>), grid, dim3(RS_THREADS), 0, s, key, a, v, count, shift,
-                           nblocks, goff, okey, oa, ov);
+                           nblocks, goff, okey, oa, ov, flat);
     else
         hipLaunchKernelGGL((k_rs_scatter<HAS_A, HAS_V, false>), grid, dim3(RS_THREADS), 0, s, key, a, v, count, shift,
-                           nblocks, goff, okey, oa, ov);
+                           nblocks, goff, okey, oa, ov, flat);
     CSX_LAUNCH_CHECK();
     return CSX_OK;
 }
