@@ -31,19 +31,18 @@
 // reference's cs_lsolve + cs_ltsolve on the same L) and writes the result back:
 // B is read once and written once, L is read once.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 
 #include "csx_internal.h"
 
 namespace csx {
 
-// csx_host.cpp
-void upper_pattern(int32_t n, const int32_t *Ap, const int32_t *Ai, const int32_t *pinv, std::vector<int32_t> &up_ptr,
-                   std::vector<int32_t> &up_idx);
-int symbolic_fill(int32_t n, const std::vector<int32_t> &up_ptr, const std::vector<int32_t> &up_idx,
-                  const int32_t *parent, const int32_t *cp, std::vector<int32_t> &Li, std::vector<int32_t> &row_ptr,
-                  std::vector<int32_t> &row_col, std::vector<int32_t> &row_pos);
+// csx_cholsym.hip
+int chol_symbolic_device(const Csc *A, const int32_t *parent, const int32_t *cp, const int32_t *pinv, int32_t **Lp_out,
+                         int32_t **Li_out, int32_t **row_ptr_out, int32_t **row_col_out, int32_t **row_pos_out);
 // csx_trisolve.hip
 struct TriPlan;
 int tri_solve_raw(TriPlan *P, double *X, int32_t nrhs);
@@ -117,7 +116,7 @@ __device__ __forceinline__ void chol_column(int32_t j, const int32_t *__restrict
         }
     }
     __builtin_amdgcn_wave_barrier();
-    const int32_t qe = row_ptr[j + 1];
+    const int32_t qe = row_ptr[j + 1] - 1;   // the row view ends with the diagonal L(j,j)
     for (int32_t q = row_ptr[j]; q < qe; q++) {
         const int32_t k = row_col[q], pos = row_pos[q];
         const double ljk = Lx[pos];
@@ -198,6 +197,57 @@ __global__ __launch_bounds__(64 * CH_WAVES) void k_chol_trees(const Tree *__rest
                     notspd);
 }
 
+// one wave per DENSE small tree (a dense lower-triangular block on consecutive columns, <= 64 of them:
+// the G-spd benchmark's blocks).  The block's columns are contiguous in L.x, so the whole block is copied
+// to LDS, factored there, and copied back: L.x is read once and written once.  Right-looking, lane = row;
+// every entry L(i,c) receives its updates - L(i,j) L(c,j) for j = 0, 1, ... in ascending order, multiply
+// then subtract, then one division by the pivot -- the operation sequence of cs_chol's up-looking row
+// solve on a chain elimination tree (csparse.py:598-612), so the factor is bit-identical to it.
+constexpr int CD_MAX = 64;
+__global__ __launch_bounds__(64 * CH_WAVES) void k_chol_dense_trees(const Tree *__restrict__ trees, int32_t ntrees,
+                                                                   const int32_t *__restrict__ tree_cols,
+                                                                   const int32_t *__restrict__ Lp, double *Lx,
+                                                                   int *notspd) {
+#pragma clang fp contract(off)
+    __shared__ double sa[CH_WAVES][CD_MAX * (CD_MAX + 1) / 2];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t t = (int64_t)blockIdx.x * CH_WAVES + w;
+    if (t >= ntrees) return;   // no workgroup barrier below
+    const Tree tr = trees[t];
+    const int bs = tr.count;
+    const int32_t c0 = tree_cols[tr.first];
+    const int64_t base = Lp[c0];
+    const int nent = bs * (bs + 1) / 2;
+    double *a = sa[w];
+    for (int e = lane; e < nent; e += 64) a[e] = Lx[base + e];
+    __builtin_amdgcn_wave_barrier();
+    const bool row = lane < bs;
+    for (int j = 0; j < bs; j++) {
+        const int offj = j * bs - j * (j - 1) / 2;      // start of column j (its diagonal)
+        const double d = a[offj];
+        if (d <= 0.0 && lane == 0) atomicMin(notspd, c0 + j);   // csparse.py:612
+        const double ljj = sqrt(d);
+        double lij = 0.0;
+        if (row && lane > j) {
+            lij = a[offj + lane - j] / ljj;
+            a[offj + lane - j] = lij;
+        }
+        if (lane == j) a[offj] = ljj;
+        int offc = offj;
+#pragma unroll 4
+        for (int c = j + 1; c < bs; c++) {
+            offc += bs - (c - 1);                        // start of column c
+            // L(c,j) from lane c: read with every lane enabled, then predicate only the update
+            const int lo = __builtin_amdgcn_readlane(__double2loint(lij), c);
+            const int hi = __builtin_amdgcn_readlane(__double2hiint(lij), c);
+            const double lcj = __hiloint2double(hi, lo);
+            if (row && lane >= c) a[offc + lane - c] -= lij * lcj;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    for (int e = lane; e < nent; e += 64) Lx[base + e] = a[e];
+}
+
 template <class T>
 static int upload(T **d, const std::vector<T> &h) {
     CSX_TRY(dalloc(d, h.size()));
@@ -270,33 +320,48 @@ static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, c
         CSX_TRY(dalloc(&L->x, 0));
         return CSX_OK;
     }
-    // host: pattern of A -> pattern of L and its row view
-    std::vector<int32_t> hAp((size_t)n + 1), hAi((size_t)A->nnz);
-    CSX_HIP(hipMemcpyAsync(hAp.data(), A->p, hAp.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    if (A->nnz) CSX_HIP(hipMemcpyAsync(hAi.data(), A->i, hAi.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    CSX_HIP(hipStreamSynchronize(s));
-    std::vector<int32_t> up_ptr, up_idx, hLi, row_ptr, row_col, row_pos;
-    upper_pattern(n, hAp.data(), hAi.data(), pinv, up_ptr, up_idx);
-    CSX_TRY(symbolic_fill(n, up_ptr, up_idx, parent, cp, hLi, row_ptr, row_col, row_pos));
-    Forest F;
-    partition_forest(n, parent, F);
-
+    // pattern of L and its row view, on the device (csx_cholsym.hip); the host only orders the tree
+    const bool timing = getenv("CSX_CHOL_TIMING") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(s);
+        auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[cs_chol] %-18s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    };
     int32_t *d_rp = nullptr, *d_rc = nullptr, *d_rpos = nullptr, *d_pinv = nullptr, *d_win = nullptr;
     int32_t *d_small_cols = nullptr, *d_level_cols = nullptr, *d_level_ptr = nullptr;
-    Tree *d_trees = nullptr;
+    Tree *d_trees = nullptr, *d_dense = nullptr;
     int *d_flags = nullptr;
-    std::vector<int32_t> hcp(cp, cp + n + 1), hpinv;
+    CSX_TRY(chol_symbolic_device(A, parent, cp, pinv, &L->p, &L->i, &d_rp, &d_rc, &d_rpos));
+    lap("pattern (device)");
+    Forest F;
+    partition_forest(n, parent, F);
+    // small trees that are dense blocks on consecutive columns take the LDS block kernel
+    std::vector<Tree> dense_trees, other_trees;
+    for (const Tree &tr : F.small) {
+        bool dense = tr.count <= CD_MAX;
+        const int32_t c0 = F.small_cols[(size_t)tr.first];
+        for (int32_t a = 0; dense && a < tr.count; a++) {
+            const int32_t c = F.small_cols[(size_t)tr.first + a];
+            dense = c == c0 + a && cp[c + 1] - cp[c] == tr.count - a;
+        }
+        (dense ? dense_trees : other_trees).push_back(tr);
+    }
+    if (getenv("CSX_CHOL_NO_DENSE")) {
+        other_trees = F.small;
+        dense_trees.clear();
+    }
+    lap("partition_forest");
+    std::vector<int32_t> hpinv;
     if (pinv) hpinv.assign(pinv, pinv + n);
-    int st = upload(&L->p, hcp);
-    if (st == CSX_OK) st = upload(&L->i, hLi);
-    if (st == CSX_OK) st = dalloc(&L->x, (size_t)L->nnz);
-    if (st == CSX_OK) st = upload(&d_rp, row_ptr);
-    if (st == CSX_OK) st = upload(&d_rc, row_col);
-    if (st == CSX_OK) st = upload(&d_rpos, row_pos);
+    int st = dalloc(&L->x, (size_t)L->nnz);
     if (st == CSX_OK && pinv) st = upload(&d_pinv, hpinv);
     if (st == CSX_OK) st = dalloc(&d_win, (size_t)L->nnz);
     if (st == CSX_OK) st = dalloc(&d_flags, 2);
-    if (st == CSX_OK) st = upload(&d_trees, F.small);
+    if (st == CSX_OK) st = upload(&d_trees, other_trees);
+    if (st == CSX_OK) st = upload(&d_dense, dense_trees);
     if (st == CSX_OK) st = upload(&d_small_cols, F.small_cols);
     if (st == CSX_OK) st = upload(&d_level_cols, F.level_cols);
     if (st == CSX_OK) st = upload(&d_level_ptr, F.level_ptr);
@@ -308,7 +373,11 @@ static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, c
                            L->p, L->i, d_win, d_flags);
         hipLaunchKernelGGL(k_chol_init, dim3((unsigned)(((int64_t)L->nnz + 255) / 256)), dim3(256), 0, s,
                            (int64_t)L->nnz, d_win, A->x, L->x);
-        const int32_t nt = (int32_t)F.small.size();
+        const int32_t nd = (int32_t)dense_trees.size();
+        if (nd > 0)
+            hipLaunchKernelGGL(k_chol_dense_trees, dim3((unsigned)((nd + CH_WAVES - 1) / CH_WAVES)), dim3(64 * CH_WAVES), 0,
+                               s, d_dense, nd, d_small_cols, L->p, L->x, d_flags + 1);
+        const int32_t nt = (int32_t)other_trees.size();
         if (nt > 0)
             hipLaunchKernelGGL(k_chol_trees, dim3((unsigned)((nt + CH_WAVES - 1) / CH_WAVES)), dim3(64 * CH_WAVES), 0, s,
                                d_trees, nt, d_small_cols, L->p, L->i, L->x, d_rp, d_rc, d_rpos, d_flags + 1);
@@ -336,6 +405,7 @@ static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, c
             st = CSX_ERUNTIME;
         }
     }
+    lap("numeric (device)");
     dfree(d_rp);
     dfree(d_rc);
     dfree(d_rpos);
@@ -343,6 +413,7 @@ static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, c
     dfree(d_win);
     dfree(d_flags);
     dfree(d_trees);
+    dfree(d_dense);
     dfree(d_small_cols);
     dfree(d_level_cols);
     dfree(d_level_ptr);

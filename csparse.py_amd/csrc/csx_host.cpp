@@ -81,55 +81,6 @@ static void walk_row_patterns(int32_t n, const std::vector<int32_t> &up_ptr, con
     }
 }
 
-// Pattern of L (diagonal first, then rows ascending: the order cs_chol emits, csparse.py:606-617)
-// plus the row view used by the device kernels: for row k the list of (column i, position of
-// L(k,i) in Li/Lx), columns ascending.
-int symbolic_fill(int32_t n, const std::vector<int32_t> &up_ptr, const std::vector<int32_t> &up_idx,
-                  const int32_t *parent, const int32_t *cp, std::vector<int32_t> &Li, std::vector<int32_t> &row_ptr,
-                  std::vector<int32_t> &row_col, std::vector<int32_t> &row_pos) {
-    const size_t lnz = (size_t)cp[n];
-    Li.assign(lnz, 0);
-    std::vector<int32_t> next(cp, cp + n);
-    row_ptr.assign((size_t)n + 1, 0);
-    row_col.assign(lnz - (size_t)n, 0);
-    row_pos.assign(lnz - (size_t)n, 0);
-    for (int32_t j = 0; j < n; j++) {
-        if (cp[j + 1] - cp[j] < 1) return CSX_EINVAL;
-        Li[(size_t)next[(size_t)j]++] = j;
-    }
-    bool ok = true;
-    int32_t last_row = -1;
-    size_t rc = 0;
-    walk_row_patterns(n, up_ptr, up_idx, parent, [&](int32_t k, int32_t i) {
-        while (last_row < k) row_ptr[(size_t)++last_row] = (int32_t)rc;
-        if (next[(size_t)i] >= cp[i + 1] || rc >= row_col.size()) {
-            ok = false;
-            return;
-        }
-        const int32_t pos = next[(size_t)i]++;
-        Li[(size_t)pos] = k;
-        row_col[rc] = i;
-        row_pos[rc] = pos;
-        rc++;
-    });
-    while (last_row < n) row_ptr[(size_t)++last_row] = (int32_t)rc;
-    if (!ok || rc != row_col.size()) return CSX_EINVAL;  // cp does not describe chol(A)
-    // columns ascending inside each row (the walk visits them in path order)
-    std::vector<std::pair<int32_t, int32_t>> tmp;
-    for (int32_t k = 0; k < n; k++) {
-        const int32_t b = row_ptr[(size_t)k], e = row_ptr[(size_t)k + 1];
-        if (e - b < 2) continue;
-        tmp.resize((size_t)(e - b));
-        for (int32_t q = b; q < e; q++) tmp[(size_t)(q - b)] = {row_col[(size_t)q], row_pos[(size_t)q]};
-        std::sort(tmp.begin(), tmp.end());
-        for (int32_t q = b; q < e; q++) {
-            row_col[(size_t)q] = tmp[(size_t)(q - b)].first;
-            row_pos[(size_t)q] = tmp[(size_t)(q - b)].second;
-        }
-    }
-    return CSX_OK;
-}
-
 }  // namespace csx
 
 using namespace csx;
