@@ -55,7 +55,8 @@ void *get(csx_handle_t h, Kind k) {
 // would dominate the short operations here (a transpose or product allocates several work arrays).
 // Freed blocks are kept on a free list keyed by size and handed out again; every use of device memory in
 // this library is ordered on the context's single stream (csx_set_stream synchronises when it changes),
-// so a block can be reused as soon as the host has released it.  The cache is capped (default: a quarter
+// so a block can be reused as soon as the host has released it.  Blocks carry at least 64 bytes of slack
+// past the requested size (aligned vector loads may read a few entries past an array's end).  The cache is capped (default: a quarter
 // of the device's memory, CSX_POOL_LIMIT_MB overrides, CSX_NO_POOL=1 disables) and emptied when an
 // allocation fails.
 namespace {
@@ -114,7 +115,7 @@ int dmalloc(void **p, size_t bytes) {
     *p = nullptr;
     std::lock_guard<std::mutex> lock(g_pool.mu);
     pool_configure();
-    const size_t want = pool_round(bytes);
+    const size_t want = pool_round(bytes + 64);   // every block has >= 64 readable bytes past its logical end
     if (g_pool.enabled) {
         auto it = g_pool.idle.lower_bound(want);
         if (it != g_pool.idle.end() && it->first <= want + want / 4) {   // at most 25 % slack

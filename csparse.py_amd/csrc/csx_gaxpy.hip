@@ -108,6 +108,98 @@ __global__ __launch_bounds__(256) void k_gaxpy_rows(int32_t rows, const int32_t 
     }
 }
 
+// Wide-load variant for rows of >= ~32 entries: a lane takes FOUR consecutive entries of a row per step
+// through aligned 16-byte loads (one for the indices, two for the values), so a wave instruction moves
+// 1 KiB instead of 256/512 bytes -- the load pipeline tracks instructions, and wider ones keep more bytes
+// in flight (the tiled kernel's stream, built the same way, runs at 6 TB/s; the 4/8-byte version at 3.9).
+// Chunks are aligned to 4 entries; entries of a chunk outside [b, e) are masked.  Reads may run up to 3
+// entries past the end of idx/val: every block of the device allocator carries >= 64 bytes of slack.
+typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2v __attribute__((ext_vector_type(2)));
+
+template <int G, int U>
+__global__ __launch_bounds__(256) void k_gaxpy_rows4(int32_t rows, const int32_t *__restrict__ ptr,
+                                                     const int32_t *__restrict__ idx, const double *__restrict__ val,
+                                                     const double *__restrict__ x, double *__restrict__ y) {
+    const int sub = threadIdx.x & (G - 1);
+    const int64_t group = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const int64_t ngroups = ((int64_t)gridDim.x * blockDim.x) / G;
+    int32_t nb[U], ne[U];
+    {
+        const int64_t r0 = group * U;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int64_t r = r0 + u < rows ? r0 + u : rows - 1;
+            nb[u] = r0 < rows ? ptr[r] : 0;
+            ne[u] = (r0 < rows && r0 + u < rows) ? ptr[r + 1] : nb[u];
+        }
+    }
+    for (int64_t r0 = group * U; r0 < rows; r0 += ngroups * U) {
+        int32_t b[U], e[U];
+        i32x4 c[U];
+        f64x2v v0[U], v1[U];
+        double acc[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            b[u] = nb[u];
+            e[u] = ne[u];
+        }
+        {
+            const int64_t rn = r0 + ngroups * U;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int64_t r = rn + u < rows ? rn + u : rows - 1;
+                nb[u] = ptr[r];
+                ne[u] = rn + u < rows ? ptr[r + 1] : nb[u];
+            }
+        }
+        const bool owner = sub < U && r0 + sub < rows;
+        const double y_old = owner ? y[r0 + sub] : 0.0;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int32_t q = (b[u] & ~3) + 4 * sub;
+            const bool in = q < e[u];
+            const int32_t qq = in ? q : 0;
+            c[u] = *reinterpret_cast<const i32x4 *>(idx + qq);
+            v0[u] = *reinterpret_cast<const f64x2v *>(val + qq);
+            v1[u] = *reinterpret_cast<const f64x2v *>(val + qq + 2);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int32_t q = (b[u] & ~3) + 4 * sub;
+            const bool m0 = q >= b[u] && q < e[u], m1 = q + 1 >= b[u] && q + 1 < e[u];
+            const bool m2 = q + 2 >= b[u] && q + 2 < e[u], m3 = q + 3 >= b[u] && q + 3 < e[u];
+            const double x0 = x[m0 ? c[u].x : 0], x1 = x[m1 ? c[u].y : 0];
+            const double x2 = x[m2 ? c[u].z : 0], x3 = x[m3 ? c[u].w : 0];
+            double a = m0 ? v0[u].x * x0 : 0.0;
+            a = m1 ? fma(v0[u].y, x1, a) : a;
+            a = m2 ? fma(v1[u].x, x2, a) : a;
+            a = m3 ? fma(v1[u].y, x3, a) : a;
+            acc[u] = a;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            for (int32_t q = (b[u] & ~3) + 4 * (G + sub); q < e[u]; q += 4 * G) {   // rows longer than 4 G entries
+                const i32x4 cc = *reinterpret_cast<const i32x4 *>(idx + q);
+                const f64x2v w0 = *reinterpret_cast<const f64x2v *>(val + q);
+                const f64x2v w1 = *reinterpret_cast<const f64x2v *>(val + q + 2);
+                acc[u] = fma(w0.x, x[cc.x], acc[u]);            // q >= b here; only the row end needs masks
+                if (q + 1 < e[u]) acc[u] = fma(w0.y, x[cc.y], acc[u]);
+                if (q + 2 < e[u]) acc[u] = fma(w1.x, x[cc.z], acc[u]);
+                if (q + 3 < e[u]) acc[u] = fma(w1.y, x[cc.w], acc[u]);
+            }
+#pragma unroll
+            for (int d = G >> 1; d > 0; d >>= 1) acc[u] += __shfl_xor(acc[u], d, 64);
+        }
+        if (owner) {
+            double a = acc[0];
+#pragma unroll
+            for (int u = 1; u < U; u++) a = sub == u ? acc[u] : a;
+            y[r0 + sub] = y_old + a;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_gaxpy_atomic(int32_t n, const int32_t *__restrict__ Ap,
                                                       const int32_t *__restrict__ Ai, const double *__restrict__ Ax,
                                                       const double *__restrict__ x, double *y) {
@@ -177,7 +269,25 @@ static int run_rows(const Gather *g, int64_t nnz, const double *x, double *y) {
     // 8 rows per group in flight measured 7 % faster than 4 on G-spd (0.94 vs 1.01 ms); rows with
     // fewer than ~6 entries use 4-lane groups, which need U <= 4
     static const int ru_env = std::getenv("CSX_ROWS_U") ? std::atoi(std::getenv("CSX_ROWS_U")) : 8;
-    if (ru_env == 8 && avg > 6) {
+    // 16-byte loads, 4 rows per group in flight: 0.69 ms on G-spd (5.7 TB/s); 8 rows: 0.74 ms; the 4/8-byte
+    // kernel: 1.02 ms.  CSX_ROWS_WIDE_U = 0 (off) | 4 | 8 for ablation.
+    static const int wide_env = std::getenv("CSX_ROWS_WIDE_U") ? std::atoi(std::getenv("CSX_ROWS_WIDE_U")) : 4;
+#define CSX_ROWS4(G, RU)                                                                                  \
+    {                                                                                                     \
+        int64_t blocks = (((int64_t)g->rows + RU - 1) / RU * G + 255) / 256;                              \
+        if (blocks > cap) blocks = cap;                                                                   \
+        hipLaunchKernelGGL((k_gaxpy_rows4<G, RU>), dim3((unsigned)blocks), dim3(256), 0, s, g->rows, g->ptr, \
+                           g->idx, g->val, x, y);                                                         \
+    }
+    if (wide_env && avg > 24) {
+        if (wide_env == 8) {
+            if (avg > 48) CSX_ROWS4(16, 8)
+            else CSX_ROWS4(8, 8)
+        } else {
+            if (avg > 48) CSX_ROWS4(16, 4)
+            else CSX_ROWS4(8, 4)
+        }
+    } else if (ru_env == 8 && avg > 6) {
         constexpr int RU = 8;
         if (avg > 48) CSX_ROWS(64)
         else if (avg > 24) CSX_ROWS(32)
@@ -192,6 +302,7 @@ static int run_rows(const Gather *g, int64_t nnz, const double *x, double *y) {
         else CSX_ROWS(4)
     }
 #undef CSX_ROWS
+#undef CSX_ROWS4
     CSX_LAUNCH_CHECK();
     return CSX_OK;
 }
