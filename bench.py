@@ -169,10 +169,12 @@ def main():
                    "parallelism": "independent matrices, 1 per GPU, no data-path collective"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
-                     # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes,
-                     # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes; profiles/r01_ablation.md).  Only
-                     # valid for the kernel and size it was measured on.
-                     "traffic": 5.6e9 if (chosen == "tiled" and n == 5000000 and per_col == 64) else None,
+                     # Bytes per launch crossing the L2 -> fabric boundary, from rocprofv3 --pmc FETCH_SIZE and
+                     # WRITE_SIZE (separate passes; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
+                     # gfx950): 2 x 3.39e9 + 0.04e9 (profiles/r01_pmc_bench_v2.csv).  The excess over the
+                     # algorithmic bytes is x-slab gathers missing an XCD's L2 (served by the Infinity Cache).
+                     # Only valid for the kernel and size it was measured on.
+                     "traffic": 6.8e9 if (chosen == "tiled" and n == 5000000 and per_col == 64) else None,
                      "step_ms_hip_events": round(step_ms_events, 4)},
         "gaxpy_trials_ms": {k: round(v["ms"], 4) for k, v in trial.items()},
         "gaxpy_prepare_s": {k: round(v["prepare_s"], 3) for k, v in trial.items()},
@@ -199,9 +201,16 @@ def main():
                 _csx.check(lib.csx_gaxpy(hB, hx, hy, cs.GAXPY_WAVE), "gaxpy")
         ms = max_over_ranks(tm.ms / args.steps)
         byb = gaxpy_bytes(nb * bs, nb * bs, nb * bs * bs)
-        out["gaxpy_gspd"] = {"workload": "cs_gaxpy on G-spd: %d dense %dx%d SPD blocks (n=%d)" % (nb, bs, bs, nb * bs),
-                             "ms_per_step": round(ms, 4), "achieved_GBps_per_gpu": round(byb / (ms * 1e-3) / 1e9, 2),
-                             "frac_of_peak": round(byb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "kernel": "gaxpy_wave"}
+        gbs = byb / (ms * 1e-3) / 1e9
+        out["gaxpy_gspd"] = {"workload": "cs_gaxpy on G-spd (the 5M x 5M 64-nnz/row SPD matrix of the cholsol leg): "
+                                         "%d dense %dx%d SPD blocks (n=%d)" % (nb, bs, bs, nb * bs),
+                             "ms_per_step": round(ms, 4), "achieved_GBps_per_gpu": round(gbs, 2),
+                             "whole_job_GBps": round(gbs * world, 2), "frac_of_peak": round(gbs / HBM_PEAK_GBS, 4),
+                             "kernel": "gaxpy_wave (k_gaxpy_rows4: 16-byte loads on the row-major copy)",
+                             "roofline": {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                          "frac": round(gbs / HBM_PEAK_GBS, 4),
+                                          # 2 x FETCH_SIZE 1.93e9 + WRITE_SIZE 0.04e9 (profiles/r01_pmc_bench_v2.csv)
+                                          "traffic": 3.9e9 if (nb == 78125 and bs == 64) else None}}
         if not args.skip_cholsol:
             extra = cholsol_section(args, lib, cs, hB, nb, bs, rank, world, barrier, max_over_ranks)
             if extra:
@@ -238,7 +247,7 @@ def cholsol_section(args, lib, cs, hB, nb, bs, rank, world, barrier, max_over_ra
     del i
     t_symbolic = time.perf_counter() - t0
     lnz = int(cp[n])
-    # numeric factorisation on the device (includes the host pattern fill of L)
+    # numeric factorisation on the device: pattern of L (postorder walks + sorts), values, dense-block factor
     t0 = time.perf_counter()
     hL = _csx.new_handle()
     _csx.check(lib.csx_chol(hB, _csx.pi(parent), _csx.pi(cp), None, hL), "chol")
@@ -277,7 +286,7 @@ def cholsol_section(args, lib, cs, hB, nb, bs, rank, world, barrier, max_over_ra
            "achieved_GBps_per_gpu": round(fused_bytes / (ms * 1e-3) / 1e9, 2),
            "frac_of_peak": round(fused_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
            "survey_bytes_unfused": cholsol_bytes(lnz, n, k),
-           "factor_s": {"symbolic_host": round(t_symbolic, 3), "numeric_incl_pattern_fill": round(t_numeric, 3),
+           "factor_s": {"symbolic_host": round(t_symbolic, 3), "numeric_device_incl_pattern_of_L": round(t_numeric, 3),
                         "solve_plan": round(t_plan, 3)}}
     _csx.free(plan)
     _csx.free(hR)
