@@ -710,8 +710,8 @@ def cholsol_factor(A, order=0):
         def info(self):
             a, b, c = _csx.C.c_int32(), _csx.C.c_int32(), _csx.C.c_int32()
             _csx.check(_csx.lib().csx_cholsol_info(plan, a, b, c), "csx_cholsol_info")
-            return {"fused_local": a.value >= 1, "dense_block": c.value if a.value == 2 else 0,
-                    "trees": b.value, "max_nodes": c.value}
+            return {"fused_local": a.value >= 1, "dense_block": c.value if a.value >= 2 else 0,
+                    "matrix_cores": a.value == 3, "trees": b.value, "max_nodes": c.value}
 
         def solve(self, b):
             db, bhost = _vec_in(b, n, "b")

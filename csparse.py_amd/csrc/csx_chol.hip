@@ -35,6 +35,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include "csx_internal.h"
 
@@ -444,6 +445,7 @@ struct CholPlan {
     int32_t *rev_pos = nullptr;
     int dense_bs = 0;  // > 0: every tree is a dense lower-triangular block of this size on contiguous rows
     double *dense_b = nullptr;  // dense only: backward program with every row reversed (sweep-position order)
+    double *frag_f = nullptr, *frag_b = nullptr;  // dense, block size 16/32/64: MFMA fragments (k_mfma_frags)
 };
 
 void free_cholplan(CholPlan *P) {
@@ -465,6 +467,8 @@ void free_cholplan(CholPlan *P) {
     dfree(P->diagb);
     dfree(P->rev_pos);
     dfree(P->dense_b);
+    dfree(P->frag_f);
+    dfree(P->frag_b);
     delete P;
 }
 
@@ -782,6 +786,178 @@ __global__ __launch_bounds__(256) void k_cholsol_dense(const Tree *__restrict__ 
     }
 }
 
+// ---- dense blocks on the matrix cores -------------------------------------------------------------------
+// For a dense 16 NB x 16 NB block the two substitutions are a blocked TRSM on 16 x 16 tiles:
+//     forward :  X_i <- W_ii (X_i - sum_{j<i} L_ij X_j)        backward:  X_i <- W_ii' (X_i - sum_{j>i} L_ji' X_j)
+// with W_ii = inv(L_ii) formed once at plan time.  Every product is a v_mfma_f64_16x16x4_f64 chain.  Why
+// this is the right unit here although fp64 MFMA has no rate advantage on this chip: the L operand
+// reaches the pipe as ONE double per lane (A fragment: lane l holds A[l & 15][4 s + (l >> 4)]), read once,
+// coalesced, straight from memory -- the lane-per-right-hand-side kernels above need every L value in all
+// 64 lanes, and that broadcast (LDS return path, 8 clk per 16 bytes) is what bounds them.  And the f64
+// accumulator layout (lane l, register r: row (l >> 4) + 4 r, column l & 15) IS the B-fragment layout of
+// k-step r, so a finished tile X_j feeds the next product from its registers: no LDS, no lane movement.
+// One wave: one block x 64 right-hand sides = NB x 4 tiles = the same 128 VGPRs of unknowns as before.
+// Results equal the substitution kernels to rounding (different association; explicit block inverses), so
+// the plan refuses this path when a block inverse is large (max|W| max|L| > 1e6).
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+template <int NB>
+constexpr int mfma_frags() { return (NB * (NB - 1) / 2 + NB) * 4; }
+
+// one wave per tree: fragments of -L_ij / W_ii (forward) and -L_ji' / W_ii' (backward) in use order
+template <int NB>
+__global__ __launch_bounds__(64) void k_mfma_frags(const Tree *__restrict__ trees, const int32_t *__restrict__ f_ptr,
+                                                   const double *__restrict__ f_val, const double *__restrict__ diagk,
+                                                   double *__restrict__ frag_f, double *__restrict__ frag_b,
+                                                   unsigned long long *cond_bits) {
+    constexpr int BS = 16 * NB;
+    __shared__ double Ls[BS][BS + 1];
+    __shared__ double W[NB][16][17];
+    const int lane = threadIdx.x;
+    const int32_t t = blockIdx.x, first = trees[t].first, base = f_ptr[first];
+    double lmax = 0.0;
+    for (int e = lane; e < BS * BS; e += 64) {
+        const int a = e / BS, c = e % BS;
+        const double v = c < a ? f_val[base + a * (a - 1) / 2 + c] : (c == a ? diagk[first + a] : 0.0);
+        Ls[a][c] = v;
+        lmax = fmax(lmax, fabs(v));
+    }
+    __syncthreads();
+    double wmax = 0.0;
+    {
+        const int blk = lane >> 4, col = lane & 15;
+        if (blk < NB) {
+            double wcol[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                double sres = r == col ? 1.0 : 0.0;
+#pragma unroll
+                for (int q = 0; q < r; q++) sres -= Ls[16 * blk + r][16 * blk + q] * (q >= col ? wcol[q] : 0.0);
+                wcol[r] = r >= col ? sres / Ls[16 * blk + r][16 * blk + r] : 0.0;
+                W[blk][r][col] = wcol[r];
+                wmax = fmax(wmax, fabs(wcol[r]));
+            }
+        }
+    }
+    __syncthreads();
+    const int m = lane & 15, kq = lane >> 4;
+    double *F = frag_f + (size_t)t * mfma_frags<NB>() * 64 + lane;
+    double *G = frag_b + (size_t)t * mfma_frags<NB>() * 64 + lane;
+    int f = 0;
+    for (int i = 0; i < NB; i++) {
+        for (int j = 0; j < i; j++)
+            for (int sx = 0; sx < 4; sx++) F[64 * f++] = -Ls[16 * i + m][16 * j + 4 * sx + kq];
+        for (int sx = 0; sx < 4; sx++) F[64 * f++] = W[i][m][4 * sx + kq];
+    }
+    f = 0;
+    for (int i = NB - 1; i >= 0; i--) {
+        for (int j = i + 1; j < NB; j++)
+            for (int sx = 0; sx < 4; sx++) G[64 * f++] = -Ls[16 * j + 4 * sx + kq][16 * i + m];
+        for (int sx = 0; sx < 4; sx++) G[64 * f++] = W[i][4 * sx + kq][m];
+    }
+    // largest |W| |L| over the forest, as ordered bits of a non-negative double
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        lmax = fmax(lmax, __shfl_xor(lmax, d, 64));
+        wmax = fmax(wmax, __shfl_xor(wmax, d, 64));
+    }
+    if (lane == 0) atomicMax(cond_bits, (unsigned long long)__double_as_longlong(lmax * wmax));
+}
+
+template <int NB>
+__global__ __launch_bounds__(256, 2) void k_cholsol_mfma(const Tree *__restrict__ trees, int32_t ntrees,
+                                                      const int32_t *__restrict__ nodes, const int32_t *__restrict__ perm,
+                                                      const double *__restrict__ frag_f, const double *__restrict__ frag_b,
+                                                      double *B, int32_t nrhs, int32_t chunks) {
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t task = (int64_t)blockIdx.x * 4 + w;
+    if (task >= (int64_t)ntrees * chunks) return;
+    const int32_t t = (int32_t)(task / chunks), h = (int32_t)(task % chunks);
+    const int32_t first = trees[t].first;
+    const int col = lane & 15, rq = lane >> 4;
+    // rows of B this lane touches: local row 16 i + rq + 4 r
+    int64_t roff[NB][4];
+#pragma unroll
+    for (int i = 0; i < NB; i++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            int32_t jr = nodes[first + 16 * i + rq + 4 * r];
+            if (perm) jr = perm[jr];
+            roff[i][r] = (int64_t)jr * nrhs;
+        }
+    f64x4 X[NB][4];
+    bool live[4];
+    int32_t cidx[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const int32_t rhs = h * 64 + 16 * c + col;
+        live[c] = rhs < nrhs;
+        cidx[c] = live[c] ? rhs : nrhs - 1;   // clamped: loaded, never stored
+    }
+#pragma unroll
+    for (int i = 0; i < NB; i++)
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) X[i][c][r] = B[roff[i][r] + cidx[c]];
+    const double *F = frag_f + (size_t)t * mfma_frags<NB>() * 64 + lane;
+    const double *G = frag_b + (size_t)t * mfma_frags<NB>() * 64 + lane;
+    int f = 0;
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+#pragma unroll
+        for (int j = 0; j < i; j++)
+#pragma unroll
+            for (int sx = 0; sx < 4; sx++) {
+                const double a = F[64 * f++];
+#pragma unroll
+                for (int c = 0; c < 4; c++) X[i][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[j][c][sx], X[i][c], 0, 0, 0);
+            }
+        f64x4 Y[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) Y[c] = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int sx = 0; sx < 4; sx++) {
+            const double a = F[64 * f++];
+#pragma unroll
+            for (int c = 0; c < 4; c++) Y[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[i][c][sx], Y[c], 0, 0, 0);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) X[i][c] = Y[c];
+    }
+    f = 0;
+#pragma unroll
+    for (int i = NB - 1; i >= 0; i--) {
+#pragma unroll
+        for (int j = i + 1; j < NB; j++)
+#pragma unroll
+            for (int sx = 0; sx < 4; sx++) {
+                const double a = G[64 * f++];
+#pragma unroll
+                for (int c = 0; c < 4; c++) X[i][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[j][c][sx], X[i][c], 0, 0, 0);
+            }
+        f64x4 Y[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) Y[c] = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int sx = 0; sx < 4; sx++) {
+            const double a = G[64 * f++];
+#pragma unroll
+            for (int c = 0; c < 4; c++) Y[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[i][c][sx], Y[c], 0, 0, 0);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) X[i][c] = Y[c];
+    }
+#pragma unroll
+    for (int i = 0; i < NB; i++)
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                if (live[c]) B[roff[i][r] + cidx[c]] = X[i][c][r];
+}
+
 __global__ __launch_bounds__(256) void k_perm_rows(const int32_t *__restrict__ perm, const double *__restrict__ src,
                                                    double *__restrict__ dst, int32_t n, int32_t nrhs, int to_x) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -898,6 +1074,38 @@ static int cholsol_plan(const Csc *L, const int32_t *pinv, CholPlan **out) {
             CSX_LAUNCH_CHECK();
             CSX_HIP(hipStreamSynchronize(s));
             P->dense_bs = bs;
+            if (bs >= 16 && !std::getenv("CSX_CHOLSOL_NO_MFMA")) {   // matrix-core path: block fragments + inverses
+                const int nb16 = bs / 16;
+                const size_t nfrag = (size_t)(nb16 * (nb16 - 1) / 2 + nb16) * 4;
+                unsigned long long *cond = nullptr, hcond = 0;
+                CSX_TRY(dalloc(&cond, 1));
+                CSX_HIP(hipMemsetAsync(cond, 0, sizeof(unsigned long long), s));
+                CSX_TRY(dalloc(&P->frag_f, (size_t)P->ntrees * nfrag * 64));
+                CSX_TRY(dalloc(&P->frag_b, (size_t)P->ntrees * nfrag * 64));
+                const dim3 g((unsigned)P->ntrees);
+                if (nb16 == 1)
+                    hipLaunchKernelGGL(k_mfma_frags<1>, g, dim3(64), 0, s, P->trees, P->f_ptr, P->f_val, P->diagk, P->frag_f,
+                                       P->frag_b, cond);
+                else if (nb16 == 2)
+                    hipLaunchKernelGGL(k_mfma_frags<2>, g, dim3(64), 0, s, P->trees, P->f_ptr, P->f_val, P->diagk, P->frag_f,
+                                       P->frag_b, cond);
+                else
+                    hipLaunchKernelGGL(k_mfma_frags<4>, g, dim3(64), 0, s, P->trees, P->f_ptr, P->f_val, P->diagk, P->frag_f,
+                                       P->frag_b, cond);
+                int st2 = hipGetLastError() == hipSuccess ? CSX_OK : CSX_ERUNTIME;
+                if (st2 == CSX_OK && (hipMemcpyAsync(&hcond, cond, sizeof hcond, hipMemcpyDeviceToHost, s) != hipSuccess ||
+                                      hipStreamSynchronize(s) != hipSuccess))
+                    st2 = CSX_ERUNTIME;
+                dfree(cond);
+                double growth;
+                std::memcpy(&growth, &hcond, sizeof growth);
+                if (st2 != CSX_OK || !(growth <= 1e6)) {   // badly conditioned block (or NaN): keep substitution
+                    dfree(P->frag_f);
+                    dfree(P->frag_b);
+                    P->frag_f = P->frag_b = nullptr;
+                }
+                CSX_TRY(st2);
+            }
         }
     }
     return CSX_OK;
@@ -920,6 +1128,24 @@ static int cholsol_solve(CholPlan *P, double *B, int32_t nrhs) {
             const int32_t chunks = (nrhs + 63) / 64;
             const int64_t tasks = (int64_t)P->ntrees * chunks;
             const dim3 grid((unsigned)((tasks + 3) / 4));
+            if (P->frag_f && !std::getenv("CSX_CHOLSOL_NO_MFMA")) {
+                switch (P->dense_bs) {
+                    case 16:
+                        hipLaunchKernelGGL(k_cholsol_mfma<1>, grid, dim3(256), 0, s, P->trees, P->ntrees, P->tree_nodes,
+                                           P->perm, P->frag_f, P->frag_b, B, nrhs, chunks);
+                        break;
+                    case 32:
+                        hipLaunchKernelGGL(k_cholsol_mfma<2>, grid, dim3(256), 0, s, P->trees, P->ntrees, P->tree_nodes,
+                                           P->perm, P->frag_f, P->frag_b, B, nrhs, chunks);
+                        break;
+                    default:
+                        hipLaunchKernelGGL(k_cholsol_mfma<4>, grid, dim3(256), 0, s, P->trees, P->ntrees, P->tree_nodes,
+                                           P->perm, P->frag_f, P->frag_b, B, nrhs, chunks);
+                        break;
+                }
+                CSX_LAUNCH_CHECK();
+                return CSX_OK;
+            }
 #define CSX_DENSE(BS)                                                                                          \
     hipLaunchKernelGGL(k_cholsol_dense<BS>, grid, dim3(256), 0, s, P->trees, P->ntrees, P->tree_nodes, P->perm, \
                        P->f_ptr, P->f_val, P->b_ptr, P->dense_b, P->diagk, P->diagb, B, nrhs, chunks)
@@ -1007,7 +1233,8 @@ extern "C" int csx_cholsol_plan(csx_handle_t hL, const int32_t *pinv, csx_handle
 extern "C" int csx_cholsol_info(csx_handle_t h, int32_t *local, int32_t *ntrees, int32_t *max_nodes) {
     CholPlan *P = (CholPlan *)get(h, K_CHOLPLAN);
     if (!P) return CSX_EINVAL;
-    if (local) *local = P->local ? (P->dense_bs ? 2 : 1) : 0;  // 0 level-scheduled, 1 fused in LDS, 2 dense blocks
+    // 0 level-scheduled, 1 fused in LDS, 2 dense blocks (substitution), 3 dense blocks on the matrix cores
+    if (local) *local = P->local ? (P->dense_bs ? (P->frag_f ? 3 : 2) : 1) : 0;
     if (ntrees) *ntrees = P->ntrees;
     if (max_nodes) *max_nodes = P->max_nodes;
     return CSX_OK;

@@ -140,7 +140,9 @@ int csx_chol(csx_handle_t A, const int32_t *parent, const int32_t *cp, const int
 /* The solve phase of cs_cholsol, csparse.py:640-643, for nrhs right-hand sides:
  * B (n-by-nrhs, row-major) is overwritten with the solutions. */
 int csx_cholsol_plan(csx_handle_t L, const int32_t *pinv /* host, or NULL */, csx_handle_t *plan);
-/* *path: 0 = level-scheduled generic, 1 = fused per-tree kernel (X tile in LDS), 2 = dense-block kernel */
+/* *path: 0 = level-scheduled generic, 1 = fused per-tree kernel (X tile in LDS), 2 = dense-block
+ * substitution kernel, 3 = dense blocks as a blocked TRSM on the matrix cores (fp64 MFMA; blocks of 16/32/64
+ * whose block inverses are benign) */
 int csx_cholsol_info(csx_handle_t plan, int32_t *path, int32_t *ntrees, int32_t *max_nodes);
 int csx_cholsol_solve(csx_handle_t plan, csx_handle_t B, int32_t nrhs);
 

@@ -114,7 +114,8 @@ def test_gspd_factor_and_batched_solve(cs, nblocks, bs, k):
     n = nblocks * bs
     A = cs.cs_pin(_host_cs(cs, n, n, Ap, Ai, Ax))
     F = cs.cholsol_factor(A)
-    assert F.info() == {"fused_local": True, "dense_block": bs, "trees": nblocks, "max_nodes": bs}
+    assert F.info() == {"fused_local": True, "dense_block": bs, "matrix_cores": bs >= 16, "trees": nblocks,
+                        "max_nodes": bs}
     parent, cp = CO.schol(n, Ap, Ai)
     assert F.symbolic.parent == parent.tolist() and F.symbolic.cp == cp.tolist()
     Lp, Li, Lx = CO.chol(n, Ap, Ai, Ax, parent, cp)
@@ -139,8 +140,18 @@ def test_gspd_factor_and_batched_solve(cs, nblocks, bs, k):
     gLp, gLi, gLx = _arr(L)
     for r in sorted(set([0, 1, k // 2, k - 1])):
         ref = CO.ltsolve(n, gLp, gLi, gLx, CO.lsolve(n, gLp, gLi, gLx, B[:, r]))
-        # dense-block kernel: FMA + reciprocal diagonal -> equal to rounding, not bit for bit
+        # dense-block kernels (blocked TRSM on the matrix cores for bs >= 16, FMA substitution below):
+        # equal to rounding, not bit for bit
         assert np.max(np.abs(X[:, r] - ref) / np.abs(ref)) < 1e-13, r
+    # the substitution dense kernel (matrix cores off) agrees to rounding too
+    os.environ["CSX_CHOLSOL_NO_MFMA"] = "1"
+    try:
+        dB3 = cs.dvec(B)
+        assert F.solve(dB3) is True
+        X3 = dB3.numpy()
+    finally:
+        del os.environ["CSX_CHOLSOL_NO_MFMA"]
+    assert np.max(np.abs(X3 - X) / np.abs(X)) < 1e-13
     # the reference-order fused kernel (forced) is bit-identical per right-hand side
     os.environ["CSX_CHOLSOL_NO_DENSE"] = "1"
     try:
@@ -159,6 +170,29 @@ def test_gspd_factor_and_batched_solve(cs, nblocks, bs, k):
     b = B[:, 0].tolist()
     assert cs.cs_cholsol(0, A, b) is True
     assert np.asarray(b).tobytes() == X[:, 0].tobytes()
+
+
+def test_badly_scaled_blocks_keep_substitution(cs):
+    """Block inverses with large growth (max|W| max|L| > 1e6): the plan must not use the matrix-core path,
+    and the solve still meets the tolerance."""
+    nblocks, bs, k = 6, 32, 20
+    Ap, Ai, Ax = synth.gspd(nblocks, bs, 77)
+    n = nblocks * bs
+    d = np.tile(np.logspace(-4, 4, bs), nblocks)   # symmetric scaling D A D keeps A SPD, spreads the pivots of a block
+    cols = np.repeat(np.arange(n), np.diff(Ap))
+    Ax2 = Ax * d[Ai] * d[cols]
+    A = cs.cs_pin(_host_cs(cs, n, n, Ap, Ai, Ax2))
+    F = cs.cholsol_factor(A)
+    info = F.info()
+    assert info["dense_block"] == bs and info["matrix_cores"] is False
+    B = synth.rhs(n, k, 0)
+    dB = cs.dvec(B)
+    assert F.solve(dB) is True
+    X = dB.numpy()
+    gLp, gLi, gLx = _arr(F.L)
+    for r in (0, k - 1):
+        ref = CO.ltsolve(n, gLp, gLi, gLx, CO.lsolve(n, gLp, gLi, gLx, B[:, r]))
+        assert np.max(np.abs(X[:, r] - ref) / np.abs(ref)) < 1e-10, r
 
 
 def test_forest_of_sparse_trees_uses_generic_fused_kernel(cs):
