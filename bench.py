@@ -188,7 +188,7 @@ def main():
         bs = 64
         nb = n // bs
         hB = _csx.new_handle()
-        _csx.check(lib.csx_gen_gspd(nb, bs, 20240601 + 5 + rank, hB), "gen_gspd")
+        _csx.check(lib.csx_gen_gspd(nb, bs, 20240601 + 5, hB), "gen_gspd")  # the same matrix on every rank: its right-hand sides are what is sharded
         hx, hy = _csx.new_handle(), _csx.new_handle()
         _csx.check(lib.csx_gen_vec(nb * bs, 9, 0.5, 1.5, hx), "gen_vec")
         _csx.check(lib.csx_vec_alloc(nb * bs, hy), "vec_alloc")

@@ -17,7 +17,11 @@
 // neighbouring right-hand sides (row-major X => coalesced).
 //
 // Scheduling: level sets (unknowns whose inputs are all in earlier levels).
-// Wide levels are one launch each; runs of narrow levels are executed by ONE
+// Wide levels are one launch each (measured on W, 80 dependent launches, 0.52 ms: replaying the chain
+// from a hipGraph changed nothing, so the cost is device-side dependency between dispatches, not host
+// launch calls; and one cooperative launch with a grid barrier per level was SLOWER, 0.79 ms at 10
+// workgroups and 5.4 ms at 512: an agent-scope release/acquire across the 8 XCD L2s costs more than a
+// dispatch); runs of narrow levels are executed by ONE
 // workgroup that walks them with a workgroup barrier in between, so a chain
 // (thousands of one-row levels) costs one launch, not thousands.
 //
@@ -147,9 +151,27 @@ __device__ __forceinline__ void solve_one(int32_t row, int r, int nrhs, const in
                                           const double *__restrict__ diag, int skip_first, int skip_last, double *X) {
     const int32_t b = ptr[row] + skip_first, e = ptr[row + 1] - skip_last;
     double acc = X[(int64_t)row * nrhs + r];
-    for (int32_t q = b; q < e; q++) {
-        double t = val[q] * X[(int64_t)idx[q] * nrhs + r];
-        acc = acc - t;
+    // Terms are SUBTRACTED strictly in order (that is the parity contract), but their operands are
+    // fetched eight at a time: one round trip for eight (index, value) pairs, one for the eight x's,
+    // instead of two dependent round trips per term.  Slots past the row end re-read its last term
+    // (a valid address) and are skipped in the arithmetic.
+    constexpr int TB = 8;
+    for (int32_t q0 = b; q0 < e; q0 += TB) {
+        int32_t c[TB];
+        double v[TB], xv[TB];
+#pragma unroll
+        for (int u = 0; u < TB; u++) {
+            const int32_t q = q0 + u < e ? q0 + u : e - 1;
+            c[u] = idx[q];
+            v[u] = val[q];
+        }
+#pragma unroll
+        for (int u = 0; u < TB; u++) xv[u] = X[(int64_t)c[u] * nrhs + r];
+#pragma unroll
+        for (int u = 0; u < TB; u++) {
+            const double t = v[u] * xv[u];
+            acc = q0 + u < e ? acc - t : acc;
+        }
     }
     X[(int64_t)row * nrhs + r] = acc / diag[row];
 }
