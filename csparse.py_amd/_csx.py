@@ -24,6 +24,12 @@ _PROTOS = {
     "csx_sync": [],
     "csx_set_stream": [_vp],
     "csx_device_info": [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)],
+    "csx_compress": [C.c_int32, C.c_int32, C.c_int64, _i32p, _i32p, _f64p, C.POINTER(H)],
+    "csx_add": [H, H, C.c_double, C.c_double, C.POINTER(H)],
+    "csx_dupl": [H, C.POINTER(H)],
+    "csx_drop": [H, C.c_int, C.c_double, C.POINTER(H)],
+    "csx_permute": [H, _i32p, _i32p, C.c_int, C.POINTER(H)],
+    "csx_symperm": [H, _i32p, C.c_int, C.POINTER(H)],
     "csx_mem_trim": [],
     "csx_mem_info": [C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
     "csx_timer_start": [],

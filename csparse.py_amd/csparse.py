@@ -298,6 +298,15 @@ def cs_compress(T):
     if not CS_TRIPLET(T):
         return None
     nz = T.nz
+    if T._pinned:   # cs_pin(T): sort on the device and keep the result there
+        rows, cols = _csx.i32(T.i[:nz]), _csx.i32(T.p[:nz])
+        vals = None if T.x is None else _csx.f64(T.x[:nz])
+        h = _csx.new_handle()
+        st = _csx.lib().csx_compress(T.m, T.n, nz, _csx.pi(rows), _csx.pi(cols), _csx.pd(vals), h)
+        if st == _csx.EINVAL:
+            raise IndexError("list index out of range")
+        _csx.check(st, "csx_compress")
+        return _from_device(h, lambda nnz: max(nnz, 1))
     C = cs_spalloc(T.m, T.n, nz, T.x is not None, False)
     cols = np.asarray(T.p[:nz], dtype=np.int64)
     order = np.argsort(cols, kind="stable")
@@ -414,6 +423,9 @@ def cs_pin(A):
     """Keep A resident on the device (and cache its analyses) until cs_unpin /
     its host lists are reassigned.  In-place edits of A.p / A.i / A.x after
     pinning are not seen: call cs_invalidate(A)."""
+    if CS_TRIPLET(A):   # nothing to upload yet: cs_compress will sort it on the device and keep it there
+        A._pinned = True
+        return A
     if not CS_CSC(A):
         return None
     if A._dev is None:
@@ -532,6 +544,151 @@ def cs_multiply(A, B):
         C._pinned = False
     return C
 
+
+
+def _meta(A):
+    """(number of entries, has values) of a CSC matrix without pulling a device-resident one to the host."""
+    if A._lazy:
+        _, _, nnz, hv = A._dev.info()
+        return nnz, hv
+    return A._p[A.n], A._x is not None
+
+
+def _result(h, nzmax_rule, keep_on_device):
+    """Device result -> cs: lazy and pinned when the inputs were pinned, host lists otherwise."""
+    C = _from_device(h, nzmax_rule)
+    if not keep_on_device:
+        C._materialise()
+        C._i = (C._i + [0] * C.nzmax)[:C.nzmax]
+        if C._x is not None:
+            C._x = (C._x + [0.0] * C.nzmax)[:C.nzmax]
+        C._dev = None
+        C._pinned = False
+    return C
+
+
+def _replace_in_place(A, C):
+    """Give A the contents of C (the reference's in-place functions mutate their argument)."""
+    A.nzmax = C.nzmax
+    if C._lazy:
+        A._p, A._i, A._x = [], [], []
+        A._dev, A._lazy, A._pinned = C._dev, True, True
+    else:
+        A._dev, A._lazy, A._pinned = None, False, False
+        A._p, A._i, A._x = C._p, C._i, C._x
+
+
+def cs_add(A, B, alpha, beta):
+    """C = alpha*A + beta*B (csparse.py:163-192): column j in first-touch order over A(:,j) then
+    B(:,j); not trimmed (nzmax = nnz(A) + nnz(B)).  None if not CSC or the shapes differ."""
+    if not CS_CSC(A) or not CS_CSC(B):
+        return None
+    if A.m != B.m or A.n != B.n:
+        return None
+    room = _meta(A)[0] + _meta(B)[0]
+    with _Resident(A) as dA, _Resident(B) as dB:
+        h = _csx.new_handle()
+        _csx.check(_csx.lib().csx_add(dA.handle, dB.handle, float(alpha), float(beta), h), "csx_add")
+    return _result(h, lambda nnz: max(room, 1), A._pinned and B._pinned)
+
+
+def cs_dupl(A):
+    """Sum duplicate entries into their first occurrence, in place (csparse.py:1035-1065)."""
+    if not CS_CSC(A):
+        return False
+    nnz, hv = _meta(A)
+    if not hv and nnz > 0:
+        raise TypeError("'NoneType' object is not subscriptable")   # as the reference on a pattern-only matrix
+    pinned = A._pinned
+    with _Resident(A) as dA:
+        h = _csx.new_handle()
+        _csx.check(_csx.lib().csx_dupl(dA.handle, h), "csx_dupl")
+    _replace_in_place(A, _result(h, lambda nnz: nnz, pinned))
+    return True
+
+
+def cs_fkeep(A, fkeep, other):
+    """Keep the entries for which fkeep(i, j, aij, other) is true, in place; returns the new number of
+    entries, -1 on bad input (csparse.py:1172-1196).  The predicate is a Python callable, so this generic
+    form runs on the host; cs_dropzeros / cs_droptol are the device versions of its two uses."""
+    if not CS_CSC(A) or fkeep is None:
+        return -1
+    Ap, Ai, Ax, n = A.p, A.i, A.x, A.n
+    nz = 0
+    for j in range(n):
+        p = Ap[j]
+        Ap[j] = nz
+        while p < Ap[j + 1]:
+            if fkeep(Ai[p], j, Ax[p] if Ax is not None else 1.0, other):
+                if Ax is not None:
+                    Ax[nz] = Ax[p]
+                Ai[nz] = Ai[p]
+                nz += 1
+            p += 1
+    Ap[n] = nz
+    A.p = Ap
+    A.i = (Ai + [0] * nz)[:nz] if isinstance(Ai, list) else list(Ai[:nz])
+    if Ax is not None:
+        A.x = (Ax + [0.0] * nz)[:nz] if isinstance(Ax, list) else list(Ax[:nz])
+    A.nzmax = nz
+    return nz
+
+
+def _drop(A, mode, tol):
+    if not CS_CSC(A):
+        return -1
+    if not _meta(A)[1]:   # the reference passes aij = 1 for a pattern-only matrix
+        keep_all = True if mode == 0 else 1.0 > tol
+        return cs_fkeep(A, lambda i, j, a, o: keep_all, None)
+    pinned = A._pinned
+    with _Resident(A) as dA:
+        h = _csx.new_handle()
+        _csx.check(_csx.lib().csx_drop(dA.handle, mode, float(tol), h), "csx_drop")
+    C = _result(h, lambda nnz: nnz, pinned)
+    _replace_in_place(A, C)
+    return A._dev.info()[2] if A._lazy else A._p[A.n]
+
+
+def cs_dropzeros(A):
+    """Remove explicit zeros, in place; returns the new nnz (csparse.py:1019-1031)."""
+    return _drop(A, 0, 0.0)
+
+
+def cs_droptol(A, tol):
+    """Remove entries with |a| <= tol, in place; returns the new nnz (csparse.py:1002-1014)."""
+    return _drop(A, 1, tol)
+
+
+def cs_permute(A, pinv, q, values):
+    """C = P A Q, pinv the inverse row permutation, q the column permutation (csparse.py:1666-1693)."""
+    if not CS_CSC(A):
+        return None
+    if pinv is not None and len(pinv) < A.m or q is not None and len(q) < A.n:
+        raise IndexError("list index out of range")
+    pv = None if pinv is None else _csx.i32(pinv)
+    qv = None if q is None else _csx.i32(q)
+    with _Resident(A) as dA:
+        h = _csx.new_handle()
+        st = _csx.lib().csx_permute(dA.handle, _csx.pi(pv), _csx.pi(qv), 1 if values else 0, h)
+    if st == _csx.EINVAL:
+        raise IndexError("list index out of range")
+    _csx.check(st, "csx_permute")
+    return _result(h, lambda nnz: max(nnz, 1), A._pinned)
+
+
+def cs_symperm(A, pinv, values):
+    """Upper triangle of P A P' for a symmetric A whose upper triangle is stored (csparse.py:2220-2255)."""
+    if not CS_CSC(A):
+        return None
+    room = _meta(A)[0]
+    pv = None if pinv is None else _csx.i32(pinv)
+    with _Resident(A) as dA:
+        h = _csx.new_handle()
+        st = _csx.lib().csx_symperm(dA.handle, _csx.pi(pv), 1 if values else 0, h)
+    if st == _csx.EINVAL:
+        raise IndexError("list index out of range")
+    _csx.check(st, "csx_symperm")
+    return _result(h, lambda nnz: max(room, 1), A._pinned)
 
 def _plan(dT, kind):
     h = dT.plans.get(kind)

@@ -601,7 +601,7 @@ static int run_bins(const Csc *A, const Csc *B, const uint32_t *cols, const int3
     return CSX_OK;
 }
 
-static int multiply_device(const Csc *A, const Csc *B, Csc *C) {
+int multiply_device(const Csc *A, const Csc *B, Csc *C) {
     hipStream_t s = ctx().stream;
     const int32_t m = A->m, n = B->n;
     const bool values = A->x && B->x;

@@ -146,6 +146,24 @@ int csx_cholsol_plan(csx_handle_t L, const int32_t *pinv /* host, or NULL */, cs
 int csx_cholsol_info(csx_handle_t plan, int32_t *path, int32_t *ntrees, int32_t *max_nodes);
 int csx_cholsol_solve(csx_handle_t plan, csx_handle_t B, int32_t nrhs);
 
+/* ---- assembly and reshaping around the hot path ---------
+ * Every function returns a NEW matrix handle.  p[] / i[] bit-identical to the reference's result.
+ * cs_compress, csparse.py:647-673: host triplets (row Ti[k], column Tj[k], value Tx[k] or NULL) -> CSC,
+ *   entries of a column in triplet order (stable counting sort by column).
+ * cs_add, csparse.py:163-192: alpha*A + beta*B; column pattern in first-touch order over A(:,j) then B(:,j).
+ * cs_dupl, csparse.py:1035-1065: duplicates summed into their first occurrence.
+ * cs_dropzeros / cs_droptol, csparse.py:1019-1031 / 1002-1014: mode 0 keeps a != 0, mode 1 keeps |a| > tol;
+ *   order preserved.  Needs values.
+ * cs_permute, csparse.py:1666-1693: C = P A Q (pinv: host, length m, or NULL; q: host, length n, or NULL).
+ * cs_symperm, csparse.py:2220-2255: upper triangle of P A P' (pinv host permutation or NULL), A square. */
+int csx_compress(int32_t m, int32_t n, int64_t nz, const int32_t *Ti, const int32_t *Tj, const double *Tx,
+                 csx_handle_t *out);
+int csx_add(csx_handle_t A, csx_handle_t B, double alpha, double beta, csx_handle_t *out);
+int csx_dupl(csx_handle_t A, csx_handle_t *out);
+int csx_drop(csx_handle_t A, int mode, double tol, csx_handle_t *out);
+int csx_permute(csx_handle_t A, const int32_t *pinv, const int32_t *q, int values, csx_handle_t *out);
+int csx_symperm(csx_handle_t A, const int32_t *pinv, int values, csx_handle_t *out);
+
 /* cs_lu, csparse.py:1370-1451 (+ cs_spsolve :2078-2113), natural column order: host C++
  * left-looking LU with threshold partial pivoting.  It produces the L (unit diagonal first)
  * and U (diagonal last) that cs_lsolve / cs_usolve consume in cs_lusol (csparse.py:1474-1477).
