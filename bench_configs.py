@@ -172,6 +172,70 @@ def config4(n=1000000, per_col=32):
     return out
 
 
+def assembly(n=1000000, per_col=32):
+    """The reshaping functions either side of the hot path on S-sized inputs (device-resident):
+    cs_add (A + A'), cs_dropzeros, cs_permute, cs_symperm, and cs_compress of 3.2e7 host triplets."""
+    lib = _csx.lib()
+    C = _csx.C
+    hA = _csx.new_handle()
+    _csx.check(lib.csx_gen_grand(n, per_col, 20240607, hA))
+    hB = _csx.new_handle()
+    _csx.check(lib.csx_transpose(hA, 1, hB))
+    nnzA = n * per_col
+    res = {}
+
+    def nnz_of(h):
+        m_, n_, z, hv = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int()
+        _csx.check(lib.csx_csc_info(h, m_, n_, z, hv))
+        return z.value
+
+    def timed_new(call, reps=3):
+        best, h = 1e30, None
+        for _ in range(reps):
+            if h is not None:
+                _csx.free(h)
+            h = _csx.new_handle()
+            with _csx.Timer() as tm:
+                _csx.check(call(h))
+            best = min(best, tm.ms)
+        return best, h
+
+    ms, hS = timed_new(lambda h: lib.csx_add(hA, hB, 1.0, 1.0, h))
+    nnzS = nnz_of(hS)
+    by = 12 * (2 * nnzA + nnzS) + 4 * 3 * (n + 1)
+    res["cs_add A + A'"] = {"ms": round(ms, 2), "nnz_out": nnzS, "algorithmic_GBps": round(by / ms / 1e6, 1)}
+    ms, hD = timed_new(lambda h: lib.csx_drop(hS, 0, 0.0, h))
+    by = 12 * (nnzS + nnz_of(hD)) + 8 * (n + 1)
+    res["cs_dropzeros"] = {"ms": round(ms, 2), "algorithmic_GBps": round(by / ms / 1e6, 1)}
+    rng = np.random.default_rng(3)
+    pinv = rng.permutation(n).astype(np.int32)
+    q = rng.permutation(n).astype(np.int32)
+    ms, hP = timed_new(lambda h: lib.csx_permute(hA, _csx.pi(pinv), _csx.pi(q), 1, h))
+    by = 24 * nnzA + 8 * (n + 1) + 8 * n
+    res["cs_permute"] = {"ms": round(ms, 2), "algorithmic_GBps": round(by / ms / 1e6, 1),
+                         "note": "includes uploading the two permutations (8 MB)"}
+    ms, hU = timed_new(lambda h: lib.csx_symperm(hS, _csx.pi(pinv), 1, h))
+    nnzU = nnz_of(hU)
+    by = 12 * (nnzS + nnzU) + 8 * (n + 1) + 4 * n
+    res["cs_symperm"] = {"ms": round(ms, 2), "nnz_out": nnzU, "algorithmic_GBps": round(by / ms / 1e6, 1)}
+    # cs_compress from host triplets: PCIe-inclusive by construction (the boundary hands over host arrays)
+    p = np.empty(n + 1, np.int32)
+    ti = np.empty(nnzA, np.int32)
+    tx = np.empty(nnzA, np.float64)
+    _csx.check(lib.csx_csc_download(hA, _csx.pi(p), _csx.pi(ti), _csx.pd(tx)))
+    tj = np.repeat(np.arange(n, dtype=np.int32), np.diff(p))
+    perm = rng.permutation(nnzA)
+    ti, tj, tx = ti[perm], tj[perm], tx[perm]
+    t0 = time.perf_counter()
+    hT = _csx.new_handle()
+    _csx.check(lib.csx_compress(n, n, nnzA, _csx.pi(ti), _csx.pi(tj), _csx.pd(tx), hT))
+    _csx.sync()
+    res["cs_compress (3.2e7 shuffled host triplets)"] = {"s_incl_upload": round(time.perf_counter() - t0, 3)}
+    for h in (hA, hB, hS, hD, hP, hU, hT):
+        _csx.free(h)
+    return {"config": "assembly functions on S-sized inputs (%d x %d, %d nnz/col)" % (n, n, per_col), "results": res}
+
+
 def transpose_grand(n=5000000, per_col=64):
     lib = _csx.lib()
     hA = _csx.new_handle()
@@ -204,7 +268,7 @@ def transpose_grand(n=5000000, per_col=64):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-spgemm", action="store_true")
-    ap.add_argument("--only", default=None, help="run one section: spmv | lusolve | spgemm | transpose")
+    ap.add_argument("--only", default=None, help="run one section: spmv | lusolve | spgemm | transpose | assembly")
     ap.add_argument("--skip-transpose", action="store_true")
     a = ap.parse_args()
     _csx.init()
@@ -218,6 +282,8 @@ def main():
         print(json.dumps(transpose_grand()))
     if want("spgemm") and not a.skip_spgemm:
         print(json.dumps(config4()))
+    if want("assembly"):
+        print(json.dumps(assembly()))
 
 
 if __name__ == "__main__":
