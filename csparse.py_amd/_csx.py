@@ -30,6 +30,7 @@ _PROTOS = {
     "csx_drop": [H, C.c_int, C.c_double, C.POINTER(H)],
     "csx_permute": [H, _i32p, _i32p, C.c_int, C.POINTER(H)],
     "csx_symperm": [H, _i32p, C.c_int, C.POINTER(H)],
+    "csx_schol": [H, _i32p, _i32p],
     "csx_mem_trim": [],
     "csx_mem_info": [C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
     "csx_timer_start": [],

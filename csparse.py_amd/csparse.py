@@ -783,11 +783,15 @@ def cs_schol(order, A):
     if not CS_CSC(A) or order != 0:
         return None
     n = A.n
-    p = _csx.i32(A.p[:n + 1])
-    i = _csx.i32(A.i[:int(p[n])])
     parent = np.empty(max(n, 1), dtype=np.int32)
     cp = np.empty(n + 1, dtype=np.int32)
-    st = _csx.load().csx_schol_host(n, _csx.pi(p), _csx.pi(i), _csx.pi(parent), _csx.pi(cp))
+    if A._dev is not None and A.m == A.n:
+        # device-resident matrix: tree on the host, column counts from the device's row-subtree walks
+        st = _csx.lib().csx_schol(A._dev.handle, _csx.pi(parent), _csx.pi(cp))
+    else:
+        p = _csx.i32(A.p[:n + 1])
+        i = _csx.i32(A.i[:int(p[n])])
+        st = _csx.load().csx_schol_host(n, _csx.pi(p), _csx.pi(i), _csx.pi(parent), _csx.pi(cp))
     if st != _csx.OK:
         return None
     S = css()

@@ -43,7 +43,8 @@ namespace csx {
 
 // csx_cholsym.hip
 int chol_symbolic_device(const Csc *A, const int32_t *parent, const int32_t *cp, const int32_t *pinv, int32_t **Lp_out,
-                         int32_t **Li_out, int32_t **row_ptr_out, int32_t **row_col_out, int32_t **row_pos_out);
+                         int32_t **Li_out, int32_t **row_ptr_out, int32_t **row_col_out, int32_t **row_pos_out,
+                         int32_t *cp_host_out);
 // csx_trisolve.hip
 struct TriPlan;
 int tri_solve_raw(TriPlan *P, double *X, int32_t nrhs);
@@ -335,7 +336,7 @@ static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, c
     int32_t *d_small_cols = nullptr, *d_level_cols = nullptr, *d_level_ptr = nullptr;
     Tree *d_trees = nullptr, *d_dense = nullptr;
     int *d_flags = nullptr;
-    CSX_TRY(chol_symbolic_device(A, parent, cp, pinv, &L->p, &L->i, &d_rp, &d_rc, &d_rpos));
+    CSX_TRY(chol_symbolic_device(A, parent, cp, pinv, &L->p, &L->i, &d_rp, &d_rc, &d_rpos, nullptr));
     lap("pattern (device)");
     Forest F;
     partition_forest(n, parent, F);

@@ -22,6 +22,7 @@
 //      columns k (ascending, diagonal last) and the position of L(j,k) in L.i / L.x
 //
 // The host contributes only the O(n) postorder of the tree it already holds (S.parent).
+#include <memory>
 #include <vector>
 
 #include "csx_internal.h"
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(256) void k_sym_walk(int64_t ns, const uint32_t *__
     while (v >= 0 && v < k && first[v] > prev_post) {
         if (EMIT) {
             ev[out + c] = (uint32_t)v;
-            ek[out + c] = (uint32_t)k;
+            if (ek) ek[out + c] = (uint32_t)k;
         }
         c++;
         v = parent[v];
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256) void k_sym_emit_diag(int32_t n, const int32_t 
     if (k >= n) return;
     const int64_t out = items[k + sptr[k]];
     ev[out] = (uint32_t)k;
-    ek[out] = (uint32_t)k;
+    if (ek) ek[out] = (uint32_t)k;
 }
 
 // ---- 3./4. checks and the row view --------------------------------------------------------------------
@@ -165,14 +166,22 @@ static inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256
 // On success the five outputs are device arrays owned by the caller (dfree):
 //   Lp (n+1), Li (lnz), row_ptr (n+1), row_col (lnz), row_pos (lnz); the row view includes the diagonal
 //   as the LAST entry of each row.
+// Counts-only mode (cs_schol): cp == nullptr and cp_host_out != nullptr -- the column counts of L are
+// computed from the same walks (emit the column of every entry, sort, boundaries) and returned on the
+// host as column pointers; the five device outputs are not produced.
 int chol_symbolic_device(const Csc *A, const int32_t *parent, const int32_t *cp, const int32_t *pinv, int32_t **Lp_out,
-                         int32_t **Li_out, int32_t **row_ptr_out, int32_t **row_col_out, int32_t **row_pos_out) {
+                         int32_t **Li_out, int32_t **row_ptr_out, int32_t **row_col_out, int32_t **row_pos_out,
+                         int32_t *cp_host_out) {
     hipStream_t s = ctx().stream;
     const int32_t n = A->n;
-    const int64_t lnz = cp[n];
-    if (lnz < n) return CSX_EINVAL;
-    for (int32_t j = 0; j < n; j++)
-        if (cp[j + 1] - cp[j] < 1) return CSX_EINVAL;
+    const bool counts_only = cp == nullptr;
+    if (counts_only && !cp_host_out) return CSX_EINVAL;
+    int64_t lnz = counts_only ? -1 : cp[n];
+    if (!counts_only) {
+        if (lnz < n) return CSX_EINVAL;
+        for (int32_t j = 0; j < n; j++)
+            if (cp[j + 1] - cp[j] < 1) return CSX_EINVAL;
+    }
     std::vector<int32_t> first, post, postinv;
     if (!postorder_intervals(n, parent, first, post, postinv)) return CSX_EINVAL;
     if (pinv) {   // must be a permutation of 0..n-1
@@ -202,7 +211,7 @@ int chol_symbolic_device(const Csc *A, const int32_t *parent, const int32_t *cp,
     if (st == CSX_OK) st = up(&d_first, first.data(), (size_t)n);
     if (st == CSX_OK) st = up(&d_post, post.data(), (size_t)n);
     if (st == CSX_OK) st = up(&d_postinv, postinv.data(), (size_t)n);
-    if (st == CSX_OK) st = up(&d_cp, cp, (size_t)n + 1);
+    if (st == CSX_OK && !counts_only) st = up(&d_cp, cp, (size_t)n + 1);
     if (st == CSX_OK && pinv) st = up(&d_pinv, pinv, (size_t)n);
     if (st == CSX_OK) st = dalloc(&bad, 1);
     if (st == CSX_OK) st = dalloc(&cnt, (size_t)n + 1);
@@ -241,14 +250,35 @@ int chol_symbolic_device(const Csc *A, const int32_t *parent, const int32_t *cp,
                                d_parent, items, nullptr, nullptr);
         st = scan_exclusive_i32(items, items, nitems, &total);
     }
+    if (st == CSX_OK && counts_only) {
+        if (total > 0x7FFFFFFFll) st = CSX_EINVAL;   // L does not fit int32 indices
+        lnz = total;
+    }
     if (st == CSX_OK && total != lnz) st = CSX_EINVAL;   // S.cp / S.parent do not describe chol(A)
     if (st == CSX_OK) st = dalloc(&ev, (size_t)lnz);
-    if (st == CSX_OK) st = dalloc(&ek, (size_t)lnz);
+    if (st == CSX_OK && !counts_only) st = dalloc(&ek, (size_t)lnz);
     if (st == CSX_OK) {
         hipLaunchKernelGGL(k_sym_emit_diag, dim3(blocks_for(n)), dim3(256), 0, s, n, sptr, items, ev, ek);
         if (ns > 0)
             hipLaunchKernelGGL(k_sym_walk<true>, dim3(blocks_for(ns)), dim3(256), 0, s, ns, rows, posts, d_postinv, d_first,
                                d_parent, items, ev, ek);
+    }
+    if (st == CSX_OK && counts_only) {   // column counts: sort the columns alone, boundaries = column pointers
+        st = dalloc(&sv, (size_t)lnz);
+        if (st == CSX_OK) st = dalloc(&Lp, (size_t)n + 1);
+        if (st == CSX_OK) st = stable_sort_by_key(ev, nullptr, nullptr, lnz, (uint32_t)n, sv, nullptr, nullptr);
+        if (st == CSX_OK) st = boundaries_from_sorted(sv, lnz, n, Lp);
+        if (st == CSX_OK &&
+            (hipMemcpyAsync(cp_host_out, Lp, ((size_t)n + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess ||
+             hipMemcpyAsync(&hbad, bad, sizeof hbad, hipMemcpyDeviceToHost, s) != hipSuccess ||
+             hipStreamSynchronize(s) != hipSuccess))
+            st = CSX_ERUNTIME;
+        if (st == CSX_OK && hbad) st = CSX_EINVAL;
+        for (void *p : {(void *)d_parent, (void *)d_first, (void *)d_post, (void *)d_postinv, (void *)d_pinv, (void *)cnt,
+                        (void *)sptr0, (void *)sptr, (void *)items, (void *)skey, (void *)srow, (void *)k1, (void *)r1,
+                        (void *)rows, (void *)posts, (void *)ev, (void *)sv, (void *)Lp, (void *)bad})
+            dfree(p);
+        return st;
     }
     // ---- 3. L in CSC ----
     if (st == CSX_OK) st = dalloc(&sv, (size_t)lnz);
@@ -300,4 +330,32 @@ int chol_symbolic_device(const Csc *A, const int32_t *parent, const int32_t *cp,
     return CSX_OK;
 }
 
+// csx_host.cpp
+void etree_of_csc(int32_t n, const int32_t *Ap, const int32_t *Ai, int32_t *parent);
+
 }  // namespace csx
+
+using namespace csx;
+
+// cs_schol with natural ordering (csparse.py:2051-2072) for a device-resident matrix: the elimination tree
+// on the host (Liu's algorithm with path compression is sequential and O(nnz)), the column counts on the
+// device from the same row-subtree walks cs_chol uses.  parent[n], cp[n+1] are host arrays.
+extern "C" int csx_schol(csx_handle_t hA, int32_t *parent, int32_t *cp) {
+    CSX_TRY(require_ready());
+    Csc *A = csc(hA);
+    if (!A || !parent || !cp || A->m != A->n) return CSX_EINVAL;
+    const int32_t n = A->n;
+    if (n == 0) {
+        cp[0] = 0;
+        return CSX_OK;
+    }
+    hipStream_t s = ctx().stream;
+    std::unique_ptr<int32_t[]> hp(new int32_t[(size_t)n + 1]), hi(new int32_t[(size_t)A->nnz + 1]);
+    CSX_HIP(hipMemcpyAsync(hp.get(), A->p, ((size_t)n + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    if (A->nnz) CSX_HIP(hipMemcpyAsync(hi.get(), A->i, (size_t)A->nnz * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    CSX_HIP(hipStreamSynchronize(s));
+    for (int32_t q = 0; q < A->nnz; q++)
+        if (hi[(size_t)q] < 0 || hi[(size_t)q] >= n) return CSX_EINVAL;
+    etree_of_csc(n, hp.get(), hi.get(), parent);
+    return chol_symbolic_device(A, parent, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, cp);
+}

@@ -63,6 +63,23 @@ void etree_of_upper(int32_t n, const std::vector<int32_t> &up_ptr, const std::ve
     }
 }
 
+// the same from a full CSC pattern: only entries above the diagonal of each column take part
+void etree_of_csc(int32_t n, const int32_t *Ap, const int32_t *Ai, int32_t *parent) {
+    std::vector<int32_t> anc((size_t)n, -1);
+    for (int32_t k = 0; k < n; k++) parent[k] = -1;
+    for (int32_t k = 0; k < n; k++) {
+        for (int32_t p = Ap[k]; p < Ap[k + 1]; p++) {
+            int32_t i = Ai[p];
+            while (i != -1 && i < k) {
+                const int32_t next = anc[(size_t)i];
+                anc[(size_t)i] = k;
+                if (next == -1) parent[i] = k;
+                i = next;
+            }
+        }
+    }
+}
+
 // Row patterns of L below the diagonal: for row k the columns i < k with L(k,i) != 0 are
 // the nodes on the etree paths from the entries of column k of the upper pattern up to k.
 // visit(k, i) is called once per such pair, k ascending.

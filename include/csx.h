@@ -130,6 +130,9 @@ int csx_permute_vec(csx_handle_t p, csx_handle_t b, csx_handle_t x, int32_t n, i
 /* cs_schol (natural order), csparse.py:2051-2072: host C++ symbolic analysis of
  * the upper triangle of a host CSC pattern.  parent[n], cp[n+1]. */
 int csx_schol_host(int32_t n, const int32_t *Ap, const int32_t *Ai, int32_t *parent, int32_t *cp);
+/* The same for a device-resident square matrix: elimination tree on the host, column counts of L on the
+ * device (the row-subtree walks of csx_chol).  parent[n] and cp[n+1] are host arrays. */
+int csx_schol(csx_handle_t A, int32_t *parent, int32_t *cp);
 
 /* cs_chol numeric, csparse.py:561-619.  A: device CSC (upper triangle used);
  * parent/cp: host arrays from csx_schol_host; pinv: host permutation or NULL.

@@ -251,3 +251,39 @@ def test_lusol_matches_reference(cs, name, meta):
     nz = np.abs(ref) > 1e-3 * np.max(np.abs(ref))
     assert np.max(np.abs(np.asarray(b)[nz] - ref[nz]) / np.abs(ref[nz])) < 1e-9
     assert max(abs(v) for v in b) == pytest.approx(meta[name]["lusol_norm_inf"], rel=1e-9)
+
+
+@pytest.mark.parametrize("name", ["bcsstk01", "bcsstk16", "gspd", "arrow", "random"])
+def test_schol_on_device_matches_host_and_oracle(cs, name):
+    """cs_schol for a device-resident matrix (tree on the host, column counts from the device walks) gives
+    the same S.parent / S.cp as the host path and the C oracle."""
+    if name in ("bcsstk01", "bcsstk16"):
+        A = unpack(cs, golden(name), "C")
+    elif name == "gspd":
+        Ap, Ai, Ax = synth.gspd(7, 16, 3)
+        A = _host_cs(cs, 7 * 16, 7 * 16, Ap, Ai, Ax)
+    else:
+        rng = np.random.default_rng(9)
+        n = 600
+        rows, cols = [np.arange(n)], [np.arange(n)]
+        if name == "arrow":                      # dense last row/column + a band: long row subtrees
+            rows += [np.full(n - 1, n - 1), np.arange(n - 1), np.arange(1, n), np.arange(n - 1)]
+            cols += [np.arange(n - 1), np.full(n - 1, n - 1), np.arange(n - 1), np.arange(1, n)]
+        else:
+            r, c = rng.integers(0, n, 1500), rng.integers(0, n, 1500)
+            rows += [r, c]
+            cols += [c, r]
+        T = cs.cs_spalloc(n, n, 1, True, True)
+        for i, j in zip(np.concatenate(rows).tolist(), np.concatenate(cols).tolist()):
+            cs.cs_entry(T, i, j, 1.0 if i != j else 4.0 * n)
+        A = cs.cs_compress(T)
+        cs.cs_dupl(A)
+    n = A.n
+    Sh = cs.cs_schol(0, A)                       # host lists -> csx_schol_host
+    cs.cs_pin(A)
+    Sd = cs.cs_schol(0, A)                       # device-resident -> csx_schol
+    assert Sd.parent == Sh.parent and Sd.cp == Sh.cp and Sd.lnz == Sh.lnz
+    p, i = np.asarray(A.p, np.int32), np.asarray(A.i[:A.p[n]], np.int32)
+    parent, cp = CO.schol(n, p, i)
+    assert Sd.parent == parent.tolist() and Sd.cp == cp.tolist()
+    assert cs.cs_chol(A, Sd) is not None         # and the numeric phase accepts it
