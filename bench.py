@@ -95,9 +95,17 @@ def main():
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-cholsol", action="store_true")
     ap.add_argument("--skip-gspd", action="store_true")
+    ap.add_argument("--skip-sharded", action="store_true", help="skip the column-sharded single SpMV (N > 1 only)")
+    ap.add_argument("--force-sharded", action="store_true", help="run the column-sharded SpMV code path at N = 1 too")
     args = ap.parse_args()
 
     import shard
+    if args.force_sharded:
+        # torch must initialise HIP before libcsx is loaded: the process then shares torch's bundled HIP
+        # runtime.  The other order leaves two runtimes in one process and torch finds no GPU.  (At N > 1
+        # shard.Comm does this already.)
+        import torch
+        torch.cuda.init()
     comm = shard.Comm()  # RCCL ("nccl") when launched by torch.distributed.run, no-op at N=1
     rank, world, local = comm.rank, comm.world, comm.local
     import numpy as np
@@ -219,6 +227,9 @@ def main():
         _csx.free(hx)
         _csx.free(hy)
 
+    if (world > 1 or args.force_sharded) and not args.skip_sharded:
+        out["gaxpy_one_matrix_column_sharded"] = sharded_spmv_section(args, lib, cs, comm, barrier, max_over_ranks)
+
     if rank == 0 and world == 1 and not args.skip_cpu:
         py, c = cpu_baseline(args.cpu_n, per_col, args.cpu_seconds)
         out["cpu_baseline"] = py
@@ -226,6 +237,80 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     comm.close()
+
+
+def sharded_spmv_section(args, lib, cs, comm, barrier, max_over_ranks):
+    """ONE n x n G-rand matrix sharded by columns over the ranks (second bullet): rank r owns
+    columns [r n/W, (r+1) n/W) and the matching slice of x, computes a full-length partial y with the same
+    kernels, and an RCCL reduce-scatter leaves it with its n/W rows of y.  Strong scaling; reported next to
+    (never instead of) the headline.  Every stage is guarded: a failure is reported as {"error": ...}."""
+    import numpy as np
+    import _csx
+    import shard
+    C = _csx.C
+    rank, world = comm.rank, comm.world
+    n, per_col = args.n, args.per_col
+    try:
+        import torch
+        dev = torch.device("cuda", comm.local)
+        torch.cuda.set_device(dev)
+        first, count = shard.strong_block(rank, world, n)
+        hFull = _csx.new_handle()
+        _csx.check(lib.csx_gen_grand(n, per_col, 20240601 + 77, hFull), "gen_grand")     # same matrix on every rank
+        hA = _csx.new_handle()
+        _csx.check(lib.csx_csc_col_block(hFull, first, count, hA), "col_block")
+        _csx.free(hFull)
+        hxFull = _csx.new_handle()
+        _csx.check(lib.csx_gen_vec(n, 7, 0.5, 1.5, hxFull), "gen_vec")
+        ptr, ln = C.c_void_p(), C.c_int64()
+        _csx.check(lib.csx_vec_ptr(hxFull, ptr, ln), "vec_ptr")
+        hx = _csx.new_handle()
+        _csx.check(lib.csx_vec_wrap(C.c_void_p(ptr.value + 8 * first), count, hx), "vec_wrap")
+        m_pad = (n + world - 1) // world * world
+        y_full = torch.zeros(m_pad, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        hy = _csx.new_handle()
+        _csx.check(lib.csx_vec_wrap(C.c_void_p(y_full.data_ptr()), n, hy), "vec_wrap")
+        _csx.check(lib.csx_gaxpy_prepare(hA, cs.GAXPY_AUTO), "prepare")
+
+        def step():
+            _csx.check(lib.csx_vec_fill(hy, 0.0), "fill")
+            _csx.check(lib.csx_gaxpy(hA, hx, hy, cs.GAXPY_AUTO), "gaxpy")
+            _csx.sync()                                   # the library's stream -> visible to torch's
+            mine = comm.reduce_scatter_sum(y_full)
+            torch.cuda.synchronize()
+            return mine
+
+        mine = step()
+        # total mass: sum over ranks of sum(partial y) == sum over ranks of sum(their slice of y)
+        part = comm.sum(float(y_full.sum().item())) if world > 1 else float(y_full.sum().item())
+        whole = comm.sum(float(mine.sum().item())) if world > 1 else float(mine.sum().item())
+        ok = abs(part - whole) <= 1e-9 * abs(part)
+        for _ in range(max(1, args.warmup)):
+            step()
+        steps = min(args.steps, 20)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        wall = max_over_ranks(time.perf_counter() - t0) / steps
+        with _csx.Timer() as tm:                          # the kernels alone (fill + SpMV), no exchange
+            for _ in range(steps):
+                _csx.check(lib.csx_vec_fill(hy, 0.0), "fill")
+                _csx.check(lib.csx_gaxpy(hA, hx, hy, cs.GAXPY_AUTO), "gaxpy")
+        kern = max_over_ranks(tm.ms / steps)
+        by = gaxpy_bytes(n, n, n * per_col)
+        res = {"workload": "one %d x %d G-rand matrix, columns sharded over %d GPU(s), partial y summed by RCCL "
+                           "reduce-scatter (%d MB per rank in)" % (n, n, world, m_pad * 8 // 1000000),
+               "scaling": "strong", "ms_per_spmv": round(wall * 1e3, 4), "ms_kernels_only": round(kern, 4),
+               "ms_exchange_and_sync": round(wall * 1e3 - kern, 4),
+               "whole_job_algorithmic_GBps": round(by / wall / 1e9, 2), "mass_check_ok": bool(ok)}
+        for h in (hA, hx, hy, hxFull):
+            _csx.free(h)
+        return res
+    except Exception as e:                                # never take the headline down with it
+        return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
 def cholsol_section(args, lib, cs, hB, nb, bs, rank, world, barrier, max_over_ranks):

@@ -339,6 +339,34 @@ static int compress_device(int32_t m, int32_t n, int64_t nz, const int32_t *Ti, 
     return st;
 }
 
+// ---- column block (sharding a matrix by columns) ---------------------------------------------
+__global__ __launch_bounds__(256) void k_shift_ptr(int32_t count, const int32_t *__restrict__ Ap, int32_t first,
+                                                   int32_t *__restrict__ p) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j <= count) p[j] = Ap[first + j] - Ap[first];
+}
+
+static int col_block_device(const Csc *A, int32_t first, int32_t count, Csc *C) {
+    hipStream_t s = ctx().stream;
+    int32_t ends[2] = {0, 0};
+    CSX_HIP(hipMemcpyAsync(&ends[0], A->p + first, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    CSX_HIP(hipMemcpyAsync(&ends[1], A->p + first + count, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    CSX_HIP(hipStreamSynchronize(s));
+    const int32_t nnz = ends[1] - ends[0];
+    C->m = A->m;
+    C->n = count;
+    C->nnz = nnz;
+    C->owns = true;
+    CSX_TRY(dalloc(&C->p, (size_t)count + 1));
+    CSX_TRY(dalloc(&C->i, (size_t)nnz));
+    if (A->x) CSX_TRY(dalloc(&C->x, (size_t)nnz));
+    hipLaunchKernelGGL(k_shift_ptr, dim3(blocks_for((int64_t)count + 1)), dim3(256), 0, s, count, A->p, first, C->p);
+    if (nnz) CSX_HIP(hipMemcpyAsync(C->i, A->i + ends[0], (size_t)nnz * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    if (nnz && A->x) CSX_HIP(hipMemcpyAsync(C->x, A->x + ends[0], (size_t)nnz * sizeof(double), hipMemcpyDeviceToDevice, s));
+    CSX_HIP(hipStreamSynchronize(s));
+    return CSX_OK;
+}
+
 template <class F>
 static int make_csc(csx_handle_t *out, F &&build) {
     Csc *C = new Csc();
@@ -404,4 +432,11 @@ extern "C" int csx_symperm(csx_handle_t hA, const int32_t *pinv, int values, csx
     if (!A || !out || A->m != A->n) return CSX_EINVAL;
     if (pinv && !is_permutation(pinv, A->n)) return CSX_EINVAL;
     return make_csc(out, [&](Csc *C) { return symperm_device(A, pinv, values != 0, C); });
+}
+
+extern "C" int csx_csc_col_block(csx_handle_t hA, int32_t first, int32_t count, csx_handle_t *out) {
+    CSX_TRY(require_ready());
+    Csc *A = csc(hA);
+    if (!A || !out || first < 0 || count < 0 || (int64_t)first + count > A->n) return CSX_EINVAL;
+    return make_csc(out, [&](Csc *C) { return col_block_device(A, first, count, C); });
 }

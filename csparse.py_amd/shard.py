@@ -1,8 +1,10 @@
 """One-process-per-GPU sharding of the hot path.
 
 The path shards as independent units -- right-hand-side blocks of a batched
-solve, or whole independent matrices -- so there is NO collective on the data
-path.  What ranks exchange is control only: a barrier around timed regions, the
+solve, or whole independent matrices -- so there is NO collective on that data
+path.  The one case with a real exchange step is a single SpMV sharded by
+columns: every rank produces a full-length partial y and a reduce-scatter sums
+them (reduce_scatter_sum).  What ranks exchange is control only: a barrier around timed regions, the
 max of a timing over ranks, a small object broadcast (e.g. the kernel choice made
 by rank 0), and optionally a gather of per-block results to rank 0.  On the GPU
 node that traffic goes over RCCL (torch.distributed backend "nccl"); the same
@@ -96,6 +98,25 @@ class Comm(object):
         if self.rank != dst:
             return None
         return self.torch.cat(out, dim=1)
+
+    def reduce_scatter_sum(self, full):
+        """Sum the ranks' full-length 1-D float64 tensors and leave rank r with rows
+        [r*len/world, (r+1)*len/world) -- the exchange step of a column-sharded SpMV.
+        len(full) must be a multiple of world.  RCCL reduce-scatter on the GPU node; gloo (the CPU tests)
+        has no reduce-scatter, so there it is an all-reduce followed by a slice.  world == 1: the input."""
+        if self.dist is None:
+            return full
+        n = full.numel()
+        if n % self.world:
+            raise ValueError("reduce_scatter_sum: length %d is not a multiple of world %d" % (n, self.world))
+        chunk = n // self.world
+        if self.dist.get_backend() == "nccl":
+            out = self.torch.empty(chunk, dtype=full.dtype, device=full.device)
+            self.dist.reduce_scatter_tensor(out, full, op=self.dist.ReduceOp.SUM)
+            return out
+        tmp = full.clone()
+        self.dist.all_reduce(tmp, op=self.dist.ReduceOp.SUM)
+        return tmp[self.rank * chunk:(self.rank + 1) * chunk].clone()
 
     def close(self):
         if self.dist is not None:

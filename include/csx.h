@@ -67,7 +67,7 @@ int csx_device_info(char *name, int name_cap, int *compute_units, int64_t *hbm_b
  * driver; cap = 1/4 of the device, CSX_POOL_LIMIT_MB / CSX_NO_POOL=1 override).  csx_mem_trim returns
  * every idle block to the driver; csx_mem_info reports idle bytes, bytes in use, and hipMemGetInfo's free.
  * Reuse is ordered on the context's stream: a block whose pointer was exported (csx_vec_ptr, csx_csc_ptrs)
- * must not be freed while work on another stream still uses it (csx_free does not synchronise). */
+ * must not be freed while work on another stream still uses it (csx_free waits for the context's stream only). */
 int csx_mem_trim(void);
 int csx_mem_info(int64_t *cached_bytes, int64_t *live_bytes, int64_t *device_free_bytes);
 int csx_timer_start(void);                /* hipEvent on the context's stream */
@@ -166,6 +166,8 @@ int csx_dupl(csx_handle_t A, csx_handle_t *out);
 int csx_drop(csx_handle_t A, int mode, double tol, csx_handle_t *out);
 int csx_permute(csx_handle_t A, const int32_t *pinv, const int32_t *q, int values, csx_handle_t *out);
 int csx_symperm(csx_handle_t A, const int32_t *pinv, int values, csx_handle_t *out);
+/* Columns [first, first + count) of A as a new m x count matrix: the unit of a column-sharded SpMV. */
+int csx_csc_col_block(csx_handle_t A, int32_t first, int32_t count, csx_handle_t *out);
 
 /* cs_lu, csparse.py:1370-1451 (+ cs_spsolve :2078-2113), natural column order: host C++
  * left-looking LU with threshold partial pivoting.  It produces the L (unit diagonal first)

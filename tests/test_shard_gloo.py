@@ -33,7 +33,11 @@ WORKER = textwrap.dedent("""
     total = comm.sum(k)
     choice = comm.broadcast_object("tiled" if comm.rank == 0 else "wave")
     full = comm.gather_blocks(X)
-    out = dict(rank=comm.rank, tmax=t, total=total, choice=choice, col0=col0,
+    # the exchange step of a column-sharded SpMV: partial y's summed, each rank keeps its rows
+    import torch
+    part = torch.arange(8, dtype=torch.float64) * (comm.rank + 1)     # rank 0: 0..7, rank 1: 0,2,..14
+    mine = comm.reduce_scatter_sum(part)
+    out = dict(rank=comm.rank, tmax=t, total=total, choice=choice, col0=col0, rs=mine.tolist(),
                strong=[shard.strong_block(r, 3, 10) for r in range(3)])
     if comm.rank == 0:
         out["full"] = np.asarray(full).tolist()
@@ -65,6 +69,7 @@ def test_two_rank_sharded_cholsol(tmp_path):
     assert res[0]["choice"] == res[1]["choice"] == "tiled"
     assert (res[0]["col0"], res[1]["col0"]) == (0, 3)
     assert res[0]["strong"] == [[0, 4], [4, 3], [7, 3]]
+    assert res[0]["rs"] == [0.0, 3.0, 6.0, 9.0] and res[1]["rs"] == [12.0, 15.0, 18.0, 21.0]
     # the gathered block equals the serial solve of all six right-hand sides
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import c_oracle as CO
