@@ -100,10 +100,9 @@ def main():
     args = ap.parse_args()
 
     import shard
-    if args.force_sharded:
+    if args.force_sharded or shard.env_rank()[1] > 1:
         # torch must initialise HIP before libcsx is loaded: the process then shares torch's bundled HIP
-        # runtime.  The other order leaves two runtimes in one process and torch finds no GPU.  (At N > 1
-        # shard.Comm does this already.)
+        # runtime.  The other order leaves two runtimes in one process and torch finds no GPU.
         import torch
         torch.cuda.init()
     comm = shard.Comm()  # RCCL ("nccl") when launched by torch.distributed.run, no-op at N=1

@@ -231,8 +231,8 @@ __global__ __launch_bounds__(256) void k_row_span(int32_t rows, int32_t stride, 
 static int wants_tiled(const Csc *A, bool *yes) {
     *yes = false;
     const Gather *g = A->rows;
-    // small problems: x and y live in L2 whatever the structure
-    if ((int64_t)A->n * 8 < (32ll << 20) || A->nnz < (1 << 24) || !g) return CSX_OK;
+    // small problems: x fits one XCD's L2 (every XCD gathers from all of x), or too few entries to matter
+    if ((int64_t)A->n * 8 <= (4ll << 20) || A->nnz < (1 << 24) || !g) return CSX_OK;
     hipStream_t s = ctx().stream;
     unsigned long long *d = nullptr;
     CSX_TRY(dalloc(&d, 2));

@@ -39,13 +39,15 @@ class Comm(object):
 
     def __init__(self, backend=None, device=None):
         self.rank, self.world, self.local = env_rank()
+        if os.environ.get("CSX_SINGLE_DEVICE"):   # rehearsal of the N > 1 control flow on a one-GPU box
+            self.local = 0
         self.dist = None
         self.device = device
         if self.world > 1:
             import torch
             import torch.distributed as dist
             if backend is None:
-                backend = "nccl" if torch.cuda.is_available() else "gloo"
+                backend = os.environ.get("CSX_COMM_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
             if backend == "nccl":
                 torch.cuda.set_device(self.local)
                 self.device = torch.device("cuda", self.local)
@@ -114,9 +116,9 @@ class Comm(object):
             out = self.torch.empty(chunk, dtype=full.dtype, device=full.device)
             self.dist.reduce_scatter_tensor(out, full, op=self.dist.ReduceOp.SUM)
             return out
-        tmp = full.clone()
+        tmp = full.detach().to("cpu", copy=True)       # gloo: staged through the host
         self.dist.all_reduce(tmp, op=self.dist.ReduceOp.SUM)
-        return tmp[self.rank * chunk:(self.rank + 1) * chunk].clone()
+        return tmp[self.rank * chunk:(self.rank + 1) * chunk].to(full.device, copy=True)
 
     def close(self):
         if self.dist is not None:
