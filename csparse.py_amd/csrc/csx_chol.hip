@@ -163,21 +163,118 @@ __global__ __launch_bounds__(64 * CH_WAVES) void k_chol_level(const int32_t *__r
     chol_column(cols[c], Lp, Li, Lx, row_ptr, row_col, row_pos, s_acc_v[w], s_acc_r[w], lane, notspd);
 }
 
-// one workgroup walks levels [l0, l1), a barrier after each
-__global__ __launch_bounds__(64 * CH_WAVES) void k_chol_levels_one_wg(const int32_t *__restrict__ cols,
-                                                                     const int32_t *__restrict__ level_ptr, int32_t l0,
-                                                                     int32_t l1, const int32_t *__restrict__ Lp,
-                                                                     const int32_t *__restrict__ Li, double *Lx,
-                                                                     const int32_t *__restrict__ row_ptr,
-                                                                     const int32_t *__restrict__ row_col,
-                                                                     const int32_t *__restrict__ row_pos, int *notspd) {
-    CH_SHARED
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+// One workgroup walks the narrow levels [l0, l1) of a big tree, ALL of its 16 waves working on one
+// column at a time.  A chain-like elimination tree (bcsstk16 in natural order: 4810 levels for 4884
+// columns) leaves no parallelism between columns, and one wave per column spends its time in dependent
+// round trips: row view -> L(j,k) -> column k, ~1.2 us per update, 125 updates per column.  Here the
+// updates of a column are dealt to W waves (wave w takes updates w, w+W, ... in order), each wave fetches
+// the descriptors of up to CC_Q updates in one round trip and the heads of their columns in another, and
+// sums its updates into its OWN partial column in LDS (no atomics: the lanes of one update hit distinct
+// rows); the partials are then subtracted from the column in wave order.  So the result is deterministic
+// (same bits every run) and agrees with the reference to rounding.  A row -> position map in LDS
+// (n <= CC_MAP) replaces the binary search.  W = min(16, CC_ACC / column length); columns longer than
+// CC_ACC are updated in place by one wave.
+constexpr int CC_WAVES = 16, CC_ACC = 8192, CC_MAP = 12288, CC_Q = 8;
+
+__device__ __forceinline__ int32_t cc_lookup(bool use_map, const int32_t *map, const int32_t *rows, int32_t len, int32_t r) {
+    return use_map ? map[r] : find_row(rows, len, r);
+}
+
+__global__ __launch_bounds__(64 * CC_WAVES) void k_chol_coop(const int32_t *__restrict__ cols,
+                                                            const int32_t *__restrict__ level_ptr, int32_t l0, int32_t l1,
+                                                            const int32_t *__restrict__ Lp, const int32_t *__restrict__ Li,
+                                                            double *Lx, const int32_t *__restrict__ row_ptr,
+                                                            const int32_t *__restrict__ row_col,
+                                                            const int32_t *__restrict__ row_pos, int32_t n, int *notspd) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char cc_smem[];
+    double *part = reinterpret_cast<double *>(cc_smem);             // W partial columns of `len` doubles
+    int32_t *acc_r = reinterpret_cast<int32_t *>(part + CC_ACC);    // the column's row indices (<= CC_ACC kept)
+    int32_t *map = acc_r + CC_ACC;
+    const bool use_map = n <= CC_MAP;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     for (int32_t l = l0; l < l1; l++) {
-        const int32_t first = level_ptr[l], count = level_ptr[l + 1] - first;
-        for (int32_t c = w; c < count; c += CH_WAVES)
-            chol_column(cols[first + c], Lp, Li, Lx, row_ptr, row_col, row_pos, s_acc_v[w], s_acc_r[w], lane, notspd);
-        __syncthreads();
+        const int32_t lfirst = level_ptr[l], lcount = level_ptr[l + 1] - lfirst;
+        for (int32_t c = 0; c < lcount; c++) {
+            const int32_t j = cols[lfirst + c];
+            const int32_t base = Lp[j], len = Lp[j + 1] - base;
+            const int W = len <= CC_ACC ? min(CC_WAVES, CC_ACC / max(len, 1)) : 0;   // 0: in place, wave 0 alone
+            for (int32_t t = tid; t < len; t += 64 * CC_WAVES) {
+                const int32_t r = Li[base + t];
+                if (W) acc_r[t] = r;
+                if (use_map) map[r] = t;
+            }
+            for (int32_t t = tid; t < W * len; t += 64 * CC_WAVES) part[t] = 0.0;
+            __syncthreads();
+            const int32_t *rows = W ? acc_r : Li + base;
+            const int32_t qb = row_ptr[j], qe = row_ptr[j + 1] - 1;   // the row view ends with the diagonal
+            const int Wq = W ? W : 1;
+            if (w < Wq) {
+                double *mine = part + (size_t)w * len;
+                for (int32_t q0 = qb + w; q0 < qe; q0 += Wq * CC_Q) {
+                    // lane u < CC_Q fetches the descriptor of this wave's u-th update: position of L(j,k), end of column k
+                    int32_t posq = 0, kendq = 0;
+                    double ljkq = 0.0;
+                    {
+                        const int32_t qu = q0 + Wq * lane;
+                        if (lane < CC_Q && qu < qe) {
+                            const int32_t kq = row_col[qu];
+                            posq = row_pos[qu];
+                            kendq = Lp[kq + 1];
+                            ljkq = Lx[posq];
+                        }
+                    }
+                    int32_t pos_[CC_Q], kend_[CC_Q], r_[CC_Q];
+                    double ljk_[CC_Q], v_[CC_Q];
+#pragma unroll
+                    for (int u = 0; u < CC_Q; u++) {
+                        pos_[u] = __builtin_amdgcn_readlane(posq, u);
+                        kend_[u] = __builtin_amdgcn_readlane(kendq, u);    // 0 for an absent update: nothing below
+                        ljk_[u] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ljkq), u),
+                                                   __builtin_amdgcn_readlane(__double2loint(ljkq), u));
+                    }
+#pragma unroll
+                    for (int u = 0; u < CC_Q; u++) {
+                        const int32_t p = pos_[u] + lane;
+                        const int32_t pp = p < kend_[u] ? p : pos_[u];      // a valid address either way
+                        r_[u] = Li[pp];
+                        v_[u] = Lx[pp];
+                    }
+#pragma unroll
+                    for (int u = 0; u < CC_Q; u++) {
+                        if (pos_[u] + lane < kend_[u]) {
+                            const int32_t t = cc_lookup(use_map, map, rows, len, r_[u]);
+                            const double dv = v_[u] * ljk_[u];
+                            if (W) mine[t] += dv;
+                            else Lx[base + t] -= dv;
+                        }
+                        for (int32_t p = pos_[u] + 64 + lane; p < kend_[u]; p += 64) {   // columns longer than one wave
+                            const int32_t t = cc_lookup(use_map, map, rows, len, Li[p]);
+                            const double dv = Lx[p] * ljk_[u];
+                            if (W) mine[t] += dv;
+                            else Lx[base + t] -= dv;
+                        }
+                        __builtin_amdgcn_wave_barrier();   // updates of one wave are applied one after another
+                    }
+                }
+            }
+            __syncthreads();
+            // column = initial values - partials, in wave order; then the pivot and the scaling
+            for (int32_t t = tid; t < len; t += 64 * CC_WAVES) {
+                double v = Lx[base + t];
+                for (int ww = 0; ww < W; ww++) v -= part[(size_t)ww * len + t];
+                if (W) part[t] = v;                       // partial 0 is dead: reuse it for the finished sums
+                else if (t == 0) part[0] = v;
+            }
+            __syncthreads();
+            const double d = part[0];
+            if (d <= 0.0 && tid == 0) atomicMin(notspd, j);  // csparse.py:612: not positive definite
+            const double ljj = sqrt(d);
+            for (int32_t t = tid; t < len; t += 64 * CC_WAVES) {
+                const double v = W ? part[t] : Lx[base + t];
+                Lx[base + t] = t == 0 ? ljj : v / ljj;
+            }
+            __syncthreads();   // the next column reads these values and reuses the LDS arrays
+        }
     }
 }
 
@@ -396,8 +493,11 @@ static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, c
             }
             int32_t e = l + 1;
             while (e < nlev && F.level_ptr[(size_t)e + 1] - F.level_ptr[(size_t)e] <= CH_NARROW) e++;
-            hipLaunchKernelGGL(k_chol_levels_one_wg, dim3(1), dim3(64 * CH_WAVES), 0, s, d_level_cols, d_level_ptr, l, e,
-                               L->p, L->i, L->x, d_rp, d_rc, d_rpos, d_flags + 1);
+            const size_t cc_lds = (size_t)CC_ACC * 12 + (n <= CC_MAP ? (size_t)n * 4 : 0) + 64;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chol_coop), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      160 * 1024 - 256);
+            hipLaunchKernelGGL(k_chol_coop, dim3(1), dim3(64 * CC_WAVES), cc_lds, s, d_level_cols, d_level_ptr, l, e, L->p,
+                               L->i, L->x, d_rp, d_rc, d_rpos, n, d_flags + 1);
             l = e;
         }
         if (hipGetLastError() != hipSuccess ||
