@@ -21,7 +21,10 @@
 // from a hipGraph changed nothing, so the cost is device-side dependency between dispatches, not host
 // launch calls; and one cooperative launch with a grid barrier per level was SLOWER, 0.79 ms at 10
 // workgroups and 5.4 ms at 512: an agent-scope release/acquire across the 8 XCD L2s costs more than a
-// dispatch); runs of narrow levels are executed by ONE
+// dispatch; and for pure chains -- bcsstk16's factor, 4810 one-row levels, 7.3 us per level here -- a
+// workgroup whose waves take the levels in rotation and prefetch their rows' terms into registers,
+// broadcasting them with v_readlane, was slower too: 10.8 us per level, the per-term scalar overhead
+// outweighs the saved round trip); runs of narrow levels are executed by ONE
 // workgroup that walks them with a workgroup barrier in between, so a chain
 // (thousands of one-row levels) costs one launch, not thousands.
 //
