@@ -369,3 +369,21 @@ extern "C" int csx_gaxpy(csx_handle_t hA, csx_handle_t hx, csx_handle_t hy, int 
         default: return CSX_EINVAL;
     }
 }
+
+// One-shot form for host arrays (the list-based reference signature, csparse.py:1199): y[0..m) += A x.
+// Uploads, runs the reference-order kernel (bit-identical y), downloads; nothing stays on the device.
+extern "C" int csx_gaxpy_host(int32_t m, int32_t n, const int32_t *p, const int32_t *i, const double *x, const double *xv,
+                              double *yv) {
+    CSX_TRY(require_ready());
+    if (!xv || !yv) return CSX_EINVAL;
+    csx_handle_t hA = 0, hx = 0, hy = 0;
+    int st = csx_csc_upload(m, n, p, i, x, &hA);
+    if (st == CSX_OK) st = csx_vec_upload(xv, n, &hx);
+    if (st == CSX_OK) st = csx_vec_upload(yv, m, &hy);
+    if (st == CSX_OK) st = csx_gaxpy(hA, hx, hy, CSX_GAXPY_EXACT);
+    if (st == CSX_OK) st = csx_vec_download(hy, yv, m);
+    if (hA) (void)csx_free(hA);
+    if (hx) (void)csx_free(hx);
+    if (hy) (void)csx_free(hy);
+    return st;
+}

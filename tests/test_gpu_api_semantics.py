@@ -119,3 +119,15 @@ def test_dvec_block_roundtrip_and_shapes(cs):
     assert z.tolist() == [0.0] * 5 and isinstance(z.device_ptr(), int)
     with pytest.raises(IndexError):
         cs.cs_lsolve(cs.cs_pin(unpack(cs, golden("t1"), "A")), cs.dvec(3))   # x shorter than n
+
+
+def test_one_shot_host_gaxpy_through_the_c_abi(cs):
+    import _csx
+    g = golden("bcsstk16")
+    A = unpack(cs, g, "A")
+    nnz = A.p[A.n]
+    p, i, x = _csx.i32(A.p), _csx.i32(A.i[:nnz]), _csx.f64(A.x[:nnz])
+    xv, yv = _csx.f64(g["gaxpy_x"]), _csx.f64(g["gaxpy_y0"]).copy()
+    _csx.check(_csx.lib().csx_gaxpy_host(A.m, A.n, _csx.pi(p), _csx.pi(i), _csx.pd(x), _csx.pd(xv), _csx.pd(yv)))
+    assert yv.tobytes() == g["gaxpy_y"].tobytes()          # the unmodified reference's y, bit for bit
+    assert _csx.lib().csx_gaxpy_host(A.m, A.n, _csx.pi(p), _csx.pi(i), _csx.pd(x), None, _csx.pd(yv)) == _csx.EINVAL
