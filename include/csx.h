@@ -101,11 +101,11 @@ int csx_ivec_download(csx_handle_t v, int32_t *dst, int64_t len);
 /* cs_gaxpy, csparse.py:1199-1213: y += A x.  x has >= n, y >= m entries. */
 int csx_gaxpy(csx_handle_t A, csx_handle_t x, csx_handle_t y, int mode);
 /* Build (and cache on A) the plan `mode` needs, outside any timed region. */
+int csx_gaxpy_prepare(csx_handle_t A, int mode);
 /* One-shot form for host arrays (the reference's list signature): y[0..m) += A x in the reference's
  * summation order (bit-identical), nothing left on the device.  x (values) must be present. */
 int csx_gaxpy_host(int32_t m, int32_t n, const int32_t *p, const int32_t *i, const double *x, const double *xv,
                    double *yv);
-int csx_gaxpy_prepare(csx_handle_t A, int mode);
 
 /* cs_transpose, csparse.py:2292-2315: stable counting sort by row. */
 int csx_transpose(csx_handle_t A, int values, csx_handle_t *out);
