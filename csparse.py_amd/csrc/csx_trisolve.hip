@@ -32,6 +32,7 @@
 // ...) are run by a literal one-lane-per-right-hand-side transcription of the
 // reference loop, so the answer matches even then.
 #include <algorithm>
+#include <cstdlib>
 
 #include "csx_internal.h"
 
@@ -54,6 +55,11 @@ struct TriPlan {
     double *val = nullptr;
     double *diag = nullptr;
     int32_t *order = nullptr, *level_ptr = nullptr;  // device
+    // blocked chain walker (k_tri_chain): per position in `order` the number of leading terms that come from
+    // before the row's 16-row block, and per term the block slot of its source (-1: outside the block)
+    int32_t *npre = nullptr;
+    int8_t *tslot = nullptr;
+    bool chain_ok = false;
     std::vector<int32_t> level_ptr_h;
     std::vector<Segment> segs;
     const int32_t *Tp = nullptr, *Ti = nullptr;  // the analysed matrix (not owned)
@@ -70,6 +76,8 @@ void free_triplan(TriPlan *t) {
     dfree(t->diag);
     dfree(t->order);
     dfree(t->level_ptr);
+    dfree(t->npre);
+    dfree(t->tslot);
     delete t;
 }
 
@@ -200,6 +208,115 @@ __global__ __launch_bounds__(1024) void k_tri_levels_one_wg(const int32_t *__res
         for (int32_t t = threadIdx.x; t < count * nrhs; t += 1024)
             solve_one(order[first + t / nrhs], t % nrhs, nrhs, ptr, idx, val, diag, skip_first, skip_last, X);
         __syncthreads();  // workgroup-scope release/acquire: the next level reads these x
+    }
+}
+
+// ---- narrow levels, sixteen rows at a time --------------------------------------------------------------
+// A run of narrow levels is a dependency chain; walking it one level per workgroup barrier costs a full
+// round trip (or several: a row of 125 terms is 16 batches) per level.  But most of a row's terms do not
+// depend on its immediate predecessors.  Rows are taken in blocks of 16 consecutive positions of the
+// level order (a topological order): a term whose source lies BEFORE the block is final when the block
+// starts, so the leading such terms of all 16 rows -- for a banded factor all but the last few -- are
+// subtracted by 16 x 64 threads at once (phase A, one thread per (row, right-hand side), batched loads).
+// What remains of a row, from its first in-block source on, waits for the rows above it: phase B runs
+// the rows that have such a remainder one after another, their sources read from an LDS copy of the
+// block's x, one workgroup barrier each.  Every (row, right-hand side) still subtracts its terms strictly
+// in the reference's order -- prefix first, remainder after -- so x stays bit-identical.
+constexpr int CHB = 16, CH_SUF = 32;   // rows per block; remainder terms staged in LDS per row
+
+__global__ __launch_bounds__(64 * CHB) void k_tri_chain(const int32_t *__restrict__ order, int32_t p0, int32_t p1,
+                                                        const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx,
+                                                        const double *__restrict__ val, const double *__restrict__ diag,
+                                                        int skip_first, int skip_last, const int32_t *__restrict__ npre,
+                                                        const int8_t *__restrict__ tslot, double *X, int nrhs) {
+    __shared__ double xblk[CHB][64];
+    __shared__ double sval[CHB][CH_SUF];
+    __shared__ int32_t sidx[CHB][CH_SUF];
+    __shared__ int8_t sslot[CHB][CH_SUF];
+    __shared__ int32_t nsuf[CHB];
+    const int lane = threadIdx.x & 63, slot = threadIdx.x >> 6;
+    for (int32_t blk = p0 & ~(CHB - 1); blk < p1; blk += CHB) {
+        const int32_t pos = blk + slot;
+        const bool active = pos >= p0 && pos < p1;
+        const int32_t row = pos < p1 ? order[pos] : 0;       // positions before p0 are solved rows of this block
+        int32_t b = 0, e = 0, pre = 0;
+        double dg = 1.0;
+        if (active) {
+            b = ptr[row] + skip_first;
+            e = ptr[row + 1] - skip_last;
+            pre = npre[pos];
+            dg = diag[row];
+        }
+        const int32_t ns = e - b - pre;                       // remainder: from the first in-block source on
+        for (int c0 = 0; c0 < nrhs; c0 += 64) {
+            const int rhs = c0 + lane;
+            const bool live = rhs < nrhs;
+            const int rl = live ? rhs : nrhs - 1;
+            double acc = 0.0;
+            // ---- phase A ----
+            if (active) {
+                if (lane < CH_SUF && lane < ns) {             // the row's remainder: value, source, source's slot
+                    sval[slot][lane] = val[b + pre + lane];
+                    sidx[slot][lane] = idx[b + pre + lane];
+                    sslot[slot][lane] = tslot[b + pre + lane];
+                }
+                if (lane == 0) nsuf[slot] = ns;
+                acc = X[(int64_t)row * nrhs + rl];
+                constexpr int TB = 8;
+                for (int32_t q0 = b; q0 < b + pre; q0 += TB) {
+                    int32_t c[TB];
+                    double v[TB], xv[TB];
+#pragma unroll
+                    for (int u = 0; u < TB; u++) {
+                        const int32_t q = q0 + u < b + pre ? q0 + u : b + pre - 1;
+                        c[u] = idx[q];
+                        v[u] = val[q];
+                    }
+#pragma unroll
+                    for (int u = 0; u < TB; u++) xv[u] = X[(int64_t)c[u] * nrhs + rl];
+#pragma unroll
+                    for (int u = 0; u < TB; u++) {
+                        const double t = v[u] * xv[u];
+                        acc = q0 + u < b + pre ? acc - t : acc;
+                    }
+                }
+                if (ns == 0) {                                // nothing in-block: this row is done
+                    const double xr = acc / dg;
+                    xblk[slot][lane] = xr;
+                    if (live) X[(int64_t)row * nrhs + rhs] = xr;
+                }
+            } else {
+                if (lane == 0) nsuf[slot] = 0;
+                if (pos < p0) xblk[slot][lane] = X[(int64_t)row * nrhs + rl];   // solved by an earlier segment
+            }
+            __syncthreads();
+            // ---- phase B: rows with a remainder, in order ----
+            for (int s2 = 0; s2 < CHB; s2++) {
+                if (nsuf[s2] == 0) continue;                  // uniform
+                if (slot == s2) {
+                    for (int32_t t = 0; t < ns; t++) {
+                        double v, xv;
+                        if (t < CH_SUF) {
+                            v = sval[slot][t];
+                            const int sl = sslot[slot][t];
+                            xv = sl >= 0 ? xblk[sl][lane] : X[(int64_t)sidx[slot][t] * nrhs + rl];
+                        } else {                              // very long remainder: straight from memory
+                            const int32_t q = b + pre + t;
+                            v = val[q];
+                            const int sl = tslot[q];
+                            xv = sl >= 0 ? xblk[sl][lane] : X[(int64_t)idx[q] * nrhs + rl];
+                        }
+                        const double tt = v * xv;
+                        acc = acc - tt;
+                    }
+                    const double xr = acc / dg;
+                    xblk[slot][lane] = xr;
+                    if (live) X[(int64_t)row * nrhs + rhs] = xr;
+                }
+                __syncthreads();
+            }
+            __syncthreads();   // the LDS arrays are reused by the next chunk of right-hand sides / next block
+        }
     }
 }
 
@@ -394,6 +511,35 @@ static int ensure_schedule(TriPlan *P) {
     CSX_HIP(hipMemcpyAsync(P->order, order.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, s));
     CSX_HIP(hipMemcpyAsync(P->level_ptr, P->level_ptr_h.data(), ((size_t)P->nlevels + 1) * sizeof(int32_t),
                            hipMemcpyHostToDevice, s));
+    // blocked chain walker: blocks of CHB consecutive positions of `order`
+    std::vector<int32_t> pos_of((size_t)n), hnpre((size_t)n, 0);
+    int64_t suffix_terms = 0, all_terms = 0;
+    std::vector<int8_t> hslot((size_t)P->gnnz + 1, (int8_t)-1);
+    for (int32_t q = 0; q < n; q++) pos_of[(size_t)order[(size_t)q]] = q;
+    for (int32_t q = 0; q < n; q++) {
+        const int32_t r = order[(size_t)q], blk = q & ~(CHB - 1);
+        const int32_t b = hptr[(size_t)r] + P->skip_first, e = hptr[(size_t)r + 1] - P->skip_last;
+        int32_t pre = 0;
+        bool in_prefix = true;
+        for (int32_t t = b; t < e; t++) {
+            const int32_t sp = pos_of[(size_t)hidx[(size_t)t]];
+            const bool inside = sp >= blk;              // sp < q always: sources have a lower level
+            hslot[(size_t)t] = inside ? (int8_t)(sp - blk) : (int8_t)-1;
+            if (inside) in_prefix = false;
+            if (in_prefix) pre++;
+        }
+        hnpre[(size_t)q] = pre;
+        suffix_terms += (e - b) - pre;
+        all_terms += e - b;
+    }
+    // the chain walker pays off when most of a row can be done ahead of its in-block sources (forward
+    // solves: the in-block sources are a row's LAST terms); when they come first (L' x = b in the
+    // reference's order) nearly every term would wait in phase B and the level walker is the better one
+    P->chain_ok = all_terms > 0 && suffix_terms * 4 <= all_terms;
+    CSX_TRY(dalloc(&P->npre, (size_t)n));
+    CSX_TRY(dalloc(&P->tslot, (size_t)P->gnnz + 1));
+    CSX_HIP(hipMemcpyAsync(P->npre, hnpre.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    CSX_HIP(hipMemcpyAsync(P->tslot, hslot.data(), (size_t)P->gnnz + 1, hipMemcpyHostToDevice, s));
     CSX_HIP(hipStreamSynchronize(s));
     return CSX_OK;
 }
@@ -427,8 +573,13 @@ int tri_solve_raw(TriPlan *P, double *X, int32_t nrhs) {
         return CSX_OK;
     }
     make_segments(P, nrhs);
+    static const bool no_chain = std::getenv("CSX_TRI_NO_CHAIN") != nullptr;
     for (const Segment &g : P->segs) {
-        if (g.one_wg) {
+        if (g.one_wg && !no_chain && P->chain_ok) {
+            hipLaunchKernelGGL(k_tri_chain, dim3(1), dim3(64 * CHB), 0, s, P->order, P->level_ptr_h[(size_t)g.l0],
+                               P->level_ptr_h[(size_t)g.l1], P->ptr, P->idx, P->val, P->diag, P->skip_first, P->skip_last,
+                               P->npre, P->tslot, X, nrhs);
+        } else if (g.one_wg) {
             hipLaunchKernelGGL(k_tri_levels_one_wg, dim3(1), dim3(1024), 0, s, P->order, P->level_ptr, g.l0, g.l1, P->ptr,
                                P->idx, P->val, P->diag, P->skip_first, P->skip_last, X, nrhs);
         } else {
