@@ -167,21 +167,36 @@ __device__ __forceinline__ void solve_one(int32_t row, int r, int nrhs, const in
     // instead of two dependent round trips per term.  Slots past the row end re-read its last term
     // (a valid address) and are skipped in the arithmetic.
     constexpr int TB = 8;
-    for (int32_t q0 = b; q0 < e; q0 += TB) {
-        int32_t c[TB];
-        double v[TB], xv[TB];
+    int32_t c[TB];
+    double v[TB];
 #pragma unroll
-        for (int u = 0; u < TB; u++) {
-            const int32_t q = q0 + u < e ? q0 + u : e - 1;
-            c[u] = idx[q];
-            v[u] = val[q];
-        }
+    for (int u = 0; u < TB; u++) {
+        const int32_t q = b + u < e ? b + u : (e > b ? e - 1 : 0);
+        c[u] = e > b ? idx[q] : 0;
+        v[u] = e > b ? val[q] : 0.0;
+    }
+    for (int32_t q0 = b; q0 < e; q0 += TB) {
+        double xv[TB];
 #pragma unroll
         for (int u = 0; u < TB; u++) xv[u] = X[(int64_t)c[u] * nrhs + r];
+        // the next batch's (index, value) pairs are requested behind the gathers and arrive while those are awaited
+        int32_t cn[TB];
+        double vn[TB];
+#pragma unroll
+        for (int u = 0; u < TB; u++) {
+            const int32_t q = q0 + TB + u < e ? q0 + TB + u : e - 1;
+            cn[u] = idx[q];
+            vn[u] = val[q];
+        }
 #pragma unroll
         for (int u = 0; u < TB; u++) {
             const double t = v[u] * xv[u];
             acc = q0 + u < e ? acc - t : acc;
+        }
+#pragma unroll
+        for (int u = 0; u < TB; u++) {
+            c[u] = cn[u];
+            v[u] = vn[u];
         }
     }
     X[(int64_t)row * nrhs + r] = acc / diag[row];
@@ -263,21 +278,36 @@ __global__ __launch_bounds__(64 * CHB) void k_tri_chain(const int32_t *__restric
                 if (lane == 0) nsuf[slot] = ns;
                 acc = X[(int64_t)row * nrhs + rl];
                 constexpr int TB = 8;
-                for (int32_t q0 = b; q0 < b + pre; q0 += TB) {
-                    int32_t c[TB];
-                    double v[TB], xv[TB];
+                const int32_t pe = b + pre;
+                int32_t c[TB];
+                double v[TB];
 #pragma unroll
-                    for (int u = 0; u < TB; u++) {
-                        const int32_t q = q0 + u < b + pre ? q0 + u : b + pre - 1;
-                        c[u] = idx[q];
-                        v[u] = val[q];
-                    }
+                for (int u = 0; u < TB; u++) {
+                    const int32_t q = b + u < pe ? b + u : (pe > b ? pe - 1 : 0);
+                    c[u] = pe > b ? idx[q] : 0;
+                    v[u] = pe > b ? val[q] : 0.0;
+                }
+                for (int32_t q0 = b; q0 < pe; q0 += TB) {
+                    double xv[TB];
 #pragma unroll
                     for (int u = 0; u < TB; u++) xv[u] = X[(int64_t)c[u] * nrhs + rl];
+                    int32_t cn[TB];
+                    double vn[TB];
+#pragma unroll
+                    for (int u = 0; u < TB; u++) {
+                        const int32_t q = q0 + TB + u < pe ? q0 + TB + u : pe - 1;
+                        cn[u] = idx[q];
+                        vn[u] = val[q];
+                    }
 #pragma unroll
                     for (int u = 0; u < TB; u++) {
                         const double t = v[u] * xv[u];
-                        acc = q0 + u < b + pre ? acc - t : acc;
+                        acc = q0 + u < pe ? acc - t : acc;
+                    }
+#pragma unroll
+                    for (int u = 0; u < TB; u++) {
+                        c[u] = cn[u];
+                        v[u] = vn[u];
                     }
                 }
                 if (ns == 0) {                                // nothing in-block: this row is done
