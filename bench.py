@@ -178,10 +178,10 @@ def main():
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
                      # Bytes per launch crossing the L2 -> fabric boundary, from rocprofv3 --pmc FETCH_SIZE and
                      # WRITE_SIZE (separate passes; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
-                     # gfx950): 2 x 3.39e9 + 0.04e9 (profiles/r01_pmc_bench_v2.csv).  The excess over the
+                     # gfx950): 2 x 3.15e9 + 0.04e9 (profiles/r01_pmc_bench_v3.csv; 6.2-7.0e9 across runs).  The excess over the
                      # algorithmic bytes is x-slab gathers missing an XCD's L2 (served by the Infinity Cache).
                      # Only valid for the kernel and size it was measured on.
-                     "traffic": 6.8e9 if (chosen == "tiled" and n == 5000000 and per_col == 64) else None,
+                     "traffic": 6.5e9 if (chosen == "tiled" and n == 5000000 and per_col == 64) else None,
                      "step_ms_hip_events": round(step_ms_events, 4)},
         "gaxpy_trials_ms": {k: round(v["ms"], 4) for k, v in trial.items()},
         "gaxpy_prepare_s": {k: round(v["prepare_s"], 3) for k, v in trial.items()},
@@ -366,6 +366,11 @@ def cholsol_section(args, lib, cs, hB, nb, bs, rank, world, barrier, max_over_ra
            "algorithmic_bytes_fused": fused_bytes,
            "achieved_GBps_per_gpu": round(fused_bytes / (ms * 1e-3) / 1e9, 2),
            "frac_of_peak": round(fused_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+           # PMC (profiles/r01_pmc_bench_v3.csv, k_cholsol_mfma<4>): WRITE_SIZE 5.12e9 (X, exactly once),
+           # 2 x FETCH_SIZE 4.32e9 = 8.6e9 (B once + block fragments, mostly shared by the two 64-RHS waves)
+           "roofline": {"bound": "hbm", "achieved": round(fused_bytes / (ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(fused_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "traffic": 13.8e9 if (fused.value == 3 and n == 5000000 and k == 128) else None},
            "survey_bytes_unfused": cholsol_bytes(lnz, n, k),
            "factor_s": {"symbolic_etree_host_counts_device": round(t_symbolic, 3), "numeric_device_incl_pattern_of_L": round(t_numeric, 3),
                         "solve_plan": round(t_plan, 3)}}
