@@ -32,6 +32,8 @@ from math import sqrt
 import numpy as np
 
 import _csx
+from _hostglue import (CS_FLIP, CS_MARK, CS_MARKED, CS_UNFLIP, cs_dfs, cs_ereach, cs_reach,  # noqa: F401
+                       cs_spsolve)
 from _csx import (GAXPY_ATOMIC, GAXPY_AUTO, GAXPY_EXACT, GAXPY_TILED,  # noqa: F401
                   GAXPY_WAVE, TRI_L, TRI_LT, TRI_U, TRI_UT)
 
