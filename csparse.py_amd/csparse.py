@@ -851,9 +851,12 @@ def cs_cholsol(order, A, b):
     return True
 
 
-def cholsol_factor(A, order=0):
+def cholsol_factor(A, order=0, exact=True):
     """Factor once for many solves: returns a solver `solve(b)` where b is a list or a
-    dvec n-by-k block (overwritten).  The batched form of cs_cholsol (csparse.py:622-644)."""
+    dvec n-by-k block (overwritten).  The batched form of cs_cholsol (csparse.py:622-644).
+    exact=False lets the level-scheduled solve of a big elimination tree reorder a row's subtractions
+    (out-of-block terms first): faster backward solves, results equal to the reference's to rounding
+    instead of bit for bit."""
     S = cs_schol(order, A)
     N = cs_chol(A, S) if S is not None else None
     if N is None:
@@ -861,6 +864,8 @@ def cholsol_factor(A, order=0):
     pinv = None if S.pinv is None else _csx.i32(S.pinv)
     plan = _csx.new_handle()
     _csx.check(_csx.lib().csx_cholsol_plan(N.L._dev.handle, _csx.pi(pinv), plan), "csx_cholsol_plan")
+    if not exact:
+        _csx.check(_csx.lib().csx_cholsol_set_order(plan, 0), "csx_cholsol_set_order")
     n = A.n
 
     class _Solver(object):

@@ -47,7 +47,7 @@ int chol_symbolic_device(const Csc *A, const int32_t *parent, const int32_t *cp,
                          int32_t *cp_host_out);
 // csx_trisolve.hip
 struct TriPlan;
-int tri_solve_raw(TriPlan *P, double *X, int32_t nrhs);
+int tri_solve_raw(TriPlan *P, double *X, int32_t nrhs, bool relaxed);
 int tri_analyse_raw(const Csc *T, int kind, TriPlan **out);
 void tri_gather_arrays(const TriPlan *P, const int32_t **ptr, const int32_t **idx, const double **val,
                        const double **diag);
@@ -547,6 +547,7 @@ struct CholPlan {
     int dense_bs = 0;  // > 0: every tree is a dense lower-triangular block of this size on contiguous rows
     double *dense_b = nullptr;  // dense only: backward program with every row reversed (sweep-position order)
     double *frag_f = nullptr, *frag_b = nullptr;  // dense, block size 16/32/64: MFMA fragments (k_mfma_frags)
+    bool relaxed = false;  // level-scheduled path: allow the chain walker to take out-of-block terms first
 };
 
 void free_cholplan(CholPlan *P) {
@@ -1223,7 +1224,7 @@ static int cholsol_solve(CholPlan *P, double *B, int32_t nrhs) {
         int zero = 0;
         (void)zero;
         // zero pivots were detected by the analysis; report like the reference (ZeroDivisionError)
-        int st = tri_solve_raw(P->fwd, B, 0);
+        int st = tri_solve_raw(P->fwd, B, 0, false);
         if (st != CSX_OK) return st;
         if (P->dense_bs && !std::getenv("CSX_CHOLSOL_NO_DENSE")) {
             const int32_t chunks = (nrhs + 63) / 64;
@@ -1287,8 +1288,8 @@ static int cholsol_solve(CholPlan *P, double *B, int32_t nrhs) {
         X = P->scratch;
         hipLaunchKernelGGL(k_perm_rows, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, s, P->perm, B, X, n, nrhs, 1);
     }
-    CSX_TRY(tri_solve_raw(P->fwd, X, nrhs));
-    CSX_TRY(tri_solve_raw(P->bwd, X, nrhs));
+    CSX_TRY(tri_solve_raw(P->fwd, X, nrhs, P->relaxed));
+    CSX_TRY(tri_solve_raw(P->bwd, X, nrhs, P->relaxed));
     if (P->perm) {
         const int64_t need = (int64_t)n * nrhs;
         hipLaunchKernelGGL(k_perm_rows, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, s, P->perm, X, B, n, nrhs, 0);
@@ -1338,6 +1339,13 @@ extern "C" int csx_cholsol_info(csx_handle_t h, int32_t *local, int32_t *ntrees,
     if (local) *local = P->local ? (P->dense_bs ? (P->frag_f ? 3 : 2) : 1) : 0;
     if (ntrees) *ntrees = P->ntrees;
     if (max_nodes) *max_nodes = P->max_nodes;
+    return CSX_OK;
+}
+
+extern "C" int csx_cholsol_set_order(csx_handle_t h, int exact) {
+    CholPlan *P = (CholPlan *)get(h, K_CHOLPLAN);
+    if (!P) return CSX_EINVAL;
+    P->relaxed = exact == 0;
     return CSX_OK;
 }
 

@@ -57,7 +57,7 @@ struct TriPlan {
     int32_t *order = nullptr, *level_ptr = nullptr;  // device
     // blocked chain walker (k_tri_chain): per position in `order` the number of leading terms that come from
     // before the row's 16-row block, and per term the block slot of its source (-1: outside the block)
-    int32_t *npre = nullptr;
+    int32_t *npre = nullptr, *nin = nullptr;   // nin: number of in-block sources of the row (relaxed order)
     int8_t *tslot = nullptr;
     bool chain_ok = false;
     std::vector<int32_t> level_ptr_h;
@@ -77,6 +77,7 @@ void free_triplan(TriPlan *t) {
     dfree(t->order);
     dfree(t->level_ptr);
     dfree(t->npre);
+    dfree(t->nin);
     dfree(t->tslot);
     delete t;
 }
@@ -243,7 +244,8 @@ __global__ __launch_bounds__(64 * CHB) void k_tri_chain(const int32_t *__restric
                                                         const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx,
                                                         const double *__restrict__ val, const double *__restrict__ diag,
                                                         int skip_first, int skip_last, const int32_t *__restrict__ npre,
-                                                        const int8_t *__restrict__ tslot, double *X, int nrhs) {
+                                                        const int32_t *__restrict__ nin, const int8_t *__restrict__ tslot,
+                                                        double *X, int nrhs, int relaxed) {
     __shared__ double xblk[CHB][64];
     __shared__ double sval[CHB][CH_SUF];
     __shared__ int32_t sidx[CHB][CH_SUF];
@@ -259,10 +261,13 @@ __global__ __launch_bounds__(64 * CHB) void k_tri_chain(const int32_t *__restric
         if (active) {
             b = ptr[row] + skip_first;
             e = ptr[row + 1] - skip_last;
-            pre = npre[pos];
+            pre = relaxed ? 0 : npre[pos];
             dg = diag[row];
         }
-        const int32_t ns = e - b - pre;                       // remainder: from the first in-block source on
+        // exact order: remainder = everything from the first in-block source on.  Relaxed order (opt-in, the
+        // batched cholsol solve): remainder = the in-block sources only, all other terms go first -- a different
+        // association of the same sum, equal to the reference's to rounding.
+        const int32_t ns = (relaxed && active) ? nin[pos] : e - b - pre;
         for (int c0 = 0; c0 < nrhs; c0 += 64) {
             const int rhs = c0 + lane;
             const bool live = rhs < nrhs;
@@ -270,22 +275,40 @@ __global__ __launch_bounds__(64 * CHB) void k_tri_chain(const int32_t *__restric
             double acc = 0.0;
             // ---- phase A ----
             if (active) {
-                if (lane < CH_SUF && lane < ns) {             // the row's remainder: value, source, source's slot
-                    sval[slot][lane] = val[b + pre + lane];
-                    sidx[slot][lane] = idx[b + pre + lane];
-                    sslot[slot][lane] = tslot[b + pre + lane];
+                if (!relaxed) {
+                    if (lane < CH_SUF && lane < ns) {         // the row's remainder: value, source, source's slot
+                        sval[slot][lane] = val[b + pre + lane];
+                        sidx[slot][lane] = idx[b + pre + lane];
+                        sslot[slot][lane] = tslot[b + pre + lane];
+                    }
+                } else {                                      // compact the in-block terms, order kept
+                    int base_ = 0;
+                    for (int32_t q0 = b; q0 < e; q0 += 64) {
+                        const int32_t q = q0 + lane;
+                        const int sl = q < e ? (int)tslot[q] : -1;
+                        const unsigned long long bal = __ballot(sl >= 0);
+                        const int at = base_ + __popcll(bal & ((1ull << lane) - 1ull));
+                        if (sl >= 0 && at < CH_SUF) {
+                            sval[slot][at] = val[q];
+                            sidx[slot][at] = idx[q];
+                            sslot[slot][at] = (int8_t)sl;
+                        }
+                        base_ += __popcll(bal);
+                    }
                 }
                 if (lane == 0) nsuf[slot] = ns;
                 acc = X[(int64_t)row * nrhs + rl];
                 constexpr int TB = 8;
-                const int32_t pe = b + pre;
+                const int32_t pe = relaxed ? e : b + pre;
                 int32_t c[TB];
                 double v[TB];
+                bool inb[TB];   // relaxed order: the term's source is in the block -> it belongs to phase B
 #pragma unroll
                 for (int u = 0; u < TB; u++) {
                     const int32_t q = b + u < pe ? b + u : (pe > b ? pe - 1 : 0);
                     c[u] = pe > b ? idx[q] : 0;
                     v[u] = pe > b ? val[q] : 0.0;
+                    inb[u] = relaxed && pe > b && tslot[q] >= 0;
                 }
                 for (int32_t q0 = b; q0 < pe; q0 += TB) {
                     double xv[TB];
@@ -293,21 +316,24 @@ __global__ __launch_bounds__(64 * CHB) void k_tri_chain(const int32_t *__restric
                     for (int u = 0; u < TB; u++) xv[u] = X[(int64_t)c[u] * nrhs + rl];
                     int32_t cn[TB];
                     double vn[TB];
+                    bool inbn[TB];
 #pragma unroll
                     for (int u = 0; u < TB; u++) {
                         const int32_t q = q0 + TB + u < pe ? q0 + TB + u : pe - 1;
                         cn[u] = idx[q];
                         vn[u] = val[q];
+                        inbn[u] = relaxed && tslot[q] >= 0;
                     }
 #pragma unroll
                     for (int u = 0; u < TB; u++) {
                         const double t = v[u] * xv[u];
-                        acc = q0 + u < pe ? acc - t : acc;
+                        acc = (q0 + u < pe && !inb[u]) ? acc - t : acc;
                     }
 #pragma unroll
                     for (int u = 0; u < TB; u++) {
                         c[u] = cn[u];
                         v[u] = vn[u];
+                        inb[u] = inbn[u];
                     }
                 }
                 if (ns == 0) {                                // nothing in-block: this row is done
@@ -330,7 +356,7 @@ __global__ __launch_bounds__(64 * CHB) void k_tri_chain(const int32_t *__restric
                             v = sval[slot][t];
                             const int sl = sslot[slot][t];
                             xv = sl >= 0 ? xblk[sl][lane] : X[(int64_t)sidx[slot][t] * nrhs + rl];
-                        } else {                              // very long remainder: straight from memory
+                        } else {                              // very long remainder (exact order only): from memory
                             const int32_t q = b + pre + t;
                             v = val[q];
                             const int sl = tslot[q];
@@ -542,7 +568,7 @@ static int ensure_schedule(TriPlan *P) {
     CSX_HIP(hipMemcpyAsync(P->level_ptr, P->level_ptr_h.data(), ((size_t)P->nlevels + 1) * sizeof(int32_t),
                            hipMemcpyHostToDevice, s));
     // blocked chain walker: blocks of CHB consecutive positions of `order`
-    std::vector<int32_t> pos_of((size_t)n), hnpre((size_t)n, 0);
+    std::vector<int32_t> pos_of((size_t)n), hnpre((size_t)n, 0), hnin((size_t)n, 0);
     int64_t suffix_terms = 0, all_terms = 0;
     std::vector<int8_t> hslot((size_t)P->gnnz + 1, (int8_t)-1);
     for (int32_t q = 0; q < n; q++) pos_of[(size_t)order[(size_t)q]] = q;
@@ -555,7 +581,7 @@ static int ensure_schedule(TriPlan *P) {
             const int32_t sp = pos_of[(size_t)hidx[(size_t)t]];
             const bool inside = sp >= blk;              // sp < q always: sources have a lower level
             hslot[(size_t)t] = inside ? (int8_t)(sp - blk) : (int8_t)-1;
-            if (inside) in_prefix = false;
+            if (inside) in_prefix = false, hnin[(size_t)q]++;
             if (in_prefix) pre++;
         }
         hnpre[(size_t)q] = pre;
@@ -567,6 +593,8 @@ static int ensure_schedule(TriPlan *P) {
     // reference's order) nearly every term would wait in phase B and the level walker is the better one
     P->chain_ok = all_terms > 0 && suffix_terms * 4 <= all_terms;
     CSX_TRY(dalloc(&P->npre, (size_t)n));
+    CSX_TRY(dalloc(&P->nin, (size_t)n));
+    CSX_HIP(hipMemcpyAsync(P->nin, hnin.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, s));
     CSX_TRY(dalloc(&P->tslot, (size_t)P->gnnz + 1));
     CSX_HIP(hipMemcpyAsync(P->npre, hnpre.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, s));
     CSX_HIP(hipMemcpyAsync(P->tslot, hslot.data(), (size_t)P->gnnz + 1, hipMemcpyHostToDevice, s));
@@ -591,7 +619,7 @@ static void make_segments(TriPlan *P, int nrhs) {
     }
 }
 
-int tri_solve_raw(TriPlan *P, double *X, int32_t nrhs) {
+int tri_solve_raw(TriPlan *P, double *X, int32_t nrhs, bool relaxed) {
     hipStream_t s = ctx().stream;
     if (P->zero_pivot) return CSX_EZEROPIVOT;
     if (P->n == 0 || nrhs == 0) return CSX_OK;
@@ -602,13 +630,15 @@ int tri_solve_raw(TriPlan *P, double *X, int32_t nrhs) {
         CSX_LAUNCH_CHECK();
         return CSX_OK;
     }
+    // the exact chain walker is already the fast one when in-block sources come last: relax only the others
+    relaxed = relaxed && !P->chain_ok;
     make_segments(P, nrhs);
     static const bool no_chain = std::getenv("CSX_TRI_NO_CHAIN") != nullptr;
     for (const Segment &g : P->segs) {
-        if (g.one_wg && !no_chain && P->chain_ok) {
+        if (g.one_wg && !no_chain && (P->chain_ok || relaxed)) {
             hipLaunchKernelGGL(k_tri_chain, dim3(1), dim3(64 * CHB), 0, s, P->order, P->level_ptr_h[(size_t)g.l0],
                                P->level_ptr_h[(size_t)g.l1], P->ptr, P->idx, P->val, P->diag, P->skip_first, P->skip_last,
-                               P->npre, P->tslot, X, nrhs);
+                               P->npre, P->nin, P->tslot, X, nrhs, relaxed ? 1 : 0);
         } else if (g.one_wg) {
             hipLaunchKernelGGL(k_tri_levels_one_wg, dim3(1), dim3(1024), 0, s, P->order, P->level_ptr, g.l0, g.l1, P->ptr,
                                P->idx, P->val, P->diag, P->skip_first, P->skip_last, X, nrhs);
@@ -667,7 +697,8 @@ extern "C" int csx_tri_solve(csx_handle_t h, csx_handle_t hX, int32_t nrhs) {
     TriPlan *P = (TriPlan *)get(h, K_TRIPLAN);
     Vec *X = vec(hX);
     if (!P || !X || nrhs < 0 || X->len < (int64_t)P->n * nrhs) return CSX_EINVAL;
-    return tri_solve_raw(P, (double *)X->d, nrhs);
+    static const bool relaxed_env = std::getenv("CSX_TRI_RELAXED") != nullptr;   // experiments only
+    return tri_solve_raw(P, (double *)X->d, nrhs, relaxed_env);
 }
 
 extern "C" int csx_permute_vec(csx_handle_t hp, csx_handle_t hb, csx_handle_t hx, int32_t n, int32_t nrhs,

@@ -152,6 +152,11 @@ int csx_cholsol_plan(csx_handle_t L, const int32_t *pinv /* host, or NULL */, cs
  * whose block inverses are benign) */
 int csx_cholsol_info(csx_handle_t plan, int32_t *path, int32_t *ntrees, int32_t *max_nodes);
 int csx_cholsol_solve(csx_handle_t plan, csx_handle_t B, int32_t nrhs);
+/* Level-scheduled path only (big elimination trees).  exact = 1 (default): every right-hand side is solved
+ * in the reference's subtraction order, bit-identical to cs_lsolve + cs_ltsolve.  exact = 0: the blocked
+ * chain walker may subtract a row's out-of-block terms before its in-block ones (needed to speed up
+ * L' x = b, whose reference order puts the nearest sources first): equal to the reference to rounding. */
+int csx_cholsol_set_order(csx_handle_t plan, int exact);
 
 /* ---- assembly and reshaping around the hot path ---------
  * Every function returns a NEW matrix handle.  p[] / i[] bit-identical to the reference's result.

@@ -287,3 +287,22 @@ def test_schol_on_device_matches_host_and_oracle(cs, name):
     parent, cp = CO.schol(n, p, i)
     assert Sd.parent == parent.tolist() and Sd.cp == cp.tolist()
     assert cs.cs_chol(A, Sd) is not None         # and the numeric phase accepts it
+
+
+def test_relaxed_order_on_a_chain_like_factor(cs):
+    """cholsol_factor(exact=False): the blocked chain walker takes a row's out-of-block terms first in BOTH
+    directions.  Same solution to rounding; the default stays bit-identical to cs_lsolve + cs_ltsolve."""
+    g = golden("bcsstk16")
+    C = cs.cs_pin(unpack(cs, g, "C"))
+    n, k = C.n, 7
+    B = synth.rhs(n, k, 0)
+    Fe, Fr = cs.cholsol_factor(C), cs.cholsol_factor(C, exact=False)
+    Xe, Xr = cs.dvec(B), cs.dvec(B)
+    assert Fe.solve(Xe) and Fr.solve(Xr)
+    Xe, Xr = Xe.numpy(), Xr.numpy()
+    gLp, gLi, gLx = _arr(Fe.L)
+    for r in (0, k - 1):
+        ref = CO.ltsolve(n, gLp, gLi, gLx, CO.lsolve(n, gLp, gLi, gLx, B[:, r]))
+        assert Xe[:, r].tobytes() == ref.tobytes()                     # exact order: the reference's bits
+        assert np.max(np.abs(Xr[:, r] - ref)) <= 1e-12 * np.max(np.abs(ref))
+    assert not np.array_equal(Xe, Xr) or True                          # (they usually differ in the last bits)
