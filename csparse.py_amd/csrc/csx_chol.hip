@@ -900,7 +900,7 @@ __global__ __launch_bounds__(256) void k_cholsol_dense(const Tree *__restrict__ 
 // k-step r, so a finished tile X_j feeds the next product from its registers: no LDS, no lane movement.
 // One wave: one block x 64 right-hand sides = NB x 4 tiles = the same 128 VGPRs of unknowns as before.
 // Results equal the substitution kernels to rounding (different association; explicit block inverses), so
-// the plan refuses this path when a block inverse is large (max|W| max|L| > 1e6).
+// the plan refuses this path when a block inverse is large (max|W| max|L| > 1e4: the error of a product with an explicit inverse grows with it).
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 template <int NB>
@@ -1201,7 +1201,7 @@ static int cholsol_plan(const Csc *L, const int32_t *pinv, CholPlan **out) {
                 dfree(cond);
                 double growth;
                 std::memcpy(&growth, &hcond, sizeof growth);
-                if (st2 != CSX_OK || !(growth <= 1e6)) {   // badly conditioned block (or NaN): keep substitution
+                if (st2 != CSX_OK || !(growth <= 1e4)) {   // badly conditioned block (or NaN): keep substitution
                     dfree(P->frag_f);
                     dfree(P->frag_b);
                     P->frag_f = P->frag_b = nullptr;

@@ -173,7 +173,7 @@ def test_gspd_factor_and_batched_solve(cs, nblocks, bs, k):
 
 
 def test_badly_scaled_blocks_keep_substitution(cs):
-    """Block inverses with large growth (max|W| max|L| > 1e6): the plan must not use the matrix-core path,
+    """Block inverses with large growth (max|W| max|L| > 1e4): the plan must not use the matrix-core path,
     and the solve still meets the tolerance."""
     nblocks, bs, k = 6, 32, 20
     Ap, Ai, Ax = synth.gspd(nblocks, bs, 77)
