@@ -356,7 +356,15 @@ def cs_scatter(A, j, beta, w, x, mark, C, nz):
 
 def cs_norm(A):
     """1-norm = largest column sum of |a| (csparse.py:1647-1663)."""
-    if not CS_CSC(A) or A.x is None:
+    if not CS_CSC(A):
+        return -1
+    if A._dev is not None:   # device-resident: column sums in storage order, the reference's bits
+        if not A._dev.info()[3]:
+            return -1
+        out = _csx.C.c_double(0.0)
+        _csx.check(_csx.lib().csx_norm1(A._dev.handle, out), "csx_norm1")
+        return out.value
+    if A.x is None:
         return -1
     best = 0
     for j in range(A.n):

@@ -16,6 +16,7 @@
 // p[] and i[] of every result are bit-identical to the reference's; x[] too wherever a value is copied or
 // is the sum of at most two terms (cs_add of matrices without duplicates), otherwise sums are in arrival
 // order and agree to rounding.
+#include <cstring>
 #include <vector>
 
 #include "csx_internal.h"
@@ -367,6 +368,20 @@ static int col_block_device(const Csc *A, int32_t first, int32_t count, Csc *C) 
     return CSX_OK;
 }
 
+// ---- cs_norm (csparse.py:1647-1663): largest column sum of |a| -------------------------------------------
+// One thread per column, entries added in storage order: every column sum, hence the maximum, has the
+// reference's bits.  Non-negative doubles order like their bit patterns, so the maximum is an integer atomic.
+__global__ __launch_bounds__(256) void k_norm1(int32_t n, const int32_t *__restrict__ Ap, const double *__restrict__ Ax,
+                                               unsigned long long *best) {
+#pragma clang fp contract(off)
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    double sum = 0.0;
+    for (int32_t p = Ap[j]; p < Ap[j + 1]; p++) sum += fabs(Ax[p]);
+    if (sum == sum) atomicMax(best, (unsigned long long)__double_as_longlong(sum));
+    else atomicMax(best + 1, 1ull);   // a NaN column: max(best, NaN) in the reference keeps `best`; remembered only for the caller
+}
+
 template <class F>
 static int make_csc(csx_handle_t *out, F &&build) {
     Csc *C = new Csc();
@@ -439,4 +454,24 @@ extern "C" int csx_csc_col_block(csx_handle_t hA, int32_t first, int32_t count, 
     Csc *A = csc(hA);
     if (!A || !out || first < 0 || count < 0 || (int64_t)first + count > A->n) return CSX_EINVAL;
     return make_csc(out, [&](Csc *C) { return col_block_device(A, first, count, C); });
+}
+
+extern "C" int csx_norm1(csx_handle_t hA, double *out) {
+    CSX_TRY(require_ready());
+    Csc *A = csc(hA);
+    if (!A || !out || !A->x) return CSX_EINVAL;
+    hipStream_t s = ctx().stream;
+    unsigned long long *d = nullptr, h[2] = {0, 0};
+    CSX_TRY(dalloc(&d, 2));
+    int st = CSX_OK;
+    if (hipMemsetAsync(d, 0, 2 * sizeof(unsigned long long), s) != hipSuccess) st = CSX_ERUNTIME;
+    if (st == CSX_OK && A->n > 0) hipLaunchKernelGGL(k_norm1, dim3(blocks_for(A->n)), dim3(256), 0, s, A->n, A->p, A->x, d);
+    if (st == CSX_OK && (hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess))
+        st = CSX_ERUNTIME;
+    dfree(d);
+    CSX_TRY(st);
+    double v;
+    std::memcpy(&v, &h[0], sizeof v);
+    *out = v;
+    return CSX_OK;
 }

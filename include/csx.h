@@ -175,6 +175,9 @@ int csx_dupl(csx_handle_t A, csx_handle_t *out);
 int csx_drop(csx_handle_t A, int mode, double tol, csx_handle_t *out);
 int csx_permute(csx_handle_t A, const int32_t *pinv, const int32_t *q, int values, csx_handle_t *out);
 int csx_symperm(csx_handle_t A, const int32_t *pinv, int values, csx_handle_t *out);
+/* cs_norm, csparse.py:1647-1663: 1-norm (largest column sum of |a|), column sums in storage order (the
+ * reference's bits).  Needs values. */
+int csx_norm1(csx_handle_t A, double *out);
 /* Columns [first, first + count) of A as a new m x count matrix: the unit of a column-sharded SpMV. */
 int csx_csc_col_block(csx_handle_t A, int32_t first, int32_t count, csx_handle_t *out);
 

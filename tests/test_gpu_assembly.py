@@ -151,3 +151,15 @@ def test_bad_arguments(cs):
     assert cs.cs_compress(A) is None and cs.cs_fkeep(A, None, None) == -1
     with pytest.raises(IndexError):
         cs.cs_permute(A, [0, 1], None, True)          # pinv shorter than m
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_norm_on_device_has_the_reference_bits(cs, name, meta):
+    g = golden(name)
+    A = unpack(cs, g, "A")
+    host = cs.cs_norm(A)
+    cs.cs_pin(A)
+    assert cs.cs_norm(A) == host == meta[name]["normA"]          # meta: the unmodified reference's cs_norm
+    P = unpack(cs, g, "A")
+    P.x = None
+    assert cs.cs_norm(cs.cs_pin(P)) == -1 and cs.cs_norm(None) == -1
