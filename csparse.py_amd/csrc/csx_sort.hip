@@ -147,11 +147,25 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint32_t *key, int
     __shared__ int h[RS_BINS];
     h[threadIdx.x] = 0;
     __syncthreads();
-    int64_t base = (int64_t)blockIdx.x * RS_TILE;
+    const int64_t base = (int64_t)blockIdx.x * RS_TILE;
+    if (base + RS_TILE <= count) {
+        // full tile: 16-byte loads, a wave instruction covers 1 KiB (the order of the keys does not matter here)
+        typedef uint32_t u32x4h __attribute__((ext_vector_type(4)));
+        const u32x4h *k4 = reinterpret_cast<const u32x4h *>(key + base);
+#pragma unroll
+        for (int r = 0; r < RS_ROUNDS / 4; r++) {
+            const u32x4h v = k4[r * RS_THREADS + threadIdx.x];
+            atomicAdd(&h[(v.x >> shift) & (RS_BINS - 1)], 1);
+            atomicAdd(&h[(v.y >> shift) & (RS_BINS - 1)], 1);
+            atomicAdd(&h[(v.z >> shift) & (RS_BINS - 1)], 1);
+            atomicAdd(&h[(v.w >> shift) & (RS_BINS - 1)], 1);
+        }
+    } else {
 #pragma unroll 4
-    for (int r = 0; r < RS_ROUNDS; r++) {
-        int64_t idx = base + (int64_t)r * RS_THREADS + threadIdx.x;
-        if (idx < count) atomicAdd(&h[(key[idx] >> shift) & (RS_BINS - 1)], 1);
+        for (int r = 0; r < RS_ROUNDS; r++) {
+            int64_t idx = base + (int64_t)r * RS_THREADS + threadIdx.x;
+            if (idx < count) atomicAdd(&h[(key[idx] >> shift) & (RS_BINS - 1)], 1);
+        }
     }
     __syncthreads();
     hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
