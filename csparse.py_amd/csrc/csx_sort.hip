@@ -356,16 +356,34 @@ int stable_sort_by_key(const uint32_t *key, const uint32_t *a, const double *v, 
 }
 
 // ----------------------------------------------------------- boundaries ----
+// position q (0..count) closes the keys (sorted_key[q-1], sorted_key[q]]: ptr[r] = q for those r.
+// Four positions per thread through one 16-byte load (boundaries are rare, the key stream is the cost).
 __global__ __launch_bounds__(256) void k_boundaries(const uint32_t *skey, int64_t count, int32_t nkeys, int32_t *ptr) {
-    int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q > count) return;
-    int64_t prev = (q == 0) ? -1 : (int64_t)skey[q - 1];
-    int64_t cur = (q == count) ? (int64_t)nkeys : (int64_t)skey[q];
-    for (int64_t r = prev + 1; r <= cur; r++) ptr[r] = (int32_t)q;
+    typedef uint32_t u32x4b __attribute__((ext_vector_type(4)));
+    const int64_t q0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (q0 > count) return;
+    int64_t prev = (q0 == 0) ? -1 : (int64_t)skey[q0 - 1];
+    if (q0 + 4 <= count) {
+        const u32x4b v = *reinterpret_cast<const u32x4b *>(skey + q0);
+        const uint32_t k4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int64_t cur = (int64_t)k4[k];
+            for (int64_t r = prev + 1; r <= cur; r++) ptr[r] = (int32_t)(q0 + k);
+            prev = cur;
+        }
+        return;
+    }
+    for (int64_t q = q0; q <= count; q++) {   // the last, partial group and the closing position q = count
+        const int64_t cur = (q == count) ? (int64_t)nkeys : (int64_t)skey[q];
+        for (int64_t r = prev + 1; r <= cur; r++) ptr[r] = (int32_t)q;
+        prev = cur;
+    }
 }
 
 int boundaries_from_sorted(const uint32_t *sorted_key, int64_t count, int32_t nkeys, int32_t *ptr) {
-    int64_t blocks = (count + 1 + 255) / 256;
+    const int64_t threads = count / 4 + 1;
+    const int64_t blocks = (threads + 255) / 256;
     hipLaunchKernelGGL(k_boundaries, dim3((unsigned)blocks), dim3(256), 0, ctx().stream, sorted_key, count, nkeys, ptr);
     CSX_LAUNCH_CHECK();
     return CSX_OK;
