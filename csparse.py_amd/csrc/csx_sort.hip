@@ -148,7 +148,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint32_t *key, int
     h[threadIdx.x] = 0;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * RS_TILE;
-    if (base + RS_TILE <= count) {
+    if (base + RS_TILE <= count && (reinterpret_cast<uintptr_t>(key) & 15) == 0) {
         // full tile: 16-byte loads, a wave instruction covers 1 KiB (the order of the keys does not matter here)
         typedef uint32_t u32x4h __attribute__((ext_vector_type(4)));
         const u32x4h *k4 = reinterpret_cast<const u32x4h *>(key + base);
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void k_boundaries(const uint32_t *skey, int64_
     const int64_t q0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (q0 > count) return;
     int64_t prev = (q0 == 0) ? -1 : (int64_t)skey[q0 - 1];
-    if (q0 + 4 <= count) {
+    if (q0 + 4 <= count && (reinterpret_cast<uintptr_t>(skey) & 15) == 0) {
         const u32x4b v = *reinterpret_cast<const u32x4b *>(skey + q0);
         const uint32_t k4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
