@@ -374,7 +374,8 @@ __global__ __launch_bounds__(256) void k_boundaries(const uint32_t *skey, int64_
         }
         return;
     }
-    for (int64_t q = q0; q <= count; q++) {   // the last, partial group and the closing position q = count
+    const int64_t qend = q0 + 4 <= count ? q0 + 4 : count + 1;   // the last, partial group closes with q = count
+    for (int64_t q = q0; q < qend; q++) {
         const int64_t cur = (q == count) ? (int64_t)nkeys : (int64_t)skey[q];
         for (int64_t r = prev + 1; r <= cur; r++) ptr[r] = (int32_t)q;
         prev = cur;
