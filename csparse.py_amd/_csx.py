@@ -31,6 +31,7 @@ _PROTOS = {
     "csx_permute": [H, _i32p, _i32p, C.c_int, C.POINTER(H)],
     "csx_symperm": [H, _i32p, C.c_int, C.POINTER(H)],
     "csx_schol": [H, _i32p, _i32p],
+    "csx_order_nd_host": [C.c_int32, _i32p, _i32p, _i32p],
     "csx_norm1": [H, _f64p],
     "csx_cholsol_set_order": [H, C.c_int],
     "csx_gaxpy_host": [C.c_int32, C.c_int32, _i32p, _i32p, _f64p, _f64p, _f64p],

@@ -786,12 +786,38 @@ def cs_pvec(p, b, x, n):
 
 # ------------------------------------------------------------- Cholesky ----
 
-def cs_schol(order, A):
-    """Symbolic Cholesky analysis (csparse.py:2051-2072): etree, postorder, column
-    counts -- host C++ inside libcsx.  Only the natural ordering (order 0) is
-    defined: the reference's cs_amd never yields a permutation."""
-    if not CS_CSC(A) or order != 0:
+def cs_amd(order, A):
+    """Fill-reducing ordering p (csparse.py:214-556), order 1 = for Cholesky of A (pattern of A + A').
+    The reference's implementation does not run, so there is no permutation to match:
+    this is a nested dissection, which gives the device a bushy elimination tree.  Orders 2 and 3
+    (LU / QR, pattern of A'A) are not provided: None."""
+    if not CS_CSC(A) or order != 1 or A.m != A.n:
         return None
+    n = A.n
+    p = _csx.i32(A.p[:n + 1])
+    i = _csx.i32(A.i[:int(p[n])])
+    perm = np.empty(max(n, 1), dtype=np.int32)
+    if _csx.load().csx_order_nd_host(n, _csx.pi(p), _csx.pi(i), _csx.pi(perm)) != _csx.OK:
+        return None
+    return perm[:n].tolist()
+
+
+def cs_schol(order, A):
+    """Symbolic Cholesky analysis (csparse.py:2051-2072): ordering, etree, column counts.  order 0 =
+    natural; order 1 = cs_amd (here a nested dissection).  The tree is built by host C++ inside libcsx,
+    the column counts on the device when A is resident there."""
+    if not CS_CSC(A) or order not in (0, 1):
+        return None
+    if order == 1:
+        P = cs_amd(1, A)
+        if P is None:
+            return None
+        pinv = cs_pinv(P, A.n)
+        C = cs_symperm(A, pinv, False)
+        S = cs_schol(0, C)
+        if S is not None:
+            S.pinv = pinv
+        return S
     n = A.n
     parent = np.empty(max(n, 1), dtype=np.int32)
     cp = np.empty(n + 1, dtype=np.int32)

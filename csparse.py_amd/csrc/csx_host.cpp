@@ -98,6 +98,158 @@ static void walk_row_patterns(int32_t n, const std::vector<int32_t> &up_ptr, con
     }
 }
 
+// ---- a fill-reducing ordering that suits level scheduling: nested dissection --------------------------
+// The reference's cs_amd does not run, so order = 1 has no answer to match; what the
+// device wants from an ordering is a BUSHY elimination tree (wide levels), and nested dissection gives
+// exactly that: split the graph of A + A' by a vertex separator, order the two halves first (recursively,
+// they are independent subtrees) and the separator last.  Separators here are the middle level of a
+// breadth-first level structure rooted at a pseudo-peripheral vertex (two sweeps) -- crude but O(nnz log n),
+// deterministic, and good on the mesh-like matrices sparse Cholesky is used for.  Parts of <= ND_LEAF
+// vertices, and parts whose level structure is too shallow to cut, are numbered in breadth-first order.
+// perm[k] = the original index of the k-th row/column of P A P' (cs_amd's convention, csparse.py:214).
+namespace {
+constexpr int32_t ND_LEAF = 96;
+
+struct NdGraph {
+    int32_t n;
+    std::vector<int32_t> ptr, adj;
+};
+
+void nd_build_graph(int32_t n, const int32_t *Ap, const int32_t *Ai, NdGraph &G) {
+    G.n = n;
+    G.ptr.assign((size_t)n + 1, 0);
+    for (int32_t j = 0; j < n; j++)
+        for (int32_t p = Ap[j]; p < Ap[j + 1]; p++) {
+            const int32_t i = Ai[p];
+            if (i == j) continue;
+            G.ptr[(size_t)i + 1]++;
+            G.ptr[(size_t)j + 1]++;
+        }
+    for (int32_t v = 0; v < n; v++) G.ptr[(size_t)v + 1] += G.ptr[(size_t)v];
+    G.adj.assign((size_t)G.ptr[(size_t)n], 0);
+    std::vector<int32_t> fill(G.ptr.begin(), G.ptr.end() - 1);
+    for (int32_t j = 0; j < n; j++)
+        for (int32_t p = Ap[j]; p < Ap[j + 1]; p++) {
+            const int32_t i = Ai[p];
+            if (i == j) continue;
+            G.adj[(size_t)fill[(size_t)i]++] = j;
+            G.adj[(size_t)fill[(size_t)j]++] = i;
+        }
+}
+
+// breadth-first search inside the part `tag` (part[v] == tag); fills order[] / level_of[]; returns the number of levels
+int32_t nd_bfs(const NdGraph &G, const std::vector<int32_t> &part, int32_t tag, int32_t root, std::vector<int32_t> &mark,
+               int32_t stamp, std::vector<int32_t> &order, std::vector<int32_t> &level_start) {
+    order.clear();
+    level_start.clear();
+    order.push_back(root);
+    mark[(size_t)root] = stamp;
+    size_t head = 0;
+    while (head < order.size()) {
+        level_start.push_back((int32_t)head);
+        const size_t end = order.size();
+        for (; head < end; head++) {
+            const int32_t v = order[head];
+            for (int32_t q = G.ptr[(size_t)v]; q < G.ptr[(size_t)v + 1]; q++) {
+                const int32_t u = G.adj[(size_t)q];
+                if (part[(size_t)u] == tag && mark[(size_t)u] != stamp) {
+                    mark[(size_t)u] = stamp;
+                    order.push_back(u);
+                }
+            }
+        }
+    }
+    level_start.push_back((int32_t)order.size());
+    return (int32_t)level_start.size() - 1;
+}
+}  // namespace
+
+}  // namespace csx
+
+using namespace csx;
+
+extern "C" int csx_order_nd_host(int32_t n, const int32_t *Ap, const int32_t *Ai, int32_t *perm) {
+    if (n < 0 || !Ap || (!Ai && Ap[n] > 0) || !perm) return CSX_EINVAL;
+    for (int32_t j = 0; j < n; j++)
+        for (int32_t p = Ap[j]; p < Ap[j + 1]; p++)
+            if (Ai[p] < 0 || Ai[p] >= n) return CSX_EINVAL;
+    NdGraph G;
+    nd_build_graph(n, Ap, Ai, G);
+    std::vector<int32_t> part((size_t)n, 0), mark((size_t)n, -1), order, level_start, best_order, best_levels;
+    struct Job {
+        int32_t tag, out_lo;             // the part and where its vertices go in perm
+        std::vector<int32_t> verts;
+    };
+    std::vector<Job> jobs;
+    {
+        Job all;
+        all.tag = 0;
+        all.out_lo = 0;
+        all.verts.resize((size_t)n);
+        for (int32_t v = 0; v < n; v++) all.verts[(size_t)v] = v;
+        jobs.push_back(std::move(all));
+    }
+    int32_t next_tag = 1, stamp = 0;
+    while (!jobs.empty()) {
+        Job job = std::move(jobs.back());
+        jobs.pop_back();
+        const int32_t sz = (int32_t)job.verts.size();
+        if (sz == 0) continue;
+        // one connected component at a time: the rest goes back on the stack as its own part
+        nd_bfs(G, part, job.tag, job.verts[0], mark, ++stamp, order, level_start);
+        if ((int32_t)order.size() < sz) {
+            Job rest;
+            rest.tag = next_tag++;
+            rest.out_lo = job.out_lo + (int32_t)order.size();
+            for (int32_t v : job.verts)
+                if (mark[(size_t)v] != stamp) {
+                    rest.verts.push_back(v);
+                    part[(size_t)v] = rest.tag;
+                }
+            jobs.push_back(std::move(rest));
+        }
+        const int32_t csz = (int32_t)order.size();
+        // pseudo-peripheral root: restart from a vertex of the last level (smallest degree), twice
+        for (int sweep = 0; sweep < 2 && csz > ND_LEAF; sweep++) {
+            const int32_t nl = (int32_t)level_start.size() - 1;
+            int32_t far = order[(size_t)level_start[(size_t)nl - 1]];
+            for (int32_t q = level_start[(size_t)nl - 1]; q < level_start[(size_t)nl]; q++) {
+                const int32_t v = order[(size_t)q];
+                if (G.ptr[(size_t)v + 1] - G.ptr[(size_t)v] < G.ptr[(size_t)far + 1] - G.ptr[(size_t)far]) far = v;
+            }
+            nd_bfs(G, part, job.tag, far, mark, ++stamp, order, level_start);
+        }
+        const int32_t nl = (int32_t)level_start.size() - 1;
+        if (csz <= ND_LEAF || nl < 3) {   // leaf (or too shallow to cut): breadth-first numbering
+            for (int32_t q = 0; q < csz; q++) perm[job.out_lo + q] = order[(size_t)q];
+            continue;
+        }
+        // separator = the level at which half of the component has been passed (never the first or last level)
+        int32_t s = 1;
+        while (s < nl - 2 && level_start[(size_t)s + 1] < csz / 2) s++;
+        const int32_t a_end = level_start[(size_t)s], b_begin = level_start[(size_t)s + 1];
+        Job A, B;
+        A.tag = next_tag++;
+        B.tag = next_tag++;
+        A.out_lo = job.out_lo;
+        B.out_lo = job.out_lo + a_end;
+        A.verts.assign(order.begin(), order.begin() + a_end);
+        B.verts.assign(order.begin() + b_begin, order.end());
+        for (int32_t v : A.verts) part[(size_t)v] = A.tag;
+        for (int32_t v : B.verts) part[(size_t)v] = B.tag;
+        int32_t out = job.out_lo + a_end + (csz - b_begin);     // the separator goes last
+        for (int32_t q = a_end; q < b_begin; q++) {
+            part[(size_t)order[(size_t)q]] = -1;
+            perm[out++] = order[(size_t)q];
+        }
+        jobs.push_back(std::move(A));
+        jobs.push_back(std::move(B));
+    }
+    return CSX_OK;
+}
+
+namespace csx {
+
 }  // namespace csx
 
 using namespace csx;

@@ -138,6 +138,12 @@ int csx_schol_host(int32_t n, const int32_t *Ap, const int32_t *Ai, int32_t *par
  * device (the row-subtree walks of csx_chol).  parent[n] and cp[n+1] are host arrays. */
 int csx_schol(csx_handle_t A, int32_t *parent, int32_t *cp);
 
+/* A fill-reducing ordering for order = 1 (Cholesky; the reference's cs_amd, csparse.py:214-556, does not
+ * run): nested dissection of the graph of A + A' by breadth-first level separators, which yields the wide
+ * elimination-tree levels the device kernels want.  Host arrays; perm[k] = original index of the k-th
+ * row/column of P A P'. */
+int csx_order_nd_host(int32_t n, const int32_t *Ap, const int32_t *Ai, int32_t *perm);
+
 /* cs_chol numeric, csparse.py:561-619.  A: device CSC (upper triangle used);
  * parent/cp: host arrays from csx_schol_host; pinv: host permutation or NULL.
  * Output L (device CSC, diagonal first, rows ascending). */

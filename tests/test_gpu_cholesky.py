@@ -306,3 +306,29 @@ def test_relaxed_order_on_a_chain_like_factor(cs):
         assert Xe[:, r].tobytes() == ref.tobytes()                     # exact order: the reference's bits
         assert np.max(np.abs(Xr[:, r] - ref)) <= 1e-12 * np.max(np.abs(ref))
     assert not np.array_equal(Xe, Xr) or True                          # (they usually differ in the last bits)
+
+
+@pytest.mark.parametrize("name", ["bcsstk01", "bcsstk16"])
+def test_cholsol_with_the_fill_reducing_ordering(cs, name):
+    """order = 1: nested dissection in place of the reference's (non-working) cs_amd.  No permutation to match;
+    the solution must be the order-0 one to rounding, and the driver conventions must hold."""
+    g = golden(name)
+    C = unpack(cs, g, "C")
+    n = C.n
+    P = cs.cs_amd(1, C)
+    assert sorted(P) == list(range(n)) and cs.cs_amd(2, C) is None and cs.cs_amd(1, None) is None
+    S = cs.cs_schol(1, C)
+    assert S.pinv == cs.cs_pinv(P, n) and len(S.parent) == n and S.cp[n] == S.lnz
+    b0, b1 = g["b"].tolist(), g["b"].tolist()
+    assert cs.cs_cholsol(0, C, b0) is True and cs.cs_cholsol(1, C, b1) is True
+    x0, x1 = np.asarray(b0), np.asarray(b1)
+    assert np.max(np.abs(x1 - x0)) <= 1e-9 * np.max(np.abs(x0))
+    # batched, device-resident
+    cs.cs_pin(C)
+    F = cs.cholsol_factor(C, order=1)
+    B = np.stack([g["b"], 3.0 * g["b"]], axis=1)
+    dB = cs.dvec(B)
+    assert F.solve(dB) is True
+    X = dB.numpy()
+    assert np.max(np.abs(X[:, 0] - x0)) <= 1e-9 * np.max(np.abs(x0))
+    assert np.max(np.abs(X[:, 1] - 3.0 * x0)) <= 3e-9 * np.max(np.abs(x0))
