@@ -16,7 +16,7 @@ def test_schol_host_matches_oracle(name):
     S = cs.cs_schol(0, C)
     R = O.cs_schol(0, unpack(O, g, "C"))
     assert S.parent == R.parent and S.cp == R.cp and S.lnz == R.lnz and S.pinv is None
-    assert cs.cs_schol(1, C) is None  # the reference's cs_amd never yields an ordering
+    assert cs.cs_schol(2, C) is None  # only the natural order and the order-1 ordering are defined
 
 
 def test_schol_host_block_diagonal():
