@@ -228,19 +228,31 @@ extern "C" int csx_order_nd_host(int32_t n, const int32_t *Ap, const int32_t *Ai
         int32_t s = 1;
         while (s < nl - 2 && level_start[(size_t)s + 1] < csz / 2) s++;
         const int32_t a_end = level_start[(size_t)s], b_begin = level_start[(size_t)s + 1];
+        // thin the separator: only the vertices of level s that touch level s + 1 have to be in it; the others
+        // stay with the first half (every path into the second half leaves level s through such a vertex)
+        for (int32_t q = b_begin; q < level_start[(size_t)s + 2]; q++) mark[(size_t)order[(size_t)q]] = -2 - stamp;  // level s+1
         Job A, B;
         A.tag = next_tag++;
         B.tag = next_tag++;
-        A.out_lo = job.out_lo;
-        B.out_lo = job.out_lo + a_end;
         A.verts.assign(order.begin(), order.begin() + a_end);
+        std::vector<int32_t> sep;
+        for (int32_t q = a_end; q < b_begin; q++) {
+            const int32_t v = order[(size_t)q];
+            bool touches = false;
+            for (int32_t e = G.ptr[(size_t)v]; e < G.ptr[(size_t)v + 1] && !touches; e++)
+                touches = mark[(size_t)G.adj[(size_t)e]] == -2 - stamp;
+            if (touches) sep.push_back(v);
+            else A.verts.push_back(v);
+        }
         B.verts.assign(order.begin() + b_begin, order.end());
+        A.out_lo = job.out_lo;
+        B.out_lo = job.out_lo + (int32_t)A.verts.size();
         for (int32_t v : A.verts) part[(size_t)v] = A.tag;
         for (int32_t v : B.verts) part[(size_t)v] = B.tag;
-        int32_t out = job.out_lo + a_end + (csz - b_begin);     // the separator goes last
-        for (int32_t q = a_end; q < b_begin; q++) {
-            part[(size_t)order[(size_t)q]] = -1;
-            perm[out++] = order[(size_t)q];
+        int32_t out = B.out_lo + (int32_t)B.verts.size();     // the separator goes last
+        for (int32_t v : sep) {
+            part[(size_t)v] = -1;
+            perm[out++] = v;
         }
         jobs.push_back(std::move(A));
         jobs.push_back(std::move(B));
