@@ -104,3 +104,32 @@ def test_triangular_solves_bit_identical(cs, n, mean_len):
         Xk = dB.numpy()
         for r in range(k):
             assert Xk[:, r].tobytes() == ofn(n, *arr, B[:, r]).tobytes(), (fn.__name__, r)
+
+
+def test_banded_triangles_many_right_hand_sides(cs):
+    """A banded (chain-like) triangle with more right-hand sides than one 64-lane chunk: the blocked chain
+    walker loops over chunks of right-hand sides and must stay bit-identical in each."""
+    rng = np.random.default_rng(99)
+    n, k = 900, 130
+    for lower in (True, False):
+        cols_i, cols_x = [], []
+        for j in range(n):
+            lo, hi = (j + 1, min(n, j + 40)) if lower else (max(0, j - 40), j)
+            off = np.arange(lo, hi)
+            vals = rng.uniform(-1, 1, size=len(off))
+            d = float(rng.uniform(40.0, 60.0))
+            cols_i.append(np.concatenate([[j], off]) if lower else np.concatenate([off, [j]]))
+            cols_x.append(np.concatenate([[d], vals]) if lower else np.concatenate([vals, [d]]))
+        p = np.zeros(n + 1, np.int32)
+        p[1:] = np.cumsum([len(c) for c in cols_i])
+        i, x = np.concatenate(cols_i).astype(np.int32), np.concatenate(cols_x)
+        T = cs.cs_pin(_host_cs(cs, n, n, p, i, x))
+        B = rng.uniform(-1, 1, size=(n, k))
+        pairs = ((cs.cs_lsolve, CO.lsolve), (cs.cs_ltsolve, CO.ltsolve)) if lower else \
+                ((cs.cs_usolve, CO.usolve), (cs.cs_utsolve, CO.utsolve))
+        for fn, ofn in pairs:
+            dB = cs.dvec(B)
+            assert fn(T, dB) is True
+            X = dB.numpy()
+            for r in (0, 63, 64, 129):
+                assert X[:, r].tobytes() == ofn(n, p, i, x, B[:, r]).tobytes(), (fn.__name__, r)
