@@ -119,20 +119,49 @@ __device__ __forceinline__ void chol_column(int32_t j, const int32_t *__restrict
     }
     __builtin_amdgcn_wave_barrier();
     const int32_t qe = row_ptr[j + 1] - 1;   // the row view ends with the diagonal L(j,j)
-    for (int32_t q = row_ptr[j]; q < qe; q++) {
-        const int32_t k = row_col[q], pos = row_pos[q];
-        const double ljk = Lx[pos];
-        const int32_t kend = Lp[k + 1];
-        for (int32_t p = pos + lane; p < kend; p += 64) {
-            const int32_t r = Li[p];
-            const double v = Lx[p] * ljk;
-            if (in_lds) {
-                acc_v[find_row(acc_r, len, r)] -= v;
-            } else {
-                Lx[base + find_row(Li + base, len, r)] -= v;
-            }
+    // Updates are applied in order, but fetched eight at a time: lane u reads the descriptor of update u
+    // (position of L(j,k), end of column k, L(j,k)) -- one dependent round trip for eight updates instead of
+    // one each -- and the heads of the eight columns are requested together before any is consumed.
+    constexpr int UQ = 8;
+    for (int32_t q0 = row_ptr[j]; q0 < qe; q0 += UQ) {
+        int32_t posq = 0, kendq = 0;
+        double ljkq = 0.0;
+        if (lane < UQ && q0 + lane < qe) {
+            const int32_t kq = row_col[q0 + lane];
+            posq = row_pos[q0 + lane];
+            kendq = Lp[kq + 1];
+            ljkq = Lx[posq];
         }
-        __builtin_amdgcn_wave_barrier();
+        int32_t pos_[UQ], kend_[UQ], r_[UQ];
+        double ljk_[UQ], v_[UQ];
+#pragma unroll
+        for (int u = 0; u < UQ; u++) {
+            pos_[u] = __builtin_amdgcn_readlane(posq, u);
+            kend_[u] = __builtin_amdgcn_readlane(kendq, u);    // 0 for an absent update: nothing below
+            ljk_[u] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ljkq), u),
+                                       __builtin_amdgcn_readlane(__double2loint(ljkq), u));
+        }
+#pragma unroll
+        for (int u = 0; u < UQ; u++) {
+            const int32_t p = pos_[u] + lane;
+            const int32_t pp = p < kend_[u] ? p : pos_[u];      // a valid address either way
+            r_[u] = Li[pp];
+            v_[u] = Lx[pp];
+        }
+#pragma unroll
+        for (int u = 0; u < UQ; u++) {
+            if (pos_[u] + lane < kend_[u]) {
+                const double v = v_[u] * ljk_[u];
+                if (in_lds) acc_v[find_row(acc_r, len, r_[u])] -= v;
+                else Lx[base + find_row(Li + base, len, r_[u])] -= v;
+            }
+            for (int32_t p = pos_[u] + 64 + lane; p < kend_[u]; p += 64) {   // columns longer than one wave
+                const double v = Lx[p] * ljk_[u];
+                if (in_lds) acc_v[find_row(acc_r, len, Li[p])] -= v;
+                else Lx[base + find_row(Li + base, len, Li[p])] -= v;
+            }
+            __builtin_amdgcn_wave_barrier();   // one update after the other: they may hit the same rows
+        }
     }
     const double d = in_lds ? acc_v[0] : Lx[base];
     if (d <= 0.0 && lane == 0) atomicMin(notspd, j);  // csparse.py:612: not positive definite
