@@ -8,10 +8,17 @@ Headline (BASELINE.json metric): cs_gaxpy achieved HBM GB/s on the 5M x 5M,
 solves/s on the 5M x 5M 64-nnz/row SPD matrix ("G-spd").  One "step" is one
 cs_gaxpy pass y += A x over the whole matrix.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the path shards as
-independent matrices / right-hand-side blocks -- every rank owns its
-own matrix and its own RHS block, no collective on the data path; the timed
-region is bracketed by barriers and the slowest rank's time is used ("weak").
+N > 1, one rank per GPU: either the driver starts the ranks (`python -m
+torch.distributed.run --nproc-per-node N ... bench.py --gpus N`, WORLD_SIZE set) or
+`python bench.py --gpus N` starts them itself (N child processes, before the parent
+touches a GPU).  A world size that differs from --gpus is an error (exit 2), never a
+silent 1-GPU run.  The path shards as independent matrices / right-hand-side blocks
+(SURVEY 8e): every rank owns its own matrix and its own RHS block, no collective in
+the timed headline region, which is bracketed by barriers and timed by the slowest
+rank ("weak").  The exchange steps SURVEY 8e names are measured as their own legs
+and reported under "exchange": factor once on rank 0 + RCCL broadcast of L.p / L.i /
+L.x against factoring redundantly, the RHS blocks leaving the root, the solution
+blocks gathered to the root.
 
 Rank 0 prints one JSON line.  `value` = algorithmic bytes of all ranks' steps /
 wall time.  `roofline.achieved` = algorithmic bytes of one step / average step
@@ -81,6 +88,55 @@ def cpu_baseline(n_cpu, per_col, budget_s):
     return py, c
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` run directly: start N ranks of this same command line, one per GPU, with
+    the torch.distributed.run environment (rendezvous on 127.0.0.1), and return the worst exit code.  The
+    parent makes no HIP call.  Rank 0's stdout is the one JSON line; other ranks' stdout is dropped."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    codes = [p.wait() for p in procs]
+    return max(abs(c) for c in codes)
+
+
+def rehearse(args):
+    """--rehearse: the N-rank control flow and every exchange leg on small CPU tensors over gloo.  Proves the
+    launcher starts N ranks, that a size mismatch fails, and that the collectives pair up; measures nothing."""
+    import shard
+    os.environ.setdefault("CSX_COMM_BACKEND", "gloo")
+    comm = shard.Comm(backend="gloo")
+    import torch
+    rank, world = comm.rank, comm.world
+    n, k = 1000, 3
+    legs = {}
+    Lx = torch.arange(n, dtype=torch.float64) if rank == 0 else torch.zeros(n, dtype=torch.float64)
+    comm.barrier()
+    comm.broadcast_tensor(Lx)
+    legs["broadcast_ok"] = bool(Lx[-1].item() == n - 1)
+    mine = torch.empty(n, k, dtype=torch.float64)
+    blocks = [torch.full((n, k), float(r)) .double() for r in range(world)] if rank == 0 else None
+    comm.scatter_blocks(mine, blocks)
+    legs["scatter_ok"] = bool(comm.sum(float(mine[0, 0].item() == rank)) == world)
+    got = comm.gather_to_root(mine + 1.0)
+    if rank == 0:
+        legs["gather_ok"] = [float(g[0, 0].item()) for g in got] == [r + 1.0 for r in range(world)]
+    tmax = comm.max(float(rank))
+    if rank == 0:
+        print(json.dumps({"metric": "cs_gaxpy achieved HBM GB/s (algorithmic bytes / time), 5M x 5M CSC, 64 nnz/col",
+                          "value": None, "unit": "GB/s", "n_gpus": world, "steps": 0, "warmup": 0, "rehearsal": True,
+                          "exchange": legs, "slowest_rank": tmax}))
+    comm.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -97,14 +153,23 @@ def main():
     ap.add_argument("--skip-gspd", action="store_true")
     ap.add_argument("--skip-sharded", action="store_true", help="skip the column-sharded single SpMV (N > 1 only)")
     ap.add_argument("--force-sharded", action="store_true", help="run the column-sharded SpMV code path at N = 1 too")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="launcher and exchange plumbing only, on CPU tensors (gloo): no GPU, no kernels, value = null")
+    ap.add_argument("--exchange-nrhs", type=int, default=None,
+                    help="right-hand sides per GPU in the scatter / gather legs (default: --nrhs)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))          # parent: starts the ranks, touches no GPU
     import shard
-    if args.force_sharded or shard.env_rank()[1] > 1:
-        # torch must initialise HIP before libcsx is loaded: the process then shares torch's bundled HIP
-        # runtime.  The other order leaves two runtimes in one process and torch finds no GPU.
-        import torch
-        torch.cuda.init()
+    if shard.env_rank()[1] != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE is %d: refusing to report a run of another size\n"
+                         % (args.gpus, shard.env_rank()[1]))
+        sys.exit(2)
+    if args.rehearse:
+        return rehearse(args)
+    if args.force_sharded:
+        os.environ.setdefault("CSX_SHARE_TORCH_HIP", "1")   # libcsx and torch on one HIP runtime (_csx.load)
     comm = shard.Comm()  # RCCL ("nccl") when launched by torch.distributed.run, no-op at N=1
     rank, world, local = comm.rank, comm.world, comm.local
     import numpy as np
@@ -219,7 +284,7 @@ def main():
                                           # 2 x FETCH_SIZE 1.93e9 + WRITE_SIZE 0.04e9 (profiles/r01_pmc_bench_v2.csv)
                                           "traffic": 3.9e9 if (nb == 78125 and bs == 64) else None}}
         if not args.skip_cholsol:
-            extra = cholsol_section(args, lib, cs, hB, nb, bs, rank, world, barrier, max_over_ranks)
+            extra = cholsol_section(args, lib, cs, comm, hB, nb, bs, barrier, max_over_ranks)
             if extra:
                 out["cholsol"] = extra
         _csx.free(hB)
@@ -312,11 +377,12 @@ def sharded_spmv_section(args, lib, cs, comm, barrier, max_over_ranks):
         return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
-def cholsol_section(args, lib, cs, hB, nb, bs, rank, world, barrier, max_over_ranks):
+def cholsol_section(args, lib, cs, comm, hB, nb, bs, barrier, max_over_ranks):
     """Batched cs_cholsol on G-spd: factor once per rank, solve nrhs right-hand sides per GPU."""
     import numpy as np
     import _csx
     C = _csx.C
+    rank, world = comm.rank, comm.world
     n = nb * bs
     nnz = n * bs
     k = args.nrhs
@@ -374,10 +440,142 @@ def cholsol_section(args, lib, cs, hB, nb, bs, rank, world, barrier, max_over_ra
            "survey_bytes_unfused": cholsol_bytes(lnz, n, k),
            "factor_s": {"symbolic_etree_host_counts_device": round(t_symbolic, 3), "numeric_device_incl_pattern_of_L": round(t_numeric, 3),
                         "solve_plan": round(t_plan, 3)}}
+    if world > 1 or args.force_sharded:
+        try:
+            out["exchange"] = exchange_section(args, lib, comm, hL, plan, n, lnz, t_symbolic + t_numeric + t_plan,
+                                               barrier, max_over_ranks)
+        except Exception as e:                            # never take the headline down with it
+            out["exchange"] = {"error": "%s: %s" % (type(e).__name__, e)}
     _csx.free(plan)
     _csx.free(hR)
     _csx.free(hL)
     return out
+
+
+def exchange_section(args, lib, comm, hL, plan, n, lnz, t_factor_redundant, barrier, max_over_ranks):
+    """The exchange steps of a batched cs_cholsol sharded by right-hand-side block, each timed on
+    its own, none of them inside `value`:
+      1. factor once on rank 0 and broadcast L.p / L.i / L.x (three RCCL broadcasts), against every rank
+         factoring redundantly (what the timed solve leg does);
+      2. the right-hand-side blocks leaving the root (rank r gets columns [r k, (r+1) k));
+      3. the solution blocks gathered to the root.
+    Every leg is checked: a rank rebuilds its solve plan from the RECEIVED factor and must reproduce its own
+    solution bit for bit; received RHS blocks must equal the ones the rank would generate itself; the root
+    checks the gathered blocks against each rank's checksum."""
+    import torch
+    import _csx
+    import shard
+    C = _csx.C
+    rank, world = comm.rank, comm.world
+    dev = torch.device("cuda", comm.local)
+    torch.cuda.set_device(dev)
+    k = args.exchange_nrhs or args.nrhs
+    res = {"world": world, "backend": comm.dist.get_backend() if comm.dist is not None else "none (1 rank)"}
+
+    # ---- 1. factor once + broadcast ----
+    dp, di, dx = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    _csx.check(lib.csx_csc_ptrs(hL, dp, di, dx), "csc_ptrs")
+    if rank == 0:
+        Lp = shard.tensor_from_ptr(dp.value, n + 1, "i32", dev)
+        Li = shard.tensor_from_ptr(di.value, lnz, "i32", dev)
+        Lx = shard.tensor_from_ptr(dx.value, lnz, "f64", dev)
+    else:
+        Lp = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        Li = torch.empty(lnz, dtype=torch.int32, device=dev)
+        Lx = torch.empty(lnz, dtype=torch.float64, device=dev)
+    for t in (Lp[:1], Li[:1], Lx[:1]):                    # first collective sets up the communicator: not timed
+        comm.broadcast_tensor(t.clone())
+    _csx.sync()
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for t in (Lp, Li, Lx):
+        comm.broadcast_tensor(t)
+    torch.cuda.synchronize()
+    barrier()
+    t_bcast = max_over_ranks(time.perf_counter() - t0)
+    bytes_bcast = 4 * (n + 1) + 12 * lnz
+    hR = _csx.new_handle()
+    _csx.check(lib.csx_gen_rhs(n, k, rank * k, hR), "gen_rhs")
+    _csx.check(lib.csx_cholsol_solve(plan, hR, k), "cholsol_solve")       # this rank's own factor
+    rp, rl = C.c_void_p(), C.c_int64()
+    _csx.check(lib.csx_vec_ptr(hR, rp, rl), "vec_ptr")
+    _csx.sync()
+    X_own = shard.tensor_from_ptr(rp.value, n * k, "f64", dev)
+    same = 1.0
+    if rank != 0 or world == 1:
+        hL2, plan2, hR2 = _csx.new_handle(), _csx.new_handle(), _csx.new_handle()
+        _csx.check(lib.csx_csc_wrap(n, n, lnz, C.c_void_p(Lp.data_ptr()), C.c_void_p(Li.data_ptr()),
+                                    C.c_void_p(Lx.data_ptr()), hL2), "csc_wrap")
+        t1 = time.perf_counter()
+        _csx.check(lib.csx_cholsol_plan(hL2, None, plan2), "cholsol_plan")
+        _csx.sync()
+        t_replan = time.perf_counter() - t1
+        _csx.check(lib.csx_gen_rhs(n, k, rank * k, hR2), "gen_rhs")
+        _csx.check(lib.csx_cholsol_solve(plan2, hR2, k), "cholsol_solve")  # the factor that came over the wire
+        _csx.check(lib.csx_vec_ptr(hR2, rp, rl), "vec_ptr")
+        _csx.sync()
+        same = 1.0 if torch.equal(shard.tensor_from_ptr(rp.value, n * k, "f64", dev), X_own) else 0.0
+        for h in (plan2, hR2, hL2):
+            _csx.free(h)
+    else:
+        t_replan = 0.0
+    res["factor_once_broadcast"] = {
+        "bytes": bytes_bcast, "s_broadcast": round(t_bcast, 5),
+        "GBps_per_receiver": round(bytes_bcast / t_bcast / 1e9, 2) if t_bcast > 0 else None,
+        "s_solve_plan_on_receiver": round(max_over_ranks(t_replan), 4),
+        "s_factor_redundant_per_rank": round(max_over_ranks(t_factor_redundant), 4),
+        "receivers_reproduce_own_solution_bit_for_bit": bool(comm.sum(same) == world)}
+
+    # ---- 2. right-hand-side blocks leave the root ----
+    mine = torch.empty(n * k, dtype=torch.float64, device=dev)
+    blocks, hs = None, []
+    if rank == 0:
+        blocks = []
+        for r in range(world):
+            h = _csx.new_handle()
+            _csx.check(lib.csx_gen_rhs(n, k, r * k, h), "gen_rhs")
+            _csx.check(lib.csx_vec_ptr(h, rp, rl), "vec_ptr")
+            blocks.append(shard.tensor_from_ptr(rp.value, n * k, "f64", dev))
+            hs.append(h)
+    _csx.sync()
+    barrier()
+    t0 = time.perf_counter()
+    comm.scatter_blocks(mine, blocks)
+    torch.cuda.synchronize()
+    barrier()
+    t_scatter = max_over_ranks(time.perf_counter() - t0)
+    hB2 = _csx.new_handle()
+    _csx.check(lib.csx_gen_rhs(n, k, rank * k, hB2), "gen_rhs")
+    _csx.check(lib.csx_vec_ptr(hB2, rp, rl), "vec_ptr")
+    _csx.sync()
+    ok = 1.0 if torch.equal(shard.tensor_from_ptr(rp.value, n * k, "f64", dev), mine) else 0.0
+    for h in hs + [hB2]:
+        _csx.free(h)
+    del blocks
+    res["rhs_scatter_from_root"] = {"bytes_out_of_root": 8 * n * k * (world - 1), "s": round(t_scatter, 5),
+                                    "GBps_out_of_root": round(8 * n * k * (world - 1) / t_scatter / 1e9, 2)
+                                    if world > 1 else None,
+                                    "blocks_equal_locally_generated": bool(comm.sum(ok) == world)}
+
+    # ---- 3. solutions gathered to the root ----
+    sums = comm.all_gather_object(float(X_own.sum().item()))
+    barrier()
+    t0 = time.perf_counter()
+    got = comm.gather_to_root(X_own)
+    torch.cuda.synchronize()
+    barrier()
+    t_gather = max_over_ranks(time.perf_counter() - t0)
+    okg = True
+    if rank == 0:
+        okg = all(float(g.sum().item()) == sref for g, sref in zip(got, sums))
+    del got
+    res["solutions_gather_to_root"] = {"bytes_into_root": 8 * n * k * (world - 1), "s": round(t_gather, 5),
+                                       "GBps_into_root": round(8 * n * k * (world - 1) / t_gather / 1e9, 2)
+                                       if world > 1 else None,
+                                       "nrhs_per_gpu": k, "checksums_match": bool(comm.broadcast_object(okg))}
+    _csx.free(hR)
+    return res
 
 
 if __name__ == "__main__":

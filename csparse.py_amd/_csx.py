@@ -91,13 +91,42 @@ class NotPositiveDefinite(ArithmeticError):
     pass
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch bundles its own libamdhip64.so (same soname as /opt/rocm's).
+    A process that uses both libcsx and torch (the multi-GPU path: torch.distributed over RCCL) must have
+    them on ONE runtime, or device pointers of one are foreign to the other.  Loading torch's copy by path
+    BEFORE libcsx makes the dynamic loader satisfy libcsx's DT_NEEDED libamdhip64.so.7 with it, whatever
+    order `import torch` and `_csx.load()` then come in.  Nothing is initialised and torch is not imported.
+    Taken when WORLD_SIZE > 1 or CSX_SHARE_TORCH_HIP=1; a torch that is already imported has already
+    loaded its runtime, and libcsx then binds to it with no help."""
+    import sys
+    if "torch" in sys.modules:
+        return "torch (already imported)"
+    want = os.environ.get("CSX_SHARE_TORCH_HIP")
+    if want == "0" or (want is None and int(os.environ.get("WORLD_SIZE", "1")) <= 1):
+        return None
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.origin:
+        return None
+    path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if not os.path.exists(path):
+        return None
+    C.CDLL(path, mode=C.RTLD_GLOBAL)
+    return path
+
+
+HIP_RUNTIME = None
+
+
 def load():
     """dlopen libcsx.so and set prototypes (no GPU needed for this)."""
-    global _lib
+    global _lib, HIP_RUNTIME
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise ImportError("libcsx.so is not built: run `python csparse.py_amd/build.py` "
                               "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        HIP_RUNTIME = _share_torch_hip_runtime()
         lib = C.CDLL(LIB_PATH)
         for name, args in _PROTOS.items():
             fn = getattr(lib, name)

@@ -34,6 +34,23 @@ def strong_block(rank, world, total):
     return first, base + (1 if rank < rem else 0)
 
 
+class _DevArray(object):
+    """A device buffer owned by libcsx, described to torch through __cuda_array_interface__ (no copy)."""
+
+    def __init__(self, ptr, count, typestr):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def tensor_from_ptr(ptr, count, dtype, device):
+    """torch tensor VIEW of `count` elements at device pointer `ptr` (libcsx keeps ownership): how a factor
+    that lives behind csx handles is handed to RCCL.  dtype: 'f64' or 'i32'."""
+    import torch
+    t = torch.as_tensor(_DevArray(ptr, count, {"f64": "<f8", "i32": "<i4"}[dtype]), device=device)
+    assert t.data_ptr() == int(ptr), "torch copied instead of viewing the libcsx buffer"
+    return t
+
+
 class Comm(object):
     """Thin wrapper over torch.distributed; a no-op when world == 1 (no torch import)."""
 
@@ -43,7 +60,7 @@ class Comm(object):
             self.local = 0
         self.dist = None
         self.device = device
-        if self.world > 1:
+        if self.world > 1 or os.environ.get("CSX_FORCE_DIST"):   # CSX_FORCE_DIST: a real process group of one
             import torch
             import torch.distributed as dist
             if backend is None:
@@ -88,6 +105,13 @@ class Comm(object):
         self.dist.broadcast_object_list(box, src=src)
         return box[0]
 
+    def all_gather_object(self, obj):
+        if self.dist is None:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
     def gather_blocks(self, block, dst=0):
         """Gather equally shaped 2-D float64 blocks (n x k_r, same k_r on every rank) to `dst`,
         concatenated along columns in rank order.  Returns the full block on dst, None elsewhere.
@@ -119,6 +143,77 @@ class Comm(object):
         tmp = full.detach().to("cpu", copy=True)       # gloo: staged through the host
         self.dist.all_reduce(tmp, op=self.dist.ReduceOp.SUM)
         return tmp[self.rank * chunk:(self.rank + 1) * chunk].to(full.device, copy=True)
+
+    # ---- data-path exchanges of the batched cs_cholsol (first bullet) -----------------
+    # On the GPU node these are RCCL collectives on device tensors over xGMI.  gloo (CPU tests, and the
+    # one-GPU rehearsal with CSX_COMM_BACKEND=gloo) carries host tensors only, so device tensors are
+    # staged through the host there: same call sequence, same results.
+
+    def _stage(self, t):
+        return self.dist.get_backend() != "nccl" and t.device.type != "cpu"
+
+    def broadcast_tensor(self, t, src=0):
+        """In-place broadcast of one contiguous tensor from `src` (factor once, ship L.p / L.i / L.x)."""
+        if self.dist is None:
+            return t
+        if self._stage(t):
+            h = t.detach().to("cpu", copy=True)
+            self.dist.broadcast(h, src=src)
+            if self.rank != src:
+                t.copy_(h)
+            return t
+        self.dist.broadcast(t, src=src)
+        return t
+
+    def scatter_blocks(self, out, blocks, src=0):
+        """Rank r receives blocks[r] (held by `src`, same shape as `out` everywhere) into `out`: the
+        right-hand-side blocks of a batched solve leaving the root.  RCCL has no native scatter in every
+        torch build, so it is written as the point-to-point pattern scatter is: W - 1 sends from the root."""
+        if self.dist is None:
+            out.copy_(blocks[0])
+            return out
+        stage = self._stage(out)
+        if self.rank == src:
+            reqs = []
+            for r in range(self.world):
+                if r == src:
+                    out.copy_(blocks[r])
+                else:
+                    b = blocks[r].detach().to("cpu", copy=True) if stage else blocks[r]
+                    reqs.append(self.dist.isend(b, dst=r))
+            for q in reqs:
+                q.wait()
+        else:
+            if stage:
+                h = self.torch.empty(out.shape, dtype=out.dtype, device="cpu")
+                self.dist.recv(h, src=src)
+                out.copy_(h)
+            else:
+                self.dist.recv(out, src=src)
+        return out
+
+    def gather_to_root(self, block, dst=0):
+        """Every rank's equally shaped block to `dst`: list of W tensors there (rank order), None elsewhere.
+        Point-to-point like scatter_blocks (W - 1 receives at the root; the root's inbound links are the
+        bound, SURVEY 8e: ~36 GB at 8 x 5.12 GB)."""
+        if self.dist is None:
+            return [block]
+        stage = self._stage(block)
+        if self.rank == dst:
+            outs, reqs = [], []
+            for r in range(self.world):
+                if r == dst:
+                    outs.append(block)
+                else:
+                    o = self.torch.empty(block.shape, dtype=block.dtype, device="cpu" if stage else block.device)
+                    outs.append(o)
+                    reqs.append(self.dist.irecv(o, src=r))
+            for q in reqs:
+                q.wait()
+            return [o.to(block.device) if stage and o is not block else o for o in outs]
+        b = block.detach().to("cpu", copy=True) if stage else block
+        self.dist.send(b, dst=dst)
+        return None
 
     def close(self):
         if self.dist is not None:

@@ -101,3 +101,34 @@ def test_single_rank_comm_is_a_noop():
                 os.environ[k] = v
     assert shard.weak_block(3, 128) == (384, 128)
     assert [shard.strong_block(r, 8, 1024) for r in (0, 7)] == [(0, 128), (896, 128)]
+
+
+def _run_bench(extra, env=None, timeout=300):
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=e, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, text=True, timeout=timeout)
+
+
+def test_bench_gpus_2_really_starts_two_ranks():
+    """`python bench.py --gpus 2` must start two ranks itself (no outer launcher) and say n_gpus = 2;
+    --rehearse keeps it off the GPU: launcher, world check and every exchange leg on CPU tensors over gloo."""
+    import json
+    r = _run_bench(["--gpus", "2", "--rehearse"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                       # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rehearsal"] is True and d["value"] is None
+    assert d["exchange"] == {"broadcast_ok": True, "scatter_ok": True, "gather_ok": True}
+    assert d["slowest_rank"] == 1.0
+
+
+def test_bench_refuses_a_world_of_another_size():
+    """A launcher that set up 1 rank for `--gpus 2` (or 3 for 2) is an error, not a silent smaller run."""
+    r = _run_bench(["--gpus", "2", "--rehearse"], env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode == 2 and "refusing" in r.stderr
+    r = _run_bench(["--gpus", "1", "--rehearse"], env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode == 2 and "refusing" in r.stderr
