@@ -7,7 +7,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcsx.so")
+# CSX_LIB: load another build of the library (the -DCSX_ABLATION build used for the timing experiments)
+LIB_PATH = os.environ.get("CSX_LIB") or os.path.join(_HERE, "libcsx.so")
 
 OK, EINVAL, EZEROPIVOT, ENOTSPD, ERUNTIME = 0, 1, 2, 3, 4
 TRI_L, TRI_LT, TRI_U, TRI_UT = 0, 1, 2, 3
@@ -74,6 +75,7 @@ _PROTOS = {
     "csx_lu_host": [C.c_int32, _i32p, _i32p, _f64p, C.c_double, C.POINTER(_i32p), C.POINTER(_i32p),
                     C.POINTER(_f64p), C.POINTER(_i32p), C.POINTER(_i32p), C.POINTER(_f64p), _i32p],
     "csx_gen_grand": [C.c_int32, C.c_int32, C.c_uint64, C.POINTER(H)],
+    "csx_gen_grand_uniform": [C.c_int32, C.c_int32, C.c_uint64, C.POINTER(H)],
     "csx_gen_gspd": [C.c_int32, C.c_int32, C.c_uint64, C.POINTER(H)],
     "csx_gen_vec": [C.c_int64, C.c_uint64, C.c_double, C.c_double, C.POINTER(H)],
     "csx_gen_rhs": [C.c_int32, C.c_int32, C.c_int32, C.POINTER(H)],

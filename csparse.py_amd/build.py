@@ -27,11 +27,11 @@ def newest_header():
     return max(os.path.getmtime(h) for h in hs)
 
 
-def compile_one(src, force):
-    obj = os.path.join(OBJ, os.path.basename(src) + ".o")
+def compile_one(src, force, objdir=None, extra=()):
+    obj = os.path.join(objdir or OBJ, os.path.basename(src) + ".o")
     if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), newest_header()):
         return obj, False
-    cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+    cmd = [HIPCC] + FLAGS + list(extra) + ["-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stdout + r.stderr)
@@ -41,25 +41,32 @@ def compile_one(src, force):
     return obj, True
 
 
-def build(force=False, jobs=4, verbose=True):
-    os.makedirs(OBJ, exist_ok=True)
+def build(force=False, jobs=4, verbose=True, ablation=False):
+    """ablation=True builds libcsx_ablation.so with -DCSX_ABLATION: the timing variants of the kernels (some
+    compute wrong results on purpose) exist only there and are selected by environment variables only there.
+    It is never loaded unless CSX_LIB points at it (profiles/*_ablation.md say how each number was taken)."""
+    objdir = OBJ + "_ablation" if ablation else OBJ
+    lib = os.path.join(HERE, "libcsx_ablation.so") if ablation else LIB
+    extra = ("-DCSX_ABLATION",) if ablation else ()
+    os.makedirs(objdir, exist_ok=True)
     srcs = sorted(glob.glob(os.path.join(SRC, "*.hip")) + glob.glob(os.path.join(SRC, "*.cpp")))
     objs, rebuilt = [], False
     with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
-        for obj, did in ex.map(lambda s: compile_one(s, force), srcs):
+        for obj, did in ex.map(lambda s: compile_one(s, force, objdir, extra), srcs):
             objs.append(obj)
             rebuilt |= did
-    if rebuilt or not os.path.exists(LIB):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if rebuilt or not os.path.exists(lib):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
         subprocess.check_call(cmd)
         if verbose:
-            print("built", LIB)
-    return LIB
+            print("built", lib)
+    return lib
 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--jobs", type=int, default=4)
+    ap.add_argument("--ablation", action="store_true", help="build libcsx_ablation.so (-DCSX_ABLATION) instead")
     a = ap.parse_args()
-    build(a.force, a.jobs)
+    build(a.force, a.jobs, ablation=a.ablation)

@@ -34,8 +34,7 @@
 
 namespace csx {
 
-constexpr int TL_THREADS = 1024;
-constexpr int TL_WAVES = TL_THREADS / 64;
+constexpr int TL_WAVES = 4, TL_NG = 5;          // waves per workgroup, groups per wave and step of the shipped kernel (see k_gaxpy_tiled)
 constexpr int TL_GROUP = 256;                   // entries per group = 64 lanes x 4
 constexpr int TL_LDS_BYTES = 160 * 1024 - 256;  // leave a little headroom below the CU's 160 KiB
 constexpr int TL_LDS_ROWS = TL_LDS_BYTES / 8 - 2;  // y rows per tile (one slot is the padding dummy)
@@ -131,102 +130,115 @@ __device__ __forceinline__ double load_x(const double *p) {
     return *p;
 }
 
-// VARIANT bits (timing experiments only; results are wrong unless VARIANT == 0):
+// The kernel.  NW waves per workgroup (one workgroup per CU), NG groups per wave and step.
+// Measured on G-rand 5M x 5M (profiles/r02_ablation.md): FEWER waves are faster -- 16 waves 0.97 ms, 12 waves
+// 0.83 ms, 8 waves 0.86 ms -- the x lines a wave's gathers bring into the 32 KiB L1 are shared by the
+// neighbouring lanes' entries only if they survive until the whole gather instruction has been served, and
+// the more waves stream through the same L1 the fewer do.
+//
+// VARIANT (timing experiments, compiled only with -DCSX_ABLATION; the shipped library holds VARIANT 0 alone).
+// Results are wrong for variants 1, 3, 4, 5, 7:
 //   1 = skip the x gather, 2 = full kernel with plain instead of nt stream loads, 3 = stream only,
 //   4 = gather from a 2 KB footprint (L1 hits),
 //   5 = gather from a 256 KB footprint (L2 hits, L1 misses)
 //   6 = full kernel, x gathered with L1-bypassing sc1 loads (computes y)
 //   7 = real x gathers, but the entry stream re-reads the first 32 groups of the row block (L2-resident)
-template <int VARIANT>
-__global__ __launch_bounds__(TL_THREADS) void k_gaxpy_tiled(const int32_t *__restrict__ rb_gptr,
-                                                            const uint32_t *__restrict__ group_info,
-                                                            const uint32_t *__restrict__ tile_key,
-                                                            const double *__restrict__ tile_val,
-                                                            const double *__restrict__ x, double *__restrict__ y,
-                                                            int32_t m, int32_t nrb, int32_t row_block,
-                                                            int32_t slab_cols, int rb_bits) {
-    extern __shared__ __attribute__((aligned(16))) double ytile[];  // row_block doubles
-    constexpr bool GATHER = !(VARIANT & 1) || VARIANT >= 5, ATOMIC = VARIANT != 3;
-    constexpr bool STREAM_NT = VARIANT != 2;  // variant 2: full kernel with plain (L1-allocating) stream loads
-#define load_group load_group_t<STREAM_NT>
-    constexpr uint32_t CMASK = VARIANT == 5 ? 32767u : (VARIANT == 4 ? 255u : 0xffffffffu);
-    constexpr int XLOAD = VARIANT == 6 ? 1 : 0;
-    constexpr bool RING = VARIANT == 7;
+template <int VARIANT, int NW, int NG>
+struct TiledStep {
+    static constexpr bool GATHER = !(VARIANT & 1) || VARIANT >= 5, ATOMIC = VARIANT != 3;
+    static constexpr bool STREAM_NT = VARIANT != 2;
+    static constexpr uint32_t CMASK = VARIANT == 5 ? 32767u : (VARIANT == 4 ? 255u : 0xffffffffu);
+    static constexpr int XLOAD = VARIANT == 6 ? 1 : 0;
+    static constexpr bool RING = VARIANT == 7;
+
+    // issue the entry loads of the NG groups g, g + NW, ... (indices clamped to the row block's last group
+    // instead of predicated: the loop body stays branch-free)
+    static __device__ __forceinline__ void load_set(GroupRegs (&r)[NG], const uint32_t *__restrict__ key,
+                                                    const double *__restrict__ val, const uint32_t *__restrict__ info,
+                                                    int32_t g, int32_t g0, int32_t gend, int lane) {
+#pragma unroll
+        for (int j = 0; j < NG; j++) {
+            int32_t gg = g + j * NW < gend ? g + j * NW : gend - 1;
+            if (RING) gg = g0 + ((gg - g0) & 31);
+            r[j] = load_group_t<STREAM_NT>(key, val, info, gg, lane);
+        }
+    }
+
+    // gather x for the NG groups in `cur`, put the next NG groups' entry loads behind the gathers, accumulate
+    static __device__ __forceinline__ void step(GroupRegs (&cur)[NG], GroupRegs (&nxt)[NG], double *ytile,
+                                                const uint32_t *__restrict__ key, const double *__restrict__ val,
+                                                const uint32_t *__restrict__ info, const double *__restrict__ x,
+                                                int32_t &g, int32_t g0, int32_t gend, int lane, int rb_bits,
+                                                uint32_t rmask, int32_t slab_cols, double &sink) {
+        double xv[NG][4];
+#pragma unroll
+        for (int j = 0; j < NG; j++) {
+            xv[j][0] = xv[j][1] = xv[j][2] = xv[j][3] = 1.0;
+            if (GATHER && (j == 0 || g + j * NW < gend)) {
+                const double *xs = x + (int64_t)(cur[j].info >> 9) * slab_cols;
+                xv[j][0] = load_x<XLOAD>(xs + ((cur[j].kk.x >> rb_bits) & CMASK));
+                xv[j][1] = load_x<XLOAD>(xs + ((cur[j].kk.y >> rb_bits) & CMASK));
+                xv[j][2] = load_x<XLOAD>(xs + ((cur[j].kk.z >> rb_bits) & CMASK));
+                xv[j][3] = load_x<XLOAD>(xs + ((cur[j].kk.w >> rb_bits) & CMASK));
+            }
+        }
+        load_set(nxt, key, val, info, g + NG * NW, g0, gend, lane);
+#pragma unroll
+        for (int j = 0; j < NG; j++) {
+            if (j == 0 || g + j * NW < gend) {
+                if (ATOMIC) {
+                    unsafeAtomicAdd(&ytile[cur[j].kk.x & rmask], cur[j].v0.x * xv[j][0]);
+                    unsafeAtomicAdd(&ytile[cur[j].kk.y & rmask], cur[j].v0.y * xv[j][1]);
+                    unsafeAtomicAdd(&ytile[cur[j].kk.z & rmask], cur[j].v1.x * xv[j][2]);
+                    unsafeAtomicAdd(&ytile[cur[j].kk.w & rmask], cur[j].v1.y * xv[j][3]);
+                } else {
+                    sink += cur[j].v0.x * xv[j][0] + cur[j].v0.y * xv[j][1] + cur[j].v1.x * xv[j][2] +
+                            cur[j].v1.y * xv[j][3] +
+                            (double)((cur[j].kk.x ^ cur[j].kk.y ^ cur[j].kk.z ^ cur[j].kk.w) & 1u);
+                }
+            }
+        }
+        g += NG * NW;
+    }
+};
+
+template <int VARIANT, int NW, int NG>
+__global__ __launch_bounds__(64 * NW) void k_gaxpy_tiled(const int32_t *__restrict__ rb_gptr,
+                                                         const uint32_t *__restrict__ group_info,
+                                                         const uint32_t *__restrict__ tile_key,
+                                                         const double *__restrict__ tile_val,
+                                                         const double *__restrict__ x, double *__restrict__ y,
+                                                         int32_t m, int32_t nrb, int32_t row_block,
+                                                         int32_t slab_cols, int rb_bits) {
+    extern __shared__ __attribute__((aligned(16))) double ytile[];  // row_block doubles + the padding dummy row
+    typedef TiledStep<VARIANT, NW, NG> S;
     const uint32_t rmask = (1u << rb_bits) - 1u;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double sink = 0.0;
     for (int32_t rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
         const int64_t row0 = (int64_t)rb * row_block;
         const int32_t rows = (int32_t)((row0 + row_block <= m) ? row_block : (m - row0));
-        for (int k = threadIdx.x; k < rows; k += TL_THREADS) ytile[k] = y[row0 + k];
+        for (int k = threadIdx.x; k < rows; k += 64 * NW) ytile[k] = y[row0 + k];
         __syncthreads();
         const int32_t gend = rb_gptr[rb + 1];
         const int32_t g0 = rb_gptr[rb];
-        // Each wave walks its groups two at a time (g and g + TL_WAVES) with two register sets
-        // used alternately (no copies): while set A is gathered and accumulated, set B's entries
-        // are in flight.  Prefetch indices are clamped to the last group instead of predicated,
-        // and padding entries point at a dummy LDS row, so the loop body is branch-free.
-#define CSX_GIDX(gg) (RING ? g0 + (((gg) - g0) & 31) : (gg))
-#define CSX_LOADPAIR(ra, rb2, gg)                                                                          \
-    {                                                                                                      \
-        const int32_t ga_ = (gg) < gend ? (gg) : gend - 1;                                                 \
-        const int32_t gb_ = (gg) + TL_WAVES < gend ? (gg) + TL_WAVES : gend - 1;                           \
-        ra = load_group(tile_key, tile_val, group_info, CSX_GIDX(ga_), lane);                              \
-        rb2 = load_group(tile_key, tile_val, group_info, CSX_GIDX(gb_), lane);                             \
-    }
-#define CSX_GATHER(c, xa, xb, xc, xd)                                    \
-    {                                                                    \
-        const double *xs_ = x + (int64_t)(c.info >> 9) * slab_cols;      \
-        if (GATHER) {                                                    \
-            xa = load_x<XLOAD>(xs_ + ((c.kk.x >> rb_bits) & CMASK));     \
-            xb = load_x<XLOAD>(xs_ + ((c.kk.y >> rb_bits) & CMASK));     \
-            xc = load_x<XLOAD>(xs_ + ((c.kk.z >> rb_bits) & CMASK));     \
-            xd = load_x<XLOAD>(xs_ + ((c.kk.w >> rb_bits) & CMASK));     \
-        }                                                                \
-    }
-#define CSX_ACCUM(c, xa, xb, xc, xd)                                                        \
-    {                                                                                       \
-        if (ATOMIC) {                                                                       \
-            unsafeAtomicAdd(&ytile[c.kk.x & rmask], c.v0.x * xa);                           \
-            unsafeAtomicAdd(&ytile[c.kk.y & rmask], c.v0.y * xb);                           \
-            unsafeAtomicAdd(&ytile[c.kk.z & rmask], c.v1.x * xc);                           \
-            unsafeAtomicAdd(&ytile[c.kk.w & rmask], c.v1.y * xd);                           \
-        } else {                                                                            \
-            sink += c.v0.x * xa + c.v0.y * xb + c.v1.x * xc + c.v1.y * xd +                 \
-                    (double)((c.kk.x ^ c.kk.y ^ c.kk.z ^ c.kk.w) & 1u);                     \
-        }                                                                                   \
-    }
-#define CSX_STEP(ca, cb, na, nb)                                                                          \
-    {                                                                                                     \
-        const bool two_ = g + TL_WAVES < gend;                                                            \
-        double a0 = 1.0, a1 = 1.0, a2 = 1.0, a3 = 1.0, b0 = 1.0, b1 = 1.0, b2 = 1.0, b3 = 1.0;            \
-        CSX_GATHER(ca, a0, a1, a2, a3)                                                                    \
-        if (two_) CSX_GATHER(cb, b0, b1, b2, b3)                                                          \
-        CSX_LOADPAIR(na, nb, g + 2 * TL_WAVES) /* behind the gathers */                                   \
-        CSX_ACCUM(ca, a0, a1, a2, a3)                                                                     \
-        if (two_) CSX_ACCUM(cb, b0, b1, b2, b3)                                                           \
-        g += 2 * TL_WAVES;                                                                                \
-    }
+        // Each wave walks its groups NG at a time (g, g + NW, ...) with two register sets used alternately (no
+        // copies): while set A is gathered and accumulated, set B's entries are in flight.  Padding entries
+        // point at a dummy LDS row.
         int32_t g = g0 + wave;
         if (g < gend) {
-            GroupRegs pa, pb, qa, qb;
-            CSX_LOADPAIR(pa, pb, g)
+            GroupRegs A[NG], B[NG];
+            S::load_set(A, tile_key, tile_val, group_info, g, g0, gend, lane);
             for (;;) {
-                CSX_STEP(pa, pb, qa, qb)
+                S::step(A, B, ytile, tile_key, tile_val, group_info, x, g, g0, gend, lane, rb_bits, rmask, slab_cols, sink);
                 if (g >= gend) break;
-                CSX_STEP(qa, qb, pa, pb)
+                S::step(B, A, ytile, tile_key, tile_val, group_info, x, g, g0, gend, lane, rb_bits, rmask, slab_cols, sink);
                 if (g >= gend) break;
             }
         }
-#undef CSX_STEP
-#undef CSX_GATHER
-#undef CSX_ACCUM
-#undef CSX_LOADPAIR
-#undef CSX_GIDX
-#undef load_group
         __syncthreads();
-        if (!ATOMIC && sink == 12345.678) ytile[0] = sink;  // keep the ablated arithmetic alive
-        for (int k = threadIdx.x; k < rows; k += TL_THREADS) y[row0 + k] = ytile[k];
+        if (!S::ATOMIC && sink == 12345.678) ytile[0] = sink;  // keep the ablated arithmetic alive
+        for (int k = threadIdx.x; k < rows; k += 64 * NW) y[row0 + k] = ytile[k];
         __syncthreads();
     }
 }
@@ -242,9 +254,7 @@ int gaxpy_tiled_prepare(Csc *A) {
     if (!A->x) return CSX_EINVAL;
     hipStream_t s = ctx().stream;
     // one row block per workgroup, one workgroup per CU; more rounds only if a block would not fit LDS
-    int wg_per_cu = 1;
-    if (const char *e = std::getenv("CSX_TILED_WG_PER_CU")) wg_per_cu = std::atoi(e) == 2 ? 2 : 1;
-    const int32_t nwg = (ctx().cus > 0 ? ctx().cus : 256) * wg_per_cu;
+    const int32_t nwg = ctx().cus > 0 ? ctx().cus : 256;
     const int32_t cap = TL_LDS_ROWS;
     int32_t rounds = 1;
     int32_t row_block;
@@ -259,7 +269,9 @@ int gaxpy_tiled_prepare(Csc *A) {
     int rb_bits = 1;
     while ((1 << rb_bits) <= row_block) rb_bits++;  // local row index row_block itself = dummy slot for padding
     double slab_kb = 1024.0;
+#ifdef CSX_ABLATION
     if (const char *e = std::getenv("CSX_TILED_SLAB_KB")) slab_kb = std::atof(e) >= 8.0 ? std::atof(e) : slab_kb;
+#endif
     int64_t slab_cols = (int64_t)(slab_kb * 1024 / 8);
     const int64_t max_cols_key = 1ll << (32 - rb_bits);
     if (slab_cols > max_cols_key) slab_cols = max_cols_key;
@@ -339,32 +351,61 @@ int gaxpy_tiled_run(const Csc *A, const double *x, double *y) {
     const TiledPlan *t = A->tiled;
     hipStream_t s = ctx().stream;
     const size_t lds = (((size_t)(t->row_block + 1) * sizeof(double)) + 15) & ~(size_t)15;  // + dummy row
-    int variant = 0;
-    if (const char *e = std::getenv("CSX_TILED_VARIANT")) variant = std::atoi(e) & 7;
-    if (std::getenv("CSX_TILED_XLOAD")) variant = 5 + std::atoi(std::getenv("CSX_TILED_XLOAD"));  // 1 -> sc1, 2 -> nt
-    int wg_per_cu = 1;
-    if (const char *e = std::getenv("CSX_TILED_WG_PER_CU")) wg_per_cu = std::atoi(e) == 2 ? 2 : 1;
-    const int32_t nwg = (ctx().cus > 0 ? ctx().cus : 256) * wg_per_cu;
+    const int32_t nwg = ctx().cus > 0 ? ctx().cus : 256;
     const unsigned grid = (unsigned)(t->nrb < nwg ? t->nrb : nwg);
-#define CSX_TILED_LAUNCH(V)                                                                                          \
-    case V: {                                                                                                        \
-        CSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gaxpy_tiled<V>),                               \
+#define CSX_TILED_LAUNCH(V, NW, NG)                                                                                  \
+    {                                                                                                                \
+        CSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gaxpy_tiled<V, NW, NG>),                       \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, TL_LDS_BYTES));                      \
-        hipLaunchKernelGGL(k_gaxpy_tiled<V>, dim3(grid), dim3(TL_THREADS), lds, s, t->tile_ptr,                      \
+        hipLaunchKernelGGL((k_gaxpy_tiled<V, NW, NG>), dim3(grid), dim3(64 * NW), lds, s, t->tile_ptr,               \
                            (const uint32_t *)t->tile_len, t->tile_key, t->tile_val, x, y, A->m, t->nrb, t->row_block, \
                            t->slab_cols, t->rb_bits);                                                                \
-    } break;
-    switch (variant) {
-        CSX_TILED_LAUNCH(0)
-        CSX_TILED_LAUNCH(1)
-        CSX_TILED_LAUNCH(2)
-        CSX_TILED_LAUNCH(3)
-        CSX_TILED_LAUNCH(4)
-        CSX_TILED_LAUNCH(5)
-        CSX_TILED_LAUNCH(6)
-        CSX_TILED_LAUNCH(7)
-        default: return CSX_EINVAL;
     }
+#ifdef CSX_ABLATION
+    // CSX_TILED_VARIANT = V + 100 * NW + 10000 * NG (NW, NG default to the shipped TL_WAVES, TL_NG)
+    int code = 0;
+    if (const char *e = std::getenv("CSX_TILED_VARIANT")) code = std::atoi(e);
+    const int v = code % 100, nw = (code / 100) % 100 ? (code / 100) % 100 : TL_WAVES, ng = code / 10000 ? code / 10000 : TL_NG;
+#define CSX_V(V)                                             \
+    if (v == V) {                                            \
+        if (nw == 16 && ng == 2) CSX_TILED_LAUNCH(V, 16, 2)  \
+        else if (nw == 4 && ng == 5) CSX_TILED_LAUNCH(V, 4, 5) \
+        else if (nw == 2 && ng == 10) CSX_TILED_LAUNCH(V, 2, 10) \
+        else return CSX_EINVAL;                              \
+    } else
+    if (v == 0) {
+        if (nw == 16 && ng == 1) CSX_TILED_LAUNCH(0, 16, 1)
+        else if (nw == 16 && ng == 2) CSX_TILED_LAUNCH(0, 16, 2)
+        else if (nw == 12 && ng == 2) CSX_TILED_LAUNCH(0, 12, 2)
+        else if (nw == 12 && ng == 4) CSX_TILED_LAUNCH(0, 12, 4)
+        else if (nw == 8 && ng == 2) CSX_TILED_LAUNCH(0, 8, 2)
+        else if (nw == 8 && ng == 3) CSX_TILED_LAUNCH(0, 8, 3)
+        else if (nw == 8 && ng == 4) CSX_TILED_LAUNCH(0, 8, 4)
+        else if (nw == 4 && ng == 4) CSX_TILED_LAUNCH(0, 4, 4)
+        else if (nw == 4 && ng == 5) CSX_TILED_LAUNCH(0, 4, 5)
+        else if (nw == 4 && ng == 6) CSX_TILED_LAUNCH(0, 4, 6)
+        else if (nw == 2 && ng == 6) CSX_TILED_LAUNCH(0, 2, 6)
+        else if (nw == 2 && ng == 7) CSX_TILED_LAUNCH(0, 2, 7)
+        else if (nw == 2 && ng == 8) CSX_TILED_LAUNCH(0, 2, 8)
+        else if (nw == 2 && ng == 9) CSX_TILED_LAUNCH(0, 2, 9)
+        else if (nw == 2 && ng == 10) CSX_TILED_LAUNCH(0, 2, 10)
+        else if (nw == 2 && ng == 12) CSX_TILED_LAUNCH(0, 2, 12)
+        else if (nw == 1 && ng == 10) CSX_TILED_LAUNCH(0, 1, 10)
+        else if (nw == 1 && ng == 12) CSX_TILED_LAUNCH(0, 1, 12)
+        else if (nw == 3 && ng == 5) CSX_TILED_LAUNCH(0, 3, 5)
+        else if (nw == 3 && ng == 6) CSX_TILED_LAUNCH(0, 3, 6)
+        else if (nw == 3 && ng == 7) CSX_TILED_LAUNCH(0, 3, 7)
+        else if (nw == 3 && ng == 8) CSX_TILED_LAUNCH(0, 3, 8)
+        else if (nw == 5 && ng == 4) CSX_TILED_LAUNCH(0, 5, 4)
+        else if (nw == 6 && ng == 3) CSX_TILED_LAUNCH(0, 6, 3)
+        else if (nw == 4 && ng == 7) CSX_TILED_LAUNCH(0, 4, 7)
+        else return CSX_EINVAL;
+    } else
+    CSX_V(1) CSX_V(2) CSX_V(3) CSX_V(4) CSX_V(5) CSX_V(6) CSX_V(7) return CSX_EINVAL;
+#undef CSX_V
+#else
+    CSX_TILED_LAUNCH(0, TL_WAVES, TL_NG)
+#endif
 #undef CSX_TILED_LAUNCH
     CSX_LAUNCH_CHECK();
     return CSX_OK;

@@ -12,6 +12,12 @@
 // column are distinct and ascending and uniformly spread over [0, n).
 // Values 0.5 + U(seed+1, j*per_col+k).
 //
+// G-rand, uniform draw (SURVEY 8d to the letter): column j holds `per_col` (<= 64) DISTINCT rows drawn
+// uniformly from [0, n), stored ascending.  One wavefront per column, lane t draws
+// r = H(seed, (j*per_col + t)*64 + a) % n with attempt a = 0; the lanes are sorted by (r, t) (bitonic, wave
+// shuffles); a lane whose r equals its lower neighbour's redraws with a + 1; repeat until all differ.
+// Values by position as above.  tests/synth.py:grand_uniform is the numpy twin.
+//
 // G-spd (Cholesky / batched solves): block diagonal, `nblocks` dense bs-by-bs
 // blocks  B = R R' / bs + bs I,  R[r][k] = -1 + 2 U(seed, (b*bs + r)*bs + k),
 // the sum over k taken in ascending k with separately rounded multiply and add,
@@ -45,6 +51,48 @@ __global__ __launch_bounds__(256) void k_gen_grand(int32_t n, int32_t per_col, u
     const int32_t Wk = (k == per_col - 1) ? n - (per_col - 1) * W : W;
     Ai[e] = k * W + (int32_t)(hash2(seed, (uint64_t)e) % (uint64_t)Wk);
     Ax[e] = 0.5 + unit(hash2(seed + 1, (uint64_t)e));
+}
+
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int mask) {
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, mask, 64);
+    const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), mask, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+__global__ __launch_bounds__(256) void k_gen_grand_uniform(int32_t n, int32_t per_col, uint64_t seed, int32_t *Ap,
+                                                           int32_t *Ai, double *Ax) {
+    const int lane = threadIdx.x & 63;
+    const int64_t j = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // one wave per column
+    if (j > n) return;
+    if (lane == 0) Ap[j] = (int32_t)(j * per_col);
+    if (j == n) return;
+    const uint64_t e = (uint64_t)j * per_col + lane;
+    // key = row << 12 | drawing lane << 6 | attempt; lanes beyond per_col hold the maximum and sort last
+    uint64_t key = ~0ull;
+    if (lane < per_col) key = ((hash2(seed, e * 64) % (uint64_t)n) << 12) | ((uint64_t)lane << 6);
+    for (int round = 0; round < 64; round++) {
+        for (int k = 2; k <= 64; k <<= 1)
+            for (int d = k >> 1; d > 0; d >>= 1) {
+                const uint64_t other = shfl_xor_u64(key, d);
+                const bool up = (lane & k) == 0, low = (lane & d) == 0;
+                const uint64_t mn = key < other ? key : other, mx = key < other ? other : key;
+                key = (up == low) ? mn : mx;
+            }
+        const uint32_t blo = (uint32_t)__shfl_up((int)(uint32_t)key, 1, 64);
+        const uint32_t bhi = (uint32_t)__shfl_up((int)(uint32_t)(key >> 32), 1, 64);
+        const uint64_t below = ((uint64_t)bhi << 32) | blo;  // the sorted neighbour one lane down
+        const bool dup = lane > 0 && lane < per_col && (key >> 12) == (below >> 12);
+        if (__ballot(dup) == 0ull) break;
+        if (dup) {
+            const uint64_t t = (key >> 6) & 63, a = (key & 63) + 1;
+            const uint64_t et = (uint64_t)j * per_col + t;
+            key = ((hash2(seed, et * 64 + a) % (uint64_t)n) << 12) | (t << 6) | a;
+        }
+    }
+    if (lane < per_col) {
+        Ai[e] = (int32_t)(key >> 12);
+        Ax[e] = 0.5 + unit(hash2(seed + 1, e));
+    }
 }
 
 template <int BS>
@@ -106,6 +154,20 @@ extern "C" int csx_gen_grand(int32_t n, int32_t per_col, uint64_t seed, csx_hand
     int64_t blocks = ((int64_t)nnz + 1 + 255) / 256;
     hipLaunchKernelGGL(k_gen_grand, dim3((unsigned)blocks), dim3(256), 0, ctx().stream, n, per_col, seed, A->p, A->i,
                        A->x);
+    CSX_LAUNCH_CHECK();
+    return CSX_OK;
+}
+
+extern "C" int csx_gen_grand_uniform(int32_t n, int32_t per_col, uint64_t seed, csx_handle_t *out) {
+    CSX_TRY(require_ready());
+    if (n <= 0 || per_col <= 0 || per_col > 64 || 2 * (int64_t)per_col > n || (int64_t)n * per_col > 2147483647ll || !out)
+        return CSX_EINVAL;
+    const int32_t nnz = n * per_col;
+    CSX_TRY(csx_csc_alloc(n, n, nnz, 1, out));
+    Csc *A = csc(*out);
+    int64_t blocks = ((int64_t)n + 1 + 3) / 4;  // 4 waves (columns) per workgroup; column n only writes Ap[n]
+    hipLaunchKernelGGL(k_gen_grand_uniform, dim3((unsigned)blocks), dim3(256), 0, ctx().stream, n, per_col, seed, A->p,
+                       A->i, A->x);
     CSX_LAUNCH_CHECK();
     return CSX_OK;
 }

@@ -200,6 +200,10 @@ void csx_host_free(void *p);
 /* ---- synthetic inputs of the benchmark configs, generated on
  * the device from a counter-based hash so host and device agree bit for bit ---- */
 int csx_gen_grand(int32_t n, int32_t per_col, uint64_t seed, csx_handle_t *out);
+/* G-rand exactly as SURVEY 8d words it: per_col (<= 64) distinct rows per column drawn uniformly from [0, n),
+ * ascending.  csx_gen_grand above draws one row per stratum of n/per_col rows instead (same marginal
+ * distribution, row-block loads almost exactly equal); bench.py reports both. */
+int csx_gen_grand_uniform(int32_t n, int32_t per_col, uint64_t seed, csx_handle_t *out);
 int csx_gen_gspd(int32_t nblocks, int32_t bs, uint64_t seed, csx_handle_t *out);
 int csx_gen_vec(int64_t len, uint64_t seed, double lo, double hi, csx_handle_t *out);
 int csx_gen_rhs(int32_t n, int32_t nrhs, int32_t col0, csx_handle_t *out);

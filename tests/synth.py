@@ -36,6 +36,39 @@ def grand(n, per_col, seed):
     return Ap, Ai, Ax
 
 
+def grand_uniform(n, per_col, seed):
+    """G-rand with per_col DISTINCT uniform rows per column, ascending (csx_gen_grand_uniform's twin)."""
+    assert per_col <= 64 and 2 * per_col <= n
+    nnz = n * per_col
+    e = np.arange(nnz, dtype=np.uint64)
+    t = (e % np.uint64(per_col)).reshape(n, per_col)
+    with np.errstate(over="ignore"):
+        r = (hash2(seed, e * np.uint64(64)) % np.uint64(n)).reshape(n, per_col)
+    key = (r << np.uint64(12)) | (t << np.uint64(6))
+    key.sort(axis=1)
+    rows = key >> np.uint64(12)
+    bad = np.nonzero((rows[:, 1:] == rows[:, :-1]).any(axis=1))[0]
+    for j in bad:                      # a few columns per thousand: redraw the later of two equal rows
+        k = key[j].copy()
+        for _ in range(64):
+            k.sort()
+            rr = k >> np.uint64(12)
+            dup = np.zeros(per_col, dtype=bool)
+            dup[1:] = rr[1:] == rr[:-1]
+            if not dup.any():
+                break
+            tt = (k[dup] >> np.uint64(6)) & np.uint64(63)
+            aa = (k[dup] & np.uint64(63)) + np.uint64(1)
+            with np.errstate(over="ignore"):
+                et = np.uint64(j) * np.uint64(per_col) + tt
+                k[dup] = ((hash2(seed, et * np.uint64(64) + aa) % np.uint64(n)) << np.uint64(12)) | (tt << np.uint64(6)) | aa
+        key[j] = k
+    Ai = (key >> np.uint64(12)).astype(np.int32).reshape(-1)
+    Ax = 0.5 + unit(hash2(seed + 1, e))
+    Ap = (np.arange(n + 1, dtype=np.int64) * per_col).astype(np.int32)
+    return Ap, Ai, Ax
+
+
 def gspd(nblocks, bs, seed):
     """G-spd: block-diagonal SPD, dense bs-by-bs blocks."""
     n = nblocks * bs
