@@ -40,6 +40,28 @@ for _p in (os.path.join(ROOT, "csparse.py_amd"), os.path.join(ROOT, "oracle"), o
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s copy-achievable)
 
 
+def measured_traffic(kernel_substr, **match):
+    """HBM-side bytes per launch of a kernel from the newest committed counter summary that was taken at THIS
+    size: profiles/*_traffic.json (tools/profile_bench.sh: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+    passes, 2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes).  None when no summary matches --
+    a figure measured on another kernel or size is not reported."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+        except (OSError, ValueError):
+            continue
+        meta = d.get("_meta", {})
+        if any(meta.get(k) != v for k, v in match.items()):
+            continue
+        for name, rec in d.get("kernels", {}).items():
+            if kernel_substr in name:
+                best = {"bytes": rec["hbm_bytes_per_launch"], "source": os.path.relpath(path, ROOT)}
+    return best
+
+
 def gaxpy_bytes(m, n, nnz):
     # SURVEY 8d: 12 nnz + 4 (n+1) + 8 n (x) + 16 m (y read + write)
     return 12 * nnz + 4 * (n + 1) + 8 * n + 16 * m
@@ -86,6 +108,52 @@ def cpu_baseline(n_cpu, per_col, budget_s):
     c = {"value": by / tc / 1e9, "unit": "GB/s", "cores": 1, "kind": "port",
          "sample": "same sample, plain-C port (oracle/oracle.c, gcc -O2), %.4f s/pass" % tc}
     return py, c
+
+
+def cpu_baseline_cholsol(nblocks, bs, budget_s, lnz_full):
+    """The cholsol leg on one host core: pure-Python port of cs_schol + cs_chol + (cs_lsolve, cs_ltsolve) on
+    G-spd with `nblocks` blocks, solves repeated within the time budget.  A solve costs ~2 lnz operations, so
+    the rate on the full 5M-row factor is the sample's rate x lnz(sample) / lnz(full) (reported, not measured)."""
+    import numpy as np
+    import csparse_oracle as O
+    import c_oracle as CO
+    import synth
+    n = nblocks * bs
+    Ap, Ai, Ax = synth.gspd(nblocks, bs, 20240601 + 5)
+    A = O.cs_spalloc(n, n, len(Ai), True, False)
+    A.p, A.i, A.x = Ap.tolist(), Ai.tolist(), Ax.tolist()
+    t0 = time.perf_counter()
+    S = O.cs_schol(0, A)
+    N = O.cs_chol(A, S)
+    t_factor = time.perf_counter() - t0
+    lnz = N.L.p[n]
+    B = synth.rhs(n, 8, 0)
+    t_end = time.perf_counter() + budget_s
+    solves, t_solve = 0, 0.0
+    while solves < 1 or (time.perf_counter() < t_end and solves < 8):
+        x = B[:, solves].tolist()
+        t0 = time.perf_counter()
+        O.cs_lsolve(N.L, x)
+        O.cs_ltsolve(N.L, x)
+        t_solve += time.perf_counter() - t0
+        solves += 1
+    rate = solves / t_solve
+    # plain-C port, same sample
+    parent, cp = CO.schol(n, Ap, Ai)
+    t0 = time.perf_counter()
+    Lp, Li, Lx = CO.chol(n, Ap, Ai, Ax, parent, cp)
+    tc_factor = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for r in range(8):
+        CO.ltsolve(n, Lp, Li, Lx, CO.lsolve(n, Lp, Li, Lx, B[:, r]))
+    tc = (time.perf_counter() - t0) / 8
+    return {"value": rate, "unit": "solves/s", "cores": 1, "kind": "port",
+            "sample": "cs_cholsol solve phase (cs_lsolve + cs_ltsolve), pure-Python port, G-spd %d blocks of %d (n=%d, "
+                      "lnz=%d), %d solves, %.3f s each; cs_schol + cs_chol %.2f s" % (nblocks, bs, n, lnz, solves,
+                                                                                    t_solve / solves, t_factor),
+            "solves_per_s_scaled_to_full_lnz": rate * lnz / lnz_full,
+            "plain_c_port": {"solves_per_s": 1.0 / tc, "solves_per_s_scaled_to_full_lnz": lnz / lnz_full / tc,
+                             "chol_s": tc_factor}}
 
 
 def launch_ranks(n):
@@ -148,6 +216,7 @@ def main():
     ap.add_argument("--mode", default="auto", choices=["auto", "wave", "tiled", "atomic"])
     ap.add_argument("--cpu-n", type=int, default=100000)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-chol-blocks", type=int, default=2000, help="G-spd blocks in the CPU baseline of the cholsol leg")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-cholsol", action="store_true")
     ap.add_argument("--skip-gspd", action="store_true")
@@ -224,6 +293,8 @@ def main():
     by = gaxpy_bytes(n, n, nnz)
     value = by * args.steps * world / wall / 1e9
     achieved = by / (step_ms_events * 1e-3) / 1e9
+    tr = measured_traffic({"tiled": "k_gaxpy_tiled<0,", "wave": "k_gaxpy_rows", "atomic": "k_gaxpy_atomic"}[chosen],
+                          n=n, nnz=nnz, kernel="gaxpy_" + chosen)
 
     # sanity: y accumulated (warmup+steps) passes of A x from zero; check one entry-independent property
     ysum = float(np.sum(cs.dvec(n, 1, _handle=hy).numpy()[:1000]))
@@ -241,12 +312,9 @@ def main():
                    "parallelism": "independent matrices, 1 per GPU, no data-path collective"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
-                     # Bytes per launch crossing the L2 -> fabric boundary, from rocprofv3 --pmc FETCH_SIZE and
-                     # WRITE_SIZE (separate passes; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
-                     # gfx950): 2 x 3.15e9 + 0.04e9 (profiles/r01_pmc_bench_v3.csv; 6.2-7.0e9 across runs).  The excess over the
-                     # algorithmic bytes is x-slab gathers missing an XCD's L2 (served by the Infinity Cache).
-                     # Only valid for the kernel and size it was measured on.
-                     "traffic": 6.5e9 if (chosen == "tiled" and n == 5000000 and per_col == 64) else None,
+                     # bytes per launch crossing the L2 -> fabric boundary, read from the committed counter summary
+                     # of this kernel at this size (measured_traffic); null if there is none
+                     "traffic": tr["bytes"] if tr else None, "traffic_source": tr["source"] if tr else None,
                      "step_ms_hip_events": round(step_ms_events, 4)},
         "gaxpy_trials_ms": {k: round(v["ms"], 4) for k, v in trial.items()},
         "gaxpy_prepare_s": {k: round(v["prepare_s"], 3) for k, v in trial.items()},
@@ -281,8 +349,7 @@ def main():
                              "kernel": "gaxpy_wave (k_gaxpy_rows4: 16-byte loads on the row-major copy)",
                              "roofline": {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                           "frac": round(gbs / HBM_PEAK_GBS, 4),
-                                          # 2 x FETCH_SIZE 1.93e9 + WRITE_SIZE 0.04e9 (profiles/r01_pmc_bench_v2.csv)
-                                          "traffic": 3.9e9 if (nb == 78125 and bs == 64) else None}}
+                                          "traffic": (measured_traffic("k_gaxpy_rows4", n=n, nnz=nnz) or {}).get("bytes")}}
         if not args.skip_cholsol:
             extra = cholsol_section(args, lib, cs, comm, hB, nb, bs, barrier, max_over_ranks)
             if extra:
@@ -432,14 +499,14 @@ def cholsol_section(args, lib, cs, comm, hB, nb, bs, barrier, max_over_ranks):
            "algorithmic_bytes_fused": fused_bytes,
            "achieved_GBps_per_gpu": round(fused_bytes / (ms * 1e-3) / 1e9, 2),
            "frac_of_peak": round(fused_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-           # PMC (profiles/r01_pmc_bench_v3.csv, k_cholsol_mfma<4>): WRITE_SIZE 5.12e9 (X, exactly once),
-           # 2 x FETCH_SIZE 4.32e9 = 8.6e9 (B once + block fragments, mostly shared by the two 64-RHS waves)
            "roofline": {"bound": "hbm", "achieved": round(fused_bytes / (ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(fused_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                        "traffic": 13.8e9 if (fused.value == 3 and n == 5000000 and k == 128) else None},
+                        "traffic": (measured_traffic("k_cholsol_", n=n, nrhs_per_gpu=k) or {}).get("bytes")},
            "survey_bytes_unfused": cholsol_bytes(lnz, n, k),
            "factor_s": {"symbolic_etree_host_counts_device": round(t_symbolic, 3), "numeric_device_incl_pattern_of_L": round(t_numeric, 3),
                         "solve_plan": round(t_plan, 3)}}
+    if rank == 0 and world == 1 and not args.skip_cpu:
+        out["cpu_baseline"] = cpu_baseline_cholsol(args.cpu_chol_blocks, bs, args.cpu_seconds, lnz)
     if world > 1 or args.force_sharded:
         try:
             out["exchange"] = exchange_section(args, lib, comm, hL, plan, n, lnz, t_symbolic + t_numeric + t_plan,
