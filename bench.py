@@ -72,13 +72,13 @@ def cholsol_bytes(lnz, n, k):
     return 2 * 12 * lnz + 4 * 8 * n * k
 
 
-def cpu_baseline(n_cpu, per_col, budget_s):
-    """Pure-Python port of cs_gaxpy (1 core) on G-rand at n_cpu; also the plain-C port."""
+def cpu_baseline(n_cpu, per_col, budget_s, gen="uniform"):
+    """Pure-Python port of cs_gaxpy (1 core) on G-rand (same row draw as the headline) at n_cpu; also the plain-C port."""
     import numpy as np
     import csparse_oracle as O
     import c_oracle as CO
     import synth
-    Ap, Ai, Ax = synth.grand(n_cpu, per_col, 20240601)
+    Ap, Ai, Ax = (synth.grand_uniform if gen == "uniform" else synth.grand)(n_cpu, per_col, 20240601)
     x = synth.vec(n_cpu, 1, 0.5, 1.5)
     A = O.cs_spalloc(n_cpu, n_cpu, len(Ai), True, False)
     A.p, A.i, A.x = Ap.tolist(), Ai.tolist(), Ax.tolist()
@@ -222,6 +222,9 @@ def main():
     ap.add_argument("--skip-gspd", action="store_true")
     ap.add_argument("--skip-sharded", action="store_true", help="skip the column-sharded single SpMV (N > 1 only)")
     ap.add_argument("--force-sharded", action="store_true", help="run the column-sharded SpMV code path at N = 1 too")
+    ap.add_argument("--gen", default="uniform", choices=["uniform", "stratified"],
+                    help="G-rand row draw of the headline matrix: SURVEY 8d's uniform distinct rows (default) or one "
+                         "row per stratum of n/per_col rows (round 1's generator); the other one is timed beside it")
     ap.add_argument("--rehearse", action="store_true",
                     help="launcher and exchange plumbing only, on CPU tensors (gloo): no GPU, no kernels, value = null")
     ap.add_argument("--exchange-nrhs", type=int, default=None,
@@ -255,8 +258,11 @@ def main():
     n, per_col = args.n, args.per_col
     nnz = n * per_col
     # ---- headline: cs_gaxpy on G-rand; every rank owns an independent matrix ----
+    gens = {"uniform": lib.csx_gen_grand_uniform, "stratified": lib.csx_gen_grand}
+    gen_words = {"uniform": "%d distinct rows per column drawn uniformly from [0, n), ascending (SURVEY 8d)" % per_col,
+                 "stratified": "%d rows per column, one uniformly random row per stratum of n/%d rows" % (per_col, per_col)}
     hA = _csx.new_handle()
-    _csx.check(lib.csx_gen_grand(n, per_col, 20240601 + 1 + rank, hA), "gen_grand")
+    _csx.check(gens[args.gen](n, per_col, 20240601 + 1 + rank, hA), "gen_grand")
     hx, hy = _csx.new_handle(), _csx.new_handle()
     _csx.check(lib.csx_gen_vec(n, 7 + rank, 0.5, 1.5, hx), "gen_vec")
     _csx.check(lib.csx_vec_alloc(n, hy), "vec_alloc")
@@ -297,7 +303,9 @@ def main():
                           n=n, nnz=nnz, kernel="gaxpy_" + chosen)
 
     # sanity: y accumulated (warmup+steps) passes of A x from zero; check one entry-independent property
-    ysum = float(np.sum(cs.dvec(n, 1, _handle=hy).numpy()[:1000]))
+    yhead = np.empty(1000)
+    _csx.check(lib.csx_vec_download(hy, _csx.pd(yhead), 1000), "vec_download")
+    ysum = float(np.sum(yhead))
     assert os.environ.get("CSX_TILED_VARIANT") or (np.isfinite(ysum) and ysum > 0)
 
     out = {
@@ -305,9 +313,8 @@ def main():
         "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(wall / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "cs_gaxpy y += A x on G-rand: %d x %d CSC, %d nnz per column at uniformly spread "
-                               "rows (one per stratum), int32 indices, fp64 values; one independent matrix per GPU"
-                               % (n, n, per_col),
+        "config": {"workload": "cs_gaxpy y += A x on G-rand: %d x %d CSC, %s, int32 indices, fp64 values; one "
+                               "independent matrix per GPU" % (n, n, gen_words[args.gen]), "row_draw": args.gen,
                    "n": n, "nnz": nnz, "kernel": "gaxpy_" + chosen, "algorithmic_bytes_per_step": by,
                    "parallelism": "independent matrices, 1 per GPU, no data-path collective"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -320,6 +327,22 @@ def main():
         "gaxpy_prepare_s": {k: round(v["prepare_s"], 3) for k, v in trial.items()},
     }
     _csx.free(hA)
+    # the same kernel on the other row draw (not part of `value`)
+    other = "stratified" if args.gen == "uniform" else "uniform"
+    hA2 = _csx.new_handle()
+    _csx.check(gens[other](n, per_col, 20240601 + 1 + rank, hA2), "gen_grand")
+    _csx.check(lib.csx_gaxpy_prepare(hA2, mode), "prepare")
+    for _ in range(max(1, args.warmup)):
+        _csx.check(lib.csx_gaxpy(hA2, hx, hy, mode), "gaxpy")
+    barrier()
+    with _csx.Timer() as tm:
+        for _ in range(args.steps):
+            _csx.check(lib.csx_gaxpy(hA2, hx, hy, mode), "gaxpy")
+    ms2 = max_over_ranks(tm.ms / args.steps)
+    out["gaxpy_grand_other_row_draw"] = {"row_draw": other, "workload": gen_words[other], "ms_per_step": round(ms2, 4),
+                                         "achieved_GBps_per_gpu": round(by / (ms2 * 1e-3) / 1e9, 2),
+                                         "frac_of_peak": round(by / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    _csx.free(hA2)
     _csx.free(hx)
     _csx.free(hy)
 
@@ -362,7 +385,7 @@ def main():
         out["gaxpy_one_matrix_column_sharded"] = sharded_spmv_section(args, lib, cs, comm, barrier, max_over_ranks)
 
     if rank == 0 and world == 1 and not args.skip_cpu:
-        py, c = cpu_baseline(args.cpu_n, per_col, args.cpu_seconds)
+        py, c = cpu_baseline(args.cpu_n, per_col, args.cpu_seconds, args.gen)
         out["cpu_baseline"] = py
         out["cpu_baseline_c"] = c
     if rank == 0:
@@ -471,6 +494,20 @@ def cholsol_section(args, lib, cs, comm, hB, nb, bs, barrier, max_over_ranks):
     _csx.check(lib.csx_cholsol_plan(hL, None, plan), "cholsol_plan")
     _csx.sync()
     t_plan = time.perf_counter() - t0
+    # exact (default) order first: bit-identical to cs_lsolve + cs_ltsolve, substitution kernels
+    hR0 = _csx.new_handle()
+    _csx.check(lib.csx_gen_rhs(n, k, rank * k, hR0), "gen_rhs")
+    _csx.check(lib.csx_cholsol_solve(plan, hR0, k), "cholsol_solve")
+    with _csx.Timer() as tm0:
+        for _ in range(5):
+            _csx.check(lib.csx_cholsol_solve(plan, hR0, k), "cholsol_solve")
+    ms_exact = max_over_ranks(tm0.ms / 5)
+    _csx.free(hR0)
+    # the timed leg: rounding-equal order (1e-10 budget of BASELINE.json), dense blocks on the matrix cores
+    t0 = time.perf_counter()
+    _csx.check(lib.csx_cholsol_set_order(plan, 0), "cholsol_set_order")
+    _csx.sync()
+    t_plan_mfma = time.perf_counter() - t0
     fused, trees, mx = C.c_int32(), C.c_int32(), C.c_int32()
     _csx.check(lib.csx_cholsol_info(plan, fused, trees, mx), "cholsol_info")
     # this rank's block of right-hand sides: columns [rank*k, (rank+1)*k) of the global B
@@ -504,7 +541,9 @@ def cholsol_section(args, lib, cs, comm, hB, nb, bs, barrier, max_over_ranks):
                         "traffic": (measured_traffic("k_cholsol_", n=n, nrhs_per_gpu=k) or {}).get("bytes")},
            "survey_bytes_unfused": cholsol_bytes(lnz, n, k),
            "factor_s": {"symbolic_etree_host_counts_device": round(t_symbolic, 3), "numeric_device_incl_pattern_of_L": round(t_numeric, 3),
-                        "solve_plan": round(t_plan, 3)}}
+                        "solve_plan": round(t_plan, 3), "matrix_core_fragments": round(t_plan_mfma, 3)},
+           "exact_order": {"ms_per_batch": round(ms_exact, 4), "solves_per_s_per_gpu": round(k / (ms_exact * 1e-3), 1),
+                           "note": "default order of every plan: bit-identical to cs_lsolve + cs_ltsolve"}}
     if rank == 0 and world == 1 and not args.skip_cpu:
         out["cpu_baseline"] = cpu_baseline_cholsol(args.cpu_chol_blocks, bs, args.cpu_seconds, lnz)
     if world > 1 or args.force_sharded:
@@ -576,6 +615,7 @@ def exchange_section(args, lib, comm, hL, plan, n, lnz, t_factor_redundant, barr
                                     C.c_void_p(Lx.data_ptr()), hL2), "csc_wrap")
         t1 = time.perf_counter()
         _csx.check(lib.csx_cholsol_plan(hL2, None, plan2), "cholsol_plan")
+        _csx.check(lib.csx_cholsol_set_order(plan2, 0), "cholsol_set_order")   # same order as the rank's own plan
         _csx.sync()
         t_replan = time.perf_counter() - t1
         _csx.check(lib.csx_gen_rhs(n, k, rank * k, hR2), "gen_rhs")

@@ -85,7 +85,7 @@ def config3():
     t0 = time.perf_counter()
     N = cs.cs_lu(A, cs.cs_sqr(0, A, False), 1.0)
     t_lu = time.perf_counter() - t0
-    L, U = cs.cs_pin(N.L), cs.cs_pin(N.U)
+    L, U = cs.cs_pin(N.L), cs.cs_pin(N.U)      # explicit pin: stays resident (and keeps its plans) after list reads
     b = 1.0 + np.arange(n) / n
     pb = np.empty(n)
     pb[np.asarray(N.pinv)] = b

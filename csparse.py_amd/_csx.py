@@ -35,6 +35,9 @@ _PROTOS = {
     "csx_order_nd_host": [C.c_int32, _i32p, _i32p, _i32p],
     "csx_norm1": [H, _f64p],
     "csx_cholsol_set_order": [H, C.c_int],
+    "csx_cholsol_growth": [H, _f64p],
+    "csx_csc_invalidate": [H],
+    "csx_set_option": [C.c_char_p, C.c_int],
     "csx_gaxpy_host": [C.c_int32, C.c_int32, _i32p, _i32p, _f64p, _f64p, _f64p],
     "csx_csc_col_block": [H, C.c_int32, C.c_int32, C.POINTER(H)],
     "csx_mem_trim": [],
@@ -212,6 +215,21 @@ def device_info():
     mem = C.c_int64(0)
     check(lib().csx_device_info(name, 256, C.byref(cus), C.byref(mem)), "csx_device_info")
     return name.value.decode(), cus.value, mem.value
+
+
+class option(object):
+    """with _csx.option("spgemm.one_pass", 0): ...   -- a kernel-selection override for tests (csx_set_option)"""
+
+    def __init__(self, name, value):
+        self.name, self.value = name.encode(), int(value)
+
+    def __enter__(self):
+        check(lib().csx_set_option(self.name, self.value), "csx_set_option")
+        return self
+
+    def __exit__(self, *exc):
+        check(lib().csx_set_option(self.name, 1), "csx_set_option")
+        return False
 
 
 class Timer(object):

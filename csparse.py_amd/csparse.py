@@ -83,6 +83,7 @@ class cs(object):
         self._dev = None       # _DevMatrix when a device copy exists
         self._lazy = False     # True: host lists not materialised yet
         self._pinned = False
+        self._implicit = False  # device-resident because an operation produced it there, not because of cs_pin
 
     def _materialise(self):
         if self._lazy:
@@ -97,6 +98,13 @@ class cs(object):
             self._i = i[:nnz].tolist() + [0] * (keep - nnz)
             self._x = None if x is None else x[:nnz].tolist() + [0.0] * (keep - nnz)
             self._lazy = False
+            if self._implicit:
+                # The caller now holds plain lists and may edit them in place (C.x[k] = v, the reference's
+                # idiom), which nothing here can observe: the host lists become the only copy.  cs_pin(C)
+                # keeps a result resident on purpose (and then cs_invalidate applies).
+                self._dev = None
+                self._pinned = False
+                self._implicit = False
 
     def _touch(self):
         # host data assigned: a non-pinned device copy is stale
@@ -441,10 +449,13 @@ def cs_pin(A):
     if A._dev is None:
         A._dev = _DevMatrix(_upload(A))
     A._pinned = True
+    A._implicit = False
     return A
 
 
 def cs_invalidate(A):
+    """Tell the library that A.p / A.i / A.x were edited in place after cs_pin: the device copy and every plan
+    cached on it (SpMV plans, triangular-solve plans) are dropped and rebuilt from the lists on the next use."""
     if A is not None and not A._lazy:
         A._dev = None
     return A
@@ -468,6 +479,7 @@ def _from_device(handle, nzmax_rule):
     C._dev = dev
     C._lazy = True
     C._pinned = True
+    C._implicit = True
     return C
 
 
@@ -501,7 +513,7 @@ def cs_gaxpy(A, x, y, mode=None):
     list calls, the matrix's best plan for device calls)."""
     if not CS_CSC(A) or x is None or y is None:
         return False
-    if A.x is None:
+    if not _meta(A)[1]:     # pattern only (asked of the device for a device-backed A: no download)
         raise TypeError("'NoneType' object is not subscriptable")
     dx, _ = _vec_in(x, A.n, "x")
     dy, yhost = _vec_in(y, A.m, "y")
@@ -582,7 +594,7 @@ def _replace_in_place(A, C):
     A.nzmax = C.nzmax
     if C._lazy:
         A._p, A._i, A._x = [], [], []
-        A._dev, A._lazy, A._pinned = C._dev, True, True
+        A._dev, A._lazy, A._pinned, A._implicit = C._dev, True, True, C._implicit
     else:
         A._dev, A._lazy, A._pinned = None, False, False
         A._p, A._i, A._x = C._p, C._i, C._x
@@ -712,7 +724,7 @@ def _plan(dT, kind):
 def _trisolve(T, x, kind):
     if not CS_CSC(T) or x is None:
         return False
-    if T.x is None:
+    if not _meta(T)[1]:
         raise TypeError("'NoneType' object is not subscriptable")
     if T.m != T.n:
         raise IndexError("list index out of range")
@@ -876,7 +888,8 @@ def cs_cholsol(order, A, b):
     db, bhost = _vec_in(b, n, "b")
     pinv = None if S.pinv is None else _csx.i32(S.pinv)
     plan = _csx.new_handle()
-    _csx.check(_csx.lib().csx_cholsol_plan(N.L._dev.handle, _csx.pi(pinv), plan), "csx_cholsol_plan")
+    with _Resident(N.L) as dL:
+        _csx.check(_csx.lib().csx_cholsol_plan(dL.handle, _csx.pi(pinv), plan), "csx_cholsol_plan")
     try:
         _csx.check(_csx.lib().csx_cholsol_solve(plan, db.handle, db.k), "csx_cholsol_solve")
     finally:
@@ -888,16 +901,18 @@ def cs_cholsol(order, A, b):
 def cholsol_factor(A, order=0, exact=True):
     """Factor once for many solves: returns a solver `solve(b)` where b is a list or a
     dvec n-by-k block (overwritten).  The batched form of cs_cholsol (csparse.py:622-644).
-    exact=False lets the level-scheduled solve of a big elimination tree reorder a row's subtractions
-    (out-of-block terms first): faster backward solves, results equal to the reference's to rounding
-    instead of bit for bit."""
+    exact=True (default): every solve is bit-identical to cs_lsolve + cs_ltsolve on the same L.
+    exact=False: equal to rounding (within the 1e-10 budget) and faster -- dense blocks go to the matrix cores
+    (blocked TRSM with explicit tile inverses, refused when an inverse is large), and the level-scheduled solve
+    of a big elimination tree may reorder a row's subtractions (out-of-block terms first)."""
     S = cs_schol(order, A)
     N = cs_chol(A, S) if S is not None else None
     if N is None:
         return None
     pinv = None if S.pinv is None else _csx.i32(S.pinv)
     plan = _csx.new_handle()
-    _csx.check(_csx.lib().csx_cholsol_plan(N.L._dev.handle, _csx.pi(pinv), plan), "csx_cholsol_plan")
+    with _Resident(N.L) as dL:
+        _csx.check(_csx.lib().csx_cholsol_plan(dL.handle, _csx.pi(pinv), plan), "csx_cholsol_plan")
     if not exact:
         _csx.check(_csx.lib().csx_cholsol_set_order(plan, 0), "csx_cholsol_set_order")
     n = A.n
@@ -905,6 +920,7 @@ def cholsol_factor(A, order=0, exact=True):
     class _Solver(object):
         L = N.L
         symbolic = S
+        plan_handle = plan
 
         def __init__(self):
             self._fin = weakref.finalize(self, _csx.free, plan)
@@ -912,7 +928,7 @@ def cholsol_factor(A, order=0, exact=True):
         def info(self):
             a, b, c = _csx.C.c_int32(), _csx.C.c_int32(), _csx.C.c_int32()
             _csx.check(_csx.lib().csx_cholsol_info(plan, a, b, c), "csx_cholsol_info")
-            return {"fused_local": a.value >= 1, "dense_block": c.value if a.value >= 2 else 0,
+            return {"fused_local": a.value >= 1, "dense_block": c.value if a.value >= 2 else 0,  # dense kernels in use
                     "matrix_cores": a.value == 3, "trees": b.value, "max_nodes": c.value}
 
         def solve(self, b):

@@ -477,7 +477,7 @@ static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, c
         }
         (dense ? dense_trees : other_trees).push_back(tr);
     }
-    if (getenv("CSX_CHOL_NO_DENSE")) {
+    if (!ctx().opt.chol_dense_trees) {
         other_trees = F.small;
         dense_trees.clear();
     }
@@ -576,7 +576,13 @@ struct CholPlan {
     int dense_bs = 0;  // > 0: every tree is a dense lower-triangular block of this size on contiguous rows
     double *dense_b = nullptr;  // dense only: backward program with every row reversed (sweep-position order)
     double *frag_f = nullptr, *frag_b = nullptr;  // dense, block size 16/32/64: MFMA fragments (k_mfma_frags)
-    bool relaxed = false;  // level-scheduled path: allow the chain walker to take out-of-block terms first
+    // exact (default): every right-hand side is solved in the reference's operation order -- substitution
+    // kernels, level walker in source order: bit-identical to cs_lsolve + cs_ltsolve.  !exact
+    // (csx_cholsol_set_order(plan, 0)): results equal to rounding; dense 16/32/64 blocks go to the matrix cores
+    // (explicit block inverses, built then), the chain walker may take out-of-block terms first.
+    bool relaxed = false;
+    bool mfma_tried = false;  // fragments were built, or refused by the growth guard
+    double mfma_growth = 0.0; // max|inv(L_ii)| max|L| over the forest (the guard's measure)
 };
 
 void free_cholplan(CholPlan *P) {
@@ -1118,10 +1124,11 @@ static int cholsol_plan(const Csc *L, const int32_t *pinv, CholPlan **out) {
     CSX_TRY(tri_analyse_raw(L, CSX_TRI_LT, &P->bwd));
     if (n == 0) return CSX_OK;
     // forest of small trees?  (needs a Cholesky-shaped L: diagonal first, rows ascending)
+    DevScope tmp;   // d_parent, d_flag, flen, blen: released on every exit
     int32_t *d_parent = nullptr;
     int *d_flag = nullptr;
-    CSX_TRY(dalloc(&d_parent, (size_t)n));
-    CSX_TRY(dalloc(&d_flag, 1));
+    CSX_TRY(tmp.alloc(&d_parent, (size_t)n));
+    CSX_TRY(tmp.alloc(&d_flag, 1));
     CSX_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), s));
     hipLaunchKernelGGL(k_parent_of_sorted_L, dim3((unsigned)(((int64_t)n + 3) / 4)), dim3(256), 0, s, n, L->p, L->i,
                        d_parent, d_flag);
@@ -1130,8 +1137,6 @@ static int cholsol_plan(const Csc *L, const int32_t *pinv, CholPlan **out) {
     CSX_HIP(hipMemcpyAsync(parent.data(), d_parent, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     CSX_HIP(hipMemcpyAsync(&unsorted, d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
     CSX_HIP(hipStreamSynchronize(s));
-    dfree(d_parent);
-    dfree(d_flag);
     if (unsorted) return CSX_OK;
     Forest F;
     partition_forest(n, parent.data(), F);
@@ -1150,8 +1155,8 @@ static int cholsol_plan(const Csc *L, const int32_t *pinv, CholPlan **out) {
     const double *Gx, *Gd;
     tri_gather_arrays(P->fwd, &Gp, &Gi, &Gx, &Gd);
     int32_t *flen = nullptr, *blen = nullptr;
-    CSX_TRY(dalloc(&flen, (size_t)n + 1));
-    CSX_TRY(dalloc(&blen, (size_t)n + 1));
+    CSX_TRY(tmp.alloc(&flen, (size_t)n + 1));
+    CSX_TRY(tmp.alloc(&blen, (size_t)n + 1));
     CSX_TRY(dalloc(&P->f_ptr, (size_t)n + 1));
     CSX_TRY(dalloc(&P->b_ptr, (size_t)n + 1));
     CSX_TRY(dalloc(&P->diagk, (size_t)n));
@@ -1161,8 +1166,6 @@ static int cholsol_plan(const Csc *L, const int32_t *pinv, CholPlan **out) {
     int64_t ftot = 0, btot = 0;
     int st = scan_exclusive_i32(flen, P->f_ptr, n, &ftot);
     if (st == CSX_OK) st = scan_exclusive_i32(blen, P->b_ptr, n, &btot);
-    dfree(flen);
-    dfree(blen);
     CSX_TRY(st);
     CSX_TRY(dalloc(&P->f_idx, (size_t)ftot + 8));
     CSX_TRY(dalloc(&P->f_val, (size_t)ftot + 128));
@@ -1205,41 +1208,54 @@ static int cholsol_plan(const Csc *L, const int32_t *pinv, CholPlan **out) {
             CSX_LAUNCH_CHECK();
             CSX_HIP(hipStreamSynchronize(s));
             P->dense_bs = bs;
-            if (bs >= 16 && !std::getenv("CSX_CHOLSOL_NO_MFMA")) {   // matrix-core path: block fragments + inverses
-                const int nb16 = bs / 16;
-                const size_t nfrag = (size_t)(nb16 * (nb16 - 1) / 2 + nb16) * 4;
-                unsigned long long *cond = nullptr, hcond = 0;
-                CSX_TRY(dalloc(&cond, 1));
-                CSX_HIP(hipMemsetAsync(cond, 0, sizeof(unsigned long long), s));
-                CSX_TRY(dalloc(&P->frag_f, (size_t)P->ntrees * nfrag * 64));
-                CSX_TRY(dalloc(&P->frag_b, (size_t)P->ntrees * nfrag * 64));
-                const dim3 g((unsigned)P->ntrees);
-                if (nb16 == 1)
-                    hipLaunchKernelGGL(k_mfma_frags<1>, g, dim3(64), 0, s, P->trees, P->f_ptr, P->f_val, P->diagk, P->frag_f,
-                                       P->frag_b, cond);
-                else if (nb16 == 2)
-                    hipLaunchKernelGGL(k_mfma_frags<2>, g, dim3(64), 0, s, P->trees, P->f_ptr, P->f_val, P->diagk, P->frag_f,
-                                       P->frag_b, cond);
-                else
-                    hipLaunchKernelGGL(k_mfma_frags<4>, g, dim3(64), 0, s, P->trees, P->f_ptr, P->f_val, P->diagk, P->frag_f,
-                                       P->frag_b, cond);
-                int st2 = hipGetLastError() == hipSuccess ? CSX_OK : CSX_ERUNTIME;
-                if (st2 == CSX_OK && (hipMemcpyAsync(&hcond, cond, sizeof hcond, hipMemcpyDeviceToHost, s) != hipSuccess ||
-                                      hipStreamSynchronize(s) != hipSuccess))
-                    st2 = CSX_ERUNTIME;
-                dfree(cond);
-                double growth;
-                std::memcpy(&growth, &hcond, sizeof growth);
-                if (st2 != CSX_OK || !(growth <= 1e4)) {   // badly conditioned block (or NaN): keep substitution
-                    dfree(P->frag_f);
-                    dfree(P->frag_b);
-                    P->frag_f = P->frag_b = nullptr;
-                }
-                CSX_TRY(st2);
-            }
         }
     }
     return CSX_OK;
+}
+
+// Blocked-TRSM operands for the matrix cores (rounding-equal path, built the first time a plan is switched to
+// exact = 0).  The path is refused when a block inverse is large: a product with an explicit inverse carries an
+// error of about growth x eps x block size, and 1e-10 is the budget (tests/test_gpu_cholesky.py sweeps the
+// region below the guard).
+constexpr double MFMA_GROWTH_LIMIT = 1e3;
+
+static int cholsol_build_mfma(CholPlan *P) {
+    if (P->mfma_tried || P->dense_bs < 16) return CSX_OK;
+    P->mfma_tried = true;
+    hipStream_t s = ctx().stream;
+    const int nb16 = P->dense_bs / 16;
+    const size_t nfrag = (size_t)(nb16 * (nb16 - 1) / 2 + nb16) * 4;
+    unsigned long long *cond = nullptr, hcond = 0;
+    double *ff = nullptr, *fb = nullptr;
+    int st = dalloc(&cond, 1);
+    if (st == CSX_OK) st = dalloc(&ff, (size_t)P->ntrees * nfrag * 64);
+    if (st == CSX_OK) st = dalloc(&fb, (size_t)P->ntrees * nfrag * 64);
+    if (st == CSX_OK && hipMemsetAsync(cond, 0, sizeof(unsigned long long), s) != hipSuccess) st = CSX_ERUNTIME;
+    if (st == CSX_OK) {
+        const dim3 g((unsigned)P->ntrees);
+        if (nb16 == 1)
+            hipLaunchKernelGGL(k_mfma_frags<1>, g, dim3(64), 0, s, P->trees, P->f_ptr, P->f_val, P->diagk, ff, fb, cond);
+        else if (nb16 == 2)
+            hipLaunchKernelGGL(k_mfma_frags<2>, g, dim3(64), 0, s, P->trees, P->f_ptr, P->f_val, P->diagk, ff, fb, cond);
+        else
+            hipLaunchKernelGGL(k_mfma_frags<4>, g, dim3(64), 0, s, P->trees, P->f_ptr, P->f_val, P->diagk, ff, fb, cond);
+        if (hipGetLastError() != hipSuccess ||
+            hipMemcpyAsync(&hcond, cond, sizeof hcond, hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess)
+            st = CSX_ERUNTIME;
+    }
+    dfree(cond);
+    double growth = 0.0;
+    std::memcpy(&growth, &hcond, sizeof growth);
+    P->mfma_growth = growth;
+    if (st == CSX_OK && growth <= MFMA_GROWTH_LIMIT) {   // (a NaN fails the comparison: substitution stays)
+        P->frag_f = ff;
+        P->frag_b = fb;
+    } else {
+        dfree(ff);
+        dfree(fb);
+    }
+    return st;
 }
 
 static int cholsol_solve(CholPlan *P, double *B, int32_t nrhs) {
@@ -1255,11 +1271,13 @@ static int cholsol_solve(CholPlan *P, double *B, int32_t nrhs) {
         // zero pivots were detected by the analysis; report like the reference (ZeroDivisionError)
         int st = tri_solve_raw(P->fwd, B, 0, false);
         if (st != CSX_OK) return st;
-        if (P->dense_bs && !std::getenv("CSX_CHOLSOL_NO_DENSE")) {
+        // Dense-block kernels use FMA / explicit inverses (equal to rounding): only in the rounding-equal order.
+        // The default order runs the fused per-tree kernel below: the reference's operations, bit for bit.
+        if (P->dense_bs && P->relaxed && ctx().opt.cholsol_dense_blocks) {
             const int32_t chunks = (nrhs + 63) / 64;
             const int64_t tasks = (int64_t)P->ntrees * chunks;
             const dim3 grid((unsigned)((tasks + 3) / 4));
-            if (P->frag_f && !std::getenv("CSX_CHOLSOL_NO_MFMA")) {
+            if (P->frag_f) {
                 switch (P->dense_bs) {
                     case 16:
                         hipLaunchKernelGGL(k_cholsol_mfma<1>, grid, dim3(256), 0, s, P->trees, P->ntrees, P->tree_nodes,
@@ -1365,16 +1383,25 @@ extern "C" int csx_cholsol_info(csx_handle_t h, int32_t *local, int32_t *ntrees,
     CholPlan *P = (CholPlan *)get(h, K_CHOLPLAN);
     if (!P) return CSX_EINVAL;
     // 0 level-scheduled, 1 fused in LDS, 2 dense blocks (substitution), 3 dense blocks on the matrix cores
-    if (local) *local = P->local ? (P->dense_bs ? (P->frag_f ? 3 : 2) : 1) : 0;
+    if (local) *local = P->local ? (P->dense_bs && P->relaxed ? (P->frag_f ? 3 : 2) : 1) : 0;
     if (ntrees) *ntrees = P->ntrees;
     if (max_nodes) *max_nodes = P->max_nodes;
     return CSX_OK;
 }
 
 extern "C" int csx_cholsol_set_order(csx_handle_t h, int exact) {
+    CSX_TRY(require_ready());
     CholPlan *P = (CholPlan *)get(h, K_CHOLPLAN);
     if (!P) return CSX_EINVAL;
     P->relaxed = exact == 0;
+    if (P->relaxed) CSX_TRY(cholsol_build_mfma(P));
+    return CSX_OK;
+}
+
+extern "C" int csx_cholsol_growth(csx_handle_t h, double *growth) {
+    CholPlan *P = (CholPlan *)get(h, K_CHOLPLAN);
+    if (!P || !growth) return CSX_EINVAL;
+    *growth = P->mfma_growth;
     return CSX_OK;
 }
 

@@ -4,6 +4,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <string>
 #include <unordered_map>
 
 #include "csx_internal.h"
@@ -32,22 +33,43 @@ int require_ready() {
     return CSX_OK;
 }
 
+// Handle = (generation << 32) | (slot + 1).  The table is guarded by a mutex: ctypes releases the GIL and
+// Python finalisers call csx_free from whichever thread collects garbage.  A slot's generation changes every
+// time it is reused, so a stale handle never aliases a newer object of the same kind.  (The mutex protects
+// the TABLE; the library still runs one operation at a time per context -- one stream.)
+static std::mutex g_objects_mu;
+static std::vector<size_t> g_free_slots;
+
 csx_handle_t put(Kind k, void *ptr) {
+    std::lock_guard<std::mutex> lock(g_objects_mu);
     auto &objs = g_ctx.objects;
-    for (size_t i = 0; i < objs.size(); i++)
-        if (objs[i].kind == K_FREE) {
-            objs[i] = {k, ptr};
-            return (csx_handle_t)(i + 1);
-        }
-    objs.push_back({k, ptr});
-    return (csx_handle_t)objs.size();
+    size_t i;
+    if (!g_free_slots.empty()) {
+        i = g_free_slots.back();
+        g_free_slots.pop_back();
+    } else {
+        objs.push_back(Object());
+        i = objs.size() - 1;
+    }
+    const uint32_t gen = objs[i].gen + 1 ? objs[i].gen + 1 : 1;
+    objs[i].kind = k;
+    objs[i].ptr = ptr;
+    objs[i].gen = gen;
+    return ((csx_handle_t)gen << 32) | (csx_handle_t)(i + 1);
+}
+
+static Object *slot_of(csx_handle_t h) {   // caller holds g_objects_mu
+    auto &objs = g_ctx.objects;
+    const uint64_t idx = h & 0xffffffffull;
+    if (idx == 0 || idx > objs.size()) return nullptr;
+    Object &o = objs[idx - 1];
+    return (o.kind != K_FREE && o.gen == (uint32_t)(h >> 32)) ? &o : nullptr;
 }
 
 void *get(csx_handle_t h, Kind k) {
-    auto &objs = g_ctx.objects;
-    if (h == 0 || h > objs.size()) return nullptr;
-    Object &o = objs[h - 1];
-    return o.kind == k ? o.ptr : nullptr;
+    std::lock_guard<std::mutex> lock(g_objects_mu);
+    Object *o = slot_of(h);
+    return (o && o->kind == k) ? o->ptr : nullptr;
 }
 
 // ---- device memory: a caching allocator -------------------------------------------------------------
@@ -207,7 +229,8 @@ static void free_object(Object &o) {
         case K_CHOLPLAN: free_cholplan((CholPlan *)o.ptr); break;
         default: break;
     }
-    o = {K_FREE, nullptr};
+    o.kind = K_FREE;   // the generation stays: the next put() of this slot bumps it
+    o.ptr = nullptr;
 }
 
 __global__ void k_fill_f64(double *p, int64_t n, double v) {
@@ -252,8 +275,12 @@ int csx_finalize(void) {
     Context &c = ctx();
     if (!c.ready) return CSX_OK;
     (void)hipStreamSynchronize(c.stream);
-    for (auto &o : c.objects) free_object(o);
-    c.objects.clear();
+    {
+        std::lock_guard<std::mutex> lock(g_objects_mu);
+        for (auto &o : c.objects) free_object(o);
+        c.objects.clear();
+        g_free_slots.clear();
+    }
     pool_trim();
     (void)hipEventDestroy(c.ev0);
     (void)hipEventDestroy(c.ev1);
@@ -413,10 +440,46 @@ int csx_csc_ptrs(csx_handle_t h, void **d_p, void **d_i, void **d_x) {
 }
 
 int csx_free(csx_handle_t h) {
-    auto &objs = ctx().objects;
-    if (h == 0 || h > objs.size() || objs[h - 1].kind == K_FREE) return CSX_EINVAL;
+    Object taken;
+    {
+        std::lock_guard<std::mutex> lock(g_objects_mu);
+        Object *o = slot_of(h);
+        if (!o) return CSX_EINVAL;
+        taken = *o;              // unlink under the lock, release the memory outside it
+        o->kind = K_FREE;
+        o->ptr = nullptr;
+        g_free_slots.push_back((size_t)((h & 0xffffffffull) - 1));
+    }
     if (ctx().ready) (void)hipStreamSynchronize(ctx().stream);
-    free_object(objs[h - 1]);
+    free_object(taken);
+    return CSX_OK;
+}
+
+/* Kernel-selection overrides for tests (see Options in csx_internal.h). */
+int csx_set_option(const char *name, int value) {
+    if (!name) return CSX_EINVAL;
+    Options &o = ctx().opt;
+    const std::string n(name);
+    if (n == "chol.dense_trees") o.chol_dense_trees = value != 0;
+    else if (n == "cholsol.dense_blocks") o.cholsol_dense_blocks = value != 0;
+    else if (n == "spgemm.one_pass") o.spgemm_one_pass = value != 0;
+    else if (n == "tri.chain_walker") o.tri_chain_walker = value != 0;
+    else return CSX_EINVAL;
+    return CSX_OK;
+}
+
+/* The SpMV plans cached on a matrix (the row-major copy, the LDS-tiled regrouping) hold COPIES of its values.
+ * After the arrays behind csx_csc_ptrs / csx_csc_wrap have been changed in place, drop them: the next
+ * csx_gaxpy rebuilds what it needs. */
+int csx_csc_invalidate(csx_handle_t h) {
+    CSX_TRY(require_ready());
+    Csc *A = csc(h);
+    if (!A) return CSX_EINVAL;
+    (void)hipStreamSynchronize(ctx().stream);
+    free_gather(A->rows);
+    A->rows = nullptr;
+    free_tiled(A->tiled);
+    A->tiled = nullptr;
     return CSX_OK;
 }
 

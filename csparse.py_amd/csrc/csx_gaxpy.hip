@@ -268,10 +268,10 @@ static int run_rows(const Gather *g, int64_t nnz, const double *x, double *y) {
     }
     // 8 rows per group in flight measured 7 % faster than 4 on G-spd (0.94 vs 1.01 ms); rows with
     // fewer than ~6 entries use 4-lane groups, which need U <= 4
-    static const int ru_env = std::getenv("CSX_ROWS_U") ? std::atoi(std::getenv("CSX_ROWS_U")) : 8;
+    static const int ru_env = ablation_env("CSX_ROWS_U") ? std::atoi(ablation_env("CSX_ROWS_U")) : 8;
     // 16-byte loads, 4 rows per group in flight: 0.69 ms on G-spd (5.7 TB/s); 8 rows: 0.74 ms; the 4/8-byte
     // kernel: 1.02 ms.  CSX_ROWS_WIDE_U = 0 (off) | 4 | 8 for ablation.
-    static const int wide_env = std::getenv("CSX_ROWS_WIDE_U") ? std::atoi(std::getenv("CSX_ROWS_WIDE_U")) : 4;
+    static const int wide_env = ablation_env("CSX_ROWS_WIDE_U") ? std::atoi(ablation_env("CSX_ROWS_WIDE_U")) : 4;
 #define CSX_ROWS4(G, RU)                                                                                  \
     {                                                                                                     \
         int64_t blocks = (((int64_t)g->rows + RU - 1) / RU * G + 255) / 256;                              \

@@ -1,5 +1,6 @@
 // Internal declarations shared by the libcsx translation units (gfx950 only).
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -10,6 +11,18 @@
 #include "../../include/csx.h"
 
 namespace csx {
+
+// Experiment switches exist only in the -DCSX_ABLATION build (libcsx_ablation.so, build.py --ablation): in the
+// shipped library no environment variable can change which kernel runs or what it computes.
+inline const char *ablation_env(const char *name) {
+#ifdef CSX_ABLATION
+    return std::getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 
 void set_error(const char *fmt, ...);
 
@@ -81,16 +94,27 @@ struct CholPlan;  // csx_chol.hip
 struct Object {
     Kind kind = K_FREE;
     void *ptr = nullptr;
+    uint32_t gen = 0;   // bumped on every reuse of the slot (upper half of the handle)
+};
+
+// Kernel-selection overrides for TESTS of the kernels a plan would not pick by itself (csx_set_option).  Every
+// setting computes correct results; none is read from the environment.
+struct Options {
+    bool chol_dense_trees = true;     // cs_chol: LDS dense-block kernel for trees that are dense blocks
+    bool cholsol_dense_blocks = true; // cholsol: dense-block kernels (false: the fused per-tree kernel)
+    bool spgemm_one_pass = true;      // cs_multiply: one-walk LDS hash kernel (false: the two-pass kernel)
+    bool tri_chain_walker = true;     // tri-solve: blocked chain walker for runs of narrow levels
 };
 
 struct Context {
+    Options opt;
     bool ready = false;
     int device = -1;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int cus = 0;
-    std::vector<Object> objects;  // handle = index + 1
+    std::vector<Object> objects;  // handle = generation << 32 | index + 1 (csx_core.hip: put / get)
 };
 
 Context &ctx();
@@ -114,6 +138,20 @@ void free_tiled(TiledPlan *t);
 void free_csc(Csc *A);
 void free_triplan(TriPlan *t);
 void free_cholplan(CholPlan *t);
+
+// Device temporaries of a host function with several exits: freed when the guard leaves scope.
+struct DevScope {
+    std::vector<void *> held;
+    ~DevScope() {
+        for (void *p : held) dfree(p);
+    }
+    template <class T>
+    int alloc(T **p, size_t count) {
+        const int st = dalloc(p, count);
+        if (st == CSX_OK) held.push_back((void *)*p);
+        return st;
+    }
+};
 
 // ---- device primitives (csx_scan.hip, csx_sort.hip) ----
 // out[k] = sum(in[0..k-1]) for k in [0, n]; out has n+1 slots; in may alias out

@@ -288,7 +288,7 @@ template <bool HAS_A, bool HAS_V>
 static int launch_scatter(bool write_key, dim3 grid, hipStream_t s, const uint32_t *key, const uint32_t *a,
                           const double *v, int64_t count, int shift, uint32_t nblocks, const int32_t *goff,
                           uint32_t *okey, uint32_t *oa, double *ov) {
-    const int flat = getenv("CSX_SORT_FLAT") ? 1 : 0;
+    const int flat = ablation_env("CSX_SORT_FLAT") ? 1 : 0;
     if (write_key)
         hipLaunchKernelGGL((k_rs_scatter<HAS_A, HAS_V, true>), grid, dim3(RS_THREADS), 0, s, key, a, v, count, shift,
                            nblocks, goff, okey, oa, ov, flat);

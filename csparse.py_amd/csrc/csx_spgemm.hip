@@ -650,7 +650,7 @@ int multiply_device(const Csc *A, const Csc *B, Csc *C) {
     // one-pass path for the hash bins when its product-order buffer (12 B per product) is affordable
     const int32_t hash_lo = bin_ptr[SG_BIN_HASH0], nhash = bin_ptr[SG_BIN_HASH0 + SG_HASH_BINS] - hash_lo;
     bool onepass = false;
-    if (st == CSX_OK && nhash > 0 && big[1] < 0x7FFFFFF0ull && !getenv("CSX_SPGEMM_TWO_PASS")) {
+    if (st == CSX_OK && nhash > 0 && big[1] < 0x7FFFFFF0ull && ctx().opt.spgemm_one_pass) {
         size_t free_b = 0, total_b = 0;
         const size_t need = (size_t)big[1] * (values ? 12 : 4);
         size_t idle_b = 0;

@@ -633,7 +633,7 @@ int tri_solve_raw(TriPlan *P, double *X, int32_t nrhs, bool relaxed) {
     // the exact chain walker is already the fast one when in-block sources come last: relax only the others
     relaxed = relaxed && !P->chain_ok;
     make_segments(P, nrhs);
-    static const bool no_chain = std::getenv("CSX_TRI_NO_CHAIN") != nullptr;
+    const bool no_chain = !ctx().opt.tri_chain_walker;
     for (const Segment &g : P->segs) {
         if (g.one_wg && !no_chain && (P->chain_ok || relaxed)) {
             hipLaunchKernelGGL(k_tri_chain, dim3(1), dim3(64 * CHB), 0, s, P->order, P->level_ptr_h[(size_t)g.l0],
@@ -697,7 +697,7 @@ extern "C" int csx_tri_solve(csx_handle_t h, csx_handle_t hX, int32_t nrhs) {
     TriPlan *P = (TriPlan *)get(h, K_TRIPLAN);
     Vec *X = vec(hX);
     if (!P || !X || nrhs < 0 || X->len < (int64_t)P->n * nrhs) return CSX_EINVAL;
-    static const bool relaxed_env = std::getenv("CSX_TRI_RELAXED") != nullptr;   // experiments only
+    static const bool relaxed_env = ablation_env("CSX_TRI_RELAXED") != nullptr;   // experiments only
     return tri_solve_raw(P, (double *)X->d, nrhs, relaxed_env);
 }
 

@@ -70,6 +70,11 @@ int csx_device_info(char *name, int name_cap, int *compute_units, int64_t *hbm_b
  * must not be freed while work on another stream still uses it (csx_free waits for the context's stream only). */
 int csx_mem_trim(void);
 int csx_mem_info(int64_t *cached_bytes, int64_t *live_bytes, int64_t *device_free_bytes);
+/* Kernel-selection overrides, for tests that must reach a kernel the planner would not pick for a given input.
+ * Every setting computes correct results; nothing here (or anywhere in the library) is read from the
+ * environment.  Names: "chol.dense_trees", "cholsol.dense_blocks", "spgemm.one_pass", "tri.chain_walker"
+ * (all default 1).  Unknown name: CSX_EINVAL. */
+int csx_set_option(const char *name, int value);
 int csx_timer_start(void);                /* hipEvent on the context's stream */
 int csx_timer_stop(double *ms);           /* second hipEvent, synchronises, elapsed ms */
 
@@ -82,7 +87,13 @@ int csx_csc_wrap(int32_t m, int32_t n, int32_t nnz, void *d_p, void *d_i, void *
 int csx_csc_info(csx_handle_t A, int32_t *m, int32_t *n, int32_t *nnz, int *has_values);
 int csx_csc_download(csx_handle_t A, int32_t *p, int32_t *i, double *x /* or NULL */);
 int csx_csc_ptrs(csx_handle_t A, void **d_p, void **d_i, void **d_x);
-int csx_free(csx_handle_t h);             /* any handle kind */
+/* csx_gaxpy caches plans on the matrix (a row-major copy, the LDS-tiled regrouping) that hold COPIES of its
+ * values and structure.  Arrays handed out by csx_csc_ptrs, or wrapped by csx_csc_wrap, must not be changed
+ * in place without telling the library: call csx_csc_invalidate afterwards (drops the cached plans; the next
+ * csx_gaxpy rebuilds them).  Plans that are handles of their own (csx_tri_analyse, csx_cholsol_plan) also copy
+ * the values they need: rebuild them after a change. */
+int csx_csc_invalidate(csx_handle_t A);
+int csx_free(csx_handle_t h);             /* any handle kind; handles carry a generation, a stale one is CSX_EINVAL */
 
 /* ---- dense vectors / row-major blocks (float64) and index vectors (int32) ---- */
 int csx_vec_alloc(int64_t len, csx_handle_t *out);          /* zero-filled */
@@ -153,16 +164,22 @@ int csx_chol(csx_handle_t A, const int32_t *parent, const int32_t *cp, const int
 /* The solve phase of cs_cholsol, csparse.py:640-643, for nrhs right-hand sides:
  * B (n-by-nrhs, row-major) is overwritten with the solutions. */
 int csx_cholsol_plan(csx_handle_t L, const int32_t *pinv /* host, or NULL */, csx_handle_t *plan);
-/* *path: 0 = level-scheduled generic, 1 = fused per-tree kernel (X tile in LDS), 2 = dense-block
- * substitution kernel, 3 = dense blocks as a blocked TRSM on the matrix cores (fp64 MFMA; blocks of 16/32/64
- * whose block inverses are benign) */
+/* *path, for the plan's current order (csx_cholsol_set_order): 0 = level-scheduled generic, 1 = fused per-tree
+ * kernel (X tile in LDS; the only forest path of the default, exact order), 2 = dense-block FMA substitution,
+ * 3 = dense blocks as a blocked TRSM on the matrix cores (fp64 MFMA; blocks of 16/32/64 whose block inverses
+ * are benign); 2 and 3 only in the rounding-equal order */
 int csx_cholsol_info(csx_handle_t plan, int32_t *path, int32_t *ntrees, int32_t *max_nodes);
 int csx_cholsol_solve(csx_handle_t plan, csx_handle_t B, int32_t nrhs);
-/* Level-scheduled path only (big elimination trees).  exact = 1 (default): every right-hand side is solved
- * in the reference's subtraction order, bit-identical to cs_lsolve + cs_ltsolve.  exact = 0: the blocked
- * chain walker may subtract a row's out-of-block terms before its in-block ones (needed to speed up
- * L' x = b, whose reference order puts the nearest sources first): equal to the reference to rounding. */
+/* exact = 1 (the default of every plan): every right-hand side is solved in the reference's operation order,
+ * bit-identical to cs_lsolve + cs_ltsolve on the same L, on every path (substitution kernels).
+ * exact = 0: equal to the reference to rounding (1e-10 budget).  Forests of dense blocks go to the dense-block
+ * kernels: blocks of 16/32/64 as a blocked TRSM on the matrix cores with explicit inverses of the diagonal
+ * tiles (built by this call), unless an inverse is large (max|inv(L_ii)| max|L| > 1e3), then -- like blocks of
+ * 8 -- FMA substitution with the unknowns in registers; on big elimination trees the blocked
+ * chain walker may subtract a row's out-of-block terms first.  csx_cholsol_info reports the path in use;
+ * csx_cholsol_growth the guard's measure (0 before the first exact = 0). */
 int csx_cholsol_set_order(csx_handle_t plan, int exact);
+int csx_cholsol_growth(csx_handle_t plan, double *growth);
 
 /* ---- assembly and reshaping around the hot path ---------
  * Every function returns a NEW matrix handle.  p[] / i[] bit-identical to the reference's result.

@@ -301,7 +301,27 @@ def synthetic_fixture(seed):
     np.savez_compressed(os.path.join(OUT, "synthetic_%d.npz" % seed), **d)
 
 
+def config2_fixture():
+    """BASELINE config 2: cs_gaxpy on bcsstk16 as the reference's tests use it (csparse_test.py:525: the Test2
+    problem matrix C = A + triu(A,1)', 4884 x 4884, 290 378 entries), run by the unmodified reference.
+    C itself is already in bcsstk16.npz (keys C_*); this stores the vectors."""
+    T, A, C, sym = get_problem("bcsstk16")
+    assert sym and C.p[C.n] == 290378
+    n = C.n
+    x = [1.0 + float(j) / n for j in range(n)]
+    y = [0.5 - float(i) / n for i in range(n)]
+    d = {"x": F(x), "y0": F(y)}
+    assert R.cs_gaxpy(C, x, y)
+    d["y"] = F(y)
+    d["sha_C"] = np.frombuffer(bytes.fromhex(sha(I(C.p)) + sha(I(C.i[:C.p[n]])) + sha(F(C.x[:C.p[n]]))), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, "config2_bcsstk16.npz"), **d)
+    return {"n": n, "nnz": C.p[n], "y_first": y[0], "y_last": y[-1]}
+
+
 def main():
+    if sys.argv[1:] == ["config2"]:
+        print("config2", config2_fixture())
+        return
     meta = {}
     for name in ("t1", "bcsstk01", "west0067", "ash219", "fs_183_1", "ibm32a", "ibm32b", "lp_afiro"):
         meta[name] = matrix_fixture(name)
@@ -309,6 +329,7 @@ def main():
     meta["bcsstk16"] = matrix_fixture("bcsstk16", big=True)
     print("bcsstk16", json.dumps(meta["bcsstk16"])[:300])
     synthetic_fixture(20240601)
+    meta["config2_bcsstk16"] = config2_fixture()
     with open(os.path.join(OUT, "meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)
 

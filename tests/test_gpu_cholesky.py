@@ -96,7 +96,8 @@ def test_chol_with_permutation(cs):
     np.testing.assert_allclose(xo, g["x_lusol"], rtol=1e-8)
     import _csx
     plan = _csx.new_handle()
-    _csx.check(_csx.lib().csx_cholsol_plan(N.L._dev.handle, _csx.pi(_csx.i32(pinv)), plan))
+    with cs._Resident(N.L) as dL:                # N.L's lists were read above: its device copy is gone, upload again
+        _csx.check(_csx.lib().csx_cholsol_plan(dL.handle, _csx.pi(_csx.i32(pinv)), plan))
     B = np.stack([g["b"], 2 * g["b"], g["b"] + 1.0], axis=1)
     dB = cs.dvec(B)
     _csx.check(_csx.lib().csx_cholsol_solve(plan, dB.handle, 3))
@@ -106,15 +107,17 @@ def test_chol_with_permutation(cs):
     np.testing.assert_allclose(X[:, 1], 2 * np.asarray(xo), rtol=1e-9)
 
 
-@pytest.mark.parametrize("nblocks,bs,k", [(40, 64, 130), (300, 8, 5), (3, 32, 64)])
+@pytest.mark.parametrize("nblocks,bs,k", [(40, 64, 130), (300, 8, 5), (3, 32, 64), (25, 16, 70)])
 def test_gspd_factor_and_batched_solve(cs, nblocks, bs, k):
-    """Block-diagonal SPD (the benchmark's G-spd shape): forest of small trees -> tree kernels
-    for the factorisation and the fused in-LDS solve for many right-hand sides."""
+    """Block-diagonal SPD (the benchmark's G-spd shape): forest of small trees -> tree kernels for the
+    factorisation; the solve phase in its default (exact) order must be bit-identical to cs_lsolve + cs_ltsolve
+    for EVERY right-hand side, and the rounding-equal order (matrix cores) within 1e-13 of it."""
+    import _csx
     Ap, Ai, Ax = synth.gspd(nblocks, bs, 20240606)
     n = nblocks * bs
     A = cs.cs_pin(_host_cs(cs, n, n, Ap, Ai, Ax))
-    F = cs.cholsol_factor(A)
-    assert F.info() == {"fused_local": True, "dense_block": bs, "matrix_cores": bs >= 16, "trees": nblocks,
+    F = cs.cholsol_factor(A)                      # exact=True is the default
+    assert F.info() == {"fused_local": True, "dense_block": 0, "matrix_cores": False, "trees": nblocks,
                         "max_nodes": bs}
     parent, cp = CO.schol(n, Ap, Ai)
     assert F.symbolic.parent == parent.tolist() and F.symbolic.cp == cp.tolist()
@@ -125,74 +128,73 @@ def test_gspd_factor_and_batched_solve(cs, nblocks, bs, k):
     # dense-block kernel: the reference's operation order on a chain tree -> the same bits
     assert got.tobytes() == Lx.tobytes()
     # the general column kernel (forced) sums in a different order: equal to rounding
-    import os
-    os.environ["CSX_CHOL_NO_DENSE"] = "1"
-    try:
+    with _csx.option("chol.dense_trees", 0):
         Lg = cs.cs_chol(A, F.symbolic).L
-    finally:
-        del os.environ["CSX_CHOL_NO_DENSE"]
     assert Lg.p == Lp.tolist() and Lg.i[:Lp[n]] == Li.tolist()
     assert np.max(np.abs(np.asarray(Lg.x[:Lp[n]]) - Lx)) / np.abs(Lx).max() < 1e-13
     B = synth.rhs(n, k, 0)
+    gLp, gLi, gLx = _arr(L)
+    refs = {r: CO.ltsolve(n, gLp, gLi, gLx, CO.lsolve(n, gLp, gLi, gLx, B[:, r])) for r in sorted(set([0, 1, k // 2, k - 1]))}
+    # default order (fused per-tree kernel, X tile in LDS): the reference's bits for every right-hand side
     dB = cs.dvec(B)
     assert F.solve(dB) is True
     X = dB.numpy()
-    gLp, gLi, gLx = _arr(L)
-    for r in sorted(set([0, 1, k // 2, k - 1])):
-        ref = CO.ltsolve(n, gLp, gLi, gLx, CO.lsolve(n, gLp, gLi, gLx, B[:, r]))
-        # dense-block kernels (blocked TRSM on the matrix cores for bs >= 16, FMA substitution below):
-        # equal to rounding, not bit for bit
-        assert np.max(np.abs(X[:, r] - ref) / np.abs(ref)) < 1e-13, r
-    # the substitution dense kernel (matrix cores off) agrees to rounding too
-    os.environ["CSX_CHOLSOL_NO_MFMA"] = "1"
-    try:
-        dB3 = cs.dvec(B)
-        assert F.solve(dB3) is True
-        X3 = dB3.numpy()
-    finally:
-        del os.environ["CSX_CHOLSOL_NO_MFMA"]
+    for r, ref in refs.items():
+        assert X[:, r].tobytes() == ref.tobytes(), r
+    # rounding-equal order: blocked TRSM on the matrix cores for 16/32/64 blocks, FMA substitution for 8
+    Ff = cs.cholsol_factor(A, exact=False)
+    assert Ff.info()["dense_block"] == bs and Ff.info()["matrix_cores"] is (bs >= 16)
+    dB3 = cs.dvec(B)
+    assert Ff.solve(dB3) is True
+    X3 = dB3.numpy()
     assert np.max(np.abs(X3 - X) / np.abs(X)) < 1e-13
-    # the reference-order fused kernel (forced) is bit-identical per right-hand side
-    os.environ["CSX_CHOLSOL_NO_DENSE"] = "1"
-    try:
+    assert X3.tobytes() != X.tobytes()            # it really is another kernel
+    # ... and with the dense-block kernels switched off the same plan falls back to the exact kernel
+    with _csx.option("cholsol.dense_blocks", 0):
         dB2 = cs.dvec(B)
-        assert F.solve(dB2) is True
-        X2 = dB2.numpy()
-    finally:
-        del os.environ["CSX_CHOLSOL_NO_DENSE"]
-    for r in sorted(set([0, k - 1])):
-        ref = CO.ltsolve(n, gLp, gLi, gLx, CO.lsolve(n, gLp, gLi, gLx, B[:, r]))
-        assert X2[:, r].tobytes() == ref.tobytes(), r
+        assert Ff.solve(dB2) is True
+        assert dB2.numpy().tobytes() == X.tobytes()
     # residual of the whole block against A (symmetric, full storage)
     R = np.stack([CO.gaxpy(n, n, Ap, Ai, Ax, X[:, r], -B[:, r]) for r in (0, k - 1)], axis=1)
     assert np.max(np.abs(R)) < 1e-12 * np.max(np.abs(B)) * bs
-    # one right-hand side as a list through the drop-in driver
+    # one right-hand side as a list through the drop-in driver: the default order, the reference's bits
     b = B[:, 0].tolist()
     assert cs.cs_cholsol(0, A, b) is True
-    assert np.asarray(b).tobytes() == X[:, 0].tobytes()
+    assert np.asarray(b).tobytes() == refs[0].tobytes()
 
 
-def test_badly_scaled_blocks_keep_substitution(cs):
-    """Block inverses with large growth (max|W| max|L| > 1e4): the plan must not use the matrix-core path,
-    and the solve still meets the tolerance."""
-    nblocks, bs, k = 6, 32, 20
-    Ap, Ai, Ax = synth.gspd(nblocks, bs, 77)
+@pytest.mark.parametrize("bs", [16, 64])
+@pytest.mark.parametrize("spread", [1.0, 30.0, 300.0, 800.0, 3000.0, 1e5])
+def test_matrix_core_solve_below_and_above_the_growth_guard(cs, bs, spread):
+    """exact=False solves dense blocks with explicit inverses of the diagonal tiles; its error grows with
+    max|inv(L_ii)| max|L| ("growth").  Blocks are scaled D A D with D spanning `spread`, which puts growth
+    anywhere from ~1 to far beyond the guard (1e3): below it the matrix cores run and must stay inside the
+    1e-10 budget against the plain-C oracle; above it the plan must keep (FMA) substitution, same budget."""
+    import _csx
+    nblocks, k = 30, 70
+    Ap, Ai, Ax = synth.gspd(nblocks, bs, 20240612)
     n = nblocks * bs
-    d = np.tile(np.logspace(-4, 4, bs), nblocks)   # symmetric scaling D A D keeps A SPD, spreads the pivots of a block
+    d = np.tile(np.logspace(0.0, np.log10(spread), bs), nblocks)
+    rng = np.random.default_rng(int(spread) + bs)
+    for b in range(nblocks):                       # a different ordering of the scales in every block
+        d[b * bs:(b + 1) * bs] = rng.permutation(d[b * bs:(b + 1) * bs])
     cols = np.repeat(np.arange(n), np.diff(Ap))
-    Ax2 = Ax * d[Ai] * d[cols]
-    A = cs.cs_pin(_host_cs(cs, n, n, Ap, Ai, Ax2))
-    F = cs.cholsol_factor(A)
-    info = F.info()
-    assert info["dense_block"] == bs and info["matrix_cores"] is False
+    A = cs.cs_pin(_host_cs(cs, n, n, Ap, Ai, Ax * d[Ai] * d[cols]))
+    F = cs.cholsol_factor(A, exact=False)
+    growth = _csx.C.c_double()
+    _csx.check(_csx.lib().csx_cholsol_growth(F.plan_handle, growth))
     B = synth.rhs(n, k, 0)
     dB = cs.dvec(B)
     assert F.solve(dB) is True
     X = dB.numpy()
     gLp, gLi, gLx = _arr(F.L)
-    for r in (0, k - 1):
+    on_cores = F.info()["matrix_cores"]
+    assert on_cores is (growth.value <= 1e3), (growth.value, on_cores)
+    worst = 0.0
+    for r in (0, 17, k - 1):
         ref = CO.ltsolve(n, gLp, gLi, gLx, CO.lsolve(n, gLp, gLi, gLx, B[:, r]))
-        assert np.max(np.abs(X[:, r] - ref) / np.abs(ref)) < 1e-10, r
+        worst = max(worst, float(np.max(np.abs(X[:, r] - ref) / np.abs(ref))))
+    assert worst < 1e-10, (spread, growth.value, worst)
 
 
 def test_forest_of_sparse_trees_uses_generic_fused_kernel(cs):

@@ -90,6 +90,9 @@ def test_cholsol_5m_block_spd_residual(cs, lib):
     _csx.check(lib.csx_cholsol_plan(hL, None, plan))
     path, trees, mx = C.c_int32(), C.c_int32(), C.c_int32()
     _csx.check(lib.csx_cholsol_info(plan, path, trees, mx))
+    assert (path.value, trees.value, mx.value) == (1, nb, bs)   # default order: fused per-tree kernel, the reference's bits
+    _csx.check(lib.csx_cholsol_set_order(plan, 0))              # the benchmark's leg: rounding-equal order
+    _csx.check(lib.csx_cholsol_info(plan, path, trees, mx))
     assert (path.value, trees.value, mx.value) == (3, nb, bs)   # dense blocks on the matrix cores
     hB = _csx.new_handle()
     _csx.check(lib.csx_gen_rhs(n, k, 0, hB))
@@ -104,16 +107,12 @@ def test_cholsol_5m_block_spd_residual(cs, lib):
         _csx.check(lib.csx_gaxpy(hA, xr.handle, res.handle, cs.GAXPY_WAVE))
         assert np.max(np.abs(res.numpy())) < 1e-12 * np.max(np.abs(B0[:, r])) * bs
     # the reference-order fused kernel agrees with the dense-block kernel to rounding
-    import os
-    os.environ["CSX_CHOLSOL_NO_DENSE"] = "1"
-    try:
+    with _csx.option("cholsol.dense_blocks", 0):
         hB2 = _csx.new_handle()
         _csx.check(lib.csx_gen_rhs(n, k, 0, hB2))
         dB2 = _vec(hB2, n, k)
         _csx.check(lib.csx_cholsol_solve(plan, hB2, k))
         X2 = dB2.numpy()
-    finally:
-        del os.environ["CSX_CHOLSOL_NO_DENSE"]
     assert np.max(np.abs(X2 - X) / np.abs(X2)) < 1e-12
     for h in (plan, hL, hA):
         _csx.free(h)

@@ -113,12 +113,19 @@ def _ragged(rng, m, n, lens):
 
 
 @pytest.mark.parametrize("two_pass", [False, True])
-def test_multiply_ragged_columns_hash_bins(cs, two_pass, monkeypatch):
+def test_multiply_ragged_columns_hash_bins(cs, two_pass):
     """m > 8192 with ragged shapes: A columns longer than one 32-lane chunk (and empty ones), B columns
     longer than one staged segment, duplicate rows inside a column, all four hash table sizes.  Both the
     one-pass kernel (bitmap ranking) and the two-pass kernel must reproduce the reference's column order."""
-    if two_pass:
-        monkeypatch.setenv("CSX_SPGEMM_TWO_PASS", "1")
+    import _csx
+    _csx.check(_csx.lib().csx_set_option(b"spgemm.one_pass", 0 if two_pass else 1))
+    try:
+        _ragged_body(cs)
+    finally:
+        _csx.check(_csx.lib().csx_set_option(b"spgemm.one_pass", 1))
+
+
+def _ragged_body(cs):
     rng = np.random.default_rng(20240611)
     m, k, n = 12000, 3000, 400
     alen = rng.integers(0, 90, size=k)

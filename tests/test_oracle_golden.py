@@ -326,3 +326,15 @@ def test_c_oracle_perm_and_zero_pivot():
         CO.lsolve(1, [0, 1], [0], [0.0], [1.0])
     with pytest.raises(ZeroDivisionError):
         CO.usolve(1, [0, 1], [0], [-0.0], [1.0])
+
+
+def test_config2_fixture_pins_both_oracles():
+    """BASELINE config 2 (cs_gaxpy on the symmetric-expanded bcsstk16): the unmodified reference's y."""
+    g, v = golden("bcsstk16"), golden("config2_bcsstk16")
+    C = unpack(O, g, "C")
+    assert C.p[C.n] == 290378
+    y = v["y0"].tolist()
+    assert O.cs_gaxpy(C, v["x"].tolist(), y)
+    assert np.asarray(y).tobytes() == v["y"].tobytes()
+    p, i, x = g["C_p"].astype(np.int32), g["C_i"].astype(np.int32), g["C_x"]
+    assert CO.gaxpy(4884, 4884, p, i, x, v["x"], v["y0"]).tobytes() == v["y"].tobytes()
