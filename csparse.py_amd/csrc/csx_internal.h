@@ -104,6 +104,7 @@ struct Options {
     bool cholsol_dense_blocks = true; // cholsol: dense-block kernels (false: the fused per-tree kernel)
     bool spgemm_one_pass = true;      // cs_multiply: one-walk LDS hash kernel (false: the two-pass kernel)
     bool tri_chain_walker = true;     // tri-solve: blocked chain walker for runs of narrow levels
+    bool tri_components = true;       // tri-solve: one wave per small connected component (false: level sets)
 };
 
 struct Context {

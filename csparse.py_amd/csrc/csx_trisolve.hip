@@ -35,6 +35,7 @@
 #include <cstdlib>
 
 #include "csx_internal.h"
+#include "csx_sweep.h"
 
 namespace csx {
 
@@ -64,6 +65,16 @@ struct TriPlan {
     std::vector<Segment> segs;
     const int32_t *Tp = nullptr, *Ti = nullptr;  // the analysed matrix (not owned)
     const double *Tx = nullptr;
+    // component path (k_tri_local): the dependency graph falls into many small connected components, each
+    // solved by one wave with its X tile in LDS.  Built on the device (analyse_components).
+    bool comp_tried = false, comp_ok = false;
+    int32_t ncomp = 0, comp_max = 0;
+    Tree *comps = nullptr;           // [ncomp] (first, count) into comp_nodes
+    int32_t *comp_nodes = nullptr;   // [n] rows grouped by component, ascending inside one
+    int32_t *prog_ptr = nullptr, *prog_idx = nullptr;   // per sweep position: terms (local row * 64, value)
+    double *prog_val = nullptr, *prog_diag = nullptr;
+    int few_cpw = 0;                 // components per wave of the all-in-LDS kernel (0: its tiles do not fit)
+    int32_t few_rows = 0, few_terms = 0;
 };
 
 void free_triplan(TriPlan *t) {
@@ -79,6 +90,12 @@ void free_triplan(TriPlan *t) {
     dfree(t->npre);
     dfree(t->nin);
     dfree(t->tslot);
+    dfree(t->comps);
+    dfree(t->comp_nodes);
+    dfree(t->prog_ptr);
+    dfree(t->prog_idx);
+    dfree(t->prog_val);
+    dfree(t->prog_diag);
     delete t;
 }
 
@@ -432,6 +449,591 @@ __global__ __launch_bounds__(256) void k_permute(const int32_t *__restrict__ p, 
     else x[t] = b[pk * nrhs + r];
 }
 
+
+// ---- connected components of the dependency graph, on the device ---------------------------------------
+// W (BASELINE config 3) is 1 493 independent 67 x 67 blocks: its global level sets are ~45 levels each
+// ~2 000 rows wide, i.e. ~80 dependent dispatches for L and U of ~6 us each, although no block ever waits for
+// another.  Components are found with min-label hooking + pointer jumping (every term is an edge row--source),
+// rows are grouped by component (stable sort by root keeps them ascending = a valid sweep order, descending
+// for the backward kinds), and each component becomes a packed program for the fused in-LDS sweep of
+// csx_sweep.h -- one launch, no level sets, nothing copied to the host but five counters.
+__global__ __launch_bounds__(256) void k_cc_init(int32_t n, int32_t *parent) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) parent[r] = (int32_t)r;
+}
+
+__device__ __forceinline__ int32_t cc_root(const int32_t *parent, int32_t r) {
+    int32_t p = parent[r];
+    while (p != r) {
+        r = p;
+        p = parent[r];
+    }
+    return r;
+}
+
+// one wave per row; flags[0] |= some hook happened, flags[1] |= a source does not precede its row (malformed)
+__global__ __launch_bounds__(256) void k_cc_hook(int32_t n, const int32_t *__restrict__ ptr,
+                                                 const int32_t *__restrict__ idx, int sf, int sl, int forward,
+                                                 int32_t *parent, int *flags) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (r >= n) return;
+    const int32_t b = ptr[r] + sf, e = ptr[r + 1] - sl;
+    int32_t rr = -1;
+    for (int32_t q = b + lane; q < e; q += 64) {
+        const int32_t j = idx[q];
+        if (j < 0 || j >= n || (forward ? j >= r : j <= r)) {
+            flags[1] = 1;
+            continue;
+        }
+        if (rr < 0) rr = cc_root(parent, (int32_t)r);
+        int32_t a = rr, c = cc_root(parent, j);
+        while (a != c) {                     // hook the larger root under the smaller one
+            const int32_t hi = a > c ? a : c, lo = a > c ? c : a;
+            const int32_t old = atomicMin(&parent[hi], lo);
+            if (old == hi) {
+                flags[0] = 1;
+                break;
+            }
+            a = cc_root(parent, old < lo ? old : lo);   // somebody else re-parented hi: merge with that tree
+            c = cc_root(parent, old < lo ? lo : old);
+            flags[0] = 1;
+        }
+        rr = a < c ? a : c;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cc_flatten(int32_t n, int32_t *parent) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) parent[r] = cc_root(parent, (int32_t)r);
+}
+
+__global__ __launch_bounds__(256) void k_iota_u32(int32_t n, uint32_t *v) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) v[r] = (uint32_t)r;
+}
+
+// sorted_root[k] starts a component when it differs from its left neighbour
+__global__ __launch_bounds__(256) void k_cc_heads(int32_t n, const uint32_t *__restrict__ sroot, int32_t *head) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) head[k] = (k == 0 || sroot[k] != sroot[k - 1]) ? 1 : 0;
+}
+
+// component c starts at the c-th head; its size is the distance to the next head
+__global__ __launch_bounds__(256) void k_cc_first(int32_t n, const int32_t *__restrict__ head,
+                                                  const int32_t *__restrict__ hscan, Tree *comps) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n && head[k]) comps[hscan[k]].first = (int32_t)k;
+}
+
+__global__ __launch_bounds__(256) void k_cc_count(int32_t n, int32_t ncomp, Tree *comps, int *stats) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncomp) return;
+    const int32_t cnt = (c + 1 < ncomp ? comps[c + 1].first : n) - comps[c].first;
+    comps[c].count = cnt;
+    atomicMax(&stats[0], cnt);
+}
+
+__global__ __launch_bounds__(256) void k_cc_local_id(int32_t ncomp, const Tree *__restrict__ comps,
+                                                     const uint32_t *__restrict__ srow, int32_t *local_id) {
+    const int lane = threadIdx.x & 63;
+    const int64_t c = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (c >= ncomp) return;
+    const Tree t = comps[c];
+    for (int32_t a = lane; a < t.count; a += 64) local_id[srow[t.first + a]] = a;
+}
+
+// program length of sweep position k: forward kinds sweep a component's rows ascending, backward descending
+__global__ __launch_bounds__(256) void k_prog_len(int32_t ncomp, const Tree *__restrict__ comps,
+                                                  const uint32_t *__restrict__ srow, const int32_t *__restrict__ ptr,
+                                                  int sf, int sl, int forward, int32_t *len) {
+    const int lane = threadIdx.x & 63;
+    const int64_t c = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (c >= ncomp) return;
+    const Tree t = comps[c];
+    for (int32_t sp = lane; sp < t.count; sp += 64) {
+        const int32_t row = (int32_t)srow[t.first + (forward ? sp : t.count - 1 - sp)];
+        len[t.first + sp] = (ptr[row + 1] - sl) - (ptr[row] + sf);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_prog_fill(int32_t n, const int32_t *__restrict__ comp_of_pos,
+                                                   const Tree *__restrict__ comps, const uint32_t *__restrict__ srow,
+                                                   const int32_t *__restrict__ local_id, const int32_t *__restrict__ ptr,
+                                                   const int32_t *__restrict__ idx, const double *__restrict__ val,
+                                                   const double *__restrict__ diag, int sf, int forward,
+                                                   const int32_t *__restrict__ prog_ptr, int32_t *prog_idx,
+                                                   double *prog_val, double *prog_diag) {
+    const int lane = threadIdx.x & 63;
+    const int64_t k = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;   // sweep position (global)
+    if (k >= n) return;
+    const Tree t = comps[comp_of_pos[k]];
+    const int32_t sp = (int32_t)k - t.first;
+    const int32_t row = (int32_t)srow[t.first + (forward ? sp : t.count - 1 - sp)];
+    const int32_t gb = ptr[row] + sf, o = prog_ptr[k], len = prog_ptr[k + 1] - o;
+    for (int32_t q = lane; q < len; q += 64) {
+        prog_idx[o + q] = local_id[idx[gb + q]] * 64;   // premultiplied: the X tile is [local row][64 lanes]
+        prog_val[o + q] = val[gb + q];
+    }
+    if (lane == 0) prog_diag[k] = diag[row];
+}
+
+__global__ __launch_bounds__(256) void k_comp_of_pos(int32_t n, const int32_t *__restrict__ head,
+                                                     const int32_t *__restrict__ hscan, int32_t *comp_of_pos) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) comp_of_pos[k] = hscan[k] + head[k] - 1;
+}
+
+// One wave = one component x 64 right-hand sides: X tile in LDS, one sweep in the plan's direction, every
+// (row, right-hand side) subtracting its terms in the reference's order (csx_sweep.h) -> bit-identical.
+constexpr int TL_WAVES_MAX = 4;
+template <bool FORWARD>
+__global__ __launch_bounds__(64 * TL_WAVES_MAX) void k_tri_local(const Tree *__restrict__ comps, int32_t ncomp,
+                                                                 const int32_t *__restrict__ nodes,
+                                                                 const int32_t *__restrict__ prog_ptr,
+                                                                 const int32_t *__restrict__ prog_idx,
+                                                                 const double *__restrict__ prog_val,
+                                                                 const double *__restrict__ prog_diag, double *B,
+                                                                 int32_t nrhs, int32_t chunks, int32_t max_nodes,
+                                                                 int32_t waves_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) double xt[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (w >= waves_per_wg) return;
+    const int64_t task = (int64_t)blockIdx.x * waves_per_wg + w;
+    if (task >= (int64_t)ncomp * chunks) return;
+    const int32_t t = (int32_t)(task / chunks), h = (int32_t)(task % chunks);
+    const Tree tr = comps[t];
+    const int32_t rhs = h * 64 + lane;
+    const bool live = rhs < nrhs;
+    const int32_t rl = live ? rhs : nrhs - 1;        // clamped: lanes past the last right-hand side load, never store
+    double *X = xt + (size_t)w * max_nodes * 64;
+    for (int32_t c0 = 0; c0 < tr.count; c0 += 64) {
+        const int32_t crow = min(64, tr.count - c0);
+        const int32_t jrow = lane < crow ? nodes[tr.first + c0 + lane] : 0;
+        for (int32_t r0 = 0; r0 < crow; r0 += 8) {
+            double tmp[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int32_t row = __builtin_amdgcn_readlane(jrow, min(r0 + u, crow - 1));
+                tmp[u] = B[(int64_t)row * nrhs + rl];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (r0 + u < crow) X[(c0 + r0 + u) * 64 + lane] = tmp[u];
+        }
+    }
+    sweep<FORWARD>(tr, prog_ptr, prog_idx, prog_val, prog_diag, X, lane);
+    for (int32_t c0 = 0; c0 < tr.count; c0 += 64) {
+        const int32_t crow = min(64, tr.count - c0);
+        const int32_t jrow = lane < crow ? nodes[tr.first + c0 + lane] : 0;
+        for (int32_t r = 0; r < crow; r++) {
+            const int32_t row = __builtin_amdgcn_readlane(jrow, r);
+            if (live) B[(int64_t)row * nrhs + rhs] = X[(c0 + r) * 64 + lane];
+        }
+    }
+}
+
+
+// Few right-hand sides (nrhs <= 32): a wave that gives all 64 lanes to the right-hand sides of ONE component
+// idles most of them.  Here a lane is a (component, right-hand side) pair: G = nrhs rounded up to a power of
+// two lanes per component, 64 / G components per wave, each lane walking its own component's program in
+// sweep order.  The solved unknowns of a lane's right-hand side sit in its own column of an LDS tile
+// ([component in wave][local row][g], row count padded to an odd number against bank conflicts), so no lane
+// ever reads another lane's data and no barrier is needed; a row's terms are fetched eight at a time and
+// subtracted strictly in order (multiply and subtract rounded separately): bit-identical.  The next row's
+// descriptor, right-hand-side entry and first term batch are requested while the current row is computed.
+#pragma clang fp contract(off)
+template <bool FORWARD>
+__global__ __launch_bounds__(256) void k_tri_few(const Tree *__restrict__ comps, int32_t ncomp,
+                                                 const int32_t *__restrict__ nodes,
+                                                 const int32_t *__restrict__ prog_ptr,
+                                                 const int32_t *__restrict__ prog_idx,
+                                                 const double *__restrict__ prog_val,
+                                                 const double *__restrict__ prog_diag, double *B, int32_t nrhs, int G,
+                                                 int32_t tile_rows, int32_t waves_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) double xt[];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (w >= waves_per_wg) return;
+    const int cpw = 64 / G, cw = lane / G, g = lane % G;
+    const int64_t comp = ((int64_t)blockIdx.x * waves_per_wg + w) * cpw + cw;
+    if (comp >= ncomp || g >= nrhs) return;
+    double *X = xt + ((size_t)w * cpw + cw) * tile_rows * G + g;   // this lane's column: X[local_row * G]
+    const Tree tr = comps[comp];
+    constexpr int TB = 8;
+    // descriptor of the first row
+    int32_t k = tr.first;
+    int32_t tb = prog_ptr[k], te = prog_ptr[k + 1];
+    int32_t row = nodes[FORWARD ? k : tr.first + tr.count - 1];
+    double dg = prog_diag[k];
+    double acc = B[(int64_t)row * nrhs + g];
+    int32_t c[TB];
+    double v[TB];
+#pragma unroll
+    for (int u = 0; u < TB; u++) {
+        const int32_t q = tb + u < te ? tb + u : (te > tb ? te - 1 : 0);
+        c[u] = te > tb ? prog_idx[q] : 0;
+        v[u] = te > tb ? prog_val[q] : 0.0;
+    }
+    for (int32_t sp = 0; sp < tr.count; sp++) {
+        // the next row's descriptor (clamped at the component's end: re-reads the last row, harmless)
+        const int32_t kn = sp + 1 < tr.count ? k + 1 : k;
+        const int32_t ntb = prog_ptr[kn], nte = prog_ptr[kn + 1];
+        const int32_t nrow = nodes[FORWARD ? kn : tr.first + tr.count - 1 - (kn - tr.first)];
+        const double ndg = prog_diag[kn];
+        const double nacc = B[(int64_t)nrow * nrhs + g];
+        for (int32_t q0 = tb; q0 < te; q0 += TB) {
+            double xv[TB];
+#pragma unroll
+            for (int u = 0; u < TB; u++) xv[u] = X[(c[u] >> 6) * G];
+            int32_t cn[TB];
+            double vn[TB];
+            const bool more = q0 + TB < te;   // next batch of this row, else the first batch of the next row
+            const int32_t nb_ = more ? q0 + TB : ntb, ne_ = more ? te : nte;
+#pragma unroll
+            for (int u = 0; u < TB; u++) {
+                const int32_t q = nb_ + u < ne_ ? nb_ + u : (ne_ > nb_ ? ne_ - 1 : 0);
+                cn[u] = ne_ > nb_ ? prog_idx[q] : 0;
+                vn[u] = ne_ > nb_ ? prog_val[q] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < TB; u++) {
+                const double t = v[u] * xv[u];
+                acc = q0 + u < te ? acc - t : acc;
+            }
+#pragma unroll
+            for (int u = 0; u < TB; u++) {
+                c[u] = cn[u];
+                v[u] = vn[u];
+            }
+        }
+        if (te <= tb) {   // a row without terms never entered the loop: fetch the next row's first batch here
+#pragma unroll
+            for (int u = 0; u < TB; u++) {
+                const int32_t q = ntb + u < nte ? ntb + u : (nte > ntb ? nte - 1 : 0);
+                c[u] = nte > ntb ? prog_idx[q] : 0;
+                v[u] = nte > ntb ? prog_val[q] : 0.0;
+            }
+        }
+        const double xr = acc / dg;
+        X[(FORWARD ? sp : tr.count - 1 - sp) * G] = xr;
+        B[(int64_t)row * nrhs + g] = xr;
+        k = kn;
+        tb = ntb;
+        te = nte;
+        row = nrow;
+        dg = ndg;
+        acc = nacc;
+    }
+}
+#pragma clang fp contract(fast)
+
+
+// The same lane = (component, right-hand side) scheme with everything in LDS: a wave takes CPW consecutive
+// components, whose packed programs are one contiguous piece of the plan, copies that piece and the rows'
+// right-hand-side entries into LDS with coalesced loads, and then every lane walks its own component out of
+// LDS (64 / CPW right-hand sides at a time).  Global memory sees two coalesced sweeps; the dependent chain
+// of a component -- row after row, term after term, in the reference's order -- runs at LDS latency.
+// W at one right-hand side: 241 us -> see profiles/r02_configs.jsonl.
+#pragma clang fp contract(off)
+struct __attribute__((aligned(16))) FewTerm {   // one term of a row, one 16-byte LDS read
+    double v;
+    int32_t src, pad;
+};
+struct __attribute__((aligned(16))) FewRow {    // one row: diagonal and extent of its terms, one 16-byte LDS read
+    double diag;
+    int32_t tb, te;
+};
+
+template <bool FORWARD, int CPW>
+__global__ __launch_bounds__(64) void k_tri_few_lds(const Tree *__restrict__ comps, int32_t ncomp,
+                                                    const int32_t *__restrict__ nodes,
+                                                    const int32_t *__restrict__ prog_ptr,
+                                                    const int32_t *__restrict__ prog_idx,
+                                                    const double *__restrict__ prog_val,
+                                                    const double *__restrict__ prog_diag, double *B, int32_t nrhs,
+                                                    int32_t rows_cap, int32_t terms_cap) {
+    constexpr int G = 64 / CPW;
+    extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+    FewTerm *s_term = reinterpret_cast<FewTerm *>(lds_raw);                    // [terms_cap]
+    FewRow *s_row = reinterpret_cast<FewRow *>(s_term + terms_cap);            // [rows_cap]
+    double *xs = reinterpret_cast<double *>(s_row + rows_cap);                 // [rows_cap * G]
+    const int lane = threadIdx.x;
+    const int32_t c0 = blockIdx.x * CPW, c1 = min(c0 + CPW, ncomp);
+    const int32_t first_k = comps[c0].first, last_k = comps[c1 - 1].first + comps[c1 - 1].count;
+    const int32_t nrows = last_k - first_k, tbase = prog_ptr[first_k], nterms = prog_ptr[last_k] - tbase;
+    // staging: four independent loads in flight per lane and pass (a loop that waits for each load in turn
+    // costs a memory round trip per 64 elements -- measured 27 us of a 78 us kernel)
+    constexpr int SU = 4;
+    for (int32_t i0 = lane; i0 < nrows; i0 += 64 * SU) {
+        int32_t pb[SU], pe[SU];
+        double dd[SU];
+#pragma unroll
+        for (int u = 0; u < SU; u++) {
+            const int32_t i = min(i0 + 64 * u, nrows - 1);
+            pb[u] = prog_ptr[first_k + i];
+            pe[u] = prog_ptr[first_k + i + 1];
+            dd[u] = prog_diag[first_k + i];
+        }
+#pragma unroll
+        for (int u = 0; u < SU; u++)
+            if (i0 + 64 * u < nrows) s_row[i0 + 64 * u] = {dd[u], pb[u] - tbase, pe[u] - tbase};
+    }
+    for (int32_t q0 = lane; q0 < nterms; q0 += 64 * SU) {
+        int32_t ii[SU];
+        double vv[SU];
+#pragma unroll
+        for (int u = 0; u < SU; u++) {
+            const int32_t q = min(q0 + 64 * u, nterms - 1);
+            ii[u] = prog_idx[tbase + q];
+            vv[u] = prog_val[tbase + q];
+        }
+#pragma unroll
+        for (int u = 0; u < SU; u++)
+            if (q0 + 64 * u < nterms) s_term[q0 + 64 * u] = {vv[u], ii[u] >> 6, 0};   // the plan stores local row * 64
+    }
+    const int cw = lane / G, g = lane % G;
+    const int32_t comp = c0 + cw;
+    Tree tr = {0, 0};
+    if (comp < c1) tr = comps[comp];
+    const int32_t rb = tr.first - first_k;                     // this component's first tile row
+    for (int32_t r0 = 0; r0 < nrhs; r0 += G) {
+        const int32_t gw = min(G, nrhs - r0), nx = nrows * gw;   // only the live right-hand sides are moved
+        for (int32_t i0 = lane; i0 < nx; i0 += 64 * SU) {
+            int32_t nd[SU];
+            double bb[SU];
+#pragma unroll
+            for (int u = 0; u < SU; u++) nd[u] = nodes[first_k + min(i0 + 64 * u, nx - 1) / gw];
+#pragma unroll
+            for (int u = 0; u < SU; u++) bb[u] = B[(int64_t)nd[u] * nrhs + r0 + min(i0 + 64 * u, nx - 1) % gw];
+#pragma unroll
+            for (int u = 0; u < SU; u++) {
+                const int32_t i = i0 + 64 * u;
+                if (i < nx) xs[(i / gw) * G + i % gw] = bb[u];
+            }
+        }
+        __syncthreads();
+        if (comp < c1 && r0 + g < nrhs) {
+            // The chain that cannot be shortened is: x of the sources (LDS) -> multiply -> ordered subtractions ->
+            // division -> x of this row (LDS).  The row record and the next (source, value) records do not depend
+            // on x and are read ahead, beside that chain.
+            constexpr int TB = 8;
+            FewRow cur = s_row[rb];
+            FewTerm t[TB];
+#pragma unroll
+            for (int u = 0; u < TB; u++) t[u] = s_term[cur.tb + u < cur.te ? cur.tb + u : (cur.te > cur.tb ? cur.te - 1 : 0)];
+            for (int32_t sp = 0; sp < tr.count; sp++) {
+                const FewRow nxt = s_row[rb + (sp + 1 < tr.count ? sp + 1 : sp)];
+                const int32_t trow = rb + (FORWARD ? sp : tr.count - 1 - sp);
+                double acc = xs[trow * G + g];
+                int32_t q0 = cur.tb;
+                do {
+                    double xv[TB];
+#pragma unroll
+                    for (int u = 0; u < TB; u++) xv[u] = xs[(rb + t[u].src) * G + g];
+                    // the next batch: of this row if it has more terms, else the first one of the next row
+                    const bool more = q0 + TB < cur.te;
+                    const int32_t nb_ = more ? q0 + TB : nxt.tb, ne_ = more ? cur.te : nxt.te;
+                    FewTerm tn[TB];
+#pragma unroll
+                    for (int u = 0; u < TB; u++) tn[u] = s_term[nb_ + u < ne_ ? nb_ + u : (ne_ > nb_ ? ne_ - 1 : 0)];
+#pragma unroll
+                    for (int u = 0; u < TB; u++) {
+                        const double pr = t[u].v * xv[u];
+                        acc = q0 + u < cur.te ? acc - pr : acc;
+                    }
+#pragma unroll
+                    for (int u = 0; u < TB; u++) t[u] = tn[u];
+                    q0 += TB;
+                } while (q0 < cur.te);
+                xs[trow * G + g] = acc / cur.diag;
+                cur = nxt;
+            }
+        }
+        __syncthreads();
+        for (int32_t i = lane; i < nx; i += 64) B[(int64_t)nodes[first_k + i / gw] * nrhs + r0 + i % gw] = xs[(i / gw) * G + i % gw];
+        __syncthreads();
+    }
+}
+#pragma clang fp contract(fast)
+
+// largest number of rows / terms in any group of `cpw` consecutive components
+__global__ __launch_bounds__(256) void k_group_caps(int32_t ncomp, int cpw, const Tree *__restrict__ comps,
+                                                    const int32_t *__restrict__ prog_ptr, int *caps) {
+    const int64_t gidx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t c0 = gidx * cpw;
+    if (c0 >= ncomp) return;
+    const int32_t c1 = (int32_t)(c0 + cpw < ncomp ? c0 + cpw : ncomp);
+    const int32_t fk = comps[c0].first, lk = comps[c1 - 1].first + comps[c1 - 1].count;
+    atomicMax(&caps[0], lk - fk);
+    atomicMax(&caps[1], prog_ptr[lk] - prog_ptr[fk]);
+}
+
+constexpr int COMP_MAX_ROWS = 256;    // X tile of one component: rows x 64 lanes x 8 B <= 128 KiB of LDS
+constexpr int COMP_MIN_COUNT = 64;    // fewer components than this: level scheduling fills the chip better
+
+static size_t few_lds_bytes(int32_t rows, int32_t terms, int G) {
+    return (size_t)(terms > 0 ? terms : 1) * 16 + (size_t)rows * (16 + 8 * (size_t)G) + 64;
+}
+
+// Returns CSX_OK whether or not the component path applies; P->comp_ok says which.
+static int analyse_components(TriPlan *P) {
+    if (P->comp_tried) return CSX_OK;
+    P->comp_tried = true;
+    const int32_t n = P->n;
+    if (n < COMP_MIN_COUNT) return CSX_OK;
+    hipStream_t s = ctx().stream;
+    DevScope tmp;
+    int32_t *parent = nullptr, *head = nullptr, *hscan = nullptr, *local_id = nullptr, *len = nullptr, *comp_of_pos = nullptr;
+    uint32_t *rows = nullptr, *sroot = nullptr, *srow = nullptr;
+    int *flags = nullptr;
+    CSX_TRY(tmp.alloc(&parent, (size_t)n));
+    CSX_TRY(tmp.alloc(&flags, 4));
+    const unsigned nb = (unsigned)(((int64_t)n + 255) / 256), nbw = (unsigned)(((int64_t)n + 3) / 4);
+    hipLaunchKernelGGL(k_cc_init, dim3(nb), dim3(256), 0, s, n, parent);
+    int hflags[4] = {0, 0, 0, 0};
+    for (int it = 0; it < 64; it++) {
+        CSX_HIP(hipMemsetAsync(flags, 0, 4 * sizeof(int), s));
+        hipLaunchKernelGGL(k_cc_hook, dim3(nbw), dim3(256), 0, s, n, P->ptr, P->idx, P->skip_first, P->skip_last,
+                           P->forward ? 1 : 0, parent, flags);
+        hipLaunchKernelGGL(k_cc_flatten, dim3(nb), dim3(256), 0, s, n, parent);
+        CSX_HIP(hipMemcpyAsync(hflags, flags, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+        CSX_HIP(hipStreamSynchronize(s));
+        if (hflags[1]) return CSX_OK;     // malformed triangle: the literal transcription handles it
+        if (!hflags[0]) break;
+        if (it == 63) return CSX_OK;      // did not settle (not expected): keep level scheduling
+    }
+    // group rows by root: stable, so rows stay ascending inside a component
+    CSX_TRY(tmp.alloc(&rows, (size_t)n));
+    CSX_TRY(tmp.alloc(&sroot, (size_t)n));
+    CSX_TRY(tmp.alloc(&srow, (size_t)n));
+    CSX_TRY(tmp.alloc(&head, (size_t)n + 1));
+    CSX_TRY(tmp.alloc(&hscan, (size_t)n + 1));
+    hipLaunchKernelGGL(k_iota_u32, dim3(nb), dim3(256), 0, s, n, rows);
+    CSX_TRY(stable_sort_by_key((const uint32_t *)parent, rows, nullptr, n, (uint32_t)n, sroot, srow, nullptr));
+    hipLaunchKernelGGL(k_cc_heads, dim3(nb), dim3(256), 0, s, n, sroot, head);
+    int64_t ncomp = 0;
+    CSX_TRY(scan_exclusive_i32(head, hscan, n, &ncomp));
+    if (ncomp < COMP_MIN_COUNT) return CSX_OK;
+    Tree *comps = nullptr;
+    CSX_TRY(dalloc(&comps, (size_t)ncomp));
+    P->comps = comps;
+    CSX_HIP(hipMemsetAsync(flags, 0, 4 * sizeof(int), s));
+    hipLaunchKernelGGL(k_cc_first, dim3(nb), dim3(256), 0, s, n, head, hscan, comps);
+    hipLaunchKernelGGL(k_cc_count, dim3((unsigned)((ncomp + 255) / 256)), dim3(256), 0, s, n, (int32_t)ncomp, comps, flags);
+    CSX_HIP(hipMemcpyAsync(hflags, flags, sizeof(int), hipMemcpyDeviceToHost, s));
+    CSX_HIP(hipStreamSynchronize(s));
+    if (hflags[0] > COMP_MAX_ROWS) return CSX_OK;
+    P->ncomp = (int32_t)ncomp;
+    P->comp_max = hflags[0];
+    CSX_TRY(tmp.alloc(&local_id, (size_t)n));
+    CSX_TRY(tmp.alloc(&len, (size_t)n + 1));
+    CSX_TRY(tmp.alloc(&comp_of_pos, (size_t)n));
+    const unsigned ncw = (unsigned)((ncomp + 3) / 4);
+    hipLaunchKernelGGL(k_cc_local_id, dim3(ncw), dim3(256), 0, s, P->ncomp, comps, srow, local_id);
+    hipLaunchKernelGGL(k_prog_len, dim3(ncw), dim3(256), 0, s, P->ncomp, comps, srow, P->ptr, P->skip_first, P->skip_last,
+                       P->forward ? 1 : 0, len);
+    hipLaunchKernelGGL(k_comp_of_pos, dim3(nb), dim3(256), 0, s, n, head, hscan, comp_of_pos);
+    CSX_TRY(dalloc(&P->prog_ptr, (size_t)n + 1));
+    int64_t total = 0;
+    CSX_TRY(scan_exclusive_i32(len, P->prog_ptr, n, &total));
+    CSX_TRY(dalloc(&P->prog_idx, (size_t)total + 64));
+    CSX_TRY(dalloc(&P->prog_val, (size_t)total + 64));
+    CSX_TRY(dalloc(&P->prog_diag, (size_t)n));
+    CSX_TRY(dalloc(&P->comp_nodes, (size_t)n));
+    hipLaunchKernelGGL(k_prog_fill, dim3(nbw), dim3(256), 0, s, n, comp_of_pos, comps, srow, local_id, P->ptr, P->idx, P->val,
+                       P->diag, P->skip_first, P->forward ? 1 : 0, P->prog_ptr, P->prog_idx, P->prog_val, P->prog_diag);
+    CSX_HIP(hipMemcpyAsync(P->comp_nodes, srow, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    CSX_LAUNCH_CHECK();
+    for (int cpw : {4}) {   // LDS need of the all-in-LDS kernel: 12 B per term, (12 + 8 G) B per row, G = 64 / cpw = 16
+        int hcaps[2] = {0, 0};
+        CSX_HIP(hipMemsetAsync(flags, 0, 4 * sizeof(int), s));
+        const int64_t groups = (ncomp + cpw - 1) / cpw;
+        hipLaunchKernelGGL(k_group_caps, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, P->ncomp, cpw, comps,
+                           P->prog_ptr, flags);
+        CSX_HIP(hipMemcpyAsync(hcaps, flags, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+        CSX_HIP(hipStreamSynchronize(s));
+        const size_t need = few_lds_bytes(hcaps[0], hcaps[1], 64 / cpw);
+        if (need <= 120 * 1024) {
+            P->few_cpw = cpw;
+            P->few_rows = hcaps[0];
+            P->few_terms = hcaps[1];
+            break;
+        }
+    }
+    CSX_HIP(hipStreamSynchronize(s));
+    P->comp_ok = true;
+    return CSX_OK;
+}
+
+static int solve_components(TriPlan *P, double *X, int32_t nrhs) {
+    hipStream_t s = ctx().stream;
+    if (nrhs <= 32 && P->few_cpw) {   // lanes = (component, right-hand side) pairs, programs and X in LDS
+        const int cpw = P->few_cpw;
+        const size_t lds = few_lds_bytes(P->few_rows, P->few_terms, 64 / cpw);
+        const dim3 grid((unsigned)((P->ncomp + cpw - 1) / cpw));
+#define CSX_FEW(FWD, CPW)                                                                                            \
+    hipLaunchKernelGGL((k_tri_few_lds<FWD, CPW>), grid, dim3(64), lds, s, P->comps, P->ncomp, P->comp_nodes, P->prog_ptr, \
+                       P->prog_idx, P->prog_val, P->prog_diag, X, nrhs, P->few_rows, P->few_terms)
+        if (P->forward) {
+            CSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tri_few_lds<true, 4>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+            CSX_FEW(true, 4);
+        } else {
+            CSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tri_few_lds<false, 4>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+            CSX_FEW(false, 4);
+        }
+#undef CSX_FEW
+        CSX_LAUNCH_CHECK();
+        return CSX_OK;
+    }
+    if (nrhs <= 32) {   // the same with the programs read from memory (components too big for the LDS copy)
+        int G = 1;
+        while (G < nrhs) G <<= 1;
+        const int cpw = 64 / G;
+        const int32_t tile_rows = P->comp_max | 1;
+        const size_t per_wave_f = (size_t)64 * tile_rows * sizeof(double);
+        int wv = (int)std::min<size_t>(4, (128 * 1024) / per_wave_f);
+        if (wv < 1) wv = 1;
+        const int64_t waves_needed = ((int64_t)P->ncomp + cpw - 1) / cpw;
+        const dim3 grid((unsigned)((waves_needed + wv - 1) / wv));
+        if (P->forward) {
+            CSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tri_few<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+            hipLaunchKernelGGL(k_tri_few<true>, grid, dim3(256), per_wave_f * wv, s, P->comps, P->ncomp, P->comp_nodes,
+                               P->prog_ptr, P->prog_idx, P->prog_val, P->prog_diag, X, nrhs, G, tile_rows, wv);
+        } else {
+            CSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tri_few<false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+            hipLaunchKernelGGL(k_tri_few<false>, grid, dim3(256), per_wave_f * wv, s, P->comps, P->ncomp, P->comp_nodes,
+                               P->prog_ptr, P->prog_idx, P->prog_val, P->prog_diag, X, nrhs, G, tile_rows, wv);
+        }
+        CSX_LAUNCH_CHECK();
+        return CSX_OK;
+    }
+    const size_t per_wave = (size_t)P->comp_max * 64 * sizeof(double);
+    int waves = (int)std::min<size_t>(TL_WAVES_MAX, (128 * 1024) / per_wave);
+    if (waves < 1) waves = 1;
+    const int32_t chunks = (nrhs + 63) / 64;
+    const int64_t tasks = (int64_t)P->ncomp * chunks;
+    const size_t lds = per_wave * (size_t)waves;
+    const dim3 grid((unsigned)((tasks + waves - 1) / waves));
+    if (P->forward) {
+        CSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tri_local<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+        hipLaunchKernelGGL(k_tri_local<true>, grid, dim3(64 * TL_WAVES_MAX), lds, s, P->comps, P->ncomp, P->comp_nodes,
+                           P->prog_ptr, P->prog_idx, P->prog_val, P->prog_diag, X, nrhs, chunks, P->comp_max, waves);
+    } else {
+        CSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tri_local<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+        hipLaunchKernelGGL(k_tri_local<false>, grid, dim3(64 * TL_WAVES_MAX), lds, s, P->comps, P->ncomp, P->comp_nodes,
+                           P->prog_ptr, P->prog_idx, P->prog_val, P->prog_diag, X, nrhs, chunks, P->comp_max, waves);
+    }
+    CSX_LAUNCH_CHECK();
+    return CSX_OK;
+}
+
 // ---- analysis ---------------------------------------------------------------------
 static int download_i32(std::vector<int32_t> &h, const int32_t *d, size_t count) {
     h.resize(count);
@@ -623,6 +1225,8 @@ int tri_solve_raw(TriPlan *P, double *X, int32_t nrhs, bool relaxed) {
     hipStream_t s = ctx().stream;
     if (P->zero_pivot) return CSX_EZEROPIVOT;
     if (P->n == 0 || nrhs == 0) return CSX_OK;
+    if (ctx().opt.tri_components) CSX_TRY(analyse_components(P));
+    if (P->comp_ok && ctx().opt.tri_components) return solve_components(P, X, nrhs);
     CSX_TRY(ensure_schedule(P));
     if (P->sequential) {
         hipLaunchKernelGGL(k_tri_sequential, dim3((unsigned)((nrhs + 63) / 64)), dim3(64), 0, s, P->kind, P->n, P->Tp,
@@ -689,6 +1293,13 @@ extern "C" int csx_tri_info(csx_handle_t h, int32_t *n, int32_t *levels, int32_t
     if (n) *n = P->n;
     if (levels) *levels = P->nlevels;
     if (sequential) *sequential = P->sequential ? 1 : 0;
+    return CSX_OK;
+}
+
+extern "C" int csx_tri_components(csx_handle_t h, int32_t *ncomp) {
+    TriPlan *P = (TriPlan *)get(h, K_TRIPLAN);
+    if (!P || !ncomp) return CSX_EINVAL;
+    *ncomp = P->comp_ok ? P->ncomp : 0;
     return CSX_OK;
 }
 

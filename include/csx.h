@@ -72,7 +72,7 @@ int csx_mem_trim(void);
 int csx_mem_info(int64_t *cached_bytes, int64_t *live_bytes, int64_t *device_free_bytes);
 /* Kernel-selection overrides, for tests that must reach a kernel the planner would not pick for a given input.
  * Every setting computes correct results; nothing here (or anywhere in the library) is read from the
- * environment.  Names: "chol.dense_trees", "cholsol.dense_blocks", "spgemm.one_pass", "tri.chain_walker"
+ * environment.  Names: "chol.dense_trees", "cholsol.dense_blocks", "spgemm.one_pass", "tri.chain_walker", "tri.components"
  * (all default 1).  Unknown name: CSX_EINVAL. */
 int csx_set_option(const char *name, int value);
 int csx_timer_start(void);                /* hipEvent on the context's stream */
@@ -136,6 +136,9 @@ int csx_multiply(csx_handle_t A, csx_handle_t B, csx_handle_t *out);
 int csx_tri_analyse(csx_handle_t T, int kind, csx_handle_t *plan);
 int csx_tri_info(csx_handle_t plan, int32_t *n, int32_t *levels, int32_t *sequential);
 int csx_tri_solve(csx_handle_t plan, csx_handle_t X, int32_t nrhs);
+/* After the first solve: the number of connected components of the dependency graph when the plan solves
+ * them one wave each (many components of <= 256 rows: block-diagonal factors), 0 when it level-schedules. */
+int csx_tri_components(csx_handle_t plan, int32_t *ncomp);
 
 /* cs_ipvec / cs_pvec, csparse.py:1264-1277, :1779-1792, on n-by-nrhs blocks:
  * inverse != 0: x[p[k], :] = b[k, :] (ipvec); else x[k, :] = b[p[k], :] (pvec).
