@@ -540,7 +540,7 @@ def cholsol_section(args, lib, cs, comm, hB, nb, bs, barrier, max_over_ranks):
                         "unit": "GB/s", "frac": round(fused_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                         "traffic": (measured_traffic("k_cholsol_", n=n, nrhs_per_gpu=k) or {}).get("bytes")},
            "survey_bytes_unfused": cholsol_bytes(lnz, n, k),
-           "factor_s": {"symbolic_etree_host_counts_device": round(t_symbolic, 3), "numeric_device_incl_pattern_of_L": round(t_numeric, 3),
+           "factor_s": {"symbolic_cs_schol": round(t_symbolic, 3), "numeric_device_incl_pattern_of_L": round(t_numeric, 3),
                         "solve_plan": round(t_plan, 3), "matrix_core_fragments": round(t_plan_mfma, 3)},
            "exact_order": {"ms_per_batch": round(ms_exact, 4), "solves_per_s_per_gpu": round(k / (ms_exact * 1e-3), 1),
                            "note": "default order of every plan: bit-identical to cs_lsolve + cs_ltsolve"}}

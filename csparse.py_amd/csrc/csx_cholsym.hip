@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "csx_internal.h"
+#include "csx_sweep.h"
 
 namespace csx {
 
@@ -340,6 +341,71 @@ using namespace csx;
 // cs_schol with natural ordering (csparse.py:2051-2072) for a device-resident matrix: the elimination tree
 // on the host (Liu's algorithm with path compression is sequential and O(nnz)), the column counts on the
 // device from the same row-subtree walks cs_chol uses.  parent[n], cp[n+1] are host arrays.
+// Elimination tree (csparse.py:1136-1169, ata = False) of a matrix whose graph falls into many small connected
+// components: Liu's algorithm is sequential in the columns of ONE component but components do not interact,
+// so each gets a thread that runs the reference's loop (ancestor path compression included) on its own
+// columns in ascending order.  G-spd (78 125 blocks of 64): 0.6 s on one host core incl. the copy -> see DESIGN.md.
+__global__ __launch_bounds__(64) void k_etree_components(int32_t ncomp, const Tree *__restrict__ comps,
+                                                         const uint32_t *__restrict__ nodes,
+                                                         const int32_t *__restrict__ Ap, const int32_t *__restrict__ Ai,
+                                                         int32_t *parent, int32_t *ancestor) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncomp) return;
+    const Tree t = comps[c];
+    for (int32_t a = 0; a < t.count; a++) {
+        const int32_t k = (int32_t)nodes[t.first + a];
+        parent[k] = -1;
+        ancestor[k] = -1;
+        for (int32_t p = Ap[k]; p < Ap[k + 1]; p++) {
+            int32_t i = Ai[p];
+            while (i != -1 && i < k) {          // the rows of column k above the diagonal are in k's component
+                const int32_t inext = ancestor[i];
+                ancestor[i] = k;
+                if (inext == -1) parent[i] = k;
+                i = inext;
+            }
+        }
+    }
+}
+
+constexpr int ETREE_COMP_MAX = 2048;    // columns per component for the one-thread-per-component kernel
+constexpr int ETREE_COMP_MIN_COUNT = 2048;
+
+// *done = true when the tree was built on the device (parent[] on the host filled)
+static int etree_by_components(const Csc *A, int32_t *parent_host, bool *done, bool *bad_index) {
+    *done = false;
+    *bad_index = false;
+    const int32_t n = A->n;
+    if (n < ETREE_COMP_MIN_COUNT) return CSX_OK;
+    hipStream_t s = ctx().stream;
+    DevScope tmp;
+    int32_t *root = nullptr, *d_parent = nullptr, *d_anc = nullptr;
+    uint32_t *nodes = nullptr;
+    CSX_TRY(tmp.alloc(&root, (size_t)n));
+    CSX_TRY(connected_components(n, A->p, A->i, 0, 0, 0, root, bad_index));
+    if (*bad_index) return CSX_OK;
+    CSX_TRY(tmp.alloc(&nodes, (size_t)n));
+    Tree *comps = nullptr;
+    int32_t ncomp = 0, maxc = 0;
+    int st = group_by_root(n, root, nodes, nullptr, &comps, &ncomp, &maxc);
+    if (st == CSX_OK && ncomp >= ETREE_COMP_MIN_COUNT && maxc <= ETREE_COMP_MAX) {
+        st = tmp.alloc(&d_parent, (size_t)n);
+        if (st == CSX_OK) st = tmp.alloc(&d_anc, (size_t)n);
+        if (st == CSX_OK) {
+            hipLaunchKernelGGL(k_etree_components, dim3((unsigned)((ncomp + 63) / 64)), dim3(64), 0, s, ncomp, comps, nodes,
+                               A->p, A->i, d_parent, d_anc);
+            if (hipGetLastError() != hipSuccess ||
+                hipMemcpyAsync(parent_host, d_parent, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess ||
+                hipStreamSynchronize(s) != hipSuccess)
+                st = CSX_ERUNTIME;
+            else
+                *done = true;
+        }
+    }
+    dfree(comps);
+    return st;
+}
+
 extern "C" int csx_schol(csx_handle_t hA, int32_t *parent, int32_t *cp) {
     CSX_TRY(require_ready());
     Csc *A = csc(hA);
@@ -350,12 +416,17 @@ extern "C" int csx_schol(csx_handle_t hA, int32_t *parent, int32_t *cp) {
         return CSX_OK;
     }
     hipStream_t s = ctx().stream;
-    std::unique_ptr<int32_t[]> hp(new int32_t[(size_t)n + 1]), hi(new int32_t[(size_t)A->nnz + 1]);
-    CSX_HIP(hipMemcpyAsync(hp.get(), A->p, ((size_t)n + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    if (A->nnz) CSX_HIP(hipMemcpyAsync(hi.get(), A->i, (size_t)A->nnz * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    CSX_HIP(hipStreamSynchronize(s));
-    for (int32_t q = 0; q < A->nnz; q++)
-        if (hi[(size_t)q] < 0 || hi[(size_t)q] >= n) return CSX_EINVAL;
-    etree_of_csc(n, hp.get(), hi.get(), parent);
+    bool on_device = false, bad_index = false;
+    CSX_TRY(etree_by_components(A, parent, &on_device, &bad_index));
+    if (bad_index) return CSX_EINVAL;
+    if (!on_device) {   // one big component (or a small matrix): Liu's algorithm on the host
+        std::unique_ptr<int32_t[]> hp(new int32_t[(size_t)n + 1]), hi(new int32_t[(size_t)A->nnz + 1]);
+        CSX_HIP(hipMemcpyAsync(hp.get(), A->p, ((size_t)n + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        if (A->nnz) CSX_HIP(hipMemcpyAsync(hi.get(), A->i, (size_t)A->nnz * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        CSX_HIP(hipStreamSynchronize(s));
+        for (int32_t q = 0; q < A->nnz; q++)
+            if (hi[(size_t)q] < 0 || hi[(size_t)q] >= n) return CSX_EINVAL;
+        etree_of_csc(n, hp.get(), hi.get(), parent);
+    }
     return chol_symbolic_device(A, parent, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, cp);
 }

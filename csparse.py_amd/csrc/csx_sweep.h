@@ -16,6 +16,12 @@ struct Tree {
 // are loaded coalesced (one term per lane) and broadcast with v_readlane; each lane applies them
 // to its own right-hand side in the reference's order (multiply and subtract rounded
 // separately), so the result is bit-identical to cs_lsolve + cs_ltsolve on this L.
+// csx_components.hip
+int connected_components(int32_t n, const int32_t *ptr, const int32_t *idx, int sf, int sl, int order, int32_t *root,
+                         bool *malformed);
+int group_by_root(int32_t n, const int32_t *root, uint32_t *nodes, int32_t *comp_of_pos, Tree **comps_out,
+                  int32_t *ncomp_out, int32_t *max_count);
+
 #pragma clang fp contract(off)
 struct TermRegs {  // up to 64 terms of one row, one per lane
     int32_t i;

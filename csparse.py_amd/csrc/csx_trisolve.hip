@@ -457,83 +457,6 @@ __global__ __launch_bounds__(256) void k_permute(const int32_t *__restrict__ p, 
 // rows are grouped by component (stable sort by root keeps them ascending = a valid sweep order, descending
 // for the backward kinds), and each component becomes a packed program for the fused in-LDS sweep of
 // csx_sweep.h -- one launch, no level sets, nothing copied to the host but five counters.
-__global__ __launch_bounds__(256) void k_cc_init(int32_t n, int32_t *parent) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < n) parent[r] = (int32_t)r;
-}
-
-__device__ __forceinline__ int32_t cc_root(const int32_t *parent, int32_t r) {
-    int32_t p = parent[r];
-    while (p != r) {
-        r = p;
-        p = parent[r];
-    }
-    return r;
-}
-
-// one wave per row; flags[0] |= some hook happened, flags[1] |= a source does not precede its row (malformed)
-__global__ __launch_bounds__(256) void k_cc_hook(int32_t n, const int32_t *__restrict__ ptr,
-                                                 const int32_t *__restrict__ idx, int sf, int sl, int forward,
-                                                 int32_t *parent, int *flags) {
-    const int lane = threadIdx.x & 63;
-    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (r >= n) return;
-    const int32_t b = ptr[r] + sf, e = ptr[r + 1] - sl;
-    int32_t rr = -1;
-    for (int32_t q = b + lane; q < e; q += 64) {
-        const int32_t j = idx[q];
-        if (j < 0 || j >= n || (forward ? j >= r : j <= r)) {
-            flags[1] = 1;
-            continue;
-        }
-        if (rr < 0) rr = cc_root(parent, (int32_t)r);
-        int32_t a = rr, c = cc_root(parent, j);
-        while (a != c) {                     // hook the larger root under the smaller one
-            const int32_t hi = a > c ? a : c, lo = a > c ? c : a;
-            const int32_t old = atomicMin(&parent[hi], lo);
-            if (old == hi) {
-                flags[0] = 1;
-                break;
-            }
-            a = cc_root(parent, old < lo ? old : lo);   // somebody else re-parented hi: merge with that tree
-            c = cc_root(parent, old < lo ? lo : old);
-            flags[0] = 1;
-        }
-        rr = a < c ? a : c;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_cc_flatten(int32_t n, int32_t *parent) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < n) parent[r] = cc_root(parent, (int32_t)r);
-}
-
-__global__ __launch_bounds__(256) void k_iota_u32(int32_t n, uint32_t *v) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < n) v[r] = (uint32_t)r;
-}
-
-// sorted_root[k] starts a component when it differs from its left neighbour
-__global__ __launch_bounds__(256) void k_cc_heads(int32_t n, const uint32_t *__restrict__ sroot, int32_t *head) {
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n) head[k] = (k == 0 || sroot[k] != sroot[k - 1]) ? 1 : 0;
-}
-
-// component c starts at the c-th head; its size is the distance to the next head
-__global__ __launch_bounds__(256) void k_cc_first(int32_t n, const int32_t *__restrict__ head,
-                                                  const int32_t *__restrict__ hscan, Tree *comps) {
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n && head[k]) comps[hscan[k]].first = (int32_t)k;
-}
-
-__global__ __launch_bounds__(256) void k_cc_count(int32_t n, int32_t ncomp, Tree *comps, int *stats) {
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= ncomp) return;
-    const int32_t cnt = (c + 1 < ncomp ? comps[c + 1].first : n) - comps[c].first;
-    comps[c].count = cnt;
-    atomicMax(&stats[0], cnt);
-}
-
 __global__ __launch_bounds__(256) void k_cc_local_id(int32_t ncomp, const Tree *__restrict__ comps,
                                                      const uint32_t *__restrict__ srow, int32_t *local_id) {
     const int lane = threadIdx.x & 63;
@@ -576,12 +499,6 @@ __global__ __launch_bounds__(256) void k_prog_fill(int32_t n, const int32_t *__r
         prog_val[o + q] = val[gb + q];
     }
     if (lane == 0) prog_diag[k] = diag[row];
-}
-
-__global__ __launch_bounds__(256) void k_comp_of_pos(int32_t n, const int32_t *__restrict__ head,
-                                                     const int32_t *__restrict__ hscan, int32_t *comp_of_pos) {
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n) comp_of_pos[k] = hscan[k] + head[k] - 1;
 }
 
 // One wave = one component x 64 right-hand sides: X tile in LDS, one sweep in the plan's direction, every
@@ -884,56 +801,31 @@ static int analyse_components(TriPlan *P) {
     if (n < COMP_MIN_COUNT) return CSX_OK;
     hipStream_t s = ctx().stream;
     DevScope tmp;
-    int32_t *parent = nullptr, *head = nullptr, *hscan = nullptr, *local_id = nullptr, *len = nullptr, *comp_of_pos = nullptr;
-    uint32_t *rows = nullptr, *sroot = nullptr, *srow = nullptr;
+    int32_t *root = nullptr, *local_id = nullptr, *len = nullptr, *comp_of_pos = nullptr;
+    uint32_t *srow = nullptr;
     int *flags = nullptr;
-    CSX_TRY(tmp.alloc(&parent, (size_t)n));
+    CSX_TRY(tmp.alloc(&root, (size_t)n));
     CSX_TRY(tmp.alloc(&flags, 4));
-    const unsigned nb = (unsigned)(((int64_t)n + 255) / 256), nbw = (unsigned)(((int64_t)n + 3) / 4);
-    hipLaunchKernelGGL(k_cc_init, dim3(nb), dim3(256), 0, s, n, parent);
-    int hflags[4] = {0, 0, 0, 0};
-    for (int it = 0; it < 64; it++) {
-        CSX_HIP(hipMemsetAsync(flags, 0, 4 * sizeof(int), s));
-        hipLaunchKernelGGL(k_cc_hook, dim3(nbw), dim3(256), 0, s, n, P->ptr, P->idx, P->skip_first, P->skip_last,
-                           P->forward ? 1 : 0, parent, flags);
-        hipLaunchKernelGGL(k_cc_flatten, dim3(nb), dim3(256), 0, s, n, parent);
-        CSX_HIP(hipMemcpyAsync(hflags, flags, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
-        CSX_HIP(hipStreamSynchronize(s));
-        if (hflags[1]) return CSX_OK;     // malformed triangle: the literal transcription handles it
-        if (!hflags[0]) break;
-        if (it == 63) return CSX_OK;      // did not settle (not expected): keep level scheduling
-    }
-    // group rows by root: stable, so rows stay ascending inside a component
-    CSX_TRY(tmp.alloc(&rows, (size_t)n));
-    CSX_TRY(tmp.alloc(&sroot, (size_t)n));
-    CSX_TRY(tmp.alloc(&srow, (size_t)n));
-    CSX_TRY(tmp.alloc(&head, (size_t)n + 1));
-    CSX_TRY(tmp.alloc(&hscan, (size_t)n + 1));
-    hipLaunchKernelGGL(k_iota_u32, dim3(nb), dim3(256), 0, s, n, rows);
-    CSX_TRY(stable_sort_by_key((const uint32_t *)parent, rows, nullptr, n, (uint32_t)n, sroot, srow, nullptr));
-    hipLaunchKernelGGL(k_cc_heads, dim3(nb), dim3(256), 0, s, n, sroot, head);
-    int64_t ncomp = 0;
-    CSX_TRY(scan_exclusive_i32(head, hscan, n, &ncomp));
-    if (ncomp < COMP_MIN_COUNT) return CSX_OK;
+    bool malformed = false;
+    CSX_TRY(connected_components(n, P->ptr, P->idx, P->skip_first, P->skip_last, P->forward ? 1 : 2, root, &malformed));
+    if (malformed) return CSX_OK;         // the literal transcription of the reference loop handles it
     Tree *comps = nullptr;
-    CSX_TRY(dalloc(&comps, (size_t)ncomp));
+    int32_t ncomp = 0, maxc = 0;
+    CSX_TRY(tmp.alloc(&srow, (size_t)n));
+    CSX_TRY(tmp.alloc(&comp_of_pos, (size_t)n));
+    CSX_TRY(group_by_root(n, root, srow, comp_of_pos, &comps, &ncomp, &maxc));
     P->comps = comps;
-    CSX_HIP(hipMemsetAsync(flags, 0, 4 * sizeof(int), s));
-    hipLaunchKernelGGL(k_cc_first, dim3(nb), dim3(256), 0, s, n, head, hscan, comps);
-    hipLaunchKernelGGL(k_cc_count, dim3((unsigned)((ncomp + 255) / 256)), dim3(256), 0, s, n, (int32_t)ncomp, comps, flags);
-    CSX_HIP(hipMemcpyAsync(hflags, flags, sizeof(int), hipMemcpyDeviceToHost, s));
-    CSX_HIP(hipStreamSynchronize(s));
-    if (hflags[0] > COMP_MAX_ROWS) return CSX_OK;
+    if (ncomp < COMP_MIN_COUNT || maxc > COMP_MAX_ROWS) return CSX_OK;
+    const unsigned nbw = (unsigned)(((int64_t)n + 3) / 4);
+    int hflags[4] = {maxc, 0, 0, 0};
     P->ncomp = (int32_t)ncomp;
     P->comp_max = hflags[0];
     CSX_TRY(tmp.alloc(&local_id, (size_t)n));
     CSX_TRY(tmp.alloc(&len, (size_t)n + 1));
-    CSX_TRY(tmp.alloc(&comp_of_pos, (size_t)n));
     const unsigned ncw = (unsigned)((ncomp + 3) / 4);
     hipLaunchKernelGGL(k_cc_local_id, dim3(ncw), dim3(256), 0, s, P->ncomp, comps, srow, local_id);
     hipLaunchKernelGGL(k_prog_len, dim3(ncw), dim3(256), 0, s, P->ncomp, comps, srow, P->ptr, P->skip_first, P->skip_last,
                        P->forward ? 1 : 0, len);
-    hipLaunchKernelGGL(k_comp_of_pos, dim3(nb), dim3(256), 0, s, n, head, hscan, comp_of_pos);
     CSX_TRY(dalloc(&P->prog_ptr, (size_t)n + 1));
     int64_t total = 0;
     CSX_TRY(scan_exclusive_i32(len, P->prog_ptr, n, &total));

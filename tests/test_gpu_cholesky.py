@@ -334,3 +334,46 @@ def test_cholsol_with_the_fill_reducing_ordering(cs, name):
     X = dB.numpy()
     assert np.max(np.abs(X[:, 0] - x0)) <= 1e-9 * np.max(np.abs(x0))
     assert np.max(np.abs(X[:, 1] - 3.0 * x0)) <= 3e-9 * np.max(np.abs(x0))
+
+
+@pytest.mark.parametrize("shape", ["gspd_8", "mixed"])
+def test_schol_etree_by_components_on_device(cs, shape):
+    """A matrix with thousands of small components gets its elimination tree on the device (one thread per
+    component running the reference's loop, csparse.py:1136-1169): same parent / cp as the host path and the
+    plain-C oracle."""
+    if shape == "gspd_8":
+        Ap, Ai, Ax = synth.gspd(3000, 8, 11)
+        n = 3000 * 8
+    else:
+        # blocks of size 1..40 with random symmetric patterns inside, in a random interleaving of the indices
+        rng = np.random.default_rng(21)
+        sizes = rng.integers(1, 41, size=2500)
+        n = int(sizes.sum())
+        perm = rng.permutation(n)                       # component members are NOT contiguous
+        rows, cols = [np.arange(n)], [np.arange(n)]
+        base = 0
+        for m in sizes.tolist():
+            mem = perm[base:base + m]
+            if m > 1:
+                e = rng.integers(0, m, size=(2 * m, 2))
+                ch = np.stack([np.arange(m - 1), np.arange(1, m)], axis=1)    # a chain keeps the block connected
+                e = np.concatenate([e, ch])
+                rows += [mem[e[:, 0]], mem[e[:, 1]]]
+                cols += [mem[e[:, 1]], mem[e[:, 0]]]
+            base += m
+        r, c = np.concatenate(rows), np.concatenate(cols)
+        order = np.lexsort((r, c))
+        r, c = r[order], c[order]
+        keep = np.ones(len(r), bool)
+        keep[1:] = (r[1:] != r[:-1]) | (c[1:] != c[:-1])
+        r, c = r[keep], c[keep]
+        Ap = np.concatenate([[0], np.cumsum(np.bincount(c, minlength=n))]).astype(np.int32)
+        Ai = r.astype(np.int32)
+        Ax = np.where(r == c, 100.0, 1.0)
+    A = _host_cs(cs, n, n, Ap, Ai, Ax)
+    Sh = cs.cs_schol(0, A)                       # host lists -> csx_schol_host
+    cs.cs_pin(A)
+    Sd = cs.cs_schol(0, A)                       # device-resident -> csx_schol, tree by components
+    assert Sd.parent == Sh.parent and Sd.cp == Sh.cp
+    parent, cp = CO.schol(n, Ap, Ai)
+    assert Sd.parent == parent.tolist() and Sd.cp == cp.tolist()
