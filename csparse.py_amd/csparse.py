@@ -874,6 +874,39 @@ def cs_chol(A, S):
     return N
 
 
+def cs_updown(L, sigma, C, parent):
+    """Sparse Cholesky rank-1 update (sigma = +1) / downdate (-1): L L' + sigma w w' with w = the one column of
+    C, in place (csparse.py:2318-2365).  True on success; False on bad input or when the downdate is not positive
+    definite (L is then changed exactly as far as the reference's loop gets).  L.x is bit-identical to the
+    reference's.  A list-backed L is updated in its own list objects; a device-backed L stays on the device."""
+    if not CS_CSC(L) or not CS_CSC(C) or parent is None:
+        return False
+    if not _meta(L)[1]:
+        raise TypeError("'NoneType' object is not subscriptable")
+    cnz = C.p[1] - C.p[0]
+    if cnz <= 0:
+        return True
+    ci = _csx.i32(C.i[C.p[0]:C.p[1]])
+    cx = _csx.f64(C.x[C.p[0]:C.p[1]])
+    par = _csx.i32(parent[:L.n])
+    ok = _csx.C.c_int(0)
+    lazy = L._lazy
+    with _Resident(L) as dL:
+        for h in dL.plans.values():          # triangular-solve plans hold copies of the old values
+            _csx.free(h)
+        dL.plans.clear()
+        st = _csx.lib().csx_updown(dL.handle, int(sigma), cnz, _csx.pi(ci), _csx.pd(cx), _csx.pi(par), ok)
+        if st == _csx.EINVAL:
+            raise IndexError("list index out of range")
+        _csx.check(st, "csx_updown")
+        if not lazy:                         # the caller holds L.x: update that list in place, like the reference
+            m, n, nnz, hv = dL.info()
+            x = np.empty(max(nnz, 1), dtype=np.float64)
+            _csx.check(_csx.lib().csx_csc_download(dL.handle, None, None, _csx.pd(x)), "csx_csc_download")
+            L._x[:nnz] = x[:nnz].tolist()
+    return bool(ok.value)
+
+
 def cs_cholsol(order, A, b):
     """Solve A x = b, A symmetric positive definite, upper triangle used; b is
     overwritten (csparse.py:622-644).  b may be a list (one system) or a dvec

@@ -207,6 +207,13 @@ int csx_norm1(csx_handle_t A, double *out);
 /* Columns [first, first + count) of A as a new m x count matrix: the unit of a column-sharded SpMV. */
 int csx_csc_col_block(csx_handle_t A, int32_t first, int32_t count, csx_handle_t *out);
 
+/* cs_updown, csparse.py:2318-2365: L L' + sigma w w' (sigma = +1 update, -1 downdate) applied to the device
+ * factor L in place; w is given as host arrays (rows Ci[0..cnz), values Cx), parent = elimination tree (host,
+ * length n).  *ok = 0 when a downdate is not positive definite (L is then changed exactly as far as the
+ * reference's loop gets).  Solve plans built from L before the call hold stale values: rebuild them. */
+int csx_updown(csx_handle_t L, int sigma, int32_t cnz, const int32_t *Ci, const double *Cx, const int32_t *parent,
+               int *ok);
+
 /* cs_lu, csparse.py:1370-1451 (+ cs_spsolve :2078-2113), natural column order: host C++
  * left-looking LU with threshold partial pivoting.  It produces the L (unit diagonal first)
  * and U (diagonal last) that cs_lsolve / cs_usolve consume in cs_lusol (csparse.py:1474-1477).

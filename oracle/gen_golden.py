@@ -318,7 +318,64 @@ def config2_fixture():
     return {"n": n, "nnz": C.p[n], "y_first": y[0], "y_last": y[-1]}
 
 
+def updown_fixture():
+    """cs_updown (csparse.py:2318-2365) runs unmodified; cs_chol does not, so the factor it is given
+    comes from this repository's restated cs_chol (oracle/csparse_oracle.py) -- an INPUT; every expected output
+    below is what the unmodified reference's cs_updown makes of it.  W is built as csparse_test.py:680-690 does
+    (column n/2 of L, scaled by seeded random numbers)."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import csparse_oracle as O
+    d, meta = {}, {}
+    rng = random.Random(20240613)
+    for name in ("bcsstk01", "bcsstk16"):
+        T, A, C, sym = get_problem(name)
+        n = C.n
+        Co = O.cs_spalloc(n, n, len(C.i), True, False)
+        Co.p, Co.i, Co.x = list(C.p), list(C.i), list(C.x)
+        S = O.cs_schol(0, Co)
+        N = O.cs_chol(Co, S)
+        L = mk(n, n, N.L.p, N.L.i, N.L.x)                 # a reference `cs` object holding that factor
+        lnz = L.p[n]
+        k = n // 2
+        cnt = L.p[k + 1] - L.p[k]
+        W = R.cs_spalloc(n, 1, n, True, False)
+        W.p[0], W.p[1] = 0, cnt
+        s0 = L.x[L.p[k]]
+        for q in range(cnt):
+            W.i[q] = L.i[L.p[k] + q]
+            W.x[q] = s0 * rng.random()
+        big = name == "bcsstk16"
+        pre = name + "_"
+        d[pre + "parent"] = I(S.parent)
+        d[pre + "W_i"], d[pre + "W_x"] = I(W.i[:cnt]), F(W.x[:cnt])
+        d[pre + "W2_x"] = F([v if q == 0 else 50.0 * v for q, v in enumerate(W.x[:cnt])])
+        if not big:
+            d[pre + "L_p"], d[pre + "L_i"], d[pre + "L_x"] = I(L.p), I(L.i[:lnz]), F(L.x[:lnz])
+        ok_up = R.cs_updown(L, +1, W, S.parent)
+        up = F(L.x[:lnz])
+        ok_down = R.cs_updown(L, -1, W, S.parent)
+        down = F(L.x[:lnz])
+        # a downdate that is not positive definite: the reference stops part way and leaves L partly changed
+        W2 = clone(W)
+        W2.x = [v if q == 0 else 50.0 * v for q, v in enumerate(W.x)]   # first column passes, a later one fails
+        ok_bad = R.cs_updown(L, -1, W2, S.parent)
+        bad = F(L.x[:lnz])
+        meta[name] = dict(n=n, lnz=lnz, k=k, ok_update=bool(ok_up), ok_downdate=bool(ok_down), ok_not_pd=bool(ok_bad),
+                          sha_up=sha(up), sha_down=sha(down), sha_not_pd=sha(bad))
+        if big:
+            sel = list(range(0, lnz, max(1, lnz // 2000)))
+            d[pre + "sample"] = I(sel)
+            d[pre + "up_s"], d[pre + "down_s"], d[pre + "bad_s"] = up[sel], down[sel], bad[sel]
+        else:
+            d[pre + "up"], d[pre + "down"], d[pre + "bad"] = up, down, bad
+    np.savez_compressed(os.path.join(OUT, "updown.npz"), **d)
+    return meta
+
+
 def main():
+    if sys.argv[1:] == ["updown"]:
+        print(json.dumps(updown_fixture(), indent=1))
+        return
     if sys.argv[1:] == ["config2"]:
         print("config2", config2_fixture())
         return
@@ -330,6 +387,7 @@ def main():
     print("bcsstk16", json.dumps(meta["bcsstk16"])[:300])
     synthetic_fixture(20240601)
     meta["config2_bcsstk16"] = config2_fixture()
+    meta["updown"] = updown_fixture()
     with open(os.path.join(OUT, "meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)
 
