@@ -32,6 +32,30 @@ import csparse as cs  # noqa: E402
 PEAK = 8000.0
 
 
+SKIP_CPU = False
+
+
+def cpu_port(label, fn, units, unit_name, sample):
+    """One-core CPU baseline beside a GPU figure: the pure-Python port (oracle/csparse_oracle.py -- the reference is
+    pure Python, single-threaded), timed here on the GPU box's host, best of 2, on a bounded sample."""
+    if SKIP_CPU:
+        return None
+    best = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        fn()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return {"value": units / best, "unit": unit_name, "cores": 1, "kind": "port",
+            "sample": "%s: %s, %.3f s" % (label, sample, best)}
+
+
+def oracle_cs(O, m, n, p, i, x):
+    A = O.cs_spalloc(m, n, len(i), True, False)
+    A.p, A.i, A.x = np.asarray(p).tolist(), np.asarray(i).tolist(), np.asarray(x).tolist()
+    return A
+
+
 def timed(fn, reps):
     fn()
     _csx.sync()
@@ -64,8 +88,12 @@ def config2():
         ms = timed(lambda: cs.cs_gaxpy(A, dx, dy, mode), 200)
         out[name] = {"us_per_call": round(ms * 1e3, 2), "max_rel_err": err}
     by = 12 * len(i) + 4 * (n + 1) + 8 * n + 16 * n
+    import csparse_oracle as O
+    Ao, xl = oracle_cs(O, n, n, p, i, x), xv.tolist()
+    cpu = cpu_port("cs_gaxpy", lambda: O.cs_gaxpy(Ao, xl, [0.0] * n), len(i) / 1e6, "M nnz/s", "bcsstk16 sym-expanded, full size")
     return {"config": "cs_gaxpy bcsstk16 sym-expanded (4884^2, %d nnz)" % len(i), "algorithmic_bytes": by,
-            "modes": out, "note": "3.6 MB working set: L2-resident, launch-latency-bound; no roofline claim"}
+            "modes": out, "note": "3.6 MB working set: L2-resident, launch-latency-bound; no roofline claim",
+            "cpu_baseline": cpu}
 
 
 def config3():
@@ -114,21 +142,28 @@ def config3():
         res["nrhs_%d" % k] = {"ms_lsolve_plus_usolve": round(ms, 4), "solves_per_s": round(k / (ms * 1e-3), 1),
                               "bit_identical_to_c_oracle": exact, "first_call_incl_analysis_s": round(first, 3),
                               "algorithmic_GBps": round(by / (ms * 1e-3) / 1e9, 2)}
-    import ctypes
-    lv = ctypes.c_int32()
-    _csx.check(_csx.lib().csx_tri_info(L._dev.plans[cs.TRI_L], None, lv, None))
+    comp = _csx.C.c_int32()
+    _csx.check(_csx.lib().csx_tri_components(L._dev.plans[cs.TRI_L], comp))
+    import csparse_oracle as O
+    Lo, Uo = oracle_cs(O, n, n, Lp, Li, Lx), oracle_cs(O, n, n, Up, Ui, Ux)
+
+    def cpu_solve():
+        y = pb.tolist()
+        O.cs_lsolve(Lo, y)
+        O.cs_usolve(Uo, y)
+    cpu = cpu_port("cs_lsolve + cs_usolve", cpu_solve, 1.0, "solves/s", "W at full size (n=%d, nnz(L)+nnz(U)=%d)" % (n, int(Lp[-1] + Up[-1])))
     # residual of the whole cs_lusol sequence against A
     r = CO.gaxpy(n, n, Ap, Ai, Ax, ref_x, -b)
     return {"config": "cs_lusol solve phase on W (west0067 tiling, n=%d, nnz(A)=%d, nnz(L)+nnz(U)=%d)"
                       % (n, nb * bnnz, int(Lp[-1] + Up[-1])),
-            "host_lu_s": round(t_lu, 3), "levels_L": lv.value, "results": res,
-            "residual_inf": float(np.max(np.abs(r)))}
+            "host_lu_s": round(t_lu, 3), "components_of_L": comp.value, "results": res,
+            "residual_inf": float(np.max(np.abs(r))), "cpu_baseline": cpu}
 
 
 def config4(n=1000000, per_col=32):
     lib = _csx.lib()
     hA = _csx.new_handle()
-    _csx.check(lib.csx_gen_grand(n, per_col, 20240605, hA))
+    _csx.check(lib.csx_gen_grand_uniform(n, per_col, 20240605, hA))   # S: 32 distinct uniform rows per column
     hB = _csx.new_handle()
     t0 = time.perf_counter()
     _csx.check(lib.csx_transpose(hA, 1, hB))
@@ -169,6 +204,14 @@ def config4(n=1000000, per_col=32):
            "identity_C1_eq_A_At1_max_rel": ident}
     for h in (hA, hB, hC, ones):
         _csx.free(h)
+    import csparse_oracle as O
+    import synth
+    nc = 20000
+    Sp, Si, Sx = synth.grand_uniform(nc, per_col, 20240605)
+    So = oracle_cs(O, nc, nc, Sp, Si, Sx)
+    STo = O.cs_transpose(So, True)
+    out["cpu_baseline"] = cpu_port("cs_multiply A*A'", lambda: O.cs_multiply(So, STo), nc * per_col * per_col / 1e9,
+                                   "G products/s", "S at n=%d (%d per column, %d products)" % (nc, per_col, nc * per_col * per_col))
     return out
 
 
@@ -239,7 +282,7 @@ def assembly(n=1000000, per_col=32):
 def transpose_grand(n=5000000, per_col=64):
     lib = _csx.lib()
     hA = _csx.new_handle()
-    _csx.check(lib.csx_gen_grand(n, per_col, 20240602, hA))
+    _csx.check(lib.csx_gen_grand_uniform(n, per_col, 20240602, hA))
     hT = _csx.new_handle()
     _csx.check(lib.csx_transpose(hA, 1, hT))
     _csx.sync()
@@ -260,9 +303,17 @@ def transpose_grand(n=5000000, per_col=64):
     by = 24 * nnz + 8 * (n + 1)
     for h in (hA, hT, hTT):
         _csx.free(h)
-    return {"config": "cs_transpose on G-rand (%d x %d, %d nnz/col)" % (n, n, per_col), "s": round(dt, 4),
+    import csparse_oracle as O
+    import synth
+    nc = 100000
+    Gp, Gi, Gx = synth.grand_uniform(nc, per_col, 20240602)
+    Go = oracle_cs(O, nc, nc, Gp, Gi, Gx)
+    cpu = cpu_port("cs_transpose", lambda: O.cs_transpose(Go, True), nc * per_col / 1e6, "M nnz/s",
+                   "G-rand at n=%d (%d nnz)" % (nc, nc * per_col))
+    return {"config": "cs_transpose on G-rand (%d x %d, %d nnz/col, uniform row draw)" % (n, n, per_col), "s": round(dt, 4),
             "algorithmic_GBps": round(by / dt / 1e9, 1), "frac_of_peak": round(by / dt / 1e9 / PEAK, 4),
-            "double_transpose_restores_p": bool((p1 == p2).all())}
+            "M_nnz_per_s": round(nnz / dt / 1e6, 1),
+            "double_transpose_restores_p": bool((p1 == p2).all()), "cpu_baseline": cpu}
 
 
 def main():
@@ -270,7 +321,10 @@ def main():
     ap.add_argument("--skip-spgemm", action="store_true")
     ap.add_argument("--only", default=None, help="run one section: spmv | lusolve | spgemm | transpose | assembly")
     ap.add_argument("--skip-transpose", action="store_true")
+    ap.add_argument("--skip-cpu", action="store_true", help="no one-core CPU baselines beside the GPU figures")
     a = ap.parse_args()
+    global SKIP_CPU
+    SKIP_CPU = a.skip_cpu
     _csx.init()
     print(json.dumps({"device": _csx.device_info()}))
     want = lambda name: a.only in (None, name)
