@@ -229,8 +229,10 @@ class option(object):
         check(lib().csx_set_option(self.name, self.value), "csx_set_option")
         return self
 
+    DEFAULTS = {b"tri.levels_where": 0}
+
     def __exit__(self, *exc):
-        check(lib().csx_set_option(self.name, 1), "csx_set_option")
+        check(lib().csx_set_option(self.name, self.DEFAULTS.get(self.name, 1)), "csx_set_option")
         return False
 
 

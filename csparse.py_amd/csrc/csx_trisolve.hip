@@ -1034,12 +1034,178 @@ static int analyse(const Csc *T, int kind, TriPlan **out) {
     return CSX_OK;
 }
 
+
+// ---- level sets and chain-walker tables on the device ----------------------------------------------------
+// For big factors the host analysis below starts with a copy of the whole gather structure (2 GB over PCIe at
+// lnz = 1.6e8) and then walks it on one core.  On the device: level by level, every unresolved row looks at its
+// sources; it joins level L when all of them are in levels < L (pull form: only the gather structure the plan
+// already has; a row at level l is inspected l + 1 times, which is cheap for the wide, shallow graphs big
+// factors have -- deep chains of small factors stay with the host pass, ensure_schedule picks by size).
+__global__ __launch_bounds__(256) void k_lv_init(int32_t n, int32_t *level) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) level[r] = -1;
+}
+
+// one wave per row; stats[0] += rows resolved in this round, stats[1] |= malformed (a source does not precede)
+__global__ __launch_bounds__(256) void k_lv_round(int32_t n, const int32_t *__restrict__ ptr,
+                                                  const int32_t *__restrict__ idx, int sf, int sl, int forward,
+                                                  int32_t L, int32_t *level, int *stats) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (r >= n) return;
+    if (level[r] >= 0) return;                              // wave-uniform
+    const int32_t b = ptr[r] + sf, e = ptr[r + 1] - sl;
+    bool ready = true, bad = false;
+    for (int32_t q = b + lane; q < e; q += 64) {
+        const int32_t j = idx[q];
+        if (j < 0 || j >= n || (forward ? j >= r : j <= r)) {
+            bad = true;
+            continue;
+        }
+        const int32_t lj = level[j];
+        if (lj < 0 || lj >= L) ready = false;               // unresolved, or resolved in THIS round by another wave
+    }
+    if (__ballot(bad) != 0ull) {
+        if (lane == 0) stats[1] = 1;
+        return;
+    }
+    if (__ballot(!ready) == 0ull && lane == 0) {
+        level[r] = L;
+        atomicAdd(&stats[0], 1);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_iota_u32_tri(int32_t n, uint32_t *v) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) v[r] = (uint32_t)r;
+}
+
+__global__ __launch_bounds__(256) void k_lv_pos_of(int32_t n, const uint32_t *__restrict__ order, int32_t *pos_of) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n) pos_of[order[q]] = (int32_t)q;
+}
+
+// the tables of the blocked chain walker (see k_tri_chain): one thread per position of the level order
+__global__ __launch_bounds__(256) void k_lv_chain_tables(int32_t n, const uint32_t *__restrict__ order,
+                                                         const int32_t *__restrict__ pos_of,
+                                                         const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx,
+                                                         int sf, int sl, int32_t *npre, int32_t *nin, int8_t *tslot,
+                                                         unsigned long long *sums) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long suffix = 0, all = 0;
+    if (q < n) {
+        const int32_t r = (int32_t)order[q], blk = (int32_t)q & ~(CHB - 1);
+        const int32_t b = ptr[r] + sf, e = ptr[r + 1] - sl;
+        int32_t pre = 0, inb = 0;
+        bool in_prefix = true;
+        for (int32_t t = b; t < e; t++) {
+            const int32_t sp = pos_of[idx[t]];
+            const bool inside = sp >= blk;
+            tslot[t] = inside ? (int8_t)(sp - blk) : (int8_t)-1;
+            if (inside) {
+                in_prefix = false;
+                inb++;
+            }
+            if (in_prefix) pre++;
+        }
+        npre[q] = pre;
+        nin[q] = inb;
+        suffix = (unsigned long long)((e - b) - pre);
+        all = (unsigned long long)(e - b);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        suffix += __shfl_xor(suffix, d, 64);
+        all += __shfl_xor(all, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0 && all) {
+        atomicAdd(&sums[0], suffix);
+        atomicAdd(&sums[1], all);
+    }
+}
+
+constexpr int64_t LV_DEVICE_MIN_TERMS = 4 << 20;   // below this the copy is small and deep chains favour the host pass
+constexpr int LV_MAX_ROUNDS = 4096;
+
+// *done = false: not attempted or gave up (too deep) -> the host pass runs instead
+static int schedule_on_device(TriPlan *P, bool *done) {
+    *done = false;
+    hipStream_t s = ctx().stream;
+    const int32_t n = P->n;
+    DevScope tmp;
+    int32_t *level = nullptr, *pos_of = nullptr;
+    uint32_t *rows = nullptr, *slevel = nullptr, *order = nullptr;
+    int *stats = nullptr;
+    unsigned long long *sums = nullptr;
+    CSX_TRY(tmp.alloc(&level, (size_t)n));
+    CSX_TRY(tmp.alloc(&stats, 2));
+    const unsigned nb = (unsigned)(((int64_t)n + 255) / 256), nbw = (unsigned)(((int64_t)n + 3) / 4);
+    hipLaunchKernelGGL(k_lv_init, dim3(nb), dim3(256), 0, s, n, level);
+    int64_t resolved = 0;
+    int32_t L = 0;
+    for (; resolved < n; L++) {
+        if (L >= LV_MAX_ROUNDS) return CSX_OK;                 // a deep chain: the host pass is the better tool
+        int h[2] = {0, 0};
+        CSX_HIP(hipMemsetAsync(stats, 0, 2 * sizeof(int), s));
+        hipLaunchKernelGGL(k_lv_round, dim3(nbw), dim3(256), 0, s, n, P->ptr, P->idx, P->skip_first, P->skip_last,
+                           P->forward ? 1 : 0, L, level, stats);
+        CSX_HIP(hipMemcpyAsync(h, stats, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+        CSX_HIP(hipStreamSynchronize(s));
+        if (h[1] || h[0] == 0) {                               // malformed triangle: literal transcription of the loop
+            P->scheduled = true;
+            P->sequential = true;
+            P->nlevels = n;
+            *done = true;
+            return CSX_OK;
+        }
+        resolved += h[0];
+    }
+    P->nlevels = L;
+    // rows by level, ascending row inside a level (stable sort of 0..n-1 by level)
+    CSX_TRY(tmp.alloc(&rows, (size_t)n));
+    CSX_TRY(tmp.alloc(&slevel, (size_t)n));
+    CSX_TRY(dalloc(&order, (size_t)n));
+    P->order = (int32_t *)order;
+    hipLaunchKernelGGL(k_iota_u32_tri, dim3(nb), dim3(256), 0, s, n, rows);
+    CSX_TRY(stable_sort_by_key((const uint32_t *)level, rows, nullptr, n, (uint32_t)L, slevel, order, nullptr));
+    CSX_TRY(dalloc(&P->level_ptr, (size_t)L + 1));
+    CSX_TRY(boundaries_from_sorted(slevel, n, L, P->level_ptr));
+    P->level_ptr_h.resize((size_t)L + 1);
+    CSX_HIP(hipMemcpyAsync(P->level_ptr_h.data(), P->level_ptr, ((size_t)L + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    // chain-walker tables
+    CSX_TRY(tmp.alloc(&pos_of, (size_t)n));
+    CSX_TRY(tmp.alloc(&sums, 2));
+    CSX_TRY(dalloc(&P->npre, (size_t)n));
+    CSX_TRY(dalloc(&P->nin, (size_t)n));
+    CSX_TRY(dalloc(&P->tslot, (size_t)P->gnnz + 1));
+    CSX_HIP(hipMemsetAsync(sums, 0, 2 * sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(k_lv_pos_of, dim3(nb), dim3(256), 0, s, n, order, pos_of);
+    hipLaunchKernelGGL(k_lv_chain_tables, dim3(nb), dim3(256), 0, s, n, order, pos_of, P->ptr, P->idx, P->skip_first,
+                       P->skip_last, P->npre, P->nin, P->tslot, sums);
+    unsigned long long hs[2] = {0, 0};
+    CSX_HIP(hipMemcpyAsync(hs, sums, sizeof hs, hipMemcpyDeviceToHost, s));
+    CSX_LAUNCH_CHECK();
+    CSX_HIP(hipStreamSynchronize(s));
+    P->chain_ok = hs[1] > 0 && hs[0] * 4 <= hs[1];
+    P->scheduled = true;
+    *done = true;
+    return CSX_OK;
+}
+
 // Level sets (host, O(nnz)): deferred until a level-scheduled solve needs them, so plans that
 // only feed the fused in-LDS cholsol kernel never pay for the download.
 static int ensure_schedule(TriPlan *P) {
     if (P->scheduled || P->n == 0) return CSX_OK;
     hipStream_t s = ctx().stream;
     const int32_t n = P->n;
+    const int where = ctx().opt.tri_levels_where;   // 0: by size, 1: host, 2: device
+    if (where == 2 || (where == 0 && (int64_t)P->gnnz >= LV_DEVICE_MIN_TERMS)) {
+        bool done = false;
+        CSX_TRY(schedule_on_device(P, &done));
+        if (done) return CSX_OK;
+        dfree(P->order);          // gave up part way (deeper than LV_MAX_ROUNDS): start over on the host
+        P->order = nullptr;
+    }
     std::vector<int32_t> hptr, hidx;
     CSX_TRY(download_i32(hptr, P->ptr, (size_t)n + 1));
     CSX_TRY(download_i32(hidx, P->idx, (size_t)P->gnnz));

@@ -92,3 +92,60 @@ def test_W_factors_take_the_component_path(cs):
         comp = _csx.C.c_int32()
         _csx.check(_csx.lib().csx_tri_components(M._dev.plans[k], comp))
         assert comp.value >= 1493                  # a block may itself fall apart
+
+
+@pytest.mark.parametrize("kind", ["lsolve", "ltsolve", "usolve", "utsolve"])
+def test_level_analysis_on_the_device_gives_the_same_plan(cs, kind):
+    """Level sets and chain-walker tables computed on the device (the path big factors take) must give the same
+    bits as the host analysis: forced here on a medium factor with the component path switched off."""
+    import _csx
+    rng = np.random.default_rng(7)
+    lower = kind in ("lsolve", "ltsolve")
+    n, Tp, Ti, Tx = _block_tri(rng, 40, [300, 17, 64], 0.05, lower, True)
+    B = synth.rhs(n, 5, 0)
+    ref = np.stack([getattr(CO, kind)(n, Tp, Ti, Tx, B[:, r]) for r in range(5)], axis=1)
+    outs = {}
+    for where in (1, 2):
+        with _csx.option("tri.components", 0), _csx.option("tri.levels_where", where):
+            T = cs.cs_pin(_host_cs(cs, n, n, Tp, Ti, Tx))
+            X = cs.dvec(B)
+            assert getattr(cs, "cs_" + kind)(T, X) is True
+            outs[where] = X.numpy()
+            plan = T._dev.plans[{"lsolve": cs.TRI_L, "ltsolve": cs.TRI_LT, "usolve": cs.TRI_U, "utsolve": cs.TRI_UT}[kind]]
+            lv = _csx.C.c_int32()
+            _csx.check(_csx.lib().csx_tri_info(plan, None, lv, None))
+            outs[("levels", where)] = lv.value
+    assert outs[1].tobytes() == ref.tobytes() and outs[2].tobytes() == ref.tobytes()
+    assert outs[("levels", 1)] == outs[("levels", 2)] > 1
+
+
+def test_device_level_analysis_gives_up_on_deep_chains(cs):
+    """bcsstk16's factor has 4810 levels: deeper than the device pass is willing to go; it must hand over to the host
+    pass and still produce the reference's bits."""
+    import _csx
+    from conftest import GOLDEN, unpack
+    g = np.load(__import__("os").path.join(GOLDEN, "bcsstk16.npz"))
+    with _csx.option("tri.levels_where", 2):
+        L = cs.cs_pin(unpack(cs, g, "Lo"))
+        x = g["b"].tolist()
+        assert cs.cs_lsolve(L, x) is True
+    assert np.asarray(x).tobytes() == g["x_lsolve"].tobytes()
+
+
+def test_malformed_triangle_through_the_device_analysis(cs):
+    """An entry above the diagonal in 'L': the reference still runs its loop; so must the device path."""
+    import _csx
+    n = 300
+    rng = np.random.default_rng(3)
+    _, Tp, Ti, Tx = _block_tri(rng, 1, [n], 0.05, True, True)
+    Ti = Ti.copy()
+    q = int(Tp[200]) + 1 if Tp[201] - Tp[200] > 1 else int(Tp[200])
+    if Tp[201] - Tp[200] > 1:
+        Ti[q] = 5                                 # row 5 in column 200: above the diagonal
+    b = synth.rhs(n, 1, 0)[:, 0]
+    ref = CO.lsolve(n, Tp, Ti, Tx, b)
+    with _csx.option("tri.components", 0), _csx.option("tri.levels_where", 2):
+        T = cs.cs_pin(_host_cs(cs, n, n, Tp, Ti, Tx))
+        x = b.tolist()
+        assert cs.cs_lsolve(T, x) is True
+    assert np.asarray(x).tobytes() == ref.tobytes()
