@@ -73,6 +73,7 @@ struct TriPlan {
     int32_t *comp_nodes = nullptr;   // [n] rows grouped by component, ascending inside one
     int32_t *prog_ptr = nullptr, *prog_idx = nullptr;   // per sweep position: terms (local row * 64, value)
     double *prog_val = nullptr, *prog_diag = nullptr;
+    int col_state = 0;               // k_tri_columns: 0 not examined, 1 usable, 2 not (duplicate rows in a column)
     int few_cpw = 0;                 // components per wave of the all-in-LDS kernel (0: its tiles do not fit)
     int32_t few_rows = 0, few_terms = 0;
 };
@@ -786,6 +787,115 @@ __global__ __launch_bounds__(256) void k_group_caps(int32_t ncomp, int cpw, cons
     atomicMax(&caps[1], prog_ptr[lk] - prog_ptr[fk]);
 }
 
+
+// ---- small chain-like systems: the reference's loop, one wave per right-hand side, x in LDS ----------------
+// bcsstk16's factor (n = 4 884, 125 entries per column, 4 810 levels) offers a level schedule nothing to
+// schedule: 7 us per level made the forward solve 15 ms and the backward one 34 ms, against a third of a
+// millisecond for one host core.  When the whole x of one right-hand side fits LDS (n <= 15 360) a single wave
+// simply runs the reference's column loop: for L and U (column push) the column's entries are spread over the
+// lanes (distinct rows, each x[i] still receives its updates in ascending / descending column order); for L'
+// and U' (column gather) the products of a column are formed in parallel, one or two per lane, and subtracted
+// in storage order by a v_readlane broadcast chain that every lane runs.  No workgroup barrier, the next
+// column's entries already in flight.  Bit-identical, every kind.  Right-hand sides are independent workgroups.
+#pragma clang fp contract(off)
+constexpr int TC_THREADS = 64;     // ONE wave: a column's first 128 entries live in registers
+constexpr int TC_MAX_N = 15360;
+
+template <int KIND>
+__global__ __launch_bounds__(TC_THREADS) void k_tri_columns(int32_t n, const int32_t *__restrict__ Tp,
+                                                            const int32_t *__restrict__ Ti, const double *__restrict__ Tx,
+                                                            double *X, int nrhs) {
+    extern __shared__ __attribute__((aligned(16))) double xs[];   // the whole x of this right-hand side
+    const int lane = threadIdx.x, r = blockIdx.x;
+    for (int32_t i0 = lane; i0 < n; i0 += 64 * 8) {               // eight loads in flight per lane
+        double t[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) t[u] = X[(int64_t)min(i0 + 64 * u, n - 1) * nrhs + r];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (i0 + 64 * u < n) xs[i0 + 64 * u] = t[u];
+    }
+    __syncthreads();
+    constexpr bool PUSH = KIND == CSX_TRI_L || KIND == CSX_TRI_U;
+    constexpr bool ASC = KIND == CSX_TRI_L || KIND == CSX_TRI_UT;
+    constexpr bool DIAG_FIRST = KIND == CSX_TRI_L || KIND == CSX_TRI_LT;
+    // entries lane and lane + 64 of the current column's off-diagonal part, fetched one column ahead
+    int32_t j = ASC ? 0 : n - 1;
+    int32_t b = Tp[j], e = Tp[j + 1];
+    int32_t lo = DIAG_FIRST ? b + 1 : b, hi = DIAG_FIRST ? e : e - 1;
+    double dg = Tx[DIAG_FIRST ? b : e - 1];
+    int32_t ci0 = lo + lane < hi ? Ti[lo + lane] : 0, ci1 = lo + 64 + lane < hi ? Ti[lo + 64 + lane] : 0;
+    double cv0 = lo + lane < hi ? Tx[lo + lane] : 0.0, cv1 = lo + 64 + lane < hi ? Tx[lo + 64 + lane] : 0.0;
+    for (int32_t step = 0; step < n; step++) {
+        const int32_t jn = step + 1 < n ? (ASC ? j + 1 : j - 1) : j;
+        const int32_t nb = Tp[jn], ne = Tp[jn + 1];
+        const int32_t nlo = DIAG_FIRST ? nb + 1 : nb, nhi = DIAG_FIRST ? ne : ne - 1;
+        const double ndg = Tx[DIAG_FIRST ? nb : ne - 1];
+        const int32_t nci0 = nlo + lane < nhi ? Ti[nlo + lane] : 0, nci1 = nlo + 64 + lane < nhi ? Ti[nlo + 64 + lane] : 0;
+        const double ncv0 = nlo + lane < nhi ? Tx[nlo + lane] : 0.0, ncv1 = nlo + 64 + lane < nhi ? Tx[nlo + 64 + lane] : 0.0;
+        const int32_t len = hi - lo;                           // wave-uniform
+        if (PUSH) {
+            const double xj = xs[j] / dg;                      // every lane: same operands, same result
+            if (lane == 0) X[(int64_t)j * nrhs + r] = xj;      // x[j] is final and not read again
+            if (lane < len) {
+                const double t = cv0 * xj;
+                xs[ci0] = xs[ci0] - t;
+            }
+            if (64 + lane < len) {
+                const double t = cv1 * xj;
+                xs[ci1] = xs[ci1] - t;
+            }
+            for (int32_t p = lo + 128 + lane; p < hi; p += 64) {   // columns longer than 128
+                const int32_t i = Ti[p];
+                const double t = Tx[p] * xj;
+                xs[i] = xs[i] - t;
+            }
+        } else {
+            // products in parallel, subtracted in storage order: lane q's product is broadcast by v_readlane and
+            // every lane runs the same (serial) chain
+            double acc = xs[j];
+            const double t0 = cv0 * xs[ci0], t1 = cv1 * xs[ci1];
+            const int l0 = len < 64 ? len : 64, l1 = len < 128 ? len - 64 : 64;
+#pragma unroll 8
+            for (int q = 0; q < l0; q++) acc = acc - bcast_f64(t0, q);
+#pragma unroll 8
+            for (int q = 0; q < l1; q++) acc = acc - bcast_f64(t1, q);
+            for (int32_t p0 = lo + 128; p0 < hi; p0 += 64) {   // columns longer than 128: 64 more at a time
+                const int32_t p = p0 + lane;
+                const double t2 = p < hi ? Tx[p] * xs[Ti[p]] : 0.0;
+                const int l2 = hi - p0 < 64 ? hi - p0 : 64;
+                for (int q = 0; q < l2; q++) acc = acc - bcast_f64(t2, q);
+            }
+            const double xj = acc / dg;
+            if (lane == 0) {
+                xs[j] = xj;
+                X[(int64_t)j * nrhs + r] = xj;
+            }
+        }
+        __syncthreads();   // one wave: orders this column's LDS writes before the next column's reads
+        j = jn;
+        lo = nlo;
+        hi = nhi;
+        dg = ndg;
+        ci0 = nci0;
+        ci1 = nci1;
+        cv0 = ncv0;
+        cv1 = ncv1;
+    }
+}
+#pragma clang fp contract(fast)
+
+// a column of T with two entries in the same row (the reference's own LU factors have them) must keep their
+// order: the push kernels above would race on x[row].  G = stable transpose: such entries are neighbours in a row.
+__global__ __launch_bounds__(256) void k_adjacent_equal(int32_t n, const int32_t *__restrict__ ptr,
+                                                        const int32_t *__restrict__ idx, int *flag) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (r >= n) return;
+    for (int32_t q = ptr[r] + 1 + lane; q < ptr[r + 1]; q += 64)
+        if (idx[q] == idx[q - 1]) *flag = 1;
+}
+
 constexpr int COMP_MAX_ROWS = 256;    // X tile of one component: rows x 64 lanes x 8 B <= 128 KiB of LDS
 constexpr int COMP_MIN_COUNT = 64;    // fewer components than this: level scheduling fills the chip better
 
@@ -1291,6 +1401,43 @@ int tri_solve_raw(TriPlan *P, double *X, int32_t nrhs, bool relaxed) {
                            P->Ti, P->Tx, X, nrhs);
         CSX_LAUNCH_CHECK();
         return CSX_OK;
+    }
+    // small and chain-like: the column loop, one wave per right-hand side, beats any schedule
+    if (ctx().opt.tri_columns && P->n <= TC_MAX_N && (int64_t)P->nlevels * 12 > P->n) {
+        if (P->col_state == 0) {
+            P->col_state = 1;
+            if (P->kind == CSX_TRI_L || P->kind == CSX_TRI_U) {   // gather structure of a push kind = stable transpose
+                DevScope tmp;
+                int *flag = nullptr;
+                int h = 0;
+                CSX_TRY(tmp.alloc(&flag, 1));
+                CSX_HIP(hipMemsetAsync(flag, 0, sizeof(int), s));
+                hipLaunchKernelGGL(k_adjacent_equal, dim3((unsigned)(((int64_t)P->n + 3) / 4)), dim3(256), 0, s, P->n, P->ptr,
+                                   P->idx, flag);
+                CSX_HIP(hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, s));
+                CSX_HIP(hipStreamSynchronize(s));
+                if (h) P->col_state = 2;
+            }
+        }
+        if (P->col_state == 1) {
+            const size_t lds = ((size_t)P->n + 8) * sizeof(double);
+#define CSX_TC(K)                                                                                                  \
+    {                                                                                                              \
+        CSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tri_columns<K>),                             \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));                \
+        hipLaunchKernelGGL(k_tri_columns<K>, dim3((unsigned)nrhs), dim3(TC_THREADS), lds, s, P->n, P->Tp, P->Ti, P->Tx, \
+                           X, nrhs);                                                                               \
+    }
+            switch (P->kind) {
+                case CSX_TRI_L: CSX_TC(CSX_TRI_L) break;
+                case CSX_TRI_LT: CSX_TC(CSX_TRI_LT) break;
+                case CSX_TRI_U: CSX_TC(CSX_TRI_U) break;
+                default: CSX_TC(CSX_TRI_UT) break;
+            }
+#undef CSX_TC
+            CSX_LAUNCH_CHECK();
+            return CSX_OK;
+        }
     }
     // the exact chain walker is already the fast one when in-block sources come last: relax only the others
     relaxed = relaxed && !P->chain_ok;
