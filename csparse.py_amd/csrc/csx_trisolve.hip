@@ -74,6 +74,7 @@ struct TriPlan {
     int32_t *prog_ptr = nullptr, *prog_idx = nullptr;   // per sweep position: terms (local row * 64, value)
     double *prog_val = nullptr, *prog_diag = nullptr;
     int col_state = 0;               // k_tri_columns: 0 not examined, 1 usable, 2 not (duplicate rows in a column)
+    int32_t max_col = 0;             // longest column of T (gather kinds: product buffer)
     int few_cpw = 0;                 // components per wave of the all-in-LDS kernel (0: its tiles do not fit)
     int32_t few_rows = 0, few_terms = 0;
 };
@@ -788,99 +789,89 @@ __global__ __launch_bounds__(256) void k_group_caps(int32_t ncomp, int cpw, cons
 }
 
 
-// ---- small chain-like systems: the reference's loop, one wave per right-hand side, x in LDS ----------------
+// ---- small chain-like systems: the reference's loop, one workgroup per right-hand side, x in LDS ------------
 // bcsstk16's factor (n = 4 884, 125 entries per column, 4 810 levels) offers a level schedule nothing to
 // schedule: 7 us per level made the forward solve 15 ms and the backward one 34 ms, against a third of a
-// millisecond for one host core.  When the whole x of one right-hand side fits LDS (n <= 15 360) a single wave
+// millisecond for one host core.  When the whole x of one right-hand side fits LDS (n <= 15 360) the workgroup
 // simply runs the reference's column loop: for L and U (column push) the column's entries are spread over the
-// lanes (distinct rows, each x[i] still receives its updates in ascending / descending column order); for L'
-// and U' (column gather) the products of a column are formed in parallel, one or two per lane, and subtracted
-// in storage order by a v_readlane broadcast chain that every lane runs.  No workgroup barrier, the next
-// column's entries already in flight.  Bit-identical, every kind.  Right-hand sides are independent workgroups.
+// threads (distinct rows, each x[i] still receives its updates in ascending / descending column order); for L'
+// and U' (column gather) the products of a column are formed in parallel and subtracted by one lane in storage
+// order.  One workgroup barrier (two for the gathers) per column, the next column's entries already in flight.
+// Bit-identical, every kind.  Right-hand sides are independent workgroups.  (A one-wave version whose subtraction
+// chain broadcasts the products with v_readlane instead of reading them from LDS was slower: 20.7 against 9.0 ms
+// for L' on bcsstk16.)
 #pragma clang fp contract(off)
-constexpr int TC_THREADS = 64;     // ONE wave: a column's first 128 entries live in registers
+constexpr int TC_THREADS = 256;
 constexpr int TC_MAX_N = 15360;
 
 template <int KIND>
 __global__ __launch_bounds__(TC_THREADS) void k_tri_columns(int32_t n, const int32_t *__restrict__ Tp,
                                                             const int32_t *__restrict__ Ti, const double *__restrict__ Tx,
                                                             double *X, int nrhs) {
-    extern __shared__ __attribute__((aligned(16))) double xs[];   // the whole x of this right-hand side
-    const int lane = threadIdx.x, r = blockIdx.x;
-    for (int32_t i0 = lane; i0 < n; i0 += 64 * 8) {               // eight loads in flight per lane
-        double t[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) t[u] = X[(int64_t)min(i0 + 64 * u, n - 1) * nrhs + r];
-#pragma unroll
-        for (int u = 0; u < 8; u++)
-            if (i0 + 64 * u < n) xs[i0 + 64 * u] = t[u];
-    }
+    extern __shared__ __attribute__((aligned(16))) double xs[];   // n doubles, then the product buffer (gathers)
+    double *prod = xs + n;
+    const int tid = threadIdx.x, r = blockIdx.x;
+    for (int32_t i = tid; i < n; i += TC_THREADS) xs[i] = X[(int64_t)i * nrhs + r];
     __syncthreads();
     constexpr bool PUSH = KIND == CSX_TRI_L || KIND == CSX_TRI_U;
     constexpr bool ASC = KIND == CSX_TRI_L || KIND == CSX_TRI_UT;
     constexpr bool DIAG_FIRST = KIND == CSX_TRI_L || KIND == CSX_TRI_LT;
-    // entries lane and lane + 64 of the current column's off-diagonal part, fetched one column ahead
+    // this thread's entry of the current column, fetched one column ahead
     int32_t j = ASC ? 0 : n - 1;
     int32_t b = Tp[j], e = Tp[j + 1];
-    int32_t lo = DIAG_FIRST ? b + 1 : b, hi = DIAG_FIRST ? e : e - 1;
+    int32_t lo = DIAG_FIRST ? b + 1 : b, hi = DIAG_FIRST ? e : e - 1;   // the off-diagonal entries
     double dg = Tx[DIAG_FIRST ? b : e - 1];
-    int32_t ci0 = lo + lane < hi ? Ti[lo + lane] : 0, ci1 = lo + 64 + lane < hi ? Ti[lo + 64 + lane] : 0;
-    double cv0 = lo + lane < hi ? Tx[lo + lane] : 0.0, cv1 = lo + 64 + lane < hi ? Tx[lo + 64 + lane] : 0.0;
+    int32_t ci = lo + tid < hi ? Ti[lo + tid] : 0;
+    double cv = lo + tid < hi ? Tx[lo + tid] : 0.0;
     for (int32_t step = 0; step < n; step++) {
+        // next column's descriptor and first entry per thread
         const int32_t jn = step + 1 < n ? (ASC ? j + 1 : j - 1) : j;
         const int32_t nb = Tp[jn], ne = Tp[jn + 1];
         const int32_t nlo = DIAG_FIRST ? nb + 1 : nb, nhi = DIAG_FIRST ? ne : ne - 1;
         const double ndg = Tx[DIAG_FIRST ? nb : ne - 1];
-        const int32_t nci0 = nlo + lane < nhi ? Ti[nlo + lane] : 0, nci1 = nlo + 64 + lane < nhi ? Ti[nlo + 64 + lane] : 0;
-        const double ncv0 = nlo + lane < nhi ? Tx[nlo + lane] : 0.0, ncv1 = nlo + 64 + lane < nhi ? Tx[nlo + 64 + lane] : 0.0;
-        const int32_t len = hi - lo;                           // wave-uniform
+        const int32_t nci = nlo + tid < nhi ? Ti[nlo + tid] : 0;
+        const double ncv = nlo + tid < nhi ? Tx[nlo + tid] : 0.0;
         if (PUSH) {
-            const double xj = xs[j] / dg;                      // every lane: same operands, same result
-            if (lane == 0) X[(int64_t)j * nrhs + r] = xj;      // x[j] is final and not read again
-            if (lane < len) {
-                const double t = cv0 * xj;
-                xs[ci0] = xs[ci0] - t;
+            const double xj = xs[j] / dg;                      // every thread: same operands, same result
+            if (tid == 0) X[(int64_t)j * nrhs + r] = xj;       // x[j] is final and not read again
+            if (lo + tid < hi) {
+                const double t = cv * xj;
+                xs[ci] = xs[ci] - t;
             }
-            if (64 + lane < len) {
-                const double t = cv1 * xj;
-                xs[ci1] = xs[ci1] - t;
-            }
-            for (int32_t p = lo + 128 + lane; p < hi; p += 64) {   // columns longer than 128
+            for (int32_t p = lo + tid + TC_THREADS; p < hi; p += TC_THREADS) {   // columns longer than the workgroup
                 const int32_t i = Ti[p];
                 const double t = Tx[p] * xj;
                 xs[i] = xs[i] - t;
             }
+            __syncthreads();
         } else {
-            // products in parallel, subtracted in storage order: lane q's product is broadcast by v_readlane and
-            // every lane runs the same (serial) chain
-            double acc = xs[j];
-            const double t0 = cv0 * xs[ci0], t1 = cv1 * xs[ci1];
-            const int l0 = len < 64 ? len : 64, l1 = len < 128 ? len - 64 : 64;
-#pragma unroll 8
-            for (int q = 0; q < l0; q++) acc = acc - bcast_f64(t0, q);
-#pragma unroll 8
-            for (int q = 0; q < l1; q++) acc = acc - bcast_f64(t1, q);
-            for (int32_t p0 = lo + 128; p0 < hi; p0 += 64) {   // columns longer than 128: 64 more at a time
-                const int32_t p = p0 + lane;
-                const double t2 = p < hi ? Tx[p] * xs[Ti[p]] : 0.0;
-                const int l2 = hi - p0 < 64 ? hi - p0 : 64;
-                for (int q = 0; q < l2; q++) acc = acc - bcast_f64(t2, q);
-            }
-            const double xj = acc / dg;
-            if (lane == 0) {
+            const int32_t len = hi - lo;
+            if (tid < len) prod[tid] = cv * xs[ci];
+            for (int32_t q = tid + TC_THREADS; q < len; q += TC_THREADS) prod[q] = Tx[lo + q] * xs[Ti[lo + q]];
+            __syncthreads();
+            if (tid == 0) {
+                double acc = xs[j];
+                int32_t q = 0;
+                for (; q + 8 <= len; q += 8) {
+                    double t[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) t[u] = prod[q + u];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) acc = acc - t[u];
+                }
+                for (; q < len; q++) acc = acc - prod[q];
+                const double xj = acc / dg;
                 xs[j] = xj;
                 X[(int64_t)j * nrhs + r] = xj;
             }
+            __syncthreads();
         }
-        __syncthreads();   // one wave: orders this column's LDS writes before the next column's reads
         j = jn;
         lo = nlo;
         hi = nhi;
         dg = ndg;
-        ci0 = nci0;
-        ci1 = nci1;
-        cv0 = ncv0;
-        cv1 = ncv1;
+        ci = nci;
+        cv = ncv;
     }
 }
 #pragma clang fp contract(fast)
@@ -1406,6 +1397,9 @@ int tri_solve_raw(TriPlan *P, double *X, int32_t nrhs, bool relaxed) {
     if (ctx().opt.tri_columns && P->n <= TC_MAX_N && (int64_t)P->nlevels * 12 > P->n) {
         if (P->col_state == 0) {
             P->col_state = 1;
+            std::vector<int32_t> hp;
+            CSX_TRY(download_i32(hp, P->Tp, (size_t)P->n + 1));
+            for (int32_t c = 0; c < P->n; c++) P->max_col = std::max(P->max_col, hp[(size_t)c + 1] - hp[(size_t)c]);
             if (P->kind == CSX_TRI_L || P->kind == CSX_TRI_U) {   // gather structure of a push kind = stable transpose
                 DevScope tmp;
                 int *flag = nullptr;
@@ -1419,8 +1413,8 @@ int tri_solve_raw(TriPlan *P, double *X, int32_t nrhs, bool relaxed) {
                 if (h) P->col_state = 2;
             }
         }
-        if (P->col_state == 1) {
-            const size_t lds = ((size_t)P->n + 8) * sizeof(double);
+        if (P->col_state == 1 && ((size_t)P->n + (size_t)P->max_col + 8) * sizeof(double) <= 150 * 1024) {
+            const size_t lds = ((size_t)P->n + (size_t)P->max_col + 8) * sizeof(double);
 #define CSX_TC(K)                                                                                                  \
     {                                                                                                              \
         CSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tri_columns<K>),                             \
