@@ -382,6 +382,150 @@ static int upload(T **d, const std::vector<T> &h) {
     return CSX_OK;
 }
 
+
+// ---- banded factors: the whole window in registers --------------------------------------------------------
+// bcsstk16 in natural order: n = 4 884, L is 98.8 % dense inside a band of half-width 140 and its elimination
+// tree is a chain (4 810 levels).  Column after column with 125 sparse updates each took 32 ms here, 20 ms on one
+// host core.  For such a factor the live part of a RIGHT-looking factorisation is small: element (r, c) is touched
+// by the columns r - b .. c - 1 only, so at column j the live elements are j <= c <= r <= j + b -- a triangle of
+// side b + 1 (10 K doubles for bcsstk16).  One workgroup keeps that window in REGISTERS (a BW x BW circular
+// array spread over 1024 threads, thread = (row slot, a few column slots)), and per column: the entering row
+// is fetched through the row view into a staging row, the column's elements are gathered into LDS, scaled
+// (sqrt, divisions) and written to L.x, and every thread subtracts l_r l_c from its live elements.  Three
+// workgroup barriers per column, no memory traffic but the entering row and the leaving column.  Each element
+// receives its updates in ascending column order, multiply and subtract rounded separately: on a chain tree that
+// is the reference's operation sequence, so L.x comes out bit-identical (tests/test_gpu_cholesky.py).
+#pragma clang fp contract(off)
+template <int BW, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_chol_band(int32_t n, const int32_t *__restrict__ Lp,
+                                                       const int32_t *__restrict__ Li, double *Lx,
+                                                       const int32_t *__restrict__ row_ptr,
+                                                       const int32_t *__restrict__ row_col,
+                                                       const int32_t *__restrict__ row_pos, int *notspd) {
+    constexpr int TPR = THREADS / BW;                // threads per window row
+    constexpr int NS = (BW + TPR - 1) / TPR;         // elements of the row per thread
+    __shared__ double colbuf[BW], lcol[BW], stage[BW];
+    const int tid = threadIdx.x;
+    const int rr = tid / TPR, tc = tid % TPR;
+    const bool owner = rr < BW;
+    // Row slot rr holds the window row r = j + dr (r = rr mod BW); of that row this thread keeps the elements on the
+    // diagonals dd = tc, tc + TPR, ... (dd = r - c never changes during an element's life).  Element (r, c) is live
+    // while c >= j, i.e. dd <= dr: a row enters with all BW diagonals live and loses one per column, so the loops
+    // below stop at dd > dr -- and the threads of a wave belong to neighbouring rows, whose dr differ by a few.
+    double W[NS];
+#pragma unroll
+    for (int sl = 0; sl < NS; sl++) W[sl] = 0.0;
+    int dr = owner ? (rr + BW - 1) % BW : -1;        // at j = -(BW - 1); -1: not an owner, every loop below is empty
+    // The entering row is fetched through three dependent loads (row extent -> column / position -> value).  They are
+    // spread over three columns: each step issues one load of each kind, for the rows entering 3, 2 and 1 steps
+    // later, and consumes what was issued a whole step earlier -- no step waits for a chain of round trips.
+    // (A row has at most BW entries: thread t < BW handles entry t.)
+    const int32_t j0 = -(BW - 1);
+    auto row_extent = [&](int32_t r, int32_t &qb, int32_t &qe) {
+        qb = qe = 0;
+        if (r >= 0 && r < n) {
+            qb = row_ptr[r];
+            qe = row_ptr[r + 1];
+        }
+    };
+    auto row_entry = [&](int32_t qb, int32_t qe, int32_t &c, int32_t &p) {
+        c = 0;
+        p = -1;
+        if (qb + tid < qe) {
+            c = row_col[qb + tid];
+            p = row_pos[qb + tid];
+        }
+    };
+    int32_t c0, p0, c1, p1, qb2, qe2;                // row entering now / at the next step / extent of the one after
+    double v0;
+    {   // prologue: the state at the top of step j0 (rows 0, 1, 2)
+        int32_t qb, qe;
+        row_extent(j0 + BW - 1, qb, qe);
+        row_entry(qb, qe, c0, p0);
+        v0 = p0 >= 0 ? Lx[p0] : 0.0;
+        row_extent(j0 + BW, qb, qe);
+        row_entry(qb, qe, c1, p1);
+        row_extent(j0 + BW + 1, qb2, qe2);
+    }
+    int32_t ncb = 0, nce = 0, nrow = 0;              // next column's extent and this thread's row index in it
+    if (n > 0) {
+        ncb = Lp[0];
+        nce = Lp[1];
+        nrow = ncb + tid < nce ? Li[ncb + tid] : 0;
+    }
+    if (tid < BW) stage[tid] = 0.0;
+    __syncthreads();
+    for (int32_t j = j0; j < n; j++) {
+        // ---- pipeline: this step's loads, each independent of the others ----
+        int32_t qb3, qe3, c2, p2;
+        row_extent(j + BW + 2, qb3, qe3);            // extent of the row entering three steps from now
+        row_entry(qb2, qe2, c2, p2);                 // entries of the row entering two steps from now
+        const double v1 = p1 >= 0 ? Lx[p1] : 0.0;    // values of the row entering at the next step
+        // ---- 1. the row that enters the window now, r_in = j + BW - 1: element (r_in, c) sits on diagonal r_in - c ----
+        if (p0 >= 0) stage[j + BW - 1 - c0] = v0;    // stage was zeroed at the end of the last step
+        __syncthreads();
+        if (dr == BW - 1) {
+#pragma unroll
+            for (int sl = 0; sl < NS; sl++)
+                if (tc + TPR * sl < BW) W[sl] = stage[tc + TPR * sl];
+        }
+        // this step's column descriptor was fetched one step ago; fetch the next one now
+        const int32_t cb_ = ncb, ce_ = nce, myrow = nrow;
+        if (j + 1 >= 0 && j + 1 < n) {
+            ncb = Lp[j + 1];
+            nce = Lp[j + 2];
+            nrow = ncb + tid < nce ? Li[ncb + tid] : 0;
+        }
+        if (j >= 0) {
+            // ---- 2. column j is complete: element (r, j) is the one on diagonal dd == dr of row r ----
+            if (dr >= 0 && dr % TPR == tc) {
+#pragma unroll
+                for (int sl = 0; sl < NS; sl++)
+                    if (tc + TPR * sl == dr) colbuf[dr] = W[sl];
+            }
+            __syncthreads();
+            const double d = colbuf[0];
+            if (!(d > 0.0)) {                                   // not positive definite (uniform)
+                if (tid == 0) atomicMin(notspd, j);
+                break;
+            }
+            const double ljj = sqrt(d);
+            if (tid < BW) lcol[tid] = tid == 0 ? ljj : colbuf[tid] / ljj;
+            if (cb_ + tid < ce_) Lx[cb_ + tid] = myrow == j ? ljj : colbuf[myrow - j] / ljj;   // <= BW entries per column
+            __syncthreads();
+            // ---- 3. rank-1 update of the live elements: c > j  <=>  dd < dr ----
+            if (dr >= 1) {
+                const double lr = lcol[dr];
+#pragma unroll
+                for (int sl = 0; sl < NS; sl++) {
+                    const int dd = tc + TPR * sl;
+                    if (dd >= dr) break;
+                    const double t = lr * lcol[dr - dd];
+                    W[sl] = W[sl] - t;
+                }
+            }
+        }
+        if (j < 0) __syncthreads();                  // (for j >= 0 the barriers of step 2 already separate the reads of stage)
+        if (tid < BW) stage[tid] = 0.0;
+        __syncthreads();   // stage / colbuf / lcol are rewritten by the next column
+        c0 = c1;
+        p0 = p1;
+        v0 = v1;
+        c1 = c2;
+        p1 = p2;
+        qb2 = qb3;
+        qe2 = qe3;
+        if (owner) dr = dr == 0 ? BW - 1 : dr - 1;
+    }
+}
+#pragma clang fp contract(fast)
+
+__global__ __launch_bounds__(256) void k_band_width(int32_t n, const int32_t *__restrict__ Lp,
+                                                    const int32_t *__restrict__ Li, int *bw) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) atomicMax(bw, Li[Lp[j + 1] - 1] - (int32_t)j);    // rows ascending: the last entry is the lowest row
+}
+
 struct Forest {
     std::vector<Tree> small;             // trees handled by the tree kernel
     std::vector<int32_t> small_cols;     // their columns, ascending inside a tree
@@ -485,7 +629,7 @@ static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, c
     int st = dalloc(&L->x, (size_t)L->nnz);
     if (st == CSX_OK && pinv) st = upload(&d_pinv, hpinv);
     if (st == CSX_OK) st = dalloc(&d_win, (size_t)L->nnz);
-    if (st == CSX_OK) st = dalloc(&d_flags, 2);
+    if (st == CSX_OK) st = dalloc(&d_flags, 3);   // [0] foreign symbolic data, [1] first non-positive pivot, [2] band width
     if (st == CSX_OK) st = upload(&d_trees, other_trees);
     if (st == CSX_OK) st = upload(&d_dense, dense_trees);
     if (st == CSX_OK) st = upload(&d_small_cols, F.small_cols);
@@ -499,15 +643,37 @@ static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, c
                            L->p, L->i, d_win, d_flags);
         hipLaunchKernelGGL(k_chol_init, dim3((unsigned)(((int64_t)L->nnz + 255) / 256)), dim3(256), 0, s,
                            (int64_t)L->nnz, d_win, A->x, L->x);
-        const int32_t nd = (int32_t)dense_trees.size();
+        // a chain-like big tree whose factor is a narrow band: the register-window kernel does the whole matrix
+        bool banded = false;
+        const int32_t nlev_all = (int32_t)F.level_ptr.size() - 1;
+        const int64_t big_cols = (int64_t)F.level_cols.size();   // columns of trees too big for the tree kernels
+        if (ctx().opt.chol_band && big_cols * 2 > n && (int64_t)nlev_all * 4 > big_cols) {
+            int hb = 0;
+            (void)hipMemsetAsync(d_flags + 2, 0, sizeof(int), s);
+            hipLaunchKernelGGL(k_band_width, dim3((unsigned)(((int64_t)n + 255) / 256)), dim3(256), 0, s, n, L->p, L->i,
+                               d_flags + 2);
+            (void)hipMemcpyAsync(&hb, d_flags + 2, sizeof(int), hipMemcpyDeviceToHost, s);
+            (void)hipStreamSynchronize(s);
+            const int need = hb + 1;
+#define CSX_BAND(BWV)                                                                                                \
+    hipLaunchKernelGGL((k_chol_band<BWV, 1024>), dim3(1), dim3(1024), 0, s, n, L->p, L->i, L->x, d_rp, d_rc, d_rpos, \
+                       d_flags + 1)
+            if (need <= 48) { CSX_BAND(48); banded = true; }
+            else if (need <= 80) { CSX_BAND(80); banded = true; }
+            else if (need <= 112) { CSX_BAND(112); banded = true; }
+            else if (need <= 144) { CSX_BAND(144); banded = true; }
+            else if (need <= 176) { CSX_BAND(176); banded = true; }
+#undef CSX_BAND
+        }
+        const int32_t nd = banded ? 0 : (int32_t)dense_trees.size();
         if (nd > 0)
             hipLaunchKernelGGL(k_chol_dense_trees, dim3((unsigned)((nd + CH_WAVES - 1) / CH_WAVES)), dim3(64 * CH_WAVES), 0,
                                s, d_dense, nd, d_small_cols, L->p, L->x, d_flags + 1);
-        const int32_t nt = (int32_t)other_trees.size();
+        const int32_t nt = banded ? 0 : (int32_t)other_trees.size();
         if (nt > 0)
             hipLaunchKernelGGL(k_chol_trees, dim3((unsigned)((nt + CH_WAVES - 1) / CH_WAVES)), dim3(64 * CH_WAVES), 0, s,
                                d_trees, nt, d_small_cols, L->p, L->i, L->x, d_rp, d_rc, d_rpos, d_flags + 1);
-        const int32_t nlev = (int32_t)F.level_ptr.size() - 1;
+        const int32_t nlev = banded ? 0 : (int32_t)F.level_ptr.size() - 1;
         int32_t l = 0;
         while (l < nlev) {
             const int32_t cnt = F.level_ptr[(size_t)l + 1] - F.level_ptr[(size_t)l];

@@ -100,6 +100,7 @@ struct Object {
 // Kernel-selection overrides for TESTS of the kernels a plan would not pick by itself (csx_set_option).  Every
 // setting computes correct results; none is read from the environment.
 struct Options {
+    bool chol_band = true;            // cs_chol: register-window kernel for chain-like banded factors
     bool chol_dense_trees = true;     // cs_chol: LDS dense-block kernel for trees that are dense blocks
     bool cholsol_dense_blocks = true; // cholsol: dense-block kernels (false: the fused per-tree kernel)
     bool spgemm_one_pass = true;      // cs_multiply: one-walk LDS hash kernel (false: the two-pass kernel)

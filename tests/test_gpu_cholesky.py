@@ -377,3 +377,33 @@ def test_schol_etree_by_components_on_device(cs, shape):
     assert Sd.parent == Sh.parent and Sd.cp == Sh.cp
     parent, cp = CO.schol(n, Ap, Ai)
     assert Sd.parent == parent.tolist() and Sd.cp == cp.tolist()
+
+
+def test_banded_chain_factor_takes_the_register_window_kernel(cs):
+    """bcsstk16 in natural order: chain-like elimination tree, L dense inside a band of half-width 140 -> the
+    register-window kernel (k_chol_band).  On a chain tree a right-looking band factorisation applies the
+    reference's operations in the reference's order: L.x bit-identical to the plain-C oracle.  The general column
+    kernels (forced) agree to rounding.  A banded matrix that is NOT positive definite must be refused (None)."""
+    import _csx
+    g = golden("bcsstk16")
+    C = unpack(cs, g, "C")
+    p, i, x = g["C_p"].astype(np.int32), g["C_i"].astype(np.int32), g["C_x"]
+    n = C.n
+    parent, cp = CO.schol(n, p, i)
+    Lp, Li, Lx = CO.chol(n, p, i, x, parent, cp)
+    S = cs.cs_schol(0, C)
+    N = cs.cs_chol(C, S)
+    assert N.L.p == Lp.tolist() and N.L.i[:Lp[n]] == Li.tolist()
+    got = np.asarray(N.L.x[:Lp[n]])
+    assert got.tobytes() == Lx.tobytes()
+    with _csx.option("chol.band", 0):
+        Ng = cs.cs_chol(C, S)
+    gg = np.asarray(Ng.L.x[:Lp[n]])
+    assert np.max(np.abs(gg - Lx)) / np.abs(Lx).max() < 1e-12 and gg.tobytes() != Lx.tobytes()
+    # not positive definite: flip the sign of a diagonal entry half way down
+    C2 = unpack(cs, g, "C")
+    j = n // 2
+    for q in range(C2.p[j], C2.p[j + 1]):
+        if C2.i[q] == j:
+            C2.x[q] = -C2.x[q]
+    assert cs.cs_chol(C2, S) is None
