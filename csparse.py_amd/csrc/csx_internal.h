@@ -106,6 +106,7 @@ struct Options {
     bool spgemm_one_pass = true;      // cs_multiply: one-walk LDS hash kernel (false: the two-pass kernel)
     bool tri_chain_walker = true;     // tri-solve: blocked chain walker for runs of narrow levels
     bool tri_components = true;       // tri-solve: one wave per small connected component (false: level sets)
+    bool tri_push = true;             // tri-solve: component kernels in column-push form for L / U with few RHS
     bool tri_columns = true;          // tri-solve: small chain-like systems by the column loop, x in LDS
     int tri_levels_where = 0;         // level analysis: 0 = device for big factors, host for small; 1 = host; 2 = device
 };

@@ -75,6 +75,9 @@ struct TriPlan {
     double *prog_val = nullptr, *prog_diag = nullptr;
     int col_state = 0;               // k_tri_columns: 0 not examined, 1 usable, 2 not (duplicate rows in a column)
     int32_t max_col = 0;             // longest column of T (gather kinds: product buffer)
+    int32_t *cptr = nullptr, *cidx = nullptr;   // push kinds (L, U): per sweep position the COLUMN's entries
+    double *cval = nullptr, *cdiag = nullptr;
+    int32_t push_terms = 0;          // most terms of one component (0: no push program)
     int few_cpw = 0;                 // components per wave of the all-in-LDS kernel (0: its tiles do not fit)
     int32_t few_rows = 0, few_terms = 0;
 };
@@ -98,6 +101,10 @@ void free_triplan(TriPlan *t) {
     dfree(t->prog_idx);
     dfree(t->prog_val);
     dfree(t->prog_diag);
+    dfree(t->cptr);
+    dfree(t->cidx);
+    dfree(t->cval);
+    dfree(t->cdiag);
     delete t;
 }
 
@@ -776,6 +783,136 @@ __global__ __launch_bounds__(64) void k_tri_few_lds(const Tree *__restrict__ com
 }
 #pragma clang fp contract(fast)
 
+
+// ---- components, column-push form (kinds L and U, few right-hand sides) ----------------------------------
+// In gather form a row waits for its ~7 terms one after the other; in the reference's own COLUMN-PUSH form the
+// ~7 updates a finished x[j] causes go to distinct rows and can be done by as many lanes at once, each row still
+// receiving its updates in ascending (L) / descending (U) column order -- bit-identical.  One wave per
+// component, its column program (local row, value) and its x copied into LDS, lanes = (entry of the column,
+// right-hand side).  The chain that remains is one division and one LDS round trip per column.
+#pragma clang fp contract(off)
+template <bool FORWARD>
+__global__ __launch_bounds__(64) void k_tri_comp_push(const Tree *__restrict__ comps, int32_t ncomp,
+                                                      const int32_t *__restrict__ nodes,
+                                                      const int32_t *__restrict__ cptr, const int32_t *__restrict__ cidx,
+                                                      const double *__restrict__ cval, const double *__restrict__ cdiag,
+                                                      double *B, int32_t nrhs, int G, int32_t rows_cap, int32_t terms_cap) {
+    extern __shared__ __attribute__((aligned(16))) double lds_raw[];
+    FewTerm *s_term = reinterpret_cast<FewTerm *>(lds_raw);                    // [terms_cap]
+    FewRow *s_col = reinterpret_cast<FewRow *>(s_term + terms_cap);            // [rows_cap]: diagonal, extent
+    double *xs = reinterpret_cast<double *>(s_col + rows_cap);                 // [rows_cap * G]
+    const int lane = threadIdx.x;
+    const int32_t comp = blockIdx.x;
+    if (comp >= ncomp) return;
+    const Tree tr = comps[comp];
+    const int32_t first_k = tr.first, nrows = tr.count, tbase = cptr[first_k], nterms = cptr[first_k + nrows] - tbase;
+    constexpr int SU = 4;
+    for (int32_t i0 = lane; i0 < nrows; i0 += 64 * SU) {
+        int32_t pb[SU], pe[SU];
+        double dd[SU];
+#pragma unroll
+        for (int u = 0; u < SU; u++) {
+            const int32_t i = min(i0 + 64 * u, nrows - 1);
+            pb[u] = cptr[first_k + i];
+            pe[u] = cptr[first_k + i + 1];
+            dd[u] = cdiag[first_k + i];
+        }
+#pragma unroll
+        for (int u = 0; u < SU; u++)
+            if (i0 + 64 * u < nrows) s_col[i0 + 64 * u] = {dd[u], pb[u] - tbase, pe[u] - tbase};
+    }
+    for (int32_t q0 = lane; q0 < nterms; q0 += 64 * SU) {
+        int32_t ii[SU];
+        double vv[SU];
+#pragma unroll
+        for (int u = 0; u < SU; u++) {
+            const int32_t q = min(q0 + 64 * u, nterms - 1);
+            ii[u] = cidx[tbase + q];
+            vv[u] = cval[tbase + q];
+        }
+#pragma unroll
+        for (int u = 0; u < SU; u++)
+            if (q0 + 64 * u < nterms) s_term[q0 + 64 * u] = {vv[u], ii[u], 0};
+    }
+    const int epl = 64 / G, t = lane / G, g = lane % G;    // entries of a column handled per pass; this lane's entry, RHS
+    for (int32_t r0 = 0; r0 < nrhs; r0 += G) {
+        const int32_t gw = min(G, nrhs - r0), nx = nrows * gw;
+        for (int32_t i0 = lane; i0 < nx; i0 += 64 * SU) {
+            int32_t nd[SU];
+            double bb[SU];
+#pragma unroll
+            for (int u = 0; u < SU; u++) nd[u] = nodes[first_k + min(i0 + 64 * u, nx - 1) / gw];
+#pragma unroll
+            for (int u = 0; u < SU; u++) bb[u] = B[(int64_t)nd[u] * nrhs + r0 + min(i0 + 64 * u, nx - 1) % gw];
+#pragma unroll
+            for (int u = 0; u < SU; u++) {
+                const int32_t i = i0 + 64 * u;
+                if (i < nx) xs[(i / gw) * G + i % gw] = bb[u];
+            }
+        }
+        __syncthreads();
+        if (g < gw) {
+            FewRow cur = s_col[0];
+            for (int32_t sp = 0; sp < nrows; sp++) {
+                const FewRow nxt = s_col[sp + 1 < nrows ? sp + 1 : sp];
+                const int32_t a = FORWARD ? sp : nrows - 1 - sp;          // local row of this column's unknown
+                const double xj = xs[a * G + g] / cur.diag;               // every entry lane: same operands, same result
+                for (int32_t q = cur.tb + t; q < cur.te; q += epl) {
+                    const FewTerm e = s_term[q];
+                    const double pr = e.v * xj;
+                    xs[e.src * G + g] = xs[e.src * G + g] - pr;
+                }
+                if (t == 0) xs[a * G + g] = xj;                           // after every lane's read of it (same wave, in order)
+                cur = nxt;
+            }
+        }
+        __syncthreads();
+        for (int32_t i = lane; i < nx; i += 64) B[(int64_t)nodes[first_k + i / gw] * nrhs + r0 + i % gw] = xs[(i / gw) * G + i % gw];
+        __syncthreads();
+    }
+}
+#pragma clang fp contract(fast)
+
+// column program of the push kinds: sweep position k of a component <-> column j of T without its diagonal;
+// local row = ascending index of the row inside the component
+__global__ __launch_bounds__(256) void k_push_len(int32_t ncomp, const Tree *__restrict__ comps,
+                                                  const uint32_t *__restrict__ srow, const int32_t *__restrict__ Tp,
+                                                  int forward, int32_t *len) {
+    const int lane = threadIdx.x & 63;
+    const int64_t c = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (c >= ncomp) return;
+    const Tree t = comps[c];
+    for (int32_t sp = lane; sp < t.count; sp += 64) {
+        const int32_t j = (int32_t)srow[t.first + (forward ? sp : t.count - 1 - sp)];
+        len[t.first + sp] = Tp[j + 1] - Tp[j] - 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_push_fill(int32_t n, const int32_t *__restrict__ comp_of_pos,
+                                                   const Tree *__restrict__ comps, const uint32_t *__restrict__ srow,
+                                                   const int32_t *__restrict__ local_id, const int32_t *__restrict__ Tp,
+                                                   const int32_t *__restrict__ Ti, const double *__restrict__ Tx, int forward,
+                                                   const int32_t *__restrict__ cptr, int32_t *cidx, double *cval, double *cdiag,
+                                                   int *stats) {
+    const int lane = threadIdx.x & 63;
+    const int64_t k = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (k >= n) return;
+    const Tree t = comps[comp_of_pos[k]];
+    const int32_t sp = (int32_t)k - t.first;
+    const int32_t j = (int32_t)srow[t.first + (forward ? sp : t.count - 1 - sp)];
+    const int32_t b = Tp[j], e = Tp[j + 1];
+    const int32_t lo = forward ? b + 1 : b;           // L: diagonal first; U: diagonal last
+    const int32_t o = cptr[k], len = cptr[k + 1] - o;
+    for (int32_t q = lane; q < len; q += 64) {
+        cidx[o + q] = local_id[Ti[lo + q]];
+        cval[o + q] = Tx[lo + q];
+    }
+    if (lane == 0) {
+        cdiag[k] = Tx[forward ? b : e - 1];
+        if (sp == 0) atomicMax(&stats[0], cptr[t.first + t.count] - cptr[t.first]);   // most terms in one component
+    }
+}
+
 // largest number of rows / terms in any group of `cpw` consecutive components
 __global__ __launch_bounds__(256) void k_group_caps(int32_t ncomp, int cpw, const Tree *__restrict__ comps,
                                                     const int32_t *__restrict__ prog_ptr, int *caps) {
@@ -938,6 +1075,33 @@ static int analyse_components(TriPlan *P) {
                        P->diag, P->skip_first, P->forward ? 1 : 0, P->prog_ptr, P->prog_idx, P->prog_val, P->prog_diag);
     CSX_HIP(hipMemcpyAsync(P->comp_nodes, srow, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
     CSX_LAUNCH_CHECK();
+    if (P->kind == CSX_TRI_L || P->kind == CSX_TRI_U) {
+        // column program for k_tri_comp_push -- unless some column holds the same row twice (the reference's own LU
+        // factors do): the lanes of a column would race on it; the gather kernels keep such entries in order
+        int hdup = 0;
+        CSX_HIP(hipMemsetAsync(flags, 0, 4 * sizeof(int), s));
+        hipLaunchKernelGGL(k_adjacent_equal, dim3(nbw), dim3(256), 0, s, n, P->ptr, P->idx, flags);
+        CSX_HIP(hipMemcpyAsync(&hdup, flags, sizeof(int), hipMemcpyDeviceToHost, s));
+        CSX_HIP(hipStreamSynchronize(s));
+        if (!hdup) {
+            int32_t *clen = nullptr;
+            CSX_TRY(tmp.alloc(&clen, (size_t)n + 1));
+            hipLaunchKernelGGL(k_push_len, dim3(ncw), dim3(256), 0, s, P->ncomp, comps, srow, P->Tp, P->forward ? 1 : 0, clen);
+            CSX_TRY(dalloc(&P->cptr, (size_t)n + 1));
+            int64_t ctotal = 0;
+            CSX_TRY(scan_exclusive_i32(clen, P->cptr, n, &ctotal));
+            CSX_TRY(dalloc(&P->cidx, (size_t)ctotal + 64));
+            CSX_TRY(dalloc(&P->cval, (size_t)ctotal + 64));
+            CSX_TRY(dalloc(&P->cdiag, (size_t)n));
+            CSX_HIP(hipMemsetAsync(flags, 0, 4 * sizeof(int), s));
+            hipLaunchKernelGGL(k_push_fill, dim3(nbw), dim3(256), 0, s, n, comp_of_pos, comps, srow, local_id, P->Tp, P->Ti,
+                               P->Tx, P->forward ? 1 : 0, P->cptr, P->cidx, P->cval, P->cdiag, flags);
+            int hmax = 0;
+            CSX_HIP(hipMemcpyAsync(&hmax, flags, sizeof(int), hipMemcpyDeviceToHost, s));
+            CSX_HIP(hipStreamSynchronize(s));
+            P->push_terms = hmax > 0 ? hmax : 1;
+        }
+    }
     for (int cpw : {4}) {   // LDS need of the all-in-LDS kernel: 12 B per term, (12 + 8 G) B per row, G = 64 / cpw = 16
         int hcaps[2] = {0, 0};
         CSX_HIP(hipMemsetAsync(flags, 0, 4 * sizeof(int), s));
@@ -961,6 +1125,28 @@ static int analyse_components(TriPlan *P) {
 
 static int solve_components(TriPlan *P, double *X, int32_t nrhs) {
     hipStream_t s = ctx().stream;
+    // L, U with up to 8 right-hand sides: one wave per component, column-push form (W, L + U pair: 43 us at 1 RHS,
+    // 78 us at 8; at 64 the entry-parallel lanes are gone and it loses to k_tri_local, 483 against 272 us)
+    if (nrhs <= 8 && P->push_terms > 0 && ctx().opt.tri_push) {
+        int G = 1;
+        while (G < nrhs) G <<= 1;
+        const size_t lds = (size_t)P->push_terms * 16 + (size_t)P->comp_max * (16 + 8 * (size_t)G) + 64;
+        if (lds <= 120 * 1024) {
+            if (P->forward) {
+                CSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tri_comp_push<true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+                hipLaunchKernelGGL(k_tri_comp_push<true>, dim3((unsigned)P->ncomp), dim3(64), lds, s, P->comps, P->ncomp,
+                                   P->comp_nodes, P->cptr, P->cidx, P->cval, P->cdiag, X, nrhs, G, P->comp_max, P->push_terms);
+            } else {
+                CSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tri_comp_push<false>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+                hipLaunchKernelGGL(k_tri_comp_push<false>, dim3((unsigned)P->ncomp), dim3(64), lds, s, P->comps, P->ncomp,
+                                   P->comp_nodes, P->cptr, P->cidx, P->cval, P->cdiag, X, nrhs, G, P->comp_max, P->push_terms);
+            }
+            CSX_LAUNCH_CHECK();
+            return CSX_OK;
+        }
+    }
     if (nrhs <= 32 && P->few_cpw) {   // lanes = (component, right-hand side) pairs, programs and X in LDS
         const int cpw = P->few_cpw;
         const size_t lds = few_lds_bytes(P->few_rows, P->few_terms, 64 / cpw);
