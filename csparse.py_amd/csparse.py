@@ -1005,6 +1005,23 @@ def cs_lu(A, S, tol):
     n = A.n
     if A.m != n:
         raise IndexError("list index out of range")
+    if n >= 4096 or A._dev is not None:
+        # a batch of small independent blocks (block-diagonal up to a symmetric permutation) factors on the device,
+        # one workgroup per block; anything else comes back with done = 0 and takes the host code below
+        pinv = np.empty(max(n, 1), dtype=np.int32)
+        hL, hU, done = _csx.new_handle(), _csx.new_handle(), _csx.C.c_int(0)
+        with _Resident(A) as dA:
+            st = _csx.lib().csx_lu_blocks(dA.handle, float(tol), hL, hU, _csx.pi(pinv), done)
+        if st == _csx.ENOTSPD:
+            return None
+        _csx.check(st, "csx_lu_blocks")
+        if done.value:
+            N = csn()
+            N.L = _from_device(hL, lambda nnz: max(nnz, 1))
+            N.U = _from_device(hU, lambda nnz: max(nnz, 1))
+            N.pinv = pinv[:n].tolist()
+            N.B = None
+            return N
     p = _csx.i32(A.p[:n + 1])
     nnz = int(p[n])
     i, x = _csx.i32(A.i[:nnz]), _csx.f64(A.x[:nnz])

@@ -224,6 +224,12 @@ int csx_lu_host(int32_t n, const int32_t *Ap, const int32_t *Ai, const double *A
                 int32_t **Lp, int32_t **Li, double **Lx, int32_t **Up, int32_t **Ui, double **Ux,
                 int32_t *pinv);
 void csx_host_free(void *p);
+/* The same factorisation on the device for a matrix that is a batch of small independent blocks (many connected
+ * components of at most 96 rows, found on the device): one workgroup per block, dense in LDS, the reference's
+ * pivot rule.  *done = 0 when the matrix is not of that shape (or has duplicate entries): use csx_lu_host.
+ * L, U: new device matrices (unit diagonal first / diagonal last, row indices in pivot order); pinv: host, n.
+ * Values equal the left-looking code's to rounding.  CSX_ENOTSPD: a singular block. */
+int csx_lu_blocks(csx_handle_t A, double tol, csx_handle_t *L, csx_handle_t *U, int32_t *pinv, int *done);
 
 /* ---- synthetic inputs of the benchmark configs, generated on
  * the device from a counter-based hash so host and device agree bit for bit ---- */
