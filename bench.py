@@ -219,6 +219,7 @@ def main():
     ap.add_argument("--cpu-chol-blocks", type=int, default=2000, help="G-spd blocks in the CPU baseline of the cholsol leg")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-cholsol", action="store_true")
+    ap.add_argument("--skip-configs", action="store_true", help="skip BASELINE's other configs (bench_configs.py sections)")
     ap.add_argument("--skip-gspd", action="store_true")
     ap.add_argument("--skip-sharded", action="store_true", help="skip the column-sharded single SpMV (N > 1 only)")
     ap.add_argument("--force-sharded", action="store_true", help="run the column-sharded SpMV code path at N = 1 too")
@@ -384,6 +385,19 @@ def main():
     if (world > 1 or args.force_sharded) and not args.skip_sharded:
         out["gaxpy_one_matrix_column_sharded"] = sharded_spmv_section(args, lib, cs, comm, barrier, max_over_ranks)
 
+    if rank == 0 and world == 1 and not args.skip_configs:
+        # BASELINE's other configs (2: bcsstk16 SpMV, 3: cs_lusol on W, 4: A*A' on S) and cs_transpose at the headline
+        # size, each checking itself; never part of `value`.  bench_configs.py is the stand-alone form.
+        import bench_configs as bc
+        bc.SKIP_CPU = args.skip_cpu
+        other = {}
+        for name, fn in (("config2_gaxpy_bcsstk16", bc.config2), ("config3_lusol_W", bc.config3),
+                         ("transpose_grand_5M", bc.transpose_grand), ("config4_multiply_S", bc.config4)):
+            try:
+                other[name] = fn()
+            except Exception as e:                        # never take the headline down with it
+                other[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        out["other_configs"] = other
     if rank == 0 and world == 1 and not args.skip_cpu:
         py, c = cpu_baseline(args.cpu_n, per_col, args.cpu_seconds, args.gen)
         out["cpu_baseline"] = py
