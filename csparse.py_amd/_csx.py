@@ -76,6 +76,9 @@ _PROTOS = {
     "csx_cholsol_plan": [H, _i32p, C.POINTER(H)],
     "csx_cholsol_solve": [H, H, C.c_int32],
     "csx_cholsol_info": [H, _i32p, _i32p, _i32p],
+    "csx_qr_host": [C.c_int32, C.c_int32, C.c_int32, _i32p, _i32p, _f64p, _i32p, _i32p, _i32p, _i32p, C.c_int32, C.c_int32,
+                    _i32p, _i32p, _f64p, _i32p, _i32p, _f64p, _f64p],
+    "csx_qr_apply_host": [C.c_int32, _i32p, _i32p, _f64p, _f64p, C.c_int, _f64p],
     "csx_lu_blocks": [H, C.c_double, C.POINTER(H), C.POINTER(H), _i32p, C.POINTER(C.c_int)],
     "csx_updown": [H, C.c_int, C.c_int32, _i32p, _f64p, _i32p, C.POINTER(C.c_int)],
     "csx_lu_host": [C.c_int32, _i32p, _i32p, _f64p, C.c_double, C.POINTER(_i32p), C.POINTER(_i32p),

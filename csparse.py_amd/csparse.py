@@ -1294,68 +1294,48 @@ def cs_happly(V, i, beta, x):
 
 def cs_qr(A, S):
     """Sparse Householder QR, A = Q R (csparse.py:1797-1870).  N.L = V, N.U = R (diagonal last in
-    every column), N.B = beta."""
+    every column), N.B = beta.  Host C++ (csx_qr_host, csx_host.cpp): column by column along the column
+    elimination tree, like cs_lu a sequence of data-dependent steps."""
     if not CS_CSC(A) or S is None:
         return None
-    n, Ap, Ai, Ax = A.n, A.p, A.i, A.x
-    q, parent, pinv, m2, leftmost = S.q, S.parent, S.pinv, S.m2, S.leftmost
-    mark = [-1] * m2
-    stack = [0] * n
-    x = [0.0] * m2
+    if A.x is None:
+        raise TypeError("'NoneType' object is not subscriptable")
+    m, n, m2 = A.m, A.n, S.m2
+    Ap = _csx.i32(A.p[:n + 1])
+    nnz = int(Ap[n])
+    Ai, Ax = _csx.i32(A.i[:nnz]), _csx.f64(A.x[:nnz])
+    q = None if S.q is None else _csx.i32(S.q)
+    parent, pinv, leftmost = _csx.i32(S.parent), _csx.i32(S.pinv), _csx.i32(S.leftmost)
+    vcap, rcap = max(int(S.lnz), 1), max(int(S.unz), 1)
+    Vp, Rp = np.zeros(n + 1, np.int32), np.zeros(n + 1, np.int32)
+    Vi, Ri = np.zeros(vcap, np.int32), np.zeros(rcap, np.int32)
+    Vx, Rx, beta = np.zeros(vcap), np.zeros(rcap), np.zeros(max(n, 1))
+    st = _csx.load().csx_qr_host(m, n, m2, _csx.pi(Ap), _csx.pi(Ai), _csx.pd(Ax), _csx.pi(q), _csx.pi(parent), _csx.pi(pinv),
+                                 _csx.pi(leftmost), vcap, rcap, _csx.pi(Vp), _csx.pi(Vi), _csx.pd(Vx), _csx.pi(Rp),
+                                 _csx.pi(Ri), _csx.pd(Rx), _csx.pd(beta))
+    if st == _csx.EINVAL:
+        raise IndexError("list index out of range")
+    _csx.check(st, "csx_qr_host")
     N = csn()
-    N.L = V = cs_spalloc(m2, n, S.lnz, True, False)
-    N.U = R = cs_spalloc(m2, n, S.unz, True, False)
-    N.B = Beta = [0.0] * n
+    N.L = V = cs_spalloc(m2, n, vcap, True, False)
+    N.U = R = cs_spalloc(m2, n, rcap, True, False)
+    V.p, V.i, V.x = Vp.tolist(), Vi.tolist(), Vx.tolist()
+    R.p, R.i, R.x = Rp.tolist(), Ri.tolist(), Rx.tolist()
+    N.B = beta[:n].tolist()
     N.pinv = None
-    Rp, Ri, Rx = R.p, R.i, R.x
-    Vp, Vi, Vx = V.p, V.i, V.x
-    rnz = vnz = 0
-    for k in range(n):
-        Rp[k] = rnz
-        Vp[k] = p1 = vnz
-        mark[k] = k
-        Vi[vnz] = k
-        vnz += 1
-        top = n
-        col = q[k] if q is not None else k
-        for p in range(Ap[col], Ap[col + 1]):
-            i = leftmost[Ai[p]]
-            length = 0
-            while mark[i] != k:
-                stack[length] = i
-                length += 1
-                mark[i] = k
-                i = parent[i]
-            while length > 0:
-                top -= 1
-                length -= 1
-                stack[top] = stack[length]
-            i = pinv[Ai[p]]
-            x[i] = Ax[p]
-            if i > k and mark[i] < k:
-                Vi[vnz] = i
-                vnz += 1
-                mark[i] = k
-        for p in range(top, n):
-            i = stack[p]
-            cs_happly(V, i, Beta[i], x)
-            Ri[rnz] = i
-            Rx[rnz] = x[i]
-            rnz += 1
-            x[i] = 0
-            if parent[i] == k:
-                vnz = cs_scatter(V, i, 0, mark, None, k, V, vnz)
-        for p in range(p1, vnz):
-            Vx[p] = x[Vi[p]]
-            x[Vi[p]] = 0
-        Ri[rnz] = k
-        b = [Beta[k]]
-        Rx[rnz] = cs_house(Vx, p1, b, vnz - p1)
-        rnz += 1
-        Beta[k] = b[0]
-    Rp[n] = rnz
-    Vp[n] = vnz
     return N
+
+
+def _apply_q(N, x, transpose):
+    """x <- Q' x (transpose) or Q x for the Householder vectors in N.L / N.B (csx_qr_apply_host)."""
+    V = N.L
+    n = V.n
+    Vp = _csx.i32(V.p[:n + 1])
+    vnz = int(Vp[n])
+    xv = _csx.f64(x)
+    _csx.check(_csx.load().csx_qr_apply_host(n, _csx.pi(Vp), _csx.pi(_csx.i32(V.i[:vnz])), _csx.pd(_csx.f64(V.x[:vnz])),
+                                             _csx.pd(_csx.f64(N.B)), 1 if transpose else 0, _csx.pd(xv)), "csx_qr_apply_host")
+    x[:] = xv.tolist()
 
 
 def _square_view(T):
@@ -1383,8 +1363,7 @@ def cs_qrsol(order, A, b):
             return False
         x = xalloc(S.m2)
         cs_ipvec(S.pinv, b, x, m)
-        for k in range(n):
-            cs_happly(N.L, k, N.B[k], x)
+        _apply_q(N, x, True)
         cs_usolve(_square_view(N.U), x)
         cs_ipvec(S.q, x, b, n)
     else:
@@ -1396,8 +1375,7 @@ def cs_qrsol(order, A, b):
         x = xalloc(S.m2)
         cs_pvec(S.q, b, x, m)
         cs_utsolve(_square_view(N.U), x)
-        for k in range(m - 1, -1, -1):
-            cs_happly(N.L, k, N.B[k], x)
+        _apply_q(N, x, False)
         cs_pvec(S.pinv, x, b, n)
     return True
 

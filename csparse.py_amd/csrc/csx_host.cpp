@@ -404,3 +404,117 @@ extern "C" int csx_lu_host(int32_t n, const int32_t *Ap, const int32_t *Ai, cons
 }
 
 extern "C" void csx_host_free(void *p) { std::free(p); }
+
+// ---- sparse Householder QR, numeric phase (csparse.py:1797-1870 with :1216-1261) -------------------------------
+// Left-looking: column k of R and the Householder vector V(:,k) come from column q[k] of A after the earlier
+// reflections that touch it have been applied.  Which ones touch it is read off the column elimination tree:
+// every nonzero row i of the column starts a walk from leftmost[i] (the first column that has an entry in row i)
+// towards the root; the walk stops at a column already collected for this k.  The collected columns, each path
+// kept in root-ward order and later paths placed in front of earlier ones, are the nonzero pattern of R(:,k) in
+// an order in which every reflection precedes its ancestors -- the order the reflections are applied in and the
+// order the entries of R(:,k) are stored in (diagonal last).  V(:,k)'s pattern is the permuted rows of the column
+// below k together with the patterns of the V columns whose tree parent is k.
+//
+// Symbolic input from cs_sqr: parent (column etree of A'A), pinv (row permutation, length m2), leftmost (length m),
+// m2 (rows incl. fictitious ones), capacities vcap / rcap.  Output arrays are the caller's (sized by cs_sqr's counts).
+extern "C" int csx_qr_host(int32_t m, int32_t n, int32_t m2, const int32_t *Ap, const int32_t *Ai, const double *Ax,
+                           const int32_t *q, const int32_t *parent, const int32_t *pinv, const int32_t *leftmost,
+                           int32_t vcap, int32_t rcap, int32_t *Vp, int32_t *Vi, double *Vx, int32_t *Rp, int32_t *Ri,
+                           double *Rx, double *beta) {
+    if (m < 0 || n < 0 || m2 < m || !Ap || !Ai || !Ax || !parent || !pinv || !leftmost || !Vp || !Vi || !Vx || !Rp ||
+        !Ri || !Rx || !beta)
+        return CSX_EINVAL;
+    std::vector<int32_t> stamp((size_t)m2, -1);      // stamp[r] == k: row / column r already collected for column k
+    std::vector<int32_t> order((size_t)n > 0 ? (size_t)n : 1), path((size_t)n > 0 ? (size_t)n : 1);
+    std::vector<double> work((size_t)m2, 0.0);       // the column being reduced, in permuted row numbering
+    int32_t vnz = 0, rnz = 0;
+    // y <- (I - b v v') y for a stored reflection
+    auto reflect = [&](int32_t col, double b) {
+        double dot = 0.0;
+        for (int32_t p = Vp[col]; p < Vp[col + 1]; p++) dot += Vx[p] * work[(size_t)Vi[p]];
+        dot *= b;
+        for (int32_t p = Vp[col]; p < Vp[col + 1]; p++) work[(size_t)Vi[p]] -= Vx[p] * dot;
+    };
+    for (int32_t k = 0; k < n; k++) {
+        Rp[k] = rnz;
+        Vp[k] = vnz;
+        const int32_t vstart = vnz;
+        if (vnz >= vcap) return CSX_EINVAL;
+        stamp[(size_t)k] = k;                        // the diagonal position leads V(:,k)
+        Vi[vnz++] = k;
+        int32_t front = n;                           // order[front..n) = reflections to apply, children before parents
+        const int32_t col = q ? q[k] : k;
+        for (int32_t p = Ap[col]; p < Ap[col + 1]; p++) {
+            int32_t len = 0;
+            for (int32_t c = leftmost[Ai[p]]; stamp[(size_t)c] != k; c = parent[c]) {
+                path[(size_t)len++] = c;
+                stamp[(size_t)c] = k;
+            }
+            while (len > 0) order[(size_t)--front] = path[(size_t)--len];
+            const int32_t r = pinv[Ai[p]];
+            work[(size_t)r] = Ax[p];
+            if (r > k && stamp[(size_t)r] < k) {     // a row below the diagonal not yet in V(:,k)'s pattern
+                if (vnz >= vcap) return CSX_EINVAL;
+                Vi[vnz++] = r;
+                stamp[(size_t)r] = k;
+            }
+        }
+        for (int32_t t = front; t < n; t++) {
+            const int32_t c = order[(size_t)t];
+            reflect(c, beta[c]);
+            if (rnz >= rcap) return CSX_EINVAL;
+            Ri[rnz] = c;
+            Rx[rnz++] = work[(size_t)c];
+            work[(size_t)c] = 0.0;
+            if (parent[c] == k) {                    // V(:,c)'s rows below c pass on to V(:,k)
+                for (int32_t p = Vp[c]; p < Vp[c + 1]; p++) {
+                    const int32_t r = Vi[p];
+                    if (stamp[(size_t)r] < k) {
+                        if (vnz >= vcap) return CSX_EINVAL;
+                        stamp[(size_t)r] = k;
+                        Vi[vnz++] = r;
+                    }
+                }
+            }
+        }
+        for (int32_t p = vstart; p < vnz; p++) {
+            Vx[p] = work[(size_t)Vi[p]];
+            work[(size_t)Vi[p]] = 0.0;
+        }
+        // Householder vector of Vx[vstart..vnz): afterwards (I - beta v v') x = s e1 (csparse.py:1238-1261)
+        double tail2 = 0.0;
+        for (int32_t p = vstart + 1; p < vnz; p++) tail2 += Vx[p] * Vx[p];
+        const double head = Vx[vstart];
+        double s, b;
+        if (tail2 == 0.0) {
+            s = std::fabs(head);
+            b = head <= 0.0 ? 2.0 : 0.0;
+            Vx[vstart] = 1.0;
+        } else {
+            s = std::sqrt(head * head + tail2);
+            Vx[vstart] = head <= 0.0 ? head - s : -tail2 / (head + s);
+            b = -1.0 / (s * Vx[vstart]);
+        }
+        if (rnz >= rcap) return CSX_EINVAL;
+        Ri[rnz] = k;
+        Rx[rnz++] = s;
+        beta[k] = b;
+    }
+    Rp[n] = rnz;
+    Vp[n] = vnz;
+    return CSX_OK;
+}
+
+// x <- Q' x (transpose = 1: reflections 0 .. n-1 in order) or x <- Q x (transpose = 0: n-1 .. 0), csparse.py:1216-1235
+extern "C" int csx_qr_apply_host(int32_t n, const int32_t *Vp, const int32_t *Vi, const double *Vx, const double *beta,
+                                 int transpose, double *x) {
+    if (n < 0 || !Vp || !Vi || !Vx || !beta || !x) return CSX_EINVAL;
+    for (int32_t t = 0; t < n; t++) {
+        const int32_t k = transpose ? t : n - 1 - t;
+        double dot = 0.0;
+        for (int32_t p = Vp[k]; p < Vp[k + 1]; p++) dot += Vx[p] * x[Vi[p]];
+        dot *= beta[k];
+        for (int32_t p = Vp[k]; p < Vp[k + 1]; p++) x[Vi[p]] -= Vx[p] * dot;
+    }
+    return CSX_OK;
+}

@@ -224,6 +224,18 @@ int csx_lu_host(int32_t n, const int32_t *Ap, const int32_t *Ai, const double *A
                 int32_t **Lp, int32_t **Li, double **Lx, int32_t **Up, int32_t **Ui, double **Ux,
                 int32_t *pinv);
 void csx_host_free(void *p);
+
+/* cs_qr numeric phase, csparse.py:1797-1870 (+ cs_house :1238-1261, cs_happly :1216-1235): sparse Householder QR on
+ * the host (C++), A m-by-n with the symbolic analysis of cs_sqr(order 0, qr): parent (column etree of A'A), pinv
+ * (length m2), leftmost (length m), m2 rows incl. fictitious ones.  V (m2-by-n) and R (diagonal last in every column)
+ * are written into caller arrays of capacity vcap / rcap entries (cs_sqr's counts), beta has n entries.
+ * csx_qr_apply_host: x <- Q' x (transpose != 0) or Q x, x of length m2. */
+int csx_qr_host(int32_t m, int32_t n, int32_t m2, const int32_t *Ap, const int32_t *Ai, const double *Ax,
+                const int32_t *q /* or NULL */, const int32_t *parent, const int32_t *pinv, const int32_t *leftmost,
+                int32_t vcap, int32_t rcap, int32_t *Vp, int32_t *Vi, double *Vx, int32_t *Rp, int32_t *Ri, double *Rx,
+                double *beta);
+int csx_qr_apply_host(int32_t n, const int32_t *Vp, const int32_t *Vi, const double *Vx, const double *beta, int transpose,
+                      double *x);
 /* The same factorisation on the device for a matrix that is a batch of small independent blocks (many connected
  * components of at most 96 rows, found on the device): one workgroup per block, dense in LDS, the reference's
  * pivot rule.  *done = 0 when the matrix is not of that shape (or has duplicate entries): use csx_lu_host.
