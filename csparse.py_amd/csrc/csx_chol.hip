@@ -985,6 +985,110 @@ __global__ __launch_bounds__(256) void k_cholsol_dense(const Tree *__restrict__ 
     }
 }
 
+// ---- dense blocks, the reference's order (the DEFAULT solve of a forest of dense blocks) ------------------
+// Same organisation as k_cholsol_dense (one wave = one block x 64 right-hand sides, a lane's BS unknowns in
+// registers, the packed block staged in LDS by global->LDS DMA and broadcast), but every operation is the
+// reference's: multiply and subtract rounded separately, a true division by the diagonal, and the terms of an
+// unknown taken in the reference's order -- forward: ascending column (the sweep order); backward: ascending row,
+// which in the reversed sweep numbering is DEscending t, so the two passes are two bodies.  x is bit-identical
+// to cs_lsolve + cs_ltsolve for every right-hand side; the fused per-tree kernel it replaces on dense forests took
+// 24.8 ms per 128 right-hand sides on the 5M-row G-spd.
+#pragma clang fp contract(off)
+template <int BS, bool BACKWARD>
+__device__ __forceinline__ void dense_exact_pass(double (&x)[BS], const double *M, const double *D) {
+#pragma unroll
+    for (int sp = 0; sp < BS; sp++) {
+        double acc = x[sp];
+        if (!BACKWARD) {
+#pragma unroll
+            for (int tt = 0; tt < sp; tt++) {
+                const double t = M[sp * (sp - 1) / 2 + tt] * x[tt];
+                acc = acc - t;
+            }
+        } else {
+#pragma unroll
+            for (int tt = sp - 1; tt >= 0; tt--) {
+                const double t = M[sp * (sp - 1) / 2 + tt] * x[tt];
+                acc = acc - t;
+            }
+        }
+        x[sp] = acc / D[sp];
+        // without a fence the optimiser hoists every row's LDS reads to the top of the pass (they depend on nothing):
+        // 512 VGPRs and spills at BS = 32, 292 VGPRs at BS = 64
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// second launch-bound argument = waves per SIMD the register allocation must leave room for: without it the
+// scheduler spends 284-512 VGPRs on hoisted loads (one wave per SIMD, spills at BS = 32)
+template <int BS>
+__global__ __launch_bounds__(256, 2) void k_cholsol_dense_exact(const Tree *__restrict__ trees, int32_t ntrees,
+                                                             const int32_t *__restrict__ nodes,
+                                                             const int32_t *__restrict__ perm,
+                                                             const int32_t *__restrict__ f_ptr,
+                                                             const double *__restrict__ f_val,
+                                                             const int32_t *__restrict__ b_ptr,
+                                                             const double *__restrict__ b_val,
+                                                             const double *__restrict__ diagf,
+                                                             const double *__restrict__ diagb, double *B, int32_t nrhs,
+                                                             int32_t chunks) {
+    constexpr int NT = BS * (BS - 1) / 2;
+    constexpr int MSZ = ((NT + 127) / 128 * 128 > NT + BS) ? (NT + 127) / 128 * 128 : NT + BS;
+    __shared__ __attribute__((aligned(16))) double s_m[4][MSZ];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t task = (int64_t)blockIdx.x * 4 + w;
+    if (task >= (int64_t)ntrees * chunks) return;
+    const int32_t t = (int32_t)(task / chunks), h = (int32_t)(task % chunks);
+    const int32_t first = trees[t].first;
+    const int32_t rhs = h * 64 + lane;
+    const bool live = rhs < nrhs;
+    double *M = s_m[w], *DG = s_m[w] + NT;   // DG overlaps the DMA overrun and is written after it
+    int32_t jrow = 0;
+    if (lane < BS) {
+        jrow = nodes[first + lane];
+        if (perm) jrow = perm[jrow];
+    }
+    const int32_t rhs_ld = live ? rhs : nrhs - 1;
+    double x[BS];
+#pragma unroll
+    for (int a = 0; a < BS; a++) {
+        const int32_t row = __builtin_amdgcn_readlane(jrow, a);
+        x[a] = B[(int64_t)row * nrhs + rhs_ld];
+    }
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+        const int32_t *ptr = pass ? b_ptr : f_ptr;
+        const double *val = pass ? b_val : f_val;    // b_val here is the row-reversed dense copy
+        const double *dg = pass ? diagb : diagf;
+        const int32_t base = ptr[first];
+        const double dv = lane < BS ? dg[first + lane] : 1.0;
+#pragma unroll
+        for (int k = 0; k < (NT + 127) / 128; k++)
+            __builtin_amdgcn_global_load_lds((csx_gptr)(val + base + k * 128 + 2 * lane), (csx_lptr)(M + k * 128), 16, 0,
+                                             0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane < BS) DG[lane] = dv;
+        __builtin_amdgcn_wave_barrier();
+        if (pass == 0) dense_exact_pass<BS, false>(x, M, DG);
+        else dense_exact_pass<BS, true>(x, M, DG);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int a = 0; a < BS / 2; a++) {           // reverse: sweep order of the other pass / back to row order
+            const double tmp = x[a];
+            x[a] = x[BS - 1 - a];
+            x[BS - 1 - a] = tmp;
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < BS; a++) {
+        const int32_t row = __builtin_amdgcn_readlane(jrow, a);
+        if (live) B[(int64_t)row * nrhs + rhs] = x[a];
+    }
+}
+#pragma clang fp contract(fast)
+
 // ---- dense blocks on the matrix cores -------------------------------------------------------------------
 // For a dense 16 NB x 16 NB block the two substitutions are a blocked TRSM on 16 x 16 tiles:
 //     forward :  X_i <- W_ii (X_i - sum_{j<i} L_ij X_j)        backward:  X_i <- W_ii' (X_i - sum_{j>i} L_ji' X_j)
@@ -1333,8 +1437,25 @@ static int cholsol_solve(CholPlan *P, double *B, int32_t nrhs) {
         // zero pivots were detected by the analysis; report like the reference (ZeroDivisionError)
         int st = tri_solve_raw(P->fwd, B, 0, false);
         if (st != CSX_OK) return st;
-        // Dense-block kernels use FMA / explicit inverses (equal to rounding): only in the rounding-equal order.
-        // The default order runs the fused per-tree kernel below: the reference's operations, bit for bit.
+        // Forests of dense blocks: the default (exact) order runs the substitution kernel that keeps the reference's
+        // operations and their order; the rounding-equal order the FMA / matrix-core kernels.
+        if (P->dense_bs && !P->relaxed && ctx().opt.cholsol_dense_blocks) {
+            const int32_t chunks = (nrhs + 63) / 64;
+            const int64_t tasks = (int64_t)P->ntrees * chunks;
+            const dim3 grid((unsigned)((tasks + 3) / 4));
+#define CSX_DENSE_X(BS)                                                                                             \
+    hipLaunchKernelGGL(k_cholsol_dense_exact<BS>, grid, dim3(256), 0, s, P->trees, P->ntrees, P->tree_nodes, P->perm, \
+                       P->f_ptr, P->f_val, P->b_ptr, P->dense_b, P->diagk, P->diagb, B, nrhs, chunks)
+            switch (P->dense_bs) {
+                case 8: CSX_DENSE_X(8); break;
+                case 16: CSX_DENSE_X(16); break;
+                case 32: CSX_DENSE_X(32); break;
+                default: CSX_DENSE_X(64); break;
+            }
+#undef CSX_DENSE_X
+            CSX_LAUNCH_CHECK();
+            return CSX_OK;
+        }
         if (P->dense_bs && P->relaxed && ctx().opt.cholsol_dense_blocks) {
             const int32_t chunks = (nrhs + 63) / 64;
             const int64_t tasks = (int64_t)P->ntrees * chunks;
@@ -1445,7 +1566,7 @@ extern "C" int csx_cholsol_info(csx_handle_t h, int32_t *local, int32_t *ntrees,
     CholPlan *P = (CholPlan *)get(h, K_CHOLPLAN);
     if (!P) return CSX_EINVAL;
     // 0 level-scheduled, 1 fused in LDS, 2 dense blocks (substitution), 3 dense blocks on the matrix cores
-    if (local) *local = P->local ? (P->dense_bs && P->relaxed ? (P->frag_f ? 3 : 2) : 1) : 0;
+    if (local) *local = P->local ? (P->dense_bs ? (P->relaxed && P->frag_f ? 3 : 2) : 1) : 0;
     if (ntrees) *ntrees = P->ntrees;
     if (max_nodes) *max_nodes = P->max_nodes;
     return CSX_OK;

@@ -117,7 +117,7 @@ def test_gspd_factor_and_batched_solve(cs, nblocks, bs, k):
     n = nblocks * bs
     A = cs.cs_pin(_host_cs(cs, n, n, Ap, Ai, Ax))
     F = cs.cholsol_factor(A)                      # exact=True is the default
-    assert F.info() == {"fused_local": True, "dense_block": 0, "matrix_cores": False, "trees": nblocks,
+    assert F.info() == {"fused_local": True, "dense_block": bs, "matrix_cores": False, "trees": nblocks,
                         "max_nodes": bs}
     parent, cp = CO.schol(n, Ap, Ai)
     assert F.symbolic.parent == parent.tolist() and F.symbolic.cp == cp.tolist()
@@ -135,12 +135,17 @@ def test_gspd_factor_and_batched_solve(cs, nblocks, bs, k):
     B = synth.rhs(n, k, 0)
     gLp, gLi, gLx = _arr(L)
     refs = {r: CO.ltsolve(n, gLp, gLi, gLx, CO.lsolve(n, gLp, gLi, gLx, B[:, r])) for r in sorted(set([0, 1, k // 2, k - 1]))}
-    # default order (fused per-tree kernel, X tile in LDS): the reference's bits for every right-hand side
+    # default order (dense-block substitution in the reference's order): the reference's bits for every right-hand side
     dB = cs.dvec(B)
     assert F.solve(dB) is True
     X = dB.numpy()
     for r, ref in refs.items():
         assert X[:, r].tobytes() == ref.tobytes(), r
+    # the fused per-tree kernel (what forests of non-dense trees use) gives the same bits
+    with _csx.option("cholsol.dense_blocks", 0):
+        dB1 = cs.dvec(B)
+        assert F.solve(dB1) is True
+        assert dB1.numpy().tobytes() == X.tobytes()
     # rounding-equal order: blocked TRSM on the matrix cores for 16/32/64 blocks, FMA substitution for 8
     Ff = cs.cholsol_factor(A, exact=False)
     assert Ff.info()["dense_block"] == bs and Ff.info()["matrix_cores"] is (bs >= 16)

@@ -90,7 +90,7 @@ def test_cholsol_5m_block_spd_residual(cs, lib):
     _csx.check(lib.csx_cholsol_plan(hL, None, plan))
     path, trees, mx = C.c_int32(), C.c_int32(), C.c_int32()
     _csx.check(lib.csx_cholsol_info(plan, path, trees, mx))
-    assert (path.value, trees.value, mx.value) == (1, nb, bs)   # default order: fused per-tree kernel, the reference's bits
+    assert (path.value, trees.value, mx.value) == (2, nb, bs)   # default order: dense-block substitution, the reference's bits
     _csx.check(lib.csx_cholsol_set_order(plan, 0))              # the benchmark's leg: rounding-equal order
     _csx.check(lib.csx_cholsol_info(plan, path, trees, mx))
     assert (path.value, trees.value, mx.value) == (3, nb, bs)   # dense blocks on the matrix cores
