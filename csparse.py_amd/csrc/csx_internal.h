@@ -169,6 +169,18 @@ int expand_columns(const int32_t *Ap, int32_t n, int32_t nnz, int32_t *col);
 // alias inputs.  out_key may be nullptr.
 int stable_sort_by_key(const uint32_t *key, const uint32_t *a, const double *v, int64_t count,
                        uint32_t key_limit, uint32_t *out_key, uint32_t *out_a, double *out_v);
+// The same sort with what cs_transpose adds to it (both optional): expand_ptr -- the 32-bit payload is not read but
+// is the column of the record's position under these column pointers (expand_n columns); out_ptr -- the segment
+// starts of the sorted keys, out_ptr[r] = first slot with key >= r for r in [0, nkeys], written by the last pass
+// itself (then out_key may be null and no pass over the sorted keys is needed).
+struct SortExtra {
+    const int32_t *expand_ptr;
+    int32_t expand_n;
+    int32_t *out_ptr;
+    int32_t nkeys;
+};
+int stable_sort_by_key_ex(const uint32_t *key, const uint32_t *a, const double *v, int64_t count, uint32_t key_limit,
+                          uint32_t *out_key, uint32_t *out_a, double *out_v, const SortExtra *ex);
 // ptr[r] = first position q with sorted_key[q] >= r, r in [0, nkeys]; ptr has nkeys+1 slots
 int boundaries_from_sorted(const uint32_t *sorted_key, int64_t count, int32_t nkeys, int32_t *ptr);
 

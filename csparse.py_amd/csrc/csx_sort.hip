@@ -142,8 +142,17 @@ constexpr int RS_ROUNDS = 16;
 constexpr int RS_TILE = RS_THREADS * RS_ROUNDS;  // records per workgroup
 constexpr int RS_BINS = 256;
 
-__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint32_t *key, int64_t count, int shift,
-                                                        uint32_t nblocks, int32_t *hist) {
+// Between two passes a record with both payloads travels as its key (4 bytes, an array of its own: the next pass's
+// histogram reads nothing else) and (a, v) packed into 12 bytes: a tile's run in a bucket is then 16 x 12 = 192
+// contiguous bytes instead of 64 + 128 in two places, and runs below 128 bytes are what slows a scatter down
+// (tools/ubench/scatter_runs.hip: 64-byte runs 81 %, 32-byte runs 49 % of the rate of 128-byte runs).
+struct __attribute__((packed, aligned(4))) Pay {
+    uint32_t a, vlo, vhi;
+};
+
+// hist[tile][digit]: one coalesced 1 KiB row per tile
+__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint32_t *key, int64_t count, int shift, uint32_t mask,
+                                                        int32_t *hist) {
     __shared__ int h[RS_BINS];
     h[threadIdx.x] = 0;
     __syncthreads();
@@ -152,49 +161,123 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint32_t *key, int
         // full tile: 16-byte loads, a wave instruction covers 1 KiB (the order of the keys does not matter here)
         typedef uint32_t u32x4h __attribute__((ext_vector_type(4)));
         const u32x4h *k4 = reinterpret_cast<const u32x4h *>(key + base);
+        u32x4h v[RS_ROUNDS / 4];
+#pragma unroll
+        for (int r = 0; r < RS_ROUNDS / 4; r++) v[r] = k4[r * RS_THREADS + threadIdx.x];
 #pragma unroll
         for (int r = 0; r < RS_ROUNDS / 4; r++) {
-            const u32x4h v = k4[r * RS_THREADS + threadIdx.x];
-            atomicAdd(&h[(v.x >> shift) & (RS_BINS - 1)], 1);
-            atomicAdd(&h[(v.y >> shift) & (RS_BINS - 1)], 1);
-            atomicAdd(&h[(v.z >> shift) & (RS_BINS - 1)], 1);
-            atomicAdd(&h[(v.w >> shift) & (RS_BINS - 1)], 1);
+            atomicAdd(&h[(v[r].x >> shift) & mask], 1);
+            atomicAdd(&h[(v[r].y >> shift) & mask], 1);
+            atomicAdd(&h[(v[r].z >> shift) & mask], 1);
+            atomicAdd(&h[(v[r].w >> shift) & mask], 1);
         }
     } else {
 #pragma unroll 4
         for (int r = 0; r < RS_ROUNDS; r++) {
             int64_t idx = base + (int64_t)r * RS_THREADS + threadIdx.x;
-            if (idx < count) atomicAdd(&h[(key[idx] >> shift) & (RS_BINS - 1)], 1);
+            if (idx < count) atomicAdd(&h[(key[idx] >> shift) & mask], 1);
         }
     }
     __syncthreads();
-    hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+    hist[(size_t)blockIdx.x * RS_BINS + threadIdx.x] = h[threadIdx.x];
 }
+
+// hist[tile][digit] -> goff[tile][digit] = records with a smaller digit + records with this digit in earlier tiles,
+// i.e. the exclusive scan in (digit, tile) order, done on the tile-major matrix in three small steps: sums over
+// chunks of tiles, one workgroup that scans the chunk sums in (digit, chunk) order, running sums inside a chunk.
+__global__ __launch_bounds__(RS_BINS) void k_rs_colsum(const int32_t *hist, uint32_t nblocks, uint32_t chunk,
+                                                       int32_t *part) {
+    const uint32_t t0 = blockIdx.x * chunk, t1 = min(t0 + chunk, nblocks);
+    int s = 0;
+#pragma unroll 8
+    for (uint32_t t = t0; t < t1; t++) s += hist[(size_t)t * RS_BINS + threadIdx.x];
+    part[(size_t)blockIdx.x * RS_BINS + threadIdx.x] = s;
+}
+
+__global__ __launch_bounds__(RS_BINS) void k_rs_chunkscan(int32_t *part, uint32_t nchunks) {
+    int run = 0;
+#pragma unroll 8
+    for (uint32_t c = 0; c < nchunks; c++) {
+        const int v = part[(size_t)c * RS_BINS + threadIdx.x];
+        part[(size_t)c * RS_BINS + threadIdx.x] = run;
+        run += v;
+    }
+    int tot;
+    const int base = block_exclusive_scan(run, &tot);
+#pragma unroll 8
+    for (uint32_t c = 0; c < nchunks; c++) part[(size_t)c * RS_BINS + threadIdx.x] += base;
+}
+
+__global__ __launch_bounds__(RS_BINS) void k_rs_tileprefix(int32_t *hist, const int32_t *part, uint32_t nblocks,
+                                                           uint32_t chunk) {
+    const uint32_t t0 = blockIdx.x * chunk, t1 = min(t0 + chunk, nblocks);
+    int run = part[(size_t)blockIdx.x * RS_BINS + threadIdx.x];
+#pragma unroll 8
+    for (uint32_t t = t0; t < t1; t++) {
+        const int v = hist[(size_t)t * RS_BINS + threadIdx.x];
+        hist[(size_t)t * RS_BINS + threadIdx.x] = run;
+        run += v;
+    }
+}
+
+// tilecol[t] = the column that holds position min(t * RS_TILE, count - 1): the largest j < n with Ap[j] <= it
+__global__ void k_rs_tilecol(const int32_t *Ap, int32_t n, int64_t count, uint32_t nblocks, int32_t *tilecol) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > nblocks) return;
+    int64_t target = (int64_t)t * RS_TILE;
+    if (target > count - 1) target = count - 1;
+    int32_t lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int32_t mid = lo + (hi - lo + 1) / 2;
+        if ((int64_t)Ap[mid] <= target) lo = mid;
+        else hi = mid - 1;
+    }
+    tilecol[t] = lo;
+}
+
+struct RsArgs {
+    const uint32_t *key, *a;   // inputs: keys; 32-bit payload as an array (or none / expanded / inside pay)
+    const double *v;           //         64-bit payload as an array
+    const Pay *pay;            //         (a, v) records of the previous pass
+    uint32_t *okey, *oa;       // outputs (okey may be null)
+    double *ov;
+    Pay *opay;
+    const int32_t *goff;       // [tile][digit] global slot of the tile's first record with that digit
+    const int32_t *xp;         // not null: a = column of the record's position under the column pointers xp
+    const int32_t *tilecol;
+    int32_t *optr;             // not null (last pass): optr[key] = min(position of a record with that key)
+    int64_t count;
+    int shift;
+    uint32_t mask, nblocks;
+    int flat;
+};
 
 // Stable scatter of one workgroup tile (4096 records).  Ranks follow (wave, round, lane) = source
 // order.  Records are first placed in LDS in their sorted order inside the tile, then written out
 // position by position: consecutive threads write consecutive slots of a bucket, so the stores are
 // runs of whole 64/128-byte pieces instead of 4/8-byte singles.
-template <bool HAS_A, bool HAS_V, bool WRITE_KEY>
-__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint32_t *key, const uint32_t *a, const double *v,
-                                                           int64_t count, int shift, uint32_t nblocks,
-                                                           const int32_t *goff, uint32_t *okey, uint32_t *oa,
-                                                           double *ov, int getenv_flat) {
+template <bool HAS_A, bool HAS_V, bool IN_AOS, bool OUT_AOS>
+__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const RsArgs g) {
+    static_assert(!(IN_AOS || OUT_AOS) || (HAS_A && HAS_V), "packed records carry both payloads");
     __shared__ int wh[RS_WAVES][RS_BINS];
     __shared__ int gbase[RS_BINS];  // global slot of a bucket's first record minus its local start
     __shared__ int wsum[RS_WAVES];
     __shared__ uint32_t s_key[RS_TILE];
-    __shared__ uint32_t s_a[HAS_A ? RS_TILE : 1];
-    __shared__ double s_v[HAS_V ? RS_TILE : 1];
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[(HAS_A ? 4 : 0) * RS_TILE + (HAS_V ? 8 : 0) * RS_TILE + 16];
+    uint32_t *const s_a = reinterpret_cast<uint32_t *>(s_raw);
+    double *const s_v = reinterpret_cast<double *>(s_raw + (HAS_A ? 4 * RS_TILE : 0));
+    Pay *const s_pay = reinterpret_cast<Pay *>(s_raw);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t count = g.count;
+    const int shift = g.shift;
+    const uint32_t mask = g.mask, nblocks = g.nblocks;
 #pragma unroll
     for (int k = 0; k < RS_WAVES; k++) wh[k][threadIdx.x] = 0;
-    __syncthreads();
     // Workgroups are dealt to the 8 XCDs round-robin; give each XCD a contiguous range of tiles, so that
     // neighbouring tiles -- whose runs in a bucket are adjacent in memory -- meet in the same L2 and the
     // partial lines at the run boundaries are merged there.
     uint32_t tile = blockIdx.x;
-    if (!getenv_flat) {
+    if (!g.flat) {
         const uint32_t q = nblocks >> 3, rem = nblocks & 7u, x = blockIdx.x & 7u, kk = blockIdx.x >> 3;
         tile = x * q + (x < rem ? x : rem) + kk;
     }
@@ -209,14 +292,55 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint32_t *key, 
     for (int r = 0; r < RS_ROUNDS; r++) {
         const int64_t idx = wbase + r * 64 + lane;
         const int64_t cl = idx < count ? idx : count - 1;   // clamped: count > 0
-        kreg[r] = key[cl];
-        if (HAS_A) areg[r] = a[cl];
-        if (HAS_V) vreg[r] = v[cl];
+        kreg[r] = g.key[cl];
+        if (IN_AOS) {
+            const Pay pr = g.pay[cl];
+            areg[r] = pr.a;
+            vreg[r] = __hiloint2double((int)pr.vhi, (int)pr.vlo);
+        } else {
+            if (HAS_A && !g.xp) areg[r] = g.a[cl];
+            if (HAS_V) vreg[r] = g.v[cl];
+        }
     }
+    if (HAS_A && !IN_AOS && g.xp) {
+        // cs_transpose's first pass: the 32-bit payload is the record's column.  The columns that start inside this
+        // tile are listed in LDS (s_key is free until the ranking rounds) and every record counts the starts at or
+        // before its position.
+        const int32_t j0 = g.tilecol[tile], j1 = g.tilecol[tile + 1];
+        const int32_t K = j1 - j0;
+        if (K <= RS_TILE) {
+            for (int k = threadIdx.x; k < K; k += RS_THREADS) s_key[k] = (uint32_t)((int64_t)g.xp[j0 + 1 + k] - tbase);
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < RS_ROUNDS; r++) {
+                const uint32_t li = (uint32_t)(w * 64 * RS_ROUNDS + r * 64 + lane);
+                int lo = 0, hi = K;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (s_key[mid] <= li) lo = mid + 1;
+                    else hi = mid;
+                }
+                areg[r] = (uint32_t)(j0 + lo);
+            }
+        } else {  // a stretch of empty columns: search the pointer array itself
+#pragma unroll 1
+            for (int r = 0; r < RS_ROUNDS; r++) {
+                const int64_t pos = wbase + r * 64 + lane;
+                int32_t lo = j0, hi = j1;
+                while (lo < hi) {
+                    const int32_t mid = lo + (hi - lo + 1) / 2;
+                    if ((int64_t)g.xp[mid] <= pos) lo = mid;
+                    else hi = mid - 1;
+                }
+                areg[r] = (uint32_t)lo;
+            }
+        }
+    }
+    __syncthreads();
 #pragma unroll
     for (int r = 0; r < RS_ROUNDS; r++) {
         const int64_t idx = wbase + r * 64 + lane;
-        if (idx < count) atomicAdd(&wh[w][(kreg[r] >> shift) & (RS_BINS - 1)], 1);
+        if (idx < count) atomicAdd(&wh[w][(kreg[r] >> shift) & mask], 1);
     }
     __syncthreads();
     {
@@ -238,7 +362,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint32_t *key, 
         for (int k = 0; k < RS_WAVES; k++)
             if (k < w) off += wsum[k];
         int run = off + inc - tot;  // local start of bucket d
-        gbase[d] = goff[(size_t)d * nblocks + tile] - run;
+        gbase[d] = g.goff[(size_t)tile * RS_BINS + d] - run;
 #pragma unroll
         for (int k = 0; k < RS_WAVES; k++) {
             int c = wh[k][d];
@@ -253,7 +377,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint32_t *key, 
         int64_t idx = wbase + r * 64 + lane;
         bool valid = idx < count;
         uint32_t k = kreg[r];
-        uint32_t d = (k >> shift) & (RS_BINS - 1);
+        uint32_t d = (k >> shift) & mask;
         // lanes holding the same digit (multi-split by ballots, one per digit bit)
         unsigned long long peers = __ballot(valid);
 #pragma unroll
@@ -269,90 +393,224 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint32_t *key, 
         __builtin_amdgcn_wave_barrier();
         if (valid) {
             s_key[pos] = k;
-            if (HAS_A) s_a[pos] = areg[r];
-            if (HAS_V) s_v[pos] = vreg[r];
+            if (OUT_AOS) {
+                Pay pr;
+                pr.a = areg[r];
+                pr.vlo = (uint32_t)__double2loint(vreg[r]);
+                pr.vhi = (uint32_t)__double2hiint(vreg[r]);
+                s_pay[pos] = pr;
+            } else {
+                if (HAS_A) s_a[pos] = areg[r];
+                if (HAS_V) s_v[pos] = vreg[r];
+            }
         }
     }
     __syncthreads();
     const int tcount = (int)((count - tbase) < RS_TILE ? (count - tbase) : RS_TILE);
     for (int i = threadIdx.x; i < tcount; i += RS_THREADS) {
         const uint32_t k = s_key[i];
-        const int64_t g = (int64_t)gbase[(k >> shift) & (RS_BINS - 1)] + i;
-        if (WRITE_KEY) okey[g] = k;
-        if (HAS_A) oa[g] = s_a[i];
-        if (HAS_V) ov[g] = s_v[i];
+        const int64_t gp = (int64_t)gbase[(k >> shift) & mask] + i;
+        if (g.okey) g.okey[gp] = k;
+        if (OUT_AOS) {
+            g.opay[gp] = s_pay[i];
+        } else {
+            if (HAS_A) g.oa[gp] = s_a[i];
+            if (HAS_V) g.ov[gp] = s_v[i];
+        }
+        // last pass: equal keys are neighbours in a bucket; the first of each group in this tile proposes its slot
+        if (g.optr && (i == 0 || s_key[i - 1] != k)) atomicMin(&g.optr[k], (int32_t)gp);
     }
 }
 
 template <bool HAS_A, bool HAS_V>
-static int launch_scatter(bool write_key, dim3 grid, hipStream_t s, const uint32_t *key, const uint32_t *a,
-                          const double *v, int64_t count, int shift, uint32_t nblocks, const int32_t *goff,
-                          uint32_t *okey, uint32_t *oa, double *ov) {
-    const int flat = ablation_env("CSX_SORT_FLAT") ? 1 : 0;
-    if (write_key)
-        hipLaunchKernelGGL((k_rs_scatter<HAS_A, HAS_V, true>), grid, dim3(RS_THREADS), 0, s, key, a, v, count, shift,
-                           nblocks, goff, okey, oa, ov, flat);
-    else
-        hipLaunchKernelGGL((k_rs_scatter<HAS_A, HAS_V, false>), grid, dim3(RS_THREADS), 0, s, key, a, v, count, shift,
-                           nblocks, goff, okey, oa, ov, flat);
-    CSX_LAUNCH_CHECK();
-    return CSX_OK;
+static void launch_scatter(bool in_aos, bool out_aos, dim3 grid, hipStream_t s, const RsArgs &g) {
+    if constexpr (HAS_A && HAS_V) {
+        if (in_aos && out_aos) hipLaunchKernelGGL((k_rs_scatter<true, true, true, true>), grid, dim3(RS_THREADS), 0, s, g);
+        else if (in_aos) hipLaunchKernelGGL((k_rs_scatter<true, true, true, false>), grid, dim3(RS_THREADS), 0, s, g);
+        else if (out_aos) hipLaunchKernelGGL((k_rs_scatter<true, true, false, true>), grid, dim3(RS_THREADS), 0, s, g);
+        else hipLaunchKernelGGL((k_rs_scatter<true, true, false, false>), grid, dim3(RS_THREADS), 0, s, g);
+    } else {
+        hipLaunchKernelGGL((k_rs_scatter<HAS_A, HAS_V, false, false>), grid, dim3(RS_THREADS), 0, s, g);
+    }
 }
 
-int stable_sort_by_key(const uint32_t *key, const uint32_t *a, const double *v, int64_t count, uint32_t key_limit,
-                       uint32_t *out_key, uint32_t *out_a, double *out_v) {
-    if (count <= 0) return CSX_OK;
+// ---- reverse running minimum: p[r] = min(p[r], ..., p[n-1]) (turns "first slot of each key" into column pointers) ----
+constexpr int SM_ITEMS = 8;
+constexpr int SM_TILE = SCAN_THREADS * SM_ITEMS;
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_sufmin_block(const int32_t *p, int64_t n, int32_t *bm) {
+    __shared__ int wmin[SCAN_THREADS / 64];
+    const int64_t base = (int64_t)blockIdx.x * SM_TILE;
+    int m = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < SM_ITEMS; k++) {
+        const int64_t idx = base + (int64_t)k * SCAN_THREADS + threadIdx.x;
+        if (idx < n) m = min(m, p[idx]);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = min(m, __shfl_xor(m, d, 64));
+    if ((threadIdx.x & 63) == 0) wmin[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 1; k < SCAN_THREADS / 64; k++) m = min(m, wmin[k]);
+        bm[blockIdx.x] = m;
+    }
+}
+
+// bm_suffix: already the reverse running minimum of the block minima (or null for a single block)
+__global__ __launch_bounds__(SCAN_THREADS) void k_sufmin_apply(int32_t *p, int64_t n, const int32_t *bm_suffix,
+                                                               int64_t nb) {
+    __shared__ int tmin[SCAN_THREADS];
+    const int64_t base = (int64_t)blockIdx.x * SM_TILE + (int64_t)threadIdx.x * SM_ITEMS;
+    int v[SM_ITEMS];
+    int m = 0x7fffffff;
+#pragma unroll
+    for (int k = SM_ITEMS - 1; k >= 0; k--) {
+        v[k] = (base + k < n) ? p[base + k] : 0x7fffffff;
+        m = min(m, v[k]);
+    }
+    tmin[threadIdx.x] = m;
+    __syncthreads();
+    // minimum over the threads after this one: suffix scan over 256 values (Hillis-Steele in LDS)
+    for (int d = 1; d < SCAN_THREADS; d <<= 1) {
+        const int o = (threadIdx.x + d < SCAN_THREADS) ? tmin[threadIdx.x + d] : 0x7fffffff;
+        __syncthreads();
+        tmin[threadIdx.x] = min(tmin[threadIdx.x], o);
+        __syncthreads();
+    }
+    int carry = (bm_suffix && (int64_t)blockIdx.x + 1 < nb) ? bm_suffix[blockIdx.x + 1] : 0x7fffffff;
+    if (threadIdx.x + 1 < SCAN_THREADS) carry = min(carry, tmin[threadIdx.x + 1]);
+#pragma unroll
+    for (int k = SM_ITEMS - 1; k >= 0; k--) {
+        carry = min(carry, v[k]);
+        if (base + k < n) p[base + k] = carry;
+    }
+}
+
+static int suffix_min_i32(int32_t *p, int64_t n) {
+    if (n <= 0) return CSX_OK;
     hipStream_t s = ctx().stream;
+    const int64_t nb = (n + SM_TILE - 1) / SM_TILE;
+    int32_t *bm = nullptr;
+    if (nb > 1) {
+        CSX_TRY(dalloc(&bm, (size_t)nb));
+        hipLaunchKernelGGL(k_sufmin_block, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, p, n, bm);
+        const int st = suffix_min_i32(bm, nb);
+        if (st != CSX_OK) {
+            dfree(bm);
+            return st;
+        }
+    }
+    hipLaunchKernelGGL(k_sufmin_apply, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, p, n, bm, nb);
+    int st = hipGetLastError() == hipSuccess ? CSX_OK : CSX_ERUNTIME;
+    if (bm) {
+        if (hipStreamSynchronize(s) != hipSuccess) st = CSX_ERUNTIME;  // bm is freed below
+        dfree(bm);
+    }
+    return st;
+}
+
+__global__ void k_ptr_init(int32_t *ptr, int32_t nkeys, int32_t count) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nkeys) ptr[i] = 0x7fffffff;
+    else if (i == nkeys) ptr[i] = count;
+}
+
+int stable_sort_by_key_ex(const uint32_t *key, const uint32_t *a, const double *v, int64_t count, uint32_t key_limit,
+                          uint32_t *out_key, uint32_t *out_a, double *out_v, const SortExtra *ex) {
+    hipStream_t s = ctx().stream;
+    const int32_t *xp = ex ? ex->expand_ptr : nullptr;
+    int32_t *optr = ex ? ex->out_ptr : nullptr;
+    if (optr) {
+        const int64_t nk = (int64_t)ex->nkeys + 1;
+        hipLaunchKernelGGL(k_ptr_init, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, s, optr, ex->nkeys,
+                           (int32_t)(count > 0 ? count : 0));
+        CSX_LAUNCH_CHECK();
+    }
+    if (count <= 0) return optr ? suffix_min_i32(optr, (int64_t)ex->nkeys + 1) : CSX_OK;
     int bits = 1;
     while (bits < 32 && (1ull << bits) < (unsigned long long)key_limit) bits++;
     const int passes = (bits + 7) / 8;
     const uint32_t nblocks = (uint32_t)((count + RS_TILE - 1) / RS_TILE);
-    const bool has_a = a != nullptr, has_v = v != nullptr;
+    uint32_t chunk = (nblocks + 1023) / 1024;
+    if (chunk < 64) chunk = 64;
+    const uint32_t nchunks = (nblocks + chunk - 1) / chunk;
+    const bool has_a = a != nullptr || xp != nullptr, has_v = v != nullptr;
+    const bool packed = has_a && has_v;   // (a, v) travel as 12-byte records between passes
 
-    int32_t *hist = nullptr;
+    DevScope scope;
+    int32_t *hist = nullptr, *part = nullptr, *tilecol = nullptr;
     uint32_t *tk[2] = {nullptr, nullptr}, *ta[2] = {nullptr, nullptr};
     double *tv[2] = {nullptr, nullptr};
-    int st = dalloc(&hist, (size_t)RS_BINS * nblocks + 1);
+    Pay *tp[2] = {nullptr, nullptr};
+    int st = scope.alloc(&hist, (size_t)RS_BINS * nblocks);
+    if (st == CSX_OK) st = scope.alloc(&part, (size_t)RS_BINS * nchunks);
+    if (st == CSX_OK && xp) st = scope.alloc(&tilecol, (size_t)nblocks + 1);
     const int ntmp = passes > 2 ? 2 : passes - 1;
     for (int t = 0; t < ntmp && st == CSX_OK; t++) {
-        st = dalloc(&tk[t], (size_t)count);
-        if (st == CSX_OK && has_a) st = dalloc(&ta[t], (size_t)count);
-        if (st == CSX_OK && has_v) st = dalloc(&tv[t], (size_t)count);
+        st = scope.alloc(&tk[t], (size_t)count);
+        if (packed) {
+            if (st == CSX_OK) st = scope.alloc(&tp[t], (size_t)count);
+        } else {
+            if (st == CSX_OK && has_a) st = scope.alloc(&ta[t], (size_t)count);
+            if (st == CSX_OK && has_v) st = scope.alloc(&tv[t], (size_t)count);
+        }
     }
-    const uint32_t *ik = key, *ia = a;
-    const double *iv = v;
+    if (st == CSX_OK && xp) {
+        hipLaunchKernelGGL(k_rs_tilecol, dim3((nblocks + 1 + 255) / 256), dim3(256), 0, s, xp, ex->expand_n, count, nblocks,
+                           tilecol);
+        if (hipGetLastError() != hipSuccess) st = CSX_ERUNTIME;
+    }
+    RsArgs g{};
+    g.key = key;
+    g.a = a;
+    g.v = v;
+    g.xp = xp;
+    g.tilecol = tilecol;
+    g.count = count;
+    g.nblocks = nblocks;
+    g.flat = ablation_env("CSX_SORT_FLAT") ? 1 : 0;
+    bool in_aos = false;
+    int shift = 0;
     for (int ps = 0; ps < passes && st == CSX_OK; ps++) {
         const bool last = ps == passes - 1;
-        uint32_t *ok = last ? out_key : tk[ps & 1];
-        uint32_t *oa = last ? out_a : ta[ps & 1];
-        double *ov = last ? out_v : tv[ps & 1];
-        const int shift = ps * 8;
-        hipLaunchKernelGGL(k_rs_hist, dim3(nblocks), dim3(RS_THREADS), 0, s, ik, count, shift, nblocks, hist);
-        st = hipGetLastError() == hipSuccess ? CSX_OK : CSX_ERUNTIME;
-        if (st == CSX_OK) st = scan_exclusive_i32(hist, hist, (int64_t)RS_BINS * nblocks, nullptr);
-        if (st != CSX_OK) break;
-        const bool wk = ok != nullptr;
-        if (has_a && has_v)
-            st = launch_scatter<true, true>(wk, dim3(nblocks), s, ik, ia, iv, count, shift, nblocks, hist, ok, oa, ov);
-        else if (has_a)
-            st = launch_scatter<true, false>(wk, dim3(nblocks), s, ik, ia, iv, count, shift, nblocks, hist, ok, oa, ov);
-        else if (has_v)
-            st = launch_scatter<false, true>(wk, dim3(nblocks), s, ik, ia, iv, count, shift, nblocks, hist, ok, oa, ov);
-        else
-            st = launch_scatter<false, false>(wk, dim3(nblocks), s, ik, ia, iv, count, shift, nblocks, hist, ok, oa, ov);
-        ik = ok;
-        ia = oa;
-        iv = ov;
+        const int width = bits / passes + (ps < bits % passes ? 1 : 0);   // digits as even as the key allows
+        const bool out_aos = packed && !last;
+        g.shift = shift;
+        g.mask = (1u << width) - 1u;
+        g.okey = last ? out_key : tk[ps & 1];
+        g.oa = last ? out_a : ta[ps & 1];
+        g.ov = last ? out_v : tv[ps & 1];
+        g.opay = last ? nullptr : tp[ps & 1];
+        g.optr = last ? optr : nullptr;
+        g.goff = hist;
+        hipLaunchKernelGGL(k_rs_hist, dim3(nblocks), dim3(RS_THREADS), 0, s, g.key, count, g.shift, g.mask, hist);
+        hipLaunchKernelGGL(k_rs_colsum, dim3(nchunks), dim3(RS_BINS), 0, s, hist, nblocks, chunk, part);
+        hipLaunchKernelGGL(k_rs_chunkscan, dim3(1), dim3(RS_BINS), 0, s, part, nchunks);
+        hipLaunchKernelGGL(k_rs_tileprefix, dim3(nchunks), dim3(RS_BINS), 0, s, hist, part, nblocks, chunk);
+        if (has_a && has_v) launch_scatter<true, true>(in_aos, out_aos, dim3(nblocks), s, g);
+        else if (has_a) launch_scatter<true, false>(false, false, dim3(nblocks), s, g);
+        else if (has_v) launch_scatter<false, true>(false, false, dim3(nblocks), s, g);
+        else launch_scatter<false, false>(false, false, dim3(nblocks), s, g);
+        if (hipGetLastError() != hipSuccess) st = CSX_ERUNTIME;
+        g.key = g.okey;
+        g.a = g.oa;
+        g.v = g.ov;
+        g.pay = g.opay;
+        g.xp = nullptr;
+        in_aos = out_aos;
+        shift += width;
     }
-    if (st == CSX_OK && hipStreamSynchronize(s) != hipSuccess) st = CSX_ERUNTIME;
+    if (st == CSX_OK && optr) st = suffix_min_i32(optr, (int64_t)ex->nkeys + 1);
+    if (st == CSX_OK && hipStreamSynchronize(s) != hipSuccess) st = CSX_ERUNTIME;   // the temporaries go back now
     if (st == CSX_ERUNTIME) set_error("stable_sort_by_key: HIP failure (%s)", hipGetErrorString(hipGetLastError()));
-    dfree(hist);
-    for (int t = 0; t < 2; t++) {
-        dfree(tk[t]);
-        dfree(ta[t]);
-        dfree(tv[t]);
-    }
     return st;
+}
+
+int stable_sort_by_key(const uint32_t *key, const uint32_t *a, const double *v, int64_t count, uint32_t key_limit,
+                       uint32_t *out_key, uint32_t *out_a, double *out_v) {
+    return stable_sort_by_key_ex(key, a, v, count, key_limit, out_key, out_a, out_v, nullptr);
 }
 
 // ----------------------------------------------------------- boundaries ----

@@ -637,7 +637,7 @@ int multiply_device(const Csc *A, const Csc *B, Csc *C) {
         hipLaunchKernelGGL(k_sg_products, dim3((unsigned)(((int64_t)n + 3) / 4)), dim3(256), 0, s, n, A->p, B->p, B->i, m,
                            bin, colid, hprod, too_big);
         hipLaunchKernelGGL(k_sum_i32, dim3(512), dim3(256), 0, s, hprod, (int64_t)n, too_big + 1);
-        st = stable_sort_by_key(bin, colid, nullptr, n, 8, sbin, scol, nullptr);
+        st = stable_sort_by_key(bin, colid, nullptr, n, SG_NBINS, sbin, scol, nullptr);
     }
     if (st == CSX_OK) st = boundaries_from_sorted(sbin, n, SG_NBINS, bin_ptr_d);
     if (st == CSX_OK) {

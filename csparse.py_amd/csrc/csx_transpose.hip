@@ -3,9 +3,9 @@
 // The reference transposes with a counting sort by row: row counts
 // (:2305-2306), cs_cumsum (:2307), then a fill in ascending (column, position)
 // order (:2308-2314).  That is a STABLE sort of the entries by row index.  Here:
-// expand the column index of every entry, stable LSD radix sort of
-// (row key, column, value) records (csx_sort.hip), column pointers of the result
-// from the sorted keys.  p[] and i[] come out bit-identical to the reference,
+// stable LSD radix sort of (row key, column, value) records (csx_sort.hip); the
+// first pass derives each entry's column from its position, the last pass leaves
+// the first slot of every row, from which the column pointers of the result follow.  p[] and i[] come out bit-identical to the reference,
 // x[] is a pure permutation (no arithmetic).
 //
 // Algorithmic bytes: read 12 nnz + 4(n+1), write 12 nnz + 4(m+1).  The radix
@@ -29,18 +29,12 @@ int transpose_device(const Csc *A, bool values, Csc *C) {
         CSX_HIP(hipMemsetAsync(C->p, 0, ((size_t)C->n + 1) * sizeof(int32_t), s));
         return CSX_OK;
     }
-    int32_t *col = nullptr;
-    uint32_t *skey = nullptr;
-    int st = dalloc(&col, (size_t)A->nnz);
-    if (st == CSX_OK) st = dalloc(&skey, (size_t)A->nnz);
-    if (st == CSX_OK) st = expand_columns(A->p, A->n, A->nnz, col);
-    if (st == CSX_OK)
-        st = stable_sort_by_key((const uint32_t *)A->i, (const uint32_t *)col, with_values ? A->x : nullptr, A->nnz,
-                                (uint32_t)A->m, skey, (uint32_t *)C->i, C->x);
-    if (st == CSX_OK) st = boundaries_from_sorted(skey, A->nnz, A->m, C->p);
+    // one stable sort of the entries by row: columns are derived from positions in its first pass, the column
+    // pointers of the result come out of its last pass
+    SortExtra ex{A->p, A->n, C->p, A->m};
+    int st = stable_sort_by_key_ex((const uint32_t *)A->i, nullptr, with_values ? A->x : nullptr, A->nnz, (uint32_t)A->m,
+                                   nullptr, (uint32_t *)C->i, C->x, &ex);
     if (st == CSX_OK && hipStreamSynchronize(s) != hipSuccess) st = CSX_ERUNTIME;
-    dfree(col);
-    dfree(skey);
     return st;
 }
 
