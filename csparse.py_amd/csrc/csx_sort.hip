@@ -194,24 +194,55 @@ __global__ __launch_bounds__(RS_BINS) void k_rs_colsum(const int32_t *hist, uint
     part[(size_t)blockIdx.x * RS_BINS + threadIdx.x] = s;
 }
 
-__global__ __launch_bounds__(RS_BINS) void k_rs_chunkscan(int32_t *part, uint32_t nchunks) {
+// one workgroup, thread = (segment of chunks, digit): running sums over the chunks per digit, and dbase[d] = records
+// with a smaller digit
+constexpr int RS_SEGS = 4;
+__global__ __launch_bounds__(RS_BINS * RS_SEGS) void k_rs_chunkscan(int32_t *part, uint32_t nchunks, int32_t *dbase) {
+    __shared__ int segsum[RS_SEGS][RS_BINS];
+    const int d = threadIdx.x & (RS_BINS - 1), sg = threadIdx.x / RS_BINS;
+    const uint32_t per = (nchunks + RS_SEGS - 1) / RS_SEGS;
+    const uint32_t c0 = min(sg * per, nchunks), c1 = min(c0 + per, nchunks);
     int run = 0;
 #pragma unroll 8
-    for (uint32_t c = 0; c < nchunks; c++) {
-        const int v = part[(size_t)c * RS_BINS + threadIdx.x];
-        part[(size_t)c * RS_BINS + threadIdx.x] = run;
+    for (uint32_t c = c0; c < c1; c++) run += part[(size_t)c * RS_BINS + d];
+    segsum[sg][d] = run;
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < RS_SEGS; k++) {
+        const int v = segsum[k][d];
+        if (k < sg) before += v;
+        total += v;
+    }
+    run = before;
+#pragma unroll 8
+    for (uint32_t c = c0; c < c1; c++) {
+        const int v = part[(size_t)c * RS_BINS + d];
+        part[(size_t)c * RS_BINS + d] = run;
         run += v;
     }
-    int tot;
-    const int base = block_exclusive_scan(run, &tot);
-#pragma unroll 8
-    for (uint32_t c = 0; c < nchunks; c++) part[(size_t)c * RS_BINS + threadIdx.x] += base;
+    // exclusive scan of the digit totals by the first segment's threads (wave scans + 4 wave sums)
+    __shared__ int wtot[RS_BINS / 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int inc = 0;
+    if (sg == 0) {
+        inc = wave_inclusive_scan(total, lane);
+        if (lane == 63) wtot[w] = inc;
+    }
+    __syncthreads();
+    if (sg == 0) {
+        int off = 0;
+#pragma unroll
+        for (int k = 0; k < RS_BINS / 64; k++)
+            if (k < w) off += wtot[k];
+        dbase[d] = off + inc - total;
+    }
 }
 
-__global__ __launch_bounds__(RS_BINS) void k_rs_tileprefix(int32_t *hist, const int32_t *part, uint32_t nblocks,
-                                                           uint32_t chunk) {
+__global__ __launch_bounds__(RS_BINS) void k_rs_tileprefix(int32_t *hist, const int32_t *part, const int32_t *dbase,
+                                                           uint32_t nblocks, uint32_t chunk) {
     const uint32_t t0 = blockIdx.x * chunk, t1 = min(t0 + chunk, nblocks);
-    int run = part[(size_t)blockIdx.x * RS_BINS + threadIdx.x];
+    int run = part[(size_t)blockIdx.x * RS_BINS + threadIdx.x] + dbase[threadIdx.x];
 #pragma unroll 8
     for (uint32_t t = t0; t < t1; t++) {
         const int v = hist[(size_t)t * RS_BINS + threadIdx.x];
@@ -220,19 +251,46 @@ __global__ __launch_bounds__(RS_BINS) void k_rs_tileprefix(int32_t *hist, const 
     }
 }
 
-// tilecol[t] = the column that holds position min(t * RS_TILE, count - 1): the largest j < n with Ap[j] <= it
-__global__ void k_rs_tilecol(const int32_t *Ap, int32_t n, int64_t count, uint32_t nblocks, int32_t *tilecol) {
+// cs_transpose's first pass needs the column of every record.  One 512-byte descriptor per tile, written before the
+// pass and read by the tile with a single load that depends on nothing: word 0 = j0, the column that holds the tile's
+// first position (largest j with Ap[j] <= tile base); word 1 = K, the number of columns that start strictly inside the
+// tile; then the first RS_DESC_STARTS of those starts, relative to the tile base, 16 bits each.
+constexpr int RS_DESC_WORDS = 128;
+constexpr int RS_DESC_STARTS = (RS_DESC_WORDS - 2) * 2;
+
+__global__ void k_rs_tiledesc_head(const int32_t *Ap, int32_t n, int64_t count, uint32_t nblocks, uint32_t *desc) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t > nblocks) return;
-    int64_t target = (int64_t)t * RS_TILE;
-    if (target > count - 1) target = count - 1;
-    int32_t lo = 0, hi = n - 1;
+    if (t >= nblocks) return;
+    const int64_t tb = (int64_t)t * RS_TILE;
+    int64_t te = tb + RS_TILE - 1;
+    if (te > count - 1) te = count - 1;
+    int32_t lo = 0, hi = n - 1;   // largest j with Ap[j] <= tb
     while (lo < hi) {
         const int32_t mid = lo + (hi - lo + 1) / 2;
-        if ((int64_t)Ap[mid] <= target) lo = mid;
+        if ((int64_t)Ap[mid] <= tb) lo = mid;
         else hi = mid - 1;
     }
-    tilecol[t] = lo;
+    const int32_t j0 = lo;
+    hi = n - 1;                   // largest j with Ap[j] <= te (>= j0)
+    while (lo < hi) {
+        const int32_t mid = lo + (hi - lo + 1) / 2;
+        if ((int64_t)Ap[mid] <= te) lo = mid;
+        else hi = mid - 1;
+    }
+    desc[(size_t)t * RS_DESC_WORDS] = (uint32_t)j0;
+    desc[(size_t)t * RS_DESC_WORDS + 1] = (uint32_t)(lo - j0);
+}
+
+__global__ void k_rs_tiledesc_starts(const int32_t *Ap, int32_t n, int64_t count, uint32_t *desc) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int64_t p = Ap[j];
+    if (p >= count) return;                       // empty columns at the end start in no tile
+    const int64_t t = p / RS_TILE;
+    const uint32_t rel = (uint32_t)(p - t * RS_TILE);
+    if (rel == 0) return;                         // at the tile base: that is j0 or an empty column before it
+    const int64_t k = j - (int64_t)desc[(size_t)t * RS_DESC_WORDS] - 1;
+    if (k < RS_DESC_STARTS) reinterpret_cast<uint16_t *>(desc + (size_t)t * RS_DESC_WORDS + 2)[k] = (uint16_t)rel;
 }
 
 struct RsArgs {
@@ -244,7 +302,7 @@ struct RsArgs {
     Pay *opay;
     const int32_t *goff;       // [tile][digit] global slot of the tile's first record with that digit
     const int32_t *xp;         // not null: a = column of the record's position under the column pointers xp
-    const int32_t *tilecol;
+    const uint32_t *desc;      //           and the per-tile descriptors for it
     int32_t *optr;             // not null (last pass): optr[key] = min(position of a record with that key)
     int64_t count;
     int shift;
@@ -288,6 +346,13 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const RsArgs g) {
     // (latency-bound) ranking rounds start, instead of one exposed round trip per round
     uint32_t kreg[RS_ROUNDS], areg[HAS_A ? RS_ROUNDS : 1];
     double vreg[HAS_V ? RS_ROUNDS : 1];
+    // cs_transpose's first pass: the tile's descriptor is requested with the records
+    const bool expand = HAS_A && !IN_AOS && g.xp != nullptr;
+    uint32_t d0 = 0, d1 = 0;
+    if (expand) {
+        d0 = g.desc[(size_t)tile * RS_DESC_WORDS + lane];
+        d1 = g.desc[(size_t)tile * RS_DESC_WORDS + 64 + lane];
+    }
 #pragma unroll
     for (int r = 0; r < RS_ROUNDS; r++) {
         const int64_t idx = wbase + r * 64 + lane;
@@ -302,26 +367,54 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const RsArgs g) {
             if (HAS_V) vreg[r] = g.v[cl];
         }
     }
-    if (HAS_A && !IN_AOS && g.xp) {
-        // cs_transpose's first pass: the 32-bit payload is the record's column.  The columns that start inside this
-        // tile are listed in LDS (s_key is free until the ranking rounds) and every record counts the starts at or
-        // before its position.
-        const int32_t j0 = g.tilecol[tile], j1 = g.tilecol[tile + 1];
-        const int32_t K = j1 - j0;
-        if (K <= RS_TILE) {
-            for (int k = threadIdx.x; k < K; k += RS_THREADS) s_key[k] = (uint32_t)((int64_t)g.xp[j0 + 1 + k] - tbase);
+    if (expand) {
+        // the 32-bit payload is the record's column
+        const int32_t j0 = __builtin_amdgcn_readlane((int)d0, 0), K = __builtin_amdgcn_readlane((int)d0, 1);
+        const int32_t j1 = j0 + K;
+        if (K <= RS_DESC_STARTS) {
+            // every start is in the descriptor: wave w paints the positions of the columns w, w + 4, ... (and of j0,
+            // which holds the positions before the first start) with their column, then each record reads its own
+            uint32_t *const s_col = reinterpret_cast<uint32_t *>(s_raw);   // free until the ranking rounds
+            const int wu = __builtin_amdgcn_readfirstlane(w);
+            for (int c = wu - 1; c < K; c += RS_WAVES) {
+                int b = 0, e = RS_TILE;
+                if (c >= 0) {
+                    const int h = c + 4;
+                    const uint32_t wd = (h >> 1) < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)d0, (h >> 1) & 63)
+                                                      : (uint32_t)__builtin_amdgcn_readlane((int)d1, (h >> 1) & 63);
+                    b = (int)((wd >> (16 * (h & 1))) & 0xffffu);
+                }
+                if (c + 1 < K) {
+                    const int h = c + 5;
+                    const uint32_t wd = (h >> 1) < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)d0, (h >> 1) & 63)
+                                                      : (uint32_t)__builtin_amdgcn_readlane((int)d1, (h >> 1) & 63);
+                    e = (int)((wd >> (16 * (h & 1))) & 0xffffu);
+                }
+                for (int q = b + lane; q < e; q += 64) s_col[q] = (uint32_t)(j0 + 1 + c);
+            }
             __syncthreads();
 #pragma unroll
-            for (int r = 0; r < RS_ROUNDS; r++) {
-                const uint32_t li = (uint32_t)(w * 64 * RS_ROUNDS + r * 64 + lane);
-                int lo = 0, hi = K;
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (s_key[mid] <= li) lo = mid + 1;
-                    else hi = mid;
+            for (int r = 0; r < RS_ROUNDS; r++) areg[r] = s_col[w * 64 * RS_ROUNDS + r * 64 + lane];
+        } else if (K <= RS_TILE) {
+            // many short columns: their starts are listed in LDS (s_key is free until the ranking rounds) and every
+            // record counts the starts at or before its position, 16 searches side by side
+            for (int k = threadIdx.x; k < K; k += RS_THREADS) s_key[k] = (uint32_t)((int64_t)g.xp[j0 + 1 + k] - tbase);
+            __syncthreads();
+            int lo[RS_ROUNDS];
+#pragma unroll
+            for (int r = 0; r < RS_ROUNDS; r++) lo[r] = 0;
+            int top = 1;
+            while (top * 2 <= K) top *= 2;
+            for (int half = top; half > 0; half >>= 1) {
+#pragma unroll
+                for (int r = 0; r < RS_ROUNDS; r++) {
+                    const uint32_t li = (uint32_t)(w * 64 * RS_ROUNDS + r * 64 + lane);
+                    const int mid = lo[r] + half;
+                    if (mid <= K && s_key[mid - 1] <= li) lo[r] = mid;
                 }
-                areg[r] = (uint32_t)(j0 + lo);
             }
+#pragma unroll
+            for (int r = 0; r < RS_ROUNDS; r++) areg[r] = (uint32_t)(j0 + lo[r]);
         } else {  // a stretch of empty columns: search the pointer array itself
 #pragma unroll 1
             for (int r = 0; r < RS_ROUNDS; r++) {
@@ -540,13 +633,15 @@ int stable_sort_by_key_ex(const uint32_t *key, const uint32_t *a, const double *
     const bool packed = has_a && has_v;   // (a, v) travel as 12-byte records between passes
 
     DevScope scope;
-    int32_t *hist = nullptr, *part = nullptr, *tilecol = nullptr;
+    int32_t *hist = nullptr, *part = nullptr;
+    uint32_t *desc = nullptr;
     uint32_t *tk[2] = {nullptr, nullptr}, *ta[2] = {nullptr, nullptr};
     double *tv[2] = {nullptr, nullptr};
     Pay *tp[2] = {nullptr, nullptr};
     int st = scope.alloc(&hist, (size_t)RS_BINS * nblocks);
-    if (st == CSX_OK) st = scope.alloc(&part, (size_t)RS_BINS * nchunks);
-    if (st == CSX_OK && xp) st = scope.alloc(&tilecol, (size_t)nblocks + 1);
+    if (st == CSX_OK) st = scope.alloc(&part, (size_t)RS_BINS * (nchunks + 1));
+    int32_t *const dbase = part + (size_t)RS_BINS * nchunks;
+    if (st == CSX_OK && xp) st = scope.alloc(&desc, (size_t)nblocks * RS_DESC_WORDS);
     const int ntmp = passes > 2 ? 2 : passes - 1;
     for (int t = 0; t < ntmp && st == CSX_OK; t++) {
         st = scope.alloc(&tk[t], (size_t)count);
@@ -558,8 +653,10 @@ int stable_sort_by_key_ex(const uint32_t *key, const uint32_t *a, const double *
         }
     }
     if (st == CSX_OK && xp) {
-        hipLaunchKernelGGL(k_rs_tilecol, dim3((nblocks + 1 + 255) / 256), dim3(256), 0, s, xp, ex->expand_n, count, nblocks,
-                           tilecol);
+        hipLaunchKernelGGL(k_rs_tiledesc_head, dim3((nblocks + 255) / 256), dim3(256), 0, s, xp, ex->expand_n, count, nblocks,
+                           desc);
+        hipLaunchKernelGGL(k_rs_tiledesc_starts, dim3((unsigned)(((int64_t)ex->expand_n + 255) / 256)), dim3(256), 0, s, xp,
+                           ex->expand_n, count, desc);
         if (hipGetLastError() != hipSuccess) st = CSX_ERUNTIME;
     }
     RsArgs g{};
@@ -567,7 +664,7 @@ int stable_sort_by_key_ex(const uint32_t *key, const uint32_t *a, const double *
     g.a = a;
     g.v = v;
     g.xp = xp;
-    g.tilecol = tilecol;
+    g.desc = desc;
     g.count = count;
     g.nblocks = nblocks;
     g.flat = ablation_env("CSX_SORT_FLAT") ? 1 : 0;
@@ -587,8 +684,8 @@ int stable_sort_by_key_ex(const uint32_t *key, const uint32_t *a, const double *
         g.goff = hist;
         hipLaunchKernelGGL(k_rs_hist, dim3(nblocks), dim3(RS_THREADS), 0, s, g.key, count, g.shift, g.mask, hist);
         hipLaunchKernelGGL(k_rs_colsum, dim3(nchunks), dim3(RS_BINS), 0, s, hist, nblocks, chunk, part);
-        hipLaunchKernelGGL(k_rs_chunkscan, dim3(1), dim3(RS_BINS), 0, s, part, nchunks);
-        hipLaunchKernelGGL(k_rs_tileprefix, dim3(nchunks), dim3(RS_BINS), 0, s, hist, part, nblocks, chunk);
+        hipLaunchKernelGGL(k_rs_chunkscan, dim3(1), dim3(RS_BINS * RS_SEGS), 0, s, part, nchunks, dbase);
+        hipLaunchKernelGGL(k_rs_tileprefix, dim3(nchunks), dim3(RS_BINS), 0, s, hist, part, dbase, nblocks, chunk);
         if (has_a && has_v) launch_scatter<true, true>(in_aos, out_aos, dim3(nblocks), s, g);
         else if (has_a) launch_scatter<true, false>(false, false, dim3(nblocks), s, g);
         else if (has_v) launch_scatter<false, true>(false, false, dim3(nblocks), s, g);

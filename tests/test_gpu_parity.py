@@ -196,3 +196,45 @@ def test_transpose_wide_keys_three_radix_passes(cs):
     AT = cs.cs_transpose(A, True)
     assert AT.m == n and AT.n == m
     assert AT.p == Tp.tolist() and AT.i == Ti.tolist() and np.asarray(AT.x).tobytes() == Tx.tobytes()
+
+
+def _transpose_abi(A_np, values=True):
+    """cs_transpose through the C ABI on numpy arrays (no Python lists: for cases with millions of rows)."""
+    import _csx
+    m, n, Ap, Ai, Ax = A_np
+    lib = _csx.lib()
+    hA, hT = _csx.new_handle(), _csx.new_handle()
+    _csx.check(lib.csx_csc_upload(m, n, _csx.pi(Ap), _csx.pi(Ai), _csx.pd(Ax), hA))
+    _csx.check(lib.csx_transpose(hA, 1 if values else 0, hT))
+    nnz = int(Ap[-1])
+    Tp, Ti, Tx = np.empty(m + 1, np.int32), np.empty(nnz, np.int32), np.empty(nnz, np.float64)
+    _csx.check(lib.csx_csc_download(hT, _csx.pi(Tp), _csx.pi(Ti), _csx.pd(Tx) if values else None))
+    _csx.free(hA)
+    _csx.free(hT)
+    return Tp, Ti, Tx
+
+
+@pytest.mark.parametrize("m,n,nnz,what", [
+    (41, 30011, 3000, "thousands of empty columns start inside one tile: columns searched in the pointer array"),
+    (5000, 9000, 30000, "about 1 200 column starts per tile: starts listed in LDS and searched"),
+    (70001, 400, 50000, "about 30 starts per tile: columns painted from the tile descriptor; three-block pointer scan"),
+    (17000001, 7, 9000, "25-bit row keys: four passes"),
+    (300, 3, 20000, "three long columns: most tiles lie inside one column"),
+])
+def test_transpose_column_expansion_paths(cs, m, n, nnz, what):
+    """The first radix pass derives each entry's column from its position (csparse.py:2308-2314 walks the columns);
+    every way the kernel does that, with duplicates and unsorted rows, against the C oracle, bit for bit."""
+    rng = np.random.default_rng(m + n)
+    cols = np.sort(rng.integers(0, n, nnz))
+    if n > 10:
+        cols[cols < n // 10] = n // 10                      # empty columns in front ...
+        cols[cols > n - n // 20] = n - n // 20              # ... and at the end
+    rows = rng.integers(0, m, nnz).astype(np.int32)
+    rows[::5] = rows[1::5][: len(rows[::5])]                # duplicates, source order must survive
+    vals = rng.standard_normal(nnz)
+    Ap = np.concatenate([[0], np.cumsum(np.bincount(cols, minlength=n))]).astype(np.int32)
+    Rp, Ri, Rx = CO.transpose(m, n, Ap, rows, vals)
+    Tp, Ti, Tx = _transpose_abi((m, n, Ap, rows, vals))
+    assert np.array_equal(Tp, Rp) and np.array_equal(Ti, Ri) and Tx.tobytes() == Rx.tobytes(), what
+    Tp, Ti, _ = _transpose_abi((m, n, Ap, rows, vals), values=False)
+    assert np.array_equal(Tp, Rp) and np.array_equal(Ti, Ri), what
