@@ -167,12 +167,37 @@ def config3():
         O.cs_lsolve(Lo, y)
         O.cs_usolve(Uo, y)
     cpu = cpu_port("cs_lsolve + cs_usolve", cpu_solve, 1.0, "solves/s", "W at full size (n=%d, nnz(L)+nnz(U)=%d)" % (n, int(Lp[-1] + Up[-1])))
+    # cs_spsolve for every column of A against L (the step cs_lu takes per column, here with the finished factor):
+    # one device call, one lane per column; beside it the reference's loop on a sample of columns
+    X = cs.spsolve_columns(L, A, None, True)
+    _csx.sync()
+    t0 = time.perf_counter()
+    X = cs.spsolve_columns(L, A, None, True)
+    _csx.sync()
+    t_sps = time.perf_counter() - t0
+    xn = X._dev.info()[2]
+    Ao = oracle_cs(O, n, n, Ap, Ai, Ax)
+    ncpu = 20 * bs
+    xi_w, x_w = [0] * (2 * n), [0.0] * n
+    same = True
+    Xp = np.asarray(X.p[:ncpu + 1])
+    Xi_, Xx_ = np.asarray(X.i[:int(Xp[-1])]), np.asarray(X.x[:int(Xp[-1])])
+
+    def cpu_sps():
+        nonlocal same
+        for k in range(ncpu):
+            top = O.cs_spsolve(Lo, Ao, k, xi_w, x_w, None, True)
+            same = same and xi_w[top:n] == Xi_[Xp[k]:Xp[k + 1]].tolist() and \
+                np.asarray([x_w[j] for j in xi_w[top:n]]).tobytes() == Xx_[Xp[k]:Xp[k + 1]].tobytes()
+    cpu_sps_res = cpu_port("cs_spsolve", cpu_sps, float(ncpu), "columns/s", "the first %d columns of W against L" % ncpu)
+    spsolve = {"columns": n, "entries_of_X": int(xn), "s": round(t_sps, 4), "columns_per_s": round(n / t_sps, 1),
+               "bit_identical_to_oracle_on_sample": bool(same) if cpu_sps_res else None, "cpu_baseline": cpu_sps_res}
     # residual of the whole cs_lusol sequence against A
     r = CO.gaxpy(n, n, Ap, Ai, Ax, ref_x, -b)
     return {"config": "cs_lusol solve phase on W (west0067 tiling, n=%d, nnz(A)=%d, nnz(L)+nnz(U)=%d)"
                       % (n, nb * bnnz, int(Lp[-1] + Up[-1])),
             "device_lu_s": round(t_lu, 4), "host_lu_s_one_core": round(t_lu_host, 4), "same_pivots_as_host": bool(same_pivots),
-            "components_of_L": comp.value, "results": res,
+            "components_of_L": comp.value, "results": res, "spsolve_all_columns": spsolve,
             "residual_inf": float(np.max(np.abs(r))), "cpu_baseline": cpu}
 
 

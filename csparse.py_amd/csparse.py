@@ -874,6 +874,35 @@ def cs_chol(A, S):
     return N
 
 
+def spsolve_columns(G, B, pinv=None, lo=True, values=True):
+    """cs_spsolve (csparse.py:2078-2113) for every column of B in one device call: a CSC matrix X whose column k
+    lists the reach of B(:,k) in the reference's xi[top..n-1] order (cs_reach :1939-1958, cs_dfs :789-829) with the
+    solution of G x = B(:,k) beside it, bit-identical to the reference called column by column.  G lower (lo) or
+    upper triangular; pinv as in cs_lu (negative = no column yet).  values=False: the reaches alone.  None on bad
+    input.  The list-level cs_spsolve / cs_reach / cs_dfs (one column, caller-owned work arrays) stay host functions."""
+    if not CS_CSC(G) or not CS_CSC(B) or G.m != G.n or B.m != G.n:
+        return None
+    pv = None if pinv is None else _csx.i32(pinv[:G.n])
+    with _Resident(G) as dG, _Resident(B) as dB:
+        h = _csx.new_handle()
+        st = _csx.lib().csx_spsolve(dG.handle, dB.handle, None if pv is None else _csx.pi(pv), 1 if lo else 0,
+                                    1 if values else 0, h)
+        if st == _csx.EINVAL:
+            raise IndexError("list index out of range")
+        _csx.check(st, "csx_spsolve")
+    X = _from_device(h, lambda nnz: max(nnz, 1))
+    if not (G._pinned and B._pinned):
+        X._materialise()
+        X._dev = None
+        X._pinned = False
+    return X
+
+
+def reach_columns(G, B, pinv=None):
+    """cs_reach (csparse.py:1939-1958) for every column of B: column k of the result = xi[top..n-1]."""
+    return spsolve_columns(G, B, pinv, True, False)
+
+
 def cs_updown(L, sigma, C, parent):
     """Sparse Cholesky rank-1 update (sigma = +1) / downdate (-1): L L' + sigma w w' with w = the one column of
     C, in place (csparse.py:2318-2365).  True on success; False on bad input or when the downdate is not positive

@@ -243,6 +243,15 @@ int csx_qr_apply_host(int32_t n, const int32_t *Vp, const int32_t *Vi, const dou
  * Values equal the left-looking code's to rounding.  CSX_ENOTSPD: a singular block. */
 int csx_lu_blocks(csx_handle_t A, double tol, csx_handle_t *L, csx_handle_t *U, int32_t *pinv, int *done);
 
+/* cs_spsolve (csparse.py:2078-2113) with cs_reach (:1939-1958) and cs_dfs (:789-829), for every column of B at once:
+ * X(:,k) solves G X(:,k) = B(:,k), G n-by-n lower (lo != 0, diagonal first in every column) or upper (diagonal last)
+ * triangular, B n-by-nb sparse.  pinv (host, n entries, or NULL): column pinv[j] of G belongs to node j, a negative
+ * entry = no column (the partial permutation cs_lu hands over).  Column k of X lists the reach of B(:,k) in the
+ * reference's xi[top..n-1] order with the solution beside it -- pattern order and values bit-identical to calling the
+ * reference column by column.  values == 0: pattern only (cs_reach for every column; G and B need no values).
+ * One lane per column of B runs the reference's own loops; work space n * 17 bytes per column in flight. */
+int csx_spsolve(csx_handle_t G, csx_handle_t B, const int32_t *pinv /* or NULL */, int lo, int values, csx_handle_t *X);
+
 /* ---- synthetic inputs of the benchmark configs, generated on
  * the device from a counter-based hash so host and device agree bit for bit ---- */
 int csx_gen_grand(int32_t n, int32_t per_col, uint64_t seed, csx_handle_t *out);
