@@ -41,7 +41,11 @@ constexpr int SG_GLOBAL_WGS = 64;     // concurrent workgroups with global accum
 enum { ACC_LDS_DENSE = 0, ACC_LDS_HASH = 1, ACC_GLOBAL_DENSE = 2 };
 
 // column bins (sort key): dense LDS accumulator, eight LDS-hash bins by number of products, global accumulator
-constexpr int SG_BIN_DENSE = 0, SG_BIN_HASH0 = 1, SG_HASH_BINS = 8, SG_BIN_GLOBAL = 9, SG_BIN_EMPTY = 15, SG_NBINS = 16;
+// and, for the one-pass kernels, six more hash bins for "narrow" columns: at most 64 entries in B(:,j), each naming a
+// column of A with at most 32 entries (k_sg_hash2)
+constexpr int SG_BIN_DENSE = 0, SG_BIN_HASH0 = 1, SG_HASH_BINS = 8, SG_BIN_NARROW0 = 9, SG_NARROW_BINS = 6,
+              SG_BIN_GLOBAL = 15, SG_BIN_EMPTY = 31, SG_NBINS = 32;
+constexpr int H2_MAXSEG = 64, H2_MAXLEN = 32, H2_MAXP = 2048;
 constexpr int SG_HASH_MAXP = 4096;
 __host__ __device__ constexpr int sg_hash_limit(int hb) {   // products a column of hash bin hb may have
     return hb == 0 ? 256 : hb == 1 ? 512 : hb == 2 ? 768 : hb == 3 ? 1024 : hb == 4 ? 1536 : hb == 5 ? 2048 : hb == 6 ? 3072 : 4096;
@@ -55,12 +59,18 @@ __global__ __launch_bounds__(256) void k_sg_products(int32_t n, const int32_t *_
     const int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (j >= n) return;
     unsigned long long P = 0;
+    int32_t maxlen = 0;
     for (int32_t p = Bp[j] + lane; p < Bp[j + 1]; p += 64) {
         const int32_t c = Bi[p];
-        P += (unsigned long long)(Ap[c + 1] - Ap[c]);
+        const int32_t len = Ap[c + 1] - Ap[c];
+        P += (unsigned long long)len;
+        maxlen = max(maxlen, len);
     }
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) P += __shfl_xor(P, d, 64);
+    for (int d = 32; d > 0; d >>= 1) {
+        P += __shfl_xor(P, d, 64);
+        maxlen = max(maxlen, __shfl_xor(maxlen, d, 64));
+    }
     if (lane == 0) {
         if (P > 0xFFFFFFF0ull) atomicAdd(too_big, 1ull);
         uint32_t b;
@@ -68,12 +78,14 @@ __global__ __launch_bounds__(256) void k_sg_products(int32_t n, const int32_t *_
         else if (m <= SG_DENSE_MAX) b = SG_BIN_DENSE;
         else if (P > (unsigned long long)SG_HASH_MAXP) b = SG_BIN_GLOBAL;
         else {
-            b = SG_BIN_HASH0;
-            while ((unsigned long long)sg_hash_limit((int)(b - SG_BIN_HASH0)) < P) b++;
+            int hb = 0;
+            while ((unsigned long long)sg_hash_limit(hb) < P) hb++;
+            const bool narrow = Bp[j + 1] - Bp[j] <= H2_MAXSEG && maxlen <= H2_MAXLEN && P <= (unsigned long long)H2_MAXP;
+            b = (uint32_t)((narrow ? SG_BIN_NARROW0 : SG_BIN_HASH0) + hb);
         }
         bin[j] = b;
         colid[j] = (uint32_t)j;
-        hprod[j] = (b >= SG_BIN_HASH0 && b < SG_BIN_HASH0 + SG_HASH_BINS) ? (int32_t)P : 0;
+        hprod[j] = (b >= SG_BIN_HASH0 && b < SG_BIN_NARROW0 + SG_NARROW_BINS) ? (int32_t)P : 0;
     }
 }
 
@@ -340,7 +352,12 @@ __global__ __launch_bounds__(256) void k_sg_hash1(int slots_, const int4 *__rest
                                                   const int32_t *__restrict__ Ap, const int32_t *__restrict__ Ai,
                                                   const double *__restrict__ Ax, const int32_t *__restrict__ Bi,
                                                   const double *__restrict__ Bx, int32_t *__restrict__ count,
-                                                  int32_t *__restrict__ tmp_i, double *__restrict__ tmp_x) {
+                                                  int32_t *__restrict__ tmp_i, double *__restrict__ tmp_x, int abl) {
+    // abl (timing experiments, ablation build only; results are wrong unless 0): 1 = no inserts, 2 = no read-out /
+    // copy-out, 4 = rows made up instead of gathered
+#ifndef CSX_ABLATION
+    abl = 0;
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t slots = (uint32_t)slots_;
     double *val = reinterpret_cast<double *>(smem);
@@ -439,11 +456,17 @@ __global__ __launch_bounds__(256) void k_sg_hash1(int slots_, const int4 *__rest
                     ts_[u] = tbase + seg_off[kk] + (uint32_t)gl;
                     bxs_[u] = VALUES ? seg_bx[kk] : 0.0;
                     const int32_t q = (uint32_t)gl < lens_[u] ? abs_[u] + gl : 0;   // clamped: nnz(A) > 0
-                    rows_[u] = (uint32_t)Ai[q];
-                    vs_[u] = VALUES ? Ax[q] : 0.0;
+                    if (abl & 4) {
+                        rows_[u] = (uint32_t)q * 2654435761u >> 12;
+                        vs_[u] = 1.0;
+                    } else {
+                        rows_[u] = (uint32_t)Ai[q];
+                        vs_[u] = VALUES ? Ax[q] : 0.0;
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < H1_UN; u++) {
+                    if ((abl & 1) && rows_[u] != 0x12345u) continue;
                     if ((uint32_t)gl < lens_[u]) h1_insert<VALUES>(keys, tmin, val, slots, rows_[u], ts_[u], bxs_[u] * vs_[u]);
                     for (uint32_t q = (uint32_t)gl + 32; q < lens_[u]; q += 32) {   // A columns longer than 32
                         const uint32_t row = (uint32_t)Ai[abs_[u] + (int32_t)q];
@@ -462,6 +485,23 @@ __global__ __launch_bounds__(256) void k_sg_hash1(int slots_, const int4 *__rest
             e1 = Ap[c1 + 1];
         }
         // ---- read-out: mark first touches in product order, rank them, emit, and leave the table clean ----
+        if (abl & 2) {
+            for (uint32_t k = tid; k < slots; k += 256) {
+                keys[k] = SG_UNSET;
+                tmin[k] = SG_UNSET;
+                if (VALUES) val[k] = 0.0;
+            }
+            if (tid == 0) count[j] = 0;
+            __syncthreads();
+            ci += G;
+            if (ci >= ncols) break;
+            cur = nxt;
+            nxt = nn;
+            ab0 = ab1;
+            len0 = (uint32_t)(e1 - ab1);
+            bx0 = bx1;
+            continue;
+        }
         for (uint32_t s = tid; s < slots; s += 256)
             if (keys[s] != SG_UNSET) {
                 const uint32_t t = tmin[s];
@@ -515,6 +555,217 @@ __global__ __launch_bounds__(256) void k_sg_hash1(int slots_, const int4 *__rest
     }
 }
 
+// ---- one-pass kernel for narrow columns (at most 64 entries in B(:,j), A columns of at most 32 entries) -------------
+// The same algorithm with the per-column machinery cut down to three barriers and its instruction count following
+// the column's length (the general kernel above is bound by instruction issue, not by LDS or memory):
+//  * every wave keeps the whole B column in registers (entry l in lane l, prefetched one column ahead as above), so the
+//    offsets of the A columns in product order are one wave scan; a wave instruction covers two entries, k0 in its low
+//    half and k0 + 1 in its high half with k0 wave-uniform, so what a half-wave needs of its entry comes by v_readlane:
+//    nothing is staged in LDS;
+//  * a thread issues the compare-and-swaps of its products together and resolves collisions afterwards (one returning
+//    LDS atomic per product is the latency that matters);
+//  * a thread remembers slot and product number of its (at most 8) products, so first touches are found by asking
+//    tmin[slot] == t -- no walk over the table, no bitmap: a half-wave holds one entry's products in order, a ballot
+//    gives the first touches before each lane and their count per entry, one wave scan over the 64 entry counts the
+//    rest -- and each first touch writes row and sum straight to the product-order buffer (runs) and wipes its slot;
+//  * slot i of a thread = entries 8 i .. 8 i + 7; slots at or past the column's length are skipped in every phase.
+template <bool VALUES, int N>
+__device__ __forceinline__ void h2_insert(uint32_t *keys, uint32_t *tmin, double *val, uint32_t slots,
+                                          const uint32_t *row, const uint32_t *t, const double *v, const bool *act,
+                                          uint32_t *s) {
+    uint32_t prev[N];
+#pragma unroll
+    for (int u = 0; u < N; u++) s[u] = __umulhi(row[u] * 0x9E3779B1u, slots);
+#pragma unroll
+    for (int u = 0; u < N; u++) prev[u] = act[u] ? atomicCAS(&keys[s[u]], SG_UNSET, row[u]) : SG_UNSET;
+#pragma unroll
+    for (int u = 0; u < N; u++)
+        if (act[u] && prev[u] != SG_UNSET && prev[u] != row[u]) {
+            for (;;) {
+                s[u] = s[u] + 1 == slots ? 0u : s[u] + 1;
+                const uint32_t p = atomicCAS(&keys[s[u]], SG_UNSET, row[u]);
+                if (p == SG_UNSET || p == row[u]) break;
+            }
+        }
+#pragma unroll
+    for (int u = 0; u < N; u++)
+        if (act[u]) {
+            atomicMin(&tmin[s[u]], t[u]);
+            if (VALUES) unsafeAtomicAdd(&val[s[u]], v[u]);
+        }
+}
+
+__device__ __forceinline__ int h2_pick(int v, int k0, bool hi) {   // v of lane k0 (low half-wave) / k0 + 1 (high)
+    const int a = __builtin_amdgcn_readlane(v, k0), b = __builtin_amdgcn_readlane(v, k0 + 1);
+    return hi ? b : a;
+}
+
+template <bool VALUES>
+__global__ __launch_bounds__(256) void k_sg_hash2(int slots_, const int4 *__restrict__ info, int32_t ncols,
+                                                  const int32_t *__restrict__ Ap, const int32_t *__restrict__ Ai,
+                                                  const double *__restrict__ Ax, const int32_t *__restrict__ Bi,
+                                                  const double *__restrict__ Bx, int32_t *__restrict__ count,
+                                                  int32_t *__restrict__ tmp_i, double *__restrict__ tmp_x) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t slots = (uint32_t)slots_;
+    double *val = reinterpret_cast<double *>(smem);
+    uint32_t *keys = reinterpret_cast<uint32_t *>(smem + (VALUES ? (size_t)slots * 8 : 0));
+    uint32_t *tmin = keys + slots;
+    uint32_t *ecnt = tmin + slots;              // first touches per entry of B(:,j): H2_MAXSEG words
+    const int tid = threadIdx.x, lane = tid & 63, gl = tid & 31;
+    const bool hi = (lane & 32) != 0;
+    const int wu = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t below = (1u << gl) - 1u;     // lanes of the half-wave before this one
+    const int32_t G = (int32_t)gridDim.x;
+    const int4 none = make_int4(-1, 0, 0, 0);
+    int32_t ci = blockIdx.x;                    // the host launches at most ncols workgroups
+    int4 cur = info[ci];
+    int4 nxt = ci + G < ncols ? info[ci + G] : none;
+    // entry `lane` of the column, in every wave
+    int32_t ab0 = 0;
+    uint32_t len0 = 0;
+    double bx0 = 0.0;
+    if (lane < cur.z - cur.y) {
+        const int32_t c = Bi[cur.y + lane];
+        ab0 = Ap[c];
+        len0 = (uint32_t)(Ap[c + 1] - ab0);
+        if (VALUES) bx0 = Bx[cur.y + lane];
+    }
+    for (uint32_t k = tid; k < slots; k += 256) {
+        keys[k] = SG_UNSET;
+        tmin[k] = SG_UNSET;
+        if (VALUES) val[k] = 0.0;
+    }
+    __syncthreads();
+    for (;;) {
+        // ---- prefetch: descriptor two columns ahead, B entries one column ahead ----
+        const int4 nn = ci + 2 * G < ncols ? info[ci + 2 * G] : none;
+        const int nseg1 = nxt.x >= 0 ? nxt.z - nxt.y : 0;
+        int32_t c1 = 0;
+        double bx1 = 0.0;
+        if (lane < nseg1) {
+            c1 = Bi[nxt.y + lane];
+            if (VALUES) bx1 = Bx[nxt.y + lane];
+        }
+        const int32_t j = cur.x;
+        const int nseg = cur.z - cur.y;
+        uint32_t inc = len0;                    // product number of the first product of entry `lane`
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += up;
+        }
+        const uint32_t off0 = inc - len0;
+        const int bxlo = __double2loint(bx0), bxhi = __double2hiint(bx0);
+        uint32_t ps[8], pt[8], prow[8];
+        double pv[8];
+        bool pact[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            pact[i] = false;
+            ps[i] = pt[i] = prow[i] = 0;
+            pv[i] = 0.0;
+        }
+#define CSX_H2_FETCH(i)                                                                                              \
+    {                                                                                                                \
+        const int k0 = 8 * (i) + 2 * wu;                                                                             \
+        const int32_t abk = h2_pick(ab0, k0, hi);                                                                    \
+        const uint32_t lenk = (uint32_t)h2_pick((int)len0, k0, hi);                                                  \
+        const uint32_t offk = (uint32_t)h2_pick((int)off0, k0, hi);                                                  \
+        const double bxk = VALUES ? __hiloint2double(h2_pick(bxhi, k0, hi), h2_pick(bxlo, k0, hi)) : 0.0;            \
+        pact[i] = k0 + (hi ? 1 : 0) < nseg && (uint32_t)gl < lenk;                                                   \
+        const int32_t q = pact[i] ? abk + gl : 0; /* clamped: nnz(A) > 0 */                                          \
+        prow[i] = (uint32_t)Ai[q];                                                                                   \
+        pv[i] = VALUES ? bxk * Ax[q] : 0.0;                                                                          \
+        pt[i] = offk + (uint32_t)gl;                                                                                 \
+    }
+        CSX_H2_FETCH(0) CSX_H2_FETCH(1) CSX_H2_FETCH(2) CSX_H2_FETCH(3)
+        if (nseg > 32) { CSX_H2_FETCH(4) CSX_H2_FETCH(5) }
+        if (nseg > 48) { CSX_H2_FETCH(6) CSX_H2_FETCH(7) }
+#undef CSX_H2_FETCH
+        h2_insert<VALUES, 4>(keys, tmin, val, slots, prow, pt, pv, pact, ps);
+        if (nseg > 32) h2_insert<VALUES, 2>(keys, tmin, val, slots, prow + 4, pt + 4, pv + 4, pact + 4, ps + 4);
+        if (nseg > 48) h2_insert<VALUES, 2>(keys, tmin, val, slots, prow + 6, pt + 6, pv + 6, pact + 6, ps + 6);
+        // ---- prefetch, second half: extents of the A columns the next column names ----
+        int32_t ab1 = 0, e1 = 0;
+        if (lane < nseg1) {
+            ab1 = Ap[c1];
+            e1 = Ap[c1 + 1];
+        }
+        __syncthreads();
+        // ---- first touches: a product is one iff it holds its row's smallest product number; per entry of B their
+        //      count (one ballot), inside an entry the rank is the number of first touches in the lanes before ----
+        bool first[8];
+        uint32_t rank_in[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            first[i] = false;
+            rank_in[i] = 0;
+            if (8 * i < nseg) {   // uniform
+                first[i] = pact[i] && tmin[ps[i]] == pt[i];
+                const unsigned long long bal = __ballot(first[i]);
+                const uint32_t m32 = hi ? (uint32_t)(bal >> 32) : (uint32_t)bal;
+                rank_in[i] = (uint32_t)__popc(m32 & below);
+                if (gl == 0) ecnt[8 * i + 2 * wu + (hi ? 1 : 0)] = (uint32_t)__popc(m32);
+            }
+        }
+        __syncthreads();
+        // ---- position in the column = first touches of the entries before + rank inside the entry; emit; wipe ----
+        const uint32_t ec = lane < ((nseg + 7) & ~7) ? ecnt[lane] : 0u;
+        uint32_t einc = ec;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(einc, d, 64);
+            if (lane >= d) einc += up;
+        }
+        const int eex = (int)(einc - ec);
+        const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)einc, 63);
+        const int64_t base = cur.w;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if (8 * i < nseg) {   // uniform
+                const uint32_t pre = (uint32_t)h2_pick(eex, 8 * i + 2 * wu, hi);
+                if (first[i]) {
+                    const uint32_t pos = pre + rank_in[i];
+                    const uint32_t sl = ps[i];
+                    tmp_i[base + pos] = (int32_t)prow[i];
+                    keys[sl] = SG_UNSET;
+                    tmin[sl] = SG_UNSET;
+                    if (VALUES) {
+                        tmp_x[base + pos] = val[sl];
+                        val[sl] = 0.0;
+                    }
+                }
+            }
+        }
+        if (tid == 0) count[j] = (int32_t)cnt;
+        __syncthreads();                        // table clean, ecnt read: the next column may start
+        ci += G;
+        if (ci >= ncols) break;
+        cur = nxt;
+        nxt = nn;
+        ab0 = ab1;
+        len0 = (uint32_t)(e1 - ab1);
+        bx0 = bx1;
+    }
+}
+
+template <bool VALUES>
+static int launch_hash2(int slots, const Csc *A, const Csc *B, const int4 *info, int32_t ncols, int32_t *count,
+                        int32_t *tmp_i, double *tmp_x) {
+    if (ncols <= 0) return CSX_OK;
+    const size_t lds = (size_t)(slots + (slots & 1)) * (VALUES ? 16 : 8) + H2_MAXSEG * 4 + 64;
+    auto kern = k_sg_hash2<VALUES>;
+    CSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024 - 256));
+    const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(8, (160 * 1024) / (int64_t)(lds + 256)));
+    const int64_t grid = std::min<int64_t>(ncols, (int64_t)ctx().cus * per_cu);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, ctx().stream, slots, info, ncols, A->p, A->i, A->x,
+                       B->i, B->x, count, tmp_i, tmp_x);
+    CSX_LAUNCH_CHECK();
+    return CSX_OK;
+}
+
 // one wave per column: move its rows (and sums) from the product-order buffer to their place in C
 __global__ __launch_bounds__(256) void k_sg_compact(const uint32_t *__restrict__ cols, int32_t ncols,
                                                     const int32_t *__restrict__ toff, const int32_t *__restrict__ Cp,
@@ -548,8 +799,9 @@ static int launch_hash1(int slots, const Csc *A, const Csc *B, const int4 *info,
     // exactly the workgroups that are resident at once (LDS-limited, at most 8 x 4 waves per CU)
     const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(8, (160 * 1024) / (int64_t)(lds + 256)));
     const int64_t grid = std::min<int64_t>(ncols, (int64_t)ctx().cus * per_cu);
+    const int abl = ablation_env("CSX_SG_ABL") ? std::atoi(ablation_env("CSX_SG_ABL")) : 0;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, ctx().stream, slots, info, ncols, A->p, A->i, A->x,
-                       B->i, B->x, count, tmp_i, tmp_x);
+                       B->i, B->x, count, tmp_i, tmp_x, abl);
     CSX_LAUNCH_CHECK();
     return CSX_OK;
 }
@@ -589,13 +841,14 @@ static int run_bins(const Csc *A, const Csc *B, const uint32_t *cols, const int3
                     const int32_t *Cp, int32_t *Ci, double *Cx, uint32_t *g_tmin, double *g_val, bool skip_hash) {
     for (int b = 0; b < SG_NBINS; b++) {
         const int32_t nb = bin_ptr[b + 1] - bin_ptr[b];
-        const bool hashed = b >= SG_BIN_HASH0 && b < SG_BIN_HASH0 + SG_HASH_BINS;
+        const bool hashed = b >= SG_BIN_HASH0 && b < SG_BIN_NARROW0 + SG_NARROW_BINS;
+        const int hb = b >= SG_BIN_NARROW0 ? b - SG_BIN_NARROW0 : b - SG_BIN_HASH0;
         if (b == SG_BIN_EMPTY || (hashed && skip_hash)) continue;  // hash bins: done by the one-pass kernel
         if (!hashed && b != SG_BIN_DENSE && b != SG_BIN_GLOBAL) continue;
         const int kind = b == SG_BIN_DENSE ? ACC_LDS_DENSE : (b == SG_BIN_GLOBAL ? ACC_GLOBAL_DENSE : ACC_LDS_HASH);
         int slots = 0;  // two-pass hash tables: power of two, load <= 1/2
         if (hashed)
-            for (slots = 1024; slots < 2 * sg_hash_limit(b - SG_BIN_HASH0); slots <<= 1) {}
+            for (slots = 1024; slots < 2 * sg_hash_limit(hb); slots <<= 1) {}
         CSX_TRY((launch_bin<NUMERIC, VALUES>(kind, slots, A, B, cols + bin_ptr[b], nb, count, Cp, Ci, Cx, g_tmin, g_val)));
     }
     return CSX_OK;
@@ -648,7 +901,7 @@ int multiply_device(const Csc *A, const Csc *B, Csc *C) {
     }
     if (st == CSX_OK && big[0]) st = CSX_EINVAL;  // a column with >= 2^32 products
     // one-pass path for the hash bins when its product-order buffer (12 B per product) is affordable
-    const int32_t hash_lo = bin_ptr[SG_BIN_HASH0], nhash = bin_ptr[SG_BIN_HASH0 + SG_HASH_BINS] - hash_lo;
+    const int32_t hash_lo = bin_ptr[SG_BIN_HASH0], nhash = bin_ptr[SG_BIN_NARROW0 + SG_NARROW_BINS] - hash_lo;
     bool onepass = false;
     if (st == CSX_OK && nhash > 0 && big[1] < 0x7FFFFFF0ull && ctx().opt.spgemm_one_pass) {
         size_t free_b = 0, total_b = 0;
@@ -672,6 +925,12 @@ int multiply_device(const Csc *A, const Csc *B, Csc *C) {
             const int slots = sg_hash_limit(hb) * 3 / 2;   // load factor <= 2/3
             st = values ? launch_hash1<true>(slots, A, B, info + (lo - hash_lo), nb, count, tmp_i, tmp_x)
                         : launch_hash1<false>(slots, A, B, info + (lo - hash_lo), nb, count, tmp_i, nullptr);
+        }
+        for (int hb = 0; hb < SG_NARROW_BINS && st == CSX_OK; hb++) {
+            const int32_t lo = bin_ptr[SG_BIN_NARROW0 + hb], nb = bin_ptr[SG_BIN_NARROW0 + hb + 1] - lo;
+            const int slots = sg_hash_limit(hb) * 3 / 2;
+            st = values ? launch_hash2<true>(slots, A, B, info + (lo - hash_lo), nb, count, tmp_i, tmp_x)
+                        : launch_hash2<false>(slots, A, B, info + (lo - hash_lo), nb, count, tmp_i, nullptr);
         }
     }
     const int32_t nglobal = bin_ptr[SG_BIN_GLOBAL + 1] - bin_ptr[SG_BIN_GLOBAL];
