@@ -600,12 +600,70 @@ __device__ __forceinline__ int h2_pick(int v, int k0, bool hi) {   // v of lane 
     return hi ? b : a;
 }
 
+// the (at most 8) products of a thread in one column: slot i = entries 8 i .. 8 i + 7 of B(:,j), two per wave
+struct H2Prod {
+    uint32_t row[8], t[8];
+    double v[8];
+    bool act[8];
+};
+
+// Gather the products of a column whose entries sit one per lane (ab = start of the A column the entry names, len its
+// length, off = its first product number, bx = the entry's value).  A wave instruction covers two entries: k0 in
+// its low half and k0 + 1 in its high half, k0 wave-uniform, so the half-waves get their entry by v_readlane.
+template <bool VALUES>
+__device__ __forceinline__ void h2_fetch(H2Prod &P, int32_t ab, uint32_t len, uint32_t off, double bx, int nseg, int wu,
+                                         bool hi, int gl, const int32_t *__restrict__ Ai,
+                                         const double *__restrict__ Ax, int abl) {
+    const int bxlo = __double2loint(bx), bxhi = __double2hiint(bx);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        P.act[i] = false;
+        P.row[i] = P.t[i] = 0;
+        P.v[i] = 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        if (i < 4 || (i < 6 && nseg > 32) || nseg > 48) {   // uniform: slots past the column's length are skipped
+            const int k0 = 8 * i + 2 * wu;
+            const int32_t abk = h2_pick(ab, k0, hi);
+            const uint32_t lenk = (uint32_t)h2_pick((int)len, k0, hi);
+            const uint32_t offk = (uint32_t)h2_pick((int)off, k0, hi);
+            const double bxk = VALUES ? __hiloint2double(h2_pick(bxhi, k0, hi), h2_pick(bxlo, k0, hi)) : 0.0;
+            P.act[i] = k0 + (hi ? 1 : 0) < nseg && (uint32_t)gl < lenk;
+            const int32_t q = P.act[i] ? abk + gl : 0;   // clamped: nnz(A) > 0
+            P.row[i] = (abl & 4) ? (uint32_t)q * 2654435761u >> 12 : (uint32_t)Ai[q];
+            P.v[i] = (abl & 4) ? bxk : (VALUES ? bxk * Ax[q] : 0.0);
+            P.t[i] = offk + (uint32_t)gl;
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t h2_exclusive(uint32_t v, int lane) {   // exclusive wave scan
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += up;
+    }
+    return inc - v;
+}
+
+// Persistent workgroups, columns ci = blockIdx.x, + gridDim.x, ...  Everything a column needs from memory is requested
+// ahead of its turn and rides along with the work on earlier columns: descriptors three columns ahead, B entries two,
+// the extents of the A columns they name between one and two, and the products themselves (rows and values of A, the
+// only loads that depend on data) ONE column ahead -- issued before the current column's inserts, used after its
+// copy-out.  (Gathered just in time they cost 4.6 of 11 ms.)
 template <bool VALUES>
 __global__ __launch_bounds__(256) void k_sg_hash2(int slots_, const int4 *__restrict__ info, int32_t ncols,
                                                   const int32_t *__restrict__ Ap, const int32_t *__restrict__ Ai,
                                                   const double *__restrict__ Ax, const int32_t *__restrict__ Bi,
                                                   const double *__restrict__ Bx, int32_t *__restrict__ count,
-                                                  int32_t *__restrict__ tmp_i, double *__restrict__ tmp_x) {
+                                                  int32_t *__restrict__ tmp_i, double *__restrict__ tmp_x, int abl) {
+    // abl (timing experiments, ablation build only; results are wrong unless 0): 1 = no inserts, 2 = no stores to the
+    // product-order buffer, 4 = rows made up instead of gathered, 8 = no first-touch ranking
+#ifndef CSX_ABLATION
+    abl = 0;
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t slots = (uint32_t)slots_;
     double *val = reinterpret_cast<double *>(smem);
@@ -621,15 +679,31 @@ __global__ __launch_bounds__(256) void k_sg_hash2(int slots_, const int4 *__rest
     int32_t ci = blockIdx.x;                    // the host launches at most ncols workgroups
     int4 cur = info[ci];
     int4 nxt = ci + G < ncols ? info[ci + G] : none;
-    // entry `lane` of the column, in every wave
-    int32_t ab0 = 0;
-    uint32_t len0 = 0;
-    double bx0 = 0.0;
-    if (lane < cur.z - cur.y) {
-        const int32_t c = Bi[cur.y + lane];
-        ab0 = Ap[c];
-        len0 = (uint32_t)(Ap[c + 1] - ab0);
-        if (VALUES) bx0 = Bx[cur.y + lane];
+    int4 nn = ci + 2 * G < ncols ? info[ci + 2 * G] : none;
+    // entry `lane` of a column, in every wave: current column (products P0), next column (ab1 / len1 / bx1)
+    H2Prod P0;
+    int nseg0 = cur.z - cur.y;
+    {
+        int32_t ab = 0;
+        uint32_t len = 0;
+        double bx = 0.0;
+        if (lane < nseg0) {
+            const int32_t c = Bi[cur.y + lane];
+            ab = Ap[c];
+            len = (uint32_t)(Ap[c + 1] - ab);
+            if (VALUES) bx = Bx[cur.y + lane];
+        }
+        h2_fetch<VALUES>(P0, ab, len, h2_exclusive(len, lane), bx, nseg0, wu, hi, gl, Ai, Ax, abl);
+    }
+    int nseg1 = nxt.x >= 0 ? nxt.z - nxt.y : 0;
+    int32_t ab1 = 0;
+    uint32_t len1 = 0;
+    double bx1 = 0.0;
+    if (lane < nseg1) {
+        const int32_t c = Bi[nxt.y + lane];
+        ab1 = Ap[c];
+        len1 = (uint32_t)(Ap[c + 1] - ab1);
+        if (VALUES) bx1 = Bx[nxt.y + lane];
     }
     for (uint32_t k = tid; k < slots; k += 256) {
         keys[k] = SG_UNSET;
@@ -638,60 +712,30 @@ __global__ __launch_bounds__(256) void k_sg_hash2(int slots_, const int4 *__rest
     }
     __syncthreads();
     for (;;) {
-        // ---- prefetch: descriptor two columns ahead, B entries one column ahead ----
-        const int4 nn = ci + 2 * G < ncols ? info[ci + 2 * G] : none;
-        const int nseg1 = nxt.x >= 0 ? nxt.z - nxt.y : 0;
-        int32_t c1 = 0;
-        double bx1 = 0.0;
-        if (lane < nseg1) {
-            c1 = Bi[nxt.y + lane];
-            if (VALUES) bx1 = Bx[nxt.y + lane];
+        // ---- requests for later columns ----
+        const int4 n3 = ci + 3 * G < ncols ? info[ci + 3 * G] : none;
+        const int nseg2 = nn.x >= 0 ? nn.z - nn.y : 0;
+        int32_t c2 = 0;
+        double bx2 = 0.0;
+        if (lane < nseg2) {
+            c2 = Bi[nn.y + lane];
+            if (VALUES) bx2 = Bx[nn.y + lane];
         }
+        H2Prod P1;                              // the next column's products: on their way while this column is done
+        h2_fetch<VALUES>(P1, ab1, len1, h2_exclusive(len1, lane), bx1, nseg1, wu, hi, gl, Ai, Ax, abl);
+        // ---- this column: insert ----
         const int32_t j = cur.x;
-        const int nseg = cur.z - cur.y;
-        uint32_t inc = len0;                    // product number of the first product of entry `lane`
+        const int nseg = nseg0;
+        uint32_t ps[8];
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t up = __shfl_up(inc, d, 64);
-            if (lane >= d) inc += up;
-        }
-        const uint32_t off0 = inc - len0;
-        const int bxlo = __double2loint(bx0), bxhi = __double2hiint(bx0);
-        uint32_t ps[8], pt[8], prow[8];
-        double pv[8];
-        bool pact[8];
+        for (int i = 0; i < 8; i++) ps[i] = 0;
+        if (abl & 1) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            pact[i] = false;
-            ps[i] = pt[i] = prow[i] = 0;
-            pv[i] = 0.0;
+            for (int i = 0; i < 8; i++) P0.act[i] = P0.act[i] && P0.row[i] == 0x12345u;
         }
-#define CSX_H2_FETCH(i)                                                                                              \
-    {                                                                                                                \
-        const int k0 = 8 * (i) + 2 * wu;                                                                             \
-        const int32_t abk = h2_pick(ab0, k0, hi);                                                                    \
-        const uint32_t lenk = (uint32_t)h2_pick((int)len0, k0, hi);                                                  \
-        const uint32_t offk = (uint32_t)h2_pick((int)off0, k0, hi);                                                  \
-        const double bxk = VALUES ? __hiloint2double(h2_pick(bxhi, k0, hi), h2_pick(bxlo, k0, hi)) : 0.0;            \
-        pact[i] = k0 + (hi ? 1 : 0) < nseg && (uint32_t)gl < lenk;                                                   \
-        const int32_t q = pact[i] ? abk + gl : 0; /* clamped: nnz(A) > 0 */                                          \
-        prow[i] = (uint32_t)Ai[q];                                                                                   \
-        pv[i] = VALUES ? bxk * Ax[q] : 0.0;                                                                          \
-        pt[i] = offk + (uint32_t)gl;                                                                                 \
-    }
-        CSX_H2_FETCH(0) CSX_H2_FETCH(1) CSX_H2_FETCH(2) CSX_H2_FETCH(3)
-        if (nseg > 32) { CSX_H2_FETCH(4) CSX_H2_FETCH(5) }
-        if (nseg > 48) { CSX_H2_FETCH(6) CSX_H2_FETCH(7) }
-#undef CSX_H2_FETCH
-        h2_insert<VALUES, 4>(keys, tmin, val, slots, prow, pt, pv, pact, ps);
-        if (nseg > 32) h2_insert<VALUES, 2>(keys, tmin, val, slots, prow + 4, pt + 4, pv + 4, pact + 4, ps + 4);
-        if (nseg > 48) h2_insert<VALUES, 2>(keys, tmin, val, slots, prow + 6, pt + 6, pv + 6, pact + 6, ps + 6);
-        // ---- prefetch, second half: extents of the A columns the next column names ----
-        int32_t ab1 = 0, e1 = 0;
-        if (lane < nseg1) {
-            ab1 = Ap[c1];
-            e1 = Ap[c1 + 1];
-        }
+        h2_insert<VALUES, 4>(keys, tmin, val, slots, P0.row, P0.t, P0.v, P0.act, ps);
+        if (nseg > 32) h2_insert<VALUES, 2>(keys, tmin, val, slots, P0.row + 4, P0.t + 4, P0.v + 4, P0.act + 4, ps + 4);
+        if (nseg > 48) h2_insert<VALUES, 2>(keys, tmin, val, slots, P0.row + 6, P0.t + 6, P0.v + 6, P0.act + 6, ps + 6);
         __syncthreads();
         // ---- first touches: a product is one iff it holds its row's smallest product number; per entry of B their
         //      count (one ballot), inside an entry the rank is the number of first touches in the lanes before ----
@@ -701,8 +745,8 @@ __global__ __launch_bounds__(256) void k_sg_hash2(int slots_, const int4 *__rest
         for (int i = 0; i < 8; i++) {
             first[i] = false;
             rank_in[i] = 0;
-            if (8 * i < nseg) {   // uniform
-                first[i] = pact[i] && tmin[ps[i]] == pt[i];
+            if (8 * i < nseg && !(abl & 8)) {   // uniform
+                first[i] = P0.act[i] && tmin[ps[i]] == P0.t[i];
                 const unsigned long long bal = __ballot(first[i]);
                 const uint32_t m32 = hi ? (uint32_t)(bal >> 32) : (uint32_t)bal;
                 rank_in[i] = (uint32_t)__popc(m32 & below);
@@ -711,42 +755,52 @@ __global__ __launch_bounds__(256) void k_sg_hash2(int slots_, const int4 *__rest
         }
         __syncthreads();
         // ---- position in the column = first touches of the entries before + rank inside the entry; emit; wipe ----
-        const uint32_t ec = lane < ((nseg + 7) & ~7) ? ecnt[lane] : 0u;
-        uint32_t einc = ec;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t up = __shfl_up(einc, d, 64);
-            if (lane >= d) einc += up;
-        }
-        const int eex = (int)(einc - ec);
-        const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)einc, 63);
+        const uint32_t ec = (lane < ((nseg + 7) & ~7) && !(abl & 8)) ? ecnt[lane] : 0u;
+        const uint32_t eex = h2_exclusive(ec, lane);
+        const uint32_t cnt = (uint32_t)__builtin_amdgcn_readlane((int)(eex + ec), 63);
         const int64_t base = cur.w;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             if (8 * i < nseg) {   // uniform
-                const uint32_t pre = (uint32_t)h2_pick(eex, 8 * i + 2 * wu, hi);
+                const uint32_t pre = (uint32_t)h2_pick((int)eex, 8 * i + 2 * wu, hi);
                 if (first[i]) {
                     const uint32_t pos = pre + rank_in[i];
                     const uint32_t sl = ps[i];
-                    tmp_i[base + pos] = (int32_t)prow[i];
+                    if (!(abl & 2)) tmp_i[base + pos] = (int32_t)P0.row[i];
                     keys[sl] = SG_UNSET;
                     tmin[sl] = SG_UNSET;
                     if (VALUES) {
-                        tmp_x[base + pos] = val[sl];
+                        if (!(abl & 2)) tmp_x[base + pos] = val[sl];
                         val[sl] = 0.0;
                     }
                 }
             }
         }
-        if (tid == 0) count[j] = (int32_t)cnt;
+        if (tid == 0) count[j] = (abl & 10) ? 0 : (int32_t)cnt;
+        if (abl & 8)
+            for (uint32_t k = tid; k < slots; k += 256) {
+                keys[k] = SG_UNSET;
+                tmin[k] = SG_UNSET;
+                if (VALUES) val[k] = 0.0;
+            }
+        // ---- extents of the A columns named two columns ahead (their B entries have arrived by now) ----
+        int32_t ab2 = 0, e2 = 0;
+        if (lane < nseg2) {
+            ab2 = Ap[c2];
+            e2 = Ap[c2 + 1];
+        }
         __syncthreads();                        // table clean, ecnt read: the next column may start
         ci += G;
         if (ci >= ncols) break;
         cur = nxt;
         nxt = nn;
-        ab0 = ab1;
-        len0 = (uint32_t)(e1 - ab1);
-        bx0 = bx1;
+        nn = n3;
+        P0 = P1;
+        nseg0 = nseg1;
+        nseg1 = nseg2;
+        ab1 = ab2;
+        len1 = (uint32_t)(e2 - ab2);
+        bx1 = bx2;
     }
 }
 
@@ -760,8 +814,9 @@ static int launch_hash2(int slots, const Csc *A, const Csc *B, const int4 *info,
                                 160 * 1024 - 256));
     const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(8, (160 * 1024) / (int64_t)(lds + 256)));
     const int64_t grid = std::min<int64_t>(ncols, (int64_t)ctx().cus * per_cu);
+    const int abl = ablation_env("CSX_SG_ABL") ? std::atoi(ablation_env("CSX_SG_ABL")) : 0;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, ctx().stream, slots, info, ncols, A->p, A->i, A->x,
-                       B->i, B->x, count, tmp_i, tmp_x);
+                       B->i, B->x, count, tmp_i, tmp_x, abl);
     CSX_LAUNCH_CHECK();
     return CSX_OK;
 }
@@ -777,7 +832,24 @@ __global__ __launch_bounds__(256) void k_sg_compact(const uint32_t *__restrict__
     const int32_t j = (int32_t)cols[w];
     const int64_t src = toff[j], dst = Cp[j];
     const int32_t cnt = Cp[j + 1] - Cp[j];
-    for (int32_t k = lane; k < cnt; k += 64) {
+    int32_t k = lane;
+    for (; k + 192 < cnt; k += 256) {   // four loads of each array in flight per lane
+        int32_t ri[4];
+        double rx[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) ri[u] = tmp_i[src + k + 64 * u];
+        if (tmp_x) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) rx[u] = tmp_x[src + k + 64 * u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) Ci[dst + k + 64 * u] = ri[u];
+        if (tmp_x) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) Cx[dst + k + 64 * u] = rx[u];
+        }
+    }
+    for (; k < cnt; k += 64) {
         Ci[dst + k] = tmp_i[src + k];
         if (tmp_x) Cx[dst + k] = tmp_x[src + k];
     }

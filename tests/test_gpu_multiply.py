@@ -147,3 +147,32 @@ def _ragged_body(cs):
     A0.x = None
     C0 = cs.cs_multiply(A0, B0)                           # pattern only
     assert C0.x is None and C0.p == Cp.tolist() and C0.i[:int(Cp[-1])] == Ci.tolist()
+
+
+def test_multiply_narrow_columns_one_pass_kernel(cs):
+    """Columns with at most 64 entries in B(:,j) that name A columns of at most 32 entries take k_sg_hash2: B columns of
+    every length 0..64 (so every number of 8-entry slots per thread), A columns of 0..32 entries (all six table sizes up to
+    2048 products), duplicate rows inside and across A columns, a few wide columns beside them that take the general
+    kernel; values and pattern-only, against the C oracle (first-touch order bit for bit)."""
+    rng = np.random.default_rng(20240612)
+    m, k, n = 30000, 2500, 1300
+    alen = rng.integers(0, 33, size=k)
+    alen[:40] = 32
+    Ap, Ai, Ax = _ragged(rng, m, k, alen)
+    hot = rng.integers(0, m, size=50).astype(np.int32)           # rows shared by many columns: collisions on purpose
+    sel = rng.random(Ai.size) < 0.3
+    Ai[sel] = hot[rng.integers(0, 50, size=int(sel.sum()))]
+    blen = np.concatenate([np.arange(65), rng.integers(0, 65, size=n - 65 - 5), [64, 64, 70, 100, 64]])
+    Bp, Bi, Bx = _ragged(rng, k, n, blen)
+    Bi[Bp[n - 5]:Bp[n - 4]] = rng.integers(0, 40, size=64)       # 64 entries x 32 = 2048 products: the largest narrow column
+    prods = np.array([int(np.sum(alen[Bi[Bp[j]:Bp[j + 1]]])) for j in range(n)])
+    assert prods[n - 5] == 2048 and (blen > 64).any() and (prods[blen <= 64] <= 2048).all()
+    for lo, hi_ in ((0, 256), (256, 512), (512, 768), (768, 1024), (1024, 1536), (1536, 2048)):
+        assert ((prods > lo) & (prods <= hi_) & (blen <= 64)).any()
+    Cp, Ci, Cx = CO.multiply(m, k, n, Ap, Ai, Ax, Bp, Bi, Bx)
+    _, _, Sx = CO.multiply(m, k, n, Ap, Ai, np.abs(Ax), Bp, Bi, np.abs(Bx))
+    check_product(cs.cs_multiply(_host_cs(cs, m, k, Ap, Ai, Ax), _host_cs(cs, k, n, Bp, Bi, Bx)), Cp, Ci, Cx, Sx)
+    A0, B0 = _host_cs(cs, m, k, Ap, Ai, Ax), _host_cs(cs, k, n, Bp, Bi, Bx)
+    A0.x = None
+    C0 = cs.cs_multiply(A0, B0)
+    assert C0.x is None and C0.p == Cp.tolist() and C0.i[:int(Cp[-1])] == Ci.tolist()
