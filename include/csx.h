@@ -127,7 +127,12 @@ int csx_transpose(csx_handle_t A, int values, csx_handle_t *out);
 int csx_cumsum(csx_handle_t p, csx_handle_t c, int64_t n, int64_t *total);
 
 /* cs_multiply (+ cs_scatter), csparse.py:1608-1642, :1961-1989: C = A*B with
- * each column of C in first-touch order; pattern only if A or B has no values. */
+ * each column of C in first-touch order; pattern only if A or B has no values.
+ * p[] and i[] are exactly the reference's.  x[]: the products of an entry are summed by LDS / memory atomics in the
+ * order they arrive, not in the reference's order, so x[] equals the reference's to rounding (tests: 1e-10 relative to
+ * the sum of |products|) and may differ in the last bits from one run to the next -- the one result of this library
+ * that is not reproducible bit for bit.  The same holds for the sums cs_dupl and cs_add form from duplicate entries
+ * (csx_dupl, csx_add); entries without duplicates come out exact. */
 int csx_multiply(csx_handle_t A, csx_handle_t B, csx_handle_t *out);
 
 /* cs_lsolve / cs_ltsolve / cs_usolve / cs_utsolve, csparse.py:1330-1365,
