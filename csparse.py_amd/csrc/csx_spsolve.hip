@@ -19,7 +19,7 @@
 
 namespace csx {
 
-constexpr size_t SPS_BUDGET = (size_t)8 << 30;   // work space of the columns in flight
+constexpr size_t SPS_BUDGET = (size_t)32 << 30;  // work space of the columns in flight: at most this, and a quarter of what is free
 constexpr int64_t SPS_MAX_LANES = 1 << 16;
 
 __global__ __launch_bounds__(64) void k_sps_reach(int32_t n, const int32_t *__restrict__ Gp,
@@ -154,7 +154,10 @@ extern "C" int csx_spsolve(csx_handle_t hG, csx_handle_t hB, const int32_t *pinv
                 st = CSX_ERUNTIME;
         }
         const size_t per_lane = (size_t)n * (8 + 1 + (with_values ? 8 : 0));
-        int64_t lanes = (int64_t)std::max<size_t>(64, SPS_BUDGET / std::max<size_t>(per_lane, 1));
+        size_t budget = SPS_BUDGET, free_b = 0, total_b = 0, idle_b = 0;
+        pool_stats(&idle_b, nullptr);   // idle blocks of the caching allocator are reusable
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min(budget, (free_b + idle_b) / 4);
+        int64_t lanes = (int64_t)std::max<size_t>(64, budget / std::max<size_t>(per_lane, 1));
         lanes = std::min<int64_t>(std::min<int64_t>(lanes, SPS_MAX_LANES), ((int64_t)nb + 63) / 64 * 64);
         if (st == CSX_OK) st = tmp.alloc(&xi, (size_t)lanes * 2 * n);
         if (st == CSX_OK) st = tmp.alloc(&mark, (size_t)lanes * n);
