@@ -1,0 +1,116 @@
+"""Run ON THE GPU BOX: a longer randomised campaign than tests/test_gpu_fuzz.py (many seeds, shapes drawn at random) for
+the kernels rewritten in round 2: the radix sort behind cs_transpose, the one-pass cs_multiply kernels, csx_spsolve,
+the list-level cs_gaxpy.  Everything is checked against the C / Python oracles.  Progress goes to gpurun_out/fuzz.log.
+  python tools/fuzz_campaign.py [seconds]"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+for d in ("csparse.py_amd", "oracle", "tests"):
+    sys.path.insert(0, os.path.join(ROOT, d))
+import csparse as cs
+import c_oracle as CO
+import csparse_oracle as O
+import _csx
+_csx.init()
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+log = open(os.path.join(ROOT, "gpurun_out", "fuzz.log"), "w")
+
+
+def say(*a):
+    print(*a, file=log, flush=True)
+    print(*a, flush=True)
+
+
+def host(mod, m, n, p, i, x):
+    A = mod.cs_spalloc(m, n, max(len(i), 1), True, False)
+    A.p, A.i, A.x = np.asarray(p).tolist(), np.asarray(i).tolist(), np.asarray(x).tolist()
+    return A
+
+
+def ragged(rng, m, n, mean_len, maxlen=None):
+    lens = rng.poisson(mean_len, size=n)
+    lens[rng.random(n) < 0.1] = 0
+    if maxlen is not None:
+        lens = np.minimum(lens, maxlen)
+    p = np.zeros(n + 1, np.int32)
+    p[1:] = np.cumsum(lens)
+    i = rng.integers(0, m, size=int(p[-1])).astype(np.int32)
+    x = rng.uniform(-2, 2, size=int(p[-1]))
+    return p, i, x
+
+
+t_end = time.time() + budget
+seed = 0
+counts = {"transpose": 0, "multiply": 0, "spsolve": 0}
+while time.time() < t_end:
+    seed += 1
+    rng = np.random.default_rng(1000 + seed)
+    kind = seed % 3
+    if kind == 0:      # transpose: shapes across one to four radix passes, all column-start paths
+        m = int(rng.choice([1, 7, 255, 257, 5000, 70000, 300000, 17000000]))
+        n = int(rng.choice([1, 3, 200, 4097, 30000]))
+        mean = float(rng.choice([0.05, 0.7, 3.0, 40.0, 300.0]))
+        if n * mean > 3e6:
+            mean = 3e6 / n
+        Ap, Ai, Ax = ragged(rng, m, n, mean)
+        Rp, Ri, Rx = CO.transpose(m, n, Ap, Ai, Ax)
+        lib = _csx.lib()
+        hA, hT = _csx.new_handle(), _csx.new_handle()
+        Ai_, Ax_ = (Ai, Ax) if len(Ai) else (np.zeros(1, np.int32), np.zeros(1))
+        _csx.check(lib.csx_csc_upload(m, n, _csx.pi(Ap), _csx.pi(Ai_), _csx.pd(Ax_), hA))
+        _csx.check(lib.csx_transpose(hA, 1, hT))
+        nnz = int(Ap[-1])
+        Tp, Ti, Tx = np.empty(m + 1, np.int32), np.empty(max(nnz, 1), np.int32), np.empty(max(nnz, 1), np.float64)
+        _csx.check(lib.csx_csc_download(hT, _csx.pi(Tp), _csx.pi(Ti), _csx.pd(Tx)))
+        _csx.free(hA); _csx.free(hT)
+        assert np.array_equal(Tp, Rp) and np.array_equal(Ti[:nnz], Ri) and Tx[:nnz].tobytes() == Rx.tobytes(), ("transpose", seed, m, n, mean)
+        counts["transpose"] += 1
+    elif kind == 1:    # multiply: m above and below the dense-accumulator limit, narrow and wide columns
+        m = int(rng.choice([50, 9000, 20000, 100000]))
+        k = int(rng.choice([30, 800, 5000]))
+        n = int(rng.choice([1, 60, 900]))
+        Ap, Ai, Ax = ragged(rng, m, k, float(rng.choice([1.0, 6.0, 25.0, 60.0])), maxlen=int(rng.choice([8, 32, 200])))
+        Bp, Bi, Bx = ragged(rng, k, n, float(rng.choice([0.5, 8.0, 40.0, 90.0])))
+        Cp, Ci, Cx = CO.multiply(m, k, n, Ap, Ai, Ax, Bp, Bi, Bx)
+        _, _, Sx = CO.multiply(m, k, n, Ap, Ai, np.abs(Ax), Bp, Bi, np.abs(Bx))
+        C = cs.cs_multiply(host(cs, m, k, Ap, Ai, Ax), host(cs, k, n, Bp, Bi, Bx))
+        nnz = int(Cp[-1])
+        assert C.p == Cp.tolist() and C.i[:nnz] == Ci.tolist(), ("multiply pattern", seed, m, k, n)
+        err = np.abs(np.asarray(C.x[:nnz]) - Cx) / np.maximum(Sx, 1e-300) if nnz else np.zeros(1)
+        assert float(err.max()) < 1e-10, ("multiply values", seed, float(err.max()))
+        counts["multiply"] += 1
+    else:              # spsolve: random triangles, with and without pinv
+        n = int(rng.choice([1, 5, 64, 400, 1500]))
+        nb = int(rng.choice([1, 70, 600]))
+        lower = bool(rng.integers(0, 2))
+        cols_i, cols_x = [], []
+        for j in range(n):
+            lo, hi = (j + 1, n) if lower else (0, j)
+            kk = min(int(rng.poisson(2.5)), hi - lo)
+            off = rng.choice(np.arange(lo, hi), size=kk, replace=False) if kk else np.zeros(0, np.int64)
+            vals = rng.uniform(-1, 1, size=kk)
+            d = float(rng.uniform(2.0, 4.0))
+            cols_i.append(np.concatenate([[j], off]) if lower else np.concatenate([off, [j]]))
+            cols_x.append(np.concatenate([[d], vals]) if lower else np.concatenate([vals, [d]]))
+        Gp = np.zeros(n + 1, np.int32); Gp[1:] = np.cumsum([len(c) for c in cols_i])
+        Gi = np.concatenate(cols_i).astype(np.int32); Gx = np.concatenate(cols_x)
+        Bp, Bi, Bx = ragged(rng, n, nb, 2.0)
+        pinv = None
+        if lower and rng.random() < 0.5:
+            pinv = rng.permutation(n).astype(np.int32)
+            pinv[rng.random(n) < 0.1] = -1
+            pinv = pinv.tolist()
+        oG, oB = host(O, n, n, Gp, Gi, Gx), host(O, n, nb, Bp, Bi, Bx)
+        xi, x = [0] * (2 * n), [0.0] * n
+        p, idx, val = [0], [], []
+        for kcol in range(nb):
+            top = O.cs_spsolve(oG, oB, kcol, xi, x, pinv, lower)
+            idx += xi[top:n]; val += [x[j] for j in xi[top:n]]; p.append(len(idx))
+        X = cs.spsolve_columns(host(cs, n, n, Gp, Gi, Gx), host(cs, n, nb, Bp, Bi, Bx), pinv, lower)
+        assert X.p == p and X.i[:p[-1]] == idx, ("spsolve pattern", seed, n, nb)
+        assert np.asarray(X.x[:p[-1]]).tobytes() == np.asarray(val, dtype=np.float64).tobytes(), ("spsolve values", seed)
+        counts["spsolve"] += 1
+    if seed % 10 == 0:
+        say("seed", seed, counts)
+say("done", counts)
