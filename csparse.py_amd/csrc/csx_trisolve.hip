@@ -931,28 +931,119 @@ __global__ __launch_bounds__(256) void k_group_caps(int32_t ncomp, int cpw, cons
 // schedule: 7 us per level made the forward solve 15 ms and the backward one 34 ms, against a third of a
 // millisecond for one host core.  When the whole x of one right-hand side fits LDS (n <= 15 360) the workgroup
 // simply runs the reference's column loop: for L and U (column push) the column's entries are spread over the
-// threads (distinct rows, each x[i] still receives its updates in ascending / descending column order); for L'
-// and U' (column gather) the products of a column are formed in parallel and subtracted by one lane in storage
-// order.  One workgroup barrier (two for the gathers) per column, the next column's entries already in flight.
-// Bit-identical, every kind.  Right-hand sides are independent workgroups.  (A one-wave version whose subtraction
-// chain broadcasts the products with v_readlane instead of reading them from LDS was slower: 20.7 against 9.0 ms
-// for L' on bcsstk16.)
+// threads (distinct rows, each x[i] still receives its updates in ascending / descending column order), one
+// workgroup barrier per column, the next column's entries already in flight; for L' and U' (column gather) one wave
+// forms a column's products, one per lane, and lane 0 subtracts them in storage order while they rotate towards it
+// (k_tri_chain).  Bit-identical, every kind.  Right-hand sides are independent workgroups.  L' on bcsstk16: 256
+// threads with the products in LDS and one lane subtracting 9.0 ms; one wave lifting products out with v_readlane
+// 9.6 ms, with the v_readlane of the next eight issued ahead 7.7; products rotated by DPP 7.1; entries requested three
+// columns ahead instead of one 6.6 ms.
 #pragma clang fp contract(off)
 constexpr int TC_THREADS = 256;
 constexpr int TC_MAX_N = 15360;
 
+// The gather kinds (L', U') on ONE wave: every lane forms one product of the column, then lane 0 subtracts them in
+// storage order while the products rotate towards it through the wave (tch_chain) -- no barrier and no LDS round trip
+// for the products between columns.  Lanes past the end of the column hold +0.0, and x - (+0.0) = x for every x, so
+// the chain runs in blocks of eight without a test per term.
+__device__ __forceinline__ double tch_chain(double acc, double p, int cnt) {
+    // Only lane 0's chain is the result.  The products are rotated through the wave, one lane per step (DPP
+    // wave_rol:1: lane l receives lane l + 1), so lane 0 meets product 0, 1, 2, ... in order; the two rotations of a
+    // step do not depend on the subtraction, which is the only chain.  (Lifting the products out with v_readlane
+    // costs ~10 cycles per scalar write: 30 cycles per term against 12 here.)
+    int plo = __double2loint(p), phi = __double2hiint(p);
+#pragma unroll
+    for (int g = 0; g < 64; g += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            acc = acc - __hiloint2double(phi, plo);
+            plo = __builtin_amdgcn_update_dpp(plo, plo, 0x134, 0xf, 0xf, false);
+            phi = __builtin_amdgcn_update_dpp(phi, phi, 0x134, 0xf, 0xf, false);
+        }
+        if (g + 8 >= cnt) break;   // uniform
+    }
+    return acc;
+}
+
+struct TchCol {   // a column's off-diagonal range, its diagonal, and two entries per lane
+    int32_t lo, hi;
+    double dg;
+    int32_t ci0, ci1;
+    double cv0, cv1;
+};
+
+template <bool DIAG_FIRST>
+__device__ __forceinline__ TchCol tch_load(int32_t b, int32_t e, const int32_t *__restrict__ Ti,
+                                           const double *__restrict__ Tx, int lane) {
+    TchCol c;
+    c.lo = DIAG_FIRST ? b + 1 : b;
+    c.hi = DIAG_FIRST ? e : e - 1;
+    c.dg = Tx[DIAG_FIRST ? b : e - 1];
+    c.ci0 = c.lo + lane < c.hi ? Ti[c.lo + lane] : 0;
+    c.ci1 = c.lo + 64 + lane < c.hi ? Ti[c.lo + 64 + lane] : 0;
+    c.cv0 = c.lo + lane < c.hi ? Tx[c.lo + lane] : 0.0;
+    c.cv1 = c.lo + 64 + lane < c.hi ? Tx[c.lo + 64 + lane] : 0.0;
+    return c;
+}
+
+// The factor does not fit an XCD's L2 (bcsstk16: 7.3 MB), so a column's entries come from the memory side and take
+// about as long as a column takes to compute: they are requested THREE columns ahead (pointers four ahead).
+template <int KIND>   // CSX_TRI_LT or CSX_TRI_UT
+__global__ __launch_bounds__(64) void k_tri_chain(int32_t n, const int32_t *__restrict__ Tp, const int32_t *__restrict__ Ti,
+                                                  const double *__restrict__ Tx, double *X, int nrhs) {
+    extern __shared__ __attribute__((aligned(16))) double xs[];   // n doubles
+    const int lane = threadIdx.x, r = blockIdx.x;
+    for (int32_t i = lane; i < n; i += 64) xs[i] = X[(int64_t)i * nrhs + r];
+    __syncthreads();
+    constexpr bool ASC = KIND == CSX_TRI_UT;
+    constexpr bool DIAG_FIRST = KIND == CSX_TRI_LT;
+    auto col_at = [&](int32_t step) {   // the column of a step, clamped to the last one
+        const int32_t st = step < n ? step : n - 1;
+        return ASC ? st : n - 1 - st;
+    };
+    int32_t j = col_at(0);
+    TchCol cur = tch_load<DIAG_FIRST>(Tp[j], Tp[j + 1], Ti, Tx, lane);
+    TchCol n1 = tch_load<DIAG_FIRST>(Tp[col_at(1)], Tp[col_at(1) + 1], Ti, Tx, lane);
+    TchCol n2 = tch_load<DIAG_FIRST>(Tp[col_at(2)], Tp[col_at(2) + 1], Ti, Tx, lane);
+    int32_t b3 = Tp[col_at(3)], e3 = Tp[col_at(3) + 1];
+    for (int32_t step = 0; step < n; step++) {
+        const int32_t j4 = col_at(step + 4);
+        const int32_t b4 = Tp[j4], e4 = Tp[j4 + 1];
+        const TchCol n3 = tch_load<DIAG_FIRST>(b3, e3, Ti, Tx, lane);
+        const int32_t len = cur.hi - cur.lo;
+        double acc = xs[j];
+        const double p0 = lane < len ? cur.cv0 * xs[cur.ci0] : 0.0;
+        const double p1 = 64 + lane < len ? cur.cv1 * xs[cur.ci1] : 0.0;
+        acc = tch_chain(acc, p0, len);
+        if (len > 64) acc = tch_chain(acc, p1, len - 64);
+        for (int32_t q0 = 128; q0 < len; q0 += 64) {   // columns longer than two rounds of the wave
+            const double pq = q0 + lane < len ? Tx[cur.lo + q0 + lane] * xs[Ti[cur.lo + q0 + lane]] : 0.0;
+            acc = tch_chain(acc, pq, len - q0);
+        }
+        const double xj = acc / cur.dg;                   // lane 0's is the one
+        if (lane == 0) {
+            xs[j] = xj;
+            X[(int64_t)j * nrhs + r] = xj;
+        }
+        j = col_at(step + 1);
+        cur = n1;
+        n1 = n2;
+        n2 = n3;
+        b3 = b4;
+        e3 = e4;
+    }
+}
 template <int KIND>
 __global__ __launch_bounds__(TC_THREADS) void k_tri_columns(int32_t n, const int32_t *__restrict__ Tp,
                                                             const int32_t *__restrict__ Ti, const double *__restrict__ Tx,
                                                             double *X, int nrhs) {
-    extern __shared__ __attribute__((aligned(16))) double xs[];   // n doubles, then the product buffer (gathers)
-    double *prod = xs + n;
+    extern __shared__ __attribute__((aligned(16))) double xs[];   // n doubles
     const int tid = threadIdx.x, r = blockIdx.x;
     for (int32_t i = tid; i < n; i += TC_THREADS) xs[i] = X[(int64_t)i * nrhs + r];
     __syncthreads();
-    constexpr bool PUSH = KIND == CSX_TRI_L || KIND == CSX_TRI_U;
-    constexpr bool ASC = KIND == CSX_TRI_L || KIND == CSX_TRI_UT;
-    constexpr bool DIAG_FIRST = KIND == CSX_TRI_L || KIND == CSX_TRI_LT;
+    static_assert(KIND == CSX_TRI_L || KIND == CSX_TRI_U, "the gather kinds run k_tri_chain");
+    constexpr bool ASC = KIND == CSX_TRI_L;
+    constexpr bool DIAG_FIRST = KIND == CSX_TRI_L;
     // this thread's entry of the current column, fetched one column ahead
     int32_t j = ASC ? 0 : n - 1;
     int32_t b = Tp[j], e = Tp[j + 1];
@@ -968,7 +1059,7 @@ __global__ __launch_bounds__(TC_THREADS) void k_tri_columns(int32_t n, const int
         const double ndg = Tx[DIAG_FIRST ? nb : ne - 1];
         const int32_t nci = nlo + tid < nhi ? Ti[nlo + tid] : 0;
         const double ncv = nlo + tid < nhi ? Tx[nlo + tid] : 0.0;
-        if (PUSH) {
+        {
             const double xj = xs[j] / dg;                      // every thread: same operands, same result
             if (tid == 0) X[(int64_t)j * nrhs + r] = xj;       // x[j] is final and not read again
             if (lo + tid < hi) {
@@ -979,27 +1070,6 @@ __global__ __launch_bounds__(TC_THREADS) void k_tri_columns(int32_t n, const int
                 const int32_t i = Ti[p];
                 const double t = Tx[p] * xj;
                 xs[i] = xs[i] - t;
-            }
-            __syncthreads();
-        } else {
-            const int32_t len = hi - lo;
-            if (tid < len) prod[tid] = cv * xs[ci];
-            for (int32_t q = tid + TC_THREADS; q < len; q += TC_THREADS) prod[q] = Tx[lo + q] * xs[Ti[lo + q]];
-            __syncthreads();
-            if (tid == 0) {
-                double acc = xs[j];
-                int32_t q = 0;
-                for (; q + 8 <= len; q += 8) {
-                    double t[8];
-#pragma unroll
-                    for (int u = 0; u < 8; u++) t[u] = prod[q + u];
-#pragma unroll
-                    for (int u = 0; u < 8; u++) acc = acc - t[u];
-                }
-                for (; q < len; q++) acc = acc - prod[q];
-                const double xj = acc / dg;
-                xs[j] = xj;
-                X[(int64_t)j * nrhs + r] = xj;
             }
             __syncthreads();
         }
@@ -1599,8 +1669,8 @@ int tri_solve_raw(TriPlan *P, double *X, int32_t nrhs, bool relaxed) {
                 if (h) P->col_state = 2;
             }
         }
-        if (P->col_state == 1 && ((size_t)P->n + (size_t)P->max_col + 8) * sizeof(double) <= 150 * 1024) {
-            const size_t lds = ((size_t)P->n + (size_t)P->max_col + 8) * sizeof(double);
+        if (P->col_state == 1 && ((size_t)P->n + 8) * sizeof(double) <= 150 * 1024) {
+            const size_t lds = ((size_t)P->n + 8) * sizeof(double);
 #define CSX_TC(K)                                                                                                  \
     {                                                                                                              \
         CSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tri_columns<K>),                             \
@@ -1608,13 +1678,21 @@ int tri_solve_raw(TriPlan *P, double *X, int32_t nrhs, bool relaxed) {
         hipLaunchKernelGGL(k_tri_columns<K>, dim3((unsigned)nrhs), dim3(TC_THREADS), lds, s, P->n, P->Tp, P->Ti, P->Tx, \
                            X, nrhs);                                                                               \
     }
+#define CSX_TCH(K)                                                                                                 \
+    {                                                                                                              \
+        CSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tri_chain<K>),                               \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));                \
+        hipLaunchKernelGGL(k_tri_chain<K>, dim3((unsigned)nrhs), dim3(64), (size_t)P->n * sizeof(double), s, P->n, P->Tp, \
+                           P->Ti, P->Tx, X, nrhs);                                                                 \
+    }
             switch (P->kind) {
                 case CSX_TRI_L: CSX_TC(CSX_TRI_L) break;
-                case CSX_TRI_LT: CSX_TC(CSX_TRI_LT) break;
+                case CSX_TRI_LT: CSX_TCH(CSX_TRI_LT) break;
                 case CSX_TRI_U: CSX_TC(CSX_TRI_U) break;
-                default: CSX_TC(CSX_TRI_UT) break;
+                default: CSX_TCH(CSX_TRI_UT) break;
             }
 #undef CSX_TC
+#undef CSX_TCH
             CSX_LAUNCH_CHECK();
             return CSX_OK;
         }
