@@ -86,7 +86,8 @@ def triangular(rng, n, mean_len, lower):
     return p, np.concatenate(cols_i).astype(np.int32), np.concatenate(cols_x)
 
 
-@pytest.mark.parametrize("n,mean_len", [(1, 0.0), (2, 1.0), (65, 3.0), (1000, 0.0), (3001, 2.5), (600, 40.0), (12007, 4.0)])
+@pytest.mark.parametrize("n,mean_len", [(1, 0.0), (2, 1.0), (65, 3.0), (1000, 0.0), (3001, 2.5), (600, 40.0), (12007, 4.0),
+                                        (700, 230.0)])   # columns of 65..128 and more than 128 entries: every round of k_tri_chain
 def test_triangular_solves_bit_identical(cs, n, mean_len):
     rng = np.random.default_rng(n * 31 + 7)
     Lp, Li, Lx = triangular(rng, n, mean_len, True)
