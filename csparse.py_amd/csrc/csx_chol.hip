@@ -391,7 +391,7 @@ static int upload(T **d, const std::vector<T> &h) {
 // side b + 1 (10 K doubles for bcsstk16).  One workgroup keeps that window in REGISTERS (a BW x BW circular
 // array spread over 1024 threads, thread = (row slot, a few column slots)), and per column: the entering row
 // is fetched through the row view into a staging row, the column's elements are gathered into LDS, scaled
-// (sqrt, divisions) and written to L.x, and every thread subtracts l_r l_c from its live elements.  Three
+// (sqrt, divisions) and written to L.x, and every thread subtracts l_r l_c from its live elements.  Two
 // workgroup barriers per column, no memory traffic but the entering row and the leaving column.  Each element
 // receives its updates in ascending column order, multiply and subtract rounded separately: on a chain tree that
 // is the reference's operation sequence, so L.x comes out bit-identical (tests/test_gpu_cholesky.py).
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(THREADS) void k_chol_band(int32_t n, const int32_t 
                                                        const int32_t *__restrict__ row_pos, int *notspd) {
     constexpr int TPR = THREADS / BW;                // threads per window row
     constexpr int NS = (BW + TPR - 1) / TPR;         // elements of the row per thread
-    __shared__ double colbuf[BW], lcol[BW], stage[BW];
+    __shared__ double colbuf[BW], lcol[BW], stage[2][BW];
     const int tid = threadIdx.x;
     const int rr = tid / TPR, tc = tid % TPR;
     const bool owner = rr < BW;
@@ -416,9 +416,11 @@ __global__ __launch_bounds__(THREADS) void k_chol_band(int32_t n, const int32_t 
 #pragma unroll
     for (int sl = 0; sl < NS; sl++) W[sl] = 0.0;
     int dr = owner ? (rr + BW - 1) % BW : -1;        // at j = -(BW - 1); -1: not an owner, every loop below is empty
-    // The entering row is fetched through three dependent loads (row extent -> column / position -> value).  They are
-    // spread over three columns: each step issues one load of each kind, for the rows entering 3, 2 and 1 steps
-    // later, and consumes what was issued a whole step earlier -- no step waits for a chain of round trips.
+    // The entering row is fetched through three dependent loads (row extent -> column / position -> value) and then
+    // staged in LDS by diagonal.  The four stages are spread over four columns: each step issues one load of each
+    // kind, for the rows entering 4, 3 and 2 steps later, stages the row entering at the NEXT step from what was
+    // loaded a whole step earlier, and takes this step's row out of the other half of the staging buffer -- no step
+    // waits for a round trip, and the staging needs no barrier of its own: a column costs two barriers.
     // (A row has at most BW entries: thread t < BW handles entry t.)
     const int32_t j0 = -(BW - 1);
     auto row_extent = [&](int32_t r, int32_t &qb, int32_t &qe) {
@@ -436,16 +438,26 @@ __global__ __launch_bounds__(THREADS) void k_chol_band(int32_t n, const int32_t 
             p = row_pos[qb + tid];
         }
     };
-    int32_t c0, p0, c1, p1, qb2, qe2;                // row entering now / at the next step / extent of the one after
-    double v0;
-    {   // prologue: the state at the top of step j0 (rows 0, 1, 2)
-        int32_t qb, qe;
+    // at the top of step j: row j + BW - 1 is staged; (c1, p1, v1) = row j + BW; (c2, p2) = row j + BW + 1; extent of
+    // row j + BW + 2
+    int32_t c1, p1, c2, p2, qb3, qe3;
+    double v1;
+    if (tid < BW) {
+        stage[0][tid] = 0.0;
+        stage[1][tid] = 0.0;
+    }
+    __syncthreads();
+    {   // prologue: the state at the top of step j0
+        int32_t qb, qe, c0, p0;
         row_extent(j0 + BW - 1, qb, qe);
         row_entry(qb, qe, c0, p0);
-        v0 = p0 >= 0 ? Lx[p0] : 0.0;
+        if (p0 >= 0) stage[(j0 & 1)][j0 + BW - 1 - c0] = Lx[p0];
         row_extent(j0 + BW, qb, qe);
         row_entry(qb, qe, c1, p1);
-        row_extent(j0 + BW + 1, qb2, qe2);
+        v1 = p1 >= 0 ? Lx[p1] : 0.0;
+        row_extent(j0 + BW + 1, qb, qe);
+        row_entry(qb, qe, c2, p2);
+        row_extent(j0 + BW + 2, qb3, qe3);
     }
     int32_t ncb = 0, nce = 0, nrow = 0;              // next column's extent and this thread's row index in it
     if (n > 0) {
@@ -453,22 +465,22 @@ __global__ __launch_bounds__(THREADS) void k_chol_band(int32_t n, const int32_t 
         nce = Lp[1];
         nrow = ncb + tid < nce ? Li[ncb + tid] : 0;
     }
-    if (tid < BW) stage[tid] = 0.0;
     __syncthreads();
     for (int32_t j = j0; j < n; j++) {
+        const int par = j & 1;
         // ---- pipeline: this step's loads, each independent of the others ----
-        int32_t qb3, qe3, c2, p2;
-        row_extent(j + BW + 2, qb3, qe3);            // extent of the row entering three steps from now
-        row_entry(qb2, qe2, c2, p2);                 // entries of the row entering two steps from now
-        const double v1 = p1 >= 0 ? Lx[p1] : 0.0;    // values of the row entering at the next step
-        // ---- 1. the row that enters the window now, r_in = j + BW - 1: element (r_in, c) sits on diagonal r_in - c ----
-        if (p0 >= 0) stage[j + BW - 1 - c0] = v0;    // stage was zeroed at the end of the last step
-        __syncthreads();
+        int32_t qb4, qe4, c3, p3;
+        row_extent(j + BW + 3, qb4, qe4);            // extent of the row entering four steps from now
+        row_entry(qb3, qe3, c3, p3);                 // entries of the row entering three steps from now
+        const double v2 = p2 >= 0 ? Lx[p2] : 0.0;    // values of the row entering two steps from now
+        // ---- 1. the row that enters the window now, r_in = j + BW - 1, was staged during the last step ----
         if (dr == BW - 1) {
 #pragma unroll
             for (int sl = 0; sl < NS; sl++)
-                if (tc + TPR * sl < BW) W[sl] = stage[tc + TPR * sl];
+                if (tc + TPR * sl < BW) W[sl] = stage[par][tc + TPR * sl];
         }
+        // ---- and the one entering at the next step is staged now: element (r, c) sits on diagonal r - c ----
+        if (p1 >= 0) stage[par ^ 1][j + BW - c1] = v1;    // that half was zeroed during the last step
         // this step's column descriptor was fetched one step ago; fetch the next one now
         const int32_t cb_ = ncb, ce_ = nce, myrow = nrow;
         if (j + 1 >= 0 && j + 1 < n) {
@@ -483,7 +495,8 @@ __global__ __launch_bounds__(THREADS) void k_chol_band(int32_t n, const int32_t 
                 for (int sl = 0; sl < NS; sl++)
                     if (tc + TPR * sl == dr) colbuf[dr] = W[sl];
             }
-            __syncthreads();
+            lds_barrier();
+            if (tid < BW) stage[par][tid] = 0.0;                // taken out above by every owner: free for step j + 1's staging
             const double d = colbuf[0];
             if (!(d > 0.0)) {                                   // not positive definite (uniform)
                 if (tid == 0) atomicMin(notspd, j);
@@ -492,7 +505,7 @@ __global__ __launch_bounds__(THREADS) void k_chol_band(int32_t n, const int32_t 
             const double ljj = sqrt(d);
             if (tid < BW) lcol[tid] = tid == 0 ? ljj : colbuf[tid] / ljj;
             if (cb_ + tid < ce_) Lx[cb_ + tid] = myrow == j ? ljj : colbuf[myrow - j] / ljj;   // <= BW entries per column
-            __syncthreads();
+            lds_barrier();
             // ---- 3. rank-1 update of the live elements: c > j  <=>  dd < dr ----
             if (dr >= 1) {
                 const double lr = lcol[dr];
@@ -504,17 +517,18 @@ __global__ __launch_bounds__(THREADS) void k_chol_band(int32_t n, const int32_t 
                     W[sl] = W[sl] - t;
                 }
             }
+        } else {
+            lds_barrier();
+            if (tid < BW) stage[par][tid] = 0.0;
+            lds_barrier();
         }
-        if (j < 0) __syncthreads();                  // (for j >= 0 the barriers of step 2 already separate the reads of stage)
-        if (tid < BW) stage[tid] = 0.0;
-        __syncthreads();   // stage / colbuf / lcol are rewritten by the next column
-        c0 = c1;
-        p0 = p1;
-        v0 = v1;
         c1 = c2;
         p1 = p2;
-        qb2 = qb3;
-        qe2 = qe3;
+        v1 = v2;
+        c2 = c3;
+        p2 = p3;
+        qb3 = qb4;
+        qe3 = qe4;
         if (owner) dr = dr == 0 ? BW - 1 : dr - 1;
     }
 }

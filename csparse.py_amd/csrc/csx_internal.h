@@ -188,6 +188,12 @@ int boundaries_from_sorted(const uint32_t *sorted_key, int64_t count, int32_t nk
 int build_row_gather(Csc *A);   // fills A->rows (values required)
 int transpose_device(const Csc *A, bool values, Csc *C);  // C fields allocated here
 
+// Workgroup barrier that orders LDS only.  __syncthreads() carries a fence over global memory as well: it waits for
+// every global load the wave has in flight (s_waitcnt vmcnt(0)), which puts the latency of software-pipelined loads
+// back on the critical path of a kernel that synchronises once or twice per step.  Use where only LDS is shared
+// across the barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // sizes
 constexpr int WAVE = 64;
 

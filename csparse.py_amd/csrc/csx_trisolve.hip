@@ -950,7 +950,8 @@ __device__ __forceinline__ double tch_chain(double acc, double p, int cnt) {
     // Only lane 0's chain is the result.  The products are rotated through the wave, one lane per step (DPP
     // wave_rol:1: lane l receives lane l + 1), so lane 0 meets product 0, 1, 2, ... in order; the two rotations of a
     // step do not depend on the subtraction, which is the only chain.  (Lifting the products out with v_readlane
-    // costs ~10 cycles per scalar write: 30 cycles per term against 12 here.)
+    // costs ~10 cycles per scalar write, 30 cycles per term; rotating in place 26; eight rotations issued ahead into
+    // registers of their own 34: a wave_rol is a long instruction and eight in a row serialise.)
     int plo = __double2loint(p), phi = __double2hiint(p);
 #pragma unroll
     for (int g = 0; g < 64; g += 8) {
@@ -1001,36 +1002,42 @@ __global__ __launch_bounds__(64) void k_tri_chain(int32_t n, const int32_t *__re
         const int32_t st = step < n ? step : n - 1;
         return ASC ? st : n - 1 - st;
     };
-    int32_t j = col_at(0);
-    TchCol cur = tch_load<DIAG_FIRST>(Tp[j], Tp[j + 1], Ti, Tx, lane);
-    TchCol n1 = tch_load<DIAG_FIRST>(Tp[col_at(1)], Tp[col_at(1) + 1], Ti, Tx, lane);
-    TchCol n2 = tch_load<DIAG_FIRST>(Tp[col_at(2)], Tp[col_at(2) + 1], Ti, Tx, lane);
-    int32_t b3 = Tp[col_at(3)], e3 = Tp[col_at(3) + 1];
-    for (int32_t step = 0; step < n; step++) {
-        const int32_t j4 = col_at(step + 4);
-        const int32_t b4 = Tp[j4], e4 = Tp[j4 + 1];
-        const TchCol n3 = tch_load<DIAG_FIRST>(b3, e3, Ti, Tx, lane);
-        const int32_t len = cur.hi - cur.lo;
-        double acc = xs[j];
-        const double p0 = lane < len ? cur.cv0 * xs[cur.ci0] : 0.0;
-        const double p1 = 64 + lane < len ? cur.cv1 * xs[cur.ci1] : 0.0;
-        acc = tch_chain(acc, p0, len);
-        if (len > 64) acc = tch_chain(acc, p1, len - 64);
-        for (int32_t q0 = 128; q0 < len; q0 += 64) {   // columns longer than two rounds of the wave
-            const double pq = q0 + lane < len ? Tx[cur.lo + q0 + lane] * xs[Ti[cur.lo + q0 + lane]] : 0.0;
-            acc = tch_chain(acc, pq, len - q0);
+    // A ring of four columns in registers, the loop unrolled by four so that every slot has a fixed name: a load
+    // issued at step s is first touched at step s + 3.  (Rotating named variables instead -- cur = n1; n1 = n2; ... --
+    // makes the compiler wait for the newest load at the end of every step: the copy needs the data.)
+    TchCol ring[4];
+    int32_t pb[4], pe[4];                       // column pointers, one step ahead of the entries
+#pragma unroll
+    for (int u = 0; u < 3; u++) ring[u] = tch_load<DIAG_FIRST>(Tp[col_at(u)], Tp[col_at(u) + 1], Ti, Tx, lane);
+    pb[3] = Tp[col_at(3)];
+    pe[3] = Tp[col_at(3) + 1];
+    for (int32_t base = 0; base < n; base += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int32_t step = base + u;
+            if (step >= n) break;                       // uniform
+            const int32_t j = col_at(step);
+            const int32_t j4 = col_at(step + 4);
+            pb[u] = Tp[j4];                             // pointers of the column four steps on (slot u is free: its
+            pe[u] = Tp[j4 + 1];                         // pointers were consumed at the previous step)
+            ring[(u + 3) & 3] = tch_load<DIAG_FIRST>(pb[(u + 3) & 3], pe[(u + 3) & 3], Ti, Tx, lane);
+            const TchCol &cur = ring[u];
+            const int32_t len = cur.hi - cur.lo;
+            double acc = xs[j];
+            const double p0 = lane < len ? cur.cv0 * xs[cur.ci0] : 0.0;
+            const double p1 = 64 + lane < len ? cur.cv1 * xs[cur.ci1] : 0.0;
+            acc = tch_chain(acc, p0, len);
+            if (len > 64) acc = tch_chain(acc, p1, len - 64);
+            for (int32_t q0 = 128; q0 < len; q0 += 64) {   // columns longer than two rounds of the wave
+                const double pq = q0 + lane < len ? Tx[cur.lo + q0 + lane] * xs[Ti[cur.lo + q0 + lane]] : 0.0;
+                acc = tch_chain(acc, pq, len - q0);
+            }
+            const double xj = acc / cur.dg;                   // lane 0's is the one
+            if (lane == 0) {
+                xs[j] = xj;
+                X[(int64_t)j * nrhs + r] = xj;
+            }
         }
-        const double xj = acc / cur.dg;                   // lane 0's is the one
-        if (lane == 0) {
-            xs[j] = xj;
-            X[(int64_t)j * nrhs + r] = xj;
-        }
-        j = col_at(step + 1);
-        cur = n1;
-        n1 = n2;
-        n2 = n3;
-        b3 = b4;
-        e3 = e4;
     }
 }
 template <int KIND>
