@@ -1051,41 +1051,54 @@ __global__ __launch_bounds__(TC_THREADS) void k_tri_columns(int32_t n, const int
     static_assert(KIND == CSX_TRI_L || KIND == CSX_TRI_U, "the gather kinds run k_tri_chain");
     constexpr bool ASC = KIND == CSX_TRI_L;
     constexpr bool DIAG_FIRST = KIND == CSX_TRI_L;
-    // this thread's entry of the current column, fetched one column ahead
-    int32_t j = ASC ? 0 : n - 1;
-    int32_t b = Tp[j], e = Tp[j + 1];
-    int32_t lo = DIAG_FIRST ? b + 1 : b, hi = DIAG_FIRST ? e : e - 1;   // the off-diagonal entries
-    double dg = Tx[DIAG_FIRST ? b : e - 1];
-    int32_t ci = lo + tid < hi ? Ti[lo + tid] : 0;
-    double cv = lo + tid < hi ? Tx[lo + tid] : 0.0;
-    for (int32_t step = 0; step < n; step++) {
-        // next column's descriptor and first entry per thread
-        const int32_t jn = step + 1 < n ? (ASC ? j + 1 : j - 1) : j;
-        const int32_t nb = Tp[jn], ne = Tp[jn + 1];
-        const int32_t nlo = DIAG_FIRST ? nb + 1 : nb, nhi = DIAG_FIRST ? ne : ne - 1;
-        const double ndg = Tx[DIAG_FIRST ? nb : ne - 1];
-        const int32_t nci = nlo + tid < nhi ? Ti[nlo + tid] : 0;
-        const double ncv = nlo + tid < nhi ? Tx[nlo + tid] : 0.0;
-        {
-            const double xj = xs[j] / dg;                      // every thread: same operands, same result
+    // A ring of four columns in registers, the loop unrolled by four so that every slot has a fixed name: a column's
+    // entries are requested three steps before they are used (see k_tri_chain), and the barrier waits for LDS only.
+    auto col_at = [&](int32_t step) {   // the column of a step, clamped to the last one
+        const int32_t st = step < n ? step : n - 1;
+        return ASC ? st : n - 1 - st;
+    };
+    struct Col {
+        int32_t lo, hi, ci;
+        double dg, cv;
+    };
+    auto load = [&](int32_t b, int32_t e) {
+        Col c;
+        c.lo = DIAG_FIRST ? b + 1 : b;
+        c.hi = DIAG_FIRST ? e : e - 1;
+        c.dg = Tx[DIAG_FIRST ? b : e - 1];
+        c.ci = c.lo + tid < c.hi ? Ti[c.lo + tid] : 0;
+        c.cv = c.lo + tid < c.hi ? Tx[c.lo + tid] : 0.0;
+        return c;
+    };
+    Col ring[4];
+    int32_t pb[4], pe[4];
+#pragma unroll
+    for (int u = 0; u < 3; u++) ring[u] = load(Tp[col_at(u)], Tp[col_at(u) + 1]);
+    pb[3] = Tp[col_at(3)];
+    pe[3] = Tp[col_at(3) + 1];
+    for (int32_t base = 0; base < n; base += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int32_t step = base + u;
+            if (step >= n) break;                          // uniform
+            const int32_t j = col_at(step), j4 = col_at(step + 4);
+            pb[u] = Tp[j4];
+            pe[u] = Tp[j4 + 1];
+            ring[(u + 3) & 3] = load(pb[(u + 3) & 3], pe[(u + 3) & 3]);
+            const Col &c = ring[u];
+            const double xj = xs[j] / c.dg;                    // every thread: same operands, same result
             if (tid == 0) X[(int64_t)j * nrhs + r] = xj;       // x[j] is final and not read again
-            if (lo + tid < hi) {
-                const double t = cv * xj;
-                xs[ci] = xs[ci] - t;
+            if (c.lo + tid < c.hi) {
+                const double t = c.cv * xj;
+                xs[c.ci] = xs[c.ci] - t;
             }
-            for (int32_t p = lo + tid + TC_THREADS; p < hi; p += TC_THREADS) {   // columns longer than the workgroup
+            for (int32_t p = c.lo + tid + TC_THREADS; p < c.hi; p += TC_THREADS) {   // columns longer than the workgroup
                 const int32_t i = Ti[p];
                 const double t = Tx[p] * xj;
                 xs[i] = xs[i] - t;
             }
-            __syncthreads();
+            lds_barrier();
         }
-        j = jn;
-        lo = nlo;
-        hi = nhi;
-        dg = ndg;
-        ci = nci;
-        cv = ncv;
     }
 }
 #pragma clang fp contract(fast)
