@@ -353,11 +353,17 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const RsArgs g) {
         d0 = g.desc[(size_t)tile * RS_DESC_WORDS + lane];
         d1 = g.desc[(size_t)tile * RS_DESC_WORDS + 64 + lane];
     }
+    // keys first, payloads after: loads return in order, so the counting and ranking below wait for the keys only and
+    // the payloads keep arriving meanwhile (the barriers of this kernel order LDS, not global memory: lds_barrier)
 #pragma unroll
     for (int r = 0; r < RS_ROUNDS; r++) {
         const int64_t idx = wbase + r * 64 + lane;
-        const int64_t cl = idx < count ? idx : count - 1;   // clamped: count > 0
-        kreg[r] = g.key[cl];
+        kreg[r] = g.key[idx < count ? idx : count - 1];   // clamped: count > 0
+    }
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; r++) {
+        const int64_t idx = wbase + r * 64 + lane;
+        const int64_t cl = idx < count ? idx : count - 1;
         if (IN_AOS) {
             const Pay pr = g.pay[cl];
             areg[r] = pr.a;
@@ -392,14 +398,14 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const RsArgs g) {
                 }
                 for (int q = b + lane; q < e; q += 64) s_col[q] = (uint32_t)(j0 + 1 + c);
             }
-            __syncthreads();
+            lds_barrier();
 #pragma unroll
             for (int r = 0; r < RS_ROUNDS; r++) areg[r] = s_col[w * 64 * RS_ROUNDS + r * 64 + lane];
         } else if (K <= RS_TILE) {
             // many short columns: their starts are listed in LDS (s_key is free until the ranking rounds) and every
             // record counts the starts at or before its position, 16 searches side by side
             for (int k = threadIdx.x; k < K; k += RS_THREADS) s_key[k] = (uint32_t)((int64_t)g.xp[j0 + 1 + k] - tbase);
-            __syncthreads();
+            lds_barrier();
             int lo[RS_ROUNDS];
 #pragma unroll
             for (int r = 0; r < RS_ROUNDS; r++) lo[r] = 0;
@@ -429,13 +435,13 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const RsArgs g) {
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int r = 0; r < RS_ROUNDS; r++) {
         const int64_t idx = wbase + r * 64 + lane;
         if (idx < count) atomicAdd(&wh[w][(kreg[r] >> shift) & mask], 1);
     }
-    __syncthreads();
+    lds_barrier();
     {
         // digit d = threadIdx.x: local start of the bucket inside the tile = exclusive scan over digits
         const int d = threadIdx.x;
@@ -449,7 +455,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const RsArgs g) {
             if (lane >= dd) inc += t;
         }
         if (lane == 63) wsum[w] = inc;
-        __syncthreads();
+        lds_barrier();
         int off = 0;
 #pragma unroll
         for (int k = 0; k < RS_WAVES; k++)
@@ -463,7 +469,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const RsArgs g) {
             run += c;
         }
     }
-    __syncthreads();
+    lds_barrier();
     const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
     for (int r = 0; r < RS_ROUNDS; r++) {
@@ -498,7 +504,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const RsArgs g) {
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
     const int tcount = (int)((count - tbase) < RS_TILE ? (count - tbase) : RS_TILE);
     for (int i = threadIdx.x; i < tcount; i += RS_THREADS) {
         const uint32_t k = s_key[i];
