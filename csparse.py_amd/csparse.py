@@ -1409,5 +1409,54 @@ def cs_qrsol(order, A, b):
     return True
 
 
+def apply_q(N, X, transpose=True):
+    """X <- Q' X (transpose) or Q X for the Householder vectors of N = cs_qr(A, S), X a dvec block of N.L.m rows
+    (cs_happly, csparse.py:1216-1235, for every reflection and every column of X, on the device: csx_happly)."""
+    if not isinstance(X, dvec) or X.n < N.L.m:
+        raise IndexError("list index out of range")
+    beta = dvec(np.asarray(N.B, dtype=np.float64) if len(N.B) else np.zeros(1))
+    with _Resident(N.L) as dV:
+        _csx.check(_csx.lib().csx_happly(dV.handle, beta.handle, X.handle, X.k, 1 if transpose else 0), "csx_happly")
+    return True
+
+
+def qrsol_factor(A, order=0):
+    """Factor once (cs_sqr + cs_qr on the host), solve least-squares problems min ||A x - b|| for blocks of right-hand
+    sides on the device: the solve sequence of cs_qrsol for m >= n (csparse.py:1893-1898) -- x = P b, Q' x, R \ x,
+    x(q) -- as csx_permute_vec, csx_happly, csx_tri_solve.  solve(B): B a dvec m-by-k block or a list of m entries;
+    returns the n-by-k solutions as a new dvec (or overwrites the list's first n entries, like cs_qrsol).  Every column
+    is bit-identical to cs_qrsol on that column."""
+    if not CS_CSC(A) or A.m < A.n:
+        return None
+    S = cs_sqr(order, A, True)
+    N = cs_qr(A, S) if S is not None else None
+    if N is None:
+        return None
+    m, n, m2 = A.m, A.n, S.m2
+    R = cs_pin(_square_view(N.U))
+    cs_pin(N.L)
+
+    class _Solver(object):
+        factors, symbolic = N, S
+
+        def solve(self, b):
+            host = None if isinstance(b, dvec) else b
+            db = b if isinstance(b, dvec) else dvec(np.asarray(b[:m], dtype=np.float64))
+            if db.n < m:
+                raise IndexError("list index out of range")
+            X = dvec(m2, db.k)                       # zeros: the fictitious rows stay zero
+            cs_ipvec(S.pinv, db, X, m)               # x(pinv) = b
+            apply_q(N, X, True)
+            cs_usolve(R, X)                          # the first n rows of the block
+            out = dvec(n, db.k)
+            cs_ipvec(S.q, X, out, n)
+            if host is not None:
+                host[:n] = out.numpy().reshape(-1)[:n].tolist()
+                return True
+            return out
+
+    return _Solver()
+
+
 def device_name():
     return _csx.device_info()

@@ -241,6 +241,11 @@ int csx_qr_host(int32_t m, int32_t n, int32_t m2, const int32_t *Ap, const int32
                 double *beta);
 int csx_qr_apply_host(int32_t n, const int32_t *Vp, const int32_t *Vi, const double *Vx, const double *beta, int transpose,
                       double *x);
+/* cs_happly (csparse.py:1216-1235) applied for every reflection of V to a block of nrhs vectors on the device: X (length
+ * V.m * nrhs, row-major: row r of all vectors contiguous) <- Q' X (transpose != 0: reflections 0 .. n-1) or Q X
+ * (n-1 .. 0); beta: device vector of V.n entries.  One lane per vector runs the reference's loops: bit-identical to
+ * cs_happly called reflection by reflection on each column. */
+int csx_happly(csx_handle_t V, csx_handle_t beta, csx_handle_t X, int32_t nrhs, int transpose);
 /* The same factorisation on the device for a matrix that is a batch of small independent blocks (many connected
  * components of at most 96 rows, found on the device): one workgroup per block, dense in LDS, the reference's
  * pivot rule.  *done = 0 when the matrix is not of that shape (or has duplicate entries): use csx_lu_host.
