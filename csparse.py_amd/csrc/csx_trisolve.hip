@@ -74,7 +74,6 @@ struct TriPlan {
     int32_t *prog_ptr = nullptr, *prog_idx = nullptr;   // per sweep position: terms (local row * 64, value)
     double *prog_val = nullptr, *prog_diag = nullptr;
     int col_state = 0;               // k_tri_columns: 0 not examined, 1 usable, 2 not (duplicate rows in a column)
-    int32_t max_col = 0;             // longest column of T (gather kinds: product buffer)
     int32_t *cptr = nullptr, *cidx = nullptr;   // push kinds (L, U): per sweep position the COLUMN's entries
     double *cval = nullptr, *cdiag = nullptr;
     int32_t push_terms = 0;          // most terms of one component (0: no push program)
@@ -1673,9 +1672,6 @@ int tri_solve_raw(TriPlan *P, double *X, int32_t nrhs, bool relaxed) {
     if (ctx().opt.tri_columns && P->n <= TC_MAX_N && (int64_t)P->nlevels * 12 > P->n) {
         if (P->col_state == 0) {
             P->col_state = 1;
-            std::vector<int32_t> hp;
-            CSX_TRY(download_i32(hp, P->Tp, (size_t)P->n + 1));
-            for (int32_t c = 0; c < P->n; c++) P->max_col = std::max(P->max_col, hp[(size_t)c + 1] - hp[(size_t)c]);
             if (P->kind == CSX_TRI_L || P->kind == CSX_TRI_U) {   // gather structure of a push kind = stable transpose
                 DevScope tmp;
                 int *flag = nullptr;

@@ -42,11 +42,94 @@ def ragged(rng, m, n, mean_len, maxlen=None):
 
 t_end = time.time() + budget
 seed = 0
-counts = {"transpose": 0, "multiply": 0, "spsolve": 0}
+counts = {"transpose": 0, "multiply": 0, "spsolve": 0, "trisolve": 0, "cholesky": 0}
 while time.time() < t_end:
     seed += 1
     rng = np.random.default_rng(1000 + seed)
-    kind = seed % 3
+    kind = seed % 5
+    if kind == 3:      # the four triangular solves, list and 3-column device block, bit for bit: random, banded (chain
+        n = int(rng.choice([1, 3, 70, 500, 2500]))          # kernels), block-diagonal (component kernels)
+        shape = int(rng.integers(0, 3))
+        band = int(rng.choice([3, 40, 150]))
+        nblk = max(1, n // int(rng.choice([4, 20, 67])))
+        tri = {}
+        for lower in (True, False):
+            cols_i, cols_x = [], []
+            for j in range(n):
+                lo, hi = (j + 1, n) if lower else (0, j)
+                if shape == 1:
+                    lo, hi = (j + 1, min(n, j + band)) if lower else (max(0, j - band), j)
+                elif shape == 2:
+                    blk = n // nblk + 1
+                    b0 = (j // blk) * blk
+                    lo, hi = (j + 1, min(n, b0 + blk)) if lower else (b0, j)
+                cand = np.arange(lo, hi)
+                kk = len(cand) if shape == 1 else min(int(rng.poisson(3.0)), len(cand))
+                off = rng.choice(cand, size=kk, replace=False) if kk else np.zeros(0, np.int64)
+                if shape == 1 or rng.random() < 0.5:
+                    off = np.sort(off)
+                vals = rng.uniform(-1, 1, size=kk)
+                d = float(rng.uniform(2.0, 4.0) * (1 + kk))
+                cols_i.append(np.concatenate([[j], off]) if lower else np.concatenate([off, [j]]))
+                cols_x.append(np.concatenate([[d], vals]) if lower else np.concatenate([vals, [d]]))
+            Tp = np.zeros(n + 1, np.int32); Tp[1:] = np.cumsum([len(c) for c in cols_i])
+            tri[lower] = (Tp, np.concatenate(cols_i).astype(np.int32), np.concatenate(cols_x))
+        B = rng.uniform(-1, 1, size=(n, 3))
+        for fn, ofn, lower in ((cs.cs_lsolve, CO.lsolve, True), (cs.cs_ltsolve, CO.ltsolve, True),
+                               (cs.cs_usolve, CO.usolve, False), (cs.cs_utsolve, CO.utsolve, False)):
+            Tp, Ti, Tx = tri[lower]
+            M = cs.cs_pin(host(cs, n, n, Tp, Ti, Tx))
+            b = B[:, 0].tolist()
+            assert fn(M, b) is True
+            assert np.asarray(b).tobytes() == ofn(n, Tp, Ti, Tx, B[:, 0]).tobytes(), ("trisolve list", seed, fn.__name__, n, shape)
+            dB = cs.dvec(B)
+            assert fn(M, dB) is True
+            Xk = dB.numpy().reshape(n, 3)
+            for r in range(3):
+                assert Xk[:, r].tobytes() == ofn(n, Tp, Ti, Tx, B[:, r]).tobytes(), ("trisolve block", seed, fn.__name__, n, shape, r)
+        counts["trisolve"] += 1
+        continue
+    if kind == 4:      # cs_schol + cs_chol + cs_cholsol on random SPD matrices: banded, block-diagonal, scattered
+        n = int(rng.choice([1, 6, 90, 400, 1500]))
+        shape = int(rng.integers(0, 3))
+        band = int(rng.choice([2, 25, 120]))
+        blk = int(rng.choice([3, 16, 64]))
+        rows, colsj, vals = [], [], []
+        for j in range(n):
+            if shape == 0:
+                cand = np.arange(j + 1, min(n, j + band))
+            elif shape == 1:
+                cand = np.arange(j + 1, min(n, (j // blk + 1) * blk))
+            else:
+                cand = rng.choice(np.arange(j + 1, n), size=min(int(rng.poisson(1.5)), n - j - 1), replace=False) if j + 1 < n else np.zeros(0, np.int64)
+            for i in cand:
+                rows.append(int(i)); colsj.append(j); vals.append(float(rng.uniform(-1, 1)))
+        import scipy.sparse as sp
+        Lw = sp.coo_matrix((vals, (rows, colsj)), shape=(n, n))
+        Sm = (Lw + Lw.T).tocsc()
+        diag = np.asarray(abs(Sm).sum(axis=0)).ravel() + rng.uniform(1.0, 2.0, size=n)
+        Sm = (Sm + sp.diags(diag)).tocsc()
+        Sm.sort_indices()
+        Cp, Ci, Cx = Sm.indptr.astype(np.int32), Sm.indices.astype(np.int32), Sm.data.astype(np.float64)
+        parent, cp = CO.schol(n, Cp, Ci)
+        Lp, Li, Lx = CO.chol(n, Cp, Ci, Cx, parent, cp)
+        A = host(cs, n, n, Cp, Ci, Cx)
+        S = cs.cs_schol(0, A)
+        assert S is not None and list(S.parent) == parent.tolist() and list(S.cp) == cp.tolist(), ("schol", seed, n, shape)
+        N = cs.cs_chol(A, S)
+        assert N is not None, ("chol returned None", seed, n, shape)
+        lnz = int(Lp[-1])
+        assert N.L.p == Lp.tolist() and N.L.i[:lnz] == Li.tolist(), ("chol pattern", seed, n, shape)
+        got = np.asarray(N.L.x[:lnz])
+        assert float(np.max(np.abs(got - Lx))) <= 1e-13 * max(1.0, float(np.max(np.abs(Lx)))), ("chol values", seed, n, shape)
+        b = rng.uniform(-1, 1, size=n)
+        x = b.tolist()
+        assert cs.cs_cholsol(0, A, x) is True
+        y = CO.lsolve(n, Lp, Li, Lx, b)
+        z = CO.ltsolve(n, Lp, Li, Lx, y)
+        assert float(np.max(np.abs(np.asarray(x) - z))) <= 1e-10 * max(1.0, float(np.max(np.abs(z)))), ("cholsol", seed, n, shape)
+        counts["cholesky"] += 1
+        continue
     if kind == 0:      # transpose: shapes across one to four radix passes, all column-start paths
         m = int(rng.choice([1, 7, 255, 257, 5000, 70000, 300000, 17000000]))
         n = int(rng.choice([1, 3, 200, 4097, 30000]))
