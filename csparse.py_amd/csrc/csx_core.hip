@@ -198,6 +198,8 @@ void free_tiled(TiledPlan *t) {
     dfree(t->tile_ptr);
     dfree(t->tile_len);
     dfree(t->tile_key);
+    dfree(t->tile_key24);
+    dfree(t->tile_base);
     dfree(t->tile_val);
     delete t;
 }
@@ -467,6 +469,7 @@ int csx_set_option(const char *name, int value) {
     else if (n == "tri.chain_walker") o.tri_chain_walker = value != 0;
     else if (n == "tri.components") o.tri_components = value != 0;
     else if (n == "tri.columns") o.tri_columns = value != 0;
+    else if (n == "gaxpy.keys24") o.gaxpy_keys24 = value != 0;
     else if (n == "tri.push") o.tri_push = value != 0;
     else if (n == "tri.levels_where") o.tri_levels_where = (value == 1 || value == 2) ? value : 0;
     else return CSX_EINVAL;

@@ -330,6 +330,16 @@ extern "C" int csx_gaxpy_prepare(csx_handle_t hA, int mode) {
     }
 }
 
+extern "C" int csx_gaxpy_plan_info(csx_handle_t hA, int *has_rows, int *has_tiled, int *key_bytes) {
+    CSX_TRY(require_ready());
+    Csc *A = csc(hA);
+    if (!A) return CSX_EINVAL;
+    if (has_rows) *has_rows = A->rows ? 1 : 0;
+    if (has_tiled) *has_tiled = A->tiled ? 1 : 0;
+    if (key_bytes) *key_bytes = A->tiled ? (A->tiled->tile_key24 ? 3 : 4) : 0;
+    return CSX_OK;
+}
+
 extern "C" int csx_gaxpy(csx_handle_t hA, csx_handle_t hx, csx_handle_t hy, int mode) {
     CSX_TRY(require_ready());
     Csc *A = csc(hA);

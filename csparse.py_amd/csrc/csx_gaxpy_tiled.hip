@@ -26,6 +26,11 @@
 //   * The entry stream (4-byte packed (col,row) key + 8-byte value = the same 12
 //     bytes per entry as CSC) is read once, coalesced, non-temporal, one group
 //     ahead of the gathers.
+//   * 3-byte keys.  A gather instruction covers 64 consecutive entries of the column-sorted tile; when every such
+//     run spans fewer than 512 columns (always, for a matrix like G-rand: a run spans 256 +- 32) an entry needs its
+//     row in the block (15 bits) and its column's offset from the run's first column (9 bits): 3 bytes, the run's
+//     base column being four words per group of 256.  The stream is then 11 bytes per entry instead of 12.  A matrix
+//     with a wider run anywhere keeps the 4-byte keys.
 //
 // HBM bytes per call ~ 12 nnz (+0.4 % padding) + 16 m + 8 n * (#XCDs that read x).
 #include <cstdlib>
@@ -88,8 +93,52 @@ __global__ __launch_bounds__(256) void k_interleave(int64_t nnz, const uint32_t 
     // half of every line and issued twice as many (64-byte) requests.
     const int64_t gbase = ((int64_t)gptr[t] + g) * TL_GROUP;
     const int l = w & 63, k = w >> 6;
-    okey[gbase + l * 4 + k] = skey[q];
+    if (okey) okey[gbase + l * 4 + k] = skey[q];
     oval[gbase + (k >> 1) * 128 + l * 2 + (k & 1)] = sval[q];
+}
+
+// 3-byte keys: is every run of 64 consecutive entries of a tile narrower than 512 columns?
+__global__ __launch_bounds__(256) void k_run_span(int64_t nnz, const uint32_t *__restrict__ stid,
+                                                  const int32_t *__restrict__ sptr, const uint32_t *__restrict__ skey,
+                                                  int rb_bits, int *too_wide) {
+    int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nnz) return;
+    const int32_t e = (int32_t)(q - sptr[stid[q]]);
+    const int64_t first = q - (e & 63);
+    if ((skey[q] >> rb_bits) - (skey[first] >> rb_bits) >= 512u) *too_wide = 1;
+}
+
+// key24 of entry w of a group: bytes 12 l + 3 k .. + 2 of the group's 768 (lane l = w & 63, run k = w >> 6), value
+// row | (column - first column of the run) << 15; base[4 g + k] = that first column
+__global__ __launch_bounds__(256) void k_interleave24(int64_t nnz, const uint32_t *__restrict__ stid,
+                                                      const int32_t *__restrict__ sptr, const int32_t *__restrict__ gptr,
+                                                      const uint32_t *__restrict__ skey, int rb_bits,
+                                                      uint8_t *__restrict__ okey, uint32_t *__restrict__ obase) {
+    int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nnz) return;
+    const uint32_t t = stid[q];
+    const int32_t e = (int32_t)(q - sptr[t]);
+    const int32_t g = e / TL_GROUP, w = e % TL_GROUP;
+    const int l = w & 63, k = w >> 6;
+    const uint32_t rmask = (1u << rb_bits) - 1u;
+    const uint32_t col = skey[q] >> rb_bits, col0 = skey[q - l] >> rb_bits;
+    const uint32_t v = (skey[q] & rmask) | ((col - col0) << 15);
+    const int64_t gg = (int64_t)gptr[t] + g;
+    uint8_t *o = okey + gg * (TL_GROUP * 3) + l * 12 + k * 3;
+    o[0] = (uint8_t)v;
+    o[1] = (uint8_t)(v >> 8);
+    o[2] = (uint8_t)(v >> 16);
+    if (l == 0) obase[gg * 4 + k] = col;
+}
+
+__global__ __launch_bounds__(256) void k_fill_key24(uint8_t *p, int64_t nslots, uint32_t v) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < nslots; i += stride) {
+        p[3 * i] = (uint8_t)v;
+        p[3 * i + 1] = (uint8_t)(v >> 8);
+        p[3 * i + 2] = (uint8_t)(v >> 16);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_fill_keys(uint32_t *p, int64_t n, uint32_t v) {
@@ -99,17 +148,31 @@ __global__ __launch_bounds__(256) void k_fill_keys(uint32_t *p, int64_t n, uint3
 }
 
 struct GroupRegs {
-    u32x4 kk;
+    u32x4 kk;      // 4-byte keys as stored; 3-byte keys unpacked to row | offset << 15
+    u32x4 base;    // 3-byte keys: first column of the four runs
     f64x2 v0, v1;
     uint32_t info;
 };
 
-template <bool NT>
+template <bool NT, bool K24>
 __device__ __forceinline__ GroupRegs load_group_t(const uint32_t *__restrict__ key, const double *__restrict__ val,
-                                                  const uint32_t *__restrict__ info, int32_t g, int lane) {
+                                                  const uint32_t *__restrict__ info, const uint32_t *__restrict__ base,
+                                                  int32_t g, int lane) {
     GroupRegs r;
     const int64_t gb = (int64_t)g * TL_GROUP;
-    if (NT) {
+    if (K24) {
+        // `key` is the byte array of 3-byte keys: 12 bytes per lane, 768 per group
+        const uint32_t *kp = key + (int64_t)g * (TL_GROUP * 3 / 4) + 3 * lane;
+        const uint32_t ka = __builtin_nontemporal_load(kp), kb = __builtin_nontemporal_load(kp + 1),
+                       kc = __builtin_nontemporal_load(kp + 2);
+        r.kk.x = ka & 0xFFFFFFu;
+        r.kk.y = (ka >> 24) | ((kb & 0xFFFFu) << 8);
+        r.kk.z = (kb >> 16) | ((kc & 0xFFu) << 16);
+        r.kk.w = kc >> 8;
+        r.base = *reinterpret_cast<const u32x4 *>(base + 4 * (int64_t)g);
+        r.v0 = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(val + gb + 2 * lane));
+        r.v1 = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(val + gb + 128 + 2 * lane));
+    } else if (NT) {
         r.kk = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(key + gb + 4 * lane));
         r.v0 = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(val + gb + 2 * lane));
         r.v1 = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(val + gb + 128 + 2 * lane));
@@ -143,7 +206,7 @@ __device__ __forceinline__ double load_x(const double *p) {
 //   5 = gather from a 256 KB footprint (L2 hits, L1 misses)
 //   6 = full kernel, x gathered with L1-bypassing sc1 loads (computes y)
 //   7 = real x gathers, but the entry stream re-reads the first 32 groups of the row block (L2-resident)
-template <int VARIANT, int NW, int NG>
+template <int VARIANT, int NW, int NG, bool K24>
 struct TiledStep {
     static constexpr bool GATHER = !(VARIANT & 1) || VARIANT >= 5, ATOMIC = VARIANT != 3;
     static constexpr bool STREAM_NT = VARIANT != 2;
@@ -155,34 +218,42 @@ struct TiledStep {
     // instead of predicated: the loop body stays branch-free)
     static __device__ __forceinline__ void load_set(GroupRegs (&r)[NG], const uint32_t *__restrict__ key,
                                                     const double *__restrict__ val, const uint32_t *__restrict__ info,
-                                                    int32_t g, int32_t g0, int32_t gend, int lane) {
+                                                    const uint32_t *__restrict__ base, int32_t g, int32_t g0,
+                                                    int32_t gend, int lane) {
 #pragma unroll
         for (int j = 0; j < NG; j++) {
             int32_t gg = g + j * NW < gend ? g + j * NW : gend - 1;
             if (RING) gg = g0 + ((gg - g0) & 31);
-            r[j] = load_group_t<STREAM_NT>(key, val, info, gg, lane);
+            r[j] = load_group_t<STREAM_NT, K24>(key, val, info, base, gg, lane);
         }
     }
 
     // gather x for the NG groups in `cur`, put the next NG groups' entry loads behind the gathers, accumulate
     static __device__ __forceinline__ void step(GroupRegs (&cur)[NG], GroupRegs (&nxt)[NG], double *ytile,
                                                 const uint32_t *__restrict__ key, const double *__restrict__ val,
-                                                const uint32_t *__restrict__ info, const double *__restrict__ x,
-                                                int32_t &g, int32_t g0, int32_t gend, int lane, int rb_bits,
-                                                uint32_t rmask, int32_t slab_cols, double &sink) {
+                                                const uint32_t *__restrict__ info, const uint32_t *__restrict__ base,
+                                                const double *__restrict__ x, int32_t &g, int32_t g0, int32_t gend,
+                                                int lane, int rb_bits, uint32_t rmask, int32_t slab_cols, double &sink) {
         double xv[NG][4];
 #pragma unroll
         for (int j = 0; j < NG; j++) {
             xv[j][0] = xv[j][1] = xv[j][2] = xv[j][3] = 1.0;
             if (GATHER && (j == 0 || g + j * NW < gend)) {
                 const double *xs = x + (int64_t)(cur[j].info >> 9) * slab_cols;
-                xv[j][0] = load_x<XLOAD>(xs + ((cur[j].kk.x >> rb_bits) & CMASK));
-                xv[j][1] = load_x<XLOAD>(xs + ((cur[j].kk.y >> rb_bits) & CMASK));
-                xv[j][2] = load_x<XLOAD>(xs + ((cur[j].kk.z >> rb_bits) & CMASK));
-                xv[j][3] = load_x<XLOAD>(xs + ((cur[j].kk.w >> rb_bits) & CMASK));
+                if (K24) {
+                    xv[j][0] = load_x<XLOAD>(xs + ((cur[j].base.x + (cur[j].kk.x >> 15)) & CMASK));
+                    xv[j][1] = load_x<XLOAD>(xs + ((cur[j].base.y + (cur[j].kk.y >> 15)) & CMASK));
+                    xv[j][2] = load_x<XLOAD>(xs + ((cur[j].base.z + (cur[j].kk.z >> 15)) & CMASK));
+                    xv[j][3] = load_x<XLOAD>(xs + ((cur[j].base.w + (cur[j].kk.w >> 15)) & CMASK));
+                } else {
+                    xv[j][0] = load_x<XLOAD>(xs + ((cur[j].kk.x >> rb_bits) & CMASK));
+                    xv[j][1] = load_x<XLOAD>(xs + ((cur[j].kk.y >> rb_bits) & CMASK));
+                    xv[j][2] = load_x<XLOAD>(xs + ((cur[j].kk.z >> rb_bits) & CMASK));
+                    xv[j][3] = load_x<XLOAD>(xs + ((cur[j].kk.w >> rb_bits) & CMASK));
+                }
             }
         }
-        load_set(nxt, key, val, info, g + NG * NW, g0, gend, lane);
+        load_set(nxt, key, val, info, base, g + NG * NW, g0, gend, lane);
 #pragma unroll
         for (int j = 0; j < NG; j++) {
             if (j == 0 || g + j * NW < gend) {
@@ -202,17 +273,18 @@ struct TiledStep {
     }
 };
 
-template <int VARIANT, int NW, int NG>
+template <int VARIANT, int NW, int NG, bool K24>
 __global__ __launch_bounds__(64 * NW) void k_gaxpy_tiled(const int32_t *__restrict__ rb_gptr,
                                                          const uint32_t *__restrict__ group_info,
                                                          const uint32_t *__restrict__ tile_key,
+                                                         const uint32_t *__restrict__ tile_base,
                                                          const double *__restrict__ tile_val,
                                                          const double *__restrict__ x, double *__restrict__ y,
                                                          int32_t m, int32_t nrb, int32_t row_block,
                                                          int32_t slab_cols, int rb_bits) {
     extern __shared__ __attribute__((aligned(16))) double ytile[];  // row_block doubles + the padding dummy row
-    typedef TiledStep<VARIANT, NW, NG> S;
-    const uint32_t rmask = (1u << rb_bits) - 1u;
+    typedef TiledStep<VARIANT, NW, NG, K24> S;
+    const uint32_t rmask = K24 ? 0x7FFFu : (1u << rb_bits) - 1u;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double sink = 0.0;
     for (int32_t rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
@@ -228,11 +300,11 @@ __global__ __launch_bounds__(64 * NW) void k_gaxpy_tiled(const int32_t *__restri
         int32_t g = g0 + wave;
         if (g < gend) {
             GroupRegs A[NG], B[NG];
-            S::load_set(A, tile_key, tile_val, group_info, g, g0, gend, lane);
+            S::load_set(A, tile_key, tile_val, group_info, tile_base, g, g0, gend, lane);
             for (;;) {
-                S::step(A, B, ytile, tile_key, tile_val, group_info, x, g, g0, gend, lane, rb_bits, rmask, slab_cols, sink);
+                S::step(A, B, ytile, tile_key, tile_val, group_info, tile_base, x, g, g0, gend, lane, rb_bits, rmask, slab_cols, sink);
                 if (g >= gend) break;
-                S::step(B, A, ytile, tile_key, tile_val, group_info, x, g, g0, gend, lane, rb_bits, rmask, slab_cols, sink);
+                S::step(B, A, ytile, tile_key, tile_val, group_info, tile_base, x, g, g0, gend, lane, rb_bits, rmask, slab_cols, sink);
                 if (g >= gend) break;
             }
         }
@@ -314,17 +386,45 @@ int gaxpy_tiled_prepare(Csc *A) {
         hipLaunchKernelGGL(k_padded_lengths, dim3(tb), dim3(256), 0, s, ntiles, sptr, gptr);
         st = scan_exclusive_i32(gptr, gptr, ntiles, &ngroups);
     }
+    // 3-byte keys when every 64-entry run is narrower than 512 columns (and the row fits 15 bits: always, LDS bounds it)
+    bool k24 = false;
+    if (st == CSX_OK && ngroups > 0 && rb_bits <= 15 && ctx().opt.gaxpy_keys24) {
+        int *flag = nullptr;
+        int h = 1;
+        st = dalloc(&flag, 1);
+        if (st == CSX_OK) {
+            (void)hipMemsetAsync(flag, 0, sizeof(int), s);
+            hipLaunchKernelGGL(k_run_span, dim3((unsigned)(((int64_t)A->nnz + 255) / 256)), dim3(256), 0, s, (int64_t)A->nnz,
+                               stid, sptr, skey, rb_bits, flag);
+            if (hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
+                hipStreamSynchronize(s) != hipSuccess)
+                st = CSX_ERUNTIME;
+        }
+        dfree(flag);
+        k24 = st == CSX_OK && h == 0;
+    }
     if (st == CSX_OK) st = dalloc(&t->tile_len, (size_t)ngroups);  // group_info
-    if (st == CSX_OK) st = dalloc(&t->tile_key, (size_t)ngroups * TL_GROUP);
+    if (st == CSX_OK && !k24) st = dalloc(&t->tile_key, (size_t)ngroups * TL_GROUP);
+    if (st == CSX_OK && k24) st = dalloc(&t->tile_key24, (size_t)ngroups * TL_GROUP * 3 + 16);
+    if (st == CSX_OK && k24) st = dalloc(&t->tile_base, (size_t)ngroups * 4);
     if (st == CSX_OK) st = dalloc(&t->tile_val, (size_t)ngroups * TL_GROUP);
     if (st == CSX_OK && ngroups > 0) {
-        // padding slots: column 0 of the slab, dummy row, value 0 -> adds 0 * x into an unused LDS slot
-        hipLaunchKernelGGL(k_fill_keys, dim3(2048), dim3(256), 0, s, t->tile_key, (int64_t)ngroups * TL_GROUP,
-                           (uint32_t)row_block);
+        // padding slots: column 0 of the slab / offset 0 of the run, dummy row, value 0 -> adds 0 * x into an unused LDS slot
+        if (k24) {
+            hipLaunchKernelGGL(k_fill_key24, dim3(2048), dim3(256), 0, s, t->tile_key24, (int64_t)ngroups * TL_GROUP,
+                               (uint32_t)row_block);
+            (void)hipMemsetAsync(t->tile_base, 0, (size_t)ngroups * 4 * sizeof(uint32_t), s);
+        } else {
+            hipLaunchKernelGGL(k_fill_keys, dim3(2048), dim3(256), 0, s, t->tile_key, (int64_t)ngroups * TL_GROUP,
+                               (uint32_t)row_block);
+        }
         (void)hipMemsetAsync(t->tile_val, 0, (size_t)ngroups * TL_GROUP * sizeof(double), s);
         hipLaunchKernelGGL(k_group_info, dim3(tb), dim3(256), 0, s, ntiles, nslab, sptr, gptr, (uint32_t *)t->tile_len);
         hipLaunchKernelGGL(k_interleave, dim3((unsigned)(((int64_t)A->nnz + 255) / 256)), dim3(256), 0, s,
                            (int64_t)A->nnz, stid, sptr, gptr, skey, sval, t->tile_key, t->tile_val);
+        if (k24)
+            hipLaunchKernelGGL(k_interleave24, dim3((unsigned)(((int64_t)A->nnz + 255) / 256)), dim3(256), 0, s,
+                               (int64_t)A->nnz, stid, sptr, gptr, skey, rb_bits, t->tile_key24, t->tile_base);
     }
     if (st == CSX_OK) {
         hipLaunchKernelGGL(k_rb_group_ptr, dim3((unsigned)((nrb + 256) / 256)), dim3(256), 0, s, nrb, nslab, gptr,
@@ -353,13 +453,18 @@ int gaxpy_tiled_run(const Csc *A, const double *x, double *y) {
     const size_t lds = (((size_t)(t->row_block + 1) * sizeof(double)) + 15) & ~(size_t)15;  // + dummy row
     const int32_t nwg = ctx().cus > 0 ? ctx().cus : 256;
     const unsigned grid = (unsigned)(t->nrb < nwg ? t->nrb : nwg);
+#define CSX_TILED_LAUNCH_K(V, NW, NG, K24)                                                                           \
+    {                                                                                                                \
+        CSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gaxpy_tiled<V, NW, NG, K24>),                  \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, TL_LDS_BYTES));                      \
+        hipLaunchKernelGGL((k_gaxpy_tiled<V, NW, NG, K24>), dim3(grid), dim3(64 * NW), lds, s, t->tile_ptr,          \
+                           (const uint32_t *)t->tile_len,                                                            \
+                           K24 ? reinterpret_cast<const uint32_t *>(t->tile_key24) : t->tile_key, t->tile_base,      \
+                           t->tile_val, x, y, A->m, t->nrb, t->row_block, t->slab_cols, t->rb_bits);                 \
+    }
 #define CSX_TILED_LAUNCH(V, NW, NG)                                                                                  \
     {                                                                                                                \
-        CSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gaxpy_tiled<V, NW, NG>),                       \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, TL_LDS_BYTES));                      \
-        hipLaunchKernelGGL((k_gaxpy_tiled<V, NW, NG>), dim3(grid), dim3(64 * NW), lds, s, t->tile_ptr,               \
-                           (const uint32_t *)t->tile_len, t->tile_key, t->tile_val, x, y, A->m, t->nrb, t->row_block, \
-                           t->slab_cols, t->rb_bits);                                                                \
+        if (t->tile_key24) CSX_TILED_LAUNCH_K(V, NW, NG, true) else CSX_TILED_LAUNCH_K(V, NW, NG, false)             \
     }
 #ifdef CSX_ABLATION
     // CSX_TILED_VARIANT = V + 100 * NW + 10000 * NG (NW, NG default to the shipped TL_WAVES, TL_NG)
@@ -407,6 +512,7 @@ int gaxpy_tiled_run(const Csc *A, const double *x, double *y) {
     CSX_TILED_LAUNCH(0, TL_WAVES, TL_NG)
 #endif
 #undef CSX_TILED_LAUNCH
+#undef CSX_TILED_LAUNCH_K
     CSX_LAUNCH_CHECK();
     return CSX_OK;
 }

@@ -66,9 +66,12 @@ struct TiledPlan {
     int32_t slab_cols = 0;         // columns per slab
     int32_t *tile_ptr = nullptr;   // [nrb + 1] first group of every row block
     int32_t *tile_len = nullptr;   // [ngroups] group info: (slab << 9) | entries in the group
-    uint32_t *tile_key = nullptr;  // packed (local col << rb_bits) | local row
+    uint32_t *tile_key = nullptr;  // packed (local col << rb_bits) | local row; null when the 3-byte keys are in use
     double *tile_val = nullptr;
     int rb_bits = 0;
+    // 3-byte keys (row | column offset << 15), used when every run of 64 column-sorted entries spans < 512 columns:
+    uint8_t *tile_key24 = nullptr; // [ngroups * 768]
+    uint32_t *tile_base = nullptr; // [ngroups * 4] slab-local column of the first entry of each 64-entry run
 };
 
 struct Csc {
@@ -108,6 +111,7 @@ struct Options {
     bool tri_components = true;       // tri-solve: one wave per small connected component (false: level sets)
     bool tri_push = true;             // tri-solve: component kernels in column-push form for L / U with few RHS
     bool tri_columns = true;          // tri-solve: small chain-like systems by the column loop, x in LDS
+    bool gaxpy_keys24 = true;         // tiled cs_gaxpy plan: 3-byte keys when the matrix allows them
     int tri_levels_where = 0;         // level analysis: 0 = device for big factors, host for small; 1 = host; 2 = device
 };
 

@@ -114,6 +114,10 @@ int csx_ivec_download(csx_handle_t v, int32_t *dst, int64_t len);
 int csx_gaxpy(csx_handle_t A, csx_handle_t x, csx_handle_t y, int mode);
 /* Build (and cache on A) the plan `mode` needs, outside any timed region. */
 int csx_gaxpy_prepare(csx_handle_t A, int mode);
+/* Which plans the matrix holds: the row-major copy (EXACT / WAVE), the LDS-tiled regrouping (TILED), and the bytes
+ * per key of the latter: 4 (column, row packed) or 3 (row + 9-bit column offset inside a run of 64 column-sorted
+ * entries; chosen when every run is narrower than 512 columns); 0 without a tiled plan.  Any pointer may be NULL. */
+int csx_gaxpy_plan_info(csx_handle_t A, int *has_rows, int *has_tiled, int *key_bytes);
 /* One-shot form for host arrays (the reference's list signature): y[0..m) += A x in the reference's
  * summation order (bit-identical), nothing left on the device.  x (values) must be present. */
 int csx_gaxpy_host(int32_t m, int32_t n, const int32_t *p, const int32_t *i, const double *x, const double *xv,

@@ -238,3 +238,34 @@ def test_transpose_column_expansion_paths(cs, m, n, nnz, what):
     assert np.array_equal(Tp, Rp) and np.array_equal(Ti, Ri) and Tx.tobytes() == Rx.tobytes(), what
     Tp, Ti, _ = _transpose_abi((m, n, Ap, rows, vals), values=False)
     assert np.array_equal(Tp, Rp) and np.array_equal(Ti, Ri), what
+
+
+@pytest.mark.parametrize("n,per_col,expect", [(65536, 64, 3), (60000, 64, 4), (30000, 3, 4)])
+def test_tiled_plan_key_formats(cs, n, per_col, expect):
+    """The LDS-tiled cs_gaxpy plan stores 3-byte keys (row + 9-bit column offset inside a run of 64 column-sorted
+    entries) when every run is narrower than 512 columns, 4-byte keys otherwise.  Dense-enough random matrices take
+    the first (65 536 rows = 256 equal row blocks), sparse ones the second (a run of 64 entries of a tile spans
+    thousands of columns; at 60 000 rows the last row block has 75 rows instead of 235); both must give the
+    oracle's y (rounding-equal: the tiled plan accumulates with LDS atomics)."""
+    import _csx
+    Ap, Ai, Ax = synth.grand(n, per_col, 20240615)
+    x = synth.vec(n, 11, 0.5, 1.5)
+    y0 = synth.vec(n, 12, -1.0, 1.0)
+    ref = CO.gaxpy(n, n, Ap, Ai, Ax, x, y0)
+    scale = CO.gaxpy(n, n, Ap, Ai, np.abs(Ax), np.abs(x), np.abs(y0))
+    lib = _csx.lib()
+    out = {}
+    for keys24 in (1, 0):
+        _csx.check(lib.csx_set_option(b"gaxpy.keys24", keys24))
+        try:
+            A = cs.cs_pin(_host_cs(cs, n, n, Ap, Ai, Ax))
+            dy = cs.dvec(y0)
+            assert cs.cs_gaxpy(A, cs.dvec(x), dy, cs.GAXPY_TILED) is True
+            kb = _csx.C.c_int(0)
+            _csx.check(lib.csx_gaxpy_plan_info(A._dev.handle, None, None, kb))
+            assert kb.value == (expect if keys24 else 4)
+            out[keys24] = dy.numpy()
+            assert rel_err(out[keys24], ref, scale) < RTOL
+        finally:
+            _csx.check(lib.csx_set_option(b"gaxpy.keys24", 1))
+    assert rel_err(out[1], out[0], scale) < RTOL     # LDS atomics: the two runs agree to rounding, not bit for bit
