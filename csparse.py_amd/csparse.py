@@ -1324,17 +1324,36 @@ def cs_happly(V, i, beta, x):
 def cs_qr(A, S):
     """Sparse Householder QR, A = Q R (csparse.py:1797-1870).  N.L = V, N.U = R (diagonal last in
     every column), N.B = beta.  Host C++ (csx_qr_host, csx_host.cpp): column by column along the column
-    elimination tree, like cs_lu a sequence of data-dependent steps."""
+    elimination tree, like cs_lu a sequence of data-dependent steps -- except for a square matrix that is a batch of
+    small independent blocks, which factors on the device (csx_qr_blocks: one lane per block, same results bit for bit)."""
     if not CS_CSC(A) or S is None:
         return None
     if A.x is None:
         raise TypeError("'NoneType' object is not subscriptable")
     m, n, m2 = A.m, A.n, S.m2
+    q = None if S.q is None else _csx.i32(S.q)
+    parent, pinv, leftmost = _csx.i32(S.parent), _csx.i32(S.pinv), _csx.i32(S.leftmost)
+    if q is None and m == n and m2 == m and (n >= 4096 or A._dev is not None):
+        # a batch of small independent blocks factors on the device, one lane per block running the host code's loop
+        # (csx_qr_blocks); anything else comes back with done = 0 and takes the host code below
+        beta = np.zeros(max(n, 1))
+        hV, hR, done = _csx.new_handle(), _csx.new_handle(), _csx.C.c_int(0)
+        with _Resident(A) as dA:
+            st = _csx.lib().csx_qr_blocks(dA.handle, _csx.pi(parent), _csx.pi(pinv), _csx.pi(leftmost), m2, hV, hR,
+                                          _csx.pd(beta), done)
+        if st == _csx.EINVAL:
+            raise IndexError("list index out of range")
+        _csx.check(st, "csx_qr_blocks")
+        if done.value:
+            N = csn()
+            N.L = _from_device(hV, lambda nnz: max(nnz, 1))
+            N.U = _from_device(hR, lambda nnz: max(nnz, 1))
+            N.B = beta[:n].tolist()
+            N.pinv = None
+            return N
     Ap = _csx.i32(A.p[:n + 1])
     nnz = int(Ap[n])
     Ai, Ax = _csx.i32(A.i[:nnz]), _csx.f64(A.x[:nnz])
-    q = None if S.q is None else _csx.i32(S.q)
-    parent, pinv, leftmost = _csx.i32(S.parent), _csx.i32(S.pinv), _csx.i32(S.leftmost)
     vcap, rcap = max(int(S.lnz), 1), max(int(S.unz), 1)
     Vp, Rp = np.zeros(n + 1, np.int32), np.zeros(n + 1, np.int32)
     Vi, Ri = np.zeros(vcap, np.int32), np.zeros(rcap, np.int32)

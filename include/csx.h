@@ -250,6 +250,13 @@ int csx_qr_apply_host(int32_t n, const int32_t *Vp, const int32_t *Vi, const dou
  * (n-1 .. 0); beta: device vector of V.n entries.  One lane per vector runs the reference's loops: bit-identical to
  * cs_happly called reflection by reflection on each column. */
 int csx_happly(csx_handle_t V, csx_handle_t beta, csx_handle_t X, int32_t nrhs, int transpose);
+/* cs_qr's numeric phase on the device for a SQUARE matrix that is a batch of small independent blocks (connected
+ * components of at most 96 rows, at least 64 of them), natural column order, no fictitious rows (m2 == m): one lane per
+ * block runs csx_qr_host's loop.  parent / pinv / leftmost: host arrays of n entries from cs_sqr.  V, R: new device
+ * matrices; beta: host, n entries.  All three bit-identical to csx_qr_host.  *done = 0 when the matrix (or the
+ * analysis) is not of that shape: use csx_qr_host. */
+int csx_qr_blocks(csx_handle_t A, const int32_t *parent, const int32_t *pinv, const int32_t *leftmost, int32_t m2,
+                  csx_handle_t *V, csx_handle_t *R, double *beta, int *done);
 /* The same factorisation on the device for a matrix that is a batch of small independent blocks (many connected
  * components of at most 96 rows, found on the device): one workgroup per block, dense in LDS, the reference's
  * pivot rule.  *done = 0 when the matrix is not of that shape (or has duplicate entries): use csx_lu_host.

@@ -61,3 +61,68 @@ def test_qrsol_solver_matches_list_level_qrsol(cs, name):
     assert F.solve(one) is True
     ref = B[:, 0].tolist()
     assert cs.cs_qrsol(0, A, ref) is True and one[:n] == ref[:n]
+
+
+def _qr_both_ways(cs, n, Ap, Ai, Ax):
+    """cs_qr through the device block path (pinned input) and through the host C++ code (csx_qr_host), same analysis"""
+    import _csx
+    A = cs.cs_pin(_host_cs(cs, n, n, Ap, Ai, Ax))
+    S = cs.cs_sqr(0, A, True)
+    assert S is not None and S.m2 == n
+    N = cs.cs_qr(A, S)
+    assert N is not None and N.L._lazy                                  # it came from csx_qr_blocks
+    parent, pinv, leftmost = _csx.i32(S.parent), _csx.i32(S.pinv), _csx.i32(S.leftmost)
+    vcap, rcap = max(int(S.lnz), 1), max(int(S.unz), 1)
+    Vp, Rp = np.zeros(n + 1, np.int32), np.zeros(n + 1, np.int32)
+    Vi, Ri = np.zeros(vcap, np.int32), np.zeros(rcap, np.int32)
+    Vx, Rx, beta = np.zeros(vcap), np.zeros(rcap), np.zeros(n)
+    st = _csx.load().csx_qr_host(n, n, n, _csx.pi(Ap), _csx.pi(Ai), _csx.pd(Ax), None, _csx.pi(parent), _csx.pi(pinv),
+                                 _csx.pi(leftmost), vcap, rcap, _csx.pi(Vp), _csx.pi(Vi), _csx.pd(Vx), _csx.pi(Rp),
+                                 _csx.pi(Ri), _csx.pd(Rx), _csx.pd(beta))
+    assert st == 0
+    vnz, rnz = int(Vp[n]), int(Rp[n])
+    assert N.L.p == Vp.tolist() and N.L.i[:vnz] == Vi[:vnz].tolist()
+    assert N.U.p == Rp.tolist() and N.U.i[:rnz] == Ri[:rnz].tolist()
+    assert np.asarray(N.L.x[:vnz]).tobytes() == Vx[:vnz].tobytes()
+    assert np.asarray(N.U.x[:rnz]).tobytes() == Rx[:rnz].tobytes()
+    assert np.asarray(N.B).tobytes() == beta.tobytes()
+    return A
+
+
+def test_qr_blocks_on_W_bit_identical_to_host_code(cs):
+    """cs_qr for a batch of independent blocks on the device (csx_qr_blocks): W of BASELINE config 3, 200 blocks of
+    west0067; V, R and beta equal the host C++ code's to the bit, and cs_qrsol on it solves the system."""
+    import c_oracle as CO
+    from test_gpu_configs import _w_matrix
+    n, Ap, Ai, Ax = _w_matrix(200)
+    A = _qr_both_ways(cs, n, Ap, Ai, Ax)
+    b = 1.0 + np.arange(n) / n
+    x = b.tolist()
+    assert cs.cs_qrsol(0, A, x) is True
+    res = CO.gaxpy(n, n, Ap, Ai, Ax, np.asarray(x), -b)
+    norm1 = float(np.max(np.add.reduceat(np.abs(Ax), Ap[:-1])))
+    assert np.max(np.abs(res)) <= 1e-11 * (norm1 * np.max(np.abs(x)) + np.max(np.abs(b)))
+
+
+def test_qr_blocks_random_blocks(cs):
+    """Blocks of mixed sizes, interleaved indices, structurally nonsingular (a cyclic off-diagonal keeps m2 == m)."""
+    rng = np.random.default_rng(23)
+    sizes = rng.integers(1, 50, size=130)
+    n = int(sizes.sum())
+    perm = rng.permutation(n)
+    rows, cols, vals = [], [], []
+    base = 0
+    for m in sizes.tolist():
+        mem = np.sort(perm[base:base + m])
+        D = rng.uniform(-1, 1, (m, m)) * (rng.random((m, m)) < 0.25)
+        D[np.arange(m), np.arange(m)] = rng.uniform(0.5, 1.5, m)
+        for a in range(m):
+            D[a, (a + 1) % m] += 0.7
+        r, c = np.nonzero(D)
+        rows.append(mem[r]); cols.append(mem[c]); vals.append(D[r, c])
+        base += m
+    r, c, v = np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
+    order = np.lexsort((r, c))
+    r, c, v = r[order], c[order], v[order]
+    Ap = np.concatenate([[0], np.cumsum(np.bincount(c, minlength=n))]).astype(np.int32)
+    _qr_both_ways(cs, n, Ap, r.astype(np.int32), v.astype(np.float64))
