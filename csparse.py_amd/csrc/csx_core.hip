@@ -213,6 +213,10 @@ void free_csc(Csc *A) {
     }
     free_gather(A->rows);
     free_tiled(A->tiled);
+    if (A->house) {
+        dfree(A->house->cols);
+        delete A->house;
+    }
     delete A;
 }
 

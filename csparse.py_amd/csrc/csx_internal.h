@@ -74,6 +74,14 @@ struct TiledPlan {
     uint32_t *tile_base = nullptr; // [ngroups * 4] slab-local column of the first entry of each 64-entry run
 };
 
+// Order in which the reflections of a matrix of Householder vectors can be applied in parallel (csx_qr.hip):
+// reflections of one level touch disjoint rows.
+struct HouseLevels {
+    int32_t nlevels = 0;
+    std::vector<int32_t> ptr;      // host: [nlevels + 1] into cols
+    int32_t *cols = nullptr;       // device: columns ordered by level, ascending inside a level
+};
+
 struct Csc {
     int32_t m = 0, n = 0, nnz = 0;
     int32_t *p = nullptr;
@@ -83,6 +91,7 @@ struct Csc {
     // cached plans (built on demand, freed with the matrix)
     Gather *rows = nullptr;   // stable transpose = rows of A in ascending column order
     TiledPlan *tiled = nullptr;
+    HouseLevels *house = nullptr;   // pattern only: survives csx_csc_invalidate (values are read live)
 };
 
 struct Vec {

@@ -102,6 +102,15 @@ def test_qr_blocks_on_W_bit_identical_to_host_code(cs):
     res = CO.gaxpy(n, n, Ap, Ai, Ax, np.asarray(x), -b)
     norm1 = float(np.max(np.add.reduceat(np.abs(Ax), Ap[:-1])))
     assert np.max(np.abs(res)) <= 1e-11 * (norm1 * np.max(np.abs(x)) + np.max(np.abs(b)))
+    # the device solve sequence (reflections applied level by level: those of a level touch disjoint rows) gives the
+    # bits of the list-level cs_qrsol (reflections one after the other on the host) for every right-hand side
+    rng = np.random.default_rng(5)
+    B = np.column_stack([b] + [rng.uniform(-1, 1, n) for _ in range(2)])
+    X = cs.qrsol_factor(A).solve(cs.dvec(B)).numpy().reshape(n, 3)
+    assert X[:, 0].tobytes() == np.asarray(x).tobytes()
+    for r in (1, 2):
+        y = B[:, r].tolist()
+        assert cs.cs_qrsol(0, A, y) is True and X[:, r].tobytes() == np.asarray(y).tobytes()
 
 
 def test_qr_blocks_random_blocks(cs):

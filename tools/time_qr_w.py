@@ -26,3 +26,11 @@ st = _csx.load().csx_qr_host(n, n, n, _csx.pi(Ap), _csx.pi(Ai), _csx.pd(Ax), Non
 t_host = time.perf_counter() - t0
 print({"n": n, "nnz_V": int(Vp[n]), "nnz_R": int(Rp[n]), "cs_sqr_python_s": round(t_sqr, 3), "cs_qr_device_ms": round(t_dev * 1e3, 2),
        "cs_qr_host_cpp_ms": round(t_host * 1e3, 2), "same_beta": bool(np.asarray(N.B).tobytes() == beta.tobytes())})
+F = cs.qrsol_factor(A)
+B = np.repeat((1.0 + np.arange(n) / n)[:, None], 64, axis=1)
+X = F.solve(cs.dvec(B)); _csx.sync()
+t0 = time.perf_counter(); X = F.solve(cs.dvec(B)); _csx.sync(); t_solve = time.perf_counter() - t0
+Xq = cs.dvec(n, 64)
+with _csx.Timer() as tm:
+    cs.apply_q(F.factors, Xq, True)
+print({"qrsol_solve_64rhs_ms": round(t_solve * 1e3, 2), "apply_q_64rhs_ms": round(tm.ms, 2)})
