@@ -1153,121 +1153,6 @@ def cs_post(parent, n):
     return post
 
 
-def _colcounts_ata(A, parent, post):
-    """Column counts of chol(A'A) (csparse.py:703-764 with :677-700): rows of A are grouped by the
-    postorder rank of their leftmost column, then the skeleton/leaf counting runs over those rows."""
-    m, n = A.m, A.n
-    AT = cs_transpose(A, False)
-    ATp, ATi = AT.p, AT.i
-    rank = [0] * n
-    for k in range(n):
-        rank[post[k]] = k
-    head = [-1] * (n + 1)
-    nxt = [-1] * m
-    for i in range(m):
-        k = n
-        for p in range(ATp[i], ATp[i + 1]):
-            k = min(k, rank[ATi[p]])
-        nxt[i] = head[k]
-        head[k] = i
-    delta = [0] * n
-    first = [-1] * n
-    maxfirst = [-1] * n
-    prevleaf = [-1] * n
-    for k in range(n):
-        j = post[k]
-        delta[j] = 1 if first[j] == -1 else 0
-        while j != -1 and first[j] == -1:
-            first[j] = k
-            j = parent[j]
-    anc = list(range(n))
-    for k in range(n):
-        j = post[k]
-        if parent[j] != -1:
-            delta[parent[j]] -= 1
-        J = head[k]
-        while J != -1:
-            for p in range(ATp[J], ATp[J + 1]):
-                i = ATi[p]
-                if i <= j or first[j] <= maxfirst[i]:
-                    continue
-                maxfirst[i] = first[j]
-                jprev = prevleaf[i]
-                prevleaf[i] = j
-                delta[j] += 1
-                if jprev != -1:
-                    q = jprev
-                    while q != anc[q]:
-                        q = anc[q]
-                    s = jprev
-                    while s != q:
-                        sp = anc[s]
-                        anc[s] = q
-                        s = sp
-                    delta[q] -= 1
-            J = nxt[J]
-        if parent[j] != -1:
-            anc[j] = parent[j]
-    for j in range(n):
-        if parent[j] != -1:
-            delta[parent[j]] += delta[j]
-    return delta
-
-
-def _vcount(A, S):
-    """nnz(V), the row permutation pinv, leftmost[] and m2 for QR (csparse.py:2118-2184).  Rows left
-    without a pivot are numbered from n upwards, as in CSparse; the reference's port restarts at
-    n - 1, which collides for m > n."""
-    m, n = A.m, A.n
-    parent = S.parent
-    pinv = [-1] * (m + n)
-    leftmost = [-1] * m
-    for k in range(n - 1, -1, -1):
-        for p in range(A.p[k], A.p[k + 1]):
-            leftmost[A.i[p]] = k
-    head = [-1] * n
-    tail = [-1] * n
-    count = [0] * n
-    nxt = [-1] * m
-    for i in range(m - 1, -1, -1):
-        k = leftmost[i]
-        if k == -1:
-            continue
-        if count[k] == 0:
-            tail[k] = i
-        count[k] += 1
-        nxt[i] = head[k]
-        head[k] = i
-    S.lnz = 0
-    S.m2 = m
-    for k in range(n):
-        i = head[k]
-        S.lnz += 1
-        if i < 0:
-            i = S.m2
-            S.m2 += 1
-        pinv[i] = k
-        count[k] -= 1
-        if count[k] <= 0:
-            continue
-        S.lnz += count[k]
-        pa = parent[k]
-        if pa != -1:
-            if count[pa] == 0:
-                tail[pa] = tail[k]
-            nxt[tail[k]] = head[pa]
-            head[pa] = nxt[i]
-            count[pa] += count[k]
-    k = n
-    for i in range(m):
-        if pinv[i] < 0:
-            pinv[i] = k
-            k += 1
-    S.pinv = pinv
-    S.leftmost = leftmost
-    return True
-
-
 def cs_sqr(order, A, qr):  # noqa: F811  (extends the LU-only version above)
     """Symbolic ordering and analysis for QR or LU (csparse.py:2187-2217), natural ordering."""
     if not CS_CSC(A) or order != 0:
@@ -1279,11 +1164,22 @@ def cs_sqr(order, A, qr):  # noqa: F811  (extends the LU-only version above)
     if not qr:
         S.unz = S.lnz = 4 * A.p[n] + n
         return S
-    S.parent = cs_etree(A, True)
-    post = cs_post(S.parent, n)
-    S.cp = _colcounts_ata(A, S.parent, post)
-    _vcount(A, S)
-    S.unz = sum(S.cp)
+    # column elimination tree, column counts of R, cs_vcount (leftmost, pinv, m2, nnz V): host C++ (csx_sqr_host)
+    m = A.m
+    Ap = _csx.i32(A.p[:n + 1])
+    nnz = int(Ap[n])
+    Ai = _csx.i32(A.i[:nnz]) if nnz else np.zeros(1, np.int32)
+    parent, cp = np.empty(max(n, 1), np.int32), np.empty(max(n, 1), np.int32)
+    pinv, leftmost = np.empty(max(m + n, 1), np.int32), np.empty(max(m, 1), np.int32)
+    m2, vnz, rnz = _csx.C.c_int32(0), _csx.C.c_int64(0), _csx.C.c_int64(0)
+    st = _csx.load().csx_sqr_host(m, n, _csx.pi(Ap), _csx.pi(Ai), _csx.pi(parent), _csx.pi(cp), _csx.pi(pinv),
+                                  _csx.pi(leftmost), m2, vnz, rnz)
+    if st == _csx.EINVAL:
+        raise IndexError("list index out of range")
+    _csx.check(st, "csx_sqr_host")
+    S.parent, S.cp = parent[:n].tolist(), cp[:n].tolist()
+    S.pinv, S.leftmost = pinv[:m + n].tolist(), leftmost[:m].tolist()
+    S.m2, S.lnz, S.unz = int(m2.value), int(vnz.value), int(rnz.value)
     return S
 
 

@@ -518,3 +518,157 @@ extern "C" int csx_qr_apply_host(int32_t n, const int32_t *Vp, const int32_t *Vi
     }
     return CSX_OK;
 }
+
+// cs_sqr for QR with the natural column order (csparse.py:2187-2217): the column elimination tree (cs_etree of A'A,
+// :1136-1169), its postorder (:1711-1742), the column counts of R = chol(A'A) (cs_counts with ata, :703-764 and
+// :677-700) and cs_vcount (:2118-2184: leftmost[], the row permutation pinv, the rows of V, m2 with the
+// fictitious rows of a structurally rank-deficient A).  Written from the algorithms; the same results as the
+// Python versions in csparse.py, which stay as the list-level functions cs_etree / cs_post.
+// parent, cp: n entries; pinv: m + n; leftmost: m.
+extern "C" int csx_sqr_host(int32_t m, int32_t n, const int32_t *Ap, const int32_t *Ai, int32_t *parent, int32_t *cp,
+                            int32_t *pinv, int32_t *leftmost, int32_t *m2_out, int64_t *vnz_out, int64_t *rnz_out) {
+    if (m < 0 || n < 0 || !Ap || !Ai || !parent || !cp || !pinv || !leftmost || !m2_out || !vnz_out || !rnz_out)
+        return CSX_EINVAL;
+    const int64_t nnz = Ap[n];
+    for (int64_t p = 0; p < nnz; p++)
+        if (Ai[p] < 0 || Ai[p] >= m) return CSX_EINVAL;
+    // ---- column elimination tree: the tree of A'A without forming it (a row links the columns it touches) ----
+    {
+        std::vector<int32_t> anc((size_t)n, -1), prev((size_t)m, -1);
+        for (int32_t k = 0; k < n; k++) {
+            parent[k] = -1;
+            for (int32_t p = Ap[k]; p < Ap[k + 1]; p++) {
+                int32_t i = prev[(size_t)Ai[p]];
+                while (i != -1 && i < k) {
+                    const int32_t up = anc[(size_t)i];
+                    anc[(size_t)i] = k;
+                    if (up == -1) parent[i] = k;
+                    i = up;
+                }
+                prev[(size_t)Ai[p]] = k;
+            }
+        }
+    }
+    // ---- postorder (children in ascending order, roots in ascending order) ----
+    std::vector<int32_t> post;
+    post.reserve((size_t)n);
+    {
+        std::vector<int32_t> first_child((size_t)n, -1), sibling((size_t)n, -1), stack;
+        for (int32_t j = n - 1; j >= 0; j--)
+            if (parent[j] != -1) {
+                sibling[(size_t)j] = first_child[(size_t)parent[j]];
+                first_child[(size_t)parent[j]] = j;
+            }
+        for (int32_t root = 0; root < n; root++) {
+            if (parent[root] != -1) continue;
+            stack.assign(1, root);
+            while (!stack.empty()) {
+                const int32_t top = stack.back();
+                const int32_t c = first_child[(size_t)top];
+                if (c == -1) {
+                    post.push_back(top);
+                    stack.pop_back();
+                } else {
+                    first_child[(size_t)top] = sibling[(size_t)c];
+                    stack.push_back(c);
+                }
+            }
+        }
+    }
+    // ---- rows of A (pattern of A'), by a counting sort: row i lists its columns in ascending order ----
+    std::vector<int32_t> ATp((size_t)m + 1, 0), ATi((size_t)nnz);
+    for (int64_t p = 0; p < nnz; p++) ATp[(size_t)Ai[p] + 1]++;
+    for (int32_t i = 0; i < m; i++) ATp[(size_t)i + 1] += ATp[(size_t)i];
+    {
+        std::vector<int32_t> fill(ATp.begin(), ATp.end() - 1);
+        for (int32_t k = 0; k < n; k++)
+            for (int32_t p = Ap[k]; p < Ap[k + 1]; p++) ATi[(size_t)fill[(size_t)Ai[p]]++] = k;
+    }
+    // ---- column counts of chol(A'A): rows grouped by the postorder rank of their leftmost column, then the
+    //      skeleton / leaf counting over those rows ----
+    {
+        std::vector<int32_t> rank((size_t)n, 0), head((size_t)n + 1, -1), nxt((size_t)m, -1);
+        for (int32_t k = 0; k < n; k++) rank[(size_t)post[(size_t)k]] = k;
+        for (int32_t i = 0; i < m; i++) {
+            int32_t k = n;
+            for (int32_t p = ATp[(size_t)i]; p < ATp[(size_t)i + 1]; p++) k = std::min(k, rank[(size_t)ATi[(size_t)p]]);
+            nxt[(size_t)i] = head[(size_t)k];
+            head[(size_t)k] = i;
+        }
+        std::vector<int32_t> first((size_t)n, -1), maxfirst((size_t)n, -1), prevleaf((size_t)n, -1), anc((size_t)n);
+        for (int32_t k = 0; k < n; k++) {
+            int32_t j = post[(size_t)k];
+            cp[j] = first[(size_t)j] == -1 ? 1 : 0;                  // cp doubles as delta
+            while (j != -1 && first[(size_t)j] == -1) {
+                first[(size_t)j] = k;
+                j = parent[j];
+            }
+        }
+        for (int32_t j = 0; j < n; j++) anc[(size_t)j] = j;
+        for (int32_t k = 0; k < n; k++) {
+            const int32_t j = post[(size_t)k];
+            if (parent[j] != -1) cp[parent[j]]--;
+            for (int32_t J = head[(size_t)k]; J != -1; J = nxt[(size_t)J]) {
+                for (int32_t p = ATp[(size_t)J]; p < ATp[(size_t)J + 1]; p++) {
+                    const int32_t i = ATi[(size_t)p];
+                    if (i <= j || first[(size_t)j] <= maxfirst[(size_t)i]) continue;
+                    maxfirst[(size_t)i] = first[(size_t)j];
+                    const int32_t jprev = prevleaf[(size_t)i];
+                    prevleaf[(size_t)i] = j;
+                    cp[j]++;
+                    if (jprev != -1) {
+                        int32_t q = jprev;
+                        while (q != anc[(size_t)q]) q = anc[(size_t)q];
+                        for (int32_t s = jprev; s != q;) {
+                            const int32_t sp = anc[(size_t)s];
+                            anc[(size_t)s] = q;
+                            s = sp;
+                        }
+                        cp[q]--;
+                    }
+                }
+            }
+            if (parent[j] != -1) anc[(size_t)j] = parent[j];
+        }
+        for (int32_t j = 0; j < n; j++)
+            if (parent[j] != -1) cp[parent[j]] += cp[j];
+    }
+    int64_t rnz = 0;
+    for (int32_t j = 0; j < n; j++) rnz += cp[j];
+    // ---- cs_vcount: leftmost column of every row, rows handed to the columns along the tree, pinv, m2, nnz(V) ----
+    for (int32_t i = 0; i < m + n; i++) pinv[i] = -1;
+    for (int32_t i = 0; i < m; i++) leftmost[i] = -1;
+    for (int32_t k = n - 1; k >= 0; k--)
+        for (int32_t p = Ap[k]; p < Ap[k + 1]; p++) leftmost[Ai[p]] = k;
+    std::vector<int32_t> head((size_t)n, -1), tail((size_t)n, -1), count((size_t)n, 0), nxt((size_t)m, -1);
+    for (int32_t i = m - 1; i >= 0; i--) {
+        const int32_t k = leftmost[i];
+        if (k == -1) continue;
+        if (count[(size_t)k]++ == 0) tail[(size_t)k] = i;
+        nxt[(size_t)i] = head[(size_t)k];
+        head[(size_t)k] = i;
+    }
+    int64_t vnz = 0;
+    int32_t m2 = m;
+    for (int32_t k = 0; k < n; k++) {
+        int32_t i = head[(size_t)k];
+        vnz++;
+        if (i < 0) i = m2++;                                       // a fictitious row for a column without one
+        pinv[i] = k;
+        if (--count[(size_t)k] <= 0) continue;
+        vnz += count[(size_t)k];
+        const int32_t pa = parent[k];
+        if (pa != -1) {
+            if (count[(size_t)pa] == 0) tail[(size_t)pa] = tail[(size_t)k];
+            nxt[(size_t)tail[(size_t)k]] = head[(size_t)pa];
+            head[(size_t)pa] = nxt[(size_t)i];
+            count[(size_t)pa] += count[(size_t)k];
+        }
+    }
+    for (int32_t i = 0, k = n; i < m; i++)
+        if (pinv[i] < 0) pinv[i] = k++;
+    *m2_out = m2;
+    *vnz_out = vnz;
+    *rnz_out = rnz;
+    return CSX_OK;
+}

@@ -250,6 +250,11 @@ int csx_qr_apply_host(int32_t n, const int32_t *Vp, const int32_t *Vi, const dou
  * (n-1 .. 0); beta: device vector of V.n entries.  One lane per vector runs the reference's loops: bit-identical to
  * cs_happly called reflection by reflection on each column. */
 int csx_happly(csx_handle_t V, csx_handle_t beta, csx_handle_t X, int32_t nrhs, int transpose);
+/* cs_sqr for QR, natural column order (csparse.py:2187-2217 with cs_etree of A'A :1136-1169, cs_post :1711-1742,
+ * cs_counts :703-764, cs_vcount :2118-2184), on the host: parent and cp (column counts of R) have n entries, pinv m + n,
+ * leftmost m; *m2 = rows of V including the fictitious ones, *vnz / *rnz = entries of V / R. */
+int csx_sqr_host(int32_t m, int32_t n, const int32_t *Ap, const int32_t *Ai, int32_t *parent, int32_t *cp, int32_t *pinv,
+                 int32_t *leftmost, int32_t *m2, int64_t *vnz, int64_t *rnz);
 /* cs_qr's numeric phase on the device for a SQUARE matrix that is a batch of small independent blocks (connected
  * components of at most 96 rows, at least 64 of them), natural column order, no fictitious rows (m2 == m): one lane per
  * block runs csx_qr_host's loop.  parent / pinv / leftmost: host arrays of n entries from cs_sqr.  V, R: new device

@@ -372,7 +372,28 @@ def updown_fixture():
     return meta
 
 
+def sqr_fixture():
+    """cs_sqr(0, A, True) -- the QR analysis: column elimination tree, column counts of R, cs_vcount -- runs
+    unmodified on the square problem matrices C of the reference's tests; parent, cp, pinv, leftmost,
+    m2, lnz, unz as the reference computes them.  (Rectangular matrices with rows left without a pivot hit the
+    reference's D10 numbering and are not pinned here.)"""
+    d, meta = {}, {}
+    for name in ("t1", "bcsstk01", "west0067", "fs_183_1", "bcsstk16"):
+        T, A, C, sym = get_problem(name)
+        S = R.cs_sqr(0, C, True)
+        assert S is not None and S.m2 == C.m
+        pre = name + "_"
+        d[pre + "parent"], d[pre + "cp"] = I(S.parent[:C.n]), I(S.cp[:C.n])
+        d[pre + "pinv"], d[pre + "leftmost"] = I(S.pinv[:C.m + C.n]), I(S.leftmost[:C.m])
+        meta[name] = dict(m=C.m, n=C.n, m2=int(S.m2), lnz=int(S.lnz), unz=int(S.unz))
+    np.savez_compressed(os.path.join(OUT, "sqr_qr.npz"), **d)
+    return meta
+
+
 def main():
+    if sys.argv[1:] == ["sqr"]:
+        print(json.dumps(sqr_fixture(), indent=1))
+        return
     if sys.argv[1:] == ["updown"]:
         print(json.dumps(updown_fixture(), indent=1))
         return
@@ -388,6 +409,7 @@ def main():
     synthetic_fixture(20240601)
     meta["config2_bcsstk16"] = config2_fixture()
     meta["updown"] = updown_fixture()
+    meta["sqr_qr"] = sqr_fixture()
     with open(os.path.join(OUT, "meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)
 

@@ -58,3 +58,39 @@ def test_lu_host_singular_and_bad_input():
     T = cs.cs_spalloc(2, 2, 2, True, True)
     assert cs.cs_lusol(0, T, [1.0, 1.0], 1.0) is False and cs.cs_lusol(0, A, None, 1.0) is False
 
+
+
+@pytest.mark.parametrize("name", ["t1", "bcsstk01", "west0067", "fs_183_1", "bcsstk16"])
+def test_sqr_qr_host_matches_unmodified_reference(name, meta):
+    """cs_sqr(0, C, True) in host C++ (csx_sqr_host) against what the unmodified reference computes for the square
+    problem matrices of its own tests (tests/golden/sqr_qr.npz, oracle/gen_golden.py sqr): column elimination tree,
+    column counts of R, row permutation, leftmost columns, sizes."""
+    import csparse as cs
+    g = golden(name)
+    q = golden("sqr_qr")
+    C = unpack(cs, g, "C")
+    S = cs.cs_sqr(0, C, True)
+    mm = meta["sqr_qr"][name]
+    assert (S.m2, S.lnz, S.unz) == (mm["m2"], mm["lnz"], mm["unz"])
+    assert S.parent == q[name + "_parent"].tolist() and S.cp == q[name + "_cp"].tolist()
+    assert S.pinv[:S.m2] == q[name + "_pinv"][:S.m2].tolist()            # beyond m2 the array is unused work space
+    assert S.leftmost == q[name + "_leftmost"].tolist()
+    assert S.q is None
+
+
+def test_sqr_qr_host_rectangular_and_rank_deficient():
+    """m > n with an empty row and a column no row starts in: fictitious rows are numbered from m upwards and rows
+    without a pivot from n upwards (CSparse's numbering; the reference's port collides there)."""
+    import csparse as cs
+    #      c0 c1 c2
+    # r0 [  x  .  . ]
+    # r1 [  x  x  . ]
+    # r2 [  .  .  . ]
+    # r3 [  x  .  x ]
+    A = cs.cs_spalloc(4, 3, 5, True, False)
+    A.p, A.i, A.x = [0, 3, 4, 5], [0, 1, 3, 1, 3], [1.0, 2.0, 3.0, 4.0, 5.0]
+    S = cs.cs_sqr(0, A, True)
+    assert S.leftmost == [0, 0, -1, 0]
+    assert S.parent == [1, 2, -1]
+    assert S.m2 == 4 and sorted(S.pinv[:4]) == [0, 1, 2, 3] and S.pinv[2] == 3   # the empty row goes last
+    assert S.lnz == 3 + 2 + 1 and S.unz == 3 + 2 + 1
