@@ -192,12 +192,35 @@ def config3():
     cpu_sps_res = cpu_port("cs_spsolve", cpu_sps, float(ncpu), "columns/s", "the first %d columns of W against L" % ncpu)
     spsolve = {"columns": n, "entries_of_X": int(xn), "s": round(t_sps, 4), "columns_per_s": round(n / t_sps, 1),
                "bit_identical_to_oracle_on_sample": bool(same) if cpu_sps_res else None, "cpu_baseline": cpu_sps_res}
+    # the same system by QR: cs_sqr (host C++), cs_qr (device: one lane per block), the cs_qrsol solve sequence for a
+    # block of right-hand sides (device: permute, Q' x level by level, R \ x, permute)
+    t0 = time.perf_counter()
+    Sq = cs.cs_sqr(0, A, True)
+    t_sqr = time.perf_counter() - t0
+    cs.cs_qr(A, Sq)
+    _csx.sync()
+    t0 = time.perf_counter()
+    Nq = cs.cs_qr(A, Sq)
+    _csx.sync()
+    t_qr = time.perf_counter() - t0
+    Fq = cs.qrsol_factor(A)
+    Bq = np.repeat(b[:, None], 64, axis=1)
+    Fq.solve(cs.dvec(Bq))
+    _csx.sync()
+    t0 = time.perf_counter()
+    Xq = Fq.solve(cs.dvec(Bq))
+    _csx.sync()
+    t_qs = time.perf_counter() - t0
+    xq = Xq.numpy().reshape(n, 64)[:, 0]
+    rq = CO.gaxpy(n, n, Ap, Ai, Ax, xq, -b)
+    qr = {"cs_sqr_host_s": round(t_sqr, 4), "cs_qr_device_s": round(t_qr, 4), "device_path": bool(Nq.L._lazy),
+          "solve_64_rhs_s": round(t_qs, 4), "residual_inf": float(np.max(np.abs(rq)))}
     # residual of the whole cs_lusol sequence against A
     r = CO.gaxpy(n, n, Ap, Ai, Ax, ref_x, -b)
     return {"config": "cs_lusol solve phase on W (west0067 tiling, n=%d, nnz(A)=%d, nnz(L)+nnz(U)=%d)"
                       % (n, nb * bnnz, int(Lp[-1] + Up[-1])),
             "device_lu_s": round(t_lu, 4), "host_lu_s_one_core": round(t_lu_host, 4), "same_pivots_as_host": bool(same_pivots),
-            "components_of_L": comp.value, "results": res, "spsolve_all_columns": spsolve,
+            "components_of_L": comp.value, "results": res, "spsolve_all_columns": spsolve, "qrsol_on_the_same_system": qr,
             "residual_inf": float(np.max(np.abs(r))), "cpu_baseline": cpu}
 
 
