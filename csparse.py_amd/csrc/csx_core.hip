@@ -492,6 +492,11 @@ int csx_csc_invalidate(csx_handle_t h) {
     A->rows = nullptr;
     free_tiled(A->tiled);
     A->tiled = nullptr;
+    if (A->house) {
+        dfree(A->house->cols);
+        delete A->house;
+        A->house = nullptr;
+    }
     return CSX_OK;
 }
 

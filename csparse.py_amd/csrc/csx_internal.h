@@ -91,7 +91,7 @@ struct Csc {
     // cached plans (built on demand, freed with the matrix)
     Gather *rows = nullptr;   // stable transpose = rows of A in ascending column order
     TiledPlan *tiled = nullptr;
-    HouseLevels *house = nullptr;   // pattern only: survives csx_csc_invalidate (values are read live)
+    HouseLevels *house = nullptr;   // csx_happly's level schedule (pattern only; dropped by csx_csc_invalidate too)
 };
 
 struct Vec {
