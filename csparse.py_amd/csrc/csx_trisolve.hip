@@ -933,7 +933,7 @@ __global__ __launch_bounds__(256) void k_group_caps(int32_t ncomp, int cpw, cons
 // threads (distinct rows, each x[i] still receives its updates in ascending / descending column order), one
 // workgroup barrier per column, the next column's entries already in flight; for L' and U' (column gather) one wave
 // forms a column's products, one per lane, and lane 0 subtracts them in storage order while they rotate towards it
-// (k_tri_chain).  Bit-identical, every kind.  Right-hand sides are independent workgroups.  L' on bcsstk16: 256
+// (k_tri_colchain).  Bit-identical, every kind.  Right-hand sides are independent workgroups.  L' on bcsstk16: 256
 // threads with the products in LDS and one lane subtracting 9.0 ms; one wave lifting products out with v_readlane
 // 9.6 ms, with the v_readlane of the next eight issued ahead 7.7; products rotated by DPP 7.1; entries requested three
 // columns ahead instead of one 6.6 ms.
@@ -989,7 +989,7 @@ __device__ __forceinline__ TchCol tch_load(int32_t b, int32_t e, const int32_t *
 // The factor does not fit an XCD's L2 (bcsstk16: 7.3 MB), so a column's entries come from the memory side and take
 // about as long as a column takes to compute: they are requested THREE columns ahead (pointers four ahead).
 template <int KIND>   // CSX_TRI_LT or CSX_TRI_UT
-__global__ __launch_bounds__(64) void k_tri_chain(int32_t n, const int32_t *__restrict__ Tp, const int32_t *__restrict__ Ti,
+__global__ __launch_bounds__(64) void k_tri_colchain(int32_t n, const int32_t *__restrict__ Tp, const int32_t *__restrict__ Ti,
                                                   const double *__restrict__ Tx, double *X, int nrhs) {
     extern __shared__ __attribute__((aligned(16))) double xs[];   // n doubles
     const int lane = threadIdx.x, r = blockIdx.x;
@@ -1047,11 +1047,11 @@ __global__ __launch_bounds__(TC_THREADS) void k_tri_columns(int32_t n, const int
     const int tid = threadIdx.x, r = blockIdx.x;
     for (int32_t i = tid; i < n; i += TC_THREADS) xs[i] = X[(int64_t)i * nrhs + r];
     __syncthreads();
-    static_assert(KIND == CSX_TRI_L || KIND == CSX_TRI_U, "the gather kinds run k_tri_chain");
+    static_assert(KIND == CSX_TRI_L || KIND == CSX_TRI_U, "the gather kinds run k_tri_colchain");
     constexpr bool ASC = KIND == CSX_TRI_L;
     constexpr bool DIAG_FIRST = KIND == CSX_TRI_L;
     // A ring of four columns in registers, the loop unrolled by four so that every slot has a fixed name: a column's
-    // entries are requested three steps before they are used (see k_tri_chain), and the barrier waits for LDS only.
+    // entries are requested three steps before they are used (see k_tri_colchain), and the barrier waits for LDS only.
     auto col_at = [&](int32_t step) {   // the column of a step, clamped to the last one
         const int32_t st = step < n ? step : n - 1;
         return ASC ? st : n - 1 - st;
@@ -1696,9 +1696,9 @@ int tri_solve_raw(TriPlan *P, double *X, int32_t nrhs, bool relaxed) {
     }
 #define CSX_TCH(K)                                                                                                 \
     {                                                                                                              \
-        CSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tri_chain<K>),                               \
+        CSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tri_colchain<K>),                               \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));                \
-        hipLaunchKernelGGL(k_tri_chain<K>, dim3((unsigned)nrhs), dim3(64), (size_t)P->n * sizeof(double), s, P->n, P->Tp, \
+        hipLaunchKernelGGL(k_tri_colchain<K>, dim3((unsigned)nrhs), dim3(64), (size_t)P->n * sizeof(double), s, P->n, P->Tp, \
                            P->Ti, P->Tx, X, nrhs);                                                                 \
     }
             switch (P->kind) {
