@@ -309,6 +309,8 @@ def main():
     ysum = float(np.sum(yhead))
     assert os.environ.get("CSX_TILED_VARIANT") or (np.isfinite(ysum) and ysum > 0)
 
+    key_bytes = _csx.C.c_int(0)
+    _csx.check(lib.csx_gaxpy_plan_info(hA, None, None, key_bytes), "plan_info")
     out = {
         "metric": "cs_gaxpy achieved HBM GB/s (algorithmic bytes / time), 5M x 5M CSC, 64 nnz/col",
         "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -316,7 +318,8 @@ def main():
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "cs_gaxpy y += A x on G-rand: %d x %d CSC, %s, int32 indices, fp64 values; one "
                                "independent matrix per GPU" % (n, n, gen_words[args.gen]), "row_draw": args.gen,
-                   "n": n, "nnz": nnz, "kernel": "gaxpy_" + chosen, "algorithmic_bytes_per_step": by,
+                   "n": n, "nnz": nnz, "kernel": "gaxpy_" + chosen, "plan_key_bytes": key_bytes.value,
+                   "algorithmic_bytes_per_step": by,
                    "parallelism": "independent matrices, 1 per GPU, no data-path collective"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
