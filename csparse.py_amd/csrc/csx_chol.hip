@@ -56,7 +56,7 @@ void tri_gather_arrays(const TriPlan *P, const int32_t **ptr, const int32_t **id
 constexpr int CH_ACC = 1024;        // column entries kept in LDS per wave
 constexpr int CH_WAVES = 4;         // waves per workgroup in the column kernels
 constexpr int CH_SMALL_TREE = 512;  // trees up to this many columns go to the tree kernel
-constexpr int CH_NARROW = 8;        // levels with <= this many columns join a one-workgroup run
+constexpr int CH_NARROW = 64;       // levels with <= this many columns: one 16-wave workgroup per column (k_chol_coop)
 
 
 // ---- scatter of C = upper(P A P') into the pattern of L ------------------------------------
@@ -221,7 +221,9 @@ __global__ __launch_bounds__(64 * CC_WAVES) void k_chol_coop(const int32_t *__re
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     for (int32_t l = l0; l < l1; l++) {
         const int32_t lfirst = level_ptr[l], lcount = level_ptr[l + 1] - lfirst;
-        for (int32_t c = 0; c < lcount; c++) {
+        // the columns of a level do not depend on each other: launched over ONE level with several workgroups, each
+        // takes its share of them; launched with one workgroup over a run of levels, it walks them all
+        for (int32_t c = blockIdx.x; c < lcount; c += gridDim.x) {
             const int32_t j = cols[lfirst + c];
             const int32_t base = Lp[j], len = Lp[j + 1] - base;
             const int W = len <= CC_ACC ? min(CC_WAVES, CC_ACC / max(len, 1)) : 0;   // 0: in place, wave 0 alone
@@ -698,13 +700,16 @@ static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, c
                 l++;
                 continue;
             }
+            // a narrow level with more than one column: its columns go to as many workgroups in one launch; a run of
+            // single-column levels (a chain) is walked by one workgroup without coming back to the host
             int32_t e = l + 1;
-            while (e < nlev && F.level_ptr[(size_t)e + 1] - F.level_ptr[(size_t)e] <= CH_NARROW) e++;
+            if (cnt == 1)
+                while (e < nlev && F.level_ptr[(size_t)e + 1] - F.level_ptr[(size_t)e] == 1) e++;
             const size_t cc_lds = (size_t)CC_ACC * 12 + (n <= CC_MAP ? (size_t)n * 4 : 0) + 64;
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chol_coop), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       160 * 1024 - 256);
-            hipLaunchKernelGGL(k_chol_coop, dim3(1), dim3(64 * CC_WAVES), cc_lds, s, d_level_cols, d_level_ptr, l, e, L->p,
-                               L->i, L->x, d_rp, d_rc, d_rpos, n, d_flags + 1);
+            hipLaunchKernelGGL(k_chol_coop, dim3((unsigned)cnt), dim3(64 * CC_WAVES), cc_lds, s, d_level_cols, d_level_ptr, l, e,
+                               L->p, L->i, L->x, d_rp, d_rc, d_rpos, n, d_flags + 1);
             l = e;
         }
         if (hipGetLastError() != hipSuccess ||
