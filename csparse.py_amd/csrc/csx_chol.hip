@@ -202,6 +202,7 @@ __global__ __launch_bounds__(64 * CH_WAVES) void k_chol_level(const int32_t *__r
 // (n <= CC_MAP) replaces the binary search.  W = min(16, CC_ACC / column length); columns longer than
 // CC_ACC are updated in place by one wave.
 constexpr int CC_WAVES = 16, CC_ACC = 8192, CC_MAP = 12288, CC_Q = 8;
+constexpr int CC_RUN_MIN = 16, CC_RUN_MAX = 64;   // narrow levels are factored in two phases, 16 .. 64 levels at a time (see k_chol_coop)
 
 __device__ __forceinline__ int32_t cc_lookup(bool use_map, const int32_t *map, const int32_t *rows, int32_t len, int32_t r) {
     return use_map ? map[r] : find_row(rows, len, r);
@@ -212,15 +213,24 @@ __global__ __launch_bounds__(64 * CC_WAVES) void k_chol_coop(const int32_t *__re
                                                             const int32_t *__restrict__ Lp, const int32_t *__restrict__ Li,
                                                             double *Lx, const int32_t *__restrict__ row_ptr,
                                                             const int32_t *__restrict__ row_col,
-                                                            const int32_t *__restrict__ row_pos, int32_t n, int *notspd) {
+                                                            const int32_t *__restrict__ row_pos, int32_t n, int *notspd,
+                                                            const int32_t *__restrict__ col_level, int mode,
+                                                            int32_t lf) {
+    // mode 0: every update of a column, then pivot and scaling.  A long RUN of narrow levels lf .. (the separators at
+    // the top of a nested-dissection tree: thousands of columns, a few per level) is done in two phases instead.
+    // mode 1, one launch, one workgroup per column of the whole run (levels l0 .. l1-1): the updates that come from
+    // columns BELOW the run (level < lf) -- all final before the run starts, so every column of the run takes them at
+    // the same time -- and the partly updated column is stored.  mode 2, level after level as in mode 0: the updates
+    // from INSIDE the run (level >= lf), then pivot and scaling.  col_level[k] = level of column k, -1 off the list.
     extern __shared__ __attribute__((aligned(16))) unsigned char cc_smem[];
     double *part = reinterpret_cast<double *>(cc_smem);             // W partial columns of `len` doubles
     int32_t *acc_r = reinterpret_cast<int32_t *>(part + CC_ACC);    // the column's row indices (<= CC_ACC kept)
     int32_t *map = acc_r + CC_ACC;
     const bool use_map = n <= CC_MAP;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    for (int32_t l = l0; l < l1; l++) {
-        const int32_t lfirst = level_ptr[l], lcount = level_ptr[l + 1] - lfirst;
+    for (int32_t l = l0; l < (mode == 1 ? l0 + 1 : l1); l++) {
+        // mode 1: the run's columns are one contiguous piece of the level list, a workgroup each
+        const int32_t lfirst = level_ptr[l], lcount = mode == 1 ? level_ptr[l1] - lfirst : level_ptr[l + 1] - lfirst;
         // the columns of a level do not depend on each other: launched over ONE level with several workgroups, each
         // takes its share of them; launched with one workgroup over a run of levels, it walks them all
         for (int32_t c = blockIdx.x; c < lcount; c += gridDim.x) {
@@ -247,9 +257,12 @@ __global__ __launch_bounds__(64 * CC_WAVES) void k_chol_coop(const int32_t *__re
                         const int32_t qu = q0 + Wq * lane;
                         if (lane < CC_Q && qu < qe) {
                             const int32_t kq = row_col[qu];
-                            posq = row_pos[qu];
-                            kendq = Lp[kq + 1];
-                            ljkq = Lx[posq];
+                            const bool inside = mode != 0 && col_level[kq] >= lf;
+                            if (mode == 0 || (mode == 1) != inside) {   // mode 1 takes the outside, mode 2 the inside
+                                posq = row_pos[qu];
+                                kendq = Lp[kq + 1];
+                                ljkq = Lx[posq];
+                            }
                         }
                     }
                     int32_t pos_[CC_Q], kend_[CC_Q], r_[CC_Q];
@@ -295,6 +308,12 @@ __global__ __launch_bounds__(64 * CC_WAVES) void k_chol_coop(const int32_t *__re
                 else if (t == 0) part[0] = v;
             }
             __syncthreads();
+            if (mode == 1) {                                  // partly updated column: the inside pass finishes it
+                if (W)
+                    for (int32_t t = tid; t < len; t += 64 * CC_WAVES) Lx[base + t] = part[t];
+                __syncthreads();
+                continue;
+            }
             const double d = part[0];
             if (d <= 0.0 && tid == 0) atomicMin(notspd, j);  // csparse.py:612: not positive definite
             const double ljj = sqrt(d);
@@ -651,6 +670,13 @@ static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, c
     if (st == CSX_OK) st = upload(&d_small_cols, F.small_cols);
     if (st == CSX_OK) st = upload(&d_level_cols, F.level_cols);
     if (st == CSX_OK) st = upload(&d_level_ptr, F.level_ptr);
+    int32_t *d_col_level = nullptr;
+    if (st == CSX_OK && !F.level_cols.empty()) {
+        std::vector<int32_t> col_level((size_t)n, -1);
+        for (size_t lv = 0; lv + 1 < F.level_ptr.size(); lv++)
+            for (int32_t q = F.level_ptr[lv]; q < F.level_ptr[lv + 1]; q++) col_level[(size_t)F.level_cols[(size_t)q]] = (int32_t)lv;
+        st = upload(&d_col_level, col_level);
+    }
     int hflags[2] = {0, 0x7fffffff};
     if (st == CSX_OK) {
         (void)hipMemsetAsync(d_win, 0xff, (size_t)L->nnz * sizeof(int32_t), s);
@@ -702,14 +728,27 @@ static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, c
             }
             // a narrow level with more than one column: its columns go to as many workgroups in one launch; a run of
             // single-column levels (a chain) is walked by one workgroup without coming back to the host
-            int32_t e = l + 1;
-            if (cnt == 1)
-                while (e < nlev && F.level_ptr[(size_t)e + 1] - F.level_ptr[(size_t)e] == 1) e++;
             const size_t cc_lds = (size_t)CC_ACC * 12 + (n <= CC_MAP ? (size_t)n * 4 : 0) + 64;
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chol_coop), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       160 * 1024 - 256);
-            hipLaunchKernelGGL(k_chol_coop, dim3((unsigned)cnt), dim3(64 * CC_WAVES), cc_lds, s, d_level_cols, d_level_ptr, l, e,
-                               L->p, L->i, L->x, d_rp, d_rc, d_rpos, n, d_flags + 1);
+            auto width = [&](int32_t lv) { return F.level_ptr[(size_t)lv + 1] - F.level_ptr[(size_t)lv]; };
+            int32_t e = l + 1;                       // the run of narrow levels, at most CC_RUN_MAX of them at a time:
+            while (e < nlev && e - l < CC_RUN_MAX && width(e) <= CH_NARROW) e++;   // the shorter, the less is left inside
+            const bool two_phase = e - l >= CC_RUN_MIN;
+            if (two_phase)                           // updates from below the run, for all of its columns at once
+                hipLaunchKernelGGL(k_chol_coop, dim3((unsigned)(F.level_ptr[(size_t)e] - F.level_ptr[(size_t)l])),
+                                   dim3(64 * CC_WAVES), cc_lds, s, d_level_cols, d_level_ptr, l, e, L->p, L->i, L->x, d_rp, d_rc,
+                                   d_rpos, n, d_flags + 1, d_col_level, 1, l);
+            for (int32_t a = l; a < e;) {
+                // a level with several columns: a workgroup each in one launch; single-column levels in a row (a chain):
+                // one workgroup walks them without coming back to the host
+                int32_t b = a + 1;
+                if (width(a) == 1)
+                    while (b < e && width(b) == 1) b++;
+                hipLaunchKernelGGL(k_chol_coop, dim3((unsigned)width(a)), dim3(64 * CC_WAVES), cc_lds, s, d_level_cols, d_level_ptr,
+                                   a, b, L->p, L->i, L->x, d_rp, d_rc, d_rpos, n, d_flags + 1, d_col_level, two_phase ? 2 : 0, l);
+                a = b;
+            }
             l = e;
         }
         if (hipGetLastError() != hipSuccess ||
@@ -731,6 +770,7 @@ static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, c
     dfree(d_small_cols);
     dfree(d_level_cols);
     dfree(d_level_ptr);
+    dfree(d_col_level);
     if (st != CSX_OK) return st;
     if (hflags[0]) return CSX_EINVAL;                 // S.cp / S.parent do not belong to A
     if (hflags[1] != 0x7fffffff) return CSX_ENOTSPD;  // some pivot d <= 0

@@ -30,3 +30,10 @@ for order in orders:
     r = A @ np.asarray(x) - b
     print({"grid": g, "n": n, "order": order, "lnz": int(S.lnz), "schol_s": round(t1 - t0, 3), "chol_s": round(t2 - t1, 3),
            "cholsol_all_s": round(t4 - t3, 3), "residual_inf": float(np.max(np.abs(r)))}, flush=True)
+    for exact in (True, False):
+        F = cs.cholsol_factor(M, order, exact=exact)
+        for k in (1, 64):
+            B = cs.dvec(np.ones((n, k)) if k > 1 else np.ones(n))
+            F.solve(B); _csx.sync()
+            t0 = time.perf_counter(); F.solve(B); _csx.sync(); dt = time.perf_counter() - t0
+            print({"order": order, "exact": exact, "nrhs": k, "solve_s": round(dt, 4)}, flush=True)
