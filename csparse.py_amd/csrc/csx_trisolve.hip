@@ -940,6 +940,7 @@ __global__ __launch_bounds__(256) void k_group_caps(int32_t ncomp, int cpw, cons
 #pragma clang fp contract(off)
 constexpr int TC_THREADS = 256;
 constexpr int TC_MAX_N = 15360;
+constexpr int TRW_MAX_RHS = 4, TRW_MIN_ROW = 24;   // a wave per row: at most so many right-hand sides, rows at least so long on average
 
 // The gather kinds (L', U') on ONE wave: every lane forms one product of the column, then lane 0 subtracts them in
 // storage order while the products rotate towards it through the wave (tch_chain) -- no barrier and no LDS round trip
@@ -1039,6 +1040,61 @@ __global__ __launch_bounds__(64) void k_tri_colchain(int32_t n, const int32_t *_
         }
     }
 }
+// ---- level schedule, ONE WAVE PER ROW (few right-hand sides, long rows) ---------------------------------------
+// The level kernels above give a thread to every (row, right-hand side): with one right-hand side and rows of
+// thousands of terms (the separator rows of a nested-dissection factor) a handful of threads walk them alone.  Here a
+// wave takes a row: the lanes fetch 64 terms at a time and multiply them by their x (all final: earlier levels), and
+// lane 0 subtracts the products in the reference's order as in k_tri_colchain -- the same bits as solve_one.
+__device__ __forceinline__ void solve_row_wave(int32_t row, int nrhs, const int32_t *__restrict__ ptr,
+                                               const int32_t *__restrict__ idx, const double *__restrict__ val,
+                                               const double *__restrict__ diag, int skip_first, int skip_last, double *X,
+                                               int lane) {
+    const int32_t b = ptr[row] + skip_first, e = ptr[row + 1] - skip_last;
+    const double dg = diag[row];
+    for (int r = 0; r < nrhs; r++) {
+        double acc = X[(int64_t)row * nrhs + r];
+        int32_t q = b + lane;
+        int32_t ci = q < e ? idx[q] : 0;
+        double cv = q < e ? val[q] : 0.0;
+        for (int32_t q0 = b; q0 < e; q0 += 64) {
+            const double xv = X[(int64_t)ci * nrhs + r];
+            const int32_t qn = q0 + 64 + lane;             // the next 64 terms ride behind the gathers
+            const int32_t cin = qn < e ? idx[qn] : 0;
+            const double cvn = qn < e ? val[qn] : 0.0;
+            const double p = q0 + lane < e ? cv * xv : 0.0;
+            acc = tch_chain(acc, p, e - q0);
+            ci = cin;
+            cv = cvn;
+        }
+        if (lane == 0) X[(int64_t)row * nrhs + r] = acc / dg;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_tri_level_rows(const int32_t *__restrict__ order, int32_t first, int32_t count,
+                                                        const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx,
+                                                        const double *__restrict__ val, const double *__restrict__ diag,
+                                                        int skip_first, int skip_last, double *X, int nrhs) {
+    const int lane = threadIdx.x & 63;
+    const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (w >= count) return;
+    solve_row_wave(order[first + w], nrhs, ptr, idx, val, diag, skip_first, skip_last, X, lane);
+}
+
+__global__ __launch_bounds__(1024) void k_tri_levels_rows_one_wg(const int32_t *__restrict__ order,
+                                                                 const int32_t *__restrict__ level_ptr, int32_t l0,
+                                                                 int32_t l1, const int32_t *__restrict__ ptr,
+                                                                 const int32_t *__restrict__ idx,
+                                                                 const double *__restrict__ val,
+                                                                 const double *__restrict__ diag, int skip_first,
+                                                                 int skip_last, double *X, int nrhs) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int32_t l = l0; l < l1; l++) {
+        const int32_t first = level_ptr[l], count = level_ptr[l + 1] - first;
+        for (int32_t t = w; t < count; t += 16) solve_row_wave(order[first + t], nrhs, ptr, idx, val, diag, skip_first, skip_last, X, lane);
+        __syncthreads();  // workgroup-scope release/acquire: the next level reads these x
+    }
+}
+
 template <int KIND>
 __global__ __launch_bounds__(TC_THREADS) void k_tri_columns(int32_t n, const int32_t *__restrict__ Tp,
                                                             const int32_t *__restrict__ Ti, const double *__restrict__ Tx,
@@ -1717,8 +1773,19 @@ int tri_solve_raw(TriPlan *P, double *X, int32_t nrhs, bool relaxed) {
     relaxed = relaxed && !P->chain_ok;
     make_segments(P, nrhs);
     const bool no_chain = !ctx().opt.tri_chain_walker;
+    // few right-hand sides and long rows: a wave per row (k_tri_level_rows) instead of a thread per (row, right-hand side)
+    const bool by_rows = nrhs <= TRW_MAX_RHS && P->n > 0 && (int64_t)P->gnnz >= (int64_t)TRW_MIN_ROW * P->n &&
+                         ctx().opt.tri_row_waves;
     for (const Segment &g : P->segs) {
-        if (g.one_wg && !no_chain && (P->chain_ok || relaxed)) {
+        if (by_rows && g.one_wg) {
+            hipLaunchKernelGGL(k_tri_levels_rows_one_wg, dim3(1), dim3(1024), 0, s, P->order, P->level_ptr, g.l0, g.l1, P->ptr,
+                               P->idx, P->val, P->diag, P->skip_first, P->skip_last, X, nrhs);
+        } else if (by_rows) {
+            const int32_t first = P->level_ptr_h[(size_t)g.l0];
+            const int32_t count = P->level_ptr_h[(size_t)g.l0 + 1] - first;
+            hipLaunchKernelGGL(k_tri_level_rows, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, s, P->order, first, count,
+                               P->ptr, P->idx, P->val, P->diag, P->skip_first, P->skip_last, X, nrhs);
+        } else if (g.one_wg && !no_chain && (P->chain_ok || relaxed)) {
             hipLaunchKernelGGL(k_tri_chain, dim3(1), dim3(64 * CHB), 0, s, P->order, P->level_ptr_h[(size_t)g.l0],
                                P->level_ptr_h[(size_t)g.l1], P->ptr, P->idx, P->val, P->diag, P->skip_first, P->skip_last,
                                P->npre, P->nin, P->tslot, X, nrhs, relaxed ? 1 : 0);
