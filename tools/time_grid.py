@@ -10,6 +10,7 @@ import _csx, csparse as cs
 _csx.init(0)
 g = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 orders = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 1]
+only_rhs = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 n = g * g
 T = sp.diags([-1, 2, -1], [-1, 0, 1], shape=(g, g))
 A = (sp.kron(sp.identity(g), T) + sp.kron(T, sp.identity(g)) + 0.01 * sp.identity(n)).tocsc()
@@ -33,6 +34,8 @@ for order in orders:
     for exact in (True, False):
         F = cs.cholsol_factor(M, order, exact=exact)
         for k in (1, 64):
+            if only_rhs and k != only_rhs:
+                continue
             B = cs.dvec(np.ones((n, k)) if k > 1 else np.ones(n))
             F.solve(B); _csx.sync()
             t0 = time.perf_counter(); F.solve(B); _csx.sync(); dt = time.perf_counter() - t0
