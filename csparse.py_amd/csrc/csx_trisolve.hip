@@ -1557,7 +1557,7 @@ __global__ __launch_bounds__(256) void k_lv_chain_tables(int32_t n, const uint32
 }
 
 constexpr int64_t LV_DEVICE_MIN_TERMS = 4 << 20;   // below this the copy is small and deep chains favour the host pass
-constexpr int LV_MAX_ROUNDS = 4096;
+constexpr int LV_MAX_ROUNDS = 512;     // a round costs ~80 us whatever it finds: deeper than this, one sequential host pass wins
 
 // *done = false: not attempted or gave up (too deep) -> the host pass runs instead
 static int schedule_on_device(TriPlan *P, bool *done) {
