@@ -156,6 +156,42 @@ def cpu_baseline_cholsol(nblocks, bs, budget_s, lnz_full):
                              "chol_s": tc_factor}}
 
 
+class Deadline(object):
+    """A bound on everything that runs after the headline measurement.  The legs reported beside the headline
+    (G-spd, cholsol, the exchange legs, the column-sharded SpMV) are collectives at N > 1: a rank that fails inside
+    one leaves the others waiting.  The headline must not be lost to that, so after `seconds` rank 0 prints the
+    JSON line as it stood when the last leg completed (with "extras_cut_short_after_s") and every rank exits 0."""
+
+    def __init__(self, seconds, rank):
+        import threading
+        self.line, self.printed, self.rank, self.seconds = None, False, rank, seconds
+        self.lock = threading.Lock()
+        self.timer = threading.Timer(seconds + (0.0 if rank == 0 else 5.0), self.fire)
+        self.timer.daemon = True
+
+    def arm(self, out):
+        self.checkpoint(out)
+        if self.seconds > 0:
+            self.timer.start()
+
+    def checkpoint(self, out):
+        with self.lock:
+            self.line = json.dumps(dict(out, extras_cut_short_after_s=self.seconds))
+
+    def emit(self, out):
+        with self.lock:
+            if self.rank == 0 and not self.printed:
+                print(json.dumps(out), flush=True)
+            self.printed = True
+
+    def fire(self):
+        with self.lock:
+            if self.rank == 0 and not self.printed and self.line:
+                sys.stdout.write(self.line + "\n")
+                sys.stdout.flush()
+            os._exit(0)
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` run directly: start N ranks of this same command line, one per GPU, with
     the torch.distributed.run environment (rendezvous on 127.0.0.1), and return the worst exit code.  The
@@ -228,6 +264,8 @@ def main():
                          "row per stratum of n/per_col rows (round 1's generator); the other one is timed beside it")
     ap.add_argument("--rehearse", action="store_true",
                     help="launcher and exchange plumbing only, on CPU tensors (gloo): no GPU, no kernels, value = null")
+    ap.add_argument("--extras-deadline", type=float, default=420.0,
+                    help="seconds the legs after the headline may take before rank 0 prints what it has (0: no bound)")
     ap.add_argument("--exchange-nrhs", type=int, default=None,
                     help="right-hand sides per GPU in the scatter / gather legs (default: --nrhs)")
     args = ap.parse_args()
@@ -331,6 +369,8 @@ def main():
         "gaxpy_prepare_s": {k: round(v["prepare_s"], 3) for k, v in trial.items()},
     }
     _csx.free(hA)
+    deadline = Deadline(args.extras_deadline, rank)
+    deadline.arm(out)
     # the same kernel on the other row draw (not part of `value`)
     other = "stratified" if args.gen == "uniform" else "uniform"
     hA2 = _csx.new_handle()
@@ -349,6 +389,7 @@ def main():
     _csx.free(hA2)
     _csx.free(hx)
     _csx.free(hy)
+    deadline.checkpoint(out)
 
     # ---- cs_gaxpy on G-spd (block-diagonal, best-case locality), same size ----
     if not args.skip_gspd:
@@ -384,6 +425,7 @@ def main():
         _csx.free(hB)
         _csx.free(hx)
         _csx.free(hy)
+        deadline.checkpoint(out)
 
     if (world > 1 or args.force_sharded) and not args.skip_sharded:
         out["gaxpy_one_matrix_column_sharded"] = sharded_spmv_section(args, lib, cs, comm, barrier, max_over_ranks)
@@ -401,13 +443,14 @@ def main():
             except Exception as e:                        # never take the headline down with it
                 other[name] = {"error": "%s: %s" % (type(e).__name__, e)}
         out["other_configs"] = other
+        deadline.checkpoint(out)
     if rank == 0 and world == 1 and not args.skip_cpu:
         py, c = cpu_baseline(args.cpu_n, per_col, args.cpu_seconds, args.gen)
         out["cpu_baseline"] = py
         out["cpu_baseline_c"] = c
-    if rank == 0:
-        print(json.dumps(out))
+    deadline.emit(out)
     comm.close()
+    deadline.timer.cancel()
 
 
 def sharded_spmv_section(args, lib, cs, comm, barrier, max_over_ranks):
