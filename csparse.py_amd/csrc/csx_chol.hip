@@ -50,6 +50,7 @@ int chol_symbolic_device(const Csc *A, const int32_t *parent, const int32_t *cp,
 struct TriPlan;
 int tri_solve_raw(TriPlan *P, double *X, int32_t nrhs, bool relaxed);
 int tri_analyse_raw(const Csc *T, int kind, TriPlan **out);
+void tri_set_mate(TriPlan *P, TriPlan *mate);
 void tri_gather_arrays(const TriPlan *P, const int32_t **ptr, const int32_t **idx, const double **val,
                        const double **diag);
 
@@ -561,6 +562,10 @@ __global__ __launch_bounds__(256) void k_band_width(int32_t n, const int32_t *__
     if (j < n) atomicMax(bw, Li[Lp[j + 1] - 1] - (int32_t)j);    // rows ascending: the last entry is the lowest row
 }
 
+// csx_cholband.hip: blocked factorisation in a dense band array, for chain-like factors of any band width
+size_t chol_wide_band_bytes(int32_t n, int32_t bw);
+int chol_wide_band(int32_t n, int32_t bw, const int32_t *Lp, const int32_t *Li, double *Lx, int *notspd, int nb);
+
 struct Forest {
     std::vector<Tree> small;             // trees handled by the tree kernel
     std::vector<int32_t> small_cols;     // their columns, ascending inside a tree
@@ -697,10 +702,22 @@ static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, c
             (void)hipMemcpyAsync(&hb, d_flags + 2, sizeof(int), hipMemcpyDeviceToHost, s);
             (void)hipStreamSynchronize(s);
             const int need = hb + 1;
+            // wide bands (and, by option, every band): blocked factorisation in a dense band array, if that array fits
+            const int wb = ctx().opt.chol_wband;
+            if (wb == 2 || (wb == 1 && need > 80)) {   // narrower: the register window costs about the same per column
+                size_t free_b = 0, total_b = 0, idle_b = 0, live_b = 0;
+                pool_stats(&idle_b, &live_b);
+                if (hipMemGetInfo(&free_b, &total_b) == hipSuccess &&
+                    chol_wide_band_bytes(n, hb) < (free_b + idle_b) / 2) {
+                    st = chol_wide_band(n, hb, L->p, L->i, L->x, d_flags + 1, ctx().opt.chol_wband_nb);
+                    banded = true;
+                }
+            }
 #define CSX_BAND(BWV)                                                                                                \
     hipLaunchKernelGGL((k_chol_band<BWV, 1024>), dim3(1), dim3(1024), 0, s, n, L->p, L->i, L->x, d_rp, d_rc, d_rpos, \
                        d_flags + 1)
-            if (need <= 48) { CSX_BAND(48); banded = true; }
+            if (banded) {}
+            else if (need <= 48) { CSX_BAND(48); banded = true; }
             else if (need <= 80) { CSX_BAND(80); banded = true; }
             else if (need <= 112) { CSX_BAND(112); banded = true; }
             else if (need <= 144) { CSX_BAND(144); banded = true; }
@@ -1347,6 +1364,7 @@ static int cholsol_plan(const Csc *L, const int32_t *pinv, CholPlan **out) {
     }
     CSX_TRY(tri_analyse_raw(L, CSX_TRI_L, &P->fwd));
     CSX_TRY(tri_analyse_raw(L, CSX_TRI_LT, &P->bwd));
+    tri_set_mate(P->bwd, P->fwd);   // the rounding-equal order may run L' in push form on the rows of L
     if (n == 0) return CSX_OK;
     // forest of small trees?  (needs a Cholesky-shaped L: diagonal first, rows ascending)
     DevScope tmp;   // d_parent, d_flag, flen, blen: released on every exit

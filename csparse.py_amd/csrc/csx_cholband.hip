@@ -1,0 +1,217 @@
+// cs_chol for chain-like factors with a WIDE band (reference: csparse.py:561-619, the up-looking row solve).
+//
+// A 2-D grid Laplacian in natural order (the only order the reference's own cs_cholsol(0, ...) offers) has an
+// elimination tree that is one chain and a factor that is dense inside a band of half-width g: a 700 x 700 grid is
+// n = 490 000 columns of 701 entries (lnz 3.4e8), every column its own level, 700 updates of 700 terms each.  The
+// column kernels of csx_chol.hip spend 350 us on such a column (171 s for the matrix); the register-window kernel
+// (k_chol_band) holds the live triangle of half-widths up to 176 in one workgroup's registers and stops there.
+//
+// Here the band is worked on in a DENSE BAND ARRAY in memory -- element (r, c), c <= r <= c + bw, at
+// W[c * (bw + 1) + r - c], 2.7 GB for the grid above, the live (bw + 1)^2 / 2 window of it (2 MB) staying in L2 --
+// by a right-looking BLOCKED factorisation, NB columns per step, two launches per step:
+//   k_wband_panel   the NB x NB diagonal block is factored by one wave (lane = row, the block's row in registers,
+//                   L(c, j) handed round by v_readlane), every workgroup doing it for itself; then each thread
+//                   takes one of the <= bw rows below it and solves its NB entries against the block;
+//   k_wband_update  64 x 64 tiles of the live window (one workgroup each, 4 x 4 elements per thread) subtract the
+//                   panel's NB products l(r, k) l(c, k) from their elements, the two l strips staged in LDS.
+// Every element receives its products in ascending column order k, multiply and subtract rounded separately, then
+// one division by the pivot: on a chain tree that is the reference's operation sequence (cs_ereach hands the row
+// solve its columns in ascending order), so L.x is bit-identical to it; structural zeros inside the band stay +0.0
+// and change nothing.  On other trees the result agrees to rounding, like the general column kernels.
+#include "csx_internal.h"
+
+namespace csx {
+
+#pragma clang fp contract(off)
+
+// one wave per column: dense band array <- L.x (scatter = true) or L.x <- dense band array
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void k_wband_copy(int32_t n, int32_t ld, const int32_t *__restrict__ Lp,
+                                                    const int32_t *__restrict__ Li, double *Lx, double *W) {
+    const int lane = threadIdx.x & 63;
+    const int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (j >= n) return;
+    for (int32_t q = Lp[j] + lane; q < Lp[j + 1]; q += 64) {
+        const int64_t at = j * ld + (Li[q] - (int32_t)j);
+        if (SCATTER) W[at] = Lx[q];
+        else Lx[q] = W[at];
+    }
+}
+
+constexpr int WB_PANEL_ROWS = 256;      // rows below the diagonal block per workgroup of k_wband_panel
+constexpr int WB_TILE = 64;             // k_wband_update: tile side
+
+// Panel [c0, c0 + NB): wave 0 of every workgroup factors the diagonal block (redundantly; workgroup 0 stores it),
+// waves 1 .. 4 of workgroup g solve rows c0 + NB + 256 g ... against it.  Element (r, c0 + t) of the panel sits at
+// Wp[t * ld + (r - c0 - t)], Wp = W + c0 * ld: 32-bit offsets from one uniform base.
+template <int NB>
+__global__ __launch_bounds__(64 + WB_PANEL_ROWS) void k_wband_panel(int32_t n, int32_t bw, int32_t c0, double *W,
+                                                                   int *notspd) {
+    __shared__ double D[NB * NB];       // the factored block: D[s * NB + t] = L(c0 + t, c0 + s), s <= t
+    const uint32_t ld = (uint32_t)bw + 1;
+    double *Wp = W + (int64_t)c0 * ld;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int32_t r = c0 + NB + (int32_t)blockIdx.x * WB_PANEL_ROWS + (tid - 64);   // this thread's row below the block
+    const int32_t rmax = min(n - 1, c0 + NB - 1 + bw);
+    const bool mine = wave > 0 && r <= rmax;
+    const uint32_t ro = (uint32_t)(r - c0);
+    double x[NB];
+    if (wave == 0) {
+        // ---- diagonal block, one wave, lane = row i of the block, a[c] = element (i, c) ----
+        const bool row = lane < NB && c0 + lane < n;
+        double a[NB];
+#pragma unroll
+        for (int c = 0; c < NB; c++) a[c] = (row && c <= lane && lane - c <= bw) ? Wp[(uint32_t)c * ld + (uint32_t)(lane - c)] : 0.0;
+#pragma unroll
+        for (int j = 0; j < NB; j++) {
+            // columns past the end of the matrix: an identity block (pivot 1, nothing below)
+            const bool live = c0 + j < n;
+            const int dlo = __builtin_amdgcn_readlane(__double2loint(a[j]), j);
+            const int dhi = __builtin_amdgcn_readlane(__double2hiint(a[j]), j);
+            const double d = live ? __hiloint2double(dhi, dlo) : 1.0;
+            if (live && !(d > 0.0) && lane == 0 && blockIdx.x == 0) atomicMin(notspd, c0 + j);   // csparse.py:612
+            const double ljj = sqrt(d);
+            double lij = 0.0;
+            if (row && lane > j) lij = a[j] / ljj;
+            if (lane == j) a[j] = ljj;
+            else a[j] = lij;
+#pragma unroll
+            for (int c = j + 1; c < NB; c++) {
+                const int lo = __builtin_amdgcn_readlane(__double2loint(lij), c);
+                const int hi = __builtin_amdgcn_readlane(__double2hiint(lij), c);
+                const double lcj = __hiloint2double(hi, lo);
+                const double t = lij * lcj;
+                if (lane >= c) a[c] = a[c] - t;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (lane < NB) {
+#pragma unroll
+            for (int c = 0; c < NB; c++) {
+                D[c * NB + lane] = a[c];
+                if (blockIdx.x == 0 && row && c <= lane && lane - c <= bw) Wp[(uint32_t)c * ld + (uint32_t)(lane - c)] = a[c];
+            }
+        }
+    } else {
+        // the row's entries in the panel's columns (outside the band or the matrix: 0), in flight while wave 0 works
+#pragma unroll
+        for (int t = 0; t < NB; t++)
+            x[t] = (mine && c0 + t < n && ro - (uint32_t)t <= (uint32_t)bw) ? Wp[(uint32_t)t * ld + (ro - (uint32_t)t)] : 0.0;
+    }
+    __syncthreads();
+    if (!mine) return;
+    // ---- this row against the block: x[t] = (x[t] - sum_{s < t} x[s] L(c0 + t, c0 + s)) / L(c0 + t, c0 + t) ----
+#pragma unroll
+    for (int t = 0; t < NB; t++) {
+        double v = x[t];
+#pragma unroll
+        for (int s = 0; s < t; s++) {
+            const double p = x[s] * D[s * NB + t];
+            v = v - p;
+        }
+        x[t] = v / D[t * NB + t];
+        asm volatile("" : "+v"(x[t]) : : "memory");   // x[t] is formed HERE: the block's values of one row, not of all rows, in registers
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int t = 0; t < NB; t++)
+        if (c0 + t < n && ro - (uint32_t)t <= (uint32_t)bw) Wp[(uint32_t)t * ld + (ro - (uint32_t)t)] = x[t];
+}
+
+// Trailing update by panel [c0, c0 + NB): element (r, c), c0 + NB <= c <= r <= min(n - 1, c0 + NB - 1 + bw),
+// loses sum_k l(r, k) l(c, k), k ascending.  Tile (blockIdx.x = row tile, blockIdx.y = column tile), 256 threads,
+// 4 x 4 elements per thread.
+template <int NB>
+__global__ __launch_bounds__(256) void k_wband_update(int32_t n, int32_t bw, int32_t c0, double *W) {
+    if (blockIdx.y > blockIdx.x) return;
+    __shared__ __attribute__((aligned(16))) double lr[NB][WB_TILE], lc[NB][WB_TILE];
+    const int64_t ld = (int64_t)bw + 1;
+    const int32_t first = c0 + NB;
+    const int32_t rmax = min(n - 1, c0 + NB - 1 + bw);
+    const int32_t R0 = first + (int32_t)blockIdx.x * WB_TILE, C0 = first + (int32_t)blockIdx.y * WB_TILE;
+    const int tid = threadIdx.x;
+    // the two strips: l(R0 + i, c0 + t) and l(C0 + i, c0 + t), zero outside the band / past rmax
+    for (int e = tid; e < NB * WB_TILE; e += 256) {
+        const int t = e / WB_TILE, i = e % WB_TILE;
+        const int32_t k = c0 + t;
+        const int32_t ra = R0 + i, rb = C0 + i;
+        lr[t][i] = (ra <= rmax && ra - k <= bw) ? W[k * ld + (ra - k)] : 0.0;
+        lc[t][i] = (rb <= rmax && rb - k <= bw) ? W[k * ld + (rb - k)] : 0.0;
+    }
+    __syncthreads();
+    const int tx = tid & 15, ty = tid >> 4;
+    const int32_t r0 = R0 + 4 * tx, cc0 = C0 + 4 * ty;
+    if (r0 > rmax || cc0 > rmax || r0 + 3 < cc0) return;     // nothing of this thread's 4 x 4 is on or below the diagonal
+    double acc[4][4];
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            const int32_t rr = r0 + a, c = cc0 + b;
+            acc[b][a] = (rr <= rmax && c <= rr) ? W[c * ld + (rr - c)] : 0.0;
+        }
+#pragma unroll 4
+    for (int t = 0; t < NB; t++) {
+        double ra[4], cb[4];
+#pragma unroll
+        for (int a = 0; a < 4; a++) ra[a] = lr[t][4 * tx + a];
+#pragma unroll
+        for (int b = 0; b < 4; b++) cb[b] = lc[t][4 * ty + b];
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+            for (int a = 0; a < 4; a++) {
+                const double p = ra[a] * cb[b];
+                acc[b][a] = acc[b][a] - p;
+            }
+    }
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            const int32_t rr = r0 + a, c = cc0 + b;
+            if (rr <= rmax && c <= rr) W[c * ld + (rr - c)] = acc[b][a];
+        }
+}
+#pragma clang fp contract(fast)
+
+// Bytes of the dense band array for a factor of n columns and half-width bw.
+size_t chol_wide_band_bytes(int32_t n, int32_t bw) { return (size_t)n * ((size_t)bw + 1) * sizeof(double); }
+
+// L.x holds A scattered into the pattern of L (k_chol_init); on return it holds the factor.  *notspd (device)
+// receives the first column with a non-positive pivot (atomicMin), as in the other kernels.
+template <int NB>
+static int wide_band_run(int32_t n, int32_t bw, double *W, int *notspd) {
+    hipStream_t s = ctx().stream;
+    for (int32_t c0 = 0; c0 < n; c0 += NB) {
+        const int32_t below = std::min(n - 1, c0 + NB - 1 + bw) - (c0 + NB) + 1;   // rows under the block (may be <= 0)
+        const unsigned g2 = (unsigned)std::max(1, (below + WB_PANEL_ROWS - 1) / WB_PANEL_ROWS);
+        hipLaunchKernelGGL((k_wband_panel<NB>), dim3(g2), dim3(64 + WB_PANEL_ROWS), 0, s, n, bw, c0, W, notspd);
+        if (below > 0) {
+            const unsigned nt = (unsigned)((below + WB_TILE - 1) / WB_TILE);
+            hipLaunchKernelGGL((k_wband_update<NB>), dim3(nt, nt), dim3(256), 0, s, n, bw, c0, W);
+        }
+    }
+    CSX_LAUNCH_CHECK();
+    return CSX_OK;
+}
+
+int chol_wide_band(int32_t n, int32_t bw, const int32_t *Lp, const int32_t *Li, double *Lx, int *notspd, int nb) {
+    hipStream_t s = ctx().stream;
+    if (n <= 0) return CSX_OK;
+    DevScope tmp;
+    double *W = nullptr;
+    const size_t count = (size_t)n * ((size_t)bw + 1);
+    CSX_TRY(tmp.alloc(&W, count));
+    CSX_HIP(hipMemsetAsync(W, 0, count * sizeof(double), s));
+    const unsigned gw = (unsigned)(((int64_t)n + 3) / 4);
+    hipLaunchKernelGGL((k_wband_copy<true>), dim3(gw), dim3(256), 0, s, n, bw + 1, Lp, Li, Lx, W);
+    if (nb == 16) CSX_TRY(wide_band_run<16>(n, bw, W, notspd));
+    else CSX_TRY(wide_band_run<32>(n, bw, W, notspd));
+    hipLaunchKernelGGL((k_wband_copy<false>), dim3(gw), dim3(256), 0, s, n, bw + 1, Lp, Li, Lx, W);
+    CSX_LAUNCH_CHECK();
+    CSX_HIP(hipStreamSynchronize(s));   // W is released when this returns
+    return CSX_OK;
+}
+
+}  // namespace csx

@@ -74,6 +74,10 @@ struct TriPlan {
     int32_t *prog_ptr = nullptr, *prog_idx = nullptr;   // per sweep position: terms (local row * 64, value)
     double *prog_val = nullptr, *prog_diag = nullptr;
     int col_state = 0;               // k_tri_columns: 0 not examined, 1 usable, 2 not (duplicate rows in a column)
+    // windowed column kernels (k_tri_wcolumns / k_tri_wcolchain): band half-width of T (max |row - column|, -1: not
+    // measured yet) and the number of columns with an entry next to the diagonal (a chain link)
+    int32_t band = -1, links = 0;
+    TriPlan *mate = nullptr;         // plan of the transposed solve on the same matrix (cholsol: L for L'), not owned
     int32_t *cptr = nullptr, *cidx = nullptr;   // push kinds (L, U): per sweep position the COLUMN's entries
     double *cval = nullptr, *cdiag = nullptr;
     int32_t push_terms = 0;          // most terms of one component (0: no push program)
@@ -1156,6 +1160,183 @@ __global__ __launch_bounds__(TC_THREADS) void k_tri_columns(int32_t n, const int
         }
     }
 }
+
+// ---- chain-like systems of ANY size whose band fits LDS: the same two loops on a WINDOW of x -------------------
+// A grid Laplacian in natural order factors into a chain elimination tree and a band as wide as the grid (n = 490 000,
+// half-width 700, lnz 3.4e8): no level schedule has anything to schedule, and x (3.9 MB) does not fit LDS.  But a
+// column only reaches `band` rows ahead, so a circular window of the next Wn > band + 2 rows does: slot = row & (Wn - 1).
+// Push kinds (k_tri_wcolumns): the row that enters the window when column j leaves it takes over slot j (fetched three
+// steps ahead by thread 0, stored after the step's barrier).  Gather kinds (k_tri_wcolchain): x[j] is written into its
+// own slot when it is formed; the right-hand side value comes from memory with the column's entries.
+// k_tri_wcolumns takes the matrix as (ptr, idx, val) + a diagonal array + how many leading / trailing entries of a
+// column to skip, so it also runs the ROWS of L (the forward plan's gather arrays, diagonal stripped) as the columns of
+// L': the backward solve in push form -- x[i] then loses its terms in descending instead of ascending source order, so
+// that is used for the rounding-equal order only (csx_cholsol_set_order(plan, 0)).
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_tri_wcolumns(int32_t n, const int32_t *__restrict__ Tp,
+                                                          const int32_t *__restrict__ Ti, const double *__restrict__ Tx,
+                                                          const double *__restrict__ diag, int skip_first, int skip_last,
+                                                          int asc, uint32_t mask, double *X, int nrhs) {
+    extern __shared__ __attribute__((aligned(16))) double xs[];   // mask + 1 doubles
+    const int tid = threadIdx.x, r = blockIdx.x;
+    const int32_t Wn = (int32_t)mask + 1;
+    for (int32_t i = tid; i < min(n, Wn); i += THREADS) {
+        const int32_t row = asc ? i : n - 1 - i;
+        xs[row & mask] = X[(int64_t)row * nrhs + r];
+    }
+    __syncthreads();
+    auto col_at = [&](int32_t step) {   // the column of a step, clamped to the last one
+        const int32_t st = step < n ? step : n - 1;
+        return asc ? st : n - 1 - st;
+    };
+    struct Col {
+        int32_t lo, hi, ci;
+        double dg, cv, xin;
+    };
+    auto load = [&](int32_t j, int32_t b, int32_t e) {
+        Col c;
+        c.lo = b + skip_first;
+        c.hi = e - skip_last;
+        c.dg = diag[j];
+        c.ci = c.lo + tid < c.hi ? Ti[c.lo + tid] : 0;
+        c.cv = c.lo + tid < c.hi ? Tx[c.lo + tid] : 0.0;
+        const int32_t rin = asc ? j + Wn : j - Wn;       // the row that takes over slot j
+        c.xin = (tid == 0 && rin >= 0 && rin < n) ? X[(int64_t)rin * nrhs + r] : 0.0;
+        return c;
+    };
+    Col ring[4];
+    int32_t pb[4], pe[4];
+#pragma unroll
+    for (int u = 0; u < 3; u++) ring[u] = load(col_at(u), Tp[col_at(u)], Tp[col_at(u) + 1]);
+    pb[3] = Tp[col_at(3)];
+    pe[3] = Tp[col_at(3) + 1];
+    for (int32_t base = 0; base < n; base += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int32_t step = base + u;
+            if (step >= n) break;                          // uniform
+            const int32_t j = col_at(step), j4 = col_at(step + 4);
+            pb[u] = Tp[j4];
+            pe[u] = Tp[j4 + 1];
+            ring[(u + 3) & 3] = load(col_at(step + 3), pb[(u + 3) & 3], pe[(u + 3) & 3]);
+            const Col &c = ring[u];
+            const double xj = xs[j & mask] / c.dg;             // every thread: same operands, same result
+            if (tid == 0) X[(int64_t)j * nrhs + r] = xj;       // x[j] is final and not read again
+            if (c.lo + tid < c.hi) {
+                const double t = c.cv * xj;
+                xs[c.ci & mask] = xs[c.ci & mask] - t;
+            }
+            for (int32_t p = c.lo + tid + THREADS; p < c.hi; p += THREADS) {   // columns longer than the workgroup
+                const int32_t i = Ti[p];
+                const double t = Tx[p] * xj;
+                xs[i & mask] = xs[i & mask] - t;
+            }
+            lds_barrier();
+            const int32_t rin = asc ? j + Wn : j - Wn;
+            if (tid == 0 && rin >= 0 && rin < n) xs[j & mask] = c.xin;   // seen after the next barrier, needed later still
+        }
+    }
+}
+
+template <int ROUNDS>
+struct TchWide {   // a column's off-diagonal range, its diagonal, the right-hand side value and ROUNDS entries per lane
+    int32_t lo, hi;
+    double dg, b;
+    int32_t ci[ROUNDS];
+    double cv[ROUNDS];
+};
+
+template <int KIND, int ROUNDS>   // CSX_TRI_LT or CSX_TRI_UT; columns of up to 64 * ROUNDS entries are fetched ahead
+__global__ __launch_bounds__(64) void k_tri_wcolchain(int32_t n, const int32_t *__restrict__ Tp,
+                                                      const int32_t *__restrict__ Ti, const double *__restrict__ Tx,
+                                                      uint32_t mask, double *X, int nrhs) {
+    extern __shared__ __attribute__((aligned(16))) double xs[];   // mask + 1 doubles: x of the last mask + 1 columns
+    const int lane = threadIdx.x, r = blockIdx.x;
+    constexpr bool ASC = KIND == CSX_TRI_UT;
+    constexpr bool DIAG_FIRST = KIND == CSX_TRI_LT;
+    auto col_at = [&](int32_t step) {
+        const int32_t st = step < n ? step : n - 1;
+        return ASC ? st : n - 1 - st;
+    };
+    auto load = [&](int32_t j, int32_t b, int32_t e) {
+        TchWide<ROUNDS> c;
+        c.lo = DIAG_FIRST ? b + 1 : b;
+        c.hi = DIAG_FIRST ? e : e - 1;
+        c.dg = Tx[DIAG_FIRST ? b : e - 1];
+        c.b = X[(int64_t)j * nrhs + r];
+#pragma unroll
+        for (int q = 0; q < ROUNDS; q++) {
+            const int32_t p = c.lo + 64 * q + lane;
+            c.ci[q] = p < c.hi ? Ti[p] : 0;
+            c.cv[q] = p < c.hi ? Tx[p] : 0.0;
+        }
+        return c;
+    };
+    TchWide<ROUNDS> ring[4];
+    int32_t pb[4], pe[4];
+#pragma unroll
+    for (int u = 0; u < 3; u++) ring[u] = load(col_at(u), Tp[col_at(u)], Tp[col_at(u) + 1]);
+    pb[3] = Tp[col_at(3)];
+    pe[3] = Tp[col_at(3) + 1];
+    for (int32_t base = 0; base < n; base += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int32_t step = base + u;
+            if (step >= n) break;                       // uniform
+            const int32_t j = col_at(step);
+            const int32_t j4 = col_at(step + 4);
+            pb[u] = Tp[j4];
+            pe[u] = Tp[j4 + 1];
+            ring[(u + 3) & 3] = load(col_at(step + 3), pb[(u + 3) & 3], pe[(u + 3) & 3]);
+            const TchWide<ROUNDS> &cur = ring[u];
+            const int32_t len = cur.hi - cur.lo;
+            double acc = cur.b;
+#pragma unroll
+            for (int q = 0; q < ROUNDS; q++) {
+                if (64 * q >= len) break;                // uniform
+                const double pq = 64 * q + lane < len ? cur.cv[q] * xs[cur.ci[q] & mask] : 0.0;
+                acc = tch_chain(acc, pq, len - 64 * q);
+            }
+            for (int32_t q0 = 64 * ROUNDS; q0 < len; q0 += 64) {   // columns longer than what is fetched ahead
+                const double pq = q0 + lane < len ? Tx[cur.lo + q0 + lane] * xs[Ti[cur.lo + q0 + lane] & mask] : 0.0;
+                acc = tch_chain(acc, pq, len - q0);
+            }
+            const double xj = acc / cur.dg;                   // lane 0's is the one
+            if (lane == 0) {
+                xs[j & mask] = xj;
+                X[(int64_t)j * nrhs + r] = xj;
+            }
+        }
+    }
+}
+
+// band half-width of T, the number of columns with an entry right next to the diagonal, and whether T is a proper
+// triangle of its kind (diagonal first in L, last in U, every other entry strictly on its side): out[0..2]
+__global__ __launch_bounds__(256) void k_tri_band(int32_t n, const int32_t *__restrict__ Tp, const int32_t *__restrict__ Ti,
+                                                  int lower, int *out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (j >= n) return;
+    int32_t far = 0, link = 0, bad = 0;
+    const int32_t b = Tp[j], e = Tp[j + 1];
+    for (int32_t p = b + lane; p < e; p += 64) {
+        const int32_t d = Ti[p] - (int32_t)j;
+        const bool is_diag = lower ? p == b : p == e - 1;
+        bad |= is_diag ? d != 0 : (lower ? d <= 0 : d >= 0);
+        far = max(far, abs(d));
+        link |= abs(d) == 1;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        far = max(far, __shfl_xor(far, o));
+        link |= __shfl_xor(link, o);
+        bad |= __shfl_xor(bad, o);
+    }
+    if (lane == 0) {
+        atomicMax(out, far);
+        if (link) atomicAdd(out + 1, 1);
+        if (bad) out[2] = 1;
+    }
+}
 #pragma clang fp contract(fast)
 
 // a column of T with two entries in the same row (the reference's own LU factors have them) must keep their
@@ -1717,6 +1898,80 @@ int tri_solve_raw(TriPlan *P, double *X, int32_t nrhs, bool relaxed) {
     if (P->n == 0 || nrhs == 0) return CSX_OK;
     if (ctx().opt.tri_components) CSX_TRY(analyse_components(P));
     if (P->comp_ok && ctx().opt.tri_components) return solve_components(P, X, nrhs);
+    // chain-like, too big for x to sit in LDS, but banded: the column loops on a window of x (no level analysis at all)
+    if (ctx().opt.tri_columns && P->n > TC_MAX_N) {
+        if (P->band < 0) {
+            DevScope tmp;
+            int *o = nullptr;
+            int h[3] = {0, 0, 0};
+            CSX_TRY(tmp.alloc(&o, 3));
+            CSX_HIP(hipMemsetAsync(o, 0, 3 * sizeof(int), s));
+            hipLaunchKernelGGL(k_tri_band, dim3((unsigned)(((int64_t)P->n + 3) / 4)), dim3(256), 0, s, P->n, P->Tp, P->Ti,
+                               (P->kind == CSX_TRI_L || P->kind == CSX_TRI_LT) ? 1 : 0, o);
+            CSX_HIP(hipMemcpyAsync(h, o, sizeof h, hipMemcpyDeviceToHost, s));
+            CSX_HIP(hipStreamSynchronize(s));
+            P->band = h[2] ? 0x7fffffff : h[0];     // not a proper triangle: the schedule's literal loop handles it
+            P->links = h[1];
+            if (P->band != 0x7fffffff && (P->kind == CSX_TRI_L || P->kind == CSX_TRI_U)) {
+                int hd = 0;                          // the same row twice in a column: the lanes of a column would race
+                CSX_HIP(hipMemsetAsync(o, 0, sizeof(int), s));
+                hipLaunchKernelGGL(k_adjacent_equal, dim3((unsigned)(((int64_t)P->n + 3) / 4)), dim3(256), 0, s, P->n, P->ptr,
+                                   P->idx, o);
+                CSX_HIP(hipMemcpyAsync(&hd, o, sizeof(int), hipMemcpyDeviceToHost, s));
+                CSX_HIP(hipStreamSynchronize(s));
+                P->col_state = hd ? 2 : 1;
+            }
+        }
+        uint32_t Wn = 64;
+        while ((int64_t)Wn < (int64_t)P->band + 4 && Wn < (1u << 20)) Wn <<= 1;
+        const bool chainlike = (int64_t)P->links * 12 > (int64_t)P->n * 11;   // nearly every column hands on to its neighbour
+        if (chainlike && P->band != 0x7fffffff && (size_t)Wn * sizeof(double) <= 128 * 1024) {
+            const size_t lds = (size_t)Wn * sizeof(double);
+            const bool push = P->kind == CSX_TRI_L || P->kind == CSX_TRI_U;
+            const TriPlan *M = P->mate;
+            // rounding-equal order, L': the rows of L (the mate's gather arrays) pushed as the columns of L'
+            const bool mate_push = !push && relaxed && P->kind == CSX_TRI_LT && M && M->kind == CSX_TRI_L && M->owns_g &&
+                                   M->col_state == 1 && M->n == P->n;
+            if ((push && P->col_state == 1) || mate_push) {
+                const int32_t *cp = mate_push ? M->ptr : P->Tp, *ci = mate_push ? M->idx : P->Ti;
+                const double *cx = mate_push ? M->val : P->Tx, *cd = mate_push ? M->diag : P->diag;
+                const int sf = (!mate_push && P->kind == CSX_TRI_L) ? 1 : 0, sl = (!mate_push && P->kind == CSX_TRI_U) ? 1 : 0;
+                const int asc = (!mate_push && P->kind == CSX_TRI_L) ? 1 : 0;
+                const int64_t terms = mate_push ? (int64_t)M->gnnz : (int64_t)P->gnnz;
+                if (terms > (int64_t)192 * P->n) {
+                    CSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tri_wcolumns<1024>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+                    hipLaunchKernelGGL(k_tri_wcolumns<1024>, dim3((unsigned)nrhs), dim3(1024), lds, s, P->n, cp, ci, cx, cd, sf,
+                                       sl, asc, Wn - 1, X, nrhs);
+                } else {
+                    CSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tri_wcolumns<256>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+                    hipLaunchKernelGGL(k_tri_wcolumns<256>, dim3((unsigned)nrhs), dim3(256), lds, s, P->n, cp, ci, cx, cd, sf, sl,
+                                       asc, Wn - 1, X, nrhs);
+                }
+                CSX_LAUNCH_CHECK();
+                return CSX_OK;
+            }
+            if (!push) {
+#define CSX_WCH(K, R)                                                                                              \
+    {                                                                                                              \
+        CSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tri_wcolchain<K, R>),                        \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));                \
+        hipLaunchKernelGGL((k_tri_wcolchain<K, R>), dim3((unsigned)nrhs), dim3(64), lds, s, P->n, P->Tp, P->Ti, P->Tx, \
+                           Wn - 1, X, nrhs);                                                                       \
+    }
+                const bool wide = (int64_t)P->gnnz > (int64_t)160 * P->n;   // columns of more than two rounds on average
+                if (P->kind == CSX_TRI_LT) {
+                    if (wide) CSX_WCH(CSX_TRI_LT, 12) else CSX_WCH(CSX_TRI_LT, 2)
+                } else {
+                    if (wide) CSX_WCH(CSX_TRI_UT, 12) else CSX_WCH(CSX_TRI_UT, 2)
+                }
+#undef CSX_WCH
+                CSX_LAUNCH_CHECK();
+                return CSX_OK;
+            }
+        }
+    }
     CSX_TRY(ensure_schedule(P));
     if (P->sequential) {
         hipLaunchKernelGGL(k_tri_sequential, dim3((unsigned)((nrhs + 63) / 64)), dim3(64), 0, s, P->kind, P->n, P->Tp,
@@ -1805,6 +2060,7 @@ int tri_solve_raw(TriPlan *P, double *X, int32_t nrhs, bool relaxed) {
 }
 
 int tri_analyse_raw(const Csc *T, int kind, TriPlan **out) { return analyse(T, kind, out); }
+void tri_set_mate(TriPlan *P, TriPlan *mate) { P->mate = mate; }
 
 void tri_gather_arrays(const TriPlan *P, const int32_t **ptr, const int32_t **idx, const double **val,
                        const double **diag) {

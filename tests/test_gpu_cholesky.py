@@ -397,7 +397,8 @@ def test_banded_chain_factor_takes_the_register_window_kernel(cs):
     parent, cp = CO.schol(n, p, i)
     Lp, Li, Lx = CO.chol(n, p, i, x, parent, cp)
     S = cs.cs_schol(0, C)
-    N = cs.cs_chol(C, S)
+    with _csx.option("chol.wband", 0):               # by default the blocked dense-band kernels take this width
+        N = cs.cs_chol(C, S)
     assert N.L.p == Lp.tolist() and N.L.i[:Lp[n]] == Li.tolist()
     got = np.asarray(N.L.x[:Lp[n]])
     assert got.tobytes() == Lx.tobytes()
@@ -412,3 +413,70 @@ def test_banded_chain_factor_takes_the_register_window_kernel(cs):
         if C2.i[q] == j:
             C2.x[q] = -C2.x[q]
     assert cs.cs_chol(C2, S) is None
+
+
+def _grid_laplacian(gx, gy, shift=0.01):
+    """5-point Laplacian of a gx x gy grid in natural order (x fastest): a chain elimination tree and a factor that is
+    dense inside a band of half-width gx."""
+    import scipy.sparse as sp
+    Tx = sp.diags([-1, 2, -1], [-1, 0, 1], shape=(gx, gx))
+    Ty = sp.diags([-1, 2, -1], [-1, 0, 1], shape=(gy, gy))
+    A = (sp.kron(sp.identity(gy), Tx) + sp.kron(Ty, sp.identity(gx)) + shift * sp.identity(gx * gy)).tocsc()
+    A.sort_indices()
+    return gx * gy, A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
+
+
+@pytest.mark.parametrize("gx,gy,wband,nb", [(200, 31, 1, 16), (200, 31, 1, 32), (61, 59, 2, 16), (61, 59, 2, 32),
+                                            (33, 17, 2, 32), (7, 80, 2, 16), (300, 2, 1, 32), (300, 2, 2, 16)])
+def test_wide_band_chain_factor_blocked_in_a_dense_band_array(cs, gx, gy, wband, nb):
+    """Natural-order grid Laplacians: chain elimination tree, band half-width gx.  Wider than the register window
+    (gx = 200) the blocked dense-band kernels (csx_cholband.hip) take the factor by themselves; forced (wband = 2)
+    they take narrow bands too.  Every element receives its updates in ascending column order, multiply and subtract
+    rounded separately: the reference's operation sequence on a chain tree (csparse.py:598-612) -> L.x bit-identical
+    to the plain-C oracle, for panel widths 16 and 32, sizes that are no multiple of the panel, and bands wider than
+    what is left of the matrix."""
+    import _csx
+    n, p, i, x = _grid_laplacian(gx, gy)
+    A = cs.cs_spalloc(n, n, len(i), True, False)
+    A.p, A.i, A.x = p.tolist(), i.tolist(), x.tolist()
+    S = cs.cs_schol(0, A)
+    parent, cp = CO.schol(n, p, i)
+    Lp, Li, Lx = CO.chol(n, p, i, x, parent, cp)
+    with _csx.option("chol.wband", wband), _csx.option("chol.wband_nb", nb):
+        N = cs.cs_chol(A, S)
+    assert N.L.p == Lp.tolist() and N.L.i[:Lp[n]] == Li.tolist()
+    assert np.asarray(N.L.x[:Lp[n]]).tobytes() == Lx.tobytes()
+    if gx == 200:
+        with _csx.option("chol.wband", 0):               # the general column kernels: same factor to rounding
+            Ng = cs.cs_chol(A, S)
+        gg = np.asarray(Ng.L.x[:Lp[n]])
+        assert np.max(np.abs(gg - Lx)) / np.abs(Lx).max() < 1e-12
+
+
+def test_wide_band_factor_refuses_a_matrix_that_is_not_positive_definite(cs):
+    n, p, i, x = _grid_laplacian(200, 12)
+    x = x.copy()
+    j = n // 2 + 7
+    for q in range(p[j], p[j + 1]):
+        if i[q] == j:
+            x[q] = -x[q]
+    A = cs.cs_spalloc(n, n, len(i), True, False)
+    A.p, A.i, A.x = p.tolist(), i.tolist(), x.tolist()
+    assert cs.cs_chol(A, cs.cs_schol(0, A)) is None       # csparse.py:612
+
+
+def test_wide_band_kernels_on_bcsstk16(cs):
+    """The reference's own matrix through the blocked dense-band kernels (its band, half-width 140, also fits the
+    register-window kernel): bit-identical to the plain-C oracle."""
+    import _csx
+    g = golden("bcsstk16")
+    C = unpack(cs, g, "C")
+    p, i, x = g["C_p"].astype(np.int32), g["C_i"].astype(np.int32), g["C_x"]
+    n = C.n
+    parent, cp = CO.schol(n, p, i)
+    Lp, Li, Lx = CO.chol(n, p, i, x, parent, cp)
+    S = cs.cs_schol(0, C)
+    for nb in (16, 32):
+        with _csx.option("chol.wband", 2), _csx.option("chol.wband_nb", nb):
+            N = cs.cs_chol(C, S)
+        assert np.asarray(N.L.x[:Lp[n]]).tobytes() == Lx.tobytes()

@@ -125,3 +125,71 @@ def test_trisolve_medium_random_against_c_oracle(cs):
         x = cs.dvec(b)
         assert _solvers(cs)[nm](U, x)
         assert x.numpy().tobytes() == ref.tobytes(), nm
+
+
+def _band_triangles(gx, gy, seed):
+    """Lower triangle L (diagonal first, rows ascending) of a gx x gy natural-order grid pattern's band, FULL inside the
+    band of half-width gx like a Cholesky factor of it, well conditioned; and U = L' (diagonal last)."""
+    import scipy.sparse as sp
+    n = gx * gy
+    rng = np.random.default_rng(seed)
+    offs = list(range(0, gx + 1))
+    diags = [4.0 + rng.random(n)] + [0.5 * (rng.random(n - d) - 0.5) / gx for d in offs[1:]]
+    L = sp.diags(diags, [-d for d in offs], shape=(n, n), format="csc")
+    L.sort_indices()
+    U = L.T.tocsc()
+    U.sort_indices()
+    return n, L, U
+
+
+@pytest.mark.parametrize("gx,gy", [(200, 90), (60, 300)])
+def test_chain_like_banded_systems_too_big_for_lds_run_on_a_window_of_x(cs, gx, gy):
+    """n > 15 360 (x does not fit LDS), every column handing on to its neighbour, band half-width gx: the column
+    loops on a circular window of x (k_tri_wcolumns for L / U, k_tri_wcolchain for L' / U'), 1 024 threads and twelve
+    rounds fetched ahead for the wide band, 256 and two for the narrow one.  Same operations in the same order as
+    cs_lsolve / cs_ltsolve / cs_usolve / cs_utsolve (csparse.py:1330-1365, 2368-2385, 2460-2475): bit-identical,
+    for one and for several right-hand sides."""
+    n, L, U = _band_triangles(gx, gy, 11)
+    assert n > 15360
+    mats = {}
+    for nm, M in (("L", L), ("U", U)):
+        A = cs.cs_spalloc(n, n, M.nnz, True, False)
+        A.p, A.i, A.x = M.indptr.tolist(), M.indices.tolist(), M.data.tolist()
+        mats[nm] = (cs.cs_pin(A), M.indptr.astype(np.int32), M.indices.astype(np.int32), M.data.astype(np.float64))
+    B = synth.rhs(n, 3, 5)
+    refs = {"lsolve": CO.lsolve, "ltsolve": CO.ltsolve, "usolve": CO.usolve, "utsolve": CO.utsolve}
+    for nm, fn in _solvers(cs).items():
+        A, p, i, x = mats["L" if nm.startswith("l") else "U"]
+        X1 = cs.dvec(B[:, 0].copy())
+        assert fn(A, X1) is True
+        assert X1.numpy().tobytes() == refs[nm](n, p, i, x, B[:, 0]).tobytes(), nm
+        X = cs.dvec(B)
+        assert fn(A, X) is True
+        got = X.numpy()
+        for r in range(3):
+            assert got[:, r].tobytes() == refs[nm](n, p, i, x, B[:, r]).tobytes(), (nm, r)
+
+
+def test_cholsol_on_a_wide_band_factor_both_orders(cs):
+    """cs_cholsol's solve phase on the factor of a natural-order grid Laplacian (n = 18 000, band 200): the default
+    order reproduces cs_lsolve + cs_ltsolve bit for bit; the rounding-equal order runs L' in push form on the rows
+    of L (k_tri_wcolumns on the forward plan's gather arrays) and agrees to 1e-12."""
+    from test_gpu_cholesky import _grid_laplacian
+    n, p, i, x = _grid_laplacian(200, 90)
+    A = cs.cs_spalloc(n, n, len(i), True, False)
+    A.p, A.i, A.x = p.tolist(), i.tolist(), x.tolist()
+    cs.cs_pin(A)
+    parent, cp = CO.schol(n, p, i)
+    Lp, Li, Lx = CO.chol(n, p, i, x, parent, cp)
+    b = synth.rhs(n, 2, 9)
+    ref = [CO.ltsolve(n, Lp, Li, Lx, CO.lsolve(n, Lp, Li, Lx, b[:, r])) for r in range(2)]
+    for exact in (True, False):
+        F = cs.cholsol_factor(A, 0, exact=exact)
+        X = cs.dvec(b)
+        assert F.solve(X) is True
+        got = X.numpy()
+        for r in range(2):
+            if exact:
+                assert got[:, r].tobytes() == ref[r].tobytes()
+            else:
+                assert np.max(np.abs(got[:, r] - ref[r])) / np.max(np.abs(ref[r])) < 1e-12
