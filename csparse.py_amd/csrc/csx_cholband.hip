@@ -173,6 +173,192 @@ __global__ __launch_bounds__(256) void k_wband_update(int32_t n, int32_t bw, int
             if (rr <= rmax && c <= rr) W[c * ld + (rr - c)] = acc[b][a];
         }
 }
+
+// ---- one launch per panel: panel k + 1 is factored WHILE panel k's update of the rest of the window runs ----------
+// Launch for panel [c1, c1 + NB), previous panel [c0, c0 + NB) = [c1 - NB, c1) (has_prev):
+//   role A (the first gA workgroups, 64 + 256 threads): the panel's own elements first lose the previous panel's
+//          products (the part of its trailing update that falls on these NB columns), then the diagonal block is
+//          factored by wave 0 and every row below is solved against it, as in k_wband_panel;
+//   role B (the other workgroups): 64 x 64 tiles of the window BEYOND the panel (columns >= c1 + NB) lose the previous
+//          panel's products, as in k_wband_update.
+// Both read the previous panel's columns (final since the launch before) and write disjoint elements, so the two
+// launches per panel become one and the serial part (block factor) hides behind the wide one.  Per-element order of
+// operations is unchanged: earlier columns first, ascending.
+template <int NB>
+__global__ __launch_bounds__(64 + WB_PANEL_ROWS) void k_wband_step(int32_t n, int32_t bw, int32_t c1, int has_prev,
+                                                                  int32_t gA, int32_t ntB, double *W, int *notspd) {
+    __shared__ __attribute__((aligned(16))) double smem[2 * NB * WB_TILE > 3 * NB * NB ? 2 * NB * WB_TILE : 3 * NB * NB];
+    const uint32_t ld = (uint32_t)bw + 1;
+    const int32_t c0 = c1 - NB;
+    const int tid = threadIdx.x;
+    if ((int32_t)blockIdx.x >= gA) {
+        // ---- role B: tile (bi, bj), bj <= bi, of the window beyond the panel ----
+        if (tid >= 256) return;
+        const int32_t tb = (int32_t)blockIdx.x - gA;
+        const int32_t bi = tb / ntB, bj = tb % ntB;
+        if (bj > bi) return;
+        double (*lr)[WB_TILE] = reinterpret_cast<double (*)[WB_TILE]>(smem);
+        double (*lc)[WB_TILE] = reinterpret_cast<double (*)[WB_TILE]>(smem + NB * WB_TILE);
+        const int64_t ldl = ld;
+        const int32_t first = c1 + NB;
+        const int32_t rmax = min(n - 1, c0 + NB - 1 + bw);
+        const int32_t R0 = first + bi * WB_TILE, C0 = first + bj * WB_TILE;
+        const int tx = tid & 15, ty = tid >> 4;
+        const int32_t r0 = R0 + 4 * tx, cc0 = C0 + 4 * ty;
+        const bool any = !(r0 > rmax || cc0 > rmax || r0 + 3 < cc0);   // something of this thread's 4 x 4 on / below the diagonal
+        double acc[4][4];
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+            for (int a = 0; a < 4; a++) {
+                const int32_t rr = r0 + a, c = cc0 + b;
+                acc[b][a] = (any && rr <= rmax && c <= rr) ? W[c * ldl + (rr - c)] : 0.0;
+            }
+        for (int e = tid; e < NB * WB_TILE; e += 256) {
+            const int t = e / WB_TILE, i = e % WB_TILE;
+            const int32_t k = c0 + t;
+            const int32_t ra = R0 + i, rb = C0 + i;
+            lr[t][i] = (ra <= rmax && ra - k <= bw) ? W[k * ldl + (ra - k)] : 0.0;
+            lc[t][i] = (rb <= rmax && rb - k <= bw) ? W[k * ldl + (rb - k)] : 0.0;
+        }
+        __syncthreads();
+        if (!any) return;
+#pragma unroll 4
+        for (int t = 0; t < NB; t++) {
+            double ra[4], cb[4];
+#pragma unroll
+            for (int a = 0; a < 4; a++) ra[a] = lr[t][4 * tx + a];
+#pragma unroll
+            for (int b = 0; b < 4; b++) cb[b] = lc[t][4 * ty + b];
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+#pragma unroll
+                for (int a = 0; a < 4; a++) {
+                    const double p = ra[a] * cb[b];
+                    acc[b][a] = acc[b][a] - p;
+                }
+        }
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+            for (int a = 0; a < 4; a++) {
+                const int32_t rr = r0 + a, c = cc0 + b;
+                if (rr <= rmax && c <= rr) W[c * ldl + (rr - c)] = acc[b][a];
+            }
+        return;
+    }
+    // ---- role A ----
+    double *E = smem;                 // E[t * NB + i] = l(c1 + i, c0 + t): the panel's diagonal rows in the previous panel's columns
+    double *Dt = smem + NB * NB;      // Dt[c * NB + i]: the diagonal block after the previous panel's update
+    double *D = smem + 2 * NB * NB;   // D[s * NB + t] = L(c1 + t, c1 + s): the factored block
+    double *Wp = W + (int64_t)c1 * ld;                       // element (r, c1 + t) at Wp[t * ld + (r - c1 - t)]
+    double *Wq = W + (int64_t)(has_prev ? c0 : c1) * ld;     // element (r, c0 + t) at Wq[t * ld + (r - c0 - t)]
+    const int lane = tid & 63, wave = tid >> 6;
+    const int32_t r = c1 + NB + (int32_t)blockIdx.x * WB_PANEL_ROWS + (tid - 64);   // this thread's row below the block
+    const int32_t rmax = min(n - 1, c1 + NB - 1 + bw);
+    const bool mine = wave > 0 && r <= rmax;
+    const uint32_t ro = (uint32_t)(r - c1), rq = (uint32_t)(r - c0);
+    double x[NB], lrow[NB];
+    constexpr int THREADS = 64 + WB_PANEL_ROWS;
+    for (int e = tid; e < NB * NB; e += THREADS) {
+        const int ec = e / NB, ei = e % NB;
+        // E: t = ec, i = ei: row c1 + ei, column c0 + ec, distance NB + ei - ec
+        const int32_t dist = NB + ei - ec;
+        E[e] = (has_prev && c1 + ei < n && dist <= bw) ? Wq[(uint32_t)ec * ld + (uint32_t)dist] : 0.0;
+        // Dt: element (c1 + ei, c1 + ec) of the block as stored (zero above the diagonal / outside the band or matrix)
+        Dt[e] = (ei >= ec && c1 + ei < n && ei - ec <= bw) ? Wp[(uint32_t)ec * ld + (uint32_t)(ei - ec)] : 0.0;
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int t = 0; t < NB; t++) {
+            x[t] = (mine && c1 + t < n && ro - (uint32_t)t <= (uint32_t)bw) ? Wp[(uint32_t)t * ld + (ro - (uint32_t)t)] : 0.0;
+            lrow[t] = (mine && has_prev && rq - (uint32_t)t <= (uint32_t)bw) ? Wq[(uint32_t)t * ld + (rq - (uint32_t)t)] : 0.0;
+        }
+    }
+    __syncthreads();
+    // the previous panel's products, ascending t
+    if (has_prev) {
+        for (int e = tid; e < NB * NB; e += THREADS) {       // the thread that stored Dt[e] updates it
+            const int ec = e / NB, ei = e % NB;
+            if (ei < ec) continue;
+            double v = Dt[e];
+#pragma unroll
+            for (int t = 0; t < NB; t++) {
+                const double p = E[t * NB + ei] * E[t * NB + ec];
+                v = v - p;
+            }
+            Dt[e] = v;
+        }
+    }
+    if (mine && has_prev) {
+#pragma unroll
+        for (int tq = 0; tq < NB; tq++) {
+            double v = x[tq];
+#pragma unroll
+            for (int t = 0; t < NB; t++) {
+                const double p = lrow[t] * E[t * NB + tq];
+                v = v - p;
+            }
+            x[tq] = v;
+            asm volatile("" : "+v"(x[tq]) : : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        // ---- diagonal block, one wave, lane = row i of the block, a[c] = element (i, c) ----
+        const bool row = lane < NB && c1 + lane < n;
+        double a[NB];
+#pragma unroll
+        for (int c = 0; c < NB; c++) a[c] = (lane < NB && c <= lane) ? Dt[c * NB + lane] : 0.0;
+#pragma unroll
+        for (int j = 0; j < NB; j++) {
+            const bool live = c1 + j < n;                     // past the end of the matrix: an identity block
+            const int dlo = __builtin_amdgcn_readlane(__double2loint(a[j]), j);
+            const int dhi = __builtin_amdgcn_readlane(__double2hiint(a[j]), j);
+            const double d = live ? __hiloint2double(dhi, dlo) : 1.0;
+            if (live && !(d > 0.0) && lane == 0 && blockIdx.x == 0) atomicMin(notspd, c1 + j);   // csparse.py:612
+            const double ljj = sqrt(d);
+            double lij = 0.0;
+            if (row && lane > j) lij = a[j] / ljj;
+            if (lane == j) a[j] = ljj;
+            else a[j] = lij;
+#pragma unroll
+            for (int c = j + 1; c < NB; c++) {
+                const int lo = __builtin_amdgcn_readlane(__double2loint(lij), c);
+                const int hi = __builtin_amdgcn_readlane(__double2hiint(lij), c);
+                const double lcj = __hiloint2double(hi, lo);
+                const double t = lij * lcj;
+                if (lane >= c) a[c] = a[c] - t;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (lane < NB) {
+#pragma unroll
+            for (int c = 0; c < NB; c++) {
+                D[c * NB + lane] = a[c];
+                if (blockIdx.x == 0 && row && c <= lane && lane - c <= bw) Wp[(uint32_t)c * ld + (uint32_t)(lane - c)] = a[c];
+            }
+        }
+    }
+    __syncthreads();
+    if (!mine) return;
+#pragma unroll
+    for (int t = 0; t < NB; t++) {
+        double v = x[t];
+#pragma unroll
+        for (int s = 0; s < t; s++) {
+            const double p = x[s] * D[s * NB + t];
+            v = v - p;
+        }
+        x[t] = v / D[t * NB + t];
+        asm volatile("" : "+v"(x[t]) : : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int t = 0; t < NB; t++)
+        if (c1 + t < n && ro - (uint32_t)t <= (uint32_t)bw) Wp[(uint32_t)t * ld + (ro - (uint32_t)t)] = x[t];
+}
 #pragma clang fp contract(fast)
 
 // Bytes of the dense band array for a factor of n columns and half-width bw.
@@ -196,6 +382,24 @@ static int wide_band_run(int32_t n, int32_t bw, double *W, int *notspd) {
     return CSX_OK;
 }
 
+template <int NB>
+static int wide_band_run_fused(int32_t n, int32_t bw, double *W, int *notspd) {
+    hipStream_t s = ctx().stream;
+    for (int32_t c1 = 0; c1 < n; c1 += NB) {
+        const int32_t below = std::min(n - 1, c1 + NB - 1 + bw) - (c1 + NB) + 1;    // rows under this panel's block
+        const int32_t gA = std::max(1, (below + WB_PANEL_ROWS - 1) / WB_PANEL_ROWS);
+        int32_t ntB = 0;
+        if (c1 > 0) {
+            const int32_t beyond = std::min(n - 1, c1 - 1 + bw) - (c1 + NB) + 1;     // window of the previous panel beyond this one
+            if (beyond > 0) ntB = (beyond + WB_TILE - 1) / WB_TILE;
+        }
+        hipLaunchKernelGGL((k_wband_step<NB>), dim3((unsigned)(gA + ntB * ntB)), dim3(64 + WB_PANEL_ROWS), 0, s, n, bw, c1,
+                           c1 > 0 ? 1 : 0, gA, ntB, W, notspd);
+    }
+    CSX_LAUNCH_CHECK();
+    return CSX_OK;
+}
+
 int chol_wide_band(int32_t n, int32_t bw, const int32_t *Lp, const int32_t *Li, double *Lx, int *notspd, int nb) {
     hipStream_t s = ctx().stream;
     if (n <= 0) return CSX_OK;
@@ -206,7 +410,9 @@ int chol_wide_band(int32_t n, int32_t bw, const int32_t *Lp, const int32_t *Li, 
     CSX_HIP(hipMemsetAsync(W, 0, count * sizeof(double), s));
     const unsigned gw = (unsigned)(((int64_t)n + 3) / 4);
     hipLaunchKernelGGL((k_wband_copy<true>), dim3(gw), dim3(256), 0, s, n, bw + 1, Lp, Li, Lx, W);
-    if (nb == 16) CSX_TRY(wide_band_run<16>(n, bw, W, notspd));
+    if (nb == 16) CSX_TRY(wide_band_run_fused<16>(n, bw, W, notspd));
+    else if (nb == 32) CSX_TRY(wide_band_run_fused<32>(n, bw, W, notspd));
+    else if (nb == -16) CSX_TRY(wide_band_run<16>(n, bw, W, notspd));     // two launches per panel (tests, timing)
     else CSX_TRY(wide_band_run<32>(n, bw, W, notspd));
     hipLaunchKernelGGL((k_wband_copy<false>), dim3(gw), dim3(256), 0, s, n, bw + 1, Lp, Li, Lx, W);
     CSX_LAUNCH_CHECK();

@@ -950,6 +950,9 @@ constexpr int TRW_MAX_RHS = 4, TRW_MIN_ROW = 24;   // a wave per row: at most so
 // storage order while the products rotate towards it through the wave (tch_chain) -- no barrier and no LDS round trip
 // for the products between columns.  Lanes past the end of the column hold +0.0, and x - (+0.0) = x for every x, so
 // the chain runs in blocks of eight without a test per term.
+// (Kept for reference and A/B timing: the kernels now hand the products over through LDS, tch_chain_lds below --
+// bcsstk16 L' 6.6 -> 5.9 ms, a band of 200: 3.1 -> 1.8 us per column; what is left is the dependent fp64 subtraction,
+// ~19 cycles per term.)
 __device__ __forceinline__ double tch_chain(double acc, double p, int cnt) {
     // Only lane 0's chain is the result.  The products are rotated through the wave, one lane per step (DPP
     // wave_rol:1: lane l receives lane l + 1), so lane 0 meets product 0, 1, 2, ... in order; the two rotations of a
@@ -966,6 +969,35 @@ __device__ __forceinline__ double tch_chain(double acc, double p, int cnt) {
             phi = __builtin_amdgcn_update_dpp(phi, phi, 0x134, 0xf, 0xf, false);
         }
         if (g + 8 >= cnt) break;   // uniform
+    }
+    return acc;
+}
+
+// The same chain with the products handed to lane 0 through LDS instead of the DPP rotation: every lane stores its
+// product (one ds_write_b64), then ALL lanes read the products back two at a time from the same addresses (broadcast
+// reads, 16 products per block, the next block requested before this block's subtractions), so the only serial chain
+// is the subtraction itself.  buf: 64 doubles private to the wave, 16-byte aligned.  LDS operations of one wave complete
+// in order, so neither the read-back nor the next call's store needs a barrier.
+__device__ __forceinline__ double tch_chain_lds(double acc, double p, int cnt, double *buf, int lane) {
+    buf[lane] = p;
+    const double2 *b2 = reinterpret_cast<const double2 *>(buf);
+    double2 cur[8], nxt[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) cur[q] = b2[q];
+#pragma unroll
+    for (int g = 0; g < 64; g += 16) {
+        if (g + 16 < 64 && g + 16 < cnt) {     // uniform
+#pragma unroll
+            for (int q = 0; q < 8; q++) nxt[q] = b2[(g + 16) / 2 + q];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            acc = acc - cur[q].x;
+            acc = acc - cur[q].y;
+        }
+        if (g + 16 >= cnt) break;              // uniform
+#pragma unroll
+        for (int q = 0; q < 8; q++) cur[q] = nxt[q];
     }
     return acc;
 }
@@ -997,6 +1029,7 @@ template <int KIND>   // CSX_TRI_LT or CSX_TRI_UT
 __global__ __launch_bounds__(64) void k_tri_colchain(int32_t n, const int32_t *__restrict__ Tp, const int32_t *__restrict__ Ti,
                                                   const double *__restrict__ Tx, double *X, int nrhs) {
     extern __shared__ __attribute__((aligned(16))) double xs[];   // n doubles
+    __shared__ __attribute__((aligned(16))) double cbuf[64];
     const int lane = threadIdx.x, r = blockIdx.x;
     for (int32_t i = lane; i < n; i += 64) xs[i] = X[(int64_t)i * nrhs + r];
     __syncthreads();
@@ -1030,11 +1063,11 @@ __global__ __launch_bounds__(64) void k_tri_colchain(int32_t n, const int32_t *_
             double acc = xs[j];
             const double p0 = lane < len ? cur.cv0 * xs[cur.ci0] : 0.0;
             const double p1 = 64 + lane < len ? cur.cv1 * xs[cur.ci1] : 0.0;
-            acc = tch_chain(acc, p0, len);
-            if (len > 64) acc = tch_chain(acc, p1, len - 64);
+            acc = tch_chain_lds(acc, p0, len, cbuf, lane);
+            if (len > 64) acc = tch_chain_lds(acc, p1, len - 64, cbuf, lane);
             for (int32_t q0 = 128; q0 < len; q0 += 64) {   // columns longer than two rounds of the wave
                 const double pq = q0 + lane < len ? Tx[cur.lo + q0 + lane] * xs[Ti[cur.lo + q0 + lane]] : 0.0;
-                acc = tch_chain(acc, pq, len - q0);
+                acc = tch_chain_lds(acc, pq, len - q0, cbuf, lane);
             }
             const double xj = acc / cur.dg;                   // lane 0's is the one
             if (lane == 0) {
@@ -1052,7 +1085,7 @@ __global__ __launch_bounds__(64) void k_tri_colchain(int32_t n, const int32_t *_
 __device__ __forceinline__ void solve_row_wave(int32_t row, int nrhs, const int32_t *__restrict__ ptr,
                                                const int32_t *__restrict__ idx, const double *__restrict__ val,
                                                const double *__restrict__ diag, int skip_first, int skip_last, double *X,
-                                               int lane) {
+                                               int lane, double *cbuf) {
     const int32_t b = ptr[row] + skip_first, e = ptr[row + 1] - skip_last;
     const double dg = diag[row];
     for (int r = 0; r < nrhs; r++) {
@@ -1066,7 +1099,7 @@ __device__ __forceinline__ void solve_row_wave(int32_t row, int nrhs, const int3
             const int32_t cin = qn < e ? idx[qn] : 0;
             const double cvn = qn < e ? val[qn] : 0.0;
             const double p = q0 + lane < e ? cv * xv : 0.0;
-            acc = tch_chain(acc, p, e - q0);
+            acc = tch_chain_lds(acc, p, e - q0, cbuf, lane);
             ci = cin;
             cv = cvn;
         }
@@ -1078,10 +1111,11 @@ __global__ __launch_bounds__(256) void k_tri_level_rows(const int32_t *__restric
                                                         const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx,
                                                         const double *__restrict__ val, const double *__restrict__ diag,
                                                         int skip_first, int skip_last, double *X, int nrhs) {
+    __shared__ __attribute__((aligned(16))) double cbuf[4][64];
     const int lane = threadIdx.x & 63;
     const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (w >= count) return;
-    solve_row_wave(order[first + w], nrhs, ptr, idx, val, diag, skip_first, skip_last, X, lane);
+    solve_row_wave(order[first + w], nrhs, ptr, idx, val, diag, skip_first, skip_last, X, lane, cbuf[threadIdx.x >> 6]);
 }
 
 __global__ __launch_bounds__(1024) void k_tri_levels_rows_one_wg(const int32_t *__restrict__ order,
@@ -1091,10 +1125,11 @@ __global__ __launch_bounds__(1024) void k_tri_levels_rows_one_wg(const int32_t *
                                                                  const double *__restrict__ val,
                                                                  const double *__restrict__ diag, int skip_first,
                                                                  int skip_last, double *X, int nrhs) {
+    __shared__ __attribute__((aligned(16))) double cbuf[16][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int32_t l = l0; l < l1; l++) {
         const int32_t first = level_ptr[l], count = level_ptr[l + 1] - first;
-        for (int32_t t = w; t < count; t += 16) solve_row_wave(order[first + t], nrhs, ptr, idx, val, diag, skip_first, skip_last, X, lane);
+        for (int32_t t = w; t < count; t += 16) solve_row_wave(order[first + t], nrhs, ptr, idx, val, diag, skip_first, skip_last, X, lane, cbuf[w]);
         __syncthreads();  // workgroup-scope release/acquire: the next level reads these x
     }
 }
@@ -1251,6 +1286,7 @@ __global__ __launch_bounds__(64) void k_tri_wcolchain(int32_t n, const int32_t *
                                                       const int32_t *__restrict__ Ti, const double *__restrict__ Tx,
                                                       uint32_t mask, double *X, int nrhs) {
     extern __shared__ __attribute__((aligned(16))) double xs[];   // mask + 1 doubles: x of the last mask + 1 columns
+    __shared__ __attribute__((aligned(16))) double cbuf[64];
     const int lane = threadIdx.x, r = blockIdx.x;
     constexpr bool ASC = KIND == CSX_TRI_UT;
     constexpr bool DIAG_FIRST = KIND == CSX_TRI_LT;
@@ -1295,11 +1331,11 @@ __global__ __launch_bounds__(64) void k_tri_wcolchain(int32_t n, const int32_t *
             for (int q = 0; q < ROUNDS; q++) {
                 if (64 * q >= len) break;                // uniform
                 const double pq = 64 * q + lane < len ? cur.cv[q] * xs[cur.ci[q] & mask] : 0.0;
-                acc = tch_chain(acc, pq, len - 64 * q);
+                acc = tch_chain_lds(acc, pq, len - 64 * q, cbuf, lane);
             }
             for (int32_t q0 = 64 * ROUNDS; q0 < len; q0 += 64) {   // columns longer than what is fetched ahead
                 const double pq = q0 + lane < len ? Tx[cur.lo + q0 + lane] * xs[Ti[cur.lo + q0 + lane] & mask] : 0.0;
-                acc = tch_chain(acc, pq, len - q0);
+                acc = tch_chain_lds(acc, pq, len - q0, cbuf, lane);
             }
             const double xj = acc / cur.dg;                   // lane 0's is the one
             if (lane == 0) {
@@ -1956,7 +1992,7 @@ int tri_solve_raw(TriPlan *P, double *X, int32_t nrhs, bool relaxed) {
 #define CSX_WCH(K, R)                                                                                              \
     {                                                                                                              \
         CSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tri_wcolchain<K, R>),                        \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));                \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));               \
         hipLaunchKernelGGL((k_tri_wcolchain<K, R>), dim3((unsigned)nrhs), dim3(64), lds, s, P->n, P->Tp, P->Ti, P->Tx, \
                            Wn - 1, X, nrhs);                                                                       \
     }
@@ -2008,7 +2044,7 @@ int tri_solve_raw(TriPlan *P, double *X, int32_t nrhs, bool relaxed) {
 #define CSX_TCH(K)                                                                                                 \
     {                                                                                                              \
         CSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tri_colchain<K>),                               \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));                \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));               \
         hipLaunchKernelGGL(k_tri_colchain<K>, dim3((unsigned)nrhs), dim3(64), (size_t)P->n * sizeof(double), s, P->n, P->Tp, \
                            P->Ti, P->Tx, X, nrhs);                                                                 \
     }

@@ -427,6 +427,7 @@ def _grid_laplacian(gx, gy, shift=0.01):
 
 
 @pytest.mark.parametrize("gx,gy,wband,nb", [(200, 31, 1, 16), (200, 31, 1, 32), (61, 59, 2, 16), (61, 59, 2, 32),
+                                            (200, 31, 1, -16), (61, 59, 2, -32), (300, 40, 1, 16),
                                             (33, 17, 2, 32), (7, 80, 2, 16), (300, 2, 1, 32), (300, 2, 2, 16)])
 def test_wide_band_chain_factor_blocked_in_a_dense_band_array(cs, gx, gy, wband, nb):
     """Natural-order grid Laplacians: chain elimination tree, band half-width gx.  Wider than the register window
@@ -434,7 +435,8 @@ def test_wide_band_chain_factor_blocked_in_a_dense_band_array(cs, gx, gy, wband,
     they take narrow bands too.  Every element receives its updates in ascending column order, multiply and subtract
     rounded separately: the reference's operation sequence on a chain tree (csparse.py:598-612) -> L.x bit-identical
     to the plain-C oracle, for panel widths 16 and 32, sizes that are no multiple of the panel, and bands wider than
-    what is left of the matrix."""
+    what is left of the matrix.  nb > 0: one launch per panel (the next panel factored while the previous one's update
+    of the rest of the window runs); nb < 0: two launches per panel."""
     import _csx
     n, p, i, x = _grid_laplacian(gx, gy)
     A = cs.cs_spalloc(n, n, len(i), True, False)
@@ -476,7 +478,7 @@ def test_wide_band_kernels_on_bcsstk16(cs):
     parent, cp = CO.schol(n, p, i)
     Lp, Li, Lx = CO.chol(n, p, i, x, parent, cp)
     S = cs.cs_schol(0, C)
-    for nb in (16, 32):
+    for nb in (16, 32, -16):
         with _csx.option("chol.wband", 2), _csx.option("chol.wband_nb", nb):
             N = cs.cs_chol(C, S)
         assert np.asarray(N.L.x[:Lp[n]]).tobytes() == Lx.tobytes()

@@ -33,7 +33,7 @@ def run(name, n, p, i, x, check=True):
         ref = Lx
     else:
         t_c = None
-    for wb, nb in ((1, 32), (2, 32), (2, 16), (0, 32)):
+    for wb, nb in ((2, 16), (2, 32), (2, -16), (0, 16)):
         if wb == 0 and S.lnz > 3e7:
             continue
         with _csx.option("chol.wband", wb), _csx.option("chol.wband_nb", nb):
