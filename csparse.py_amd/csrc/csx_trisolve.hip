@@ -78,6 +78,8 @@ struct TriPlan {
     // measured yet) and the number of columns with an entry next to the diagonal (a chain link)
     int32_t band = -1, links = 0;
     TriPlan *mate = nullptr;         // plan of the transposed solve on the same matrix (cholsol: L for L'), not owned
+    // two-phase runs of narrow levels (k_tri_run_prefix64): level of every row, and per row where its chain resumes
+    int32_t *level_of = nullptr, *resume = nullptr;
     int32_t *cptr = nullptr, *cidx = nullptr;   // push kinds (L, U): per sweep position the COLUMN's entries
     double *cval = nullptr, *cdiag = nullptr;
     int32_t push_terms = 0;          // most terms of one component (0: no push program)
@@ -98,6 +100,8 @@ void free_triplan(TriPlan *t) {
     dfree(t->npre);
     dfree(t->nin);
     dfree(t->tslot);
+    dfree(t->level_of);
+    dfree(t->resume);
     dfree(t->comps);
     dfree(t->comp_nodes);
     dfree(t->prog_ptr);
@@ -1134,6 +1138,160 @@ __global__ __launch_bounds__(1024) void k_tri_levels_rows_one_wg(const int32_t *
     }
 }
 
+// ---- level schedule, a wave per (row, block of 64 right-hand sides) -- many right-hand sides, long rows ----------
+// With a thread per (row, right-hand side) every thread fetches the row's (index, value) pairs for itself and keeps
+// eight gathers in flight: a separator row of 2 000 terms is 250 dependent round trips.  Here the lanes of a wave are
+// 64 right-hand sides of ONE row: the row's indices and values are uniform (scalar loads), a term's x values are one
+// coalesced 512-byte row of X, and a chunk of 16 terms is 16 independent loads per lane with the next chunk behind it.
+// Same subtractions in the same order as solve_one: same bits.
+constexpr int TR64_MIN_RHS = 16;
+constexpr int TR64_RUN = 64, TR64_RUN_MIN = 8;   // levels per two-phase run of narrow levels; shorter runs: one phase
+
+// The chain of one (row, 64 right-hand sides).  A row's terms are fetched 64 at a time, one per lane (coalesced, the
+// next 64 requested before these are used), and handed round by v_readlane: a term's source index becomes a scalar
+// base for one coalesced 512-byte load of X, its value a scalar factor.  Gathers are issued 16 terms ahead of the
+// subtractions.  PREFIX: stop at the first term whose source lies in level >= l0 (see k_tri_run_prefix64), no division.
+template <bool PREFIX>
+__device__ __forceinline__ void solve_row_rhs64(int32_t row, int rb, int nrhs, const int32_t *__restrict__ ptr,
+                                                const int32_t *__restrict__ idx, const double *__restrict__ val,
+                                                const double *__restrict__ diag, int skip_first, int skip_last, double *X,
+                                                int lane, const int32_t *__restrict__ resume_in,
+                                                const int32_t *__restrict__ level_of, int32_t l0, int32_t *resume_out) {
+    const int r = rb * 64 + lane;
+    const bool live = r < nrhs;
+    const int rr = live ? r : nrhs - 1;          // a valid address either way
+    const int32_t b = resume_in ? resume_in[row] : ptr[row] + skip_first, e = ptr[row + 1] - skip_last;
+    double acc = X[(int64_t)row * nrhs + rr];
+    int32_t ci = b + lane < e ? idx[b + lane] : 0;
+    double cv = b + lane < e ? val[b + lane] : 0.0;
+    int32_t stop_at = e;
+    for (int32_t q0 = b; q0 < e; q0 += 64) {
+        const int32_t qn = q0 + 64 + lane;
+        const int32_t cin = qn < e ? idx[qn] : 0;
+        const double cvn = qn < e ? val[qn] : 0.0;
+        int cnt = e - q0 < 64 ? e - q0 : 64;     // uniform
+        bool last = false;
+        if (PREFIX) {
+            const bool in_run = lane < cnt && level_of[ci] >= l0;
+            const unsigned long long m = __ballot(in_run);
+            if (m) {
+                const int first_in = __ffsll((long long)m) - 1;
+                cnt = first_in;
+                stop_at = q0 + first_in;
+                last = true;
+            }
+        }
+        const int clo = __double2loint(cv), chi = __double2hiint(cv);
+        double xa[16], xb[16];
+        auto gather = [&](int g, double *xv) {
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                const int32_t c = __builtin_amdgcn_readlane(ci, g + u);
+                xv[u] = X[(int64_t)c * nrhs + rr];
+            }
+        };
+        auto chain = [&](int g, const double *xv) {
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                const double v = __hiloint2double(__builtin_amdgcn_readlane(chi, g + u), __builtin_amdgcn_readlane(clo, g + u));
+                const double t = v * xv[u];
+                acc = g + u < cnt ? acc - t : acc;
+            }
+        };
+        if (cnt > 0) {
+            gather(0, xa);
+            if (cnt > 16) gather(16, xb);
+            chain(0, xa);
+            if (cnt > 16) {
+                if (cnt > 32) gather(32, xa);
+                chain(16, xb);
+                if (cnt > 32) {
+                    if (cnt > 48) gather(48, xb);
+                    chain(32, xa);
+                    if (cnt > 48) chain(48, xb);
+                }
+            }
+        }
+        if (last) break;
+        ci = cin;
+        cv = cvn;
+    }
+    if (PREFIX) {
+        if (live) X[(int64_t)row * nrhs + r] = acc;
+        if (rb == 0 && lane == 0) resume_out[row] = stop_at;
+    } else if (live) {
+        X[(int64_t)row * nrhs + r] = acc / diag[row];
+    }
+}
+
+// A RUN of narrow levels [l0, l1) (the separators at the top of a nested-dissection tree: a few rows per level, each
+// with thousands of terms) walked level by level costs rows x terms of serial latency.  But a row's terms come in
+// ascending source order and its leading ones -- usually nearly all -- have sources in levels BELOW the run, final
+// before the run starts.  So the run is done in two phases, 64 levels at a time: here, one launch over all rows of the
+// run at once, every (row, 64 right-hand sides) chain is run up to its first term whose source lies inside the run, the
+// partial sum stored in place (nobody reads x[row] before the row's own level) and the position kept in resume[row];
+// then the level walker takes each chain up where it stopped.  The chain itself is unchanged: same bits.
+__global__ __launch_bounds__(256) void k_tri_run_prefix64(const int32_t *__restrict__ order, int32_t first, int32_t count,
+                                                          int32_t l0, const int32_t *__restrict__ level_of,
+                                                          const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx,
+                                                          const double *__restrict__ val, int skip_first, int skip_last,
+                                                          double *X, int nrhs, int32_t *__restrict__ resume) {
+    const int lane = threadIdx.x & 63;
+    const int nblk = (nrhs + 63) >> 6;
+    const int64_t w = __builtin_amdgcn_readfirstlane((int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    if (w >= (int64_t)count * nblk) return;
+    const int32_t row = __builtin_amdgcn_readfirstlane(order[first + w / nblk]);
+    solve_row_rhs64<true>(row, (int)(w % nblk), nrhs, ptr, idx, val, nullptr, skip_first, skip_last, X, lane, nullptr,
+                          level_of, l0, resume);
+}
+
+__global__ __launch_bounds__(256) void k_tri_level_of(int32_t nlevels, const int32_t *__restrict__ level_ptr,
+                                                      const int32_t *__restrict__ order, int32_t n, int32_t *level_of) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    int32_t lo = 0, hi = nlevels;                    // level l holds positions [level_ptr[l], level_ptr[l + 1])
+    while (hi - lo > 1) {
+        const int32_t mid = (lo + hi) >> 1;
+        if (level_ptr[mid] <= q) lo = mid;
+        else hi = mid;
+    }
+    level_of[order[q]] = lo;
+}
+
+__global__ __launch_bounds__(256) void k_tri_level_rows64(const int32_t *__restrict__ order, int32_t first, int32_t count,
+                                                          const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx,
+                                                          const double *__restrict__ val, const double *__restrict__ diag,
+                                                          int skip_first, int skip_last, double *X, int nrhs) {
+    const int lane = threadIdx.x & 63;
+    const int nblk = (nrhs + 63) >> 6;
+    const int64_t w = __builtin_amdgcn_readfirstlane((int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    if (w >= (int64_t)count * nblk) return;
+    const int32_t row = __builtin_amdgcn_readfirstlane(order[first + w / nblk]);
+    solve_row_rhs64<false>(row, (int)(w % nblk), nrhs, ptr, idx, val, diag, skip_first, skip_last, X, lane, nullptr, nullptr, 0,
+                           nullptr);
+}
+
+__global__ __launch_bounds__(1024) void k_tri_levels_rows64_one_wg(const int32_t *__restrict__ order,
+                                                                   const int32_t *__restrict__ level_ptr, int32_t l0,
+                                                                   int32_t l1, const int32_t *__restrict__ ptr,
+                                                                   const int32_t *__restrict__ idx,
+                                                                   const double *__restrict__ val,
+                                                                   const double *__restrict__ diag, int skip_first,
+                                                                   int skip_last, double *X, int nrhs,
+                                                                   const int32_t *__restrict__ resume) {
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nblk = (nrhs + 63) >> 6;
+    for (int32_t l = l0; l < l1; l++) {
+        const int32_t first = level_ptr[l], count = level_ptr[l + 1] - first;
+        for (int32_t t = w; t < count * nblk; t += 16) {
+            const int32_t row = __builtin_amdgcn_readfirstlane(order[first + t / nblk]);
+            solve_row_rhs64<false>(row, t % nblk, nrhs, ptr, idx, val, diag, skip_first, skip_last, X, lane, resume, nullptr, 0,
+                                   nullptr);
+        }
+        __syncthreads();  // workgroup-scope release/acquire: the next level reads these x
+    }
+}
+
 template <int KIND>
 __global__ __launch_bounds__(TC_THREADS) void k_tri_columns(int32_t n, const int32_t *__restrict__ Tp,
                                                             const int32_t *__restrict__ Ti, const double *__restrict__ Tx,
@@ -1351,25 +1509,27 @@ __global__ __launch_bounds__(64) void k_tri_wcolchain(int32_t n, const int32_t *
 __global__ __launch_bounds__(256) void k_tri_band(int32_t n, const int32_t *__restrict__ Tp, const int32_t *__restrict__ Ti,
                                                   int lower, int *out) {
     const int lane = threadIdx.x & 63;
-    const int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (j >= n) return;
-    int32_t far = 0, link = 0, bad = 0;
-    const int32_t b = Tp[j], e = Tp[j + 1];
-    for (int32_t p = b + lane; p < e; p += 64) {
-        const int32_t d = Ti[p] - (int32_t)j;
-        const bool is_diag = lower ? p == b : p == e - 1;
-        bad |= is_diag ? d != 0 : (lower ? d <= 0 : d >= 0);
-        far = max(far, abs(d));
-        link |= abs(d) == 1;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    int32_t far = 0, links = 0, bad = 0;             // per wave, over its columns (one atomic each at the end)
+    for (int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; j < n; j += nwaves) {
+        int32_t link = 0;
+        const int32_t b = Tp[j], e = Tp[j + 1];
+        for (int32_t p = b + lane; p < e; p += 64) {
+            const int32_t d = Ti[p] - (int32_t)j;
+            const bool is_diag = lower ? p == b : p == e - 1;
+            bad |= is_diag ? d != 0 : (lower ? d <= 0 : d >= 0);
+            far = max(far, abs(d));
+            link |= abs(d) == 1;
+        }
+        links += __ballot(link) != 0ull;
     }
     for (int o = 32; o > 0; o >>= 1) {
         far = max(far, __shfl_xor(far, o));
-        link |= __shfl_xor(link, o);
         bad |= __shfl_xor(bad, o);
     }
     if (lane == 0) {
         atomicMax(out, far);
-        if (link) atomicAdd(out + 1, 1);
+        if (links) atomicAdd(out + 1, links);
         if (bad) out[2] = 1;
     }
 }
@@ -1942,7 +2102,7 @@ int tri_solve_raw(TriPlan *P, double *X, int32_t nrhs, bool relaxed) {
             int h[3] = {0, 0, 0};
             CSX_TRY(tmp.alloc(&o, 3));
             CSX_HIP(hipMemsetAsync(o, 0, 3 * sizeof(int), s));
-            hipLaunchKernelGGL(k_tri_band, dim3((unsigned)(((int64_t)P->n + 3) / 4)), dim3(256), 0, s, P->n, P->Tp, P->Ti,
+            hipLaunchKernelGGL(k_tri_band, dim3((unsigned)std::min<int64_t>(((int64_t)P->n + 3) / 4, 2048)), dim3(256), 0, s, P->n, P->Tp, P->Ti,
                                (P->kind == CSX_TRI_L || P->kind == CSX_TRI_LT) ? 1 : 0, o);
             CSX_HIP(hipMemcpyAsync(h, o, sizeof h, hipMemcpyDeviceToHost, s));
             CSX_HIP(hipStreamSynchronize(s));
@@ -2067,8 +2227,40 @@ int tri_solve_raw(TriPlan *P, double *X, int32_t nrhs, bool relaxed) {
     // few right-hand sides and long rows: a wave per row (k_tri_level_rows) instead of a thread per (row, right-hand side)
     const bool by_rows = nrhs <= TRW_MAX_RHS && P->n > 0 && (int64_t)P->gnnz >= (int64_t)TRW_MIN_ROW * P->n &&
                          ctx().opt.tri_row_waves;
+    // many right-hand sides and long rows: a wave per (row, 64 right-hand sides) (k_tri_level_rows64)
+    const bool by_rows64 = nrhs >= TR64_MIN_RHS && P->n > 0 && (int64_t)P->gnnz >= (int64_t)TRW_MIN_ROW * P->n &&
+                           ctx().opt.tri_row_waves;
     for (const Segment &g : P->segs) {
-        if (by_rows && g.one_wg) {
+        if (by_rows64 && g.one_wg) {
+            // runs of narrow levels in two phases, TR64_RUN levels at a time (see k_tri_run_prefix64)
+            if (!P->level_of && g.l1 - g.l0 >= TR64_RUN_MIN) {
+                CSX_TRY(dalloc(&P->level_of, (size_t)P->n));
+                CSX_TRY(dalloc(&P->resume, (size_t)P->n));
+                hipLaunchKernelGGL(k_tri_level_of, dim3((unsigned)(((int64_t)P->n + 255) / 256)), dim3(256), 0, s, P->nlevels,
+                                   P->level_ptr, P->order, P->n, P->level_of);
+            }
+            for (int32_t a = g.l0; a < g.l1;) {
+                const int32_t b = std::min(g.l1, a + TR64_RUN);
+                const bool two_phase = b - a >= TR64_RUN_MIN;
+                if (two_phase) {
+                    const int32_t first = P->level_ptr_h[(size_t)a], count = P->level_ptr_h[(size_t)b] - first;
+                    const int64_t waves = (int64_t)count * ((nrhs + 63) / 64);
+                    hipLaunchKernelGGL(k_tri_run_prefix64, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, P->order, first,
+                                       count, a, P->level_of, P->ptr, P->idx, P->val, P->skip_first, P->skip_last, X, nrhs,
+                                       P->resume);
+                }
+                hipLaunchKernelGGL(k_tri_levels_rows64_one_wg, dim3(1), dim3(1024), 0, s, P->order, P->level_ptr, a, b, P->ptr,
+                                   P->idx, P->val, P->diag, P->skip_first, P->skip_last, X, nrhs,
+                                   two_phase ? P->resume : nullptr);
+                a = b;
+            }
+        } else if (by_rows64) {
+            const int32_t first = P->level_ptr_h[(size_t)g.l0];
+            const int32_t count = P->level_ptr_h[(size_t)g.l0 + 1] - first;
+            const int64_t waves = (int64_t)count * ((nrhs + 63) / 64);
+            hipLaunchKernelGGL(k_tri_level_rows64, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, P->order, first, count,
+                               P->ptr, P->idx, P->val, P->diag, P->skip_first, P->skip_last, X, nrhs);
+        } else if (by_rows && g.one_wg) {
             hipLaunchKernelGGL(k_tri_levels_rows_one_wg, dim3(1), dim3(1024), 0, s, P->order, P->level_ptr, g.l0, g.l1, P->ptr,
                                P->idx, P->val, P->diag, P->skip_first, P->skip_last, X, nrhs);
         } else if (by_rows) {

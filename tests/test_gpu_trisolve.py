@@ -193,3 +193,27 @@ def test_cholsol_on_a_wide_band_factor_both_orders(cs):
                 assert got[:, r].tobytes() == ref[r].tobytes()
             else:
                 assert np.max(np.abs(got[:, r] - ref[r])) / np.max(np.abs(ref[r])) < 1e-12
+
+
+@pytest.mark.parametrize("k", [20, 70])
+def test_long_rows_with_many_right_hand_sides_take_a_wave_per_row_and_64_of_them(cs, k):
+    """bcsstk16 factored in the order-1 (nested dissection) ordering: a bushy tree, rows of 190 terms on average and
+    separator rows of thousands.  With 16 or more right-hand sides the level kernels give a wave to (row, 64
+    right-hand sides): indices and values by scalar loads, x as coalesced rows (k_tri_level_rows64).  Same
+    subtractions in the same order as cs_lsolve / cs_ltsolve: bit-identical, also with a partly filled last block."""
+    g = golden("bcsstk16")
+    C = cs.cs_pin(unpack(cs, g, "C"))
+    n = C.n
+    S = cs.cs_schol(1, C)
+    N = cs.cs_chol(C, S)
+    L = N.L
+    lnz = L.p[n]
+    Lp, Li, Lx = np.asarray(L.p, np.int32), np.asarray(L.i[:lnz], np.int32), np.asarray(L.x[:lnz], np.float64)
+    cs.cs_pin(L)
+    B = synth.rhs(n, k, 21)
+    for nm, ref in (("lsolve", CO.lsolve), ("ltsolve", CO.ltsolve)):
+        X = cs.dvec(B)
+        assert _solvers(cs)[nm](L, X) is True
+        got = X.numpy()
+        for r in (0, 1, 15, 19, k - 6, k - 1):
+            assert got[:, r].tobytes() == ref(n, Lp, Li, Lx, B[:, r]).tobytes(), (nm, r)
