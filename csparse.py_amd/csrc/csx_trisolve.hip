@@ -948,6 +948,7 @@ __global__ __launch_bounds__(256) void k_group_caps(int32_t ncomp, int cpw, cons
 #pragma clang fp contract(off)
 constexpr int TC_THREADS = 256;
 constexpr int TC_MAX_N = 15360;
+constexpr int TR64_RUN = 64, TR64_RUN_MIN = 8;   // levels per two-phase run of narrow levels; shorter runs: one phase
 constexpr int TRW_MAX_RHS = 4, TRW_MIN_ROW = 24;   // a wave per row: at most so many right-hand sides, rows at least so long on average
 
 // The gather kinds (L', U') on ONE wave: every lane forms one product of the column, then lane 0 subtracts them in
@@ -1086,29 +1087,49 @@ __global__ __launch_bounds__(64) void k_tri_colchain(int32_t n, const int32_t *_
 // thousands of terms (the separator rows of a nested-dissection factor) a handful of threads walk them alone.  Here a
 // wave takes a row: the lanes fetch 64 terms at a time and multiply them by their x (all final: earlier levels), and
 // lane 0 subtracts the products in the reference's order as in k_tri_colchain -- the same bits as solve_one.
+// The gathers of x run one block of 64 terms ahead of the chain and the (index, value) loads two blocks ahead.
+// PREFIX (first phase of a two-phase run of narrow levels, see k_tri_run_prefix64 below): the chain stops in front of
+// the first term whose source lies in level >= l0; the partial sum is stored in place, the position in resume_out.
+template <bool PREFIX>
 __device__ __forceinline__ void solve_row_wave(int32_t row, int nrhs, const int32_t *__restrict__ ptr,
                                                const int32_t *__restrict__ idx, const double *__restrict__ val,
                                                const double *__restrict__ diag, int skip_first, int skip_last, double *X,
-                                               int lane, double *cbuf) {
-    const int32_t b = ptr[row] + skip_first, e = ptr[row + 1] - skip_last;
-    const double dg = diag[row];
+                                               int lane, double *cbuf, const int32_t *__restrict__ resume_in,
+                                               const int32_t *__restrict__ level_of, int32_t l0, int32_t *resume_out) {
+    const int32_t b = resume_in ? resume_in[row] : ptr[row] + skip_first, e = ptr[row + 1] - skip_last;
+    const double dg = PREFIX ? 1.0 : diag[row];
+    int32_t stop_at = e;
     for (int r = 0; r < nrhs; r++) {
         double acc = X[(int64_t)row * nrhs + r];
-        int32_t q = b + lane;
-        int32_t ci = q < e ? idx[q] : 0;
-        double cv = q < e ? val[q] : 0.0;
+        int32_t ci0 = b + lane < e ? idx[b + lane] : 0, ci1 = b + 64 + lane < e ? idx[b + 64 + lane] : 0;
+        double cv0 = b + lane < e ? val[b + lane] : 0.0, cv1 = b + 64 + lane < e ? val[b + 64 + lane] : 0.0;
+        double xv0 = X[(int64_t)ci0 * nrhs + r];
+        int32_t lv0 = PREFIX ? level_of[ci0] : 0;
         for (int32_t q0 = b; q0 < e; q0 += 64) {
-            const double xv = X[(int64_t)ci * nrhs + r];
-            const int32_t qn = q0 + 64 + lane;             // the next 64 terms ride behind the gathers
-            const int32_t cin = qn < e ? idx[qn] : 0;
-            const double cvn = qn < e ? val[qn] : 0.0;
-            const double p = q0 + lane < e ? cv * xv : 0.0;
-            acc = tch_chain_lds(acc, p, e - q0, cbuf, lane);
-            ci = cin;
-            cv = cvn;
+            const int32_t q2 = q0 + 128 + lane;            // two blocks ahead: indices and values
+            const int32_t ci2 = q2 < e ? idx[q2] : 0;
+            const double cv2 = q2 < e ? val[q2] : 0.0;
+            const double xv1 = X[(int64_t)ci1 * nrhs + r];   // one block ahead: the gathers
+            const int32_t lv1 = PREFIX ? level_of[ci1] : 0;
+            int32_t cnt = e - q0;
+            bool last = false;
+            if (PREFIX) {
+                const unsigned long long m = __ballot(q0 + lane < e && lv0 >= l0);
+                if (m) {
+                    cnt = __ffsll((long long)m) - 1;
+                    stop_at = q0 + cnt;
+                    last = true;
+                }
+            }
+            const double p = lane < cnt ? cv0 * xv0 : 0.0;
+            if (cnt > 0) acc = tch_chain_lds(acc, p, cnt, cbuf, lane);
+            if (last) break;
+            ci0 = ci1; cv0 = cv1; xv0 = xv1; lv0 = lv1;
+            ci1 = ci2; cv1 = cv2;
         }
-        if (lane == 0) X[(int64_t)row * nrhs + r] = acc / dg;
+        if (lane == 0) X[(int64_t)row * nrhs + r] = PREFIX ? acc : acc / dg;
     }
+    if (PREFIX && lane == 0) resume_out[row] = stop_at;
 }
 
 __global__ __launch_bounds__(256) void k_tri_level_rows(const int32_t *__restrict__ order, int32_t first, int32_t count,
@@ -1119,7 +1140,22 @@ __global__ __launch_bounds__(256) void k_tri_level_rows(const int32_t *__restric
     const int lane = threadIdx.x & 63;
     const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (w >= count) return;
-    solve_row_wave(order[first + w], nrhs, ptr, idx, val, diag, skip_first, skip_last, X, lane, cbuf[threadIdx.x >> 6]);
+    solve_row_wave<false>(order[first + w], nrhs, ptr, idx, val, diag, skip_first, skip_last, X, lane, cbuf[threadIdx.x >> 6],
+                          nullptr, nullptr, 0, nullptr);
+}
+
+// first phase of a two-phase run of narrow levels, a wave per row of the run (few right-hand sides)
+__global__ __launch_bounds__(256) void k_tri_run_prefix_rows(const int32_t *__restrict__ order, int32_t first, int32_t count,
+                                                             int32_t l0, const int32_t *__restrict__ level_of,
+                                                             const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx,
+                                                             const double *__restrict__ val, int skip_first, int skip_last,
+                                                             double *X, int nrhs, int32_t *__restrict__ resume) {
+    __shared__ __attribute__((aligned(16))) double cbuf[4][64];
+    const int lane = threadIdx.x & 63;
+    const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (w >= count) return;
+    solve_row_wave<true>(order[first + w], nrhs, ptr, idx, val, nullptr, skip_first, skip_last, X, lane, cbuf[threadIdx.x >> 6],
+                         nullptr, level_of, l0, resume);
 }
 
 __global__ __launch_bounds__(1024) void k_tri_levels_rows_one_wg(const int32_t *__restrict__ order,
@@ -1128,12 +1164,15 @@ __global__ __launch_bounds__(1024) void k_tri_levels_rows_one_wg(const int32_t *
                                                                  const int32_t *__restrict__ idx,
                                                                  const double *__restrict__ val,
                                                                  const double *__restrict__ diag, int skip_first,
-                                                                 int skip_last, double *X, int nrhs) {
+                                                                 int skip_last, double *X, int nrhs,
+                                                                 const int32_t *__restrict__ resume) {
     __shared__ __attribute__((aligned(16))) double cbuf[16][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int32_t l = l0; l < l1; l++) {
         const int32_t first = level_ptr[l], count = level_ptr[l + 1] - first;
-        for (int32_t t = w; t < count; t += 16) solve_row_wave(order[first + t], nrhs, ptr, idx, val, diag, skip_first, skip_last, X, lane, cbuf[w]);
+        for (int32_t t = w; t < count; t += 16)
+            solve_row_wave<false>(order[first + t], nrhs, ptr, idx, val, diag, skip_first, skip_last, X, lane, cbuf[w], resume,
+                                  nullptr, 0, nullptr);
         __syncthreads();  // workgroup-scope release/acquire: the next level reads these x
     }
 }
@@ -1145,7 +1184,6 @@ __global__ __launch_bounds__(1024) void k_tri_levels_rows_one_wg(const int32_t *
 // coalesced 512-byte row of X, and a chunk of 16 terms is 16 independent loads per lane with the next chunk behind it.
 // Same subtractions in the same order as solve_one: same bits.
 constexpr int TR64_MIN_RHS = 16;
-constexpr int TR64_RUN = 64, TR64_RUN_MIN = 8;   // levels per two-phase run of narrow levels; shorter runs: one phase
 
 // The chain of one (row, 64 right-hand sides).  A row's terms are fetched 64 at a time, one per lane (coalesced, the
 // next 64 requested before these are used), and handed round by v_readlane: a term's source index becomes a scalar
@@ -2261,8 +2299,26 @@ int tri_solve_raw(TriPlan *P, double *X, int32_t nrhs, bool relaxed) {
             hipLaunchKernelGGL(k_tri_level_rows64, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, P->order, first, count,
                                P->ptr, P->idx, P->val, P->diag, P->skip_first, P->skip_last, X, nrhs);
         } else if (by_rows && g.one_wg) {
-            hipLaunchKernelGGL(k_tri_levels_rows_one_wg, dim3(1), dim3(1024), 0, s, P->order, P->level_ptr, g.l0, g.l1, P->ptr,
-                               P->idx, P->val, P->diag, P->skip_first, P->skip_last, X, nrhs);
+            if (!P->level_of && g.l1 - g.l0 >= TR64_RUN_MIN) {
+                CSX_TRY(dalloc(&P->level_of, (size_t)P->n));
+                CSX_TRY(dalloc(&P->resume, (size_t)P->n));
+                hipLaunchKernelGGL(k_tri_level_of, dim3((unsigned)(((int64_t)P->n + 255) / 256)), dim3(256), 0, s, P->nlevels,
+                                   P->level_ptr, P->order, P->n, P->level_of);
+            }
+            for (int32_t a = g.l0; a < g.l1;) {
+                const int32_t b = std::min(g.l1, a + TR64_RUN);
+                const bool two_phase = b - a >= TR64_RUN_MIN;
+                if (two_phase) {
+                    const int32_t first = P->level_ptr_h[(size_t)a], count = P->level_ptr_h[(size_t)b] - first;
+                    hipLaunchKernelGGL(k_tri_run_prefix_rows, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, s, P->order, first,
+                                       count, a, P->level_of, P->ptr, P->idx, P->val, P->skip_first, P->skip_last, X, nrhs,
+                                       P->resume);
+                }
+                hipLaunchKernelGGL(k_tri_levels_rows_one_wg, dim3(1), dim3(1024), 0, s, P->order, P->level_ptr, a, b, P->ptr,
+                                   P->idx, P->val, P->diag, P->skip_first, P->skip_last, X, nrhs,
+                                   two_phase ? P->resume : nullptr);
+                a = b;
+            }
         } else if (by_rows) {
             const int32_t first = P->level_ptr_h[(size_t)g.l0];
             const int32_t count = P->level_ptr_h[(size_t)g.l0 + 1] - first;

@@ -195,25 +195,36 @@ def test_cholsol_on_a_wide_band_factor_both_orders(cs):
                 assert np.max(np.abs(got[:, r] - ref[r])) / np.max(np.abs(ref[r])) < 1e-12
 
 
-@pytest.mark.parametrize("k", [20, 70])
-def test_long_rows_with_many_right_hand_sides_take_a_wave_per_row_and_64_of_them(cs, k):
-    """bcsstk16 factored in the order-1 (nested dissection) ordering: a bushy tree, rows of 190 terms on average and
-    separator rows of thousands.  With 16 or more right-hand sides the level kernels give a wave to (row, 64
-    right-hand sides): indices and values by scalar loads, x as coalesced rows (k_tri_level_rows64).  Same
-    subtractions in the same order as cs_lsolve / cs_ltsolve: bit-identical, also with a partly filled last block."""
-    g = golden("bcsstk16")
-    C = cs.cs_pin(unpack(cs, g, "C"))
-    n = C.n
-    S = cs.cs_schol(1, C)
-    N = cs.cs_chol(C, S)
+@pytest.mark.parametrize("k", [1, 3, 20, 70])
+def test_long_rows_on_a_bushy_tree_take_a_wave_per_row(cs, k):
+    """A 200 x 200 grid Laplacian factored in the order-1 (nested dissection) ordering: n = 40 000, a bushy tree, rows
+    of 35 terms on average and separator rows of thousands, hundreds of narrow levels at the top.  Up to 4 right-hand
+    sides: a wave per row, products through LDS to lane 0 (k_tri_level_rows); 16 or more: a wave per (row, 64
+    right-hand sides), terms handed round by v_readlane (k_tri_level_rows64); runs of narrow levels in two phases
+    (k_tri_run_prefix_rows / k_tri_run_prefix64, then the level walkers).  5..15 right-hand sides: a thread per (row,
+    right-hand side).  Same subtractions in the same order as cs_lsolve / cs_ltsolve (csparse.py:1330-1365):
+    bit-identical, also with a partly filled last block of 64."""
+    from test_gpu_cholesky import _grid_laplacian
+    n, p, i, x = _grid_laplacian(200, 200)
+    A = cs.cs_spalloc(n, n, len(i), True, False)
+    A.p, A.i, A.x = p.tolist(), i.tolist(), x.tolist()
+    cs.cs_pin(A)
+    S = cs.cs_schol(1, A)
+    N = cs.cs_chol(A, S)
     L = N.L
     lnz = L.p[n]
+    assert lnz >= 24 * n                                  # long rows on average: the wave-per-row kernels are chosen
     Lp, Li, Lx = np.asarray(L.p, np.int32), np.asarray(L.i[:lnz], np.int32), np.asarray(L.x[:lnz], np.float64)
     cs.cs_pin(L)
     B = synth.rhs(n, k, 21)
     for nm, ref in (("lsolve", CO.lsolve), ("ltsolve", CO.ltsolve)):
-        X = cs.dvec(B)
+        X = cs.dvec(B if k > 1 else B[:, 0].copy())
         assert _solvers(cs)[nm](L, X) is True
-        got = X.numpy()
-        for r in (0, 1, 15, 19, k - 6, k - 1):
+        got = X.numpy().reshape(n, k)
+        for r in sorted({0, 1 % k, (k - 6) % k, k - 1}):
             assert got[:, r].tobytes() == ref(n, Lp, Li, Lx, B[:, r]).tobytes(), (nm, r)
+
+
+def test_five_to_fifteen_right_hand_sides_on_the_same_factor(cs):
+    """Between the two wave-per-row kernels: 9 right-hand sides go to the thread-per-(row, right-hand side) kernels."""
+    test_long_rows_on_a_bushy_tree_take_a_wave_per_row(cs, 9)
