@@ -2132,8 +2132,10 @@ int tri_solve_raw(TriPlan *P, double *X, int32_t nrhs, bool relaxed) {
     if (P->n == 0 || nrhs == 0) return CSX_OK;
     if (ctx().opt.tri_components) CSX_TRY(analyse_components(P));
     if (P->comp_ok && ctx().opt.tri_components) return solve_components(P, X, nrhs);
-    // chain-like, too big for x to sit in LDS, but banded: the column loops on a window of x (no level analysis at all)
-    if (ctx().opt.tri_columns && P->n > TC_MAX_N) {
+    // One pass over the pattern tells a banded chain from the rest: band width, share of columns with a neighbour link,
+    // proper triangle.  Such a system goes to the column loops without any level analysis -- x in LDS when it fits,
+    // a window of x otherwise.
+    if (ctx().opt.tri_columns) {
         if (P->band < 0) {
             DevScope tmp;
             int *o = nullptr;
@@ -2159,7 +2161,7 @@ int tri_solve_raw(TriPlan *P, double *X, int32_t nrhs, bool relaxed) {
         uint32_t Wn = 64;
         while ((int64_t)Wn < (int64_t)P->band + 4 && Wn < (1u << 20)) Wn <<= 1;
         const bool chainlike = (int64_t)P->links * 12 > (int64_t)P->n * 11;   // nearly every column hands on to its neighbour
-        if (chainlike && P->band != 0x7fffffff && (size_t)Wn * sizeof(double) <= 128 * 1024) {
+        if (P->n > TC_MAX_N && chainlike && P->band != 0x7fffffff && (size_t)Wn * sizeof(double) <= 128 * 1024) {
             const size_t lds = (size_t)Wn * sizeof(double);
             const bool push = P->kind == CSX_TRI_L || P->kind == CSX_TRI_U;
             const TriPlan *M = P->mate;
@@ -2206,15 +2208,27 @@ int tri_solve_raw(TriPlan *P, double *X, int32_t nrhs, bool relaxed) {
             }
         }
     }
-    CSX_TRY(ensure_schedule(P));
-    if (P->sequential) {
-        hipLaunchKernelGGL(k_tri_sequential, dim3((unsigned)((nrhs + 63) / 64)), dim3(64), 0, s, P->kind, P->n, P->Tp,
-                           P->Ti, P->Tx, X, nrhs);
-        CSX_LAUNCH_CHECK();
+    // a proper triangle whose columns nearly all hand on to their neighbour is a chain whatever its level sets say
+    const bool chain_by_links = ctx().opt.tri_columns && P->band >= 0 && P->band != 0x7fffffff &&
+                                (int64_t)P->links * 12 > (int64_t)P->n * 11;
+    auto schedule_or_literal = [&](bool *done) -> int {
+        *done = false;
+        CSX_TRY(ensure_schedule(P));
+        if (P->sequential) {
+            hipLaunchKernelGGL(k_tri_sequential, dim3((unsigned)((nrhs + 63) / 64)), dim3(64), 0, s, P->kind, P->n, P->Tp,
+                               P->Ti, P->Tx, X, nrhs);
+            CSX_LAUNCH_CHECK();
+            *done = true;
+        }
         return CSX_OK;
+    };
+    bool done = false;
+    if (!(chain_by_links && P->n <= TC_MAX_N)) {
+        CSX_TRY(schedule_or_literal(&done));
+        if (done) return CSX_OK;
     }
     // small and chain-like: the column loop, one wave per right-hand side, beats any schedule
-    if (ctx().opt.tri_columns && P->n <= TC_MAX_N && (int64_t)P->nlevels * 12 > P->n) {
+    if (ctx().opt.tri_columns && P->n <= TC_MAX_N && (chain_by_links || (int64_t)P->nlevels * 12 > P->n)) {
         if (P->col_state == 0) {
             P->col_state = 1;
             if (P->kind == CSX_TRI_L || P->kind == CSX_TRI_U) {   // gather structure of a push kind = stable transpose
@@ -2257,6 +2271,10 @@ int tri_solve_raw(TriPlan *P, double *X, int32_t nrhs, bool relaxed) {
             CSX_LAUNCH_CHECK();
             return CSX_OK;
         }
+    }
+    if (!P->scheduled) {                 // the column loops did not apply after all (duplicate rows, x too long for LDS)
+        CSX_TRY(schedule_or_literal(&done));
+        if (done) return CSX_OK;
     }
     // the exact chain walker is already the fast one when in-block sources come last: relax only the others
     relaxed = relaxed && !P->chain_ok;
