@@ -42,11 +42,89 @@ def ragged(rng, m, n, mean_len, maxlen=None):
 
 t_end = time.time() + budget
 seed = 0
-counts = {"transpose": 0, "multiply": 0, "spsolve": 0, "trisolve": 0, "cholesky": 0}
+counts = {"transpose": 0, "multiply": 0, "spsolve": 0, "trisolve": 0, "cholesky": 0, "band_trisolve": 0, "band_cholesky": 0}
+
+
+def random_band_lower(rng, n, band, keep):
+    """strictly lower band with a share `keep` of its entries (the first sub-diagonal always), as scipy CSC."""
+    import scipy.sparse as sp
+    diags, offs = [], []
+    for d in range(1, band + 1):
+        v = rng.uniform(-1, 1, size=n - d)
+        if d > 1:
+            v = v * (rng.random(n - d) < keep)
+        diags.append(v)
+        offs.append(-d)
+    M = sp.diags(diags, offs, shape=(n, n), format="csc")
+    M.eliminate_zeros()
+    return M
+
+
 while time.time() < t_end:
     seed += 1
     rng = np.random.default_rng(1000 + seed)
     kind = seed % 5
+    if seed % 7 == 0:  # banded chains too big for x to sit in LDS (window kernels), 1 .. 70 right-hand sides (wave-per-row
+        import scipy.sparse as sp                       # kernels when the rows are long), all four kinds, bit for bit
+        n = int(rng.choice([15400, 22000, 40000]))
+        band = int(rng.choice([4, 60, 300]))
+        keep = float(rng.choice([1.0, 0.5]))
+        k = int(rng.choice([1, 3, 20, 70]))
+        Lw = random_band_lower(rng, n, band, keep)
+        L = (Lw + sp.diags(rng.uniform(2.0, 4.0, size=n) * (1 + band))).tocsc()
+        L.sort_indices()
+        U = L.T.tocsc()
+        U.sort_indices()
+        B = rng.uniform(-1, 1, size=(n, k))
+        for fn, ofn, M in ((cs.cs_lsolve, CO.lsolve, L), (cs.cs_ltsolve, CO.ltsolve, L), (cs.cs_usolve, CO.usolve, U),
+                           (cs.cs_utsolve, CO.utsolve, U)):
+            Tp, Ti, Tx = M.indptr.astype(np.int32), M.indices.astype(np.int32), M.data.astype(np.float64)
+            A = cs.cs_pin(host(cs, n, n, Tp, Ti, Tx))
+            dB = cs.dvec(B if k > 1 else B[:, 0].copy())
+            assert fn(A, dB) is True
+            Xk = dB.numpy().reshape(n, k)
+            for r in sorted({0, k // 2, k - 1}):
+                assert Xk[:, r].tobytes() == ofn(n, Tp, Ti, Tx, B[:, r]).tobytes(), ("band trisolve", seed, fn.__name__, n, band, keep, k, r)
+        counts["band_trisolve"] += 1
+        continue
+    if seed % 7 == 3:  # banded SPD matrices with a chain tree: the blocked dense-band cs_chol (band > 80) and the register
+        import scipy.sparse as sp                       # window below, bit for bit against the plain-C oracle; cholsol both orders
+        n = int(rng.choice([600, 2100, 5000]))
+        band = int(rng.choice([30, 90, 200, 400]))
+        band = min(band, n - 1)
+        keep = float(rng.choice([1.0, 0.6]))
+        Lw = random_band_lower(rng, n, band, keep)
+        Sm = (Lw + Lw.T).tocsc()
+        diag = np.asarray(abs(Sm).sum(axis=0)).ravel() + rng.uniform(1.0, 2.0, size=n)
+        Sm = (Sm + sp.diags(diag)).tocsc()
+        Sm.sort_indices()
+        Cp, Ci, Cx = Sm.indptr.astype(np.int32), Sm.indices.astype(np.int32), Sm.data.astype(np.float64)
+        parent, cp = CO.schol(n, Cp, Ci)
+        Lp, Li, Lx = CO.chol(n, Cp, Ci, Cx, parent, cp)
+        A = cs.cs_pin(host(cs, n, n, Cp, Ci, Cx))
+        S = cs.cs_schol(0, A)
+        N = cs.cs_chol(A, S)
+        assert N is not None, ("band chol returned None", seed, n, band)
+        lnz = int(Lp[-1])
+        assert N.L.p == Lp.tolist() and N.L.i[:lnz] == Li.tolist(), ("band chol pattern", seed, n, band)
+        got = np.asarray(N.L.x[:lnz])
+        chain = bool(np.all(parent[:-1] == np.arange(1, n)))
+        if chain and n > 512:
+            assert got.tobytes() == Lx.tobytes(), ("band chol bits", seed, n, band, keep)
+        else:
+            assert float(np.max(np.abs(got - Lx))) <= 1e-13 * max(1.0, float(np.max(np.abs(Lx)))), ("band chol values", seed, n, band)
+        b = rng.uniform(-1, 1, size=(n, 2))
+        z = [CO.ltsolve(n, Lp, Li, Lx, CO.lsolve(n, Lp, Li, Lx, b[:, r])) for r in range(2)]
+        for exact in (True, False):
+            F = cs.cholsol_factor(A, 0, exact=exact)
+            X = cs.dvec(b)
+            assert F.solve(X) is True
+            Xn = X.numpy()
+            for r in range(2):
+                err = float(np.max(np.abs(Xn[:, r] - z[r]))) / max(1.0, float(np.max(np.abs(z[r]))))
+                assert err <= (1e-13 if exact else 1e-10), ("band cholsol", seed, n, band, exact, err)
+        counts["band_cholesky"] += 1
+        continue
     if kind == 3:      # the four triangular solves, list and 3-column device block, bit for bit: random, banded (chain
         n = int(rng.choice([1, 3, 70, 500, 2500]))          # kernels), block-diagonal (component kernels)
         shape = int(rng.integers(0, 3))
