@@ -991,10 +991,12 @@ __device__ __forceinline__ double tch_chain_lds(double acc, double p, int cnt, d
     for (int q = 0; q < 8; q++) cur[q] = b2[q];
 #pragma unroll
     for (int g = 0; g < 64; g += 16) {
-        if (g + 16 < 64 && g + 16 < cnt) {     // uniform
+        // the next block is requested whether or not it will be used: with the request under a branch the compiler
+        // has to wait for EVERY outstanding read before the first subtraction (the two paths differ in how many there
+        // are), which puts one LDS latency per 16 terms back on the chain
 #pragma unroll
-            for (int q = 0; q < 8; q++) nxt[q] = b2[(g + 16) / 2 + q];
-        }
+        for (int q = 0; q < 8; q++) nxt[q] = b2[((g + 16) & 63) / 2 + q];
+        __builtin_amdgcn_sched_barrier(0);     // ... and BEFORE this block's subtractions
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             acc = acc - cur[q].x;
