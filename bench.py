@@ -437,7 +437,8 @@ def main():
         bc.SKIP_CPU = args.skip_cpu
         other = {}
         for name, fn in (("config2_gaxpy_bcsstk16", bc.config2), ("config3_lusol_W", bc.config3),
-                         ("transpose_grand_5M", bc.transpose_grand), ("config4_multiply_S", bc.config4)):
+                         ("transpose_grand_5M", bc.transpose_grand), ("config4_multiply_S", bc.config4),
+                         ("cholsol_connected", bc.cholsol_connected)):
             try:
                 other[name] = fn()
             except Exception as e:                        # never take the headline down with it

@@ -380,10 +380,67 @@ def transpose_grand(n=5000000, per_col=64):
             "double_transpose_restores_p": bool((p1 == p2).all()), "cpu_baseline": cpu}
 
 
+def cholsol_connected(grid=300):
+    """cs_cholsol on CONNECTED problems (one component, unlike the block forest of the headline's cholsol leg): the
+    reference's own matrix bcsstk16 (config 2's matrix, csparse_test.py:525) and a grid x grid 5-point Laplacian, in
+    natural order (a chain tree, band = grid: blocked dense-band cs_chol, windowed column solves) and in the order-1
+    nested-dissection ordering (bushy tree: level kernels, wave-per-row solves).  Exact order: bit-identical to
+    cs_lsolve + cs_ltsolve.  Beside each: the plain-C port on one host core (same algorithm, natural order)."""
+    import c_oracle as CO
+    import scipy.sparse as sp
+    out = {}
+
+    def run(name, n, p, i, x, orders, cpu=True):
+        A = cs.cs_pin(host_cs(n, n, p, i, x))
+        b = np.linspace(1.0, 2.0, n)
+        res = {"n": n, "nnz": int(len(i))}
+        for order in orders:
+            _csx.sync()
+            t0 = time.perf_counter(); S = cs.cs_schol(order, A); _csx.sync(); t1 = time.perf_counter()
+            N = cs.cs_chol(A, S); _csx.sync(); t2 = time.perf_counter()
+            N = cs.cs_chol(A, S); _csx.sync(); t3 = time.perf_counter()
+            r = {"lnz": int(S.lnz), "cs_schol_ms": round((t1 - t0) * 1e3, 2), "cs_chol_ms": round((t3 - t2) * 1e3, 2)}
+            xb = cs.dvec(b.copy())
+            t0 = time.perf_counter(); ok = cs.cs_cholsol(order, A, xb); _csx.sync()
+            r["cs_cholsol_one_shot_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
+            xv = xb.numpy()
+            Am = sp.csc_matrix((x, i, p), shape=(n, n))
+            r["residual_inf"] = float(np.max(np.abs(Am @ xv - b))) if ok else None
+            for exact in (True, False):
+                F = cs.cholsol_factor(A, order, exact=exact)
+                for k in (1, 64):
+                    B = cs.dvec(np.repeat(b[:, None], k, axis=1) if k > 1 else b.copy())
+                    F.solve(B); _csx.sync()
+                    t0 = time.perf_counter(); F.solve(B); _csx.sync()
+                    r["solve_ms_%s_k%d" % ("exact" if exact else "rounding_equal", k)] = round((time.perf_counter() - t0) * 1e3, 2)
+            res["order_%d" % order] = r
+        if cpu and not SKIP_CPU:
+            t0 = time.perf_counter()
+            parent, cp = CO.schol(n, p, i)
+            Lp, Li, Lx = CO.chol(n, p, i, x, parent, cp)
+            t1 = time.perf_counter()
+            z = CO.ltsolve(n, Lp, Li, Lx, CO.lsolve(n, Lp, Li, Lx, b))
+            t2 = time.perf_counter()
+            res["plain_c_one_core_natural_order"] = {"schol_plus_chol_ms": round((t1 - t0) * 1e3, 1),
+                                                     "lsolve_plus_ltsolve_ms": round((t2 - t1) * 1e3, 2), "kind": "port", "cores": 1}
+        out[name] = res
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", "bcsstk16.npz"))
+    run("bcsstk16", 4884, g["C_p"].astype(np.int32), g["C_i"].astype(np.int32), g["C_x"], (0, 1))
+    n = grid * grid
+    T = sp.diags([-1, 2, -1], [-1, 0, 1], shape=(grid, grid))
+    A = (sp.kron(sp.identity(grid), T) + sp.kron(T, sp.identity(grid)) + 0.01 * sp.identity(n)).tocsc()
+    A.sort_indices()
+    run("grid_%dx%d_laplacian" % (grid, grid), n, A.indptr.astype(np.int32), A.indices.astype(np.int32),
+        A.data.astype(np.float64), (0, 1), cpu=grid <= 300)
+    return {"config": "cs_cholsol on connected problems: bcsstk16 and a %d x %d grid Laplacian, natural order and order 1" % (grid, grid),
+            "results": out}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-spgemm", action="store_true")
-    ap.add_argument("--only", default=None, help="run one section: spmv | lusolve | spgemm | transpose | assembly")
+    ap.add_argument("--only", default=None, help="run one section: spmv | lusolve | spgemm | transpose | assembly | connected")
     ap.add_argument("--skip-transpose", action="store_true")
     ap.add_argument("--skip-cpu", action="store_true", help="no one-core CPU baselines beside the GPU figures")
     a = ap.parse_args()
@@ -402,6 +459,8 @@ def main():
         print(json.dumps(config4()))
     if want("assembly"):
         print(json.dumps(assembly()))
+    if want("connected"):
+        print(json.dumps(cholsol_connected()))
 
 
 if __name__ == "__main__":

@@ -2163,14 +2163,15 @@ int tri_solve_raw(TriPlan *P, double *X, int32_t nrhs, bool relaxed) {
         uint32_t Wn = 64;
         while ((int64_t)Wn < (int64_t)P->band + 4 && Wn < (1u << 20)) Wn <<= 1;
         const bool chainlike = (int64_t)P->links * 12 > (int64_t)P->n * 11;   // nearly every column hands on to its neighbour
-        if (P->n > TC_MAX_N && chainlike && P->band != 0x7fffffff && (size_t)Wn * sizeof(double) <= 128 * 1024) {
+        if (chainlike && P->band != 0x7fffffff && (size_t)Wn * sizeof(double) <= 128 * 1024) {
             const size_t lds = (size_t)Wn * sizeof(double);
+            const bool big = P->n > TC_MAX_N;       // x of one right-hand side does not fit LDS: only the window kernels apply
             const bool push = P->kind == CSX_TRI_L || P->kind == CSX_TRI_U;
             const TriPlan *M = P->mate;
-            // rounding-equal order, L': the rows of L (the mate's gather arrays) pushed as the columns of L'
+            // rounding-equal order, L' (any size): the rows of L (the mate's gather arrays) pushed as the columns of L'
             const bool mate_push = !push && relaxed && P->kind == CSX_TRI_LT && M && M->kind == CSX_TRI_L && M->owns_g &&
                                    M->col_state == 1 && M->n == P->n;
-            if ((push && P->col_state == 1) || mate_push) {
+            if ((big && push && P->col_state == 1) || mate_push) {
                 const int32_t *cp = mate_push ? M->ptr : P->Tp, *ci = mate_push ? M->idx : P->Ti;
                 const double *cx = mate_push ? M->val : P->Tx, *cd = mate_push ? M->diag : P->diag;
                 const int sf = (!mate_push && P->kind == CSX_TRI_L) ? 1 : 0, sl = (!mate_push && P->kind == CSX_TRI_U) ? 1 : 0;
@@ -2190,7 +2191,7 @@ int tri_solve_raw(TriPlan *P, double *X, int32_t nrhs, bool relaxed) {
                 CSX_LAUNCH_CHECK();
                 return CSX_OK;
             }
-            if (!push) {
+            if (big && !push) {
 #define CSX_WCH(K, R)                                                                                              \
     {                                                                                                              \
         CSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tri_wcolchain<K, R>),                        \
