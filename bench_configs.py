@@ -400,9 +400,11 @@ def cholsol_connected(grid=300):
             N = cs.cs_chol(A, S); _csx.sync(); t2 = time.perf_counter()
             N = cs.cs_chol(A, S); _csx.sync(); t3 = time.perf_counter()
             r = {"lnz": int(S.lnz), "cs_schol_ms": round((t1 - t0) * 1e3, 2), "cs_chol_ms": round((t3 - t2) * 1e3, 2)}
-            xb = cs.dvec(b.copy())
-            t0 = time.perf_counter(); ok = cs.cs_cholsol(order, A, xb); _csx.sync()
-            r["cs_cholsol_one_shot_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
+            for rep in range(2):                     # the second call: kernels loaded, pool grown (the first pays ~80 ms once per process)
+                xb = cs.dvec(b.copy())
+                _csx.sync()
+                t0 = time.perf_counter(); ok = cs.cs_cholsol(order, A, xb); _csx.sync()
+                r["cs_cholsol_one_shot_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
             xv = xb.numpy()
             Am = sp.csc_matrix((x, i, p), shape=(n, n))
             r["residual_inf"] = float(np.max(np.abs(Am @ xv - b))) if ok else None
