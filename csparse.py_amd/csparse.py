@@ -798,37 +798,58 @@ def cs_pvec(p, b, x, n):
 
 # ------------------------------------------------------------- Cholesky ----
 
+def _pattern_np(A):
+    """Column pointers and row indices of A as int32 arrays: straight from the device copy when there is one (a pinned
+    or device-made matrix: that copy is the matrix), else from the lists."""
+    n = A.n
+    if A._dev is not None:
+        m_, n_, nnz, hv = A._dev.info()
+        p = np.empty(n + 1, dtype=np.int32)
+        i = np.empty(max(nnz, 1), dtype=np.int32)
+        _csx.check(_csx.lib().csx_csc_download(A._dev.handle, _csx.pi(p), _csx.pi(i), None), "csx_csc_download")
+        return p, i[:nnz]
+    p = _csx.i32(A.p[:n + 1])
+    return p, _csx.i32(A.i[:int(p[n])])
+
+
+def _amd_np(order, A):
+    if not CS_CSC(A) or order != 1 or A.m != A.n:
+        return None
+    n = A.n
+    p, i = _pattern_np(A)
+    perm = np.empty(max(n, 1), dtype=np.int32)
+    if _csx.load().csx_order_nd_host(n, _csx.pi(p), _csx.pi(i), _csx.pi(perm)) != _csx.OK:
+        return None
+    return perm[:n]
+
+
 def cs_amd(order, A):
     """Fill-reducing ordering p (csparse.py:214-556), order 1 = for Cholesky of A (pattern of A + A').
     The reference's implementation does not run, so there is no permutation to match:
     this is a nested dissection, which gives the device a bushy elimination tree.  Orders 2 and 3
     (LU / QR, pattern of A'A) are not provided: None."""
-    if not CS_CSC(A) or order != 1 or A.m != A.n:
-        return None
-    n = A.n
-    p = _csx.i32(A.p[:n + 1])
-    i = _csx.i32(A.i[:int(p[n])])
-    perm = np.empty(max(n, 1), dtype=np.int32)
-    if _csx.load().csx_order_nd_host(n, _csx.pi(p), _csx.pi(i), _csx.pi(perm)) != _csx.OK:
-        return None
-    return perm[:n].tolist()
+    perm = _amd_np(order, A)
+    return None if perm is None else perm.tolist()
 
 
-def cs_schol(order, A):
+def cs_schol(order, A, _arrays=False):
     """Symbolic Cholesky analysis (csparse.py:2051-2072): ordering, etree, column counts.  order 0 =
     natural; order 1 = cs_amd (here a nested dissection).  The tree is built by host C++ inside libcsx,
-    the column counts on the device when A is resident there."""
+    the column counts on the device when A is resident there.  (_arrays: internal -- S.parent / S.cp / S.pinv stay
+    int32 arrays instead of becoming lists; cs_cholsol and cholsol_factor, which keep S to themselves, use it to skip
+    half a dozen list conversions of length n.)"""
     if not CS_CSC(A) or order not in (0, 1):
         return None
     if order == 1:
-        P = cs_amd(1, A)
+        P = _amd_np(1, A)
         if P is None:
             return None
-        pinv = cs_pinv(P, A.n)
+        pinv = np.empty(A.n, dtype=np.int32)
+        pinv[P] = np.arange(A.n, dtype=np.int32)          # cs_pinv (csparse.py:1696-1708)
         C = cs_symperm(A, pinv, False)
-        S = cs_schol(0, C)
+        S = cs_schol(0, C, _arrays)
         if S is not None:
-            S.pinv = pinv
+            S.pinv = pinv if _arrays else pinv.tolist()
         return S
     n = A.n
     parent = np.empty(max(n, 1), dtype=np.int32)
@@ -845,9 +866,9 @@ def cs_schol(order, A):
     S = css()
     S.pinv = None
     S.q = None
-    S.parent = parent[:n].tolist()
-    S.cp = cp.tolist()
-    S.unz = S.lnz = S.cp[n]
+    S.parent = parent[:n] if _arrays else parent[:n].tolist()
+    S.cp = cp if _arrays else cp.tolist()
+    S.unz = S.lnz = int(cp[n])
     return S
 
 
@@ -943,7 +964,7 @@ def cs_cholsol(order, A, b):
     if not CS_CSC(A) or b is None:
         return False
     n = A.n
-    S = cs_schol(order, A)
+    S = cs_schol(order, A, _arrays=True)
     N = cs_chol(A, S) if S is not None else None
     if S is None or N is None:
         return False
@@ -967,11 +988,15 @@ def cholsol_factor(A, order=0, exact=True):
     exact=False: equal to rounding (within the 1e-10 budget) and faster -- dense blocks go to the matrix cores
     (blocked TRSM with explicit tile inverses, refused when an inverse is large), and the level-scheduled solve
     of a big elimination tree may reorder a row's subtractions (out-of-block terms first)."""
-    S = cs_schol(order, A)
+    S = cs_schol(order, A, _arrays=True)
     N = cs_chol(A, S) if S is not None else None
     if N is None:
         return None
     pinv = None if S.pinv is None else _csx.i32(S.pinv)
+    for name in ("parent", "cp", "pinv"):                  # the solver exposes S: lists, as cs_schol returns them
+        v = getattr(S, name)
+        if v is not None and not isinstance(v, list):
+            setattr(S, name, v.tolist())
     plan = _csx.new_handle()
     with _Resident(N.L) as dL:
         _csx.check(_csx.lib().csx_cholsol_plan(dL.handle, _csx.pi(pinv), plan), "csx_cholsol_plan")

@@ -51,6 +51,7 @@ struct TriPlan;
 int tri_solve_raw(TriPlan *P, double *X, int32_t nrhs, bool relaxed);
 int tri_analyse_raw(const Csc *T, int kind, TriPlan **out);
 void tri_set_mate(TriPlan *P, TriPlan *mate);
+void tri_set_level_hint(TriPlan *P, std::vector<int32_t> &&level);
 void tri_gather_arrays(const TriPlan *P, const int32_t **ptr, const int32_t **idx, const double **val,
                        const double **diag);
 
@@ -1383,7 +1384,26 @@ static int cholsol_plan(const Csc *L, const int32_t *pinv, CholPlan **out) {
     if (unsorted) return CSX_OK;
     Forest F;
     partition_forest(n, parent.data(), F);
-    if (!F.level_cols.empty() || F.max_tree > 256) return CSX_OK;  // some tree is too big for LDS
+    if (!F.level_cols.empty() || F.max_tree > 256) {   // some tree is too big for LDS: the level-scheduled solves
+    {
+            // The level sets of the two solves with a Cholesky factor are heights (L x = b) and depths (L' x = b) in its
+            // elimination tree: proposed to the plans, which verify them in one pass over the pattern instead of finding
+            // them level by level (a nested-dissection factor of a 700 x 700 grid has ~3 000 levels).
+            bool tree = true;
+            for (int32_t j = 0; j < n && tree; j++) tree = parent[(size_t)j] < 0 || (parent[(size_t)j] > j && parent[(size_t)j] < n);
+            if (tree) {
+                std::vector<int32_t> height((size_t)n, 0), depth((size_t)n, 0);
+                for (int32_t j = 0; j < n; j++)
+                    if (parent[(size_t)j] >= 0)
+                        height[(size_t)parent[(size_t)j]] = std::max(height[(size_t)parent[(size_t)j]], height[(size_t)j] + 1);
+                for (int32_t j = n - 1; j >= 0; j--)
+                    if (parent[(size_t)j] >= 0) depth[(size_t)j] = depth[(size_t)parent[(size_t)j]] + 1;
+                tri_set_level_hint(P->fwd, std::move(height));
+                tri_set_level_hint(P->bwd, std::move(depth));
+            }
+        }
+        return CSX_OK;
+    }
     std::vector<int32_t> local((size_t)n, 0);
     for (const Tree &t : F.small)
         for (int32_t a = 0; a < t.count; a++) local[(size_t)F.small_cols[(size_t)(t.first + a)]] = a;

@@ -10,6 +10,11 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "csx_internal.h"
@@ -137,13 +142,19 @@ void nd_build_graph(int32_t n, const int32_t *Ap, const int32_t *Ai, NdGraph &G)
         }
 }
 
-// breadth-first search inside the part `tag` (part[v] == tag); fills order[] / level_of[]; returns the number of levels
-int32_t nd_bfs(const NdGraph &G, const std::vector<int32_t> &part, int32_t tag, int32_t root, std::vector<int32_t> &mark,
-               int32_t stamp, std::vector<int32_t> &order, std::vector<int32_t> &level_start) {
+// breadth-first search inside the part `tag` (part[v] == tag); fills order[] / level_start[]; returns the number of
+// levels.  part / mark are shared by the worker threads: a thread writes only vertices of the part it owns, and reads
+// of other parts' entries only ever compare unequal (tags and stamps are unique), hence relaxed atomics.
+using AtomicVec = std::unique_ptr<std::atomic<int32_t>[]>;
+inline int32_t ld(const AtomicVec &a, int32_t i) { return a[(size_t)i].load(std::memory_order_relaxed); }
+inline void st(AtomicVec &a, int32_t i, int32_t v) { a[(size_t)i].store(v, std::memory_order_relaxed); }
+
+int32_t nd_bfs(const NdGraph &G, const AtomicVec &part, int32_t tag, int32_t root, AtomicVec &mark, int32_t stamp,
+               std::vector<int32_t> &order, std::vector<int32_t> &level_start) {
     order.clear();
     level_start.clear();
     order.push_back(root);
-    mark[(size_t)root] = stamp;
+    st(mark, root, stamp);
     size_t head = 0;
     while (head < order.size()) {
         level_start.push_back((int32_t)head);
@@ -152,8 +163,8 @@ int32_t nd_bfs(const NdGraph &G, const std::vector<int32_t> &part, int32_t tag, 
             const int32_t v = order[head];
             for (int32_t q = G.ptr[(size_t)v]; q < G.ptr[(size_t)v + 1]; q++) {
                 const int32_t u = G.adj[(size_t)q];
-                if (part[(size_t)u] == tag && mark[(size_t)u] != stamp) {
-                    mark[(size_t)u] = stamp;
+                if (ld(part, u) == tag && ld(mark, u) != stamp) {
+                    st(mark, u, stamp);
                     order.push_back(u);
                 }
             }
@@ -162,6 +173,128 @@ int32_t nd_bfs(const NdGraph &G, const std::vector<int32_t> &part, int32_t tag, 
     level_start.push_back((int32_t)order.size());
     return (int32_t)level_start.size() - 1;
 }
+
+struct NdJob {
+    int32_t tag, out_lo;             // the part and where its vertices go in perm
+    std::vector<int32_t> verts;
+};
+
+// The recursion as a pool of jobs: the two halves of a cut are independent, so after a few levels every worker has
+// parts of its own.  The ordering does not depend on which thread takes which part (a part's numbering is a function
+// of its vertex list and the graph alone).
+struct NdPool {
+    const NdGraph &G;
+    int32_t *perm;
+    AtomicVec part, mark;
+    std::atomic<int32_t> next_tag{1}, stamp{0};
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<NdJob> jobs;
+    int pending = 0;                 // jobs queued or being worked on
+
+    NdPool(const NdGraph &g, int32_t *p) : G(g), perm(p) {
+        part.reset(new std::atomic<int32_t>[(size_t)std::max(g.n, 1)]);
+        mark.reset(new std::atomic<int32_t>[(size_t)std::max(g.n, 1)]);
+        for (int32_t v = 0; v < g.n; v++) {
+            st(part, v, 0);
+            st(mark, v, -1);
+        }
+    }
+    void push(NdJob &&j) {
+        std::lock_guard<std::mutex> lock(mu);
+        jobs.push_back(std::move(j));
+        pending++;
+        cv.notify_one();
+    }
+    bool pop(NdJob &j) {
+        std::unique_lock<std::mutex> lock(mu);
+        cv.wait(lock, [&] { return !jobs.empty() || pending == 0; });
+        if (jobs.empty()) return false;
+        j = std::move(jobs.back());
+        jobs.pop_back();
+        return true;
+    }
+    void finished() {
+        std::lock_guard<std::mutex> lock(mu);
+        if (--pending == 0) cv.notify_all();
+    }
+    void work() {
+        std::vector<int32_t> order, level_start;
+        NdJob job;
+        while (pop(job)) {
+            run(job, order, level_start);
+            finished();
+        }
+    }
+    void run(NdJob &job, std::vector<int32_t> &order, std::vector<int32_t> &level_start) {
+        const int32_t sz = (int32_t)job.verts.size();
+        if (sz == 0) return;
+        // one connected component at a time: the rest goes back to the pool as its own part
+        int32_t stp = ++stamp;
+        nd_bfs(G, part, job.tag, job.verts[0], mark, stp, order, level_start);
+        if ((int32_t)order.size() < sz) {
+            NdJob rest;
+            rest.tag = next_tag++;
+            rest.out_lo = job.out_lo + (int32_t)order.size();
+            for (int32_t v : job.verts)
+                if (ld(mark, v) != stp) {
+                    rest.verts.push_back(v);
+                    st(part, v, rest.tag);
+                }
+            push(std::move(rest));
+        }
+        const int32_t csz = (int32_t)order.size();
+        // pseudo-peripheral root: restart from a vertex of the last level (smallest degree), twice
+        for (int sweep = 0; sweep < 2 && csz > ND_LEAF; sweep++) {
+            const int32_t nl = (int32_t)level_start.size() - 1;
+            int32_t far = order[(size_t)level_start[(size_t)nl - 1]];
+            for (int32_t q = level_start[(size_t)nl - 1]; q < level_start[(size_t)nl]; q++) {
+                const int32_t v = order[(size_t)q];
+                if (G.ptr[(size_t)v + 1] - G.ptr[(size_t)v] < G.ptr[(size_t)far + 1] - G.ptr[(size_t)far]) far = v;
+            }
+            stp = ++stamp;
+            nd_bfs(G, part, job.tag, far, mark, stp, order, level_start);
+        }
+        const int32_t nl = (int32_t)level_start.size() - 1;
+        if (csz <= ND_LEAF || nl < 3) {   // leaf (or too shallow to cut): breadth-first numbering
+            for (int32_t q = 0; q < csz; q++) perm[job.out_lo + q] = order[(size_t)q];
+            return;
+        }
+        // separator = the level at which half of the component has been passed (never the first or last level)
+        int32_t s = 1;
+        while (s < nl - 2 && level_start[(size_t)s + 1] < csz / 2) s++;
+        const int32_t a_end = level_start[(size_t)s], b_begin = level_start[(size_t)s + 1];
+        // thin the separator: only the vertices of level s that touch level s + 1 have to be in it; the others
+        // stay with the first half (every path into the second half leaves level s through such a vertex)
+        const int32_t next_mark = -2 - stp;
+        for (int32_t q = b_begin; q < level_start[(size_t)s + 2]; q++) st(mark, order[(size_t)q], next_mark);  // level s+1
+        NdJob A, B;
+        A.tag = next_tag++;
+        B.tag = next_tag++;
+        A.verts.assign(order.begin(), order.begin() + a_end);
+        std::vector<int32_t> sep;
+        for (int32_t q = a_end; q < b_begin; q++) {
+            const int32_t v = order[(size_t)q];
+            bool touches = false;
+            for (int32_t e = G.ptr[(size_t)v]; e < G.ptr[(size_t)v + 1] && !touches; e++)
+                touches = ld(mark, G.adj[(size_t)e]) == next_mark;
+            if (touches) sep.push_back(v);
+            else A.verts.push_back(v);
+        }
+        B.verts.assign(order.begin() + b_begin, order.end());
+        A.out_lo = job.out_lo;
+        B.out_lo = job.out_lo + (int32_t)A.verts.size();
+        for (int32_t v : A.verts) st(part, v, A.tag);
+        for (int32_t v : B.verts) st(part, v, B.tag);
+        int32_t out = B.out_lo + (int32_t)B.verts.size();     // the separator goes last
+        for (int32_t v : sep) {
+            st(part, v, -1);
+            perm[out++] = v;
+        }
+        push(std::move(A));
+        push(std::move(B));
+    }
+};
 }  // namespace
 
 }  // namespace csx
@@ -173,90 +306,25 @@ extern "C" int csx_order_nd_host(int32_t n, const int32_t *Ap, const int32_t *Ai
     for (int32_t j = 0; j < n; j++)
         for (int32_t p = Ap[j]; p < Ap[j + 1]; p++)
             if (Ai[p] < 0 || Ai[p] >= n) return CSX_EINVAL;
+    if (n == 0) return CSX_OK;
     NdGraph G;
     nd_build_graph(n, Ap, Ai, G);
-    std::vector<int32_t> part((size_t)n, 0), mark((size_t)n, -1), order, level_start, best_order, best_levels;
-    struct Job {
-        int32_t tag, out_lo;             // the part and where its vertices go in perm
-        std::vector<int32_t> verts;
-    };
-    std::vector<Job> jobs;
+    NdPool pool(G, perm);
     {
-        Job all;
+        NdJob all;
         all.tag = 0;
         all.out_lo = 0;
         all.verts.resize((size_t)n);
         for (int32_t v = 0; v < n; v++) all.verts[(size_t)v] = v;
-        jobs.push_back(std::move(all));
+        pool.push(std::move(all));
     }
-    int32_t next_tag = 1, stamp = 0;
-    while (!jobs.empty()) {
-        Job job = std::move(jobs.back());
-        jobs.pop_back();
-        const int32_t sz = (int32_t)job.verts.size();
-        if (sz == 0) continue;
-        // one connected component at a time: the rest goes back on the stack as its own part
-        nd_bfs(G, part, job.tag, job.verts[0], mark, ++stamp, order, level_start);
-        if ((int32_t)order.size() < sz) {
-            Job rest;
-            rest.tag = next_tag++;
-            rest.out_lo = job.out_lo + (int32_t)order.size();
-            for (int32_t v : job.verts)
-                if (mark[(size_t)v] != stamp) {
-                    rest.verts.push_back(v);
-                    part[(size_t)v] = rest.tag;
-                }
-            jobs.push_back(std::move(rest));
-        }
-        const int32_t csz = (int32_t)order.size();
-        // pseudo-peripheral root: restart from a vertex of the last level (smallest degree), twice
-        for (int sweep = 0; sweep < 2 && csz > ND_LEAF; sweep++) {
-            const int32_t nl = (int32_t)level_start.size() - 1;
-            int32_t far = order[(size_t)level_start[(size_t)nl - 1]];
-            for (int32_t q = level_start[(size_t)nl - 1]; q < level_start[(size_t)nl]; q++) {
-                const int32_t v = order[(size_t)q];
-                if (G.ptr[(size_t)v + 1] - G.ptr[(size_t)v] < G.ptr[(size_t)far + 1] - G.ptr[(size_t)far]) far = v;
-            }
-            nd_bfs(G, part, job.tag, far, mark, ++stamp, order, level_start);
-        }
-        const int32_t nl = (int32_t)level_start.size() - 1;
-        if (csz <= ND_LEAF || nl < 3) {   // leaf (or too shallow to cut): breadth-first numbering
-            for (int32_t q = 0; q < csz; q++) perm[job.out_lo + q] = order[(size_t)q];
-            continue;
-        }
-        // separator = the level at which half of the component has been passed (never the first or last level)
-        int32_t s = 1;
-        while (s < nl - 2 && level_start[(size_t)s + 1] < csz / 2) s++;
-        const int32_t a_end = level_start[(size_t)s], b_begin = level_start[(size_t)s + 1];
-        // thin the separator: only the vertices of level s that touch level s + 1 have to be in it; the others
-        // stay with the first half (every path into the second half leaves level s through such a vertex)
-        for (int32_t q = b_begin; q < level_start[(size_t)s + 2]; q++) mark[(size_t)order[(size_t)q]] = -2 - stamp;  // level s+1
-        Job A, B;
-        A.tag = next_tag++;
-        B.tag = next_tag++;
-        A.verts.assign(order.begin(), order.begin() + a_end);
-        std::vector<int32_t> sep;
-        for (int32_t q = a_end; q < b_begin; q++) {
-            const int32_t v = order[(size_t)q];
-            bool touches = false;
-            for (int32_t e = G.ptr[(size_t)v]; e < G.ptr[(size_t)v + 1] && !touches; e++)
-                touches = mark[(size_t)G.adj[(size_t)e]] == -2 - stamp;
-            if (touches) sep.push_back(v);
-            else A.verts.push_back(v);
-        }
-        B.verts.assign(order.begin() + b_begin, order.end());
-        A.out_lo = job.out_lo;
-        B.out_lo = job.out_lo + (int32_t)A.verts.size();
-        for (int32_t v : A.verts) part[(size_t)v] = A.tag;
-        for (int32_t v : B.verts) part[(size_t)v] = B.tag;
-        int32_t out = B.out_lo + (int32_t)B.verts.size();     // the separator goes last
-        for (int32_t v : sep) {
-            part[(size_t)v] = -1;
-            perm[out++] = v;
-        }
-        jobs.push_back(std::move(A));
-        jobs.push_back(std::move(B));
-    }
+    // small problems: one thread (the pool costs more than it saves); else up to eight workers
+    unsigned workers = 1;
+    if (n >= 20000) workers = std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    std::vector<std::thread> threads;
+    for (unsigned t = 1; t < workers; t++) threads.emplace_back([&pool] { pool.work(); });
+    pool.work();
+    for (auto &t : threads) t.join();
     return CSX_OK;
 }
 

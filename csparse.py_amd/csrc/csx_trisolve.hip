@@ -78,6 +78,7 @@ struct TriPlan {
     // measured yet) and the number of columns with an entry next to the diagonal (a chain link)
     int32_t band = -1, links = 0;
     TriPlan *mate = nullptr;         // plan of the transposed solve on the same matrix (cholsol: L for L'), not owned
+    std::vector<int32_t> level_hint; // levels proposed by the caller (cholsol: elimination-tree heights / depths); verified before use
     // two-phase runs of narrow levels (k_tri_run_prefix64): level of every row, and per row where its chain resumes
     int32_t *level_of = nullptr, *resume = nullptr;
     int32_t *cptr = nullptr, *cidx = nullptr;   // push kinds (L, U): per sweep position the COLUMN's entries
@@ -1976,39 +1977,32 @@ __global__ __launch_bounds__(256) void k_lv_chain_tables(int32_t n, const uint32
 constexpr int64_t LV_DEVICE_MIN_TERMS = 4 << 20;   // below this the copy is small and deep chains favour the host pass
 constexpr int LV_MAX_ROUNDS = 512;     // a round costs ~80 us whatever it finds: deeper than this, one sequential host pass wins
 
-// *done = false: not attempted or gave up (too deep) -> the host pass runs instead
-static int schedule_on_device(TriPlan *P, bool *done) {
-    *done = false;
+// Every term's source must lie in a lower level than its row (and on the proper side of the diagonal): what makes a
+// proposed level array a valid schedule, whether or not it is the shallowest one.  stats[0]: rows with a violation.
+__global__ __launch_bounds__(256) void k_lv_verify(int32_t n, const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx,
+                                                   int sf, int sl, int forward, const int32_t *__restrict__ level, int *stats) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (r >= n) return;
+    const int32_t lr = level[r];
+    bool bad = lr < 0;
+    for (int32_t q = ptr[r] + sf + lane; q < ptr[r + 1] - sl; q += 64) {
+        const int32_t j = idx[q];
+        if (j < 0 || j >= n || (forward ? j >= r : j <= r)) bad = true;
+        else if (level[j] >= lr) bad = true;
+    }
+    if (__ballot(bad) != 0ull && lane == 0) stats[0] = 1;
+}
+
+// rows by level, level boundaries and the chain walker's tables from a device array of levels (L of them)
+static int schedule_from_levels(TriPlan *P, const int32_t *level, int32_t L) {
     hipStream_t s = ctx().stream;
     const int32_t n = P->n;
     DevScope tmp;
-    int32_t *level = nullptr, *pos_of = nullptr;
+    int32_t *pos_of = nullptr;
     uint32_t *rows = nullptr, *slevel = nullptr, *order = nullptr;
-    int *stats = nullptr;
     unsigned long long *sums = nullptr;
-    CSX_TRY(tmp.alloc(&level, (size_t)n));
-    CSX_TRY(tmp.alloc(&stats, 2));
-    const unsigned nb = (unsigned)(((int64_t)n + 255) / 256), nbw = (unsigned)(((int64_t)n + 3) / 4);
-    hipLaunchKernelGGL(k_lv_init, dim3(nb), dim3(256), 0, s, n, level);
-    int64_t resolved = 0;
-    int32_t L = 0;
-    for (; resolved < n; L++) {
-        if (L >= LV_MAX_ROUNDS) return CSX_OK;                 // a deep chain: the host pass is the better tool
-        int h[2] = {0, 0};
-        CSX_HIP(hipMemsetAsync(stats, 0, 2 * sizeof(int), s));
-        hipLaunchKernelGGL(k_lv_round, dim3(nbw), dim3(256), 0, s, n, P->ptr, P->idx, P->skip_first, P->skip_last,
-                           P->forward ? 1 : 0, L, level, stats);
-        CSX_HIP(hipMemcpyAsync(h, stats, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
-        CSX_HIP(hipStreamSynchronize(s));
-        if (h[1] || h[0] == 0) {                               // malformed triangle: literal transcription of the loop
-            P->scheduled = true;
-            P->sequential = true;
-            P->nlevels = n;
-            *done = true;
-            return CSX_OK;
-        }
-        resolved += h[0];
-    }
+    const unsigned nb = (unsigned)(((int64_t)n + 255) / 256);
     P->nlevels = L;
     // rows by level, ascending row inside a level (stable sort of 0..n-1 by level)
     CSX_TRY(tmp.alloc(&rows, (size_t)n));
@@ -2037,6 +2031,72 @@ static int schedule_on_device(TriPlan *P, bool *done) {
     CSX_HIP(hipStreamSynchronize(s));
     P->chain_ok = hs[1] > 0 && hs[0] * 4 <= hs[1];
     P->scheduled = true;
+    return CSX_OK;
+}
+
+// Levels proposed by the caller (cholsol_plan: heights / depths in the elimination tree, which ARE the level sets of a
+// Cholesky factor's two solves): one verification pass over the pattern instead of one round per level.
+static int schedule_from_hint(TriPlan *P, bool *done) {
+    *done = false;
+    hipStream_t s = ctx().stream;
+    const int32_t n = P->n;
+    if ((int32_t)P->level_hint.size() != n) return CSX_OK;
+    int32_t L = 0;
+    for (int32_t v : P->level_hint) {
+        if (v < 0) return CSX_OK;
+        L = std::max(L, v + 1);
+    }
+    DevScope tmp;
+    int32_t *level = nullptr;
+    int *stats = nullptr;
+    CSX_TRY(tmp.alloc(&level, (size_t)n));
+    CSX_TRY(tmp.alloc(&stats, 1));
+    CSX_HIP(hipMemcpyAsync(level, P->level_hint.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    CSX_HIP(hipMemsetAsync(stats, 0, sizeof(int), s));
+    hipLaunchKernelGGL(k_lv_verify, dim3((unsigned)(((int64_t)n + 3) / 4)), dim3(256), 0, s, n, P->ptr, P->idx, P->skip_first,
+                       P->skip_last, P->forward ? 1 : 0, level, stats);
+    int bad = 0;
+    CSX_HIP(hipMemcpyAsync(&bad, stats, sizeof(int), hipMemcpyDeviceToHost, s));
+    CSX_HIP(hipStreamSynchronize(s));
+    std::vector<int32_t>().swap(P->level_hint);
+    if (bad) return CSX_OK;                 // not the factor the hint was made for: the general analysis runs
+    CSX_TRY(schedule_from_levels(P, level, L));
+    *done = true;
+    return CSX_OK;
+}
+
+// *done = false: not attempted or gave up (too deep) -> the host pass runs instead
+static int schedule_on_device(TriPlan *P, bool *done) {
+    *done = false;
+    hipStream_t s = ctx().stream;
+    const int32_t n = P->n;
+    DevScope tmp;
+    int32_t *level = nullptr;
+    int *stats = nullptr;
+    CSX_TRY(tmp.alloc(&level, (size_t)n));
+    CSX_TRY(tmp.alloc(&stats, 2));
+    const unsigned nb = (unsigned)(((int64_t)n + 255) / 256), nbw = (unsigned)(((int64_t)n + 3) / 4);
+    hipLaunchKernelGGL(k_lv_init, dim3(nb), dim3(256), 0, s, n, level);
+    int64_t resolved = 0;
+    int32_t L = 0;
+    for (; resolved < n; L++) {
+        if (L >= LV_MAX_ROUNDS) return CSX_OK;                 // a deep chain: the host pass is the better tool
+        int h[2] = {0, 0};
+        CSX_HIP(hipMemsetAsync(stats, 0, 2 * sizeof(int), s));
+        hipLaunchKernelGGL(k_lv_round, dim3(nbw), dim3(256), 0, s, n, P->ptr, P->idx, P->skip_first, P->skip_last,
+                           P->forward ? 1 : 0, L, level, stats);
+        CSX_HIP(hipMemcpyAsync(h, stats, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+        CSX_HIP(hipStreamSynchronize(s));
+        if (h[1] || h[0] == 0) {                               // malformed triangle: literal transcription of the loop
+            P->scheduled = true;
+            P->sequential = true;
+            P->nlevels = n;
+            *done = true;
+            return CSX_OK;
+        }
+        resolved += h[0];
+    }
+    CSX_TRY(schedule_from_levels(P, level, L));
     *done = true;
     return CSX_OK;
 }
@@ -2048,6 +2108,11 @@ static int ensure_schedule(TriPlan *P) {
     hipStream_t s = ctx().stream;
     const int32_t n = P->n;
     const int where = ctx().opt.tri_levels_where;   // 0: by size, 1: host, 2: device
+    if (!P->level_hint.empty() && where != 1) {
+        bool done = false;
+        CSX_TRY(schedule_from_hint(P, &done));
+        if (done) return CSX_OK;
+    }
     if (where == 2 || (where == 0 && (int64_t)P->gnnz >= LV_DEVICE_MIN_TERMS)) {
         bool done = false;
         CSX_TRY(schedule_on_device(P, &done));
@@ -2366,6 +2431,7 @@ int tri_solve_raw(TriPlan *P, double *X, int32_t nrhs, bool relaxed) {
 
 int tri_analyse_raw(const Csc *T, int kind, TriPlan **out) { return analyse(T, kind, out); }
 void tri_set_mate(TriPlan *P, TriPlan *mate) { P->mate = mate; }
+void tri_set_level_hint(TriPlan *P, std::vector<int32_t> &&level) { P->level_hint = std::move(level); }
 
 void tri_gather_arrays(const TriPlan *P, const int32_t **ptr, const int32_t **idx, const double **val,
                        const double **diag) {
