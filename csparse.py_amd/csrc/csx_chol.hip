@@ -217,13 +217,16 @@ __global__ __launch_bounds__(64 * CC_WAVES) void k_chol_coop(const int32_t *__re
                                                             const int32_t *__restrict__ row_col,
                                                             const int32_t *__restrict__ row_pos, int32_t n, int *notspd,
                                                             const int32_t *__restrict__ col_level, int mode,
-                                                            int32_t lf) {
+                                                            int32_t lf, int32_t *__restrict__ split) {
     // mode 0: every update of a column, then pivot and scaling.  A long RUN of narrow levels lf .. (the separators at
     // the top of a nested-dissection tree: thousands of columns, a few per level) is done in two phases instead.
     // mode 1, one launch, one workgroup per column of the whole run (levels l0 .. l1-1): the updates that come from
     // columns BELOW the run (level < lf) -- all final before the run starts, so every column of the run takes them at
     // the same time -- and the partly updated column is stored.  mode 2, level after level as in mode 0: the updates
     // from INSIDE the run (level >= lf), then pivot and scaling.  col_level[k] = level of column k, -1 off the list.
+    // A row's updates are listed in ascending column order and a nested-dissection ordering numbers the separators
+    // last, so the inside updates are the tail of the list: mode 1 leaves the position of the first one in split[j]
+    // (atomicMin) and mode 2 starts there instead of reading thousands of descriptors to find a few dozen.
     extern __shared__ __attribute__((aligned(16))) unsigned char cc_smem[];
     double *part = reinterpret_cast<double *>(cc_smem);             // W partial columns of `len` doubles
     int32_t *acc_r = reinterpret_cast<int32_t *>(part + CC_ACC);    // the column's row indices (<= CC_ACC kept)
@@ -247,7 +250,8 @@ __global__ __launch_bounds__(64 * CC_WAVES) void k_chol_coop(const int32_t *__re
             for (int32_t t = tid; t < W * len; t += 64 * CC_WAVES) part[t] = 0.0;
             __syncthreads();
             const int32_t *rows = W ? acc_r : Li + base;
-            const int32_t qb = row_ptr[j], qe = row_ptr[j + 1] - 1;   // the row view ends with the diagonal
+            const int32_t qe = row_ptr[j + 1] - 1;                     // the row view ends with the diagonal
+            const int32_t qb = mode == 2 ? max(row_ptr[j], min(split[j], qe)) : row_ptr[j];
             const int Wq = W ? W : 1;
             if (w < Wq) {
                 double *mine = part + (size_t)w * len;
@@ -260,6 +264,7 @@ __global__ __launch_bounds__(64 * CC_WAVES) void k_chol_coop(const int32_t *__re
                         if (lane < CC_Q && qu < qe) {
                             const int32_t kq = row_col[qu];
                             const bool inside = mode != 0 && col_level[kq] >= lf;
+                            if (mode == 1 && inside) atomicMin(&split[j], qu);
                             if (mode == 0 || (mode == 1) != inside) {   // mode 1 takes the outside, mode 2 the inside
                                 posq = row_pos[qu];
                                 kendq = Lp[kq + 1];
@@ -676,7 +681,11 @@ static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, c
     if (st == CSX_OK) st = upload(&d_small_cols, F.small_cols);
     if (st == CSX_OK) st = upload(&d_level_cols, F.level_cols);
     if (st == CSX_OK) st = upload(&d_level_ptr, F.level_ptr);
-    int32_t *d_col_level = nullptr;
+    int32_t *d_col_level = nullptr, *d_split = nullptr;
+    if (st == CSX_OK && !F.level_cols.empty()) {
+        st = dalloc(&d_split, (size_t)n);
+        if (st == CSX_OK) (void)hipMemsetAsync(d_split, 0x7f, (size_t)n * sizeof(int32_t), s);   // "no inside update seen"
+    }
     if (st == CSX_OK && !F.level_cols.empty()) {
         std::vector<int32_t> col_level((size_t)n, -1);
         for (size_t lv = 0; lv + 1 < F.level_ptr.size(); lv++)
@@ -756,7 +765,7 @@ static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, c
             if (two_phase)                           // updates from below the run, for all of its columns at once
                 hipLaunchKernelGGL(k_chol_coop, dim3((unsigned)(F.level_ptr[(size_t)e] - F.level_ptr[(size_t)l])),
                                    dim3(64 * CC_WAVES), cc_lds, s, d_level_cols, d_level_ptr, l, e, L->p, L->i, L->x, d_rp, d_rc,
-                                   d_rpos, n, d_flags + 1, d_col_level, 1, l);
+                                   d_rpos, n, d_flags + 1, d_col_level, 1, l, d_split);
             for (int32_t a = l; a < e;) {
                 // a level with several columns: a workgroup each in one launch; single-column levels in a row (a chain):
                 // one workgroup walks them without coming back to the host
@@ -764,7 +773,8 @@ static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, c
                 if (width(a) == 1)
                     while (b < e && width(b) == 1) b++;
                 hipLaunchKernelGGL(k_chol_coop, dim3((unsigned)width(a)), dim3(64 * CC_WAVES), cc_lds, s, d_level_cols, d_level_ptr,
-                                   a, b, L->p, L->i, L->x, d_rp, d_rc, d_rpos, n, d_flags + 1, d_col_level, two_phase ? 2 : 0, l);
+                                   a, b, L->p, L->i, L->x, d_rp, d_rc, d_rpos, n, d_flags + 1, d_col_level, two_phase ? 2 : 0, l,
+                                   d_split);
                 a = b;
             }
             l = e;
@@ -789,6 +799,7 @@ static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, c
     dfree(d_level_cols);
     dfree(d_level_ptr);
     dfree(d_col_level);
+    dfree(d_split);
     if (st != CSX_OK) return st;
     if (hflags[0]) return CSX_EINVAL;                 // S.cp / S.parent do not belong to A
     if (hflags[1] != 0x7fffffff) return CSX_ENOTSPD;  // some pivot d <= 0
