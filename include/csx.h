@@ -73,8 +73,11 @@ int csx_mem_info(int64_t *cached_bytes, int64_t *live_bytes, int64_t *device_fre
 /* Kernel-selection overrides, for tests that must reach a kernel the planner would not pick for a given input.
  * Every setting computes correct results; nothing here (or anywhere in the library) is read from the
  * environment.  Names (default 1): "chol.dense_trees", "chol.band", "cholsol.dense_blocks", "spgemm.one_pass",
- * "tri.chain_walker", "tri.components", "tri.columns", "tri.push"; "tri.levels_where" (default 0: level analysis of a triangular plan on the
- * device for big factors and on the host for small ones; 1 = host, 2 = device).  Unknown name: CSX_EINVAL. */
+ * "tri.chain_walker", "tri.components", "tri.columns", "tri.push", "tri.row_waves", "gaxpy.keys24"; "tri.levels_where" (default 0: level
+ * analysis of a triangular plan on the device for big factors and on the host for small ones; 1 = host, 2 = device);
+ * "chol.wband" (blocked dense-band cs_chol for chain-like factors: default 1 = for half-widths above 80, 0 = never,
+ * 2 = whenever the tree is chain-like) and "chol.wband_nb" (columns per step: 16 (default) or 32; negative: two
+ * launches per step instead of one).  Unknown name: CSX_EINVAL. */
 int csx_set_option(const char *name, int value);
 int csx_timer_start(void);                /* hipEvent on the context's stream */
 int csx_timer_stop(double *ms);           /* second hipEvent, synchronises, elapsed ms */
