@@ -572,6 +572,14 @@ __global__ __launch_bounds__(256) void k_band_width(int32_t n, const int32_t *__
 size_t chol_wide_band_bytes(int32_t n, int32_t bw);
 int chol_wide_band(int32_t n, int32_t bw, const int32_t *Lp, const int32_t *Li, double *Lx, int *notspd, int nb);
 
+// csx_cholband.hip: fundamental supernodes (a, w, r) factored in place as dense trapezoids
+struct SnDesc {
+    int32_t a, w, r;
+};
+int chol_supernodes(const void *d_sns, int32_t nsn, int32_t max_w, int32_t max_rows, const int32_t *Lp, double *Lx,
+                    int *notspd);
+constexpr int32_t SN_MIN_WIDTH = 32;   // narrower chains stay with the column kernels
+
 struct Forest {
     std::vector<Tree> small;             // trees handled by the tree kernel
     std::vector<int32_t> small_cols;     // their columns, ascending inside a tree
@@ -669,6 +677,77 @@ static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, c
         other_trees = F.small;
         dense_trees.clear();
     }
+    // ---- fundamental supernodes of the big trees: w >= 32 consecutive columns, each the ONLY child of the next, column
+    // counts falling by one (the separators of a nested-dissection ordering).  They leave the level lists: when the
+    // walk below reaches the level of a supernode's first column, every update from outside it is available (all of
+    // them come from below that first column), so its columns take them in one launch and the trapezoid is then
+    // factored densely in place (chol_supernodes).
+    const int64_t big_cols_all = (int64_t)F.level_cols.size();   // columns of trees too big for the tree kernels
+    std::vector<int32_t> col_level_h;                      // level of every column of a big tree, -1 elsewhere
+    std::vector<SnDesc> sns;                               // grouped by the level of their first column
+    std::vector<int32_t> sn_cols, sn_group_ptr{0}, sn_group_first{0}, sn_group_maxw, sn_group_maxrows;
+    std::vector<int32_t> sn_group_at;                      // level -> group index, -1 none
+    if (!F.level_cols.empty()) {
+        const int32_t nlev0 = (int32_t)F.level_ptr.size() - 1;
+        col_level_h.assign((size_t)n, -1);
+        for (int32_t lv = 0; lv < nlev0; lv++)
+            for (int32_t q = F.level_ptr[(size_t)lv]; q < F.level_ptr[(size_t)lv + 1]; q++) col_level_h[(size_t)F.level_cols[(size_t)q]] = lv;
+        sn_group_at.assign((size_t)nlev0 + 1, -1);
+        if (ctx().opt.chol_supernodes) {
+            std::vector<int32_t> nchild((size_t)n, 0);
+            for (int32_t j = 0; j < n; j++)
+                if (parent[j] >= 0) nchild[(size_t)parent[j]]++;
+            std::vector<std::pair<int32_t, SnDesc>> found;     // (start level, supernode)
+            std::vector<char> member((size_t)n, 0);
+            for (int32_t j = 0; j < n;) {
+                if (col_level_h[(size_t)j] < 0) {
+                    j++;
+                    continue;
+                }
+                const int32_t a = j;
+                while (j + 1 < n && parent[j] == j + 1 && nchild[(size_t)j + 1] == 1 &&
+                       cp[j + 2] - cp[j + 1] == cp[j + 1] - cp[j] - 1)
+                    j++;
+                const int32_t w = j - a + 1;
+                if (w >= SN_MIN_WIDTH) {
+                    found.push_back({col_level_h[(size_t)a], SnDesc{a, w, cp[a + 1] - cp[a] - w}});
+                    for (int32_t c = a; c <= j; c++) member[(size_t)c] = 1;
+                }
+                j++;
+            }
+            if (!found.empty()) {
+                std::stable_sort(found.begin(), found.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
+                for (size_t f = 0; f < found.size(); f++) {
+                    const int32_t lv = found[f].first;
+                    if (f == 0 || lv != found[f - 1].first) {
+                        if (f) {
+                            sn_group_ptr.push_back((int32_t)sn_cols.size());
+                            sn_group_first.push_back((int32_t)sns.size());
+                        }
+                        sn_group_at[(size_t)lv] = (int32_t)sn_group_maxw.size();
+                        sn_group_maxw.push_back(0);
+                        sn_group_maxrows.push_back(0);
+                    }
+                    const SnDesc &d = found[f].second;
+                    sns.push_back(d);
+                    for (int32_t c = d.a; c < d.a + d.w; c++) sn_cols.push_back(c);
+                    sn_group_maxw.back() = std::max(sn_group_maxw.back(), d.w);
+                    sn_group_maxrows.back() = std::max(sn_group_maxrows.back(), d.w + d.r);
+                }
+                sn_group_ptr.push_back((int32_t)sn_cols.size());
+                sn_group_first.push_back((int32_t)sns.size());
+                // the level lists without the supernodes' columns
+                std::vector<int32_t> cols2, ptr2{0};
+                for (int32_t lv = 0; lv < nlev0; lv++) {
+                    for (int32_t q = F.level_ptr[(size_t)lv]; q < F.level_ptr[(size_t)lv + 1]; q++)
+                        if (!member[(size_t)F.level_cols[(size_t)q]]) cols2.push_back(F.level_cols[(size_t)q]);
+                    ptr2.push_back((int32_t)cols2.size());
+                }
+                F.level_cols.swap(cols2);
+                F.level_ptr.swap(ptr2);
+            }
+        }
+    }
     lap("partition_forest");
     std::vector<int32_t> hpinv;
     if (pinv) hpinv.assign(pinv, pinv + n);
@@ -682,15 +761,17 @@ static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, c
     if (st == CSX_OK) st = upload(&d_level_cols, F.level_cols);
     if (st == CSX_OK) st = upload(&d_level_ptr, F.level_ptr);
     int32_t *d_col_level = nullptr, *d_split = nullptr;
-    if (st == CSX_OK && !F.level_cols.empty()) {
+    if (st == CSX_OK && !col_level_h.empty()) {
         st = dalloc(&d_split, (size_t)n);
         if (st == CSX_OK) (void)hipMemsetAsync(d_split, 0x7f, (size_t)n * sizeof(int32_t), s);   // "no inside update seen"
     }
-    if (st == CSX_OK && !F.level_cols.empty()) {
-        std::vector<int32_t> col_level((size_t)n, -1);
-        for (size_t lv = 0; lv + 1 < F.level_ptr.size(); lv++)
-            for (int32_t q = F.level_ptr[lv]; q < F.level_ptr[lv + 1]; q++) col_level[(size_t)F.level_cols[(size_t)q]] = (int32_t)lv;
-        st = upload(&d_col_level, col_level);
+    SnDesc *d_sns = nullptr;
+    int32_t *d_sn_cols = nullptr, *d_sn_ptr = nullptr;
+    if (st == CSX_OK && !col_level_h.empty()) st = upload(&d_col_level, col_level_h);
+    if (st == CSX_OK && !sns.empty()) {
+        st = upload(&d_sns, sns);
+        if (st == CSX_OK) st = upload(&d_sn_cols, sn_cols);
+        if (st == CSX_OK) st = upload(&d_sn_ptr, sn_group_ptr);
     }
     int hflags[2] = {0, 0x7fffffff};
     if (st == CSX_OK) {
@@ -703,7 +784,7 @@ static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, c
         // a chain-like big tree whose factor is a narrow band: the register-window kernel does the whole matrix
         bool banded = false;
         const int32_t nlev_all = (int32_t)F.level_ptr.size() - 1;
-        const int64_t big_cols = (int64_t)F.level_cols.size();   // columns of trees too big for the tree kernels
+        const int64_t big_cols = big_cols_all;
         if (ctx().opt.chol_band && big_cols * 2 > n && (int64_t)nlev_all * 4 > big_cols) {
             int hb = 0;
             (void)hipMemsetAsync(d_flags + 2, 0, sizeof(int), s);
@@ -744,8 +825,28 @@ static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, c
                                d_trees, nt, d_small_cols, L->p, L->i, L->x, d_rp, d_rc, d_rpos, d_flags + 1);
         const int32_t nlev = banded ? 0 : (int32_t)F.level_ptr.size() - 1;
         int32_t l = 0;
+        const size_t cc_lds = (size_t)CC_ACC * 12 + (n <= CC_MAP ? (size_t)n * 4 : 0) + 64;
+        if (nlev > 0)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chol_coop), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      160 * 1024 - 256);
         while (l < nlev) {
+            if (!banded && !sn_group_at.empty() && sn_group_at[(size_t)l] >= 0) {
+                // supernodes whose first column sits at this level: outside updates for all their columns at once
+                // (k_chol_coop, first phase), then the dense trapezoids in place
+                const int32_t g = sn_group_at[(size_t)l];
+                sn_group_at[(size_t)l] = -1;
+                hipLaunchKernelGGL(k_chol_coop, dim3((unsigned)(sn_group_ptr[(size_t)g + 1] - sn_group_ptr[(size_t)g])),
+                                   dim3(64 * CC_WAVES), cc_lds, s, d_sn_cols, d_sn_ptr, g, g + 1, L->p, L->i, L->x, d_rp, d_rc,
+                                   d_rpos, n, d_flags + 1, d_col_level, 1, l, d_split);
+                if (chol_supernodes(d_sns + sn_group_first[(size_t)g], sn_group_first[(size_t)g + 1] - sn_group_first[(size_t)g],
+                                    sn_group_maxw[(size_t)g], sn_group_maxrows[(size_t)g], L->p, L->x, d_flags + 1) != CSX_OK)
+                    break;
+            }
             const int32_t cnt = F.level_ptr[(size_t)l + 1] - F.level_ptr[(size_t)l];
+            if (cnt == 0) {                          // all of this level's columns belong to supernodes
+                l++;
+                continue;
+            }
             if (cnt > CH_NARROW) {
                 hipLaunchKernelGGL(k_chol_level, dim3((unsigned)((cnt + CH_WAVES - 1) / CH_WAVES)), dim3(64 * CH_WAVES), 0,
                                    s, d_level_cols + F.level_ptr[(size_t)l], cnt, L->p, L->i, L->x, d_rp, d_rc, d_rpos,
@@ -755,13 +856,10 @@ static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, c
             }
             // a narrow level with more than one column: its columns go to as many workgroups in one launch; a run of
             // single-column levels (a chain) is walked by one workgroup without coming back to the host
-            const size_t cc_lds = (size_t)CC_ACC * 12 + (n <= CC_MAP ? (size_t)n * 4 : 0) + 64;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_chol_coop), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      160 * 1024 - 256);
             auto width = [&](int32_t lv) { return F.level_ptr[(size_t)lv + 1] - F.level_ptr[(size_t)lv]; };
             int32_t e = l + 1;                       // the run of narrow levels, at most CC_RUN_MAX of them at a time:
-            while (e < nlev && e - l < CC_RUN_MAX && width(e) <= CH_NARROW) e++;   // the shorter, the less is left inside
-            const bool two_phase = e - l >= CC_RUN_MIN;
+            while (e < nlev && e - l < CC_RUN_MAX && width(e) <= CH_NARROW && sn_group_at[(size_t)e] < 0) e++;   // the shorter, the less is left inside
+            const bool two_phase = e - l >= CC_RUN_MIN && F.level_ptr[(size_t)e] > F.level_ptr[(size_t)l];
             if (two_phase)                           // updates from below the run, for all of its columns at once
                 hipLaunchKernelGGL(k_chol_coop, dim3((unsigned)(F.level_ptr[(size_t)e] - F.level_ptr[(size_t)l])),
                                    dim3(64 * CC_WAVES), cc_lds, s, d_level_cols, d_level_ptr, l, e, L->p, L->i, L->x, d_rp, d_rc,
@@ -769,6 +867,10 @@ static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, c
             for (int32_t a = l; a < e;) {
                 // a level with several columns: a workgroup each in one launch; single-column levels in a row (a chain):
                 // one workgroup walks them without coming back to the host
+                if (width(a) == 0) {                 // emptied by the supernodes
+                    a++;
+                    continue;
+                }
                 int32_t b = a + 1;
                 if (width(a) == 1)
                     while (b < e && width(b) == 1) b++;
@@ -800,6 +902,9 @@ static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, c
     dfree(d_level_ptr);
     dfree(d_col_level);
     dfree(d_split);
+    dfree(d_sns);
+    dfree(d_sn_cols);
+    dfree(d_sn_ptr);
     if (st != CSX_OK) return st;
     if (hflags[0]) return CSX_EINVAL;                 // S.cp / S.parent do not belong to A
     if (hflags[1] != 0x7fffffff) return CSX_ENOTSPD;  // some pivot d <= 0

@@ -359,7 +359,213 @@ __global__ __launch_bounds__(64 + WB_PANEL_ROWS) void k_wband_step(int32_t n, in
     for (int t = 0; t < NB; t++)
         if (c1 + t < n && ro - (uint32_t)t <= (uint32_t)bw) Wp[(uint32_t)t * ld + (ro - (uint32_t)t)] = x[t];
 }
+
+// ---- dense fronts of a bushy tree: fundamental supernodes factored in place ------------------------------------------
+// A separator of a nested-dissection ordering is a FUNDAMENTAL SUPERNODE of L: w consecutive columns a .. a + w - 1, each
+// the only child of the next, column a + t holding rows a + t .. a + w - 1 followed by the SAME r rows below the block.
+// Its part of L.x is therefore a dense trapezoid stored column after column, element (v, t) -- v = t .. w + r - 1 a
+// "virtual" row: the triangle's rows, then the r common rows -- at Lx[Lp[a + t] + v - t].  Every update from outside the
+// supernode comes from below its FIRST column in the tree, so once those are in (k_chol_coop, mode 1, all w columns in one
+// launch) the rest is a dense right-looking factorisation of the trapezoid: the blocked scheme of k_wband_step with
+// nothing clipped by a band, run where the entries lie.  Supernodes of one tree level are independent: blockIdx.y.
+struct SnDesc {
+    int32_t a, w, r;     // first column, columns, rows below the triangular block
+};
+
+template <int NB>
+__global__ __launch_bounds__(64 + WB_PANEL_ROWS) void k_sn_step(const SnDesc *__restrict__ sns, int32_t c1, int32_t gA,
+                                                               int32_t ntR, int32_t ntC, const int32_t *__restrict__ Lp,
+                                                               double *Lx, int *notspd) {
+    __shared__ __attribute__((aligned(16))) double smem[2 * NB * WB_TILE > 3 * NB * NB ? 2 * NB * WB_TILE : 3 * NB * NB];
+    const SnDesc sn = sns[blockIdx.y];
+    const int32_t w = sn.w, nrows = sn.w + sn.r;
+    if (c1 >= w) return;                                  // this supernode is finished
+    const int32_t c0 = c1 - NB;
+    const bool has_prev = c1 > 0;
+    const int tid = threadIdx.x;
+    auto colp = [&](int32_t c) { return Lx + Lp[sn.a + c] - c; };   // element (v, c) at colp(c)[v]
+    if ((int32_t)blockIdx.x >= gA) {
+        // ---- role B: tile (bi over rows, bj over columns) of what lies beyond the panel ----
+        if (tid >= 256 || !has_prev) return;
+        const int32_t tb = (int32_t)blockIdx.x - gA;
+        if (tb >= ntR * ntC) return;
+        const int32_t bi = tb / ntC, bj = tb % ntC;
+        const int32_t first = c1 + NB;
+        const int32_t R0 = first + bi * WB_TILE, C0 = first + bj * WB_TILE;
+        if (C0 >= w || R0 >= nrows || R0 + WB_TILE - 1 < C0) return;   // no column / no row / wholly above the diagonal
+        double (*lr)[WB_TILE] = reinterpret_cast<double (*)[WB_TILE]>(smem);
+        double (*lc)[WB_TILE] = reinterpret_cast<double (*)[WB_TILE]>(smem + NB * WB_TILE);
+        const int tx = tid & 15, ty = tid >> 4;
+        const int32_t r0 = R0 + 4 * tx, cc0 = C0 + 4 * ty;
+        const bool any = r0 < nrows && cc0 < w && r0 + 3 >= cc0;
+        double acc[4][4];
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+            for (int a = 0; a < 4; a++) {
+                const int32_t rr = r0 + a, c = cc0 + b;
+                acc[b][a] = (any && rr < nrows && c < w && c <= rr) ? colp(c)[rr] : 0.0;
+            }
+        for (int e = tid; e < NB * WB_TILE; e += 256) {
+            const int t = e / WB_TILE, i = e % WB_TILE;
+            const double *cp = colp(c0 + t);
+            const int32_t ra = R0 + i, rb = C0 + i;
+            lr[t][i] = ra < nrows ? cp[ra] : 0.0;
+            lc[t][i] = rb < w ? cp[rb] : 0.0;             // rb >= first > c0 + t: below the diagonal of column c0 + t
+        }
+        __syncthreads();
+        if (!any) return;
+#pragma unroll 4
+        for (int t = 0; t < NB; t++) {
+            double ra[4], cb[4];
+#pragma unroll
+            for (int a = 0; a < 4; a++) ra[a] = lr[t][4 * tx + a];
+#pragma unroll
+            for (int b = 0; b < 4; b++) cb[b] = lc[t][4 * ty + b];
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+#pragma unroll
+                for (int a = 0; a < 4; a++) {
+                    const double p = ra[a] * cb[b];
+                    acc[b][a] = acc[b][a] - p;
+                }
+        }
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+            for (int a = 0; a < 4; a++) {
+                const int32_t rr = r0 + a, c = cc0 + b;
+                if (rr < nrows && c < w && c <= rr) colp(c)[rr] = acc[b][a];
+            }
+        return;
+    }
+    // ---- role A: the panel [c1, c1 + NB) of the supernode ----
+    double *E = smem;                 // E[t * NB + i] = l(c1 + i, c0 + t)
+    double *Dt = smem + NB * NB;      // Dt[c * NB + i]: the diagonal block after the previous panel's update
+    double *D = smem + 2 * NB * NB;   // D[s * NB + t] = L(c1 + t, c1 + s)
+    const int lane = tid & 63, wave = tid >> 6;
+    const int32_t v = c1 + NB + (int32_t)blockIdx.x * WB_PANEL_ROWS + (tid - 64);   // this thread's (virtual) row below the block
+    const bool mine = wave > 0 && v < nrows;
+    if ((int32_t)blockIdx.x * WB_PANEL_ROWS >= nrows - (c1 + NB) && blockIdx.x > 0) return;   // no rows for this workgroup
+    double x[NB], lrow[NB];
+    constexpr int THREADS = 64 + WB_PANEL_ROWS;
+    for (int e = tid; e < NB * NB; e += THREADS) {
+        const int ec = e / NB, ei = e % NB;
+        // block rows c1 + ei exist as virtual rows while c1 + ei < nrows; block COLUMNS only while c1 + ec < w
+        E[e] = (has_prev && c1 + ei < nrows) ? colp(c0 + ec)[c1 + ei] : 0.0;
+        Dt[e] = (ei >= ec && c1 + ec < w && c1 + ei < nrows) ? colp(c1 + ec)[c1 + ei] : 0.0;
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int t = 0; t < NB; t++) {
+            x[t] = (mine && c1 + t < w) ? colp(c1 + t)[v] : 0.0;
+            lrow[t] = (mine && has_prev) ? colp(c0 + t)[v] : 0.0;
+        }
+    }
+    __syncthreads();
+    if (has_prev) {
+        for (int e = tid; e < NB * NB; e += THREADS) {
+            const int ec = e / NB, ei = e % NB;
+            if (ei < ec) continue;
+            double vv = Dt[e];
+#pragma unroll
+            for (int t = 0; t < NB; t++) {
+                const double p = E[t * NB + ei] * E[t * NB + ec];
+                vv = vv - p;
+            }
+            Dt[e] = vv;
+        }
+    }
+    if (mine && has_prev) {
+#pragma unroll
+        for (int tq = 0; tq < NB; tq++) {
+            double vv = x[tq];
+#pragma unroll
+            for (int t = 0; t < NB; t++) {
+                const double p = lrow[t] * E[t * NB + tq];
+                vv = vv - p;
+            }
+            x[tq] = vv;
+            asm volatile("" : "+v"(x[tq]) : : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        // the block's COLUMNS past the supernode's width do not exist: identity there (pivot 1, nothing below); its ROWS
+        // past w are rows of the rectangular part: they take part as rows of the block (entries in the existing columns)
+        const bool row = lane < NB && c1 + lane < nrows;
+        double a[NB];
+#pragma unroll
+        for (int c = 0; c < NB; c++) a[c] = (row && c <= lane) ? Dt[c * NB + lane] : 0.0;
+#pragma unroll
+        for (int j = 0; j < NB; j++) {
+            const bool live = c1 + j < w;
+            const int dlo = __builtin_amdgcn_readlane(__double2loint(a[j]), j);
+            const int dhi = __builtin_amdgcn_readlane(__double2hiint(a[j]), j);
+            const double d = live ? __hiloint2double(dhi, dlo) : 1.0;
+            if (live && !(d > 0.0) && lane == 0 && blockIdx.x == 0) atomicMin(notspd, sn.a + c1 + j);   // csparse.py:612
+            const double ljj = sqrt(d);
+            double lij = 0.0;
+            if (row && lane > j) lij = a[j] / ljj;
+            if (lane == j) a[j] = ljj;
+            else a[j] = lij;
+#pragma unroll
+            for (int c = j + 1; c < NB; c++) {
+                const int lo = __builtin_amdgcn_readlane(__double2loint(lij), c);
+                const int hi = __builtin_amdgcn_readlane(__double2hiint(lij), c);
+                const double lcj = __hiloint2double(hi, lo);
+                const double t = lij * lcj;
+                if (lane >= c) a[c] = a[c] - t;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (lane < NB) {
+#pragma unroll
+            for (int c = 0; c < NB; c++) {
+                D[c * NB + lane] = a[c];
+                if (blockIdx.x == 0 && row && c <= lane && c1 + c < w) colp(c1 + c)[c1 + lane] = a[c];
+            }
+        }
+    }
+    __syncthreads();
+    if (!mine) return;
+#pragma unroll
+    for (int t = 0; t < NB; t++) {
+        double vv = x[t];
+#pragma unroll
+        for (int s2 = 0; s2 < t; s2++) {
+            const double p = x[s2] * D[s2 * NB + t];
+            vv = vv - p;
+        }
+        x[t] = vv / D[t * NB + t];
+        asm volatile("" : "+v"(x[t]) : : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int t = 0; t < NB; t++)
+        if (c1 + t < w) colp(c1 + t)[v] = x[t];
+}
+
 #pragma clang fp contract(fast)
+
+// Factor nsn supernodes (descriptors on the device, independent of each other, outside updates already applied) in
+// place: max_w / max_rows = the widest supernode / the most virtual rows (w + r) among them.
+int chol_supernodes(const void *d_sns, int32_t nsn, int32_t max_w, int32_t max_rows, const int32_t *Lp, double *Lx,
+                    int *notspd) {
+    constexpr int NB = 16;
+    hipStream_t s = ctx().stream;
+    for (int32_t c1 = 0; c1 < max_w; c1 += NB) {
+        const int32_t below = max_rows - (c1 + NB);
+        const int32_t gA = std::max(1, (below + WB_PANEL_ROWS - 1) / WB_PANEL_ROWS);
+        const int32_t ntR = below > 0 && c1 > 0 ? (below + WB_TILE - 1) / WB_TILE : 0;
+        const int32_t ntC = max_w - (c1 + NB) > 0 && c1 > 0 ? (max_w - (c1 + NB) + WB_TILE - 1) / WB_TILE : 0;
+        hipLaunchKernelGGL((k_sn_step<NB>), dim3((unsigned)(gA + ntR * ntC), (unsigned)nsn), dim3(64 + WB_PANEL_ROWS), 0, s,
+                           (const SnDesc *)d_sns, c1, gA, ntR, ntC, Lp, Lx, notspd);
+    }
+    CSX_LAUNCH_CHECK();
+    return CSX_OK;
+}
 
 // Bytes of the dense band array for a factor of n columns and half-width bw.
 size_t chol_wide_band_bytes(int32_t n, int32_t bw) { return (size_t)n * ((size_t)bw + 1) * sizeof(double); }

@@ -468,6 +468,7 @@ int csx_set_option(const char *name, int value) {
     const std::string n(name);
     if (n == "chol.dense_trees") o.chol_dense_trees = value != 0;
     else if (n == "chol.band") o.chol_band = value != 0;
+    else if (n == "chol.supernodes") o.chol_supernodes = value != 0;
     else if (n == "chol.wband") o.chol_wband = (value == 0 || value == 2) ? value : 1;
     else if (n == "chol.wband_nb") o.chol_wband_nb = (value == 32 || value == -16 || value == -32) ? value : 16;   // negative: two launches per panel
     else if (n == "cholsol.dense_blocks") o.cholsol_dense_blocks = value != 0;

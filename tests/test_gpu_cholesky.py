@@ -482,3 +482,58 @@ def test_wide_band_kernels_on_bcsstk16(cs):
         with _csx.option("chol.wband", 2), _csx.option("chol.wband_nb", nb):
             N = cs.cs_chol(C, S)
         assert np.asarray(N.L.x[:Lp[n]]).tobytes() == Lx.tobytes()
+
+
+@pytest.mark.parametrize("gx,gy", [(120, 120), (75, 131)])
+def test_supernodes_of_a_nested_dissection_factor_are_factored_as_dense_trapezoids(cs, gx, gy):
+    """Order 1 on a grid Laplacian: the separators are fundamental supernodes (w consecutive columns, each the only child
+    of the next, column counts falling by one).  Those of 32+ columns leave the level lists: their columns take every
+    outside update in one launch and the trapezoid is factored densely in place (k_sn_step), 16 columns per launch,
+    widths that are no multiple of 16 included.  L.p / L.i exact, L.x within 1e-13 of the plain-C oracle on the permuted
+    matrix, and the same with the supernode path switched off; a non-positive pivot inside a supernode -> None."""
+    import _csx
+    n, p, i, x = _grid_laplacian(gx, gy)
+    A = cs.cs_spalloc(n, n, len(i), True, False)
+    A.p, A.i, A.x = p.tolist(), i.tolist(), x.tolist()
+    S = cs.cs_schol(1, A)
+    C = cs.cs_symperm(A, S.pinv, True)
+    Cp, Ci, Cx = _arr(C)
+    parent, cp = CO.schol(n, Cp, Ci)
+    assert S.parent == parent.tolist() and S.cp == cp.tolist()
+    # there ARE wide supernodes in this factor
+    nchild = np.bincount(parent[parent >= 0], minlength=n)
+    cnt = np.diff(cp)
+    chain = (parent[:-1] == np.arange(1, n)) & (nchild[1:] == 1) & (cnt[1:] == cnt[:-1] - 1)
+    runs, best = 0, 0
+    for v in chain:
+        runs = runs + 1 if v else 0
+        best = max(best, runs + 1)
+    assert best >= 64
+    Lp, Li, Lx = CO.chol(n, Cp, Ci, Cx, parent, cp)
+    N = cs.cs_chol(A, S)
+    assert N.L.p == Lp.tolist() and N.L.i[:Lp[n]] == Li.tolist()
+    got = np.asarray(N.L.x[:Lp[n]])
+    assert np.max(np.abs(got - Lx)) / np.abs(Lx).max() < 1e-13
+    with _csx.option("chol.supernodes", 0):
+        N0 = cs.cs_chol(A, S)
+    g0 = np.asarray(N0.L.x[:Lp[n]])
+    assert np.max(np.abs(g0 - Lx)) / np.abs(Lx).max() < 1e-13
+    assert np.max(np.abs(g0 - got)) / np.abs(Lx).max() < 1e-13
+    # the solve through the driver
+    b = np.linspace(1.0, 2.0, n)
+    xb = b.tolist()
+    assert cs.cs_cholsol(1, A, xb) is True
+    import scipy.sparse as sp
+    Am = sp.csc_matrix((x, i, p), shape=(n, n))
+    Am = Am + sp.triu(Am, 1).T if (Am != Am.T).nnz else Am
+    assert np.max(np.abs(Am @ np.asarray(xb) - b)) < 1e-10
+    # not positive definite: the diagonal entry of the LAST column (inside the top separator's supernode) negated
+    pinv = np.asarray(S.pinv)
+    orig = int(np.where(pinv == n - 3)[0][0])
+    x2 = x.copy()
+    for q in range(p[orig], p[orig + 1]):
+        if i[q] == orig:
+            x2[q] = -50.0
+    A2 = cs.cs_spalloc(n, n, len(i), True, False)
+    A2.p, A2.i, A2.x = p.tolist(), i.tolist(), x2.tolist()
+    assert cs.cs_chol(A2, S) is None
