@@ -932,7 +932,7 @@ struct CholPlan {
     int32_t *rev_pos = nullptr;
     int dense_bs = 0;  // > 0: every tree is a dense lower-triangular block of this size on contiguous rows
     double *dense_b = nullptr;  // dense only: backward program with every row reversed (sweep-position order)
-    double *frag_f = nullptr, *frag_b = nullptr;  // dense, block size 16/32/64: MFMA fragments (k_mfma_frags)
+    double *frag_f = nullptr;   // dense, block size 16/32/64: MFMA fragments (k_mfma_frags); the backward sweep reads them transposed
     // exact (default): every right-hand side is solved in the reference's operation order -- substitution
     // kernels, level walker in source order: bit-identical to cs_lsolve + cs_ltsolve.  !exact
     // (csx_cholsol_set_order(plan, 0)): results equal to rounding; dense 16/32/64 blocks go to the matrix cores
@@ -962,7 +962,6 @@ void free_cholplan(CholPlan *P) {
     dfree(P->rev_pos);
     dfree(P->dense_b);
     dfree(P->frag_f);
-    dfree(P->frag_b);
     delete P;
 }
 
@@ -1304,8 +1303,7 @@ constexpr int mfma_frags() { return (NB * (NB - 1) / 2 + NB) * 4; }
 template <int NB>
 __global__ __launch_bounds__(64) void k_mfma_frags(const Tree *__restrict__ trees, const int32_t *__restrict__ f_ptr,
                                                    const double *__restrict__ f_val, const double *__restrict__ diagk,
-                                                   double *__restrict__ frag_f, double *__restrict__ frag_b,
-                                                   unsigned long long *cond_bits) {
+                                                   double *__restrict__ frag_f, unsigned long long *cond_bits) {
     constexpr int BS = 16 * NB;
     __shared__ double Ls[BS][BS + 1];
     __shared__ double W[NB][16][17];
@@ -1338,19 +1336,15 @@ __global__ __launch_bounds__(64) void k_mfma_frags(const Tree *__restrict__ tree
     __syncthreads();
     const int m = lane & 15, kq = lane >> 4;
     double *F = frag_f + (size_t)t * mfma_frags<NB>() * 64 + lane;
-    double *G = frag_b + (size_t)t * mfma_frags<NB>() * 64 + lane;
     int f = 0;
     for (int i = 0; i < NB; i++) {
         for (int j = 0; j < i; j++)
             for (int sx = 0; sx < 4; sx++) F[64 * f++] = -Ls[16 * i + m][16 * j + 4 * sx + kq];
         for (int sx = 0; sx < 4; sx++) F[64 * f++] = W[i][m][4 * sx + kq];
     }
-    f = 0;
-    for (int i = NB - 1; i >= 0; i--) {
-        for (int j = i + 1; j < NB; j++)
-            for (int sx = 0; sx < 4; sx++) G[64 * f++] = -Ls[16 * j + 4 * sx + kq][16 * i + m];
-        for (int sx = 0; sx < 4; sx++) G[64 * f++] = W[i][4 * sx + kq][m];
-    }
+    // (The backward sweep needs the TRANSPOSED tiles -L_ji' and W_ii' as A fragments.  They are the same 256 numbers
+    // per tile: k_cholsol_mfma reads them out of these fragments with the roles of lane and k-step exchanged, instead
+    // of a second, transposed copy -- half the fragment bytes, 1.5 GB less traffic per batch at 5M rows.)
     // largest |W| |L| over the forest, as ordered bits of a non-negative double
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
@@ -1363,8 +1357,8 @@ __global__ __launch_bounds__(64) void k_mfma_frags(const Tree *__restrict__ tree
 template <int NB>
 __global__ __launch_bounds__(256, 2) void k_cholsol_mfma(const Tree *__restrict__ trees, int32_t ntrees,
                                                       const int32_t *__restrict__ nodes, const int32_t *__restrict__ perm,
-                                                      const double *__restrict__ frag_f, const double *__restrict__ frag_b,
-                                                      double *B, int32_t nrhs, int32_t chunks) {
+                                                      const double *__restrict__ frag_f, double *B, int32_t nrhs,
+                                                      int32_t chunks) {
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t task = (int64_t)blockIdx.x * 4 + w;
@@ -1398,7 +1392,11 @@ __global__ __launch_bounds__(256, 2) void k_cholsol_mfma(const Tree *__restrict_
 #pragma unroll
             for (int r = 0; r < 4; r++) X[i][c][r] = B[roff[i][r] + cidx[c]];
     const double *F = frag_f + (size_t)t * mfma_frags<NB>() * 64 + lane;
-    const double *G = frag_b + (size_t)t * mfma_frags<NB>() * 64 + lane;
+    // Transposed read of a stored tile: the A fragment of tile' for (lane = (m, kq), k-step sx) is element (4 sx + kq, m)
+    // of the tile, which the forward layout keeps in k-step m >> 2 at lane (m & 3) * 16 + 4 sx + kq.  tile_at(a, b):
+    // tiles of block row a come in the order (a, 0) .. (a, a - 1), W_a.
+    const double *Ft = frag_f + (size_t)t * mfma_frags<NB>() * 64 + (size_t)(col >> 2) * 64 + (col & 3) * 16 + rq;
+    auto tile_at = [](int a, int b) { return (a * (a + 1) / 2 + b) * 4; };   // first of the tile's four fragments
     int f = 0;
 #pragma unroll
     for (int i = 0; i < NB; i++) {
@@ -1422,14 +1420,13 @@ __global__ __launch_bounds__(256, 2) void k_cholsol_mfma(const Tree *__restrict_
 #pragma unroll
         for (int c = 0; c < 4; c++) X[i][c] = Y[c];
     }
-    f = 0;
 #pragma unroll
     for (int i = NB - 1; i >= 0; i--) {
 #pragma unroll
         for (int j = i + 1; j < NB; j++)
 #pragma unroll
             for (int sx = 0; sx < 4; sx++) {
-                const double a = G[64 * f++];
+                const double a = Ft[(size_t)tile_at(j, i) * 64 + 4 * sx];   // -L_ji' from the stored -L_ji
 #pragma unroll
                 for (int c = 0; c < 4; c++) X[i][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[j][c][sx], X[i][c], 0, 0, 0);
             }
@@ -1438,7 +1435,7 @@ __global__ __launch_bounds__(256, 2) void k_cholsol_mfma(const Tree *__restrict_
         for (int c = 0; c < 4; c++) Y[c] = f64x4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int sx = 0; sx < 4; sx++) {
-            const double a = G[64 * f++];
+            const double a = Ft[(size_t)tile_at(i, i) * 64 + 4 * sx];       // W_ii' from the stored W_ii
 #pragma unroll
             for (int c = 0; c < 4; c++) Y[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[i][c][sx], Y[c], 0, 0, 0);
         }
@@ -1605,19 +1602,18 @@ static int cholsol_build_mfma(CholPlan *P) {
     const int nb16 = P->dense_bs / 16;
     const size_t nfrag = (size_t)(nb16 * (nb16 - 1) / 2 + nb16) * 4;
     unsigned long long *cond = nullptr, hcond = 0;
-    double *ff = nullptr, *fb = nullptr;
+    double *ff = nullptr;
     int st = dalloc(&cond, 1);
     if (st == CSX_OK) st = dalloc(&ff, (size_t)P->ntrees * nfrag * 64);
-    if (st == CSX_OK) st = dalloc(&fb, (size_t)P->ntrees * nfrag * 64);
     if (st == CSX_OK && hipMemsetAsync(cond, 0, sizeof(unsigned long long), s) != hipSuccess) st = CSX_ERUNTIME;
     if (st == CSX_OK) {
         const dim3 g((unsigned)P->ntrees);
         if (nb16 == 1)
-            hipLaunchKernelGGL(k_mfma_frags<1>, g, dim3(64), 0, s, P->trees, P->f_ptr, P->f_val, P->diagk, ff, fb, cond);
+            hipLaunchKernelGGL(k_mfma_frags<1>, g, dim3(64), 0, s, P->trees, P->f_ptr, P->f_val, P->diagk, ff, cond);
         else if (nb16 == 2)
-            hipLaunchKernelGGL(k_mfma_frags<2>, g, dim3(64), 0, s, P->trees, P->f_ptr, P->f_val, P->diagk, ff, fb, cond);
+            hipLaunchKernelGGL(k_mfma_frags<2>, g, dim3(64), 0, s, P->trees, P->f_ptr, P->f_val, P->diagk, ff, cond);
         else
-            hipLaunchKernelGGL(k_mfma_frags<4>, g, dim3(64), 0, s, P->trees, P->f_ptr, P->f_val, P->diagk, ff, fb, cond);
+            hipLaunchKernelGGL(k_mfma_frags<4>, g, dim3(64), 0, s, P->trees, P->f_ptr, P->f_val, P->diagk, ff, cond);
         if (hipGetLastError() != hipSuccess ||
             hipMemcpyAsync(&hcond, cond, sizeof hcond, hipMemcpyDeviceToHost, s) != hipSuccess ||
             hipStreamSynchronize(s) != hipSuccess)
@@ -1629,10 +1625,8 @@ static int cholsol_build_mfma(CholPlan *P) {
     P->mfma_growth = growth;
     if (st == CSX_OK && growth <= MFMA_GROWTH_LIMIT) {   // (a NaN fails the comparison: substitution stays)
         P->frag_f = ff;
-        P->frag_b = fb;
     } else {
         dfree(ff);
-        dfree(fb);
     }
     return st;
 }
@@ -1677,15 +1671,15 @@ static int cholsol_solve(CholPlan *P, double *B, int32_t nrhs) {
                 switch (P->dense_bs) {
                     case 16:
                         hipLaunchKernelGGL(k_cholsol_mfma<1>, grid, dim3(256), 0, s, P->trees, P->ntrees, P->tree_nodes,
-                                           P->perm, P->frag_f, P->frag_b, B, nrhs, chunks);
+                                           P->perm, P->frag_f, B, nrhs, chunks);
                         break;
                     case 32:
                         hipLaunchKernelGGL(k_cholsol_mfma<2>, grid, dim3(256), 0, s, P->trees, P->ntrees, P->tree_nodes,
-                                           P->perm, P->frag_f, P->frag_b, B, nrhs, chunks);
+                                           P->perm, P->frag_f, B, nrhs, chunks);
                         break;
                     default:
                         hipLaunchKernelGGL(k_cholsol_mfma<4>, grid, dim3(256), 0, s, P->trees, P->ntrees, P->tree_nodes,
-                                           P->perm, P->frag_f, P->frag_b, B, nrhs, chunks);
+                                           P->perm, P->frag_f, B, nrhs, chunks);
                         break;
                 }
                 CSX_LAUNCH_CHECK();
