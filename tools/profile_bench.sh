@@ -1,7 +1,9 @@
 #!/bin/bash
 # Run ON THE GPU BOX (through gpurun): rocprofv3 kernel trace + HBM counters for a command, reduced to small
 # CSV/JSON summaries under gpurun_out/<tag>/ that are then copied into profiles/ and committed.
-#   tools/profile_bench.sh <tag> <python script + args ...>       e.g.  tools/profile_bench.sh r02_bench bench.py --skip-cpu
+#   tools/profile_bench.sh <tag> <python script + args ...>       e.g.  tools/profile_bench.sh r02_bench bench.py --skip-cpu --skip-configs --mode tiled
+# (--mode tiled: without it bench.py also TRIES the wave kernel on G-rand, and the per-kernel counter summary of
+# k_gaxpy_rows4 would mix those launches with the G-spd ones it is quoted for)
 # Passes: (1) --kernel-trace --stats, (2) --pmc FETCH_SIZE, (3) --pmc WRITE_SIZE -- counters in their own runs,
 # never together with a trace (MI355X_MICROARCH.md, rocprofv3 PMC slots).  The program itself follows `--`.
 set -e
