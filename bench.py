@@ -349,6 +349,9 @@ def main():
 
     key_bytes = _csx.C.c_int(0)
     _csx.check(lib.csx_gaxpy_plan_info(hA, None, None, key_bytes), "plan_info")
+    shape, shape_ms = _csx.C.c_int(-1), (_csx.C.c_double * 4)()
+    if chosen == "tiled":
+        _csx.check(lib.csx_gaxpy_plan_shape(hA, shape, shape_ms), "plan_shape")
     out = {
         "metric": "cs_gaxpy achieved HBM GB/s (algorithmic bytes / time), 5M x 5M CSC, 64 nnz/col",
         "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -357,6 +360,9 @@ def main():
         "config": {"workload": "cs_gaxpy y += A x on G-rand: %d x %d CSC, %s, int32 indices, fp64 values; one "
                                "independent matrix per GPU" % (n, n, gen_words[args.gen]), "row_draw": args.gen,
                    "n": n, "nnz": nnz, "kernel": "gaxpy_" + chosen, "plan_key_bytes": key_bytes.value,
+                   "plan_launch_shape": {"picked": ["4x5", "2x10", "8x4", "2x8"][shape.value] if shape.value >= 0 else None,
+                                         "ms_when_the_plan_was_built": {k: round(v, 4) for k, v in
+                                                                        zip(("4x5", "2x10", "8x4", "2x8"), shape_ms)}},
                    "algorithmic_bytes_per_step": by,
                    "parallelism": "independent matrices, 1 per GPU, no data-path collective"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -87,6 +87,7 @@ _PROTOS = {
                      C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
     "csx_qr_blocks": [H, _i32p, _i32p, _i32p, C.c_int32, C.POINTER(H), C.POINTER(H), _f64p, C.POINTER(C.c_int)],
     "csx_gaxpy_plan_info": [H, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    "csx_gaxpy_plan_shape": [H, C.POINTER(C.c_int), C.POINTER(C.c_double)],
     "csx_lu_host": [C.c_int32, _i32p, _i32p, _f64p, C.c_double, C.POINTER(_i32p), C.POINTER(_i32p),
                     C.POINTER(_f64p), C.POINTER(_i32p), C.POINTER(_i32p), C.POINTER(_f64p), _i32p],
     "csx_gen_grand": [C.c_int32, C.c_int32, C.c_uint64, C.POINTER(H)],

@@ -340,6 +340,18 @@ extern "C" int csx_gaxpy_plan_info(csx_handle_t hA, int *has_rows, int *has_tile
     return CSX_OK;
 }
 
+/* Launch shape the tiled plan picked by timing its candidates when it was built (0: 4 waves x 5 groups, 1: 2 x 10,
+ * 2: 8 x 4, 3: 2 x 8; -1: not tuned -- small matrix -- the default 4 x 5) and the candidates' times (ms per pass). */
+extern "C" int csx_gaxpy_plan_shape(csx_handle_t hA, int *shape, double *ms4) {
+    CSX_TRY(require_ready());
+    Csc *A = csc(hA);
+    if (!A || !A->tiled) return CSX_EINVAL;
+    if (shape) *shape = A->tiled->shape;
+    if (ms4)
+        for (int k = 0; k < 4; k++) ms4[k] = A->tiled->shape_ms[k];
+    return CSX_OK;
+}
+
 extern "C" int csx_gaxpy(csx_handle_t hA, csx_handle_t hx, csx_handle_t hy, int mode) {
     CSX_TRY(require_ready());
     Csc *A = csc(hA);

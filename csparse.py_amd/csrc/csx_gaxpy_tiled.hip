@@ -321,6 +321,8 @@ __global__ __launch_bounds__(256) void k_rb_group_ptr(int32_t nrb, int32_t nslab
     if (b <= nrb) rb_gptr[b] = gptr[(int64_t)b * nslab];
 }
 
+static int gaxpy_tiled_pick_shape(Csc *A);
+
 int gaxpy_tiled_prepare(Csc *A) {
     if (A->tiled) return CSX_OK;
     if (!A->x) return CSX_EINVAL;
@@ -444,10 +446,57 @@ int gaxpy_tiled_prepare(Csc *A) {
         return st;
     }
     A->tiled = t;
+#ifndef CSX_ABLATION
+    CSX_TRY(gaxpy_tiled_pick_shape(A));
+#endif
     return CSX_OK;
 }
 
-int gaxpy_tiled_run(const Csc *A, const double *x, double *y) {
+// Launch shapes offered to the plan: the same kernel body, plan and LDS tile, only waves per workgroup x groups per wave
+// and step differ.  4 x 5 and 2 x 10 are within 1 % of each other on the boxes measured (profiles/r02_ablation.md, 1),
+// 8 x 4 and 2 x 8 within 5 %, and the whole kernel varies by 8 % from box to box -- so the plan times them where it runs.
+constexpr int TL_NSHAPES = 4;
+static int gaxpy_tiled_launch(const Csc *A, const double *x, double *y, int shape);
+
+static int gaxpy_tiled_pick_shape(Csc *A) {
+    TiledPlan *t = A->tiled;
+    if ((int64_t)A->nnz < (int64_t)1 << 24) return CSX_OK;      // small matrices: the default shape, no 10 ms of tuning
+    hipStream_t s = ctx().stream;
+    DevScope tmp;
+    double *x = nullptr, *y = nullptr;
+    if (tmp.alloc(&x, (size_t)A->n) != CSX_OK || tmp.alloc(&y, (size_t)A->m) != CSX_OK) return CSX_OK;   // no room: default
+    CSX_HIP(hipMemsetAsync(x, 0, (size_t)A->n * sizeof(double), s));   // the gathers go where they always go; values do not matter
+    CSX_HIP(hipMemsetAsync(y, 0, (size_t)A->m * sizeof(double), s));
+    hipEvent_t e0, e1;
+    CSX_HIP(hipEventCreate(&e0));
+    CSX_HIP(hipEventCreate(&e1));
+    int best = 0;
+    int st = CSX_OK;
+    for (int round = 0; round < 2 && st == CSX_OK; round++)             // second round: best of two per shape
+        for (int sh = 0; sh < TL_NSHAPES && st == CSX_OK; sh++) {
+            if (round == 0) st = gaxpy_tiled_launch(A, x, y, sh);       // not timed: first launch of this instantiation
+            if (st != CSX_OK) break;
+            (void)hipEventRecord(e0, s);
+            for (int rep = 0; rep < 3 && st == CSX_OK; rep++) st = gaxpy_tiled_launch(A, x, y, sh);
+            (void)hipEventRecord(e1, s);
+            if (hipEventSynchronize(e1) != hipSuccess) st = CSX_ERUNTIME;
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            ms /= 3;
+            if (round == 0 || ms < t->shape_ms[sh]) t->shape_ms[sh] = ms;
+        }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (st != CSX_OK) return st;
+    for (int sh = 1; sh < TL_NSHAPES; sh++)
+        if (t->shape_ms[sh] < t->shape_ms[best]) best = sh;
+    t->shape = best;
+    return CSX_OK;
+}
+
+int gaxpy_tiled_run(const Csc *A, const double *x, double *y) { return gaxpy_tiled_launch(A, x, y, A->tiled->shape); }
+
+static int gaxpy_tiled_launch(const Csc *A, const double *x, double *y, int shape) {
     const TiledPlan *t = A->tiled;
     hipStream_t s = ctx().stream;
     const size_t lds = (((size_t)(t->row_block + 1) * sizeof(double)) + 15) & ~(size_t)15;  // + dummy row
@@ -508,8 +557,14 @@ int gaxpy_tiled_run(const Csc *A, const double *x, double *y) {
     } else
     CSX_V(1) CSX_V(2) CSX_V(3) CSX_V(4) CSX_V(5) CSX_V(6) CSX_V(7) return CSX_EINVAL;
 #undef CSX_V
+    (void)shape;
 #else
-    CSX_TILED_LAUNCH(0, TL_WAVES, TL_NG)
+    switch (shape) {
+        case 1: CSX_TILED_LAUNCH(0, 2, 10) break;
+        case 2: CSX_TILED_LAUNCH(0, 8, 4) break;
+        case 3: CSX_TILED_LAUNCH(0, 2, 8) break;
+        default: CSX_TILED_LAUNCH(0, TL_WAVES, TL_NG) break;     // 0 and -1 (not tuned): 4 x 5
+    }
 #endif
 #undef CSX_TILED_LAUNCH
 #undef CSX_TILED_LAUNCH_K

@@ -72,6 +72,10 @@ struct TiledPlan {
     // 3-byte keys (row | column offset << 15), used when every run of 64 column-sorted entries spans < 512 columns:
     uint8_t *tile_key24 = nullptr; // [ngroups * 768]
     uint32_t *tile_base = nullptr; // [ngroups * 4] slab-local column of the first entry of each 64-entry run
+    // launch shape (waves per workgroup x groups per wave and step), picked when the plan is built by timing the
+    // candidates on this device (gaxpy_tiled_prepare); -1: the default shape
+    int shape = -1;
+    float shape_ms[4] = {0, 0, 0, 0};
 };
 
 // Order in which the reflections of a matrix of Householder vectors can be applied in parallel (csx_qr.hip):

@@ -121,6 +121,10 @@ int csx_gaxpy_prepare(csx_handle_t A, int mode);
  * per key of the latter: 4 (column, row packed) or 3 (row + 9-bit column offset inside a run of 64 column-sorted
  * entries; chosen when every run is narrower than 512 columns); 0 without a tiled plan.  Any pointer may be NULL. */
 int csx_gaxpy_plan_info(csx_handle_t A, int *has_rows, int *has_tiled, int *key_bytes);
+/* The tiled plan times its launch shapes (waves per workgroup x groups per wave and step: same kernel, plan and
+ * results) on the device when it is built and keeps the fastest: *shape = 0 (4 x 5), 1 (2 x 10), 2 (8 x 4), 3 (2 x 8),
+ * or -1 (small matrix: not timed, 4 x 5); ms4[0..3] = the candidates' ms per pass.  CSX_EINVAL without a tiled plan. */
+int csx_gaxpy_plan_shape(csx_handle_t A, int *shape, double *ms4);
 /* One-shot form for host arrays (the reference's list signature): y[0..m) += A x in the reference's
  * summation order (bit-identical), nothing left on the device.  x (values) must be present. */
 int csx_gaxpy_host(int32_t m, int32_t n, const int32_t *p, const int32_t *i, const double *x, const double *xv,
