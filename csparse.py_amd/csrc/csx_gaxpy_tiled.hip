@@ -159,6 +159,9 @@ __device__ __forceinline__ GroupRegs load_group_t(const uint32_t *__restrict__ k
                                                   const uint32_t *__restrict__ info, const uint32_t *__restrict__ base,
                                                   int32_t g, int lane) {
     GroupRegs r;
+    // a group belongs to ONE wave: its index is uniform, and saying so turns the group's 4-byte info word and 16-byte
+    // base record into scalar loads -- two vector memory instructions per group (of nine) leave the vector queue
+    g = __builtin_amdgcn_readfirstlane(g);
     const int64_t gb = (int64_t)g * TL_GROUP;
     if (K24) {
         // `key` is the byte array of 3-byte keys: 12 bytes per lane, 768 per group
