@@ -795,7 +795,10 @@ static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, c
             const int need = hb + 1;
             // wide bands (and, by option, every band): blocked factorisation in a dense band array, if that array fits
             const int wb = ctx().opt.chol_wband;
-            if (wb == 2 || (wb == 1 && need > 80)) {   // narrower: the register window costs about the same per column
+            // ... and only when the band is mostly FULL (bcsstk16: 89 %, a grid in natural order: 100 %): the dense band
+            // array does n x band^2 work whatever the factor holds (an arrow matrix has band n and a sparse factor)
+            const bool full_band = (double)L->nnz >= 0.5 * (double)n * ((double)hb + 1.0);
+            if ((wb == 2 || (wb == 1 && need > 80)) && full_band) {   // narrower: the register window costs about the same per column
                 size_t free_b = 0, total_b = 0, idle_b = 0, live_b = 0;
                 pool_stats(&idle_b, &live_b);
                 if (hipMemGetInfo(&free_b, &total_b) == hipSuccess &&

@@ -537,3 +537,35 @@ def test_supernodes_of_a_nested_dissection_factor_are_factored_as_dense_trapezoi
     A2 = cs.cs_spalloc(n, n, len(i), True, False)
     A2.p, A2.i, A2.x = p.tolist(), i.tolist(), x2.tolist()
     assert cs.cs_chol(A2, S) is None
+
+
+def test_chain_tree_with_a_wide_but_empty_band_stays_with_the_sparse_kernels(cs):
+    """An arrow matrix (tridiagonal + a dense last row / column): the elimination tree is a chain and the band is n - 1
+    wide, but the factor is as sparse as the matrix.  The dense-band kernels would do n x band^2 work on it; they are
+    taken only when the band is mostly full.  The factor must come out right (and quickly) from the sparse kernels."""
+    import time
+    import scipy.sparse as sp
+    n = 6000
+    main = np.full(n, 4.0)
+    off = np.full(n - 1, -1.0)
+    A = sp.diags([off, main, off], [-1, 0, 1], shape=(n, n), format="lil")
+    A[n - 1, :] = -0.001
+    A[:, n - 1] = -0.001
+    A[n - 1, n - 1] = 10.0
+    A = A.tocsc()
+    A.sort_indices()
+    p, i, x = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64)
+    M = cs.cs_spalloc(n, n, len(i), True, False)
+    M.p, M.i, M.x = p.tolist(), i.tolist(), x.tolist()
+    parent, cp = CO.schol(n, p, i)
+    Lp, Li, Lx = CO.chol(n, p, i, x, parent, cp)
+    assert Lp[n] < 3 * n                                   # sparse factor, band n - 1
+    S = cs.cs_schol(0, M)
+    cs.cs_chol(M, S)
+    t0 = time.perf_counter()
+    N = cs.cs_chol(M, S)
+    dt = time.perf_counter() - t0
+    assert N.L.p == Lp.tolist() and N.L.i[:Lp[n]] == Li.tolist()
+    # (the last pivot is a sum of 6 000 terms, taken in 16 partial sums by the cooperative column kernel: 1.5e-13)
+    assert np.max(np.abs(np.asarray(N.L.x[:Lp[n]]) - Lx)) / np.abs(Lx).max() < 1e-12
+    assert dt < 5.0                                        # the dense-band path would take far longer than this

@@ -109,7 +109,8 @@ while time.time() < t_end:
         assert N.L.p == Lp.tolist() and N.L.i[:lnz] == Li.tolist(), ("band chol pattern", seed, n, band)
         got = np.asarray(N.L.x[:lnz])
         chain = bool(np.all(parent[:-1] == np.arange(1, n)))
-        if chain and n > 512:
+        full = lnz >= 0.5 * n * (band + 1)              # the dense-band kernels take mostly-full bands only
+        if chain and n > 512 and (full or band <= 176):
             assert got.tobytes() == Lx.tobytes(), ("band chol bits", seed, n, band, keep)
         else:
             assert float(np.max(np.abs(got - Lx))) <= 1e-13 * max(1.0, float(np.max(np.abs(Lx)))), ("band chol values", seed, n, band)
