@@ -42,7 +42,8 @@ def ragged(rng, m, n, mean_len, maxlen=None):
 
 t_end = time.time() + budget
 seed = 0
-counts = {"transpose": 0, "multiply": 0, "spsolve": 0, "trisolve": 0, "cholesky": 0, "band_trisolve": 0, "band_cholesky": 0}
+counts = {"transpose": 0, "multiply": 0, "spsolve": 0, "trisolve": 0, "cholesky": 0, "band_trisolve": 0, "band_cholesky": 0,
+          "nd_cholesky": 0}
 
 
 def random_band_lower(rng, n, band, keep):
@@ -86,6 +87,46 @@ while time.time() < t_end:
             for r in sorted({0, k // 2, k - 1}):
                 assert Xk[:, r].tobytes() == ofn(n, Tp, Ti, Tx, B[:, r]).tobytes(), ("band trisolve", seed, fn.__name__, n, band, keep, k, r)
         counts["band_trisolve"] += 1
+        continue
+    if seed % 7 == 5:  # order 1 (nested dissection) on grids with random holes: supernodes as dense trapezoids, level hints from
+        import scipy.sparse as sp                       # the tree, wave-per-row solves; L against the oracle on the permuted matrix
+        gx, gy = int(rng.integers(20, 160)), int(rng.integers(20, 160))
+        n = gx * gy
+        Tx = sp.diags([-1, 2, -1], [-1, 0, 1], shape=(gx, gx))
+        Ty = sp.diags([-1, 2, -1], [-1, 0, 1], shape=(gy, gy))
+        G = (sp.kron(sp.identity(gy), Tx) + sp.kron(Ty, sp.identity(gx))).tocoo()
+        keep = (G.row == G.col) | (rng.random(G.nnz) < float(rng.choice([1.0, 0.9])))
+        Lw = sp.coo_matrix((G.data[keep & (G.row > G.col)], (G.row[keep & (G.row > G.col)], G.col[keep & (G.row > G.col)])), shape=(n, n))
+        Sm = (Lw + Lw.T).tocsc()
+        Sm = (Sm + sp.diags(np.asarray(abs(Sm).sum(axis=0)).ravel() + rng.uniform(0.01, 1.0, size=n))).tocsc()
+        Sm.sort_indices()
+        Cp, Ci, Cx = Sm.indptr.astype(np.int32), Sm.indices.astype(np.int32), Sm.data.astype(np.float64)
+        A = cs.cs_pin(host(cs, n, n, Cp, Ci, Cx))
+        S = cs.cs_schol(1, A)
+        assert S is not None, ("nd schol", seed)
+        Cperm = cs.cs_symperm(A, S.pinv, True)
+        nz = Cperm.p[n]
+        Pp, Pi, Px = np.asarray(Cperm.p, np.int32), np.asarray(Cperm.i[:nz], np.int32), np.asarray(Cperm.x[:nz], np.float64)
+        parent, cp = CO.schol(n, Pp, Pi)
+        assert list(S.parent) == parent.tolist() and list(S.cp) == cp.tolist(), ("nd schol tree", seed, gx, gy)
+        Lp, Li, Lx = CO.chol(n, Pp, Pi, Px, parent, cp)
+        N = cs.cs_chol(A, S)
+        assert N is not None, ("nd chol None", seed, gx, gy)
+        lnz = int(Lp[-1])
+        assert N.L.p == Lp.tolist() and N.L.i[:lnz] == Li.tolist(), ("nd chol pattern", seed, gx, gy)
+        got = np.asarray(N.L.x[:lnz])
+        assert float(np.max(np.abs(got - Lx))) <= 1e-12 * float(np.max(np.abs(Lx))), ("nd chol values", seed, gx, gy)
+        k = int(rng.choice([1, 3, 20, 70]))
+        b = rng.uniform(-1, 1, size=(n, k))
+        for exact in (True, False):
+            F = cs.cholsol_factor(A, 1, exact=exact)
+            X = cs.dvec(b if k > 1 else b[:, 0].copy())
+            assert F.solve(X) is True
+            Xn = X.numpy().reshape(n, k)
+            for r in sorted({0, k - 1}):
+                res = float(np.max(np.abs(Sm @ Xn[:, r] - b[:, r])))
+                assert res <= 1e-9, ("nd cholsol residual", seed, gx, gy, k, exact, res)
+        counts["nd_cholesky"] += 1
         continue
     if seed % 7 == 3:  # banded SPD matrices with a chain tree: the blocked dense-band cs_chol (band > 80) and the register
         import scipy.sparse as sp                       # window below, bit for bit against the plain-C oracle; cholsol both orders
