@@ -132,3 +132,31 @@ def test_bench_refuses_a_world_of_another_size():
     assert r.returncode == 2 and "refusing" in r.stderr
     r = _run_bench(["--gpus", "1", "--rehearse"], env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode == 2 and "refusing" in r.stderr
+
+
+def test_bench_deadline_prints_the_headline_when_a_later_leg_hangs():
+    """bench.py's legs after the headline are collectives at N > 1: if one hangs, rank 0 must still print the JSON line
+    as it stood after the last finished leg, marked, and exit 0 (bench.Deadline)."""
+    import json
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, time; sys.path.insert(0, %r)\n"
+        "import bench\n"
+        "out = {'metric': 'm', 'value': 1.0}\n"
+        "d = bench.Deadline(0.3, 0); d.arm(out)\n"
+        "out['leg1'] = 'done'; d.checkpoint(out)\n"
+        "time.sleep(30)\n"          # a leg that never returns
+        "print('not reached')\n" % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=20)
+    assert r.returncode == 0
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and "not reached" not in r.stdout
+    got = json.loads(lines[0])
+    assert got["value"] == 1.0 and got["leg1"] == "done" and got["extras_cut_short_after_s"] == 0.3
+    # a rank other than 0 exits 0 without printing
+    code2 = code.replace("bench.Deadline(0.3, 0)", "bench.Deadline(0.3, 1)")
+    r2 = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, timeout=30)
+    assert r2.returncode == 0 and r2.stdout.strip() == ""
