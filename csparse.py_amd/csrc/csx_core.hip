@@ -84,7 +84,12 @@ void *get(csx_handle_t h, Kind k) {
 namespace {
 struct Pool {
     std::mutex mu;
-    std::multimap<size_t, void *> idle;          // size -> block
+    struct Idle {
+        void *p;
+        uint64_t stamp;                            // when it was released: the oldest goes first when room is needed
+    };
+    std::multimap<size_t, Idle> idle;            // size -> block
+    uint64_t clock = 0;
     std::unordered_map<void *, size_t> size_of;  // every block handed out or idle
     size_t cached = 0, live = 0, limit = 0;
     bool enabled = true, configured = false;
@@ -114,8 +119,8 @@ void pool_configure() {
 
 void pool_release_locked() {
     for (auto &kv : g_pool.idle) {
-        g_pool.size_of.erase(kv.second);
-        (void)hipFree(kv.second);
+        g_pool.size_of.erase(kv.second.p);
+        (void)hipFree(kv.second.p);
     }
     g_pool.idle.clear();
     g_pool.cached = 0;
@@ -141,7 +146,7 @@ int dmalloc(void **p, size_t bytes) {
     if (g_pool.enabled) {
         auto it = g_pool.idle.lower_bound(want);
         if (it != g_pool.idle.end() && it->first <= want + want / 4) {   // at most 25 % slack
-            *p = it->second;
+            *p = it->second.p;
             g_pool.cached -= it->first;
             g_pool.live += it->first;
             g_pool.idle.erase(it);
@@ -176,8 +181,21 @@ void dfree(void *p) {
     }
     const size_t sz = it->second;
     g_pool.live -= sz;
-    if (g_pool.enabled && g_pool.cached + sz <= g_pool.limit) {
-        g_pool.idle.emplace(sz, p);
+    if (g_pool.enabled && sz <= g_pool.limit) {
+        // The block just released is the likeliest to be asked for again (a loop's temporaries): when the cache is
+        // full it is the OLDEST idle blocks that go back to the driver, not this one.  (Freeing the newcomer instead
+        // made a 12 GB work array of cs_multiply cost a hipFree + hipMalloc per call once an earlier phase had filled
+        // the cache: 590 ms per multiply instead of 15.)
+        while (g_pool.cached + sz > g_pool.limit && !g_pool.idle.empty()) {
+            auto old = g_pool.idle.begin();
+            for (auto k = g_pool.idle.begin(); k != g_pool.idle.end(); ++k)
+                if (k->second.stamp < old->second.stamp) old = k;
+            g_pool.cached -= old->first;
+            g_pool.size_of.erase(old->second.p);
+            (void)hipFree(old->second.p);
+            g_pool.idle.erase(old);
+        }
+        g_pool.idle.emplace(sz, Pool::Idle{p, ++g_pool.clock});
         g_pool.cached += sz;
         return;
     }
