@@ -441,7 +441,6 @@ def main():
         # size, each checking itself; never part of `value`.  bench_configs.py is the stand-alone form.
         import bench_configs as bc
         bc.SKIP_CPU = args.skip_cpu
-        bc.spin_up()                                      # the cholsol leg's CPU baseline left the device idle for seconds
         other = {}
         for name, fn in (("config2_gaxpy_bcsstk16", bc.config2), ("config3_lusol_W", bc.config3),
                          ("transpose_grand_5M", bc.transpose_grand), ("config4_multiply_S", bc.config4),

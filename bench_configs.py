@@ -56,31 +56,7 @@ def oracle_cs(O, m, n, p, i, x):
     return A
 
 
-def spin_up(max_s=2.0):
-    """Bring the device out of its idle clock state before a timed region: the one-core CPU baselines in between
-    leave it idle for seconds, and the first hundreds of milliseconds of work after such a pause have been seen to run
-    an order of magnitude slow (cs_multiply 451 ms instead of 15).  Streams a 256 MB fill until two consecutive
-    batches of 20 take the same time to 5 %, at most max_s."""
-    lib = _csx.lib()
-    h = _csx.new_handle()
-    _csx.check(lib.csx_vec_alloc(1 << 25, h))
-    t_end = time.perf_counter() + max_s
-    prev = None
-    while time.perf_counter() < t_end:
-        _csx.sync()
-        t0 = time.perf_counter()
-        for _ in range(20):
-            _csx.check(lib.csx_vec_fill(h, 0.0))
-        _csx.sync()
-        dt = time.perf_counter() - t0
-        if prev is not None and abs(dt - prev) <= 0.05 * prev:
-            break
-        prev = dt
-    _csx.free(h)
-
-
 def timed(fn, reps):
-    spin_up()
     fn()
     _csx.sync()
     with _csx.Timer() as t:
@@ -257,7 +233,6 @@ def config4(n=1000000, per_col=32):
     _csx.check(lib.csx_transpose(hA, 1, hB))
     _csx.sync()
     t_tr = time.perf_counter() - t0
-    spin_up()
     hC = _csx.new_handle()
     _csx.check(lib.csx_multiply(hA, hB, hC))  # warm-up (also builds nothing persistent)
     _csx.sync()
@@ -372,7 +347,6 @@ def transpose_grand(n=5000000, per_col=64):
     lib = _csx.lib()
     hA = _csx.new_handle()
     _csx.check(lib.csx_gen_grand_uniform(n, per_col, 20240602, hA))
-    spin_up()
     hT = _csx.new_handle()
     _csx.check(lib.csx_transpose(hA, 1, hT))
     _csx.sync()
@@ -421,7 +395,7 @@ def cholsol_connected(grid=300):
         b = np.linspace(1.0, 2.0, n)
         res = {"n": n, "nnz": int(len(i))}
         for order in orders:
-            spin_up()
+            _csx.sync()
             t0 = time.perf_counter(); S = cs.cs_schol(order, A); _csx.sync(); t1 = time.perf_counter()
             N = cs.cs_chol(A, S); _csx.sync(); t2 = time.perf_counter()
             N = cs.cs_chol(A, S); _csx.sync(); t3 = time.perf_counter()
