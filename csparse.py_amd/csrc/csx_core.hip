@@ -132,6 +132,18 @@ void pool_trim() {
     pool_release_locked();
 }
 
+// cap of the cache in bytes (tests; 0 restores the default quarter of the device)
+void pool_set_limit(size_t bytes) {
+    std::lock_guard<std::mutex> lock(g_pool.mu);
+    pool_configure();
+    if (bytes == 0) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) total_b = (size_t)64 << 30;
+        bytes = total_b / 4;
+    }
+    g_pool.limit = bytes;
+}
+
 void pool_stats(size_t *cached, size_t *live) {
     std::lock_guard<std::mutex> lock(g_pool.mu);
     if (cached) *cached = g_pool.cached;
@@ -487,6 +499,7 @@ int csx_set_option(const char *name, int value) {
     if (n == "chol.dense_trees") o.chol_dense_trees = value != 0;
     else if (n == "chol.band") o.chol_band = value != 0;
     else if (n == "chol.supernodes") o.chol_supernodes = value != 0;
+    else if (n == "pool.limit_mb") pool_set_limit(value > 0 ? (size_t)value << 20 : 0);   // 0: the default
     else if (n == "chol.wband") o.chol_wband = (value == 0 || value == 2) ? value : 1;
     else if (n == "chol.wband_nb") o.chol_wband_nb = (value == 32 || value == -16 || value == -32) ? value : 16;   // negative: two launches per panel
     else if (n == "cholsol.dense_blocks") o.cholsol_dense_blocks = value != 0;

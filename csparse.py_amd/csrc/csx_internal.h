@@ -159,6 +159,7 @@ inline int dalloc(T **p, size_t count) { return dmalloc((void **)p, count * size
 void dfree(void *p);
 void pool_trim();                               // release every idle block to the driver
 void pool_stats(size_t *cached, size_t *live);  // bytes idle in the cache / handed out
+void pool_set_limit(size_t bytes);              // cap of the cache (0: the default quarter of the device)
 
 void free_gather(Gather *g);
 void free_tiled(TiledPlan *t);

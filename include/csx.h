@@ -77,7 +77,8 @@ int csx_mem_info(int64_t *cached_bytes, int64_t *live_bytes, int64_t *device_fre
  * analysis of a triangular plan on the device for big factors and on the host for small ones; 1 = host, 2 = device);
  * "chol.wband" (blocked dense-band cs_chol for chain-like factors: default 1 = for half-widths above 80, 0 = never,
  * 2 = whenever the tree is chain-like) and "chol.wband_nb" (columns per step: 16 (default) or 32; negative: two
- * launches per step instead of one).  Unknown name: CSX_EINVAL. */
+ * launches per step instead of one); "chol.supernodes" (default 1); "pool.limit_mb" (cap of the device-memory cache in MB,
+ * 0 = the default quarter of the device).  Unknown name: CSX_EINVAL. */
 int csx_set_option(const char *name, int value);
 int csx_timer_start(void);                /* hipEvent on the context's stream */
 int csx_timer_stop(double *ms);           /* second hipEvent, synchronises, elapsed ms */

@@ -131,3 +131,37 @@ def test_one_shot_host_gaxpy_through_the_c_abi(cs):
     _csx.check(_csx.lib().csx_gaxpy_host(A.m, A.n, _csx.pi(p), _csx.pi(i), _csx.pd(x), _csx.pd(xv), _csx.pd(yv)))
     assert yv.tobytes() == g["gaxpy_y"].tobytes()          # the unmodified reference's y, bit for bit
     assert _csx.lib().csx_gaxpy_host(A.m, A.n, _csx.pi(p), _csx.pi(i), _csx.pd(x), None, _csx.pd(yv)) == _csx.EINVAL
+
+
+def test_full_cache_keeps_the_block_just_released_and_drops_the_oldest(cs):
+    """The device-memory cache under pressure: with room for one 40 MB block, releasing A then B must leave B cached (A
+    goes back to the driver), and the next request of that size must be served from the cache.  (Freeing the newcomer
+    instead cost cs_multiply a hipFree + hipMalloc of its 12 GB work arrays per call in a full cache.)"""
+    import _csx
+    lib = _csx.lib()
+    C = _csx.C
+
+    def info():
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        _csx.check(lib.csx_mem_info(a, b, c), "mem_info")
+        return a.value, b.value
+
+    _csx.check(lib.csx_mem_trim(), "trim")
+    n = 5 * 1000 * 1000                                    # 40 MB of doubles
+    with _csx.option("pool.limit_mb", 64):
+        hA, hB = _csx.new_handle(), _csx.new_handle()
+        _csx.check(lib.csx_vec_alloc(n, hA), "alloc")
+        _csx.check(lib.csx_vec_alloc(n, hB), "alloc")
+        cached0, live0 = info()
+        _csx.free(hA)
+        cached1, _ = info()
+        assert cached1 - cached0 >= 8 * n                  # A is cached
+        _csx.free(hB)
+        cached2, _ = info()
+        assert 8 * n <= cached2 - cached0 < 16 * n          # room for one: B stayed, A went back to the driver
+        hC = _csx.new_handle()
+        _csx.check(lib.csx_vec_alloc(n, hC), "alloc")
+        cached3, _ = info()
+        assert cached3 - cached0 < 8 * n                   # served from the cache
+        _csx.free(hC)
+    _csx.check(lib.csx_mem_trim(), "trim")
