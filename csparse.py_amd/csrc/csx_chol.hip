@@ -578,7 +578,7 @@ struct SnDesc {
 };
 int chol_supernodes(const void *d_sns, int32_t nsn, int32_t max_w, int32_t max_rows, const int32_t *Lp, double *Lx,
                     int *notspd);
-constexpr int32_t SN_MIN_WIDTH = 32;   // narrower chains stay with the column kernels
+constexpr int32_t SN_MIN_WIDTH = 8;    // narrower chains stay with the column kernels (700 x 700 grid, order 1, numeric part: 32 -> 44 ms, 16 -> 36, 8 -> 31, 4 -> 29)
 
 struct Forest {
     std::vector<Tree> small;             // trees handled by the tree kernel
@@ -677,7 +677,7 @@ static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, c
         other_trees = F.small;
         dense_trees.clear();
     }
-    // ---- fundamental supernodes of the big trees: w >= 32 consecutive columns, each the ONLY child of the next, column
+    // ---- fundamental supernodes of the big trees: w >= 8 consecutive columns, each the ONLY child of the next, column
     // counts falling by one (the separators of a nested-dissection ordering).  They leave the level lists: when the
     // walk below reaches the level of a supernode's first column, every update from outside it is available (all of
     // them come from below that first column), so its columns take them in one launch and the trapezoid is then

@@ -120,7 +120,7 @@ struct Options {
     int chol_wband = 1;               // cs_chol: blocked dense-band kernels for chain-like factors: 0 never, 1 for half-widths
                                       // above 80 (below, the register-window kernel), 2 whenever the tree is chain-like
     int chol_wband_nb = 16;           // ... columns per step (16 or 32)
-    bool chol_supernodes = true;      // cs_chol: fundamental supernodes of >= 32 columns factored as dense trapezoids in place
+    bool chol_supernodes = true;      // cs_chol: fundamental supernodes of >= 8 columns factored as dense trapezoids in place
     bool chol_dense_trees = true;     // cs_chol: LDS dense-block kernel for trees that are dense blocks
     bool cholsol_dense_blocks = true; // cholsol: dense-block kernels (false: the fused per-tree kernel)
     bool spgemm_one_pass = true;      // cs_multiply: one-walk LDS hash kernel (false: the two-pass kernel)

@@ -487,7 +487,7 @@ def test_wide_band_kernels_on_bcsstk16(cs):
 @pytest.mark.parametrize("gx,gy", [(120, 120), (75, 131)])
 def test_supernodes_of_a_nested_dissection_factor_are_factored_as_dense_trapezoids(cs, gx, gy):
     """Order 1 on a grid Laplacian: the separators are fundamental supernodes (w consecutive columns, each the only child
-    of the next, column counts falling by one).  Those of 32+ columns leave the level lists: their columns take every
+    of the next, column counts falling by one).  Those of 8+ columns leave the level lists: their columns take every
     outside update in one launch and the trapezoid is factored densely in place (k_sn_step), 16 columns per launch,
     widths that are no multiple of 16 included.  L.p / L.i exact, L.x within 1e-13 of the plain-C oracle on the permuted
     matrix, and the same with the supernode path switched off; a non-positive pivot inside a supernode -> None."""
