@@ -24,17 +24,24 @@ namespace csx {
 
 #pragma clang fp contract(off)
 
-// one wave per column: dense band array <- L.x (scatter = true) or L.x <- dense band array
+// one wave per column: dense band array <- L.x (scatter = true) or L.x <- dense band array.  On the way back the entries
+// of a column inside its own NB x NB diagonal block come from `dfac` (panel-major, [panel][column of the block][row of
+// the block]): the factored blocks are NOT stored into the band array while the factorisation runs -- every workgroup of
+// a panel's launch reads the block as the earlier launches left it and factors it for itself, so the one that stores the
+// result must not store it where the others read.
 template <bool SCATTER>
 __global__ __launch_bounds__(256) void k_wband_copy(int32_t n, int32_t ld, const int32_t *__restrict__ Lp,
-                                                    const int32_t *__restrict__ Li, double *Lx, double *W) {
+                                                    const int32_t *__restrict__ Li, double *Lx, double *W,
+                                                    const double *__restrict__ dfac, int nb) {
     const int lane = threadIdx.x & 63;
     const int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (j >= n) return;
+    const int32_t p0 = (int32_t)(j / nb) * nb;            // first column / row of j's diagonal block
     for (int32_t q = Lp[j] + lane; q < Lp[j + 1]; q += 64) {
-        const int64_t at = j * ld + (Li[q] - (int32_t)j);
+        const int32_t r = Li[q];
+        const int64_t at = j * ld + (r - (int32_t)j);
         if (SCATTER) W[at] = Lx[q];
-        else Lx[q] = W[at];
+        else Lx[q] = r < p0 + nb ? dfac[(int64_t)(j / nb) * nb * nb + (int64_t)(j - p0) * nb + (r - p0)] : W[at];
     }
 }
 
@@ -46,7 +53,7 @@ constexpr int WB_TILE = 64;             // k_wband_update: tile side
 // Wp[t * ld + (r - c0 - t)], Wp = W + c0 * ld: 32-bit offsets from one uniform base.
 template <int NB>
 __global__ __launch_bounds__(64 + WB_PANEL_ROWS) void k_wband_panel(int32_t n, int32_t bw, int32_t c0, double *W,
-                                                                   int *notspd) {
+                                                                   double *__restrict__ dfac, int *notspd) {
     __shared__ double D[NB * NB];       // the factored block: D[s * NB + t] = L(c0 + t, c0 + s), s <= t
     const uint32_t ld = (uint32_t)bw + 1;
     double *Wp = W + (int64_t)c0 * ld;
@@ -89,7 +96,7 @@ __global__ __launch_bounds__(64 + WB_PANEL_ROWS) void k_wband_panel(int32_t n, i
 #pragma unroll
             for (int c = 0; c < NB; c++) {
                 D[c * NB + lane] = a[c];
-                if (blockIdx.x == 0 && row && c <= lane && lane - c <= bw) Wp[(uint32_t)c * ld + (uint32_t)(lane - c)] = a[c];
+                if (blockIdx.x == 0 && row && c <= lane) dfac[(int64_t)(c0 / NB) * NB * NB + c * NB + lane] = a[c];   // see k_wband_copy
             }
         }
     } else {
@@ -186,7 +193,8 @@ __global__ __launch_bounds__(256) void k_wband_update(int32_t n, int32_t bw, int
 // operations is unchanged: earlier columns first, ascending.
 template <int NB>
 __global__ __launch_bounds__(64 + WB_PANEL_ROWS) void k_wband_step(int32_t n, int32_t bw, int32_t c1, int has_prev,
-                                                                  int32_t gA, int32_t ntB, double *W, int *notspd) {
+                                                                  int32_t gA, int32_t ntB, double *W,
+                                                                  double *__restrict__ dfac, int *notspd) {
     __shared__ __attribute__((aligned(16))) double smem[2 * NB * WB_TILE > 3 * NB * NB ? 2 * NB * WB_TILE : 3 * NB * NB];
     const uint32_t ld = (uint32_t)bw + 1;
     const int32_t c0 = c1 - NB;
@@ -337,7 +345,7 @@ __global__ __launch_bounds__(64 + WB_PANEL_ROWS) void k_wband_step(int32_t n, in
 #pragma unroll
             for (int c = 0; c < NB; c++) {
                 D[c * NB + lane] = a[c];
-                if (blockIdx.x == 0 && row && c <= lane && lane - c <= bw) Wp[(uint32_t)c * ld + (uint32_t)(lane - c)] = a[c];
+                if (blockIdx.x == 0 && row && c <= lane) dfac[(int64_t)(c1 / NB) * NB * NB + c * NB + lane] = a[c];   // see k_wband_copy
             }
         }
     }
@@ -375,7 +383,8 @@ struct SnDesc {
 template <int NB>
 __global__ __launch_bounds__(64 + WB_PANEL_ROWS) void k_sn_step(const SnDesc *__restrict__ sns, int32_t c1, int32_t gA,
                                                                int32_t ntR, int32_t ntC, const int32_t *__restrict__ Lp,
-                                                               double *Lx, int *notspd) {
+                                                               double *Lx, double *__restrict__ dfac, int32_t dstride,
+                                                               int *notspd) {
     __shared__ __attribute__((aligned(16))) double smem[2 * NB * WB_TILE > 3 * NB * NB ? 2 * NB * WB_TILE : 3 * NB * NB];
     const SnDesc sn = sns[blockIdx.y];
     const int32_t w = sn.w, nrows = sn.w + sn.r;
@@ -524,7 +533,10 @@ __global__ __launch_bounds__(64 + WB_PANEL_ROWS) void k_sn_step(const SnDesc *__
 #pragma unroll
             for (int c = 0; c < NB; c++) {
                 D[c * NB + lane] = a[c];
-                if (blockIdx.x == 0 && row && c <= lane && c1 + c < w) colp(c1 + c)[c1 + lane] = a[c];
+                // the factored block goes to dfac (k_sn_put_blocks moves it into place when every panel is done): the
+                // other workgroups of this launch read the block as the earlier launches left it
+                if (blockIdx.x == 0 && row && c <= lane && c1 + c < w)
+                    dfac[(int64_t)blockIdx.y * dstride + (int64_t)(c1 / NB) * NB * NB + c * NB + lane] = a[c];
             }
         }
     }
@@ -549,21 +561,42 @@ __global__ __launch_bounds__(64 + WB_PANEL_ROWS) void k_sn_step(const SnDesc *__
 
 #pragma clang fp contract(fast)
 
+// the factored diagonal blocks into their places in L.x: grid (panels of the widest supernode, supernodes), NB * NB threads
+template <int NB>
+__global__ __launch_bounds__(NB * NB) void k_sn_put_blocks(const SnDesc *__restrict__ sns, const int32_t *__restrict__ Lp,
+                                                           double *Lx, const double *__restrict__ dfac, int32_t dstride) {
+    const SnDesc sn = sns[blockIdx.y];
+    const int32_t c1 = (int32_t)blockIdx.x * NB;
+    if (c1 >= sn.w) return;
+    const int c = threadIdx.x / NB, i = threadIdx.x % NB;      // element (row c1 + i, column c1 + c) of the trapezoid
+    if (i < c || c1 + c >= sn.w || c1 + i >= sn.w + sn.r) return;
+    Lx[Lp[sn.a + c1 + c] + (i - c)] = dfac[(int64_t)blockIdx.y * dstride + (int64_t)blockIdx.x * NB * NB + c * NB + i];
+}
+
 // Factor nsn supernodes (descriptors on the device, independent of each other, outside updates already applied) in
 // place: max_w / max_rows = the widest supernode / the most virtual rows (w + r) among them.
 int chol_supernodes(const void *d_sns, int32_t nsn, int32_t max_w, int32_t max_rows, const int32_t *Lp, double *Lx,
                     int *notspd) {
     constexpr int NB = 16;
     hipStream_t s = ctx().stream;
+    const int32_t npan = (max_w + NB - 1) / NB;
+    const int32_t dstride = npan * NB * NB;
+    DevScope tmp;
+    double *dfac = nullptr;
+    CSX_TRY(tmp.alloc(&dfac, (size_t)nsn * dstride));
     for (int32_t c1 = 0; c1 < max_w; c1 += NB) {
         const int32_t below = max_rows - (c1 + NB);
         const int32_t gA = std::max(1, (below + WB_PANEL_ROWS - 1) / WB_PANEL_ROWS);
         const int32_t ntR = below > 0 && c1 > 0 ? (below + WB_TILE - 1) / WB_TILE : 0;
         const int32_t ntC = max_w - (c1 + NB) > 0 && c1 > 0 ? (max_w - (c1 + NB) + WB_TILE - 1) / WB_TILE : 0;
         hipLaunchKernelGGL((k_sn_step<NB>), dim3((unsigned)(gA + ntR * ntC), (unsigned)nsn), dim3(64 + WB_PANEL_ROWS), 0, s,
-                           (const SnDesc *)d_sns, c1, gA, ntR, ntC, Lp, Lx, notspd);
+                           (const SnDesc *)d_sns, c1, gA, ntR, ntC, Lp, Lx, dfac, dstride, notspd);
     }
+    hipLaunchKernelGGL((k_sn_put_blocks<NB>), dim3((unsigned)npan, (unsigned)nsn), dim3(NB * NB), 0, s, (const SnDesc *)d_sns,
+                       Lp, Lx, dfac, dstride);
     CSX_LAUNCH_CHECK();
+    // dfac goes back to the cache when this returns: every use of device memory is ordered on the one stream, and the
+    // cache hands a block out again only to work enqueued after this
     return CSX_OK;
 }
 
@@ -573,12 +606,12 @@ size_t chol_wide_band_bytes(int32_t n, int32_t bw) { return (size_t)n * ((size_t
 // L.x holds A scattered into the pattern of L (k_chol_init); on return it holds the factor.  *notspd (device)
 // receives the first column with a non-positive pivot (atomicMin), as in the other kernels.
 template <int NB>
-static int wide_band_run(int32_t n, int32_t bw, double *W, int *notspd) {
+static int wide_band_run(int32_t n, int32_t bw, double *W, double *dfac, int *notspd) {
     hipStream_t s = ctx().stream;
     for (int32_t c0 = 0; c0 < n; c0 += NB) {
         const int32_t below = std::min(n - 1, c0 + NB - 1 + bw) - (c0 + NB) + 1;   // rows under the block (may be <= 0)
         const unsigned g2 = (unsigned)std::max(1, (below + WB_PANEL_ROWS - 1) / WB_PANEL_ROWS);
-        hipLaunchKernelGGL((k_wband_panel<NB>), dim3(g2), dim3(64 + WB_PANEL_ROWS), 0, s, n, bw, c0, W, notspd);
+        hipLaunchKernelGGL((k_wband_panel<NB>), dim3(g2), dim3(64 + WB_PANEL_ROWS), 0, s, n, bw, c0, W, dfac, notspd);
         if (below > 0) {
             const unsigned nt = (unsigned)((below + WB_TILE - 1) / WB_TILE);
             hipLaunchKernelGGL((k_wband_update<NB>), dim3(nt, nt), dim3(256), 0, s, n, bw, c0, W);
@@ -589,7 +622,7 @@ static int wide_band_run(int32_t n, int32_t bw, double *W, int *notspd) {
 }
 
 template <int NB>
-static int wide_band_run_fused(int32_t n, int32_t bw, double *W, int *notspd) {
+static int wide_band_run_fused(int32_t n, int32_t bw, double *W, double *dfac, int *notspd) {
     hipStream_t s = ctx().stream;
     for (int32_t c1 = 0; c1 < n; c1 += NB) {
         const int32_t below = std::min(n - 1, c1 + NB - 1 + bw) - (c1 + NB) + 1;    // rows under this panel's block
@@ -600,7 +633,7 @@ static int wide_band_run_fused(int32_t n, int32_t bw, double *W, int *notspd) {
             if (beyond > 0) ntB = (beyond + WB_TILE - 1) / WB_TILE;
         }
         hipLaunchKernelGGL((k_wband_step<NB>), dim3((unsigned)(gA + ntB * ntB)), dim3(64 + WB_PANEL_ROWS), 0, s, n, bw, c1,
-                           c1 > 0 ? 1 : 0, gA, ntB, W, notspd);
+                           c1 > 0 ? 1 : 0, gA, ntB, W, dfac, notspd);
     }
     CSX_LAUNCH_CHECK();
     return CSX_OK;
@@ -615,12 +648,15 @@ int chol_wide_band(int32_t n, int32_t bw, const int32_t *Lp, const int32_t *Li, 
     CSX_TRY(tmp.alloc(&W, count));
     CSX_HIP(hipMemsetAsync(W, 0, count * sizeof(double), s));
     const unsigned gw = (unsigned)(((int64_t)n + 3) / 4);
-    hipLaunchKernelGGL((k_wband_copy<true>), dim3(gw), dim3(256), 0, s, n, bw + 1, Lp, Li, Lx, W);
-    if (nb == 16) CSX_TRY(wide_band_run_fused<16>(n, bw, W, notspd));
-    else if (nb == 32) CSX_TRY(wide_band_run_fused<32>(n, bw, W, notspd));
-    else if (nb == -16) CSX_TRY(wide_band_run<16>(n, bw, W, notspd));     // two launches per panel (tests, timing)
-    else CSX_TRY(wide_band_run<32>(n, bw, W, notspd));
-    hipLaunchKernelGGL((k_wband_copy<false>), dim3(gw), dim3(256), 0, s, n, bw + 1, Lp, Li, Lx, W);
+    const int NBv = (nb == 32 || nb == -32) ? 32 : 16;
+    double *dfac = nullptr;                              // the factored diagonal blocks, panel-major
+    CSX_TRY(tmp.alloc(&dfac, ((size_t)n / NBv + 1) * NBv * NBv));
+    hipLaunchKernelGGL((k_wband_copy<true>), dim3(gw), dim3(256), 0, s, n, bw + 1, Lp, Li, Lx, W, dfac, NBv);
+    if (nb == 16) CSX_TRY(wide_band_run_fused<16>(n, bw, W, dfac, notspd));
+    else if (nb == 32) CSX_TRY(wide_band_run_fused<32>(n, bw, W, dfac, notspd));
+    else if (nb == -16) CSX_TRY(wide_band_run<16>(n, bw, W, dfac, notspd));     // two launches per panel (tests, timing)
+    else CSX_TRY(wide_band_run<32>(n, bw, W, dfac, notspd));
+    hipLaunchKernelGGL((k_wband_copy<false>), dim3(gw), dim3(256), 0, s, n, bw + 1, Lp, Li, Lx, W, dfac, NBv);
     CSX_LAUNCH_CHECK();
     CSX_HIP(hipStreamSynchronize(s));   // W is released when this returns
     return CSX_OK;
