@@ -198,7 +198,10 @@ void dfree(void *p) {
         // full it is the OLDEST idle blocks that go back to the driver, not this one.  (Freeing the newcomer instead
         // made a 12 GB work array of cs_multiply cost a hipFree + hipMalloc per call once an earlier phase had filled
         // the cache: 590 ms per multiply instead of 15.)
-        while (g_pool.cached + sz > g_pool.limit && !g_pool.idle.empty()) {
+        // Small blocks may overshoot the cap by up to 1/16 of it instead of evicting: handing a multi-GB block back to
+        // the driver takes tens of milliseconds, which is no price for caching a few megabytes.
+        const size_t cap = sz < ((size_t)64 << 20) ? g_pool.limit + g_pool.limit / 16 : g_pool.limit;
+        while (g_pool.cached + sz > cap && !g_pool.idle.empty()) {
             auto old = g_pool.idle.begin();
             for (auto k = g_pool.idle.begin(); k != g_pool.idle.end(); ++k)
                 if (k->second.stamp < old->second.stamp) old = k;
