@@ -320,7 +320,7 @@ extern "C" int csx_order_nd_host(int32_t n, const int32_t *Ap, const int32_t *Ai
     }
     // small problems: one thread (the pool costs more than it saves); else up to eight workers
     unsigned workers = 1;
-    if (n >= 20000) workers = std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    if (n >= 20000 || Ap[n] >= 200000) workers = std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
     std::vector<std::thread> threads;
     for (unsigned t = 1; t < workers; t++) threads.emplace_back([&pool] { pool.work(); });
     pool.work();
