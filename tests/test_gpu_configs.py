@@ -190,3 +190,27 @@ def test_results_on_pinned_inputs_stop_being_device_backed_once_read(cs):
     yl = [0.0] * n
     assert cs.cs_gaxpy(T, x.tolist(), yl)
     assert np.asarray(yl).tobytes() == ref.tobytes()
+
+
+def test_connected_problem_section_of_the_bench_runs_and_solves(cs):
+    """bench_configs.cholsol_connected (bench.py carries it under other_configs): bcsstk16 and a grid Laplacian, natural
+    order and order 1, one-shot call and both solve orders -- every residual small, the factor sizes as the symbolic
+    analysis says.  (A smaller grid than the bench's, same code path.)"""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench_configs as bc
+    keep = bc.SKIP_CPU
+    bc.SKIP_CPU = True
+    try:
+        out = bc.cholsol_connected(grid=90)["results"]
+    finally:
+        bc.SKIP_CPU = keep
+    for name, res in out.items():
+        for order in ("order_0", "order_1"):
+            r = res[order]
+            assert r["residual_inf"] is not None and r["residual_inf"] < 1e-9, (name, order, r)
+            assert r["lnz"] > res["n"] and r["cs_chol_ms"] > 0
+    assert out["bcsstk16"]["order_0"]["lnz"] == 610800
