@@ -240,7 +240,7 @@ class option(object):
         check(lib().csx_set_option(self.name, self.value), "csx_set_option")
         return self
 
-    DEFAULTS = {b"tri.levels_where": 0, b"chol.wband_nb": 16, b"pool.limit_mb": 0}
+    DEFAULTS = {b"tri.levels_where": 0, b"chol.wband_nb": 16, b"pool.limit_mb": 0, b"gaxpy.tune_shape": 0}
 
     def __exit__(self, *exc):
         check(lib().csx_set_option(self.name, self.DEFAULTS.get(self.name, 1)), "csx_set_option")

@@ -511,6 +511,7 @@ int csx_set_option(const char *name, int value) {
     else if (n == "tri.components") o.tri_components = value != 0;
     else if (n == "tri.columns") o.tri_columns = value != 0;
     else if (n == "gaxpy.keys24") o.gaxpy_keys24 = value != 0;
+    else if (n == "gaxpy.tune_shape") o.gaxpy_tune_shape = value != 0;
     else if (n == "tri.row_waves") o.tri_row_waves = value != 0;
     else if (n == "tri.push") o.tri_push = value != 0;
     else if (n == "tri.levels_where") o.tri_levels_where = (value == 1 || value == 2) ? value : 0;

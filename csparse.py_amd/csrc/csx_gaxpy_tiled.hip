@@ -159,9 +159,8 @@ __device__ __forceinline__ GroupRegs load_group_t(const uint32_t *__restrict__ k
                                                   const uint32_t *__restrict__ info, const uint32_t *__restrict__ base,
                                                   int32_t g, int lane) {
     GroupRegs r;
-    // a group belongs to ONE wave: its index is uniform, and saying so turns the group's 4-byte info word and 16-byte
-    // base record into scalar loads -- two vector memory instructions per group (of nine) leave the vector queue
-    g = __builtin_amdgcn_readfirstlane(g);
+    // (Tried: g = readfirstlane(g), which turns the group's info word and base record into scalar loads -- two of nine
+    // vector memory instructions per group gone, same time, 2.4 % more bytes at the memory side.  Not kept.)
     const int64_t gb = (int64_t)g * TL_GROUP;
     if (K24) {
         // `key` is the byte array of 3-byte keys: 12 bytes per lane, 768 per group
@@ -450,7 +449,10 @@ int gaxpy_tiled_prepare(Csc *A) {
     }
     A->tiled = t;
 #ifndef CSX_ABLATION
-    CSX_TRY(gaxpy_tiled_pick_shape(A));
+    // Off by default ("gaxpy.tune_shape"): on every box and run seen 4 x 5 was the fastest or within the noise of the
+    // fastest, and a choice made from two short timings is itself noisy (under the profiler it picked 8 x 4, which
+    // moves 13 % more bytes).  A plan that is not tuned launches 4 x 5.
+    if (ctx().opt.gaxpy_tune_shape) CSX_TRY(gaxpy_tiled_pick_shape(A));
 #endif
     return CSX_OK;
 }

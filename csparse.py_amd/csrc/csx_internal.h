@@ -129,6 +129,7 @@ struct Options {
     bool tri_push = true;             // tri-solve: component kernels in column-push form for L / U with few RHS
     bool tri_columns = true;          // tri-solve: small chain-like systems by the column loop, x in LDS
     bool gaxpy_keys24 = true;         // tiled cs_gaxpy plan: 3-byte keys when the matrix allows them
+    bool gaxpy_tune_shape = false;    // tiled cs_gaxpy plan: time the launch shapes when the plan is built and keep the fastest
     bool tri_row_waves = true;        // level-scheduled solves: a wave per row for few right-hand sides and long rows
     int tri_levels_where = 0;         // level analysis: 0 = device for big factors, host for small; 1 = host; 2 = device
 };

@@ -73,7 +73,7 @@ int csx_mem_info(int64_t *cached_bytes, int64_t *live_bytes, int64_t *device_fre
 /* Kernel-selection overrides, for tests that must reach a kernel the planner would not pick for a given input.
  * Every setting computes correct results; nothing here (or anywhere in the library) is read from the
  * environment.  Names (default 1): "chol.dense_trees", "chol.band", "cholsol.dense_blocks", "spgemm.one_pass",
- * "tri.chain_walker", "tri.components", "tri.columns", "tri.push", "tri.row_waves", "gaxpy.keys24"; "tri.levels_where" (default 0: level
+ * "tri.chain_walker", "tri.components", "tri.columns", "tri.push", "tri.row_waves", "gaxpy.keys24"; "gaxpy.tune_shape" (default 0); "tri.levels_where" (default 0: level
  * analysis of a triangular plan on the device for big factors and on the host for small ones; 1 = host, 2 = device);
  * "chol.wband" (blocked dense-band cs_chol for chain-like factors: default 1 = for half-widths above 80, 0 = never,
  * 2 = whenever the tree is chain-like) and "chol.wband_nb" (columns per step: 16 (default) or 32; negative: two
@@ -122,9 +122,10 @@ int csx_gaxpy_prepare(csx_handle_t A, int mode);
  * per key of the latter: 4 (column, row packed) or 3 (row + 9-bit column offset inside a run of 64 column-sorted
  * entries; chosen when every run is narrower than 512 columns); 0 without a tiled plan.  Any pointer may be NULL. */
 int csx_gaxpy_plan_info(csx_handle_t A, int *has_rows, int *has_tiled, int *key_bytes);
-/* The tiled plan times its launch shapes (waves per workgroup x groups per wave and step: same kernel, plan and
- * results) on the device when it is built and keeps the fastest: *shape = 0 (4 x 5), 1 (2 x 10), 2 (8 x 4), 3 (2 x 8),
- * or -1 (small matrix: not timed, 4 x 5); ms4[0..3] = the candidates' ms per pass.  CSX_EINVAL without a tiled plan. */
+/* With csx_set_option("gaxpy.tune_shape", 1) (default 0) the tiled plan times its launch shapes (waves per workgroup
+ * x groups per wave and step: same kernel, plan and results) on the device when it is built and keeps the fastest:
+ * *shape = 0 (4 x 5), 1 (2 x 10), 2 (8 x 4), 3 (2 x 8), or -1 (not timed: 4 x 5); ms4[0..3] = the candidates' ms per
+ * pass (0 when not timed).  CSX_EINVAL without a tiled plan. */
 int csx_gaxpy_plan_shape(csx_handle_t A, int *shape, double *ms4);
 /* One-shot form for host arrays (the reference's list signature): y[0..m) += A x in the reference's
  * summation order (bit-identical), nothing left on the device.  x (values) must be present. */
