@@ -71,8 +71,9 @@ int csx_device_info(char *name, int name_cap, int *compute_units, int64_t *hbm_b
 int csx_mem_trim(void);
 int csx_mem_info(int64_t *cached_bytes, int64_t *live_bytes, int64_t *device_free_bytes);
 /* Kernel-selection overrides, for tests that must reach a kernel the planner would not pick for a given input.
- * Every setting computes correct results; nothing here (or anywhere in the library) is read from the
- * environment.  Names (default 1): "chol.dense_trees", "chol.band", "cholsol.dense_blocks", "spgemm.one_pass",
+ * Every setting computes correct results; no environment variable changes which kernel runs or what it computes
+ * (the environment is read for the allocator's cap above and for CSX_CHOL_TIMING=1, which prints cs_chol's phase
+ * times to stderr).  Names (default 1): "chol.dense_trees", "chol.band", "cholsol.dense_blocks", "spgemm.one_pass",
  * "tri.chain_walker", "tri.components", "tri.columns", "tri.push", "tri.row_waves", "gaxpy.keys24"; "gaxpy.tune_shape" (default 0); "tri.levels_where" (default 0: level
  * analysis of a triangular plan on the device for big factors and on the host for small ones; 1 = host, 2 = device);
  * "chol.wband" (blocked dense-band cs_chol for chain-like factors: default 1 = for half-widths above 80, 0 = never,
