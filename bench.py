@@ -341,11 +341,26 @@ def main():
     tr = measured_traffic({"tiled": "k_gaxpy_tiled<0,", "wave": "k_gaxpy_rows", "atomic": "k_gaxpy_atomic"}[chosen],
                           n=n, nnz=nnz, kernel="gaxpy_" + chosen)
 
-    # sanity: y accumulated (warmup+steps) passes of A x from zero; check one entry-independent property
-    yhead = np.empty(1000)
-    _csx.check(lib.csx_vec_download(hy, _csx.pd(yhead), 1000), "vec_download")
-    ysum = float(np.sum(yhead))
-    assert os.environ.get("CSX_TILED_VARIANT") or (np.isfinite(ysum) and ysum > 0)
+    # parity of the timed kernel ON THE TIMED MATRIX, after the timed region: one pass of the chosen kernel from y = 0
+    # against one pass of the reference-order kernel (GAXPY_EXACT: thread per row, terms in ascending (column, position)
+    # order, multiply and add rounded separately -- bit-identical to csparse.py:1210-1212, tests/test_gpu_parity.py).
+    hy1, hy2 = _csx.new_handle(), _csx.new_handle()
+    _csx.check(lib.csx_vec_alloc(n, hy1), "vec_alloc")
+    _csx.check(lib.csx_vec_alloc(n, hy2), "vec_alloc")
+    _csx.check(lib.csx_gaxpy(hA, hx, hy1, mode), "gaxpy check")
+    _csx.check(lib.csx_gaxpy(hA, hx, hy2, cs.GAXPY_EXACT), "gaxpy exact")
+    ya, ye = np.empty(n), np.empty(n)
+    _csx.check(lib.csx_vec_download(hy1, _csx.pd(ya), n), "vec_download")
+    _csx.check(lib.csx_vec_download(hy2, _csx.pd(ye), n), "vec_download")
+    for h in (hy1, hy2):
+        _csx.free(h)
+    nzr = ye > 0                                          # all-positive data; a row may be empty under the uniform draw
+    parity_err = float(np.max(np.abs(ya[nzr] - ye[nzr]) / ye[nzr])) if nzr.any() else 0.0
+    parity_ok = bool(np.all(np.isfinite(ye)) and np.all(ya[~nzr] == 0) and parity_err < 1e-12)
+    if not (parity_ok or os.environ.get("CSX_TILED_VARIANT")):
+        raise SystemExit("bench.py: the timed kernel disagrees with the reference-order kernel on the timed matrix "
+                         "(max relative error %.3e)" % parity_err)
+    del ya, ye
 
     key_bytes = _csx.C.c_int(0)
     _csx.check(lib.csx_gaxpy_plan_info(hA, None, None, key_bytes), "plan_info")
@@ -360,9 +375,6 @@ def main():
         "config": {"workload": "cs_gaxpy y += A x on G-rand: %d x %d CSC, %s, int32 indices, fp64 values; one "
                                "independent matrix per GPU" % (n, n, gen_words[args.gen]), "row_draw": args.gen,
                    "n": n, "nnz": nnz, "kernel": "gaxpy_" + chosen, "plan_key_bytes": key_bytes.value,
-                   "plan_launch_shape": {"picked": ["4x5", "2x10", "8x4", "2x8"][shape.value] if shape.value >= 0 else None,
-                                         "ms_when_the_plan_was_built": {k: round(v, 4) for k, v in
-                                                                        zip(("4x5", "2x10", "8x4", "2x8"), shape_ms)}},
                    "algorithmic_bytes_per_step": by,
                    "parallelism": "independent matrices, 1 per GPU, no data-path collective"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -373,7 +385,32 @@ def main():
                      "step_ms_hip_events": round(step_ms_events, 4)},
         "gaxpy_trials_ms": {k: round(v["ms"], 4) for k, v in trial.items()},
         "gaxpy_prepare_s": {k: round(v["prepare_s"], 3) for k, v in trial.items()},
+        "parity_on_the_timed_matrix": {"against": "GAXPY_EXACT (reference summation order, csparse.py:1210-1212)",
+                                       "max_rel_err": parity_err, "tolerance": 1e-12, "ok": parity_ok},
     }
+    if shape.value >= 0:                                  # only when the plan timed its launch shapes (gaxpy.tune_shape)
+        out["config"]["plan_launch_shape"] = {"picked": ["4x5", "2x10", "8x4", "2x8"][shape.value],
+                                              "ms_when_the_plan_was_built": {k: round(v, 4) for k, v in
+                                                                             zip(("4x5", "2x10", "8x4", "2x8"), shape_ms)}}
+    # the spread of the headline with the device's state: three more trials of the same K steps, each behind a different
+    # kernel (a transposing sort, the exact kernel, nothing), HIP-event timed.  `value` stays the contract's timed region.
+    spread = []
+    for k in range(3):
+        if k == 0:
+            _csx.check(lib.csx_gaxpy(hA, hx, hy, cs.GAXPY_EXACT), "gaxpy exact")
+        elif k == 1:
+            hT = _csx.new_handle()
+            _csx.check(lib.csx_transpose(hA, 1, hT), "transpose")
+            _csx.free(hT)
+        with _csx.Timer() as tm:
+            for _ in range(args.steps):
+                _csx.check(lib.csx_gaxpy(hA, hx, hy, mode), "gaxpy")
+        spread.append(max_over_ranks(tm.ms / args.steps))
+    allt = sorted(spread + [step_ms_events])
+    med = allt[len(allt) // 2] if len(allt) % 2 else 0.5 * (allt[len(allt) // 2 - 1] + allt[len(allt) // 2])
+    out["headline_trials"] = {"ms_per_step": [round(step_ms_events, 4)] + [round(t, 4) for t in spread],
+                              "median_ms": round(med, 4), "median_frac_of_peak": round(by / (med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                              "note": "first = the timed region of `value`; then behind the exact kernel, behind a transpose, back to back"}
     _csx.free(hA)
     deadline = Deadline(args.extras_deadline, rank)
     deadline.arm(out)

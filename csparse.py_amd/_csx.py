@@ -38,6 +38,7 @@ _PROTOS = {
     "csx_cholsol_growth": [H, _f64p],
     "csx_csc_invalidate": [H],
     "csx_set_option": [C.c_char_p, C.c_int],
+    "csx_get_option": [C.c_char_p, C.POINTER(C.c_int)],
     "csx_gaxpy_host": [C.c_int32, C.c_int32, _i32p, _i32p, _f64p, _f64p, _f64p],
     "csx_csc_col_block": [H, C.c_int32, C.c_int32, C.POINTER(H)],
     "csx_mem_trim": [],
@@ -237,13 +238,14 @@ class option(object):
         self.name, self.value = name.encode(), int(value)
 
     def __enter__(self):
+        old = C.c_int(0)
+        check(lib().csx_get_option(self.name, C.byref(old)), "csx_get_option")
+        self.old = old.value                      # the value in force on entry: nested blocks restore correctly
         check(lib().csx_set_option(self.name, self.value), "csx_set_option")
         return self
 
-    DEFAULTS = {b"tri.levels_where": 0, b"chol.wband_nb": 16, b"pool.limit_mb": 0, b"gaxpy.tune_shape": 0}
-
     def __exit__(self, *exc):
-        check(lib().csx_set_option(self.name, self.DEFAULTS.get(self.name, 1)), "csx_set_option")
+        check(lib().csx_set_option(self.name, self.old), "csx_set_option")
         return False
 
 

@@ -52,6 +52,7 @@ class _DevMatrix(object):
     def __init__(self, handle):
         self.handle = handle
         self.plans = {}
+        self.version = 0      # bumped when the values change in place (cs_updown): solvers built on it re-plan
         self._fin = weakref.finalize(self, _DevMatrix._release, handle, self.plans)
 
     @staticmethod
@@ -945,6 +946,7 @@ def cs_updown(L, sigma, C, parent):
         for h in dL.plans.values():          # triangular-solve plans hold copies of the old values
             _csx.free(h)
         dL.plans.clear()
+        dL.version += 1                      # cholsol_factor solvers built on this factor re-plan at their next solve
         st = _csx.lib().csx_updown(dL.handle, int(sigma), cnz, _csx.pi(ci), _csx.pd(cx), _csx.pi(par), ok)
         if st == _csx.EINVAL:
             raise IndexError("list index out of range")
@@ -997,30 +999,49 @@ def cholsol_factor(A, order=0, exact=True):
         v = getattr(S, name)
         if v is not None and not isinstance(v, list):
             setattr(S, name, v.tolist())
-    plan = _csx.new_handle()
-    with _Resident(N.L) as dL:
-        _csx.check(_csx.lib().csx_cholsol_plan(dL.handle, _csx.pi(pinv), plan), "csx_cholsol_plan")
-    if not exact:
-        _csx.check(_csx.lib().csx_cholsol_set_order(plan, 0), "csx_cholsol_set_order")
+    # The C plan BORROWS L's device arrays (CholPlan::L is not owned; the L' plan reads L.p / L.i / L.x directly),
+    # so the factor must stay on the device for as long as the solver lives: N.L is pinned (reading F.L.p / .i / .x
+    # copies to the host but keeps the device matrix), and the solver holds the _DevMatrix itself.
+    cs_pin(N.L)
+    dev = N.L._dev
     n = A.n
+
+    def _build():
+        h = _csx.new_handle()
+        _csx.check(_csx.lib().csx_cholsol_plan(dev.handle, _csx.pi(pinv), h), "csx_cholsol_plan")
+        if not exact:
+            _csx.check(_csx.lib().csx_cholsol_set_order(h, 0), "csx_cholsol_set_order")
+        return h
 
     class _Solver(object):
         L = N.L
         symbolic = S
-        plan_handle = plan
 
         def __init__(self):
-            self._fin = weakref.finalize(self, _csx.free, plan)
+            self._dev = dev                      # keeps the device factor alive (see above)
+            self._built = dev.version
+            self.plan_handle = _build()
+            self._box = [self.plan_handle]
+            self._fin = weakref.finalize(self, lambda box: _csx.free(box[0]), self._box)
+
+        def _current(self):
+            """The plan copies part of L's values (forward gather arrays, fragments): after cs_updown(F.L, ...) changed
+            the factor in place it is rebuilt from the factor as it now stands."""
+            if self._built != dev.version:
+                _csx.free(self.plan_handle)
+                self.plan_handle = self._box[0] = _build()
+                self._built = dev.version
+            return self.plan_handle
 
         def info(self):
             a, b, c = _csx.C.c_int32(), _csx.C.c_int32(), _csx.C.c_int32()
-            _csx.check(_csx.lib().csx_cholsol_info(plan, a, b, c), "csx_cholsol_info")
+            _csx.check(_csx.lib().csx_cholsol_info(self._current(), a, b, c), "csx_cholsol_info")
             return {"fused_local": a.value >= 1, "dense_block": c.value if a.value >= 2 else 0,  # dense kernels in use
                     "matrix_cores": a.value == 3, "trees": b.value, "max_nodes": c.value}
 
         def solve(self, b):
             db, bhost = _vec_in(b, n, "b")
-            _csx.check(_csx.lib().csx_cholsol_solve(plan, db.handle, db.k), "csx_cholsol_solve")
+            _csx.check(_csx.lib().csx_cholsol_solve(self._current(), db.handle, db.k), "csx_cholsol_solve")
             _write_back(bhost, db, n * db.k)
             return True
 
@@ -1054,7 +1075,7 @@ def cs_lu(A, S, tol):
     diagonal first in every column, U its diagonal last -- what cs_lsolve / cs_usolve need."""
     if not CS_CSC(A) or S is None:
         return None
-    if A.x is None:
+    if not _meta(A)[1]:        # asked of the device for a device-made A: no download, the device copy stays
         raise TypeError("'NoneType' object is not subscriptable")
     n = A.n
     if A.m != n:
@@ -1249,7 +1270,7 @@ def cs_qr(A, S):
     small independent blocks, which factors on the device (csx_qr_blocks: one lane per block, same results bit for bit)."""
     if not CS_CSC(A) or S is None:
         return None
-    if A.x is None:
+    if not _meta(A)[1]:
         raise TypeError("'NoneType' object is not subscriptable")
     m, n, m2 = A.m, A.n, S.m2
     q = None if S.q is None else _csx.i32(S.q)

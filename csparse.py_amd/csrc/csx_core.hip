@@ -1,4 +1,5 @@
 // Context, handles, host<->device transfers, timers.
+#include <algorithm>
 #include <cstdarg>
 #include <cstdlib>
 #include <cstring>
@@ -442,9 +443,44 @@ int csx_csc_wrap(int32_t m, int32_t n, int32_t nnz, void *d_p, void *d_i, void *
     A->i = (int32_t *)d_i;
     A->x = (double *)d_x;
     A->owns = false;
+    A->trusted = false;   // caller's arrays: checked (csc_validate) by the kernels that index work space with them
     *out = put(K_CSC, A);
     return CSX_OK;
 }
+
+}  // extern "C"
+
+namespace csx {
+__global__ void k_csc_validate(int32_t m, int32_t n, int32_t nnz, const int32_t *__restrict__ p,
+                               const int32_t *__restrict__ i, int32_t *bad) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+    bool b = false;
+    for (int64_t j = t; j < n; j += stride) b |= p[j] > p[j + 1] || p[j] < 0;
+    if (t == 0) b |= p[0] != 0 || p[n] != nnz;
+    for (int64_t q = t; q < nnz; q += stride) b |= (uint32_t)i[q] >= (uint32_t)m;
+    if (b) atomicOr(bad, 1);
+}
+
+int csc_validate(Csc *A) {
+    if (A->trusted) return CSX_OK;
+    hipStream_t s = ctx().stream;
+    DevScope tmp;
+    int32_t *bad = nullptr, h = 0;
+    CSX_TRY(tmp.alloc(&bad, 1));
+    CSX_HIP(hipMemsetAsync(bad, 0, sizeof(int32_t), s));
+    const int64_t work = std::max<int64_t>((int64_t)A->n, (int64_t)A->nnz);
+    const unsigned grid = (unsigned)std::min<int64_t>(4096, (work + 255) / 256 + 1);
+    hipLaunchKernelGGL(k_csc_validate, dim3(grid), dim3(256), 0, s, A->m, A->n, A->nnz, A->p, A->i, bad);
+    CSX_LAUNCH_CHECK();
+    CSX_HIP(hipMemcpyAsync(&h, bad, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    CSX_HIP(hipStreamSynchronize(s));
+    if (h) return CSX_EINVAL;
+    A->trusted = true;
+    return CSX_OK;
+}
+}  // namespace csx
+
+extern "C" {
 
 int csx_csc_info(csx_handle_t h, int32_t *m, int32_t *n, int32_t *nnz, int *has_values) {
     Csc *A = csc(h);
@@ -495,28 +531,67 @@ int csx_free(csx_handle_t h) {
 }
 
 /* Kernel-selection overrides for tests (see Options in csx_internal.h). */
+/* name -> (slot, kind): kind 0 = flag (0 / 1), otherwise the option's own value rule (normalise()). */
+namespace {
+struct OptSlot {
+    const char *name;
+    int Options::*field;
+    int kind;
+};
+const OptSlot kOptSlots[] = {
+    {"chol.dense_trees", &Options::chol_dense_trees, 0}, {"chol.band", &Options::chol_band, 0},
+    {"chol.supernodes", &Options::chol_supernodes, 0},   {"chol.wband", &Options::chol_wband, 1},
+    {"chol.wband_nb", &Options::chol_wband_nb, 2},       {"cholsol.dense_blocks", &Options::cholsol_dense_blocks, 0},
+    {"spgemm.one_pass", &Options::spgemm_one_pass, 0},   {"tri.chain_walker", &Options::tri_chain_walker, 0},
+    {"tri.components", &Options::tri_components, 0},     {"tri.columns", &Options::tri_columns, 0},
+    {"gaxpy.keys24", &Options::gaxpy_keys24, 0},         {"gaxpy.tune_shape", &Options::gaxpy_tune_shape, 0},
+    {"tri.row_waves", &Options::tri_row_waves, 0},       {"tri.push", &Options::tri_push, 0},
+    {"tri.levels_where", &Options::tri_levels_where, 3}, {"tri.supernodes", &Options::tri_supernodes, 0},
+    {"spgemm.ordered", &Options::spgemm_ordered, 0},     {"spgemm.chunks", &Options::spgemm_chunks, 4},
+    {"lu.etree", &Options::lu_etree, 0},
+};
+int normalise(int kind, int value) {
+    switch (kind) {
+    case 0: return value != 0;
+    case 1: return (value == 0 || value == 2) ? value : 1;
+    case 2: return (value == 32 || value == -16 || value == -32) ? value : 16;   // negative: two launches per panel
+    case 3: return (value == 1 || value == 2) ? value : 0;
+    case 4: return value < 0 ? 0 : (value > 64 ? 64 : value);
+    }
+    return value;
+}
+int g_pool_limit_mb = 0;
+}  // namespace
+
 int csx_set_option(const char *name, int value) {
     if (!name) return CSX_EINVAL;
-    Options &o = ctx().opt;
     const std::string n(name);
-    if (n == "chol.dense_trees") o.chol_dense_trees = value != 0;
-    else if (n == "chol.band") o.chol_band = value != 0;
-    else if (n == "chol.supernodes") o.chol_supernodes = value != 0;
-    else if (n == "pool.limit_mb") pool_set_limit(value > 0 ? (size_t)value << 20 : 0);   // 0: the default
-    else if (n == "chol.wband") o.chol_wband = (value == 0 || value == 2) ? value : 1;
-    else if (n == "chol.wband_nb") o.chol_wband_nb = (value == 32 || value == -16 || value == -32) ? value : 16;   // negative: two launches per panel
-    else if (n == "cholsol.dense_blocks") o.cholsol_dense_blocks = value != 0;
-    else if (n == "spgemm.one_pass") o.spgemm_one_pass = value != 0;
-    else if (n == "tri.chain_walker") o.tri_chain_walker = value != 0;
-    else if (n == "tri.components") o.tri_components = value != 0;
-    else if (n == "tri.columns") o.tri_columns = value != 0;
-    else if (n == "gaxpy.keys24") o.gaxpy_keys24 = value != 0;
-    else if (n == "gaxpy.tune_shape") o.gaxpy_tune_shape = value != 0;
-    else if (n == "tri.row_waves") o.tri_row_waves = value != 0;
-    else if (n == "tri.push") o.tri_push = value != 0;
-    else if (n == "tri.levels_where") o.tri_levels_where = (value == 1 || value == 2) ? value : 0;
-    else return CSX_EINVAL;
-    return CSX_OK;
+    if (n == "pool.limit_mb") {
+        g_pool_limit_mb = value > 0 ? value : 0;
+        pool_set_limit(value > 0 ? (size_t)value << 20 : 0);   // 0: the default
+        return CSX_OK;
+    }
+    for (const OptSlot &s : kOptSlots)
+        if (n == s.name) {
+            ctx().opt.*(s.field) = normalise(s.kind, value);
+            return CSX_OK;
+        }
+    return CSX_EINVAL;
+}
+
+int csx_get_option(const char *name, int *value) {
+    if (!name || !value) return CSX_EINVAL;
+    const std::string n(name);
+    if (n == "pool.limit_mb") {
+        *value = g_pool_limit_mb;
+        return CSX_OK;
+    }
+    for (const OptSlot &s : kOptSlots)
+        if (n == s.name) {
+            *value = ctx().opt.*(s.field);
+            return CSX_OK;
+        }
+    return CSX_EINVAL;
 }
 
 /* The SpMV plans cached on a matrix (the row-major copy, the LDS-tiled regrouping) hold COPIES of its values.
@@ -527,6 +602,7 @@ int csx_csc_invalidate(csx_handle_t h) {
     Csc *A = csc(h);
     if (!A) return CSX_EINVAL;
     (void)hipStreamSynchronize(ctx().stream);
+    if (!A->owns) A->trusted = false;   // the caller changed its arrays: check them again
     free_gather(A->rows);
     A->rows = nullptr;
     free_tiled(A->tiled);

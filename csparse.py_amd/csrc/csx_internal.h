@@ -92,6 +92,7 @@ struct Csc {
     int32_t *i = nullptr;
     double *x = nullptr;  // nullptr: pattern only
     bool owns = true;
+    bool trusted = true;  // structure made or checked by the library; false for csx_csc_wrap until csc_validate has passed
     // cached plans (built on demand, freed with the matrix)
     Gather *rows = nullptr;   // stable transpose = rows of A in ascending column order
     TiledPlan *tiled = nullptr;
@@ -116,22 +117,26 @@ struct Object {
 // Kernel-selection overrides for TESTS of the kernels a plan would not pick by itself (csx_set_option).  Every
 // setting computes correct results; none is read from the environment.
 struct Options {
-    bool chol_band = true;            // cs_chol: register-window kernel for chain-like banded factors
+    int chol_band = 1;                // cs_chol: register-window kernel for chain-like banded factors
     int chol_wband = 1;               // cs_chol: blocked dense-band kernels for chain-like factors: 0 never, 1 for half-widths
                                       // above 80 (below, the register-window kernel), 2 whenever the tree is chain-like
     int chol_wband_nb = 16;           // ... columns per step (16 or 32)
-    bool chol_supernodes = true;      // cs_chol: fundamental supernodes of >= 8 columns factored as dense trapezoids in place
-    bool chol_dense_trees = true;     // cs_chol: LDS dense-block kernel for trees that are dense blocks
-    bool cholsol_dense_blocks = true; // cholsol: dense-block kernels (false: the fused per-tree kernel)
-    bool spgemm_one_pass = true;      // cs_multiply: one-walk LDS hash kernel (false: the two-pass kernel)
-    bool tri_chain_walker = true;     // tri-solve: blocked chain walker for runs of narrow levels
-    bool tri_components = true;       // tri-solve: one wave per small connected component (false: level sets)
-    bool tri_push = true;             // tri-solve: component kernels in column-push form for L / U with few RHS
-    bool tri_columns = true;          // tri-solve: small chain-like systems by the column loop, x in LDS
-    bool gaxpy_keys24 = true;         // tiled cs_gaxpy plan: 3-byte keys when the matrix allows them
-    bool gaxpy_tune_shape = false;    // tiled cs_gaxpy plan: time the launch shapes when the plan is built and keep the fastest
-    bool tri_row_waves = true;        // level-scheduled solves: a wave per row for few right-hand sides and long rows
+    int chol_supernodes = 1;      // cs_chol: fundamental supernodes of >= 8 columns factored as dense trapezoids in place
+    int chol_dense_trees = 1;     // cs_chol: LDS dense-block kernel for trees that are dense blocks
+    int cholsol_dense_blocks = 1; // cholsol: dense-block kernels (false: the fused per-tree kernel)
+    int spgemm_one_pass = 1;      // cs_multiply: one-walk LDS hash kernel (false: the two-pass kernel)
+    int tri_chain_walker = 1;     // tri-solve: blocked chain walker for runs of narrow levels
+    int tri_components = 1;       // tri-solve: one wave per small connected component (false: level sets)
+    int tri_push = 1;             // tri-solve: component kernels in column-push form for L / U with few RHS
+    int tri_columns = 1;          // tri-solve: small chain-like systems by the column loop, x in LDS
+    int gaxpy_keys24 = 1;         // tiled cs_gaxpy plan: 3-byte keys when the matrix allows them
+    int gaxpy_tune_shape = 0;    // tiled cs_gaxpy plan: time the launch shapes when the plan is built and keep the fastest
+    int tri_row_waves = 1;        // level-scheduled solves: a wave per row for few right-hand sides and long rows
     int tri_levels_where = 0;         // level analysis: 0 = device for big factors, host for small; 1 = host; 2 = device
+    int tri_supernodes = 1;           // cholsol: dense-block (supernodal) forward / backward solves on factors with supernodes
+    int spgemm_ordered = 0;           // cs_multiply: sum every entry's products in the reference's order (bit-identical x)
+    int spgemm_chunks = 8;            // cs_multiply: column chunks whose compaction overlaps the next chunk's hashing (0/1: off)
+    int lu_etree = 1;                 // cs_lu of one connected matrix on the device, columns scheduled by the column etree
 };
 
 struct Context {
@@ -210,6 +215,9 @@ int boundaries_from_sorted(const uint32_t *sorted_key, int64_t count, int32_t nk
 
 // ---- building blocks shared across files ----
 int build_row_gather(Csc *A);   // fills A->rows (values required)
+// Structure check of a matrix whose arrays the library did not make (csx_csc_wrap): p non-decreasing from 0 to nnz,
+// every row index in [0, m), in one device pass.  CSX_EINVAL (IndexError in Python) otherwise; remembered in A->trusted.
+int csc_validate(Csc *A);
 int transpose_device(const Csc *A, bool values, Csc *C);  // C fields allocated here
 
 // Workgroup barrier that orders LDS only.  __syncthreads() carries a fence over global memory as well: it waits for

@@ -123,6 +123,9 @@ extern "C" int csx_spsolve(csx_handle_t hG, csx_handle_t hB, const int32_t *pinv
     if (!G || !B || !out || G->m != G->n || B->m != G->n) return CSX_EINVAL;
     const bool with_values = values != 0;
     if (with_values && (!G->x || !B->x)) return CSX_EINVAL;
+    // the reach kernels index per-lane work arrays with G's and B's row indices: arrays the library did not make are checked
+    CSX_TRY(csc_validate(G));
+    CSX_TRY(csc_validate(B));
     const int32_t n = G->n, nb = B->n;
     if (pinv_host)
         for (int32_t j = 0; j < n; j++)

@@ -81,6 +81,7 @@ int csx_mem_info(int64_t *cached_bytes, int64_t *live_bytes, int64_t *device_fre
  * launches per step instead of one); "chol.supernodes" (default 1); "pool.limit_mb" (cap of the device-memory cache in MB,
  * 0 = the default quarter of the device).  Unknown name: CSX_EINVAL. */
 int csx_set_option(const char *name, int value);
+int csx_get_option(const char *name, int *value);   /* the value in force (after csx_set_option's normalisation) */
 int csx_timer_start(void);                /* hipEvent on the context's stream */
 int csx_timer_stop(double *ms);           /* second hipEvent, synchronises, elapsed ms */
 

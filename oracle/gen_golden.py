@@ -400,12 +400,24 @@ def main():
     if sys.argv[1:] == ["config2"]:
         print("config2", config2_fixture())
         return
+    if sys.argv[1:] == ["mbeacxc"]:
+        # the tenth matrix of csparse_test.py (Test1 :381-394, Test2 :596-606): 492 x 490, 49 920 entries, rank deficient;
+        # added to an existing fixture set without regenerating the others
+        with open(os.path.join(OUT, "meta.json")) as f:
+            meta = json.load(f)
+        meta["mbeacxc"] = matrix_fixture("mbeacxc", big=True)
+        print("mbeacxc", json.dumps(meta["mbeacxc"])[:400])
+        with open(os.path.join(OUT, "meta.json"), "w") as f:
+            json.dump(meta, f, indent=1, sort_keys=True)
+        return
     meta = {}
     for name in ("t1", "bcsstk01", "west0067", "ash219", "fs_183_1", "ibm32a", "ibm32b", "lp_afiro"):
         meta[name] = matrix_fixture(name)
         print(name, json.dumps(meta[name])[:200])
     meta["bcsstk16"] = matrix_fixture("bcsstk16", big=True)
     print("bcsstk16", json.dumps(meta["bcsstk16"])[:300])
+    meta["mbeacxc"] = matrix_fixture("mbeacxc", big=True)
+    print("mbeacxc", json.dumps(meta["mbeacxc"])[:300])
     synthetic_fixture(20240601)
     meta["config2_bcsstk16"] = config2_fixture()
     meta["updown"] = updown_fixture()

@@ -69,6 +69,37 @@ def grand_uniform(n, per_col, seed):
     return Ap, Ai, Ax
 
 
+def grand_uniform_columns(n, per_col, seed, j0, count):
+    """Columns [j0, j0 + count) of grand_uniform(n, per_col, seed) without building the rest: (Ai, Ax) of the window.
+    (Every column is a pure function of its own entry numbers, so a window of the full-size matrix can be checked.)"""
+    e = np.arange(j0 * per_col, (j0 + count) * per_col, dtype=np.uint64)
+    t = (e % np.uint64(per_col)).reshape(count, per_col)
+    with np.errstate(over="ignore"):
+        r = (hash2(seed, e * np.uint64(64)) % np.uint64(n)).reshape(count, per_col)
+    key = (r << np.uint64(12)) | (t << np.uint64(6))
+    key.sort(axis=1)
+    rows = key >> np.uint64(12)
+    bad = np.nonzero((rows[:, 1:] == rows[:, :-1]).any(axis=1))[0]
+    for jj in bad:
+        k = key[jj].copy()
+        for _ in range(64):
+            k.sort()
+            rr = k >> np.uint64(12)
+            dup = np.zeros(per_col, dtype=bool)
+            dup[1:] = rr[1:] == rr[:-1]
+            if not dup.any():
+                break
+            tt = (k[dup] >> np.uint64(6)) & np.uint64(63)
+            aa = (k[dup] & np.uint64(63)) + np.uint64(1)
+            with np.errstate(over="ignore"):
+                et = np.uint64(j0 + jj) * np.uint64(per_col) + tt
+                k[dup] = ((hash2(seed, et * np.uint64(64) + aa) % np.uint64(n)) << np.uint64(12)) | (tt << np.uint64(6)) | aa
+        key[jj] = k
+    Ai = (key >> np.uint64(12)).astype(np.int32).reshape(-1)
+    Ax = 0.5 + unit(hash2(seed + 1, e))
+    return Ai, Ax
+
+
 def gspd(nblocks, bs, seed):
     """G-spd: block-diagonal SPD, dense bs-by-bs blocks."""
     n = nblocks * bs

@@ -165,3 +165,27 @@ def test_full_cache_keeps_the_block_just_released_and_drops_the_oldest(cs):
         assert cached3 - cached0 < 8 * n                   # served from the cache
         _csx.free(hC)
     _csx.check(lib.csx_mem_trim(), "trim")
+
+
+def test_option_blocks_nest_and_restore_what_was_in_force(cs):
+    import _csx
+    lib = _csx.lib()
+    v = _csx.C.c_int(-7)
+
+    def get(name):
+        _csx.check(lib.csx_get_option(name.encode(), v))
+        return v.value
+
+    assert get("chol.wband") == 1 and get("tri.levels_where") == 0 and get("chol.wband_nb") == 16
+    _csx.check(lib.csx_set_option(b"chol.wband", 2))            # a process-wide non-default setting ...
+    with _csx.option("chol.wband", 0):
+        assert get("chol.wband") == 0
+        with _csx.option("chol.wband", 1):
+            assert get("chol.wband") == 1
+        assert get("chol.wband") == 0                           # ... inner block restores the outer block's value
+    assert get("chol.wband") == 2                               # ... and the outer one the process-wide one
+    _csx.check(lib.csx_set_option(b"chol.wband", 1))
+    with _csx.option("tri.levels_where", 5):                    # normalised by the library
+        assert get("tri.levels_where") == 0
+    assert lib.csx_get_option(b"no.such.option", v) == _csx.EINVAL
+    assert lib.csx_set_option(b"no.such.option", 1) == _csx.EINVAL

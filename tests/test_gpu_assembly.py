@@ -163,3 +163,49 @@ def test_norm_on_device_has_the_reference_bits(cs, name, meta):
     P = unpack(cs, g, "A")
     P.x = None
     assert cs.cs_norm(cs.cs_pin(P)) == -1 and cs.cs_norm(None) == -1
+
+
+@pytest.mark.parametrize("name", ["west0067", "ash219", "lp_afiro", "bcsstk16"])
+def test_col_block_is_the_oracle_column_slice(cs, name):
+    """csx_csc_col_block (the unit of a column-sharded SpMV): columns [first, first + count) of A as an
+    m x count matrix -- p rebased to 0, i and x the slice, bit for bit -- for every split the strong-scaling
+    partition makes at 1 / 2 / 3 / 8 ranks, and empty and full ranges; the blocks' SpMVs sum to the unsharded one."""
+    import _csx
+    import shard
+    lib = _csx.lib()
+    g = golden(name)
+    A = cs.cs_pin(unpack(cs, g, "A"))
+    Ap, nnz = np.asarray(g["A_p"]), int(g["A_p"][-1])
+    Ai, Ax = np.asarray(g["A_i"]), np.asarray(g["A_x"])
+    m, n = A.m, A.n
+    x = 1.0 + np.arange(n) / n
+    yfull = np.zeros(m)
+    dy = cs.dvec(m)
+    assert cs.cs_gaxpy(A, cs.dvec(x), dy, cs.GAXPY_EXACT)
+    yfull = dy.numpy()
+    for world in (1, 2, 3, 8):
+        ysum = np.zeros(m)
+        for r in range(world):
+            first, count = shard.strong_block(r, world, n)
+            h = _csx.new_handle()
+            _csx.check(lib.csx_csc_col_block(A._dev.handle, first, count, h))
+            mm, nn, zz, hv = (_csx.C.c_int32(), _csx.C.c_int32(), _csx.C.c_int32(), _csx.C.c_int())
+            _csx.check(lib.csx_csc_info(h, mm, nn, zz, hv))
+            lo, hi = int(Ap[first]), int(Ap[first + count])
+            assert (mm.value, nn.value, zz.value, hv.value) == (m, count, hi - lo, 1)
+            p, i, v = np.empty(count + 1, np.int32), np.empty(max(hi - lo, 1), np.int32), np.empty(max(hi - lo, 1))
+            _csx.check(lib.csx_csc_download(h, _csx.pi(p), _csx.pi(i), _csx.pd(v)))
+            assert (p == Ap[first:first + count + 1] - lo).all()
+            assert (i[:hi - lo] == Ai[lo:hi]).all() and v[:hi - lo].tobytes() == Ax[lo:hi].tobytes()
+            part = cs.dvec(m)
+            xs = cs.dvec(x[first:first + count] if count else np.zeros(1))     # this rank's slice of x
+            _csx.check(lib.csx_gaxpy(h, xs.handle, part.handle, cs.GAXPY_EXACT))
+            ysum += part.numpy()
+            _csx.free(h)
+        scale = np.abs(yfull) + 1e-300
+        assert np.max(np.abs(ysum - yfull) / scale) < 1e-12, world
+    h = _csx.new_handle()
+    assert lib.csx_csc_col_block(A._dev.handle, n - 1, 2, h) == _csx.EINVAL
+    assert lib.csx_csc_col_block(A._dev.handle, -1, 1, h) == _csx.EINVAL
+    _csx.check(lib.csx_csc_col_block(A._dev.handle, n, 0, h))          # empty block at the end is legal
+    _csx.free(h)

@@ -569,3 +569,46 @@ def test_chain_tree_with_a_wide_but_empty_band_stays_with_the_sparse_kernels(cs)
     # (the last pivot is a sum of 6 000 terms, taken in 16 partial sums by the cooperative column kernel: 1.5e-13)
     assert np.max(np.abs(np.asarray(N.L.x[:Lp[n]]) - Lx)) / np.abs(Lx).max() < 1e-12
     assert dt < 5.0                                        # the dense-band path would take far longer than this
+
+
+def test_solver_keeps_its_factor_alive_and_follows_updown(cs):
+    """cholsol_factor's C plan borrows L's device arrays.  (1) Reading F.L.p / .i / .x (which copies to the host) and
+    then churning the allocator with same-size blocks must not pull the factor out from under the plan: on a big-tree
+    matrix (bcsstk16: the level-scheduled path, whose L' plan reads L.p / L.i / L.x directly) the solve must still be
+    bit-identical to the oracle's cs_lsolve + cs_ltsolve.  (2) cs_updown(F.L, ...) changes the factor in place: the
+    solver re-plans and solves with the NEW factor in both sweeps."""
+    import _csx
+    g = golden("bcsstk16")
+    C = cs.cs_pin(unpack(cs, g, "C"))
+    n = C.n
+    with _csx.option("pool.limit_mb", 64):           # a small cache: freed blocks go back to the driver / get reused at once
+        F = cs.cholsol_factor(C)
+        Lp, Li, Lx = np.asarray(F.L.p, np.int32), np.asarray(F.L.i, np.int32), np.asarray(F.L.x)   # materialises L
+        lnz = int(Lp[n])
+        assert F.L._dev is not None                  # the factor stays on the device
+        junk = [cs.dvec(np.full(lnz, 7.0)) for _ in range(6)]     # same size as L.x
+        junk += [cs.dvec(np.full((lnz + 1) // 2, 3.0)) for _ in range(6)]   # same bytes as L.i
+        del junk
+        import gc
+        gc.collect()
+        junk2 = [cs.dvec(np.full(lnz, -1.0)) for _ in range(3)]
+        b = g["b"].copy()
+        x = b.tolist()
+        assert F.solve(x)
+        ref = CO.ltsolve(n, Lp, Li[:lnz], Lx[:lnz], CO.lsolve(n, Lp, Li[:lnz], Lx[:lnz], b))
+        assert np.asarray(x).tobytes() == ref.tobytes()
+        del junk2
+        # (2) rank-1 update with w = column 10 of L scaled: the factor changes in place on the device
+        parent = F.symbolic.parent
+        j = 10
+        w = cs.cs_spalloc(n, 1, int(Lp[j + 1] - Lp[j]), True, False)
+        w.p = [0, int(Lp[j + 1] - Lp[j])]
+        w.i = Li[Lp[j]:Lp[j + 1]].tolist()
+        w.x = (0.01 * Lx[Lp[j]:Lp[j + 1]]).tolist()
+        assert cs.cs_updown(F.L, 1, w, parent) is True
+        L2x = np.asarray(F.L.x[:lnz])
+        assert not np.array_equal(L2x, Lx[:lnz])
+        x2 = b.tolist()
+        assert F.solve(x2)
+        ref2 = CO.ltsolve(n, Lp, Li[:lnz], L2x, CO.lsolve(n, Lp, Li[:lnz], L2x, b))
+        assert np.asarray(x2).tobytes() == ref2.tobytes()

@@ -72,6 +72,55 @@ def test_gaxpy_5m_modes_agree_and_are_linear(cs, lib):
         _csx.free(h)
 
 
+def test_gaxpy_5m_uniform_draw_the_benchmarked_matrix(cs, lib):
+    """The exact workload of bench.py's `value`: csx_gen_grand_uniform(5M, 64, 20240601 + 1), x = csx_gen_vec(seed 7),
+    the tiled plan with 3-byte keys.  The timed kernel's result against the reference-order kernel (bit-identical to
+    csparse.py:1210-1212 on small sizes, tests/test_gpu_parity.py) at 1e-12, plus a sampled check of the device
+    generator against its host twin at this size (columns picked across the range, rows and values bit for bit)."""
+    import _csx
+    import synth
+    n, per_col, seed = 5000000, 64, 20240602
+    hA = _csx.new_handle()
+    _csx.check(lib.csx_gen_grand_uniform(n, per_col, seed, hA))
+    # the generator at full size: 4 windows of 1000 columns against the host twin (the twin is pure per column)
+    pA, iA, xA = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    _csx.check(lib.csx_csc_ptrs(hA, pA, iA, xA))
+    for j0 in (0, 1234567, 3999000, n - 1000):
+        hw = _csx.new_handle()
+        _csx.check(lib.csx_csc_col_block(hA, j0, 1000, hw))
+        wp, wi, wx = np.empty(1001, np.int32), np.empty(64000, np.int32), np.empty(64000)
+        _csx.check(lib.csx_csc_download(hw, _csx.pi(wp), _csx.pi(wi), _csx.pd(wx)))
+        _csx.free(hw)
+        ri, rx = synth.grand_uniform_columns(n, per_col, seed, j0, 1000)
+        assert (wp == np.arange(1001) * 64).all() and (wi == ri).all() and wx.tobytes() == rx.tobytes(), j0
+    hx = _csx.new_handle()
+    _csx.check(lib.csx_gen_vec(n, 7, 0.5, 1.5, hx))
+    _csx.check(lib.csx_gaxpy_prepare(hA, cs.GAXPY_TILED))
+    kb = C.c_int(0)
+    _csx.check(lib.csx_gaxpy_plan_info(hA, None, None, kb))
+    assert kb.value == 3                                         # the plan the benchmark line reports (plan_key_bytes)
+    yt, ye = cs.dvec(n), cs.dvec(n)
+    _csx.check(lib.csx_gaxpy(hA, hx, yt.handle, cs.GAXPY_TILED))
+    _csx.check(lib.csx_gaxpy(hA, hx, ye.handle, cs.GAXPY_EXACT))
+    a, e = yt.numpy(), ye.numpy()
+    assert np.all(np.isfinite(e)) and e.min() >= 0
+    nz = e > 0                                                   # a row can be empty under the uniform draw
+    assert (a[~nz] == 0).all()
+    assert np.max(np.abs(a[nz] - e[nz]) / e[nz]) < 1e-12
+    # the 4-byte-key plan of the same matrix agrees too (and really is another plan)
+    with _csx.option("gaxpy.keys24", 0):
+        _csx.check(lib.csx_csc_invalidate(hA))
+        _csx.check(lib.csx_gaxpy_prepare(hA, cs.GAXPY_TILED))
+        _csx.check(lib.csx_gaxpy_plan_info(hA, None, None, kb))
+        assert kb.value == 4
+        y4 = cs.dvec(n)
+        _csx.check(lib.csx_gaxpy(hA, hx, y4.handle, cs.GAXPY_TILED))
+        b = y4.numpy()
+        assert np.max(np.abs(b[nz] - e[nz]) / e[nz]) < 1e-12
+    for h in (hA, hx):
+        _csx.free(h)
+
+
 def test_cholsol_5m_block_spd_residual(cs, lib):
     import _csx
     nb, bs, k = 78125, 64, 128

@@ -86,3 +86,32 @@ def test_spsolve_bad_input(cs):
     assert cs.spsolve_columns(L, wide) is None
     with pytest.raises(IndexError):
         cs.spsolve_columns(L, A, [L.n] * L.n, True)
+
+
+def test_wrapped_arrays_with_bad_indices_are_refused(cs):
+    """Arrays the library did not make (csx_csc_wrap) are checked on the device before the reach kernels index their
+    per-lane work space with them: an out-of-range row index is CSX_EINVAL (IndexError in the reference), not a stray write."""
+    import _csx
+    lib = _csx.lib()
+    n = 8
+    Gp = np.arange(n + 1, dtype=np.int32)
+    Gi = np.arange(n, dtype=np.int32)
+    Gx = np.ones(n)
+    hG = _csx.new_handle()
+    _csx.check(lib.csx_csc_upload(n, n, _csx.pi(Gp), _csx.pi(Gi), _csx.pd(Gx), hG))
+    # B's arrays live in device vectors of ours and are wrapped; row index 8 is out of range
+    for bad, expect in ((np.asarray([0, 3, 8], np.int32), _csx.EINVAL), (np.asarray([0, 3, 7], np.int32), _csx.OK)):
+        hi = _csx.new_handle()
+        _csx.check(lib.csx_ivec_upload(_csx.pi(bad), 3, hi))
+        hp = _csx.new_handle()
+        _csx.check(lib.csx_ivec_upload(_csx.pi(np.asarray([0, 3], np.int32)), 2, hp))
+        hx = _csx.new_handle()
+        _csx.check(lib.csx_vec_upload(_csx.pd(np.ones(3)), 3, hx))
+        ptr = lambda h: (lambda p, l: (_csx.check(lib.csx_vec_ptr(h, p, l)), p.value)[1])(_csx.C.c_void_p(), _csx.C.c_int64())
+        hB = _csx.new_handle()
+        _csx.check(lib.csx_csc_wrap(n, 1, 3, ptr(hp), ptr(hi), ptr(hx), hB))
+        hX = _csx.new_handle()
+        assert lib.csx_spsolve(hG, hB, None, 1, 1, hX) == expect
+        for h in (hB, hi, hp, hx) + ((hX,) if expect == _csx.OK else ()):
+            _csx.free(h)
+    _csx.free(hG)

@@ -10,7 +10,7 @@ import csparse_oracle as O
 from conftest import golden, unpack, same_csc
 
 SMALL = ["t1", "bcsstk01", "west0067", "ash219", "fs_183_1", "ibm32a", "ibm32b", "lp_afiro"]
-ALL = SMALL + ["bcsstk16"]
+ALL = SMALL + ["bcsstk16", "mbeacxc"]
 
 
 def sha(a, dt):
@@ -60,7 +60,8 @@ def test_compress_transpose_gaxpy_multiply(name, meta):
 # known answers of csparse_test.py Test1 (:269-426): nnz(D), |D|_1 with the tests' own delta
 TEST1 = {"t1": (16, 139.58), "bcsstk01": (764, 1.73403e19), "bcsstk16": (544856, 4.13336e19),
          "west0067": (1041, 61.0906), "ash219": (2205, 32.0), "fs_183_1": (19665, 2.80249e18),
-         "ibm32a": (386, 70.0), "ibm32b": (373, 64.0), "lp_afiro": (153, 128.963)}
+         "ibm32a": (386, 70.0), "ibm32b": (373, 64.0), "lp_afiro": (153, 128.963),
+         "mbeacxc": (157350, 19.6068)}   # csparse_test.py:381-394
 
 
 @pytest.mark.parametrize("name", ALL)
