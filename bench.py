@@ -279,9 +279,7 @@ def main():
         sys.exit(2)
     if args.rehearse:
         return rehearse(args)
-    if args.force_sharded:
-        os.environ.setdefault("CSX_SHARE_TORCH_HIP", "1")   # libcsx and torch on one HIP runtime (_csx.load)
-    comm = shard.Comm()  # RCCL ("nccl") when launched by torch.distributed.run, no-op at N=1
+    comm = shard.Comm()  # RCCL inside libcsx (csx_comm_*) when there is more than one rank, no-op at N = 1
     rank, world, local = comm.rank, comm.world, comm.local
     import numpy as np
     import _csx
@@ -499,8 +497,10 @@ def main():
 
 def sharded_spmv_section(args, lib, cs, comm, barrier, max_over_ranks):
     """ONE n x n G-rand matrix sharded by columns over the ranks (second bullet): rank r owns
-    columns [r n/W, (r+1) n/W) and the matching slice of x, computes a full-length partial y with the same
-    kernels, and an RCCL reduce-scatter leaves it with its n/W rows of y.  Strong scaling; reported next to
+    columns [r n/W, (r+1) n/W) and the matching slice of x; y = sum of the ranks' partial products, rank r keeping
+    rows [r ceil(n/W), ...).  Both exchange forms of csx_gaxpy_sharded are timed: one SpMV + one RCCL reduce-scatter,
+    and row pieces leaving over direct links while the next piece is computed.  The result is checked ROW FOR ROW
+    against the unsharded cs_gaxpy of the whole matrix (exact-order kernel).  Strong scaling; reported next to
     (never instead of) the headline.  Every stage is guarded: a failure is reported as {"error": ...}."""
     import numpy as np
     import _csx
@@ -509,66 +509,83 @@ def sharded_spmv_section(args, lib, cs, comm, barrier, max_over_ranks):
     rank, world = comm.rank, comm.world
     n, per_col = args.n, args.per_col
     try:
-        import torch
-        dev = torch.device("cuda", comm.local)
-        torch.cuda.set_device(dev)
         first, count = shard.strong_block(rank, world, n)
         hFull = _csx.new_handle()
         _csx.check(lib.csx_gen_grand(n, per_col, 20240601 + 77, hFull), "gen_grand")     # same matrix on every rank
         hA = _csx.new_handle()
         _csx.check(lib.csx_csc_col_block(hFull, first, count, hA), "col_block")
-        _csx.free(hFull)
         hxFull = _csx.new_handle()
         _csx.check(lib.csx_gen_vec(n, 7, 0.5, 1.5, hxFull), "gen_vec")
+        # the unsharded answer, reference summation order, this rank's rows of it
+        r0, rc = shard.row_chunk(rank, world, n)
+        chunk = (n + world - 1) // world
+        hyRef = _csx.new_handle()
+        _csx.check(lib.csx_vec_alloc(n, hyRef), "vec_alloc")
+        _csx.check(lib.csx_gaxpy(hFull, hxFull, hyRef, cs.GAXPY_EXACT), "gaxpy exact")
+        yref = np.empty(n)
+        _csx.check(lib.csx_vec_download(hyRef, _csx.pd(yref), n), "vec_download")
+        yref = yref[r0:r0 + rc]
+        _csx.free(hyRef)
+        _csx.free(hFull)
         ptr, ln = C.c_void_p(), C.c_int64()
         _csx.check(lib.csx_vec_ptr(hxFull, ptr, ln), "vec_ptr")
         hx = _csx.new_handle()
         _csx.check(lib.csx_vec_wrap(C.c_void_p(ptr.value + 8 * first), count, hx), "vec_wrap")
-        m_pad = (n + world - 1) // world * world
-        y_full = torch.zeros(m_pad, dtype=torch.float64, device=dev)
-        torch.cuda.synchronize()
         hy = _csx.new_handle()
-        _csx.check(lib.csx_vec_wrap(C.c_void_p(y_full.data_ptr()), n, hy), "vec_wrap")
-        _csx.check(lib.csx_gaxpy_prepare(hA, cs.GAXPY_AUTO), "prepare")
-
-        def step():
-            _csx.check(lib.csx_vec_fill(hy, 0.0), "fill")
-            _csx.check(lib.csx_gaxpy(hA, hx, hy, cs.GAXPY_AUTO), "gaxpy")
-            _csx.sync()                                   # the library's stream -> visible to torch's
-            mine = comm.reduce_scatter_sum(y_full)
-            torch.cuda.synchronize()
-            return mine
-
-        mine = step()
-        # total mass: sum over ranks of sum(partial y) == sum over ranks of sum(their slice of y)
-        part = comm.sum(float(y_full.sum().item())) if world > 1 else float(y_full.sum().item())
-        whole = comm.sum(float(mine.sum().item())) if world > 1 else float(mine.sum().item())
-        ok = abs(part - whole) <= 1e-9 * abs(part)
-        for _ in range(max(1, args.warmup)):
-            step()
-        steps = min(args.steps, 20)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
-        barrier()
-        wall = max_over_ranks(time.perf_counter() - t0) / steps
-        with _csx.Timer() as tm:                          # the kernels alone (fill + SpMV), no exchange
-            for _ in range(steps):
-                _csx.check(lib.csx_vec_fill(hy, 0.0), "fill")
-                _csx.check(lib.csx_gaxpy(hA, hx, hy, cs.GAXPY_AUTO), "gaxpy")
-        kern = max_over_ranks(tm.ms / steps)
+        _csx.check(lib.csx_vec_alloc(chunk, hy), "vec_alloc")
+        sg = shard.ShardedGaxpy(comm, hA, n)
+        assert sg.rows() == (r0, rc)
         by = gaxpy_bytes(n, n, n * per_col)
-        res = {"workload": "one %d x %d G-rand matrix, columns sharded over %d GPU(s), partial y summed by RCCL "
-                           "reduce-scatter (%d MB per rank in)" % (n, n, world, m_pad * 8 // 1000000),
-               "scaling": "strong", "ms_per_spmv": round(wall * 1e3, 4), "ms_kernels_only": round(kern, 4),
-               "ms_exchange_and_sync": round(wall * 1e3 - kern, 4),
-               "whole_job_algorithmic_GBps": round(by / wall / 1e9, 2), "mass_check_ok": bool(ok)}
-        for h in (hA, hx, hy, hxFull):
+        res = {"workload": "one %d x %d G-rand matrix, columns sharded over %d GPU(s), partial y summed over %s "
+                           "(%d MB of partial sums per rank)" % (n, n, world, comm.backend, chunk * world * 8 // 1000000),
+               "scaling": "strong", "rows_owned_per_rank": chunk, "forms": {}}
+        steps = min(args.steps, 20)
+        for how, name in ((0, "spmv_then_reduce_scatter"), (1, "row_pieces_overlapped_p2p")):
+            _csx.check(lib.csx_vec_fill(hy, 0.0), "fill")
+            sg.run(hx, hy, how)
+            got = np.empty(chunk)
+            _csx.check(lib.csx_vec_download(hy, _csx.pd(got), chunk), "vec_download")
+            got = got[:rc]
+            nz = yref > 0
+            err = float(np.max(np.abs(got[nz] - yref[nz]) / yref[nz])) if nz.any() else 0.0
+            ok = bool(err < 1e-12 and np.all(got[~nz] == 0))
+            ok = bool(comm.sum(1.0 if ok else 0.0) == world)
+            err = comm.max(err)
+            for _ in range(max(1, args.warmup)):
+                sg.run(hx, hy, how)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                sg.run(hx, hy, how)
+            barrier()
+            wall = max_over_ranks(time.perf_counter() - t0) / steps
+            res["forms"][name] = {"ms_per_spmv": round(wall * 1e3, 4),
+                                  "whole_job_algorithmic_GBps": round(by / wall / 1e9, 2),
+                                  "rows_equal_unsharded_exact_order": ok, "max_rel_err": err}
+        with _csx.Timer() as tm:                          # the block's kernel alone, no exchange
+            for _ in range(steps):
+                _csx.check(lib.csx_gaxpy(hA, hx, hy_scratch(lib, _csx, n), cs.GAXPY_AUTO), "gaxpy")
+        res["ms_kernel_of_the_block_alone"] = round(max_over_ranks(tm.ms / steps), 4)
+        res["rows_equal_unsharded"] = all(f["rows_equal_unsharded_exact_order"] for f in res["forms"].values())
+        sg.free()
+        for h in (hA, hx, hy, hxFull) + tuple(_SCRATCH.values()):
             _csx.free(h)
+        _SCRATCH.clear()
         return res
     except Exception as e:                                # never take the headline down with it
         return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
+_SCRATCH = {}
+
+
+def hy_scratch(lib, _csx, n):
+    """One full-length scratch y (kept for the section)."""
+    if n not in _SCRATCH:
+        h = _csx.new_handle()
+        _csx.check(lib.csx_vec_alloc(n, h), "vec_alloc")
+        _SCRATCH[n] = h
+    return _SCRATCH[n]
 
 
 def cholsol_section(args, lib, cs, comm, hB, nb, bs, barrier, max_over_ranks):
@@ -664,59 +681,48 @@ def cholsol_section(args, lib, cs, comm, hB, nb, bs, barrier, max_over_ranks):
 
 def exchange_section(args, lib, comm, hL, plan, n, lnz, t_factor_redundant, barrier, max_over_ranks):
     """The exchange steps of a batched cs_cholsol sharded by right-hand-side block, each timed on
-    its own, none of them inside `value`:
-      1. factor once on rank 0 and broadcast L.p / L.i / L.x (three RCCL broadcasts), against every rank
+    its own, none of them inside `value`, all through libcsx's own RCCL calls (csx_comm_*):
+      1. factor once on rank 0 and ship L (csx_comm_bcast_csc: sizes, then p / i / x), against every rank
          factoring redundantly (what the timed solve leg does);
       2. the right-hand-side blocks leaving the root (rank r gets columns [r k, (r+1) k));
       3. the solution blocks gathered to the root.
     Every leg is checked: a rank rebuilds its solve plan from the RECEIVED factor and must reproduce its own
     solution bit for bit; received RHS blocks must equal the ones the rank would generate itself; the root
-    checks the gathered blocks against each rank's checksum."""
-    import torch
+    checks the gathered blocks against each rank's own bytes (a digest)."""
+    import hashlib
+    import numpy as np
     import _csx
-    import shard
     C = _csx.C
     rank, world = comm.rank, comm.world
-    dev = torch.device("cuda", comm.local)
-    torch.cuda.set_device(dev)
     k = args.exchange_nrhs or args.nrhs
-    res = {"world": world, "backend": comm.dist.get_backend() if comm.dist is not None else "none (1 rank)"}
+    res = {"world": world, "backend": comm.backend}
+
+    def block_np(h):
+        a = np.empty(n * k)
+        _csx.check(lib.csx_vec_download(h, _csx.pd(a), n * k), "vec_download")
+        return a
 
     # ---- 1. factor once + broadcast ----
-    dp, di, dx = C.c_void_p(), C.c_void_p(), C.c_void_p()
-    _csx.check(lib.csx_csc_ptrs(hL, dp, di, dx), "csc_ptrs")
-    if rank == 0:
-        Lp = shard.tensor_from_ptr(dp.value, n + 1, "i32", dev)
-        Li = shard.tensor_from_ptr(di.value, lnz, "i32", dev)
-        Lx = shard.tensor_from_ptr(dx.value, lnz, "f64", dev)
-    else:
-        Lp = torch.empty(n + 1, dtype=torch.int32, device=dev)
-        Li = torch.empty(lnz, dtype=torch.int32, device=dev)
-        Lx = torch.empty(lnz, dtype=torch.float64, device=dev)
-    for t in (Lp[:1], Li[:1], Lx[:1]):                    # first collective sets up the communicator: not timed
-        comm.broadcast_tensor(t.clone())
-    _csx.sync()
-    torch.cuda.synchronize()
+    hw = comm.bcast_csc(warm_csc(lib, _csx) if rank == 0 else None, 0)     # first collective sets up the rings: not timed
+    _csx.free(hw)
     barrier()
     t0 = time.perf_counter()
-    for t in (Lp, Li, Lx):
-        comm.broadcast_tensor(t)
-    torch.cuda.synchronize()
+    hL2 = comm.bcast_csc(hL if rank == 0 else None, 0)
     barrier()
     t_bcast = max_over_ranks(time.perf_counter() - t0)
     bytes_bcast = 4 * (n + 1) + 12 * lnz
     hR = _csx.new_handle()
     _csx.check(lib.csx_gen_rhs(n, k, rank * k, hR), "gen_rhs")
     _csx.check(lib.csx_cholsol_solve(plan, hR, k), "cholsol_solve")       # this rank's own factor
-    rp, rl = C.c_void_p(), C.c_int64()
-    _csx.check(lib.csx_vec_ptr(hR, rp, rl), "vec_ptr")
-    _csx.sync()
-    X_own = shard.tensor_from_ptr(rp.value, n * k, "f64", dev)
-    same = 1.0
+    X_own = block_np(hR)
+    same, t_replan = 1.0, 0.0
     if rank != 0 or world == 1:
-        hL2, plan2, hR2 = _csx.new_handle(), _csx.new_handle(), _csx.new_handle()
-        _csx.check(lib.csx_csc_wrap(n, n, lnz, C.c_void_p(Lp.data_ptr()), C.c_void_p(Li.data_ptr()),
-                                    C.c_void_p(Lx.data_ptr()), hL2), "csc_wrap")
+        if world == 1:                                    # a world of one: "receive" a copy so the re-plan is exercised
+            hL2 = _csx.new_handle()
+            m_, n_, z_, hv_ = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int()
+            _csx.check(lib.csx_csc_info(hL, m_, n_, z_, hv_), "csc_info")
+            _csx.check(lib.csx_csc_col_block(hL, 0, n_.value, hL2), "col_block")
+        plan2, hR2 = _csx.new_handle(), _csx.new_handle()
         t1 = time.perf_counter()
         _csx.check(lib.csx_cholsol_plan(hL2, None, plan2), "cholsol_plan")
         _csx.check(lib.csx_cholsol_set_order(plan2, 0), "cholsol_set_order")   # same order as the rank's own plan
@@ -724,13 +730,9 @@ def exchange_section(args, lib, comm, hL, plan, n, lnz, t_factor_redundant, barr
         t_replan = time.perf_counter() - t1
         _csx.check(lib.csx_gen_rhs(n, k, rank * k, hR2), "gen_rhs")
         _csx.check(lib.csx_cholsol_solve(plan2, hR2, k), "cholsol_solve")  # the factor that came over the wire
-        _csx.check(lib.csx_vec_ptr(hR2, rp, rl), "vec_ptr")
-        _csx.sync()
-        same = 1.0 if torch.equal(shard.tensor_from_ptr(rp.value, n * k, "f64", dev), X_own) else 0.0
+        same = 1.0 if block_np(hR2).tobytes() == X_own.tobytes() else 0.0
         for h in (plan2, hR2, hL2):
             _csx.free(h)
-    else:
-        t_replan = 0.0
     res["factor_once_broadcast"] = {
         "bytes": bytes_bcast, "s_broadcast": round(t_bcast, 5),
         "GBps_per_receiver": round(bytes_bcast / t_bcast / 1e9, 2) if t_bcast > 0 else None,
@@ -739,54 +741,67 @@ def exchange_section(args, lib, comm, hL, plan, n, lnz, t_factor_redundant, barr
         "receivers_reproduce_own_solution_bit_for_bit": bool(comm.sum(same) == world)}
 
     # ---- 2. right-hand-side blocks leave the root ----
-    mine = torch.empty(n * k, dtype=torch.float64, device=dev)
-    blocks, hs = None, []
+    mine = _csx.new_handle()
+    _csx.check(lib.csx_vec_alloc(n * k, mine), "vec_alloc")
+    src = None
     if rank == 0:
-        blocks = []
+        src = _csx.new_handle()
+        _csx.check(lib.csx_vec_alloc(n * k * world, src), "vec_alloc")
+        sp, sl = C.c_void_p(), C.c_int64()
+        _csx.check(lib.csx_vec_ptr(src, sp, sl), "vec_ptr")
         for r in range(world):
             h = _csx.new_handle()
             _csx.check(lib.csx_gen_rhs(n, k, r * k, h), "gen_rhs")
-            _csx.check(lib.csx_vec_ptr(h, rp, rl), "vec_ptr")
-            blocks.append(shard.tensor_from_ptr(rp.value, n * k, "f64", dev))
-            hs.append(h)
-    _csx.sync()
+            slot = _csx.new_handle()
+            _csx.check(lib.csx_vec_wrap(C.c_void_p(sp.value + 8 * n * k * r), n * k, slot), "vec_wrap")
+            _csx.check(lib.csx_vec_copy(h, slot), "vec_copy")
+            _csx.free(slot)
+            _csx.free(h)
     barrier()
     t0 = time.perf_counter()
-    comm.scatter_blocks(mine, blocks)
-    torch.cuda.synchronize()
+    comm.scatter_vec_blocks(src, mine, n * k, 0)
     barrier()
     t_scatter = max_over_ranks(time.perf_counter() - t0)
     hB2 = _csx.new_handle()
     _csx.check(lib.csx_gen_rhs(n, k, rank * k, hB2), "gen_rhs")
-    _csx.check(lib.csx_vec_ptr(hB2, rp, rl), "vec_ptr")
-    _csx.sync()
-    ok = 1.0 if torch.equal(shard.tensor_from_ptr(rp.value, n * k, "f64", dev), mine) else 0.0
-    for h in hs + [hB2]:
-        _csx.free(h)
-    del blocks
+    ok = 1.0 if block_np(hB2).tobytes() == block_np(mine).tobytes() else 0.0
+    _csx.free(hB2)
+    _csx.free(mine)
     res["rhs_scatter_from_root"] = {"bytes_out_of_root": 8 * n * k * (world - 1), "s": round(t_scatter, 5),
                                     "GBps_out_of_root": round(8 * n * k * (world - 1) / t_scatter / 1e9, 2)
                                     if world > 1 else None,
                                     "blocks_equal_locally_generated": bool(comm.sum(ok) == world)}
 
-    # ---- 3. solutions gathered to the root ----
-    sums = comm.all_gather_object(float(X_own.sum().item()))
+    # ---- 3. solutions gathered to the root (into the buffer the blocks left from) ----
+    digests = comm.all_gather_object(hashlib.sha256(X_own.tobytes()).hexdigest())
     barrier()
     t0 = time.perf_counter()
-    got = comm.gather_to_root(X_own)
-    torch.cuda.synchronize()
+    comm.gather_vec_blocks(hR, src, n * k, 0)
     barrier()
     t_gather = max_over_ranks(time.perf_counter() - t0)
     okg = True
     if rank == 0:
-        okg = all(float(g.sum().item()) == sref for g, sref in zip(got, sums))
-    del got
+        for r in range(world):
+            slot = _csx.new_handle()
+            _csx.check(lib.csx_vec_wrap(C.c_void_p(sp.value + 8 * n * k * r), n * k, slot), "vec_wrap")
+            okg = okg and hashlib.sha256(block_np(slot).tobytes()).hexdigest() == digests[r]
+            _csx.free(slot)
+        _csx.free(src)
     res["solutions_gather_to_root"] = {"bytes_into_root": 8 * n * k * (world - 1), "s": round(t_gather, 5),
                                        "GBps_into_root": round(8 * n * k * (world - 1) / t_gather / 1e9, 2)
                                        if world > 1 else None,
                                        "nrhs_per_gpu": k, "checksums_match": bool(comm.broadcast_object(okg))}
     _csx.free(hR)
     return res
+
+
+def warm_csc(lib, _csx):
+    """A 1 x 1 matrix: the first broadcast of a communicator pays its set-up."""
+    import numpy as np
+    h = _csx.new_handle()
+    p, i, x = np.asarray([0, 1], np.int32), np.asarray([0], np.int32), np.asarray([1.0])
+    _csx.check(lib.csx_csc_upload(1, 1, _csx.pi(p), _csx.pi(i), _csx.pd(x), h), "csc_upload")
+    return h
 
 
 if __name__ == "__main__":

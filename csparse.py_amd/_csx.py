@@ -91,6 +91,27 @@ _PROTOS = {
     "csx_gaxpy_plan_shape": [H, C.POINTER(C.c_int), C.POINTER(C.c_double)],
     "csx_lu_host": [C.c_int32, _i32p, _i32p, _f64p, C.c_double, C.POINTER(_i32p), C.POINTER(_i32p),
                     C.POINTER(_f64p), C.POINTER(_i32p), C.POINTER(_i32p), C.POINTER(_f64p), _i32p],
+    "csx_comm_unique_id": [C.POINTER(C.c_uint8)],
+    "csx_comm_init": [C.c_int, C.c_int, C.POINTER(C.c_uint8)],
+    "csx_comm_finalize": [],
+    "csx_comm_info": [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    "csx_comm_barrier": [],
+    "csx_comm_allreduce_host": [_f64p, C.c_int, C.c_int],
+    "csx_comm_bcast_host": [_vp, C.c_int64, C.c_int],
+    "csx_comm_bcast_csc": [C.POINTER(H), C.c_int],
+    "csx_comm_bcast_vec": [H, C.c_int],
+    "csx_comm_reduce_scatter_vec": [H, H],
+    "csx_comm_allreduce_vec": [H],
+    "csx_comm_scatter_blocks": [H, H, C.c_int64, C.c_int],
+    "csx_comm_gather_blocks": [H, H, C.c_int64, C.c_int],
+    "csx_block_cols": [H, C.c_int64, C.c_int32, C.c_int32, C.c_int32, H, C.c_int],
+    "csx_gaxpy_sharded_plan": [H, C.POINTER(H)],
+    "csx_gaxpy_sharded_rows": [H, _i32p, _i32p],
+    "csx_gaxpy_sharded": [H, H, H, C.c_int],
+    "csx_gaxpy_sharded_plan_for": [H, C.c_int, C.POINTER(H)],
+    "csx_gaxpy_sharded_piece": [H, C.c_int, H],
+    "csx_gaxpy_sharded_buffers": [H, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(C.c_int64)],
+    "csx_gaxpy_sharded_sum": [H, C.c_int, C.c_int, H],
     "csx_gen_grand": [C.c_int32, C.c_int32, C.c_uint64, C.POINTER(H)],
     "csx_gen_grand_uniform": [C.c_int32, C.c_int32, C.c_uint64, C.POINTER(H)],
     "csx_gen_gspd": [C.c_int32, C.c_int32, C.c_uint64, C.POINTER(H)],

@@ -1039,10 +1039,64 @@ def cholsol_factor(A, order=0, exact=True):
             return {"fused_local": a.value >= 1, "dense_block": c.value if a.value >= 2 else 0,  # dense kernels in use
                     "matrix_cores": a.value == 3, "trees": b.value, "max_nodes": c.value}
 
-        def solve(self, b):
+        def solve(self, b, comm=None, nrhs=None):
+            """b: a list (one system) or a dvec n-by-k block, overwritten with the solutions.
+            comm (a shard.Comm of more than one rank, every rank holding this same factor -- factored redundantly or
+            shipped with comm.bcast_csc): the batch is sharded by right-hand-side block.  The root (rank 0)
+            passes the n-by-K block, the other ranks pass None and nrhs = K; rank r solves columns [r k, (r + 1) k),
+            k = ceil(K / world): blocks leave the root (csx_comm_scatter_blocks), every rank runs the sequence of
+            csparse.py:640-643 on its block with no communication, the solutions return (csx_comm_gather_blocks) and
+            the root's block is overwritten.  Every column has the bits of the unsharded solve."""
+            if comm is not None and comm.world > 1:
+                return self._solve_sharded(b, comm, nrhs)
             db, bhost = _vec_in(b, n, "b")
             _csx.check(_csx.lib().csx_cholsol_solve(self._current(), db.handle, db.k), "csx_cholsol_solve")
             _write_back(bhost, db, n * db.k)
+            return True
+
+        def _solve_sharded(self, b, comm, nrhs):
+            lib = _csx.lib()
+            root = comm.rank == 0
+            K = comm.broadcast_object((b.k if isinstance(b, dvec) else 1) if root else None, 0)
+            if nrhs is not None and nrhs != K:
+                raise ValueError("solve: nrhs does not match the root's block")
+            db = bhost = None
+            if root:
+                db, bhost = _vec_in(b, n, "b")
+            k = (K + comm.world - 1) // comm.world
+            mine = dvec(n, k)
+            packed = dvec(n * k * comm.world) if root else None       # world blocks of n x k, rank order; pad columns = 0
+            if root:
+                for r in range(comm.world):
+                    c0 = r * k
+                    kk = max(0, min(k, K - c0))
+                    if kk <= 0:
+                        continue
+                    # columns [c0, c0 + kk) of B -> block r of `packed` (its first kk columns when the last block is short)
+                    tmp = dvec(n, kk)
+                    _csx.check(lib.csx_block_cols(db.handle, n, K, c0, kk, tmp.handle, 0), "csx_block_cols")
+                    slot = _csx.new_handle()
+                    _csx.check(lib.csx_vec_wrap(_csx.C.c_void_p(packed.device_ptr() + 8 * n * k * r), n * k, slot),
+                               "csx_vec_wrap")
+                    _csx.check(lib.csx_block_cols(slot, n, k, 0, kk, tmp.handle, 1), "csx_block_cols")
+                    _csx.free(slot)
+            comm.scatter_vec_blocks(packed.handle if root else None, mine.handle, n * k, 0)
+            _csx.check(lib.csx_cholsol_solve(self._current(), mine.handle, k), "csx_cholsol_solve")
+            comm.gather_vec_blocks(mine.handle, packed.handle if root else None, n * k, 0)
+            if root:
+                for r in range(comm.world):
+                    c0 = r * k
+                    kk = max(0, min(k, K - c0))
+                    if kk <= 0:
+                        continue
+                    ptr = packed.device_ptr() + 8 * n * k * r
+                    slot = _csx.new_handle()
+                    _csx.check(lib.csx_vec_wrap(_csx.C.c_void_p(ptr), n * k, slot), "csx_vec_wrap")
+                    tmp = dvec(n, kk)
+                    _csx.check(lib.csx_block_cols(slot, n, k, 0, kk, tmp.handle, 0), "csx_block_cols")
+                    _csx.check(lib.csx_block_cols(db.handle, n, K, c0, kk, tmp.handle, 1), "csx_block_cols")
+                    _csx.free(slot)
+                _write_back(bhost, db, n * K)
             return True
 
     return _Solver()

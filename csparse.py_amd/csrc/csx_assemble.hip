@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void k_shift_ptr(int32_t count, const int32_t 
     if (j <= count) p[j] = Ap[first + j] - Ap[first];
 }
 
-static int col_block_device(const Csc *A, int32_t first, int32_t count, Csc *C) {
+int col_block_device(const Csc *A, int32_t first, int32_t count, Csc *C) {
     hipStream_t s = ctx().stream;
     int32_t ends[2] = {0, 0};
     CSX_HIP(hipMemcpyAsync(&ends[0], A->p + first, sizeof(int32_t), hipMemcpyDeviceToHost, s));

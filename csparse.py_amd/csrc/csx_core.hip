@@ -267,6 +267,7 @@ static void free_object(Object &o) {
         case K_IVEC: free_vec((Vec *)o.ptr); break;
         case K_TRIPLAN: free_triplan((TriPlan *)o.ptr); break;
         case K_CHOLPLAN: free_cholplan((CholPlan *)o.ptr); break;
+        case K_SHARDPLAN: free_shardplan((ShardPlan *)o.ptr); break;
         default: break;
     }
     o.kind = K_FREE;   // the generation stays: the next put() of this slot bumps it

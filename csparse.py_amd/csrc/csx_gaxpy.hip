@@ -311,10 +311,8 @@ static int run_rows(const Gather *g, int64_t nnz, const double *x, double *y) {
 
 using namespace csx;
 
-extern "C" int csx_gaxpy_prepare(csx_handle_t hA, int mode) {
-    CSX_TRY(require_ready());
-    Csc *A = csc(hA);
-    if (!A || !A->x) return CSX_EINVAL;
+int csx::gaxpy_prepare_device(Csc *A, int mode) {
+    if (!A->x) return CSX_EINVAL;
     switch (mode) {
         case CSX_GAXPY_ATOMIC: return CSX_OK;
         case CSX_GAXPY_TILED: return gaxpy_tiled_prepare(A);
@@ -328,6 +326,13 @@ extern "C" int csx_gaxpy_prepare(csx_handle_t hA, int mode) {
         case CSX_GAXPY_WAVE: return build_row_gather(A);
         default: return CSX_EINVAL;
     }
+}
+
+extern "C" int csx_gaxpy_prepare(csx_handle_t hA, int mode) {
+    CSX_TRY(require_ready());
+    Csc *A = csc(hA);
+    if (!A) return CSX_EINVAL;
+    return gaxpy_prepare_device(A, mode);
 }
 
 extern "C" int csx_gaxpy_plan_info(csx_handle_t hA, int *has_rows, int *has_tiled, int *key_bytes) {
@@ -352,17 +357,13 @@ extern "C" int csx_gaxpy_plan_shape(csx_handle_t hA, int *shape, double *ms4) {
     return CSX_OK;
 }
 
-extern "C" int csx_gaxpy(csx_handle_t hA, csx_handle_t hx, csx_handle_t hy, int mode) {
-    CSX_TRY(require_ready());
-    Csc *A = csc(hA);
-    Vec *x = vec(hx), *y = vec(hy);
-    if (!A || !x || !y || !A->x || x->len < A->n || y->len < A->m) return CSX_EINVAL;
+// y += A x on raw device pointers (x: A->n entries, y: A->m): what csx_gaxpy and the sharded SpMV (csx_comm.hip) call.
+int csx::gaxpy_device(Csc *A, const double *xd, double *yd, int mode) {
+    if (!A->x) return CSX_EINVAL;
     if (A->nnz == 0 || A->m == 0) return CSX_OK;
     hipStream_t s = ctx().stream;
-    const double *xd = (const double *)x->d;
-    double *yd = (double *)y->d;
     if (mode == CSX_GAXPY_AUTO) {
-        if (!A->tiled && !A->rows) CSX_TRY(csx_gaxpy_prepare(hA, CSX_GAXPY_AUTO));  // first call: probe + plan
+        if (!A->tiled && !A->rows) CSX_TRY(gaxpy_prepare_device(A, CSX_GAXPY_AUTO));   // first call: probe + plan
         mode = A->tiled ? CSX_GAXPY_TILED : CSX_GAXPY_WAVE;
     }
     switch (mode) {
@@ -390,6 +391,14 @@ extern "C" int csx_gaxpy(csx_handle_t hA, csx_handle_t hx, csx_handle_t hy, int 
         }
         default: return CSX_EINVAL;
     }
+}
+
+extern "C" int csx_gaxpy(csx_handle_t hA, csx_handle_t hx, csx_handle_t hy, int mode) {
+    CSX_TRY(require_ready());
+    Csc *A = csc(hA);
+    Vec *x = vec(hx), *y = vec(hy);
+    if (!A || !x || !y || !A->x || x->len < A->n || y->len < A->m) return CSX_EINVAL;
+    return gaxpy_device(A, (const double *)x->d, (double *)y->d, mode);
 }
 
 // One-shot form for host arrays (the list-based reference signature, csparse.py:1199): y[0..m) += A x.

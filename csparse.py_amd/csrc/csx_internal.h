@@ -43,7 +43,7 @@ void set_error(const char *fmt, ...);
 
 #define CSX_LAUNCH_CHECK() CSX_HIP(hipGetLastError())
 
-enum Kind : int { K_FREE = 0, K_CSC, K_VEC, K_IVEC, K_TRIPLAN, K_CHOLPLAN };
+enum Kind : int { K_FREE = 0, K_CSC, K_VEC, K_IVEC, K_TRIPLAN, K_CHOLPLAN, K_SHARDPLAN };
 
 struct Csc;
 
@@ -107,6 +107,7 @@ struct Vec {
 
 struct TriPlan;   // csx_trisolve.hip
 struct CholPlan;  // csx_chol.hip
+struct ShardPlan; // csx_comm.hip
 
 struct Object {
     Kind kind = K_FREE;
@@ -172,6 +173,7 @@ void free_tiled(TiledPlan *t);
 void free_csc(Csc *A);
 void free_triplan(TriPlan *t);
 void free_cholplan(CholPlan *t);
+void free_shardplan(ShardPlan *t);
 
 // Device temporaries of a host function with several exits: freed when the guard leaves scope.
 struct DevScope {
@@ -219,6 +221,9 @@ int build_row_gather(Csc *A);   // fills A->rows (values required)
 // every row index in [0, m), in one device pass.  CSX_EINVAL (IndexError in Python) otherwise; remembered in A->trusted.
 int csc_validate(Csc *A);
 int transpose_device(const Csc *A, bool values, Csc *C);  // C fields allocated here
+int gaxpy_device(Csc *A, const double *x, double *y, int mode);                 // csx_gaxpy.hip: y += A x, raw pointers
+int gaxpy_prepare_device(Csc *A, int mode);                                     // ... the plan `mode` needs, cached on A
+int col_block_device(const Csc *A, int32_t first, int32_t count, Csc *C);      // csx_assemble.hip: columns [first, first + count)
 
 // Workgroup barrier that orders LDS only.  __syncthreads() carries a fence over global memory as well: it waits for
 // every global load the wave has in flight (s_waitcnt vmcnt(0)), which puts the latency of software-pipelined loads

@@ -289,6 +289,61 @@ int csx_lu_blocks(csx_handle_t A, double tol, csx_handle_t *L, csx_handle_t *U, 
  * One lane per column of B runs the reference's own loops; work space n * 17 bytes per column in flight. */
 int csx_spsolve(csx_handle_t G, csx_handle_t B, const int32_t *pinv /* or NULL */, int lo, int values, csx_handle_t *X);
 
+/* ---- multi-GPU exchange: RCCL over xGMI inside the library, one process per GPU ----------------
+ * The reference is one Python process (no collective call site); what shards are its sequences
+ * csparse.py:640-643 (cs_ipvec, cs_lsolve, cs_ltsolve, cs_pvec: right-hand-side blocks are independent) and
+ * csparse.py:1210-1212 (cs_gaxpy: column blocks give partial y vectors that are summed).
+ * Set-up: rank 0 calls csx_comm_unique_id, the launcher's side channel (csparse.py_amd/shard.py: a TCP hand-shake on
+ * MASTER_ADDR) carries the 128 bytes to the other ranks, every rank calls csx_comm_init(rank, world, id) after csx_init.
+ * RCCL (librccl.so.1) is bound by csx_comm_init, not when libcsx is loaded.  world == 1 with id == NULL makes no RCCL
+ * call at all (every exchange is a device copy); world == 1 with an id is a real RCCL communicator of one rank.
+ * Every exchange works on device buffers behind handles and is enqueued on the context's stream, in order with the
+ * kernels around it: no synchronisation between a kernel and the collective that ships its result.  Host results
+ * (csx_comm_allreduce_host, csx_comm_bcast_host, csx_comm_barrier) are complete when the call returns. */
+#define CSX_COMM_ID_BYTES 128
+int csx_comm_unique_id(uint8_t *id128);
+int csx_comm_init(int rank, int world, const uint8_t *id128 /* NULL: world of one, no RCCL */);
+int csx_comm_finalize(void);
+int csx_comm_info(int *rank, int *world, int *uses_rccl);
+int csx_comm_barrier(void);                                        /* stream drained + every rank arrived */
+int csx_comm_allreduce_host(double *vals, int count, int op);      /* op 0 = sum, 1 = max; count <= 1024 (timings, checks) */
+int csx_comm_bcast_host(void *buf, int64_t bytes, int root);       /* small control data */
+/* Factor once on `root`, ship the factor: *A (the root's matrix) arrives as a NEW matrix handle on every other rank
+ * (sizes, then p, i, x: three ncclBroadcast).  The root's handle is unchanged. */
+int csx_comm_bcast_csc(csx_handle_t *A, int root);
+int csx_comm_bcast_vec(csx_handle_t v, int root);                  /* in place, same length on every rank */
+/* `full` has world * len(out) entries; out = entries [rank len, (rank + 1) len) of the sum over ranks (ncclReduceScatter) */
+int csx_comm_reduce_scatter_vec(csx_handle_t full, csx_handle_t out);
+int csx_comm_allreduce_vec(csx_handle_t v);                        /* in place sum */
+/* Right-hand-side blocks leave the root / solution blocks return to it: `src` / `out` (root only) hold world blocks of
+ * len doubles in rank order; world - 1 point-to-point transfers in one RCCL group, the root's own block a device copy. */
+int csx_comm_scatter_blocks(csx_handle_t src, csx_handle_t dst, int64_t len, int root);
+int csx_comm_gather_blocks(csx_handle_t block, csx_handle_t out, int64_t len, int root);
+/* Columns [c0, c0 + k) of the n x K row-major block B as a contiguous n x k block `out` (back == 0), or `out` written
+ * back into those columns of B (back != 0): a rank's share of a batch of right-hand sides. */
+int csx_block_cols(csx_handle_t B, int64_t n, int32_t K, int32_t c0, int32_t k, csx_handle_t out, int back);
+/* ONE cs_gaxpy sharded by columns: rank r holds A_r = columns [first_r, first_r + count_r) of an m x n matrix
+ * (csx_csc_col_block) and the matching slice x_r of x; y = sum_r A_r x_r, and rank r ends up with rows
+ * [r chunk, min((r + 1) chunk, m)), chunk = ceil(m / world) (csx_gaxpy_sharded_rows).
+ * csx_gaxpy_sharded(plan, x_r, y_mine, how): y_mine (chunk entries) += this rank's rows of the sum.
+ *   how 0: one SpMV into a full-length partial y, then one ncclReduceScatter;
+ *   how 1: the block is cut by rows into the world pieces y is owned in; rank r computes the piece of rank r + 1
+ *          first and its own last, and a finished piece leaves for its owner over the direct link (ncclSend /
+ *          ncclRecv on a second stream) while the next piece is computed; the owner adds the world partial pieces
+ *          in ascending rank order, so the result has the same bits on every run.
+ * The plan keeps a pointer to the block: free the plan first. */
+int csx_gaxpy_sharded_plan(csx_handle_t block, csx_handle_t *plan);
+int csx_gaxpy_sharded_rows(csx_handle_t plan, int32_t *first, int32_t *count);
+int csx_gaxpy_sharded(csx_handle_t plan, csx_handle_t x, csx_handle_t y_mine, int how);
+/* The steps of how == 1 one at a time, for a transport that is not RCCL (shard.py's host stand-in, which carries the
+ * N > 1 tests on a one-GPU box): a plan cut for `world` ranks; piece q's partial sums into the plan's work buffer
+ * (piece q at work + q * chunk); the buffers (recv: world - 1 arrival slots of chunk doubles, senders in ascending
+ * rank order); the owner's sum of the world pieces in ascending rank order into y_mine. */
+int csx_gaxpy_sharded_plan_for(csx_handle_t block, int world, csx_handle_t *plan);
+int csx_gaxpy_sharded_piece(csx_handle_t plan, int q, csx_handle_t x);
+int csx_gaxpy_sharded_buffers(csx_handle_t plan, void **work, void **recv, int64_t *chunk);
+int csx_gaxpy_sharded_sum(csx_handle_t plan, int rank, int world, csx_handle_t y_mine);
+
 /* ---- synthetic inputs of the benchmark configs, generated on
  * the device from a counter-based hash so host and device agree bit for bit ---- */
 int csx_gen_grand(int32_t n, int32_t per_col, uint64_t seed, csx_handle_t *out);

@@ -8,6 +8,7 @@ import sys
 import textwrap
 
 import numpy as np
+import pytest
 
 from conftest import ROOT
 
@@ -101,6 +102,57 @@ def test_single_rank_comm_is_a_noop():
                 os.environ[k] = v
     assert shard.weak_block(3, 128) == (384, 128)
     assert [shard.strong_block(r, 8, 1024) for r in (0, 7)] == [(0, 128), (896, 128)]
+
+
+def test_rendezvous_carries_the_unique_id_and_skips_strangers():
+    """shard.Rendezvous: the 128-byte RCCL id from rank 0 to the other ranks over TCP.  A stranger already listening
+    on the first candidate port (another job, an old launch) is skipped: its answer lacks this launch's token."""
+    import socket
+    import threading
+    sys.path.insert(0, os.path.join(ROOT, "csparse.py_amd"))
+    import shard
+    with socket.socket() as probe:
+        probe.bind(("127.0.0.1", 0))
+        base = probe.getsockname()[1]
+    stranger = socket.socket()
+    stranger.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    try:
+        stranger.bind(("127.0.0.1", base + 1))           # the first candidate port is taken by someone else
+    except OSError:
+        pytest.skip("port in use")
+    stranger.listen(8)
+    stop = threading.Event()
+
+    def strange():
+        stranger.settimeout(0.2)
+        while not stop.is_set():
+            try:
+                c, _ = stranger.accept()
+                c.sendall(b"\x05\x00\x00\x00HELLO")
+                c.close()
+            except OSError:
+                pass
+
+    th = threading.Thread(target=strange, daemon=True)
+    th.start()
+    blob = bytes(range(128))
+    got = {}
+
+    def run(rank):
+        rv = shard.Rendezvous(rank, 3, addr="127.0.0.1", port=base, token="launch-42", timeout=30)
+        got[rank] = rv.share(blob if rank == 0 else None)
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in (1, 2, 0)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(40)
+    stop.set()
+    stranger.close()
+    assert got == {0: blob, 1: blob, 2: blob}
+    # a client of ANOTHER launch (different token) is refused by rank 0 and does not consume a slot
+    assert shard.Rendezvous(0, 1).share(b"x") == b"x"                     # world of one: nothing to do
+    assert shard.row_chunk(1, 2, 3001) == (1501, 1500) and shard.row_chunk(7, 8, 10) == (10, 0)
 
 
 def _run_bench(extra, env=None, timeout=300):
