@@ -943,10 +943,16 @@ struct CholPlan {
     bool relaxed = false;
     bool mfma_tried = false;  // fragments were built, or refused by the growth guard
     double mfma_growth = 0.0; // max|inv(L_ii)| max|L| over the forest (the guard's measure)
+    // big trees, rounding-equal order: supernodal schedule (csx_snsolve.hip), built the first time the plan is relaxed
+    std::vector<int32_t> parent_h;   // elimination tree of a Cholesky-shaped L (empty: not one)
+    int32_t col_levels = 0;          // its height in columns
+    bool sn_tried = false;
+    SnPlan *sn = nullptr;
 };
 
 void free_cholplan(CholPlan *P) {
     if (!P) return;
+    free_snplan(P->sn);
     free_triplan(P->fwd);
     free_triplan(P->bwd);
     dfree(P->perm);
@@ -1547,6 +1553,8 @@ static int cholsol_plan(const Csc *L, const int32_t *pinv, CholPlan **out) {
                         height[(size_t)parent[(size_t)j]] = std::max(height[(size_t)parent[(size_t)j]], height[(size_t)j] + 1);
                 for (int32_t j = n - 1; j >= 0; j--)
                     if (parent[(size_t)j] >= 0) depth[(size_t)j] = depth[(size_t)parent[(size_t)j]] + 1;
+                for (int32_t j = 0; j < n; j++) P->col_levels = std::max(P->col_levels, height[(size_t)j] + 1);
+                P->parent_h = parent;
                 tri_set_level_hint(P->fwd, std::move(height));
                 tri_set_level_hint(P->bwd, std::move(depth));
             }
@@ -1667,6 +1675,32 @@ static int cholsol_build_mfma(CholPlan *P) {
     return st;
 }
 
+// Supernodal schedule for the rounding-equal order of a big-tree plan (nullptr when the factor gains nothing from it).
+static int cholsol_build_sn(CholPlan *P) {
+    const bool say = std::getenv("CSX_CHOL_TIMING") != nullptr;
+    if (say && !P->sn_tried)
+        std::fprintf(stderr, "cholsol_build_sn: local %d tree %d col_levels %d\n", (int)P->local, (int)!P->parent_h.empty(), P->col_levels);
+    if (P->sn_tried || P->local || P->parent_h.empty() || !ctx().opt.tri_supernodes) return CSX_OK;
+    P->sn_tried = true;
+    const int32_t *Gp, *Gi;
+    const double *Gx, *Gd;
+    tri_gather_arrays(P->fwd, &Gp, &Gi, &Gx, &Gd);
+    if (!Gp || !Gd) return CSX_OK;
+    hipStream_t s = ctx().stream;
+    const int32_t n = P->n;
+    std::vector<int32_t> hLp((size_t)n + 1), hGp((size_t)n + 1);
+    CSX_HIP(hipMemcpyAsync(hLp.data(), P->L->p, ((size_t)n + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    CSX_HIP(hipMemcpyAsync(hGp.data(), Gp, ((size_t)n + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    CSX_HIP(hipStreamSynchronize(s));
+    const int st = sn_build(P->L, P->parent_h.data(), hLp.data(), hGp.data(), Gp, Gi, Gx, P->col_levels, &P->sn);
+    if (say) {
+        int32_t a = 0, b = 0, c = 0;
+        if (P->sn) sn_info(P->sn, &a, &b, &c);
+        std::fprintf(stderr, "cholsol_build_sn: status %d plan %d supernodes %d levels %d max width %d\n", st, P->sn != nullptr, a, b, c);
+    }
+    return st;
+}
+
 static int cholsol_solve(CholPlan *P, double *B, int32_t nrhs) {
     hipStream_t s = ctx().stream;
     const int32_t n = P->n;
@@ -1761,8 +1795,14 @@ static int cholsol_solve(CholPlan *P, double *B, int32_t nrhs) {
         X = P->scratch;
         hipLaunchKernelGGL(k_perm_rows, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, s, P->perm, B, X, n, nrhs, 1);
     }
-    CSX_TRY(tri_solve_raw(P->fwd, X, nrhs, P->relaxed));
-    CSX_TRY(tri_solve_raw(P->bwd, X, nrhs, P->relaxed));
+    if (P->relaxed && P->sn && ctx().opt.tri_supernodes) {
+        CSX_TRY(tri_solve_raw(P->fwd, X, 0, false));          // a zero pivot found by the analysis: ZeroDivisionError
+        CSX_TRY(sn_solve(P->sn, true, Gp, Gi, Gx, Gd, P->L, X, nrhs));
+        CSX_TRY(sn_solve(P->sn, false, Gp, Gi, Gx, Gd, P->L, X, nrhs));
+    } else {
+        CSX_TRY(tri_solve_raw(P->fwd, X, nrhs, P->relaxed));
+        CSX_TRY(tri_solve_raw(P->bwd, X, nrhs, P->relaxed));
+    }
     if (P->perm) {
         const int64_t need = (int64_t)n * nrhs;
         hipLaunchKernelGGL(k_perm_rows, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, s, P->perm, X, B, n, nrhs, 0);
@@ -1809,7 +1849,7 @@ extern "C" int csx_cholsol_info(csx_handle_t h, int32_t *local, int32_t *ntrees,
     CholPlan *P = (CholPlan *)get(h, K_CHOLPLAN);
     if (!P) return CSX_EINVAL;
     // 0 level-scheduled, 1 fused in LDS, 2 dense blocks (substitution), 3 dense blocks on the matrix cores
-    if (local) *local = P->local ? (P->dense_bs ? (P->relaxed && P->frag_f ? 3 : 2) : 1) : 0;
+    if (local) *local = P->local ? (P->dense_bs ? (P->relaxed && P->frag_f ? 3 : 2) : 1) : (P->relaxed && P->sn ? 4 : 0);
     if (ntrees) *ntrees = P->ntrees;
     if (max_nodes) *max_nodes = P->max_nodes;
     return CSX_OK;
@@ -1821,6 +1861,7 @@ extern "C" int csx_cholsol_set_order(csx_handle_t h, int exact) {
     if (!P) return CSX_EINVAL;
     P->relaxed = exact == 0;
     if (P->relaxed) CSX_TRY(cholsol_build_mfma(P));
+    if (P->relaxed) CSX_TRY(cholsol_build_sn(P));
     return CSX_OK;
 }
 

@@ -108,6 +108,7 @@ struct Vec {
 struct TriPlan;   // csx_trisolve.hip
 struct CholPlan;  // csx_chol.hip
 struct ShardPlan; // csx_comm.hip
+struct SnPlan;    // csx_snsolve.hip
 
 struct Object {
     Kind kind = K_FREE;
@@ -174,6 +175,13 @@ void free_csc(Csc *A);
 void free_triplan(TriPlan *t);
 void free_cholplan(CholPlan *t);
 void free_shardplan(ShardPlan *t);
+void free_snplan(SnPlan *t);
+// csx_snsolve.hip: supernodal schedule of a Cholesky-shaped factor for the rounding-equal order of a cholsol plan
+int sn_build(const Csc *L, const int32_t *parent, const int32_t *Lp_h, const int32_t *Gp_h, const int32_t *Gp, const int32_t *Gi,
+             const double *Gx, int32_t col_levels, SnPlan **out);
+int sn_solve(SnPlan *P, bool forward, const int32_t *Gp, const int32_t *Gi, const double *Gx, const double *Gd, const Csc *L,
+             double *X, int32_t nrhs);
+void sn_info(const SnPlan *P, int32_t *nsn, int32_t *levels, int32_t *max_w);
 
 // Device temporaries of a host function with several exits: freed when the guard leaves scope.
 struct DevScope {

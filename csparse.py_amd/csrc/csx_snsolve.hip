@@ -1,0 +1,821 @@
+// Supernodal triangular solves with a Cholesky factor: cs_lsolve / cs_ltsolve (csparse.py:1341-1344, :1360-1364) in the
+// rounding-equal order of a cholsol plan (csx_cholsol_set_order(plan, 0)), for connected factors whose elimination tree
+// is deep in columns but shallow in SUPERNODES -- nested-dissection factors: the separators are dense trapezoids of L
+// (w consecutive columns with the same rows below them), which cs_chol already factors as dense blocks (csx_cholband.hip).
+//
+// The column-level schedule gives every column of a separator a level of its own (a 700 x 700 grid in nested dissection:
+// ~2 000 levels, each a launch or a workgroup barrier, each row's thousands of terms walked one dependent subtraction at
+// a time).  Here the schedule has three kinds of unit:
+//   * LEAF SUBTREES: maximal subtrees of the elimination tree with at most 64 columns (the small regions nested
+//     dissection stops at: most of the columns, almost none of the work).  One wave per (subtree, 64 right-hand sides)
+//     walks the subtree's rows with its x in LDS, from a packed program (local index, value) built with the plan: first
+//     of all in the forward solve, last of all in the backward one (after one launch has taken every leaf column's
+//     terms of rows OUTSIDE its subtree -- ancestors, final by then).
+//   * SUPERNODES of the rest, by height (forward) / depth (backward) in the supernodal elimination tree.  Per level,
+//       A: every row (column) of the level's supernodes takes its terms from OUTSIDE its supernode -- all final: they
+//          belong to descendants (ancestors) -- one wave per (piece of a row, 64 right-hand sides); a long row is cut
+//          into pieces of SN_SEG terms whose partial sums are added in a fixed order (reproducible bits);
+//       B: one workgroup per (supernode, 64 right-hand sides) stages the w x w triangle and the w rows of X in LDS and
+//          solves it there in panels of 16 (one wave the 16 x 16 triangle with its rows in registers, then all waves
+//          update the remaining rows).
+//   * WIDE supernodes (w > 64) are cut into chunks of 64 columns that are solved one after the other (a blocked,
+//     right-looking dense triangular solve): after chunk q, every remaining row of the supernode takes its 64 terms of
+//     that chunk in one launch across the chip (the same kernel as A), then chunk q + 1 is solved.
+// Forward reads the row-major copy of L the forward plan holds (terms of a row in ascending column order, so the terms
+// inside the row's own supernode are its LAST ones); backward reads L itself (a column: diagonal, the rows inside its
+// supernode, the rows below it).  Lane = right-hand side throughout: a term is one coalesced 512-byte load of a row of
+// X and one FMA.
+//
+// Equal to the reference to rounding (the sums are regrouped), never used by the exact order; the same bits on every
+// run.  tests/test_gpu_cholesky.py compares with the plain-C oracle at 1e-10 and with the exact order.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <utility>
+#include <vector>
+
+#include "csx_internal.h"
+
+namespace csx {
+
+constexpr int SN_SEG = 256;      // terms per piece of a long row / column
+constexpr int SN_PANEL = 16;
+constexpr int SN_CHUNK = 64;     // columns per chunk of a wide supernode
+constexpr int SN_LEAF = 64;      // columns of a leaf subtree (its x tile: SN_LEAF x 64 doubles of LDS per wave)
+
+struct SnTask {
+    int32_t line;   // row (forward) or column (backward)
+    int32_t b, e;   // term range
+    int32_t out;    // -1: subtract from X[line]; else partial slot
+};
+
+struct SnStep {
+    int32_t t0, tc;   // tasks
+    int32_t s0, sc;   // narrow virtual supernodes (at most 16 columns: one wave each)
+    int32_t m0, mc;   // up to 32 columns: two waves, a quarter of the LDS of the wide ones
+    int32_t b0, bc;   // the others (four waves each)
+};
+
+struct SnDir {
+    std::vector<SnStep> steps;       // host
+    SnTask *tasks = nullptr;         // device
+    int32_t *narrow = nullptr;       // device: virtual supernode ids by step
+    int32_t *medium = nullptr;       // device
+    int32_t *wide = nullptr;         // device
+    int32_t *part_ptr = nullptr;     // device [n + 1]: partial slots of a row / column
+    int32_t nslots = 0;
+};
+
+struct SnPlan {
+    int32_t n = 0, nsn = 0, max_w = 0, nleaf = 0, nleafcols = 0;
+    int32_t *vs_a = nullptr, *vs_w = nullptr;   // device: first column and width of every virtual supernode (chunk)
+    // leaf subtrees: columns by subtree (ascending inside), packed forward / backward programs by position in leaf_cols
+    int32_t *leaf_ptr = nullptr, *leaf_cols = nullptr;
+    int32_t *lf_ptr = nullptr, *lf_idx = nullptr, *lb_ptr = nullptr, *lb_idx = nullptr;
+    double *lf_val = nullptr, *lb_val = nullptr, *ldiag = nullptr;
+    SnTask *leaf_tasks = nullptr;               // backward: the leaf columns' rows outside their subtrees, in pieces
+    int32_t nleaftasks = 0, nleafslots = 0;
+    int32_t *lslot_ptr = nullptr;               // [nleafcols + 1] partial slots of a leaf column (after the backward plan's slots)
+    SnDir fwd, bwd;
+    double *partial = nullptr;
+    int64_t partial_len = 0;
+};
+
+void free_snplan(SnPlan *P) {
+    if (!P) return;
+    for (void *p : {(void *)P->vs_a, (void *)P->vs_w, (void *)P->leaf_ptr, (void *)P->leaf_cols, (void *)P->lf_ptr, (void *)P->lf_idx,
+                    (void *)P->lb_ptr, (void *)P->lb_idx, (void *)P->lf_val, (void *)P->lb_val, (void *)P->ldiag, (void *)P->leaf_tasks,
+                    (void *)P->lslot_ptr, (void *)P->partial})
+        dfree(p);
+    for (SnDir *d : {&P->fwd, &P->bwd}) {
+        dfree(d->tasks);
+        dfree(d->narrow);
+        dfree(d->medium);
+        dfree(d->wide);
+        dfree(d->part_ptr);
+    }
+    delete P;
+}
+
+namespace {
+
+template <class T>
+int up(T **d, const std::vector<T> &h) {
+    CSX_TRY(dalloc(d, std::max<size_t>(h.size(), 1)));
+    if (!h.empty())
+        CSX_HIP(hipMemcpyAsync(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, ctx().stream));
+    return CSX_OK;
+}
+
+// sum over q in [b, e) of val[q] * X[idx[q], r]: lane = right-hand side, a term's index and value handed round by
+// v_readlane, sixteen row loads of X in flight ahead of the multiply-adds
+__device__ __forceinline__ double sn_dot(int32_t b, int32_t e, const int32_t *__restrict__ idx, const double *__restrict__ val,
+                                         const double *X, int nrhs, int rr, int lane) {
+    double acc0 = 0.0, acc1 = 0.0;
+    int32_t ci = b + lane < e ? idx[b + lane] : 0;
+    double cv = b + lane < e ? val[b + lane] : 0.0;
+    for (int32_t q0 = b; q0 < e; q0 += 64) {
+        const int32_t qn = q0 + 64 + lane;
+        const int32_t cin = qn < e ? idx[qn] : 0;
+        const double cvn = qn < e ? val[qn] : 0.0;
+        const int cnt = e - q0 < 64 ? e - q0 : 64;   // uniform
+        const int clo = __double2loint(cv), chi = __double2hiint(cv);
+        double xa[16], xb[16];
+        auto gather = [&](int g, double *xv) {
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                const int32_t c = __builtin_amdgcn_readlane(ci, g + u);   // lanes past cnt hold row 0: a valid address
+                xv[u] = X[(int64_t)c * nrhs + rr];
+            }
+        };
+        auto fma16 = [&](int g, const double *xv) {
+#pragma unroll
+            for (int u = 0; u < 16; u += 2) {                             // lanes past cnt hold value 0.0
+                const double v0 = __hiloint2double(__builtin_amdgcn_readlane(chi, g + u), __builtin_amdgcn_readlane(clo, g + u));
+                const double v1 = __hiloint2double(__builtin_amdgcn_readlane(chi, g + u + 1), __builtin_amdgcn_readlane(clo, g + u + 1));
+                acc0 = fma(v0, xv[u], acc0);
+                acc1 = fma(v1, xv[u + 1], acc1);
+            }
+        };
+        gather(0, xa);
+        if (cnt > 16) gather(16, xb);
+        fma16(0, xa);
+        if (cnt > 16) {
+            if (cnt > 32) gather(32, xa);
+            fma16(16, xb);
+            if (cnt > 32) {
+                if (cnt > 48) gather(48, xb);
+                fma16(32, xa);
+                if (cnt > 48) fma16(48, xb);
+            }
+        }
+        ci = cin;
+        cv = cvn;
+    }
+    return acc0 + acc1;
+}
+
+// A: one wave per (task, 64 right-hand sides)
+__global__ __launch_bounds__(256) void k_sn_outside(const SnTask *__restrict__ tasks, int32_t first, int32_t count,
+                                                    const int32_t *__restrict__ idx, const double *__restrict__ val, double *X,
+                                                    double *partial, int nrhs) {
+    const int lane = threadIdx.x & 63;
+    const int nblk = (nrhs + 63) >> 6;
+    const int64_t wv = __builtin_amdgcn_readfirstlane((int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    if (wv >= (int64_t)count * nblk) return;
+    const SnTask t = tasks[first + wv / nblk];
+    if (t.e <= t.b) return;
+    const int r = (int)(wv % nblk) * 64 + lane;
+    const bool live = r < nrhs;
+    const int rr = live ? r : nrhs - 1;
+    const double d = sn_dot(t.b, t.e, idx, val, X, nrhs, rr, lane);
+    if (!live) return;
+    if (t.out < 0) X[(int64_t)t.line * nrhs + r] -= d;
+    else partial[(int64_t)t.out * nrhs + r] = d;
+}
+
+// B: (virtual) supernode columns [a, a + w), w <= W, for 64 right-hand sides: the triangle (Ls[i][t] = L(a + i, a + t), i > t)
+// and the w rows of X (less the partial sums of their outside terms) staged in LDS; solved there in panels of 16 rows,
+// the panel's triangle by one wave with its rows in registers, the update of the remaining rows by all waves.
+// FWD: rows from the forward plan's row-major copy (row a + v: its terms of columns a .. a + v - 1 are the last v of its
+// gather range), panels ascending.  !FWD: columns of L (column a + v: diagonal, then rows a + v + 1 ..), panels descending.
+template <int NW, int W, bool FWD>
+__global__ __launch_bounds__(64 * NW) void k_sn_tri(const int32_t *__restrict__ list, int32_t first,
+                                                    const int32_t *__restrict__ vs_a, const int32_t *__restrict__ vs_w,
+                                                    const int32_t *__restrict__ Tp, const double *__restrict__ Tx,
+                                                    const double *__restrict__ Td, const int32_t *__restrict__ part_ptr,
+                                                    const double *__restrict__ partial, double *X, int nrhs) {
+    extern __shared__ __attribute__((aligned(16))) double sn_smem[];     // sn_tri_lds<W>() bytes
+    double(*Ls)[W + 1] = reinterpret_cast<double(*)[W + 1]>(sn_smem);
+    double(*xt)[64] = reinterpret_cast<double(*)[64]>(sn_smem + W * (W + 1));
+    double *dg = sn_smem + W * (W + 1) + W * 64;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nblk = (nrhs + 63) >> 6;
+    const int32_t S = list[first + blockIdx.x / nblk];
+    const int r = (int)(blockIdx.x % nblk) * 64 + lane;
+    const bool live = r < nrhs;
+    const int rr = live ? r : nrhs - 1;
+    const int32_t a = vs_a[S], w = vs_w[S];
+    // Staging: lane v holds the pointers of line a + v, so that every load below has its address at once (v_readlane)
+    // and a wave's W / NW lines are all in flight together instead of one dependent chain per line.
+    const int32_t mp = lane < w ? Tp[a + lane + (FWD ? 1 : 0)] : 0;
+    const int32_t ps = lane < w ? part_ptr[a + lane] : 0, pe = lane < w ? part_ptr[a + lane + 1] : 0;
+    if (wave == 0 && lane < w) dg[lane] = 1.0 / (FWD ? Td[a + lane] : Tx[mp]);   // one division per line, off the chain below
+    constexpr int PER = W / NW;
+    double xv[PER], lv[PER];
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const int v = wave + NW * i;
+        xv[i] = 0.0;
+        lv[i] = 0.0;
+        if (v < w) {
+            const int32_t m = __builtin_amdgcn_readlane(mp, v);
+            xv[i] = X[(int64_t)(a + v) * nrhs + rr];
+            if (FWD) {
+                if (lane < v) lv[i] = Tx[m - v + lane];              // row a + v: its last v terms are columns a .. a + v - 1
+            } else {
+                if (lane > v && lane < w) lv[i] = Tx[m + lane - v];  // column a + v: row a + lane at m + lane - v
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const int v = wave + NW * i;
+        if (v < w) {
+            const int32_t s0 = __builtin_amdgcn_readlane(ps, v), s1 = __builtin_amdgcn_readlane(pe, v);
+            double acc = xv[i];
+            for (int32_t s = s0; s < s1; s++) acc -= partial[(int64_t)s * nrhs + rr];
+            xt[v][lane] = acc;
+            if (FWD) {
+                if (lane < v) Ls[v][lane] = lv[i];
+            } else {
+                if (lane > v && lane < w) Ls[lane][v] = lv[i];
+            }
+        }
+    }
+    __syncthreads();
+    const int npan = (w + SN_PANEL - 1) / SN_PANEL;
+    for (int pp = 0; pp < npan; pp++) {
+        const int p = FWD ? pp : npan - 1 - pp;
+        const int p0 = p * SN_PANEL;
+        const int np = w - p0 < SN_PANEL ? w - p0 : SN_PANEL;
+        if (wave == p % NW) {
+            double acc[SN_PANEL];
+#pragma unroll
+            for (int t = 0; t < SN_PANEL; t++) acc[t] = t < np ? xt[p0 + t][lane] : 0.0;
+            if (FWD) {
+#pragma unroll
+                for (int t = 0; t < SN_PANEL; t++)
+                    if (t < np) {
+                        const double y = acc[t] * dg[p0 + t];
+                        acc[t] = y;
+#pragma unroll
+                        for (int s = t + 1; s < SN_PANEL; s++)
+                            if (s < np) acc[s] = fma(-Ls[p0 + s][p0 + t], y, acc[s]);
+                    }
+            } else {
+#pragma unroll
+                for (int t = SN_PANEL - 1; t >= 0; t--)
+                    if (t < np) {
+                        const double y = acc[t] * dg[p0 + t];
+                        acc[t] = y;
+#pragma unroll
+                        for (int s = 0; s < t; s++) acc[s] = fma(-Ls[p0 + t][p0 + s], y, acc[s]);
+                    }
+            }
+#pragma unroll
+            for (int t = 0; t < SN_PANEL; t++)
+                if (t < np) {
+                    xt[p0 + t][lane] = acc[t];
+                    if (live) X[(int64_t)(a + p0 + t) * nrhs + r] = acc[t];
+                }
+        }
+        if (pp + 1 == npan) break;
+        __syncthreads();
+        // the rows still to be solved take their terms of this panel
+        const int lo = FWD ? p0 + np : 0, hi = FWD ? w : p0;
+        for (int v = lo + wave; v < hi; v += NW) {
+            double acc0 = xt[v][lane], acc1 = 0.0;
+#pragma unroll
+            for (int t = 0; t < SN_PANEL; t += 2) {
+                if (t < np) acc0 = fma(-(FWD ? Ls[v][p0 + t] : Ls[p0 + t][v]), xt[p0 + t][lane], acc0);
+                if (t + 1 < np) acc1 = fma(-(FWD ? Ls[v][p0 + t + 1] : Ls[p0 + t + 1][v]), xt[p0 + t + 1][lane], acc1);
+            }
+            xt[v][lane] = acc0 + acc1;
+        }
+        __syncthreads();
+    }
+}
+
+template <int W>
+constexpr size_t sn_tri_lds() {
+    return (size_t)(W * (W + 1) + W * 64 + W) * sizeof(double);
+}
+
+// Leaf subtrees: one wave per (subtree, 64 right-hand sides), the subtree's x in LDS (position in the subtree * 64 + lane),
+// the terms from a packed program: line k of the subtree (a row forward, a column backward) has its in-subtree terms at
+// [ptr[c0 + k], ptr[c0 + k + 1]) as (position of the source in the subtree, value); at most 63 of them, so one load per
+// lane fetches a line, and the next line's load is in flight while this one is summed.  FWD: lines ascending.
+template <bool FWD>
+__global__ __launch_bounds__(64) void k_sn_leaf(const int32_t *__restrict__ leaf_ptr, const int32_t *__restrict__ leaf_cols,
+                                                const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx,
+                                                const double *__restrict__ val, const double *__restrict__ ldiag,
+                                                const int32_t *__restrict__ slot_ptr, const double *__restrict__ partial, double *X,
+                                                int nrhs) {
+    __shared__ double xs[SN_LEAF * 64];
+    const int lane = threadIdx.x;
+    const int nblk = (nrhs + 63) >> 6;
+    const int32_t t = blockIdx.x / nblk;
+    const int r = (int)(blockIdx.x % nblk) * 64 + lane;
+    const bool live = r < nrhs;
+    const int rr = live ? r : nrhs - 1;
+    const int32_t c0 = leaf_ptr[t], cnt = leaf_ptr[t + 1] - c0;
+    const int32_t myptr = lane < cnt ? ptr[c0 + lane] : 0;
+    const int32_t mylen = lane < cnt ? ptr[c0 + lane + 1] - myptr : 0;
+    const int32_t myline = lane < cnt ? leaf_cols[c0 + lane] : 0;
+    const double mydg = lane < cnt ? ldiag[c0 + lane] : 1.0;
+    const int dlo = __double2loint(mydg), dhi = __double2hiint(mydg);
+    // backward: partial sums of a long column's rows outside the subtree (k_sn_outside wrote them), slots [s0, s1)
+    const int32_t mys0 = slot_ptr && lane < cnt ? slot_ptr[c0 + lane] : 0, mys1 = slot_ptr && lane < cnt ? slot_ptr[c0 + lane + 1] : 0;
+    struct Line {
+        int32_t li;
+        double cv, xb;
+    };
+    auto load = [&](int k) {
+        const int32_t p = __builtin_amdgcn_readlane(myptr, k), l = __builtin_amdgcn_readlane(mylen, k);
+        const int32_t line = __builtin_amdgcn_readlane(myline, k);
+        Line L;
+        L.li = lane < l ? idx[p + lane] : 0;
+        L.cv = lane < l ? val[p + lane] : 0.0;
+        L.xb = X[(int64_t)line * nrhs + rr];
+        const int32_t s0 = __builtin_amdgcn_readlane(mys0, k), s1 = __builtin_amdgcn_readlane(mys1, k);
+        for (int32_t sl = s0; sl < s1; sl++) L.xb -= partial[(int64_t)sl * nrhs + rr];
+        return L;
+    };
+    auto compute = [&](const Line &L, int k) {
+        const int32_t l = __builtin_amdgcn_readlane(mylen, k), line = __builtin_amdgcn_readlane(myline, k);
+        const int clo = __double2loint(L.cv), chi = __double2hiint(L.cv);
+        double acc0 = L.xb, acc1 = 0.0;
+        int u = 0;
+        for (; u + 1 < l; u += 2) {
+            const int32_t ca = __builtin_amdgcn_readlane(L.li, u), cb = __builtin_amdgcn_readlane(L.li, u + 1);
+            const double va = __hiloint2double(__builtin_amdgcn_readlane(chi, u), __builtin_amdgcn_readlane(clo, u));
+            const double vb = __hiloint2double(__builtin_amdgcn_readlane(chi, u + 1), __builtin_amdgcn_readlane(clo, u + 1));
+            acc0 = fma(-va, xs[ca * 64 + lane], acc0);
+            acc1 = fma(-vb, xs[cb * 64 + lane], acc1);
+        }
+        if (u < l) {
+            const int32_t ca = __builtin_amdgcn_readlane(L.li, u);
+            const double va = __hiloint2double(__builtin_amdgcn_readlane(chi, u), __builtin_amdgcn_readlane(clo, u));
+            acc0 = fma(-va, xs[ca * 64 + lane], acc0);
+        }
+        const double d = __hiloint2double(__builtin_amdgcn_readlane(dhi, k), __builtin_amdgcn_readlane(dlo, k));
+        const double y = (acc0 + acc1) / d;
+        xs[k * 64 + lane] = y;
+        if (live) X[(int64_t)line * nrhs + r] = y;
+    };
+    // lines in order (forward: 0 .. cnt - 1; backward: cnt - 1 .. 0), two register sets so that a load is always ahead
+    auto at = [&](int step) { return FWD ? step : cnt - 1 - step; };
+    if (cnt <= 0) return;
+    Line R0 = load(at(0)), R1 = R0, R2 = R0, R3 = R0;     // a ring of four: three lines' loads in flight behind the sums
+    if (cnt > 1) R1 = load(at(1));
+    if (cnt > 2) R2 = load(at(2));
+    for (int step = 0; step < cnt; step += 4) {
+        if (step + 3 < cnt) R3 = load(at(step + 3));
+        compute(R0, at(step));
+        if (step + 4 < cnt) R0 = load(at(step + 4));
+        if (step + 1 < cnt) compute(R1, at(step + 1));
+        if (step + 5 < cnt) R1 = load(at(step + 5));
+        if (step + 2 < cnt) compute(R2, at(step + 2));
+        if (step + 6 < cnt) R2 = load(at(step + 6));
+        if (step + 3 < cnt) compute(R3, at(step + 3));
+    }
+}
+
+// ---- plan-time kernels of the leaf subtrees ----
+// position k in leaf_cols (column j of subtree t): number of forward terms (the whole row: all of it lies in the subtree),
+// number of backward terms inside the subtree (a column's rows are ancestors: those of the subtree come first), the task
+// for the rest of the column, the diagonal.
+__global__ void k_sn_leaf_meta(int32_t ncols, const int32_t *__restrict__ leaf_cols, const int32_t *__restrict__ sub_of,
+                               const int32_t *__restrict__ Gp, const int32_t *__restrict__ Lp, const int32_t *__restrict__ Li,
+                               const double *__restrict__ Lx, int32_t *lenf, int32_t *lenb, int32_t *split, int32_t *ntask,
+                               int32_t *nslot, double *ldiag) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ncols) return;
+    const int32_t j = leaf_cols[k], t = sub_of[j];
+    lenf[k] = Gp[j + 1] - Gp[j];
+    int32_t lo = Lp[j] + 1, hi = Lp[j + 1];
+    const int32_t end = hi;
+    while (lo < hi) {                      // first row that is not of subtree t
+        const int32_t mid = (lo + hi) >> 1;
+        if (sub_of[Li[mid]] == t) lo = mid + 1;
+        else hi = mid;
+    }
+    lenb[k] = lo - (Lp[j] + 1);
+    split[k] = lo;
+    const int32_t len = end - lo, pieces = (len + SN_SEG - 1) / SN_SEG;
+    ntask[k] = pieces;
+    nslot[k] = pieces > 1 ? pieces : 0;
+    ldiag[k] = Lx[Lp[j]];
+}
+
+// the tasks of the leaf columns' rows outside their subtrees: one per piece of SN_SEG terms; a column of several pieces
+// sums into partial slots (slot0 + its slot numbers), a column of one piece straight into X
+__global__ void k_sn_leaf_tasks(int32_t ncols, const int32_t *__restrict__ leaf_cols, const int32_t *__restrict__ Lp,
+                                const int32_t *__restrict__ split, const int32_t *__restrict__ task_ptr,
+                                const int32_t *__restrict__ slot_ptr, int32_t slot0, SnTask *tasks) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ncols) return;
+    const int32_t j = leaf_cols[k], b = split[k], e = Lp[j + 1];
+    int32_t t = task_ptr[k], sl = slot0 + slot_ptr[k];
+    const bool many = task_ptr[k + 1] - t > 1;
+    for (int32_t q = b; q < e; q += SN_SEG) tasks[t++] = SnTask{j, q, q + SN_SEG < e ? q + SN_SEG : e, many ? sl++ : -1};
+}
+
+__global__ __launch_bounds__(256) void k_sn_leaf_fill(int32_t ncols, const int32_t *__restrict__ leaf_cols,
+                                                      const int32_t *__restrict__ local_of, const int32_t *__restrict__ Gp,
+                                                      const int32_t *__restrict__ Gi, const double *__restrict__ Gx,
+                                                      const int32_t *__restrict__ Lp, const int32_t *__restrict__ Li,
+                                                      const double *__restrict__ Lx, const int32_t *__restrict__ lf_ptr,
+                                                      int32_t *lf_idx, double *lf_val, const int32_t *__restrict__ lb_ptr,
+                                                      int32_t *lb_idx, double *lb_val) {
+    const int lane = threadIdx.x & 63;
+    const int64_t k = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (k >= ncols) return;
+    const int32_t j = leaf_cols[k];
+    const int32_t fb = lf_ptr[k], fl = lf_ptr[k + 1] - fb, gb = Gp[j];
+    for (int32_t q = lane; q < fl; q += 64) {
+        lf_idx[fb + q] = local_of[Gi[gb + q]];
+        lf_val[fb + q] = Gx[gb + q];
+    }
+    const int32_t bb = lb_ptr[k], bl = lb_ptr[k + 1] - bb, cb = Lp[j] + 1;
+    for (int32_t q = lane; q < bl; q += 64) {
+        lb_idx[bb + q] = local_of[Li[cb + q]];
+        lb_val[bb + q] = Lx[cb + q];
+    }
+}
+
+// The schedule rests on properties every Cholesky factor has and an arbitrary lower triangle may not: the columns of
+// a supernode share their rows (column j's rows are column j - 1's minus its diagonal), a column's rows are ancestors
+// of the column (greater forward level, smaller backward level; inside a leaf subtree: the same subtree or outside
+// any), rows ascending without duplicates.  One pass over the pattern checks all of it.  fl / bl: forward / backward
+// level of every column (leaf subtrees: -1 / INT_MAX), sn: supernode of a column (leaf: -1 - subtree).
+__global__ __launch_bounds__(256) void k_sn_verify(int32_t n, const int32_t *__restrict__ Lp, const int32_t *__restrict__ Li,
+                                                   const int32_t *__restrict__ sn, const int32_t *__restrict__ joins,
+                                                   const int32_t *__restrict__ fl, const int32_t *__restrict__ bl, int *bad) {
+    const int lane = threadIdx.x & 63;
+    const int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (j >= n) return;
+    const int32_t b = Lp[j], e = Lp[j + 1], S = sn[j];
+    const bool jn = joins[j] != 0;
+    const int32_t pb = jn ? Lp[j - 1] : 0;
+    bool wrong = e - b < 1 || Li[b] != (int32_t)j;
+    for (int32_t q = b + lane; q < e; q += 64) {
+        const int32_t i = Li[q];
+        if ((uint32_t)i >= (uint32_t)n) {
+            wrong = true;
+            continue;
+        }
+        if (jn && Li[pb + (q - b) + 1] != i) wrong = true;
+        if (q > b) {
+            if (i <= Li[q - 1]) wrong = true;            // rows ascending, no duplicates
+            const int32_t T = sn[i];
+            if (T != S && (fl[i] <= fl[j] || bl[i] >= bl[j])) wrong = true;
+        }
+    }
+    if (wrong) atomicOr(bad, 1);
+}
+
+}  // namespace
+
+/* Build the supernodal schedule of a Cholesky factor.  parent: elimination tree (host, n), Lp_h / Gp_h: host copies of
+ * L's column pointers and of the forward plan's row pointers (off-diagonal terms of each row); G*: that row-major copy
+ * on the device.  *out = nullptr when the factor gains nothing from it (no supernodes to speak of, or a chain). */
+int sn_build(const Csc *L, const int32_t *parent, const int32_t *Lp_h, const int32_t *Gp_h, const int32_t *Gp, const int32_t *Gi,
+             const double *Gx, int32_t col_levels, SnPlan **out) {
+    const int32_t n = L->n;
+    *out = nullptr;
+    if (n < 2) return CSX_OK;
+    const bool say = std::getenv("CSX_CHOL_TIMING") != nullptr;
+    // ---- leaf subtrees: maximal subtrees of at most SN_LEAF columns ----
+    std::vector<int32_t> size((size_t)n, 1), sub_of((size_t)n, -1), local_of((size_t)n, -1);
+    for (int32_t j = 0; j < n; j++)
+        if (parent[j] >= 0) size[(size_t)parent[j]] += size[(size_t)j];
+    std::vector<int32_t> leaf_ptr, leaf_cols;
+    int32_t nleaf = 0;
+    for (int32_t j = n - 1; j >= 0; j--) {            // parents before children
+        const int32_t pj = parent[j];
+        if (pj >= 0 && sub_of[(size_t)pj] >= 0) sub_of[(size_t)j] = sub_of[(size_t)pj];
+        else if (size[(size_t)j] <= SN_LEAF) sub_of[(size_t)j] = nleaf++;
+    }
+    {
+        std::vector<int32_t> cnt((size_t)nleaf + 1, 0);
+        for (int32_t j = 0; j < n; j++)
+            if (sub_of[(size_t)j] >= 0) cnt[(size_t)sub_of[(size_t)j] + 1]++;
+        for (int32_t t = 0; t < nleaf; t++) cnt[(size_t)t + 1] += cnt[(size_t)t];
+        leaf_ptr = cnt;
+        leaf_cols.assign((size_t)cnt[(size_t)nleaf], 0);
+        std::vector<int32_t> at(cnt.begin(), cnt.end() - 1);
+        for (int32_t j = 0; j < n; j++)                // ascending inside a subtree: a topological order
+            if (sub_of[(size_t)j] >= 0) {
+                const int32_t t = sub_of[(size_t)j];
+                local_of[(size_t)j] = at[(size_t)t] - leaf_ptr[(size_t)t];
+                leaf_cols[(size_t)at[(size_t)t]++] = j;
+            }
+    }
+    // ---- supernodes of the columns outside the leaf subtrees ----
+    std::vector<int32_t> first, sn_of((size_t)n, -1), joins((size_t)n, 0);
+    for (int32_t j = 0; j < n; j++) {
+        if (sub_of[(size_t)j] >= 0) continue;
+        const bool jn = j > 0 && sub_of[(size_t)j - 1] < 0 && parent[j - 1] == j &&
+                        (Lp_h[j + 1] - Lp_h[j]) == (Lp_h[j] - Lp_h[j - 1]) - 1;
+        if (!jn) first.push_back(j);
+        joins[(size_t)j] = jn ? 1 : 0;
+        sn_of[(size_t)j] = (int32_t)first.size() - 1;
+    }
+    const int32_t nsn = (int32_t)first.size();
+    if (nsn == 0) return CSX_OK;                       // a forest of small trees: the fused per-tree kernels' business
+    std::vector<int32_t> width((size_t)nsn, 0);
+    for (int32_t j = 0; j < n; j++)
+        if (sn_of[(size_t)j] >= 0) width[(size_t)sn_of[(size_t)j]]++;
+    std::vector<int32_t> sparent((size_t)nsn, -1), height((size_t)nsn, 0), depth((size_t)nsn, 0);
+    int32_t max_w = 0;
+    for (int32_t S = 0; S < nsn; S++) {
+        const int32_t last = first[(size_t)S] + width[(size_t)S] - 1;
+        max_w = std::max(max_w, width[(size_t)S]);
+        if (parent[last] >= 0) sparent[(size_t)S] = sn_of[(size_t)parent[last]];
+    }
+    for (int32_t S = 0; S < nsn; S++)
+        if (sparent[(size_t)S] >= 0) height[(size_t)sparent[(size_t)S]] = std::max(height[(size_t)sparent[(size_t)S]], height[(size_t)S] + 1);
+    for (int32_t S = nsn - 1; S >= 0; S--)
+        if (sparent[(size_t)S] >= 0) depth[(size_t)S] = depth[(size_t)sparent[(size_t)S]] + 1;
+    int32_t nlev = 0;
+    for (int32_t S = 0; S < nsn; S++) nlev = std::max(nlev, height[(size_t)S] + 1);
+    // worth it?  the supernodal schedule must be much shorter than the column one
+    int64_t est_steps = 0;
+    {
+        std::vector<int32_t> lev_w((size_t)nlev, 0);
+        for (int32_t S = 0; S < nsn; S++) lev_w[(size_t)height[(size_t)S]] = std::max(lev_w[(size_t)height[(size_t)S]], width[(size_t)S]);
+        for (int32_t l = 0; l < nlev; l++) est_steps += (lev_w[(size_t)l] + SN_CHUNK - 1) / SN_CHUNK;
+    }
+    if (say)
+        std::fprintf(stderr, "sn_build: n %d: %d leaf subtrees (%d columns), %d supernodes in %d levels, ~%d steps (column levels: %d), max width %d\n",
+                     n, nleaf, (int)leaf_cols.size(), nsn, nlev, (int)est_steps, col_levels, max_w);
+    if (est_steps * 2 > col_levels) return CSX_OK;
+    SnPlan *P = new SnPlan();
+    P->n = n;
+    P->nsn = nsn;
+    P->max_w = max_w;
+    P->nleaf = nleaf;
+    P->nleafcols = (int32_t)leaf_cols.size();
+    hipStream_t s = ctx().stream;
+    int st = CSX_OK;
+    {   // is L shaped like a Cholesky factor with these supernodes and subtrees?
+        std::vector<int32_t> snc((size_t)n), fl((size_t)n), bl((size_t)n);
+        for (int32_t j = 0; j < n; j++) {
+            const int32_t S = sn_of[(size_t)j];
+            snc[(size_t)j] = S >= 0 ? S : -1 - sub_of[(size_t)j];
+            fl[(size_t)j] = S >= 0 ? height[(size_t)S] : -1;
+            bl[(size_t)j] = S >= 0 ? depth[(size_t)S] : 0x7fffffff;
+        }
+        DevScope tmp;
+        int32_t *d_sn = nullptr, *d_j = nullptr, *d_f = nullptr, *d_b = nullptr;
+        int *d_bad = nullptr, h_bad = 0;
+        const std::pair<int32_t **, std::vector<int32_t> *> ups[] = {{&d_sn, &snc}, {&d_j, &joins}, {&d_f, &fl}, {&d_b, &bl}};
+        for (const auto &pr : ups) {
+            if (st == CSX_OK) st = tmp.alloc(pr.first, (size_t)n);
+            if (st == CSX_OK && hipMemcpyAsync(*pr.first, pr.second->data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, s) != hipSuccess)
+                st = CSX_ERUNTIME;
+        }
+        if (st == CSX_OK) st = tmp.alloc(&d_bad, 1);
+        if (st == CSX_OK && hipMemsetAsync(d_bad, 0, sizeof(int), s) != hipSuccess) st = CSX_ERUNTIME;
+        if (st == CSX_OK) {
+            hipLaunchKernelGGL(k_sn_verify, dim3((unsigned)(((int64_t)n + 3) / 4)), dim3(256), 0, s, n, L->p, L->i, d_sn, d_j, d_f, d_b,
+                               d_bad);
+            if (hipMemcpyAsync(&h_bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
+                hipStreamSynchronize(s) != hipSuccess)
+                st = CSX_ERUNTIME;
+        }
+        if (say) std::fprintf(stderr, "sn_build: verify %s\n", h_bad ? "FAILED" : "ok");
+        if (st != CSX_OK || h_bad) {            // not such a factor: the level-scheduled plans stay in charge
+            free_snplan(P);
+            return st;
+        }
+    }
+    // partial slots of the backward schedule (a column whose rows below its supernode are cut into pieces): counted here
+    // because the leaf columns' slots are numbered behind them
+    int32_t bwd_slots = 0;
+    for (int32_t S = 0; S < nsn; S++)
+        for (int32_t v = 0; v < width[(size_t)S]; v++) {
+            const int32_t col = first[(size_t)S] + v, c = Lp_h[col + 1] - (Lp_h[col] + (width[(size_t)S] - v));
+            if (c > SN_SEG) bwd_slots += (c + SN_SEG - 1) / SN_SEG;
+        }
+    // ---- leaf subtrees: packed programs ----
+    st = up(&P->leaf_ptr, leaf_ptr);
+    if (st == CSX_OK) st = up(&P->leaf_cols, leaf_cols);
+    if (st == CSX_OK && P->nleafcols > 0) {
+        DevScope tmp;
+        int32_t *d_sub = nullptr, *d_local = nullptr, *lenf = nullptr, *lenb = nullptr, *split = nullptr, *ntask = nullptr,
+                *nslot = nullptr, *task_ptr = nullptr;
+        const int32_t nc = P->nleafcols;
+        st = tmp.alloc(&d_sub, (size_t)n);
+        if (st == CSX_OK) st = tmp.alloc(&d_local, (size_t)n);
+        for (int32_t **a : {&lenf, &lenb, &split, &ntask, &nslot, &task_ptr})
+            if (st == CSX_OK) st = tmp.alloc(a, (size_t)nc + 1);
+        if (st == CSX_OK) st = dalloc(&P->lf_ptr, (size_t)nc + 1);
+        if (st == CSX_OK) st = dalloc(&P->lb_ptr, (size_t)nc + 1);
+        if (st == CSX_OK) st = dalloc(&P->lslot_ptr, (size_t)nc + 1);
+        if (st == CSX_OK) st = dalloc(&P->ldiag, (size_t)nc);
+        if (st == CSX_OK &&
+            (hipMemcpyAsync(d_sub, sub_of.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, s) != hipSuccess ||
+             hipMemcpyAsync(d_local, local_of.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, s) != hipSuccess))
+            st = CSX_ERUNTIME;
+        int64_t ftot = 0, btot = 0, ttot = 0, stot = 0;
+        if (st == CSX_OK) {
+            hipLaunchKernelGGL(k_sn_leaf_meta, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, nc, P->leaf_cols, d_sub, Gp, L->p,
+                               L->i, L->x, lenf, lenb, split, ntask, nslot, P->ldiag);
+            st = scan_exclusive_i32(lenf, P->lf_ptr, nc, &ftot);
+            if (st == CSX_OK) st = scan_exclusive_i32(lenb, P->lb_ptr, nc, &btot);
+            if (st == CSX_OK) st = scan_exclusive_i32(ntask, task_ptr, nc, &ttot);
+            if (st == CSX_OK) st = scan_exclusive_i32(nslot, P->lslot_ptr, nc, &stot);
+        }
+        P->nleaftasks = (int32_t)ttot;
+        P->nleafslots = (int32_t)stot;
+        if (st == CSX_OK) st = dalloc(&P->leaf_tasks, (size_t)ttot + 1);
+        // the leaf columns' partial slots come behind the backward schedule's own (bwd_slots: counted above)
+        if (st == CSX_OK)
+            hipLaunchKernelGGL(k_sn_leaf_tasks, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, nc, P->leaf_cols, L->p, split,
+                               task_ptr, P->lslot_ptr, bwd_slots, P->leaf_tasks);
+        if (st == CSX_OK) st = dalloc(&P->lf_idx, (size_t)ftot + 64);
+        if (st == CSX_OK) st = dalloc(&P->lf_val, (size_t)ftot + 64);
+        if (st == CSX_OK) st = dalloc(&P->lb_idx, (size_t)btot + 64);
+        if (st == CSX_OK) st = dalloc(&P->lb_val, (size_t)btot + 64);
+        if (st == CSX_OK) {
+            hipLaunchKernelGGL(k_sn_leaf_fill, dim3((unsigned)(((int64_t)nc + 3) / 4)), dim3(256), 0, s, nc, P->leaf_cols, d_local, Gp, Gi,
+                               Gx, L->p, L->i, L->x, P->lf_ptr, P->lf_idx, P->lf_val, P->lb_ptr, P->lb_idx, P->lb_val);
+            if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) st = CSX_ERUNTIME;
+        }
+    }
+    // ---- virtual supernodes: every supernode cut into chunks of SN_CHUNK columns ----
+    std::vector<int32_t> vs_a, vs_w, vs0((size_t)nsn + 1, 0);
+    for (int32_t S = 0; S < nsn; S++) {
+        vs0[(size_t)S] = (int32_t)vs_a.size();
+        for (int32_t c = 0; c < width[(size_t)S]; c += SN_CHUNK) {
+            vs_a.push_back(first[(size_t)S] + c);
+            vs_w.push_back(std::min(SN_CHUNK, width[(size_t)S] - c));
+        }
+    }
+    vs0[(size_t)nsn] = (int32_t)vs_a.size();
+    if (st == CSX_OK) st = up(&P->vs_a, vs_a);
+    if (st == CSX_OK) st = up(&P->vs_w, vs_w);
+    auto build = [&](SnDir &D, const std::vector<int32_t> &level, bool forward) -> int {
+        int32_t Lv = 0;
+        for (int32_t S = 0; S < nsn; S++) Lv = std::max(Lv, level[(size_t)S] + 1);
+        std::vector<std::vector<int32_t>> by((size_t)Lv);
+        for (int32_t S = 0; S < nsn; S++) by[(size_t)level[(size_t)S]].push_back(S);
+        std::vector<SnTask> tasks;
+        std::vector<int32_t> narrow, medium, wide, part((size_t)n + 1, 0);
+        // terms of line a + v (v: position in its supernode of width w) that lie outside the supernode
+        auto outside = [&](int32_t line, int32_t v, int32_t w, int32_t *b, int32_t *e) {
+            if (forward) {                       // row: [Gp[row], Gp[row + 1] - v)
+                *b = Gp_h[line];
+                *e = Gp_h[line + 1] - v;
+            } else {                             // column: the rows below the supernode [Lp[col] + (w - v), Lp[col + 1])
+                *b = Lp_h[line] + (w - v);
+                *e = Lp_h[line + 1];
+            }
+        };
+        for (int32_t S = 0; S < nsn; S++)
+            for (int32_t v = 0; v < width[(size_t)S]; v++) {
+                int32_t b, e;
+                outside(first[(size_t)S] + v, v, width[(size_t)S], &b, &e);
+                const int32_t c = e - b;
+                part[(size_t)(first[(size_t)S] + v) + 1] = c > SN_SEG ? (c + SN_SEG - 1) / SN_SEG : 0;
+            }
+        for (int32_t j = 0; j < n; j++) part[(size_t)j + 1] += part[(size_t)j];
+        D.nslots = part[(size_t)n];
+        for (int32_t l = 0; l < Lv; l++) {
+            int32_t nsub = 1;
+            for (int32_t S : by[(size_t)l]) nsub = std::max(nsub, vs0[(size_t)S + 1] - vs0[(size_t)S]);
+            for (int32_t q = 0; q < nsub; q++) {
+                SnStep stp{(int32_t)tasks.size(), 0, (int32_t)narrow.size(), 0, (int32_t)medium.size(), 0, (int32_t)wide.size(), 0};
+                for (int32_t S : by[(size_t)l]) {
+                    const int32_t a = first[(size_t)S], w = width[(size_t)S], nch = vs0[(size_t)S + 1] - vs0[(size_t)S];
+                    if (q >= nch) continue;
+                    if (q == 0) {
+                        // the terms from outside the supernode, for all its rows / columns
+                        for (int32_t v = 0; v < w; v++) {
+                            int32_t b, e;
+                            outside(a + v, v, w, &b, &e);
+                            if (e <= b) continue;
+                            if (e - b <= SN_SEG) {
+                                tasks.push_back({a + v, b, e, -1});
+                            } else {
+                                int32_t slot = part[(size_t)(a + v)];
+                                for (int32_t t = b; t < e; t += SN_SEG) tasks.push_back({a + v, t, std::min(e, t + SN_SEG), slot++});
+                            }
+                        }
+                    } else if (forward) {
+                        // chunk q - 1 is solved: every later row takes its terms of that chunk's columns
+                        const int32_t c0 = (q - 1) * SN_CHUNK;
+                        for (int32_t v = q * SN_CHUNK; v < w; v++) {
+                            const int32_t in0 = Gp_h[a + v + 1] - v;
+                            tasks.push_back({a + v, in0 + c0, in0 + c0 + SN_CHUNK, -1});
+                        }
+                    } else {
+                        // chunk c = nch - q is solved: every earlier column takes its terms of that chunk's rows
+                        const int32_t c = nch - q, r0 = c * SN_CHUNK, r1 = std::min(w, r0 + SN_CHUNK);
+                        for (int32_t v = 0; v < r0; v++) {
+                            const int32_t base = Lp_h[a + v] - v;
+                            tasks.push_back({a + v, base + r0, base + r1, -1});
+                        }
+                    }
+                    const int32_t chunk = vs0[(size_t)S] + (forward ? q : nch - 1 - q);
+                    const int32_t cw = vs_w[(size_t)chunk];
+                    (cw > 32 ? wide : cw > SN_PANEL ? medium : narrow).push_back(chunk);
+                }
+                stp.tc = (int32_t)tasks.size() - stp.t0;
+                stp.sc = (int32_t)narrow.size() - stp.s0;
+                stp.mc = (int32_t)medium.size() - stp.m0;
+                stp.bc = (int32_t)wide.size() - stp.b0;
+                D.steps.push_back(stp);
+            }
+        }
+        CSX_TRY(up(&D.tasks, tasks));
+        CSX_TRY(up(&D.narrow, narrow));
+        CSX_TRY(up(&D.medium, medium));
+        CSX_TRY(up(&D.wide, wide));
+        CSX_TRY(up(&D.part_ptr, part));
+        return CSX_OK;
+    };
+    if (st == CSX_OK) st = build(P->fwd, height, true);
+    if (st == CSX_OK) st = build(P->bwd, depth, false);
+    if (st == CSX_OK && P->bwd.nslots != bwd_slots) {
+        set_error("sn_build: slot count mismatch (%d / %d)", P->bwd.nslots, bwd_slots);
+        st = CSX_ERUNTIME;
+    }
+    if (st == CSX_OK && hipStreamSynchronize(s) != hipSuccess) st = CSX_ERUNTIME;
+    if (st != CSX_OK) {
+        free_snplan(P);
+        return st;
+    }
+    if (say) std::fprintf(stderr, "sn_build: %d forward steps, %d backward steps\n", (int)P->fwd.steps.size(), (int)P->bwd.steps.size());
+    *out = P;
+    return CSX_OK;
+}
+
+void sn_info(const SnPlan *P, int32_t *nsn, int32_t *levels, int32_t *max_w) {
+    if (nsn) *nsn = P->nsn;
+    if (levels) *levels = (int32_t)P->fwd.steps.size();
+    if (max_w) *max_w = P->max_w;
+}
+
+/* X (n x nrhs, row-major) <- inv(L) X (forward) or inv(L') X.  G*: the forward plan's row-major copy of L (off-diagonal
+ * terms of every row in ascending column order, diagonal apart); L: the factor. */
+int sn_solve(SnPlan *P, bool forward, const int32_t *Gp, const int32_t *Gi, const double *Gx, const double *Gd, const Csc *L,
+             double *X, int32_t nrhs) {
+    hipStream_t s = ctx().stream;
+    const SnDir &D = forward ? P->fwd : P->bwd;
+    const int64_t need = (int64_t)std::max(P->fwd.nslots, P->bwd.nslots + P->nleafslots) * nrhs;
+    if (P->partial_len < need) {
+        dfree(P->partial);
+        P->partial = nullptr;
+        P->partial_len = 0;
+        CSX_TRY(dalloc(&P->partial, (size_t)need));
+        P->partial_len = need;
+    }
+    const int nblk = (nrhs + 63) / 64;
+    const int32_t *idx = forward ? Gi : L->i;
+    const double *val = forward ? Gx : L->x;
+    static bool lds_set = false;
+    if (!lds_set) {     // the 64-column triangle + its rows of X: 66 KB of LDS, past the static limit
+        CSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sn_tri<4, SN_CHUNK, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sn_tri_lds<SN_CHUNK>()));
+        CSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sn_tri<4, SN_CHUNK, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sn_tri_lds<SN_CHUNK>()));
+        lds_set = true;
+    }
+    if (forward && P->nleaf)
+        hipLaunchKernelGGL(k_sn_leaf<true>, dim3((unsigned)(P->nleaf * nblk)), dim3(64), 0, s, P->leaf_ptr, P->leaf_cols, P->lf_ptr,
+                           P->lf_idx, P->lf_val, P->ldiag, (const int32_t *)nullptr, (const double *)nullptr, X, nrhs);
+    for (const SnStep &t : D.steps) {
+        if (t.tc > 0) {
+            const int64_t waves = (int64_t)t.tc * nblk;
+            hipLaunchKernelGGL(k_sn_outside, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, D.tasks, t.t0, t.tc, idx, val, X,
+                               P->partial, nrhs);
+        }
+        if (forward) {
+            if (t.sc > 0)
+                hipLaunchKernelGGL((k_sn_tri<1, SN_PANEL, true>), dim3((unsigned)(t.sc * nblk)), dim3(64), sn_tri_lds<SN_PANEL>(), s, D.narrow,
+                                   t.s0, P->vs_a, P->vs_w, Gp, Gx, Gd, D.part_ptr, P->partial, X, nrhs);
+            if (t.mc > 0)
+                hipLaunchKernelGGL((k_sn_tri<2, 32, true>), dim3((unsigned)(t.mc * nblk)), dim3(128), sn_tri_lds<32>(), s, D.medium, t.m0,
+                                   P->vs_a, P->vs_w, Gp, Gx, Gd, D.part_ptr, P->partial, X, nrhs);
+            if (t.bc > 0)
+                hipLaunchKernelGGL((k_sn_tri<4, SN_CHUNK, true>), dim3((unsigned)(t.bc * nblk)), dim3(256), sn_tri_lds<SN_CHUNK>(), s, D.wide,
+                                   t.b0, P->vs_a, P->vs_w, Gp, Gx, Gd, D.part_ptr, P->partial, X, nrhs);
+        } else {
+            if (t.sc > 0)
+                hipLaunchKernelGGL((k_sn_tri<1, SN_PANEL, false>), dim3((unsigned)(t.sc * nblk)), dim3(64), sn_tri_lds<SN_PANEL>(), s, D.narrow,
+                                   t.s0, P->vs_a, P->vs_w, L->p, L->x, (const double *)nullptr, D.part_ptr, P->partial, X, nrhs);
+            if (t.mc > 0)
+                hipLaunchKernelGGL((k_sn_tri<2, 32, false>), dim3((unsigned)(t.mc * nblk)), dim3(128), sn_tri_lds<32>(), s, D.medium, t.m0,
+                                   P->vs_a, P->vs_w, L->p, L->x, (const double *)nullptr, D.part_ptr, P->partial, X, nrhs);
+            if (t.bc > 0)
+                hipLaunchKernelGGL((k_sn_tri<4, SN_CHUNK, false>), dim3((unsigned)(t.bc * nblk)), dim3(256), sn_tri_lds<SN_CHUNK>(), s, D.wide,
+                                   t.b0, P->vs_a, P->vs_w, L->p, L->x, (const double *)nullptr, D.part_ptr, P->partial, X, nrhs);
+        }
+    }
+    if (!forward && P->nleaf) {
+        const int64_t waves = (int64_t)P->nleaftasks * nblk;    // every leaf column's rows outside its subtree (ancestors: final)
+        if (waves > 0)
+            hipLaunchKernelGGL(k_sn_outside, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, P->leaf_tasks, 0, P->nleaftasks, L->i,
+                               L->x, X, P->partial, nrhs);
+        hipLaunchKernelGGL(k_sn_leaf<false>, dim3((unsigned)(P->nleaf * nblk)), dim3(64), 0, s, P->leaf_ptr, P->leaf_cols, P->lb_ptr,
+                           P->lb_idx, P->lb_val, P->ldiag, P->lslot_ptr, P->partial + (int64_t)P->bwd.nslots * nrhs, X, nrhs);
+    }
+    CSX_LAUNCH_CHECK();
+    return CSX_OK;
+}
+
+}  // namespace csx

@@ -612,3 +612,91 @@ def test_solver_keeps_its_factor_alive_and_follows_updown(cs):
         assert F.solve(x2)
         ref2 = CO.ltsolve(n, Lp, Li[:lnz], L2x, CO.lsolve(n, Lp, Li[:lnz], L2x, b))
         assert np.asarray(x2).tobytes() == ref2.tobytes()
+
+
+@pytest.mark.parametrize("case", ["grid_120x120", "grid_75x131", "bcsstk16"])
+def test_supernodal_solves_in_the_rounding_equal_order(cs, case):
+    """cholsol_factor(A, order=1, exact=False) on a connected nested-dissection factor: the solves are scheduled by
+    SUPERNODE (csx_snsolve.hip: outside terms by a wave per piece of a row, the dense triangle in panels of 16) instead
+    of by column.  Against the plain-C oracle's cs_lsolve + cs_ltsolve on the same L at 1e-10 (BASELINE's tolerance),
+    for 1, 3, 64 and 70 right-hand sides (a partial second chunk); the exact order of the same factor stays bit-identical;
+    the same bits from run to run (partial sums are added in a fixed order); switched off -> the level-scheduled path."""
+    import _csx
+    if case == "bcsstk16":
+        g = golden("bcsstk16")
+        A = cs.cs_pin(unpack(cs, g, "C"))
+        n = A.n
+    else:
+        gx, gy = (int(v) for v in case[5:].split("x"))
+        n, p, i, x = _grid_laplacian(gx, gy)
+        A = cs.cs_spalloc(n, n, len(i), True, False)
+        A.p, A.i, A.x = p.tolist(), i.tolist(), x.tolist()
+        cs.cs_pin(A)
+    Fr = cs.cholsol_factor(A, order=1, exact=False)
+    path = _csx.C.c_int32(-1)
+    _csx.check(_csx.lib().csx_cholsol_info(Fr.plan_handle, path, None, None))
+    assert path.value == 4                                            # the supernodal schedule is in charge
+    Fe = cs.cholsol_factor(A, order=1)
+    Lp, Li, Lx = _arr(Fr.L)
+    pinv = np.asarray(Fr.symbolic.pinv)
+    for k in (1, 3, 64, 70):
+        B = synth.rhs(n, k, 2)
+        Xr, Xr2, Xe = cs.dvec(B), cs.dvec(B), cs.dvec(B)
+        assert Fr.solve(Xr) and Fr.solve(Xr2) and Fe.solve(Xe)
+        Xr, Xr2, Xe = Xr.numpy().reshape(n, k), Xr2.numpy().reshape(n, k), Xe.numpy().reshape(n, k)
+        assert Xr.tobytes() == Xr2.tobytes()                          # reproducible
+        for r in sorted({0, k // 2, k - 1}):
+            pb = np.empty(n)
+            pb[pinv] = B[:, r]                                        # cs_ipvec
+            y = CO.ltsolve(n, Lp, Li, Lx, CO.lsolve(n, Lp, Li, Lx, pb))
+            ref = y[pinv]                                             # cs_pvec
+            assert Xe[:, r].tobytes() == ref.tobytes()                # exact order: the reference's bits
+            assert np.max(np.abs(Xr[:, r] - ref)) <= 1e-10 * np.max(np.abs(ref))
+            scale = np.maximum(np.abs(ref), 1e-3 * np.max(np.abs(ref)))
+            assert np.max(np.abs(Xr[:, r] - ref) / scale) <= 1e-9
+    with _csx.option("tri.supernodes", 0):
+        F0 = cs.cholsol_factor(A, order=1, exact=False)
+        _csx.check(_csx.lib().csx_cholsol_info(F0.plan_handle, path, None, None))
+        assert path.value == 0
+        X0 = cs.dvec(synth.rhs(n, 3, 2))
+        assert F0.solve(X0)
+    X3 = cs.dvec(synth.rhs(n, 3, 2))
+    assert Fr.solve(X3)
+    assert np.max(np.abs(X0.numpy() - X3.numpy())) <= 1e-10 * np.max(np.abs(X3.numpy()))
+
+
+def test_supernodal_schedule_refuses_a_triangle_that_is_not_a_cholesky_factor(cs):
+    """csx_cholsol_plan takes any lower triangle with the diagonal first.  One whose columns look like supernodes by
+    their counts but do not share their rows (or whose rows are not ancestors in its own tree) must not get the
+    supernodal schedule: k_sn_verify sends it back to the level-scheduled plans, and the answer is still right."""
+    import _csx
+    lib = _csx.lib()
+    n = 400
+    rng = np.random.default_rng(3)
+    cols_i, cols_x, Ap = [], [], [0]
+    for j in range(n):
+        below = np.arange(j + 1, n)
+        # j + 1 is always the first off-diagonal row (a chain tree) and the counts fall by one from column to column
+        # within runs of eight, but the other rows are random: not the rows of the previous column
+        cnt = min(len(below), 12 - (j % 8))
+        pick = below[:1].tolist() + sorted(rng.choice(below[1:], size=max(0, min(cnt - 1, len(below) - 1)), replace=False).tolist()) if len(below) else []
+        rows = [j] + pick
+        cols_i.append(np.asarray(rows, np.int32))
+        cols_x.append(np.concatenate([[4.0 + len(rows)], rng.uniform(-1, 1, len(rows) - 1)]))
+        Ap.append(Ap[-1] + len(rows))
+    Lp, Li, Lx = np.asarray(Ap, np.int32), np.concatenate(cols_i), np.concatenate(cols_x)
+    hL = _csx.new_handle()
+    _csx.check(lib.csx_csc_upload(n, n, _csx.pi(Lp), _csx.pi(Li), _csx.pd(Lx), hL))
+    plan = _csx.new_handle()
+    _csx.check(lib.csx_cholsol_plan(hL, None, plan))
+    _csx.check(lib.csx_cholsol_set_order(plan, 0))
+    path = _csx.C.c_int32(-1)
+    _csx.check(lib.csx_cholsol_info(plan, path, None, None))
+    assert path.value == 0
+    b = synth.rhs(n, 1, 0)[:, 0]
+    X = cs.dvec(b)
+    _csx.check(lib.csx_cholsol_solve(plan, X.handle, 1))
+    ref = CO.ltsolve(n, Lp, Li, Lx, CO.lsolve(n, Lp, Li, Lx, b))
+    assert np.max(np.abs(X.numpy() - ref)) <= 1e-10 * np.max(np.abs(ref))
+    _csx.free(plan)
+    _csx.free(hL)
