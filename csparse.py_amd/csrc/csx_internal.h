@@ -137,7 +137,8 @@ struct Options {
     int tri_levels_where = 0;         // level analysis: 0 = device for big factors, host for small; 1 = host; 2 = device
     int tri_supernodes = 1;           // cholsol: dense-block (supernodal) forward / backward solves on factors with supernodes
     int spgemm_ordered = 0;           // cs_multiply: sum every entry's products in the reference's order (bit-identical x)
-    int spgemm_chunks = 8;            // cs_multiply: column chunks whose compaction overlaps the next chunk's hashing (0/1: off)
+    int spgemm_chunks = 1;            // cs_multiply: column chunks whose compaction overlaps the next chunk's hashing on a second stream
+                                      // (1 = off, the default: measured slower, profiles/r03_ablation.md section 2)
     int lu_etree = 1;                 // cs_lu of one connected matrix on the device, columns scheduled by the column etree
 };
 

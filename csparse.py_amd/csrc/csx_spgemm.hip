@@ -806,13 +806,13 @@ __global__ __launch_bounds__(256) void k_sg_hash2(int slots_, const int4 *__rest
 
 template <bool VALUES>
 static int launch_hash2(int slots, const Csc *A, const Csc *B, const int4 *info, int32_t ncols, int32_t *count,
-                        int32_t *tmp_i, double *tmp_x) {
+                        int32_t *tmp_i, double *tmp_x, int cap_per_cu = 8) {
     if (ncols <= 0) return CSX_OK;
     const size_t lds = (size_t)(slots + (slots & 1)) * (VALUES ? 16 : 8) + H2_MAXSEG * 4 + 64;
     auto kern = k_sg_hash2<VALUES>;
     CSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024 - 256));
-    const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(8, (160 * 1024) / (int64_t)(lds + 256)));
+    const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(cap_per_cu, (160 * 1024) / (int64_t)(lds + 256)));
     const int64_t grid = std::min<int64_t>(ncols, (int64_t)ctx().cus * per_cu);
     const int abl = ablation_env("CSX_SG_ABL") ? std::atoi(ablation_env("CSX_SG_ABL")) : 0;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, ctx().stream, slots, info, ncols, A->p, A->i, A->x,
@@ -862,14 +862,14 @@ static size_t h1_lds_bytes(int slots, bool values) {   // slots = 3/2 * (product
 
 template <bool VALUES>
 static int launch_hash1(int slots, const Csc *A, const Csc *B, const int4 *info, int32_t ncols, int32_t *count,
-                        int32_t *tmp_i, double *tmp_x) {
+                        int32_t *tmp_i, double *tmp_x, int cap_per_cu = 8) {
     if (ncols <= 0) return CSX_OK;
     const size_t lds = h1_lds_bytes(slots, VALUES);
     auto kern = k_sg_hash1<VALUES>;
     CSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 160 * 1024 - 256));
     // exactly the workgroups that are resident at once (LDS-limited, at most 8 x 4 waves per CU)
-    const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(8, (160 * 1024) / (int64_t)(lds + 256)));
+    const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(cap_per_cu, (160 * 1024) / (int64_t)(lds + 256)));
     const int64_t grid = std::min<int64_t>(ncols, (int64_t)ctx().cus * per_cu);
     const int abl = ablation_env("CSX_SG_ABL") ? std::atoi(ablation_env("CSX_SG_ABL")) : 0;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, ctx().stream, slots, info, ncols, A->p, A->i, A->x,
@@ -923,6 +923,301 @@ static int run_bins(const Csc *A, const Csc *B, const uint32_t *cols, const int3
             for (slots = 1024; slots < 2 * sg_hash_limit(hb); slots <<= 1) {}
         CSX_TRY((launch_bin<NUMERIC, VALUES>(kind, slots, A, B, cols + bin_ptr[b], nb, count, Cp, Ci, Cx, g_tmin, g_val)));
     }
+    return CSX_OK;
+}
+
+// ---- chunked one-pass path (opt-in, spgemm.chunks >= 2) ----------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sg_chunk_key(int32_t n, int32_t chunk_cols, const uint32_t *__restrict__ bin,
+                                                      uint32_t *__restrict__ key) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) key[j] = (uint32_t)(j / chunk_cols) * (uint32_t)SG_NBINS + bin[j];
+}
+
+// Cp[c0 .. c1] (a chunk's exclusive scan, starting at 0) += base[cur]; base[cur ^ 1] = base[cur] + the chunk's total
+__global__ __launch_bounds__(256) void k_sg_add_base(int32_t *__restrict__ Cp, int32_t c0, int32_t c1,
+                                                     unsigned long long *base, int cur) {
+    const int64_t j = c0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > c1) return;
+    const unsigned long long b = base[cur], v = b + (unsigned long long)Cp[j];
+    Cp[j] = (int32_t)(v > 0x7FFFFFFFull ? 0x7FFFFFFFull : v);
+    if (j == c1) base[cur ^ 1] = v;
+}
+
+// The chunked form of the one-pass path: columns in ascending chunks; while chunk c + 1 is hashed (an instruction- and
+// LDS-bound kernel that leaves the memory system mostly idle) chunk c -- its counts scanned behind chunk c - 1's end, which
+// IS C.p for those columns -- is compacted into C.i / C.x on a second stream (a pure copy).  C.i / C.x are allocated for
+// the upper bound "one entry per product" (the reference grows C the same way, csparse.py:1630-1631, and trims at the
+// end).  MEASURED SLOWER than the unchunked path on S (1M x 1M, 32 per column: 14.9 ms unchunked; 15.1 / 15.4 / 16.2 ms
+// with 2 / 4 / 8 chunks; with the hash kernels held to three workgroups per CU so that the copy's waves find registers,
+// 16.1 - 16.6 ms): the hash kernel fills the vector registers of every SIMD (122 VGPRs x 4 waves), so the copy's waves
+// only get in at a chunk's tail, and every chunk adds the ramp and tail of five persistent launches (one per bin).  Kept
+// as an option for matrices whose columns sit in one bin; off by default (profiles/r03_ablation.md, section 2).
+// Every non-empty column is in a hash bin (the caller checks).  bin / colid / hprod / count as multiply_device made them.
+static hipStream_t g_sg_stream = nullptr;
+#ifndef SG_OVERLAP_CAP
+#define SG_OVERLAP_CAP 4
+#endif
+
+static int multiply_chunked(const Csc *A, const Csc *B, Csc *C, bool values, const uint32_t *bin, const uint32_t *colid,
+                            const int32_t *hprod, unsigned long long P, int32_t *count) {
+    hipStream_t s = ctx().stream;
+    const int32_t n = B->n;
+    const size_t per = values ? 12 : 4;
+    int64_t nchunks = std::max(2, std::min(ctx().opt.spgemm_chunks, 64));   // opt-in (spgemm.chunks >= 2)
+    nchunks = std::min<int64_t>(nchunks, std::max<int64_t>(2, n / 2048));
+    const int32_t chunk_cols = (int32_t)(((int64_t)n + nchunks - 1) / nchunks);
+    nchunks = ((int64_t)n + chunk_cols - 1) / chunk_cols;
+    if (!g_sg_stream) CSX_HIP(hipStreamCreateWithFlags(&g_sg_stream, hipStreamNonBlocking));
+    DevScope tmp;
+    int32_t *toff = nullptr, *ptr_d = nullptr, *tmp_i = nullptr;
+    uint32_t *key = nullptr, *skey = nullptr, *scol = nullptr;
+    int4 *info = nullptr;
+    double *tmp_x = nullptr;
+    unsigned long long *base = nullptr;
+    CSX_TRY(tmp.alloc(&toff, (size_t)n + 1));
+    CSX_TRY(tmp.alloc(&key, (size_t)n));
+    CSX_TRY(tmp.alloc(&skey, (size_t)n));
+    CSX_TRY(tmp.alloc(&scol, (size_t)n));
+    CSX_TRY(tmp.alloc(&info, (size_t)n));
+    CSX_TRY(tmp.alloc(&base, 2));
+    const int32_t nkeys = (int32_t)nchunks * SG_NBINS;
+    CSX_TRY(tmp.alloc(&ptr_d, (size_t)nkeys + 1));
+    int64_t tot = 0;
+    CSX_TRY(scan_exclusive_i32(hprod, toff, n, &tot));
+    hipLaunchKernelGGL(k_sg_chunk_key, dim3((unsigned)(((int64_t)n + 255) / 256)), dim3(256), 0, s, n, chunk_cols, bin, key);
+    CSX_TRY(stable_sort_by_key(key, colid, nullptr, n, (uint32_t)nkeys, skey, scol, nullptr));
+    CSX_TRY(boundaries_from_sorted(skey, n, nkeys, ptr_d));
+    std::vector<int32_t> ptr((size_t)nkeys + 1);
+    CSX_HIP(hipMemcpyAsync(ptr.data(), ptr_d, ptr.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    CSX_HIP(hipMemsetAsync(base, 0, 2 * sizeof(unsigned long long), s));
+    CSX_TRY(tmp.alloc(&tmp_i, (size_t)P));
+    if (values) CSX_TRY(tmp.alloc(&tmp_x, (size_t)P));
+    hipLaunchKernelGGL(k_sg_colinfo, dim3((unsigned)(((int64_t)n + 255) / 256)), dim3(256), 0, s, scol, n, B->p, toff, info);
+    // C.i / C.x for the upper bound (one entry per product); C.p is written chunk by chunk
+    int32_t *Ci = nullptr;
+    double *Cx = nullptr;
+    CSX_TRY(dalloc(&Ci, (size_t)P));
+    C->i = Ci;
+    if (values) {
+        CSX_TRY(dalloc(&Cx, (size_t)P));
+        C->x = Cx;
+    }
+    CSX_HIP(hipStreamSynchronize(s));
+    std::vector<hipEvent_t> ev((size_t)nchunks, nullptr);
+    hipEvent_t done = nullptr;
+    int st = CSX_OK;
+    for (auto &e : ev)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) st = CSX_ERUNTIME;
+    if (hipEventCreateWithFlags(&done, hipEventDisableTiming) != hipSuccess) st = CSX_ERUNTIME;
+    for (int64_t c = 0; c < nchunks && st == CSX_OK; c++) {
+        const int32_t *pc = ptr.data() + c * SG_NBINS;
+        for (int hb = 0; hb < SG_HASH_BINS && st == CSX_OK; hb++) {
+            const int32_t lo = pc[SG_BIN_HASH0 + hb], nb = pc[SG_BIN_HASH0 + hb + 1] - lo;
+            const int slots = sg_hash_limit(hb) * 3 / 2;
+            st = values ? launch_hash1<true>(slots, A, B, info + lo, nb, count, tmp_i, tmp_x, SG_OVERLAP_CAP)
+                        : launch_hash1<false>(slots, A, B, info + lo, nb, count, tmp_i, nullptr, SG_OVERLAP_CAP);
+        }
+        for (int hb = 0; hb < SG_NARROW_BINS && st == CSX_OK; hb++) {
+            const int32_t lo = pc[SG_BIN_NARROW0 + hb], nb = pc[SG_BIN_NARROW0 + hb + 1] - lo;
+            const int slots = sg_hash_limit(hb) * 3 / 2;
+            st = values ? launch_hash2<true>(slots, A, B, info + lo, nb, count, tmp_i, tmp_x, SG_OVERLAP_CAP)
+                        : launch_hash2<false>(slots, A, B, info + lo, nb, count, tmp_i, nullptr, SG_OVERLAP_CAP);
+        }
+        if (st != CSX_OK) break;
+        const int32_t c0 = (int32_t)(c * chunk_cols), c1 = (int32_t)std::min<int64_t>(n, (c + 1) * (int64_t)chunk_cols);
+        st = scan_exclusive_i32(count + c0, C->p + c0, c1 - c0, nullptr);
+        if (st != CSX_OK) break;
+        hipLaunchKernelGGL(k_sg_add_base, dim3((unsigned)((c1 - c0 + 256) / 256)), dim3(256), 0, s, C->p, c0, c1, base, (int)(c & 1));
+        if (hipEventRecord(ev[(size_t)c], s) != hipSuccess || hipStreamWaitEvent(g_sg_stream, ev[(size_t)c], 0) != hipSuccess) {
+            st = CSX_ERUNTIME;
+            break;
+        }
+        const int32_t lo = pc[SG_BIN_HASH0], nh = pc[SG_BIN_NARROW0 + SG_NARROW_BINS] - lo;
+        if (nh > 0)
+            hipLaunchKernelGGL(k_sg_compact, dim3((unsigned)(((int64_t)nh + 3) / 4)), dim3(256), 0, g_sg_stream, scol + lo, nh, toff,
+                               C->p, tmp_i, tmp_x, Ci, Cx);
+    }
+    // the context's stream continues behind the last copy (and nothing is freed before it has finished)
+    if (hipEventRecord(done, g_sg_stream) != hipSuccess || hipStreamWaitEvent(s, done, 0) != hipSuccess) st = CSX_ERUNTIME;
+    unsigned long long total = 0;
+    if (hipMemcpyAsync(&total, base + (nchunks & 1), sizeof total, hipMemcpyDeviceToHost, s) != hipSuccess) st = CSX_ERUNTIME;
+    if (hipStreamSynchronize(g_sg_stream) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) st = CSX_ERUNTIME;
+    for (auto &e : ev)
+        if (e) (void)hipEventDestroy(e);
+    if (done) (void)hipEventDestroy(done);
+    if (st == CSX_OK && hipGetLastError() != hipSuccess) st = CSX_ERUNTIME;
+    CSX_TRY(st);
+    if (total > 0x7FFFFFFFull) {
+        set_error("cs_multiply: the product has %llu entries (int32 indices)", total);
+        return CSX_EINVAL;
+    }
+    C->nnz = (int32_t)total;
+    // Much of the capacity unused (many products per entry): move to arrays of the exact size, as cs_sprealloc(C, 0) does
+    if ((P - total) * per > ((size_t)256 << 20) && P > total + total / 4) {
+        int32_t *Ci2 = nullptr;
+        double *Cx2 = nullptr;
+        CSX_TRY(dalloc(&Ci2, (size_t)total));
+        CSX_HIP(hipMemcpyAsync(Ci2, Ci, (size_t)total * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+        if (values) {
+            CSX_TRY(dalloc(&Cx2, (size_t)total));
+            CSX_HIP(hipMemcpyAsync(Cx2, Cx, (size_t)total * sizeof(double), hipMemcpyDeviceToDevice, s));
+        }
+        CSX_HIP(hipStreamSynchronize(s));
+        dfree(Ci);
+        dfree(Cx);
+        C->i = Ci2;
+        C->x = Cx2;
+    }
+    return CSX_OK;
+}
+
+// ---- opt-in: C.x in the reference's summation order (spgemm.ordered) ---------------------------------------------------
+// cs_scatter adds the products of an entry in the order it meets them (csparse.py:1979-1988): B(:,j) in storage order,
+// inside it A(:,k) in storage order; the first product is ASSIGNED (x[i] = beta * Ax[p]), the later ones added, each
+// product and each sum rounded on its own.  The hash kernels add with LDS atomics in arrival order, so their x differs
+// from the reference's in the last bits and from run to run.  This pass recomputes x from the finished pattern in
+// exactly the reference's order: one wave per column of C walks the products in order, one entry of B(:,j) at a time
+// (its A column's entries one per lane); the products of one such batch go to distinct rows unless A(:,k) holds a row
+// twice, and then the lanes of equal rows take their turns in lane order.  A row's position in C(:,j) comes from a hash
+// map in LDS (columns of at most SGO_MAX entries, sums in LDS too) or from a dense map in memory (longer columns, sums
+// straight into C.x).  Bit-identical to the oracle (tests/test_gpu_multiply.py); several times slower than the atomics.
+constexpr int SGO_MAX = 2048, SGO_SLOTS = 4096;
+
+__device__ __forceinline__ int sgo_rank_of_equal_rows(int32_t row, bool active, int lane, int *rounds) {
+    // number of earlier active lanes holding the same row; *rounds = 1 + the largest such number in the wave
+    int before = 0;
+    for (int u = 0; u < 63; u++) {
+        const int32_t ru = __builtin_amdgcn_readlane(row, u);
+        const bool au = ((__ballot(active) >> u) & 1ull) != 0;
+        if (au && active && lane > u && ru == row) before++;
+    }
+    int mx = before;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) mx = max(mx, __shfl_xor(mx, d, 64));
+    *rounds = mx + 1;
+    return before;
+}
+
+template <bool BIG>
+__global__ __launch_bounds__(64) void k_sg_values_ordered(int32_t n, int32_t m, const int32_t *__restrict__ Ap,
+                                                          const int32_t *__restrict__ Ai, const double *__restrict__ Ax,
+                                                          const int32_t *__restrict__ Bp, const int32_t *__restrict__ Bi,
+                                                          const double *__restrict__ Bx, const int32_t *__restrict__ Cp,
+                                                          const int32_t *__restrict__ Ci, double *__restrict__ Cx,
+                                                          int32_t *__restrict__ gmap) {
+#pragma clang fp contract(off)
+    __shared__ int32_t hkey[BIG ? 1 : SGO_SLOTS];
+    __shared__ int32_t hpos[BIG ? 1 : SGO_SLOTS];
+    __shared__ double acc[BIG ? 1 : SGO_MAX];
+    __shared__ unsigned long long seen[BIG ? 1 : SGO_MAX / 64];
+    const int lane = threadIdx.x;
+    int32_t *map = BIG ? gmap + (int64_t)blockIdx.x * m : nullptr;
+    for (int32_t j = blockIdx.x; j < n; j += gridDim.x) {
+        const int32_t c0 = Cp[j], cnt = Cp[j + 1] - c0;
+        if (cnt == 0 || (cnt > SGO_MAX) != BIG) continue;
+        // the map row -> position in C(:,j)
+        if (!BIG) {
+            for (int s = lane; s < SGO_SLOTS; s += 64) hkey[s] = -1;
+            for (int s = lane; s < SGO_MAX / 64; s += 64) seen[s] = 0ull;
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            for (int32_t q = lane; q < cnt; q += 64) {
+                const int32_t row = Ci[c0 + q];
+                uint32_t s = (uint32_t)(row * 0x9E3779B1u) >> 20;      // 12 bits
+                for (;;) {
+                    const int32_t prev = atomicCAS(&hkey[s], -1, row);
+                    if (prev == -1) break;
+                    s = (s + 1) & (SGO_SLOTS - 1);
+                }
+                hpos[s] = q;
+            }
+        } else {
+            // dense map in memory: row -> cnt + position until the position is first touched, then the position
+            for (int32_t q = lane; q < cnt; q += 64) {
+                map[Ci[c0 + q]] = cnt + q;
+                Cx[c0 + q] = 0.0;
+            }
+            __threadfence_block();
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        for (int32_t pb = Bp[j]; pb < Bp[j + 1]; pb++) {           // B(:,j) in storage order
+            const int32_t k = Bi[pb];
+            const double beta = Bx[pb];
+            for (int32_t a0 = Ap[k]; a0 < Ap[k + 1]; a0 += 64) {   // A(:,k) in storage order, 64 entries at a time
+                const int32_t q = a0 + lane;
+                const bool active = q < Ap[k + 1];
+                const int32_t row = active ? Ai[q] : -1;
+                const double prod = active ? beta * Ax[q] : 0.0;
+                int rounds = 1;
+                const int before = sgo_rank_of_equal_rows(row, active, lane, &rounds);
+                int32_t pos = 0;
+                if (active && !BIG) {
+                    uint32_t s = (uint32_t)(row * 0x9E3779B1u) >> 20;
+                    while (hkey[s] != row) s = (s + 1) & (SGO_SLOTS - 1);
+                    pos = hpos[s];
+                }
+                for (int r = 0; r < rounds; r++) {
+                    if (active && before == r) {
+                        if (!BIG) {
+                            const unsigned long long bit = 1ull << (pos & 63);
+                            if (seen[pos >> 6] & bit) acc[pos] = acc[pos] + prod;
+                            else {
+                                acc[pos] = prod;                   // the first product is assigned (csparse.py:1986)
+                                atomicOr(&seen[pos >> 6], bit);
+                            }
+                        } else {
+                            const int32_t v = map[row];
+                            if (v >= cnt) {                        // first touch of this position
+                                Cx[c0 + v - cnt] = prod;
+                                map[row] = v - cnt;
+                            } else {
+                                Cx[c0 + v] = Cx[c0 + v] + prod;
+                            }
+                        }
+                    }
+                    if (BIG) __threadfence_block();
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
+        if (!BIG) {
+            for (int32_t q = lane; q < cnt; q += 64) Cx[c0 + q] = acc[q];
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+__global__ void k_sg_any_long(int32_t n, const int32_t *__restrict__ Cp, int *flag) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n && Cp[j + 1] - Cp[j] > SGO_MAX) atomicOr(flag, 1);
+}
+
+static int values_in_reference_order(const Csc *A, const Csc *B, Csc *C) {
+    if (!C->x || C->nnz == 0) return CSX_OK;
+    hipStream_t s = ctx().stream;
+    const int32_t n = C->n, m = C->m;
+    DevScope tmp;
+    int *flag = nullptr, h = 0;
+    CSX_TRY(tmp.alloc(&flag, 1));
+    CSX_HIP(hipMemsetAsync(flag, 0, sizeof(int), s));
+    hipLaunchKernelGGL(k_sg_any_long, dim3((unsigned)(((int64_t)n + 255) / 256)), dim3(256), 0, s, n, C->p, flag);
+    CSX_HIP(hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    const int64_t grid = std::min<int64_t>(n, (int64_t)ctx().cus * 16);
+    hipLaunchKernelGGL(k_sg_values_ordered<false>, dim3((unsigned)grid), dim3(64), 0, s, n, m, A->p, A->i, A->x, B->p, B->i, B->x,
+                       C->p, C->i, C->x, (int32_t *)nullptr);
+    CSX_HIP(hipStreamSynchronize(s));
+    if (h) {
+        const int64_t waves = std::min<int64_t>(n, 128);
+        int32_t *gmap = nullptr;
+        CSX_TRY(tmp.alloc(&gmap, (size_t)waves * (size_t)m));
+        hipLaunchKernelGGL(k_sg_values_ordered<true>, dim3((unsigned)waves), dim3(64), 0, s, n, m, A->p, A->i, A->x, B->p, B->i, B->x,
+                           C->p, C->i, C->x, gmap);
+        CSX_HIP(hipStreamSynchronize(s));
+    }
+    CSX_LAUNCH_CHECK();
     return CSX_OK;
 }
 
@@ -981,6 +1276,19 @@ int multiply_device(const Csc *A, const Csc *B, Csc *C) {
         size_t idle_b = 0;
         pool_stats(&idle_b, nullptr);   // idle blocks of the caching allocator are reusable
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need < (free_b + idle_b) / 3) onepass = true;
+    }
+    // all non-empty columns hashed, and a product-order buffer far bigger than the Infinity Cache: take the columns in chunks
+    const bool chunked = st == CSX_OK && onepass && ctx().opt.spgemm_chunks > 1 &&
+                         bin_ptr[SG_BIN_DENSE + 1] == bin_ptr[SG_BIN_DENSE] && bin_ptr[SG_BIN_GLOBAL + 1] == bin_ptr[SG_BIN_GLOBAL] &&
+                         n >= 4096 &&
+                         big[1] * (values ? 24 : 8) < (size_t)0x7FFFFFF0ull * 24;
+    if (chunked) {
+        st = multiply_chunked(A, B, C, values, bin, colid, hprod, big[1], count);
+        if (st == CSX_OK && hipStreamSynchronize(s) != hipSuccess) st = CSX_ERUNTIME;
+        for (void *q : {(void *)hprod, (void *)bin, (void *)colid, (void *)sbin, (void *)scol, (void *)bin_ptr_d, (void *)count,
+                        (void *)too_big})
+            dfree(q);
+        return st;
     }
     if (st == CSX_OK && onepass) {
         st = dalloc(&toff, (size_t)n + 1);
@@ -1069,6 +1377,7 @@ extern "C" int csx_multiply(csx_handle_t hA, csx_handle_t hB, csx_handle_t *out)
     if (!A || !B || !out || A->n != B->m) return CSX_EINVAL;
     Csc *C = new Csc();
     int st = multiply_device(A, B, C);
+    if (st == CSX_OK && ctx().opt.spgemm_ordered) st = values_in_reference_order(A, B, C);
     if (st != CSX_OK) {
         free_csc(C);
         return st;

@@ -1186,7 +1186,7 @@ __global__ __launch_bounds__(1024) void k_tri_levels_rows_one_wg(const int32_t *
 // 64 right-hand sides of ONE row: the row's indices and values are uniform (scalar loads), a term's x values are one
 // coalesced 512-byte row of X, and a chunk of 16 terms is 16 independent loads per lane with the next chunk behind it.
 // Same subtractions in the same order as solve_one: same bits.
-constexpr int TR64_MIN_RHS = 16;
+constexpr int TR64_MIN_RHS = 5;    // 5 .. 15 right-hand sides: the same kernel with idle lanes beats a thread per (row, right-hand side) on long rows (700 x 700 grid, order 1, 8 right-hand sides: 730 -> ~35 ms)
 
 // The chain of one (row, 64 right-hand sides).  A row's terms are fetched 64 at a time, one per lane (coalesced, the
 // next 64 requested before these are used), and handed round by v_readlane: a term's source index becomes a scalar

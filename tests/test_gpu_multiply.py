@@ -176,3 +176,74 @@ def test_multiply_narrow_columns_one_pass_kernel(cs):
     A0.x = None
     C0 = cs.cs_multiply(A0, B0)
     assert C0.x is None and C0.p == Cp.tolist() and C0.i[:int(Cp[-1])] == Ci.tolist()
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_multiply_values_in_reference_order_are_bit_identical(cs, name, meta):
+    """csx_set_option("spgemm.ordered", 1): after the pattern, C.x is recomputed with every entry's products added in
+    the reference's order (csparse.py:1979-1988: first product assigned, later ones added as met, each rounded on its
+    own).  The digests are those of the UNMODIFIED reference's cs_multiply (oracle/gen_golden.py)."""
+    import _csx
+    g = golden(name)
+    A, AT = unpack(cs, g, "A"), unpack(cs, g, "AT")
+    with _csx.option("spgemm.ordered", 1):
+        C = cs.cs_multiply(A, AT)
+        C2 = cs.cs_multiply(A, AT)
+    mm = meta[name]["AAT"]
+    nnz = C.p[C.n]
+    assert sha(C.p, np.int64) == mm["sha_p"] and sha(C.i[:nnz], np.int64) == mm["sha_i"]
+    assert sha(C.x[:nnz], np.float64) == mm["sha_x"]
+    assert C.x == C2.x
+    if name in SMALL:
+        same_csc(C, g, "AAT", exact_x=True)
+
+
+def test_multiply_reference_order_on_duplicates_hash_paths_and_a_long_column(cs):
+    import _csx
+    with _csx.option("spgemm.ordered", 1):
+        g = golden("synthetic_20240601")            # duplicate rows inside columns of A and B, empty columns, cancellation
+        for c, (m, n, nnz) in enumerate(g["cases"]):
+            pre = "c%d_" % c
+            A, AT = unpack(cs, g, pre + "A"), unpack(cs, g, pre + "AT")
+            same_csc(cs.cs_multiply(A, AT), g, pre + "AAT", exact_x=True)
+            same_csc(cs.cs_multiply(AT, A), g, pre + "ATA", exact_x=True)
+        # LDS hash kernels (m > 8192), against the plain-C oracle bit for bit
+        n = 20000
+        Ap, Ai, Ax = synth.grand(n, 32, 31)
+        Ax = Ax - 1.0                                # mixed signs: sums that cancel expose the order
+        Tp, Ti, Tx = CO.transpose(n, n, Ap, Ai, Ax)
+        Cp, Ci, Cx = CO.multiply(n, n, n, Ap, Ai, Ax, Tp, Ti, Tx)
+        C = cs.cs_multiply(_host_cs(cs, n, n, Ap, Ai, Ax), _host_cs(cs, n, n, Tp, Ti, Tx))
+        assert C.p == Cp.tolist() and C.i[:Cp[-1]] == Ci.tolist()
+        assert np.asarray(C.x[:Cp[-1]]).tobytes() == Cx.tobytes()
+        # one column with 24 000 products and ~16 000 distinct rows: the dense map in memory
+        n = 30000
+        Ap, Ai, Ax = synth.grand(n, 8, 77)
+        Ax = Ax - 1.0
+        rng = np.random.default_rng(1)
+        sel = np.sort(rng.choice(n, 3000, replace=False)).astype(np.int32)
+        rest = rng.integers(0, n, size=(n - 1) * 2).astype(np.int32)
+        Bi = np.concatenate([sel, rest])
+        Bp = np.concatenate([[0], 3000 + 2 * np.arange(n)]).astype(np.int32)
+        Bx = rng.uniform(-1.5, 1.5, len(Bi))
+        Cp, Ci, Cx = CO.multiply(n, n, n, Ap, Ai, Ax, Bp, Bi, Bx)
+        assert Cp[1] - Cp[0] > 2048
+        C = cs.cs_multiply(_host_cs(cs, n, n, Ap, Ai, Ax), _host_cs(cs, n, n, Bp, Bi, Bx))
+        assert C.p == Cp.tolist() and C.i[:Cp[-1]] == Ci.tolist()
+        assert np.asarray(C.x[:Cp[-1]]).tobytes() == Cx.tobytes()
+
+
+def test_multiply_in_column_chunks_gives_the_same_matrix(cs):
+    """spgemm.chunks >= 2 (opt-in): columns hashed in ascending chunks, each chunk compacted on a second stream behind the
+    previous one's end; C.p / C.i must be what the unchunked path gives, C.x equal to rounding."""
+    import _csx
+    n = 40000
+    Ap, Ai, Ax = synth.grand(n, 24, 5)
+    Tp, Ti, Tx = CO.transpose(n, n, Ap, Ai, Ax)
+    A, AT = cs.cs_pin(_host_cs(cs, n, n, Ap, Ai, Ax)), cs.cs_pin(_host_cs(cs, n, n, Tp, Ti, Tx))
+    C0 = cs.cs_multiply(A, AT)
+    for chunks in (2, 7):
+        with _csx.option("spgemm.chunks", chunks):
+            C1 = cs.cs_multiply(A, AT)
+        assert C1.p == C0.p and C1.i == C0.i and C1.nzmax == C0.nzmax
+        assert np.max(np.abs(np.asarray(C1.x) - np.asarray(C0.x)) / np.abs(np.asarray(C0.x))) < 1e-13
