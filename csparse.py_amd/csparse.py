@@ -814,10 +814,27 @@ def _pattern_np(A):
 
 
 def _amd_np(order, A):
-    if not CS_CSC(A) or order != 1 or A.m != A.n:
+    """Permutation (int32 array of n entries) for order 1 (A + A', square A), 2 (S'S with S = A less its dense rows) or
+    3 (A'A), or None: a nested dissection of that graph (csx_order_nd_host)."""
+    if not CS_CSC(A) or order not in (1, 2, 3):
         return None
     n = A.n
-    p, i = _pattern_np(A)
+    if order == 1 and A.m == n:
+        p, i = _pattern_np(A)                                   # the graph of A + A' is formed by the ordering itself
+    else:
+        # the pattern of A'A (csparse.py:236-256); order 2 first drops the dense rows of A (columns of A')
+        Ap, Ai = _pattern_np(A)
+        m = A.m
+        P = cs_spalloc(m, n, max(len(Ai), 1), False, False)
+        P.p, P.i, P.x = Ap.tolist(), Ai.tolist() if len(Ai) else [0], None
+        AT = cs_transpose(P, False)
+        if order == 2:
+            dense = min(n - 2, max(16, int(10 * sqrt(n))))
+            cs_fkeep(AT, lambda i, j, a, cnt: cnt[j] <= dense, np.diff(np.asarray(AT.p)).tolist())
+        C = cs_multiply(AT, P)
+        if C is None:
+            return None
+        p, i = _csx.i32(C.p[:n + 1]), _csx.i32(C.i[:C.p[n]])
     perm = np.empty(max(n, 1), dtype=np.int32)
     if _csx.load().csx_order_nd_host(n, _csx.pi(p), _csx.pi(i), _csx.pi(perm)) != _csx.OK:
         return None
@@ -825,10 +842,11 @@ def _amd_np(order, A):
 
 
 def cs_amd(order, A):
-    """Fill-reducing ordering p (csparse.py:214-556), order 1 = for Cholesky of A (pattern of A + A').
-    The reference's implementation does not run, so there is no permutation to match:
-    this is a nested dissection, which gives the device a bushy elimination tree.  Orders 2 and 3
-    (LU / QR, pattern of A'A) are not provided: None."""
+    """Fill-reducing ordering p (csparse.py:214-556): order 1 = for Cholesky / LU of a matrix with a symmetric pattern
+    (graph of A + A'), 2 = for LU (graph of S'S, S = A without its dense rows), 3 = for QR (graph of A'A).
+    The reference's implementation does not run, so there is no permutation to match: this is a nested
+    dissection of the same graphs (breadth-first level separators, host C++), which gives the device a bushy
+    elimination tree.  None for order 0 or bad input, like the reference."""
     perm = _amd_np(order, A)
     return None if perm is None else perm.tolist()
 
@@ -1104,18 +1122,6 @@ def cholsol_factor(A, order=0, exact=True):
 
 # -------------------------------------------------------------------- LU ----
 
-def cs_sqr(order, A, qr):
-    """Symbolic analysis for LU (csparse.py:2187-2217): natural ordering only, with the
-    reference's size guesses.  QR analysis is outside the hot path."""
-    if not CS_CSC(A) or order != 0 or qr:
-        return None
-    S = css()
-    S.q = None
-    S.pinv = None
-    S.unz = S.lnz = 4 * A.p[A.n] + A.n
-    return S
-
-
 def _cs_from_arrays(m, n, p, i, x):
     C = cs_spalloc(m, n, len(i), True, False)
     C.p, C.i, C.x = p, i if i else [0], x if x else [0.0]
@@ -1134,6 +1140,11 @@ def cs_lu(A, S, tol):
     n = A.n
     if A.m != n:
         raise IndexError("list index out of range")
+    if S.q is not None:
+        # column k of the factorisation is column q[k] of A (csparse.py:1405): the same as factoring A Q in natural order
+        Sq = css()
+        Sq.q, Sq.pinv, Sq.lnz, Sq.unz = None, None, S.lnz, S.unz
+        return cs_lu(cs_permute(A, None, S.q, True), Sq, tol)
     if n >= 4096 or A._dev is not None:
         # a batch of small independent blocks (block-diagonal up to a symmetric permutation) factors on the device,
         # one workgroup per block; anything else comes back with done = 0 and takes the host code below
@@ -1253,22 +1264,26 @@ def cs_post(parent, n):
     return post
 
 
-def cs_sqr(order, A, qr):  # noqa: F811  (extends the LU-only version above)
-    """Symbolic ordering and analysis for QR or LU (csparse.py:2187-2217), natural ordering."""
-    if not CS_CSC(A) or order != 0:
+def cs_sqr(order, A, qr):
+    """Symbolic ordering and analysis for QR or LU (csparse.py:2187-2217).  order 0 natural, 1 / 2 / 3 as cs_amd.
+    LU: only the column ordering S.q and the reference's size guesses.  QR: the column elimination tree, the column
+    counts of R and cs_vcount (leftmost, pinv, m2, entries of V) of A Q, in host C++ (csx_sqr_host)."""
+    if not CS_CSC(A) or order not in (0, 1, 2, 3):
         return None
     n = A.n
     S = css()
-    S.q = None
+    S.q = cs_amd(order, A)
+    if order and S.q is None:
+        return None
     S.pinv = None
     if not qr:
-        S.unz = S.lnz = 4 * A.p[n] + n
+        S.unz = S.lnz = 4 * _meta(A)[0] + n
         return S
-    # column elimination tree, column counts of R, cs_vcount (leftmost, pinv, m2, nnz V): host C++ (csx_sqr_host)
     m = A.m
-    Ap = _csx.i32(A.p[:n + 1])
+    C = cs_permute(A, None, S.q, False) if order else A
+    Ap = _csx.i32(C.p[:n + 1])
     nnz = int(Ap[n])
-    Ai = _csx.i32(A.i[:nnz]) if nnz else np.zeros(1, np.int32)
+    Ai = _csx.i32(C.i[:nnz]) if nnz else np.zeros(1, np.int32)
     parent, cp = np.empty(max(n, 1), np.int32), np.empty(max(n, 1), np.int32)
     pinv, leftmost = np.empty(max(m + n, 1), np.int32), np.empty(max(m, 1), np.int32)
     m2, vnz, rnz = _csx.C.c_int32(0), _csx.C.c_int64(0), _csx.C.c_int64(0)
@@ -1437,7 +1452,7 @@ def apply_q(N, X, transpose=True):
 
 def qrsol_factor(A, order=0):
     """Factor once (cs_sqr + cs_qr on the host), solve least-squares problems min ||A x - b|| for blocks of right-hand
-    sides on the device: the solve sequence of cs_qrsol for m >= n (csparse.py:1893-1898) -- x = P b, Q' x, R \ x,
+    sides on the device: the solve sequence of cs_qrsol for m >= n (csparse.py:1893-1898) -- x = P b, Q' x, solve R x,
     x(q) -- as csx_permute_vec, csx_happly, csx_tri_solve.  solve(B): B a dvec m-by-k block or a list of m entries;
     returns the n-by-k solutions as a new dvec (or overwrites the list's first n entries, like cs_qrsol).  Every column
     is bit-identical to cs_qrsol on that column."""

@@ -1195,25 +1195,40 @@ __global__ __launch_bounds__(256) void k_cholsol_dense(const Tree *__restrict__ 
 // to cs_lsolve + cs_ltsolve for every right-hand side; the fused per-tree kernel it replaces on dense forests took
 // 24.8 ms per 128 right-hand sides on the 5M-row G-spd.
 #pragma clang fp contract(off)
-template <int BS, bool BACKWARD>
-__device__ __forceinline__ void dense_exact_pass(double (&x)[BS], const double *M, const double *D) {
+// R right-hand sides per lane: the R subtraction chains of a row are independent, so they fill each other's latency, and one
+// broadcast of an L value serves R products (the broadcast -- LDS return path -- and the two separately rounded fp64
+// operations per term are what bound this kernel: 4 + 4 cycles of issue per term and right-hand side).
+template <int BS, bool BACKWARD, int R>
+__device__ __forceinline__ void dense_exact_pass(double (&x)[R][BS], const double *M, const double *D) {
 #pragma unroll
     for (int sp = 0; sp < BS; sp++) {
-        double acc = x[sp];
+        double acc[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) acc[r] = x[r][sp];
         if (!BACKWARD) {
 #pragma unroll
             for (int tt = 0; tt < sp; tt++) {
-                const double t = M[sp * (sp - 1) / 2 + tt] * x[tt];
-                acc = acc - t;
+                const double mv = M[sp * (sp - 1) / 2 + tt];
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const double t = mv * x[r][tt];
+                    acc[r] = acc[r] - t;
+                }
             }
         } else {
 #pragma unroll
             for (int tt = sp - 1; tt >= 0; tt--) {
-                const double t = M[sp * (sp - 1) / 2 + tt] * x[tt];
-                acc = acc - t;
+                const double mv = M[sp * (sp - 1) / 2 + tt];
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const double t = mv * x[r][tt];
+                    acc[r] = acc[r] - t;
+                }
             }
         }
-        x[sp] = acc / D[sp];
+        const double dv = D[sp];
+#pragma unroll
+        for (int r = 0; r < R; r++) x[r][sp] = acc[r] / dv;
         // without a fence the optimiser hoists every row's LDS reads to the top of the pass (they depend on nothing):
         // 512 VGPRs and spills at BS = 32, 292 VGPRs at BS = 64
         asm volatile("" ::: "memory");
@@ -1222,9 +1237,10 @@ __device__ __forceinline__ void dense_exact_pass(double (&x)[BS], const double *
 }
 
 // second launch-bound argument = waves per SIMD the register allocation must leave room for: without it the
-// scheduler spends 284-512 VGPRs on hoisted loads (one wave per SIMD, spills at BS = 32)
-template <int BS>
-__global__ __launch_bounds__(256, 2) void k_cholsol_dense_exact(const Tree *__restrict__ trees, int32_t ntrees,
+// scheduler spends 284-512 VGPRs on hoisted loads (one wave per SIMD, spills at BS = 32).  R = 2 (two right-hand sides
+// per lane, a task = a block x 128 right-hand sides): one wave per SIMD, 2 x BS unknowns in registers.
+template <int BS, int R>
+__global__ __launch_bounds__(256, (R == 1 ? 2 : 1)) void k_cholsol_dense_exact(const Tree *__restrict__ trees, int32_t ntrees,
                                                              const int32_t *__restrict__ nodes,
                                                              const int32_t *__restrict__ perm,
                                                              const int32_t *__restrict__ f_ptr,
@@ -1240,23 +1256,29 @@ __global__ __launch_bounds__(256, 2) void k_cholsol_dense_exact(const Tree *__re
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t task = (int64_t)blockIdx.x * 4 + w;
-    if (task >= (int64_t)ntrees * chunks) return;
+    if (task >= (int64_t)ntrees * chunks) return;          // chunks: groups of 64 R right-hand sides
     const int32_t t = (int32_t)(task / chunks), h = (int32_t)(task % chunks);
     const int32_t first = trees[t].first;
-    const int32_t rhs = h * 64 + lane;
-    const bool live = rhs < nrhs;
+    int32_t rhs[R], rhs_ld[R];
+    bool live[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        rhs[r] = (h * R + r) * 64 + lane;
+        live[r] = rhs[r] < nrhs;
+        rhs_ld[r] = live[r] ? rhs[r] : nrhs - 1;
+    }
     double *M = s_m[w], *DG = s_m[w] + NT;   // DG overlaps the DMA overrun and is written after it
     int32_t jrow = 0;
     if (lane < BS) {
         jrow = nodes[first + lane];
         if (perm) jrow = perm[jrow];
     }
-    const int32_t rhs_ld = live ? rhs : nrhs - 1;
-    double x[BS];
+    double x[R][BS];
 #pragma unroll
     for (int a = 0; a < BS; a++) {
         const int32_t row = __builtin_amdgcn_readlane(jrow, a);
-        x[a] = B[(int64_t)row * nrhs + rhs_ld];
+#pragma unroll
+        for (int r = 0; r < R; r++) x[r][a] = B[(int64_t)row * nrhs + rhs_ld[r]];
     }
 #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
@@ -1272,20 +1294,25 @@ __global__ __launch_bounds__(256, 2) void k_cholsol_dense_exact(const Tree *__re
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane < BS) DG[lane] = dv;
         __builtin_amdgcn_wave_barrier();
-        if (pass == 0) dense_exact_pass<BS, false>(x, M, DG);
-        else dense_exact_pass<BS, true>(x, M, DG);
+        if (pass == 0) dense_exact_pass<BS, false, R>(x, M, DG);
+        else dense_exact_pass<BS, true, R>(x, M, DG);
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int a = 0; a < BS / 2; a++) {           // reverse: sweep order of the other pass / back to row order
-            const double tmp = x[a];
-            x[a] = x[BS - 1 - a];
-            x[BS - 1 - a] = tmp;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const double tmp = x[r][a];
+                x[r][a] = x[r][BS - 1 - a];
+                x[r][BS - 1 - a] = tmp;
+            }
         }
     }
 #pragma unroll
     for (int a = 0; a < BS; a++) {
         const int32_t row = __builtin_amdgcn_readlane(jrow, a);
-        if (live) B[(int64_t)row * nrhs + rhs] = x[a];
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            if (live[r]) B[(int64_t)row * nrhs + rhs[r]] = x[r][a];
     }
 }
 #pragma clang fp contract(fast)
@@ -1717,17 +1744,21 @@ static int cholsol_solve(CholPlan *P, double *B, int32_t nrhs) {
         // Forests of dense blocks: the default (exact) order runs the substitution kernel that keeps the reference's
         // operations and their order; the rounding-equal order the FMA / matrix-core kernels.
         if (P->dense_bs && !P->relaxed && ctx().opt.cholsol_dense_blocks) {
-            const int32_t chunks = (nrhs + 63) / 64;
+            // more than 64 right-hand sides and blocks of at most 32: two right-hand sides per lane (independent chains, one
+            // broadcast of L for both).  At 64 the 2 x 64 unknowns alone are the 256 architectural VGPRs: the compiler
+            // spills 361 of them and the kernel is slower than with one right-hand side per lane.
+            const int R = nrhs > 64 && P->dense_bs <= 32 && ctx().opt.cholsol_exact_pairs ? 2 : 1;
+            const int32_t chunks = (nrhs + 64 * R - 1) / (64 * R);
             const int64_t tasks = (int64_t)P->ntrees * chunks;
             const dim3 grid((unsigned)((tasks + 3) / 4));
-#define CSX_DENSE_X(BS)                                                                                             \
-    hipLaunchKernelGGL(k_cholsol_dense_exact<BS>, grid, dim3(256), 0, s, P->trees, P->ntrees, P->tree_nodes, P->perm, \
+#define CSX_DENSE_X(BS, RR)                                                                                                     \
+    hipLaunchKernelGGL((k_cholsol_dense_exact<BS, RR>), grid, dim3(256), 0, s, P->trees, P->ntrees, P->tree_nodes, P->perm,     \
                        P->f_ptr, P->f_val, P->b_ptr, P->dense_b, P->diagk, P->diagb, B, nrhs, chunks)
             switch (P->dense_bs) {
-                case 8: CSX_DENSE_X(8); break;
-                case 16: CSX_DENSE_X(16); break;
-                case 32: CSX_DENSE_X(32); break;
-                default: CSX_DENSE_X(64); break;
+                case 8: if (R == 2) CSX_DENSE_X(8, 2); else CSX_DENSE_X(8, 1); break;
+                case 16: if (R == 2) CSX_DENSE_X(16, 2); else CSX_DENSE_X(16, 1); break;
+                case 32: if (R == 2) CSX_DENSE_X(32, 2); else CSX_DENSE_X(32, 1); break;
+                default: CSX_DENSE_X(64, 1); break;
             }
 #undef CSX_DENSE_X
             CSX_LAUNCH_CHECK();

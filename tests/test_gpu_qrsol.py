@@ -54,7 +54,7 @@ def test_qrsol_error_conventions(cs):
     assert cs.cs_qrsol(0, T, [1.0, 1.0]) is False
     A = cs.cs_spalloc(2, 2, 2, True, False)
     A.p, A.i, A.x = [0, 1, 2], [0, 1], [1.0, 2.0]
-    assert cs.cs_qrsol(0, A, None) is False and cs.cs_qrsol(1, A, [1.0, 1.0]) is False
+    assert cs.cs_qrsol(0, A, None) is False and cs.cs_qrsol(7, A, [1.0, 1.0]) is False
     b = [2.0, 2.0]
     assert cs.cs_qrsol(0, A, b) is True and b == [2.0, 1.0]
 

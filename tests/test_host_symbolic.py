@@ -54,7 +54,7 @@ def test_lu_host_singular_and_bad_input():
     A.p, A.i, A.x = [0, 1, 2], [0, 0], [1.0, 2.0]  # second row empty -> singular
     assert cs.cs_lu(A, cs.cs_sqr(0, A, False), 1.0) is None
     assert cs.cs_lusol(0, A, [1.0, 1.0], 1.0) is False
-    assert cs.cs_lu(A, None, 1.0) is None and cs.cs_sqr(2, A, False) is None
+    assert cs.cs_lu(A, None, 1.0) is None and cs.cs_sqr(4, A, False) is None and cs.cs_sqr(-1, A, True) is None
     T = cs.cs_spalloc(2, 2, 2, True, True)
     assert cs.cs_lusol(0, T, [1.0, 1.0], 1.0) is False and cs.cs_lusol(0, A, None, 1.0) is False
 
