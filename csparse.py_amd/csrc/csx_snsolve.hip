@@ -27,7 +27,7 @@
 // X and one FMA.
 //
 // Equal to the reference to rounding (the sums are regrouped), never used by the exact order; the same bits on every
-// run.  tests/test_gpu_cholesky.py compares with the plain-C oracle at 1e-10 and with the exact order.
+// run.  tests/test_gpu_cholesky.py compares with the plain-C restatement of the reference at 1e-10 and with the exact order.
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>

@@ -1080,7 +1080,7 @@ static int multiply_chunked(const Csc *A, const Csc *B, Csc *C, bool values, con
 // (its A column's entries one per lane); the products of one such batch go to distinct rows unless A(:,k) holds a row
 // twice, and then the lanes of equal rows take their turns in lane order.  A row's position in C(:,j) comes from a hash
 // map in LDS (columns of at most SGO_MAX entries, sums in LDS too) or from a dense map in memory (longer columns, sums
-// straight into C.x).  Bit-identical to the oracle (tests/test_gpu_multiply.py); several times slower than the atomics.
+// straight into C.x).  Bit-identical to the unmodified reference (tests/test_gpu_multiply.py); several times slower than the atomics.
 constexpr int SGO_MAX = 2048, SGO_SLOTS = 4096;
 
 __device__ __forceinline__ int sgo_rank_of_equal_rows(int32_t row, bool active, int lane, int *rounds) {
