@@ -439,10 +439,123 @@ def cholsol_connected(grid=300):
             "results": out}
 
 
+def lu_connected(grid=300, chain_blocks=1493):
+    """cs_lu of ONE connected matrix on the device (csx_lu_etree: columns scheduled by the column elimination tree, one
+    lane per column running the host loop; L, U, pinv bit-identical to the host code):
+      * an unsymmetric grid x grid convection-diffusion matrix in the order-2 column ordering (nested dissection of A'A:
+        a bushy tree) -- device against host C++ on one core;
+      * SURVEY 8d's W-chain stress variant (W's blocks linked into one chain by A(67 b, 67 b - 1) = 1e-3): the column
+        elimination tree is nearly a chain, so the planner keeps it on the host; the device time with the planner
+        overridden ("lu.etree" = 2) is the per-level latency floor the survey asks to be reported, not tuned for."""
+    import ctypes as C_
+    import scipy.sparse as sp
+    import synth
+    out = {}
+
+    def host_lu(n, Ap, Ai, Ax, tol):
+        outp = [C_.POINTER(C_.c_int32)(), C_.POINTER(C_.c_int32)(), C_.POINTER(C_.c_double)(),
+                C_.POINTER(C_.c_int32)(), C_.POINTER(C_.c_int32)(), C_.POINTER(C_.c_double)()]
+        pinv = np.empty(n, np.int32)
+        t0 = time.perf_counter()
+        _csx.check(_csx.load().csx_lu_host(n, _csx.pi(Ap), _csx.pi(Ai), _csx.pd(Ax), tol, *[C_.byref(o) for o in outp], _csx.pi(pinv)))
+        dt = time.perf_counter() - t0
+        Lp = np.ctypeslib.as_array(outp[0], shape=(n + 1,)).copy()
+        Up = np.ctypeslib.as_array(outp[3], shape=(n + 1,)).copy()
+        Lx = np.ctypeslib.as_array(outp[2], shape=(max(Lp[n], 1),))[:Lp[n]].copy()
+        for o in outp:
+            _csx.load().csx_host_free(C_.cast(o, C_.c_void_p))
+        return dt, pinv, Lp, Up, Lx
+
+    def device_lu(Ap, Ai, Ax, tol, force):
+        n = len(Ap) - 1
+        lib = _csx.lib()
+        hA = _csx.new_handle()
+        _csx.check(lib.csx_csc_upload(n, n, _csx.pi(Ap), _csx.pi(Ai), _csx.pd(Ax), hA))
+        best, res = None, None
+        with _csx.option("lu.etree", 2 if force else 1):
+            for rep in range(2):
+                hL, hU, done = _csx.new_handle(), _csx.new_handle(), C_.c_int(0)
+                pinv = np.empty(n, np.int32)
+                _csx.sync()
+                t0 = time.perf_counter()
+                _csx.check(lib.csx_lu_etree(hA, tol, hL, hU, _csx.pi(pinv), done))
+                _csx.sync()
+                dt = time.perf_counter() - t0
+                if not done.value:
+                    _csx.free(hA)
+                    return None
+                best = dt if best is None else min(best, dt)
+                z = C_.c_int32()
+                _csx.check(lib.csx_csc_info(hL, None, None, z, None))
+                lx = np.empty(max(z.value, 1))
+                _csx.check(lib.csx_csc_download(hL, None, None, _csx.pd(lx)))
+                res = (pinv, z.value, lx[:z.value])
+                _csx.free(hL); _csx.free(hU)
+        _csx.free(hA)
+        return best, res
+
+    # unsymmetric grid, order 2
+    g = grid
+    n = g * g
+    T = sp.diags([-1.7, 4.2, -0.3], [-1, 0, 1], shape=(g, g))
+    S2 = sp.diags([-1.3, 0.0, -0.7], [-1, 0, 1], shape=(g, g))
+    A = (sp.kron(sp.identity(g), T) + sp.kron(S2, sp.identity(g))).tocsc(); A.sort_indices()
+    Ah = host_cs(n, n, A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(np.float64))
+    t0 = time.perf_counter(); Sq = cs.cs_sqr(2, Ah, False); t_order = time.perf_counter() - t0
+    AQ = cs.cs_permute(Ah, None, Sq.q, True)
+    Qp, Qi, Qx = np.asarray(AQ.p, np.int32), np.asarray(AQ.i[:AQ.p[n]], np.int32), np.asarray(AQ.x[:AQ.p[n]])
+    dev = device_lu(Qp, Qi, Qx, 1.0, False)
+    r = {"n": n, "nnz": int(Qp[n]), "cs_sqr_order_2_s": round(t_order, 3)}
+    if dev is not None:
+        r.update({"device_cs_lu_s": round(dev[0], 4), "nnz_L": int(dev[1][1])})
+    if not SKIP_CPU:
+        th, pinv_h, Lp_h, Up_h, Lx_h = host_lu(n, Qp, Qi, Qx, 1.0)
+        r.update({"host_cs_lu_s_one_core": round(th, 4), "nnz_L_host": int(Lp_h[n]), "nnz_U_host": int(Up_h[n])})
+        if dev is not None:
+            r["pinv_and_L_values_bit_identical_to_host"] = bool((dev[1][0] == pinv_h).all() and dev[1][2].tobytes() == Lx_h.tobytes())
+    out["unsymmetric_grid_%dx%d_order_2" % (g, g)] = r
+    # W-chain
+    gw = np.load(os.path.join(ROOT, "tests", "golden", "west0067.npz"))
+    bp, bi, bx = gw["C_p"].astype(np.int64), gw["C_i"].astype(np.int64), gw["C_x"]
+    nb, bs = chain_blocks, 67
+    n = nb * bs
+    u = synth.vec(nb, 20240604, 0.0, 1.0)
+    cols = np.diff(bp)
+    link = np.zeros(bs, np.int64); link[bs - 1] = 1
+    per_block = cols + link
+    Ap = np.concatenate([[0], np.cumsum(np.tile(per_block, nb))]).astype(np.int64)
+    Ap[-1] -= 1                                            # the last block has no next one
+    Ai = np.empty(Ap[-1], np.int64); Ax = np.empty(Ap[-1])
+    for c in range(bs):
+        src = slice(bp[c], bp[c + 1])
+        for_b = Ap[np.arange(nb) * bs + c]
+        k = cols[c]
+        idx = for_b[:, None] + np.arange(k)[None, :]
+        Ai[idx] = bi[src][None, :] + (np.arange(nb) * bs)[:, None]
+        Ax[idx] = bx[src][None, :] * (1.0 + 1e-3 * u)[:, None]
+        if c == bs - 1:
+            Ai[for_b[:-1] + k] = (np.arange(nb - 1) + 1) * bs
+            Ax[for_b[:-1] + k] = 1e-3
+    Ap32, Ai32 = Ap.astype(np.int32), Ai.astype(np.int32)
+    r = {"n": n, "nnz": int(Ap32[-1]), "blocks": nb}
+    auto = device_lu(Ap32, Ai32, Ax, 1.0, False)
+    r["planner_keeps_it_on_the_host"] = auto is None
+    forced = device_lu(Ap32, Ai32, Ax, 1.0, True)
+    if forced is not None:
+        r["device_cs_lu_s_planner_overridden"] = round(forced[0], 4)
+    if not SKIP_CPU:
+        th, pinv_h, Lp_h, Up_h, Lx_h = host_lu(n, Ap32, Ai32, Ax, 1.0)
+        r["host_cs_lu_s_one_core"] = round(th, 4)
+        if forced is not None:
+            r["pinv_and_L_values_bit_identical_to_host"] = bool((forced[1][0] == pinv_h).all() and forced[1][2].tobytes() == Lx_h.tobytes())
+    out["W_chain"] = r
+    return {"config": "cs_lu of one connected matrix on the device (column elimination tree schedule)", "results": out}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-spgemm", action="store_true")
-    ap.add_argument("--only", default=None, help="run one section: spmv | lusolve | spgemm | transpose | assembly | connected")
+    ap.add_argument("--only", default=None, help="run one section: spmv | lusolve | spgemm | transpose | assembly | connected | lu")
     ap.add_argument("--skip-transpose", action="store_true")
     ap.add_argument("--skip-cpu", action="store_true", help="no one-core CPU baselines beside the GPU figures")
     a = ap.parse_args()
@@ -463,6 +576,8 @@ def main():
         print(json.dumps(assembly()))
     if want("connected"):
         print(json.dumps(cholsol_connected()))
+    if want("lu"):
+        print(json.dumps(lu_connected()))
 
 
 if __name__ == "__main__":

@@ -81,6 +81,7 @@ _PROTOS = {
                     _i32p, _i32p, _f64p, _i32p, _i32p, _f64p, _f64p],
     "csx_qr_apply_host": [C.c_int32, _i32p, _i32p, _f64p, _f64p, C.c_int, _f64p],
     "csx_lu_blocks": [H, C.c_double, C.POINTER(H), C.POINTER(H), _i32p, C.POINTER(C.c_int)],
+    "csx_lu_etree": [H, C.c_double, C.POINTER(H), C.POINTER(H), _i32p, C.POINTER(C.c_int)],
     "csx_updown": [H, C.c_int, C.c_int32, _i32p, _f64p, _i32p, C.POINTER(C.c_int)],
     "csx_spsolve": [H, H, _i32p, C.c_int, C.c_int, C.POINTER(H)],
     "csx_happly": [H, H, H, C.c_int32, C.c_int],

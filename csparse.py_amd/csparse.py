@@ -1155,6 +1155,14 @@ def cs_lu(A, S, tol):
         if st == _csx.ENOTSPD:
             return None
         _csx.check(st, "csx_lu_blocks")
+        if not done.value:
+            # one connected matrix: columns scheduled by the column elimination tree, a lane per column (csx_lu_etree);
+            # done = 0 again for a chain-like tree, which stays with the host loop
+            with _Resident(A) as dA:
+                st = _csx.lib().csx_lu_etree(dA.handle, float(tol), hL, hU, _csx.pi(pinv), done)
+            if st == _csx.ENOTSPD:
+                return None
+            _csx.check(st, "csx_lu_etree")
         if done.value:
             N = csn()
             N.L = _from_device(hL, lambda nnz: max(nnz, 1))

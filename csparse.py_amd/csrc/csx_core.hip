@@ -549,7 +549,7 @@ const OptSlot kOptSlots[] = {
     {"tri.row_waves", &Options::tri_row_waves, 0},       {"tri.push", &Options::tri_push, 0},
     {"tri.levels_where", &Options::tri_levels_where, 3}, {"tri.supernodes", &Options::tri_supernodes, 0},
     {"spgemm.ordered", &Options::spgemm_ordered, 0},     {"spgemm.chunks", &Options::spgemm_chunks, 4},
-    {"lu.etree", &Options::lu_etree, 0},                 {"cholsol.exact_pairs", &Options::cholsol_exact_pairs, 0},
+    {"lu.etree", &Options::lu_etree, 5},                 {"cholsol.exact_pairs", &Options::cholsol_exact_pairs, 0},
 };
 int normalise(int kind, int value) {
     switch (kind) {
@@ -558,6 +558,7 @@ int normalise(int kind, int value) {
     case 2: return (value == 32 || value == -16 || value == -32) ? value : 16;   // negative: two launches per panel
     case 3: return (value == 1 || value == 2) ? value : 0;
     case 4: return value < 0 ? 0 : (value > 64 ? 64 : value);
+    case 5: return (value == 0 || value == 2) ? value : 1;
     }
     return value;
 }

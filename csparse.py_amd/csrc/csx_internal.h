@@ -141,6 +141,7 @@ struct Options {
                                       // (1 = off, the default: measured slower, profiles/r03_ablation.md section 2)
     int cholsol_exact_pairs = 1;      // exact dense-block cholsol: two right-hand sides per lane when there are more than 64
     int lu_etree = 1;                 // cs_lu of one connected matrix on the device, columns scheduled by the column etree
+                                      // (0 never, 1 when the tree is shallow enough for its size, 2 always)
 };
 
 struct Context {

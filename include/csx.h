@@ -280,6 +280,13 @@ int csx_qr_blocks(csx_handle_t A, const int32_t *parent, const int32_t *pinv, co
  * Values equal the left-looking code's to rounding.  CSX_ENOTSPD: a singular block. */
 int csx_lu_blocks(csx_handle_t A, double tol, csx_handle_t *L, csx_handle_t *U, int32_t *pinv, int *done);
 
+/* cs_lu of ONE connected matrix on the device, natural column order: the columns are scheduled by the column elimination
+ * tree (the tree of A'A, csparse.py:1136-1169): columns that are not ancestor and descendant reach disjoint rows, so a
+ * level of the tree is one launch with one lane per column running csx_lu_host's loop.  L (unit diagonal first), U
+ * (diagonal last), pinv bit-identical to csx_lu_host.  *done = 0 when the tree is too deep for its size (a chain: a
+ * banded matrix in natural order), n < 2048 or tol <= 0: use csx_lu_host.  CSX_ENOTSPD: singular. */
+int csx_lu_etree(csx_handle_t A, double tol, csx_handle_t *L, csx_handle_t *U, int32_t *pinv, int *done);
+
 /* cs_spsolve (csparse.py:2078-2113) with cs_reach (:1939-1958) and cs_dfs (:789-829), for every column of B at once:
  * X(:,k) solves G X(:,k) = B(:,k), G n-by-n lower (lo != 0, diagonal first in every column) or upper (diagonal last)
  * triangular, B n-by-nb sparse.  pinv (host, n entries, or NULL): column pinv[j] of G belongs to node j, a negative
