@@ -479,7 +479,7 @@ def main():
         other = {}
         for name, fn in (("config2_gaxpy_bcsstk16", bc.config2), ("config3_lusol_W", bc.config3),
                          ("transpose_grand_5M", bc.transpose_grand), ("config4_multiply_S", bc.config4),
-                         ("cholsol_connected", bc.cholsol_connected)):
+                         ("cholsol_connected", bc.cholsol_connected), ("lu_connected", bc.lu_connected)):
             try:
                 other[name] = fn()
             except Exception as e:                        # never take the headline down with it

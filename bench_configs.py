@@ -266,6 +266,29 @@ def config4(n=1000000, per_col=32):
            "frac_of_peak": round(by / (tm.ms * 1e-3) / 1e9 / PEAK, 4),
            "G_products_per_s": round(products / (tm.ms * 1e-3) / 1e9, 3),
            "identity_C1_eq_A_At1_max_rel": ident}
+    # the opt-in reference summation order (spgemm.ordered): x bit-identical to the reference, two runs equal to the bit
+    with _csx.option("spgemm.ordered", 1):
+        h1, h2 = _csx.new_handle(), _csx.new_handle()
+        _csx.sync()
+        t0 = time.perf_counter()
+        _csx.check(lib.csx_multiply(hA, hB, h1))
+        _csx.sync()
+        t_ord = time.perf_counter() - t0
+        _csx.check(lib.csx_multiply(hA, hB, h2))
+        px1, px2 = C.c_void_p(), C.c_void_p()
+        _csx.check(lib.csx_csc_ptrs(h1, None, None, px1))
+        _csx.check(lib.csx_csc_ptrs(h2, None, None, px2))
+        v1, v2 = _csx.new_handle(), _csx.new_handle()
+        _csx.check(lib.csx_vec_wrap(px1, nnzC.value, v1))
+        _csx.check(lib.csx_vec_wrap(px2, nnzC.value, v2))
+        sample = min(nnzC.value, 50000000)
+        a1, a2 = np.empty(sample), np.empty(sample)
+        _csx.check(lib.csx_vec_download(v1, _csx.pd(a1), sample))
+        _csx.check(lib.csx_vec_download(v2, _csx.pd(a2), sample))
+        out["reference_summation_order"] = {"ms": round(t_ord * 1e3, 2), "two_runs_bit_identical_first_%d_values" % sample:
+                                            bool(a1.tobytes() == a2.tobytes())}
+        for h in (v1, v2, h1, h2):
+            _csx.free(h)
     for h in (hA, hB, hC, ones):
         _csx.free(h)
     import csparse_oracle as O
@@ -473,7 +496,7 @@ def lu_connected(grid=300, chain_blocks=1493):
         _csx.check(lib.csx_csc_upload(n, n, _csx.pi(Ap), _csx.pi(Ai), _csx.pd(Ax), hA))
         best, res = None, None
         with _csx.option("lu.etree", 2 if force else 1):
-            for rep in range(2):
+            for rep in range(1 if force else 2):
                 hL, hU, done = _csx.new_handle(), _csx.new_handle(), C_.c_int(0)
                 pinv = np.empty(n, np.int32)
                 _csx.sync()
