@@ -1199,7 +1199,7 @@ __global__ __launch_bounds__(256) void k_cholsol_dense(const Tree *__restrict__ 
 // broadcast of an L value serves R products (the broadcast -- LDS return path -- and the two separately rounded fp64
 // operations per term are what bound this kernel: 4 + 4 cycles of issue per term and right-hand side).
 template <int BS, bool BACKWARD, int R>
-__device__ __forceinline__ void dense_exact_pass(double (&x)[R][BS], const double *M, const double *D) {
+__device__ __forceinline__ void dense_exact_pass_rows(double (&x)[R][BS], const double *M, const double *D) {
 #pragma unroll
     for (int sp = 0; sp < BS; sp++) {
         double acc[R];
@@ -1236,11 +1236,76 @@ __device__ __forceinline__ void dense_exact_pass(double (&x)[R][BS], const doubl
     }
 }
 
+
+// The same pass with the L values read through a ring (see below); x indexed in reverse for the backward sweep.
+// R right-hand sides per lane: the R subtraction chains of a row are independent, so they fill each other's latency, and one
+// broadcast of an L value serves R products (the broadcast -- LDS return path -- and the two separately rounded fp64
+// operations per term are what bound this kernel: 4 + 4 cycles of issue per term and right-hand side).
+//
+// The L values come through a RING of K registers filled K terms ahead, in program order and fenced term by term
+// (sched_barrier): left to itself the compiler either hoists a whole row's LDS reads (hundreds of VGPRs, spills) or
+// reads each pair of values just before its use -- ds_read_b128, s_waitcnt lgkmcnt(0), two products -- and then every
+// second term pays the LDS latency (the round-2 kernel: 55 cycles per term and wave where 8 are issued).
+template <int BS, bool BACKWARD, int R>
+__device__ __forceinline__ void dense_exact_pass(double (&x)[R][BS], const double *M, const double *D) {
+    constexpr int K = 12;                               // at most 15 LDS reads can be outstanding (lgkmcnt)
+    // The backward sweep runs in sweep positions (position s = row BS - 1 - s): x is indexed through XI instead of being
+    // reversed in place -- a reversal between the passes makes the compiler keep both copies of x alive (390 registers
+    // at BS = 64 instead of 262).
+#define CSX_XI(i) (BACKWARD ? BS - 1 - (i) : (i))
+    double ring[K];
+    int lsp = 1, le = 0;                                // the next term to request: row lsp, position le in its order
+#pragma unroll
+    for (int u = 0; u < K; u++) {
+        ring[u] = 0.0;
+        if (lsp < BS) {
+            ring[u] = M[lsp * (lsp - 1) / 2 + (BACKWARD ? lsp - 1 - le : le)];
+            if (++le == lsp) {
+                lsp++;
+                le = 0;
+            }
+        }
+    }
+    double dnext = D[0];
+    int f = 0;
+#pragma unroll
+    for (int sp = 0; sp < BS; sp++) {
+        double acc[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) acc[r] = x[r][CSX_XI(sp)];
+        const double dv = dnext;
+        if (sp + 1 < BS) dnext = D[sp + 1];
+#pragma unroll
+        for (int e = 0; e < sp; e++) {
+            const int tt = BACKWARD ? sp - 1 - e : e;   // the reference's order: ascending columns forward, descending backward
+            const double mv = ring[f % K];
+            if (lsp < BS) {
+                ring[f % K] = M[lsp * (lsp - 1) / 2 + (BACKWARD ? lsp - 1 - le : le)];
+                if (++le == lsp) {
+                    lsp++;
+                    le = 0;
+                }
+            }
+            f++;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const double t = mv * x[r][CSX_XI(tt)];
+                acc[r] = acc[r] - t;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) x[r][CSX_XI(sp)] = acc[r] / dv;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef CSX_XI
+}
+
 // second launch-bound argument = waves per SIMD the register allocation must leave room for: without it the
 // scheduler spends 284-512 VGPRs on hoisted loads (one wave per SIMD, spills at BS = 32).  R = 2 (two right-hand sides
 // per lane, a task = a block x 128 right-hand sides): one wave per SIMD, 2 x BS unknowns in registers.
-template <int BS, int R>
-__global__ __launch_bounds__(256, (R == 1 ? 2 : 1)) void k_cholsol_dense_exact(const Tree *__restrict__ trees, int32_t ntrees,
+template <int BS, int R, bool RING>
+__global__ __launch_bounds__(256, (RING || R == 2 ? 1 : 2)) void k_cholsol_dense_exact(const Tree *__restrict__ trees, int32_t ntrees,
                                                              const int32_t *__restrict__ nodes,
                                                              const int32_t *__restrict__ perm,
                                                              const int32_t *__restrict__ f_ptr,
@@ -1294,16 +1359,23 @@ __global__ __launch_bounds__(256, (R == 1 ? 2 : 1)) void k_cholsol_dense_exact(c
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane < BS) DG[lane] = dv;
         __builtin_amdgcn_wave_barrier();
-        if (pass == 0) dense_exact_pass<BS, false, R>(x, M, DG);
-        else dense_exact_pass<BS, true, R>(x, M, DG);
+        if (RING) {
+            if (pass == 0) dense_exact_pass<BS, false, R>(x, M, DG);
+            else dense_exact_pass<BS, true, R>(x, M, DG);
+        } else {
+            if (pass == 0) dense_exact_pass_rows<BS, false, R>(x, M, DG);
+            else dense_exact_pass_rows<BS, true, R>(x, M, DG);
+        }
         __builtin_amdgcn_wave_barrier();
+        if (!RING) {
 #pragma unroll
-        for (int a = 0; a < BS / 2; a++) {           // reverse: sweep order of the other pass / back to row order
+            for (int a = 0; a < BS / 2; a++) {       // reverse: sweep order of the other pass / back to row order
 #pragma unroll
-            for (int r = 0; r < R; r++) {
-                const double tmp = x[r][a];
-                x[r][a] = x[r][BS - 1 - a];
-                x[r][BS - 1 - a] = tmp;
+                for (int r = 0; r < R; r++) {
+                    const double tmp = x[r][a];
+                    x[r][a] = x[r][BS - 1 - a];
+                    x[r][BS - 1 - a] = tmp;
+                }
             }
         }
     }
@@ -1743,23 +1815,42 @@ static int cholsol_solve(CholPlan *P, double *B, int32_t nrhs) {
         if (st != CSX_OK) return st;
         // Forests of dense blocks: the default (exact) order runs the substitution kernel that keeps the reference's
         // operations and their order; the rounding-equal order the FMA / matrix-core kernels.
-        if (P->dense_bs && !P->relaxed && ctx().opt.cholsol_dense_blocks) {
-            // more than 64 right-hand sides and blocks of at most 32: two right-hand sides per lane (independent chains, one
-            // broadcast of L for both).  At 64 the 2 x 64 unknowns alone are the 256 architectural VGPRs: the compiler
-            // spills 361 of them and the kernel is slower than with one right-hand side per lane.
-            const int R = nrhs > 64 && P->dense_bs <= 32 && ctx().opt.cholsol_exact_pairs ? 2 : 1;
+        // (blocks of 32: every register-resident variant of the substitution kernel compiles to heavy spilling -- 40 ms per
+        // 128 right-hand sides on 5M rows against 9.6 ms for the fused per-tree kernel below, which is just as exact)
+        if (P->dense_bs && !P->relaxed && ctx().opt.cholsol_dense_blocks &&
+            (P->dense_bs != 32 || ctx().opt.cholsol_exact_variant != 0)) {
+            // Variants, chosen per block size from measurements on G-spd (5M rows, 128 right-hand sides, ms per batch;
+            // profiles/r03_ablation.md section 3): the L values through a ring of registers filled 12 terms ahead (RING)
+            // against one fence per row; one or two right-hand sides per lane ("cholsol.exact_variant": 0 = the table
+            // below, 1 = rows / 1, 2 = ring / 1, 3 = rows / 2, 4 = ring / 2; two per lane only for blocks <= 32).
+            const int want = ctx().opt.cholsol_exact_variant;
+            int variant = P->dense_bs == 64 ? 1 : 2;
+            if (want >= 1 && want <= 4) variant = want;
+            if (P->dense_bs == 64 && variant > 2) variant -= 2;
+            if (nrhs <= 64 && variant > 2) variant -= 2;
+            const int R = variant > 2 ? 2 : 1;
+            const bool ring = variant == 2 || variant == 4;
             const int32_t chunks = (nrhs + 64 * R - 1) / (64 * R);
             const int64_t tasks = (int64_t)P->ntrees * chunks;
             const dim3 grid((unsigned)((tasks + 3) / 4));
-#define CSX_DENSE_X(BS, RR)                                                                                                     \
-    hipLaunchKernelGGL((k_cholsol_dense_exact<BS, RR>), grid, dim3(256), 0, s, P->trees, P->ntrees, P->tree_nodes, P->perm,     \
+#define CSX_DENSE_X(BS, RR, RG)                                                                                                 \
+    hipLaunchKernelGGL((k_cholsol_dense_exact<BS, RR, RG>), grid, dim3(256), 0, s, P->trees, P->ntrees, P->tree_nodes, P->perm, \
                        P->f_ptr, P->f_val, P->b_ptr, P->dense_b, P->diagk, P->diagb, B, nrhs, chunks)
+#define CSX_DENSE_V(BS)                                \
+    if (variant == 1) CSX_DENSE_X(BS, 1, false);       \
+    else if (variant == 2) CSX_DENSE_X(BS, 1, true);   \
+    else if (variant == 3) CSX_DENSE_X(BS, 2, false);  \
+    else CSX_DENSE_X(BS, 2, true)
             switch (P->dense_bs) {
-                case 8: if (R == 2) CSX_DENSE_X(8, 2); else CSX_DENSE_X(8, 1); break;
-                case 16: if (R == 2) CSX_DENSE_X(16, 2); else CSX_DENSE_X(16, 1); break;
-                case 32: if (R == 2) CSX_DENSE_X(32, 2); else CSX_DENSE_X(32, 1); break;
-                default: CSX_DENSE_X(64, 1); break;
+                case 8: CSX_DENSE_V(8); break;
+                case 16: CSX_DENSE_V(16); break;
+                case 32: CSX_DENSE_V(32); break;
+                default:
+                    if (variant == 1) CSX_DENSE_X(64, 1, false);
+                    else CSX_DENSE_X(64, 1, true);
+                    break;
             }
+#undef CSX_DENSE_V
 #undef CSX_DENSE_X
             CSX_LAUNCH_CHECK();
             return CSX_OK;

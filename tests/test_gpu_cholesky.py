@@ -700,3 +700,29 @@ def test_supernodal_schedule_refuses_a_triangle_that_is_not_a_cholesky_factor(cs
     assert np.max(np.abs(X.numpy() - ref)) <= 1e-10 * np.max(np.abs(ref))
     _csx.free(plan)
     _csx.free(hL)
+
+
+@pytest.mark.parametrize("bs", [8, 16, 32, 64])
+def test_exact_dense_block_kernel_variants_all_have_the_reference_bits(cs, bs):
+    """The default (exact) order on forests of dense blocks has four kernel variants (one fence per row or the L values
+    through a register ring; one or two right-hand sides per lane), picked per block size from measurements
+    ("cholsol.exact_variant" forces one).  Each must be bit-identical to cs_lsolve + cs_ltsolve of the oracle, for 130
+    right-hand sides (two full groups and a partial one; a partial pair for the two-per-lane variants)."""
+    import _csx
+    nblocks, k = 9, 130
+    n = nblocks * bs
+    Ap, Ai, Ax = synth.gspd(nblocks, bs, 11)
+    A = cs.cs_pin(_host_cs(cs, n, n, Ap, Ai, Ax))
+    F = cs.cholsol_factor(A)
+    assert F.info()["dense_block"] == bs
+    parent, cp = CO.schol(n, Ap, Ai)
+    Lp, Li, Lx = CO.chol(n, Ap, Ai, Ax, parent, cp)
+    B = synth.rhs(n, k, 3)
+    ref = {r: CO.ltsolve(n, Lp, Li, Lx, CO.lsolve(n, Lp, Li, Lx, B[:, r])) for r in (0, 63, 64, 127, 128, 129)}
+    for variant in (0, 1, 2, 3, 4):
+        with _csx.option("cholsol.exact_variant", variant):
+            dB = cs.dvec(B)
+            assert F.solve(dB)
+            X = dB.numpy()
+        for r, v in ref.items():
+            assert X[:, r].tobytes() == v.tobytes(), (variant, r)
