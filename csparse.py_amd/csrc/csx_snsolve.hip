@@ -51,6 +51,7 @@ struct SnTask {
 
 struct SnStep {
     int32_t t0, tc;   // tasks
+    int32_t c0, cc;   // lines of this step that were cut into pieces (k_sn_combine)
     int32_t s0, sc;   // narrow virtual supernodes (at most 16 columns: one wave each)
     int32_t m0, mc;   // up to 32 columns: two waves, a quarter of the LDS of the wide ones
     int32_t b0, bc;   // the others (four waves each)
@@ -59,6 +60,7 @@ struct SnStep {
 struct SnDir {
     std::vector<SnStep> steps;       // host
     SnTask *tasks = nullptr;         // device
+    int32_t *comb = nullptr;         // device: lines with partial slots, by step
     int32_t *narrow = nullptr;       // device: virtual supernode ids by step
     int32_t *medium = nullptr;       // device
     int32_t *wide = nullptr;         // device
@@ -89,6 +91,7 @@ void free_snplan(SnPlan *P) {
         dfree(p);
     for (SnDir *d : {&P->fwd, &P->bwd}) {
         dfree(d->tasks);
+        dfree(d->comb);
         dfree(d->narrow);
         dfree(d->medium);
         dfree(d->wide);
@@ -174,6 +177,33 @@ __global__ __launch_bounds__(256) void k_sn_outside(const SnTask *__restrict__ t
     else partial[(int64_t)t.out * nrhs + r] = d;
 }
 
+// Between A and B: a line cut into pieces takes its partial sums, in piece order, eight loads in flight at a time
+// (inside B they were one dependent load after the other per line: 26 - 47 us per chunk on bcsstk16 instead of 14).
+// entry k of the list: line = lines[k]; its slots [slot_ptr[j], slot_ptr[j + 1]) with j = k (by_pos) or the line.
+__global__ __launch_bounds__(256) void k_sn_combine(const int32_t *__restrict__ lines, int32_t first, int32_t count,
+                                                    const int32_t *__restrict__ slot_ptr, int by_pos,
+                                                    const double *__restrict__ partial, double *X, int nrhs) {
+    const int lane = threadIdx.x & 63;
+    const int nblk = (nrhs + 63) >> 6;
+    const int64_t wv = __builtin_amdgcn_readfirstlane((int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    if (wv >= (int64_t)count * nblk) return;
+    const int32_t k = first + (int32_t)(wv / nblk), line = lines[k];
+    const int32_t j = by_pos ? k : line;
+    const int32_t s0 = slot_ptr[j], s1 = slot_ptr[j + 1];
+    if (s1 <= s0) return;
+    const int r = (int)(wv % nblk) * 64 + lane;
+    if (r >= nrhs) return;
+    double acc = X[(int64_t)line * nrhs + r];
+    for (int32_t s = s0; s < s1; s += 8) {
+        double pv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) pv[u] = s + u < s1 ? partial[(int64_t)(s + u) * nrhs + r] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc -= pv[u];
+    }
+    X[(int64_t)line * nrhs + r] = acc;
+}
+
 // B: (virtual) supernode columns [a, a + w), w <= W, for 64 right-hand sides: the triangle (Ls[i][t] = L(a + i, a + t), i > t)
 // and the w rows of X (less the partial sums of their outside terms) staged in LDS; solved there in panels of 16 rows,
 // the panel's triangle by one wave with its rows in registers, the update of the remaining rows by all waves.
@@ -199,7 +229,8 @@ __global__ __launch_bounds__(64 * NW) void k_sn_tri(const int32_t *__restrict__ 
     // Staging: lane v holds the pointers of line a + v, so that every load below has its address at once (v_readlane)
     // and a wave's W / NW lines are all in flight together instead of one dependent chain per line.
     const int32_t mp = lane < w ? Tp[a + lane + (FWD ? 1 : 0)] : 0;
-    const int32_t ps = lane < w ? part_ptr[a + lane] : 0, pe = lane < w ? part_ptr[a + lane + 1] : 0;
+    // (part_ptr == nullptr: the partial sums were already taken off X by k_sn_combine)
+    const int32_t ps = part_ptr && lane < w ? part_ptr[a + lane] : 0, pe = part_ptr && lane < w ? part_ptr[a + lane + 1] : 0;
     if (wave == 0 && lane < w) dg[lane] = 1.0 / (FWD ? Td[a + lane] : Tx[mp]);   // one division per line, off the chain below
     constexpr int PER = W / NW;
     double xv[PER], lv[PER];
@@ -656,7 +687,7 @@ int sn_build(const Csc *L, const int32_t *parent, const int32_t *Lp_h, const int
         std::vector<std::vector<int32_t>> by((size_t)Lv);
         for (int32_t S = 0; S < nsn; S++) by[(size_t)level[(size_t)S]].push_back(S);
         std::vector<SnTask> tasks;
-        std::vector<int32_t> narrow, medium, wide, part((size_t)n + 1, 0);
+        std::vector<int32_t> comb, narrow, medium, wide, part((size_t)n + 1, 0);
         // terms of line a + v (v: position in its supernode of width w) that lie outside the supernode
         auto outside = [&](int32_t line, int32_t v, int32_t w, int32_t *b, int32_t *e) {
             if (forward) {                       // row: [Gp[row], Gp[row + 1] - v)
@@ -680,7 +711,8 @@ int sn_build(const Csc *L, const int32_t *parent, const int32_t *Lp_h, const int
             int32_t nsub = 1;
             for (int32_t S : by[(size_t)l]) nsub = std::max(nsub, vs0[(size_t)S + 1] - vs0[(size_t)S]);
             for (int32_t q = 0; q < nsub; q++) {
-                SnStep stp{(int32_t)tasks.size(), 0, (int32_t)narrow.size(), 0, (int32_t)medium.size(), 0, (int32_t)wide.size(), 0};
+                SnStep stp{(int32_t)tasks.size(), 0, (int32_t)comb.size(), 0, (int32_t)narrow.size(), 0, (int32_t)medium.size(), 0,
+                           (int32_t)wide.size(), 0};
                 for (int32_t S : by[(size_t)l]) {
                     const int32_t a = first[(size_t)S], w = width[(size_t)S], nch = vs0[(size_t)S + 1] - vs0[(size_t)S];
                     if (q >= nch) continue;
@@ -695,6 +727,7 @@ int sn_build(const Csc *L, const int32_t *parent, const int32_t *Lp_h, const int
                             } else {
                                 int32_t slot = part[(size_t)(a + v)];
                                 for (int32_t t = b; t < e; t += SN_SEG) tasks.push_back({a + v, t, std::min(e, t + SN_SEG), slot++});
+                                comb.push_back(a + v);
                             }
                         }
                     } else if (forward) {
@@ -717,6 +750,7 @@ int sn_build(const Csc *L, const int32_t *parent, const int32_t *Lp_h, const int
                     (cw > 32 ? wide : cw > SN_PANEL ? medium : narrow).push_back(chunk);
                 }
                 stp.tc = (int32_t)tasks.size() - stp.t0;
+                stp.cc = (int32_t)comb.size() - stp.c0;
                 stp.sc = (int32_t)narrow.size() - stp.s0;
                 stp.mc = (int32_t)medium.size() - stp.m0;
                 stp.bc = (int32_t)wide.size() - stp.b0;
@@ -724,6 +758,7 @@ int sn_build(const Csc *L, const int32_t *parent, const int32_t *Lp_h, const int
             }
         }
         CSX_TRY(up(&D.tasks, tasks));
+        CSX_TRY(up(&D.comb, comb));
         CSX_TRY(up(&D.narrow, narrow));
         CSX_TRY(up(&D.medium, medium));
         CSX_TRY(up(&D.wide, wide));
@@ -786,26 +821,31 @@ int sn_solve(SnPlan *P, bool forward, const int32_t *Gp, const int32_t *Gi, cons
             hipLaunchKernelGGL(k_sn_outside, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, D.tasks, t.t0, t.tc, idx, val, X,
                                P->partial, nrhs);
         }
+        if (t.cc > 0) {
+            const int64_t waves = (int64_t)t.cc * nblk;
+            hipLaunchKernelGGL(k_sn_combine, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, D.comb, t.c0, t.cc, D.part_ptr, 0,
+                               P->partial, X, nrhs);
+        }
         if (forward) {
             if (t.sc > 0)
                 hipLaunchKernelGGL((k_sn_tri<1, SN_PANEL, true>), dim3((unsigned)(t.sc * nblk)), dim3(64), sn_tri_lds<SN_PANEL>(), s, D.narrow,
-                                   t.s0, P->vs_a, P->vs_w, Gp, Gx, Gd, D.part_ptr, P->partial, X, nrhs);
+                                   t.s0, P->vs_a, P->vs_w, Gp, Gx, Gd, (const int32_t *)nullptr, P->partial, X, nrhs);
             if (t.mc > 0)
                 hipLaunchKernelGGL((k_sn_tri<2, 32, true>), dim3((unsigned)(t.mc * nblk)), dim3(128), sn_tri_lds<32>(), s, D.medium, t.m0,
-                                   P->vs_a, P->vs_w, Gp, Gx, Gd, D.part_ptr, P->partial, X, nrhs);
+                                   P->vs_a, P->vs_w, Gp, Gx, Gd, (const int32_t *)nullptr, P->partial, X, nrhs);
             if (t.bc > 0)
                 hipLaunchKernelGGL((k_sn_tri<4, SN_CHUNK, true>), dim3((unsigned)(t.bc * nblk)), dim3(256), sn_tri_lds<SN_CHUNK>(), s, D.wide,
-                                   t.b0, P->vs_a, P->vs_w, Gp, Gx, Gd, D.part_ptr, P->partial, X, nrhs);
+                                   t.b0, P->vs_a, P->vs_w, Gp, Gx, Gd, (const int32_t *)nullptr, P->partial, X, nrhs);
         } else {
             if (t.sc > 0)
                 hipLaunchKernelGGL((k_sn_tri<1, SN_PANEL, false>), dim3((unsigned)(t.sc * nblk)), dim3(64), sn_tri_lds<SN_PANEL>(), s, D.narrow,
-                                   t.s0, P->vs_a, P->vs_w, L->p, L->x, (const double *)nullptr, D.part_ptr, P->partial, X, nrhs);
+                                   t.s0, P->vs_a, P->vs_w, L->p, L->x, (const double *)nullptr, (const int32_t *)nullptr, P->partial, X, nrhs);
             if (t.mc > 0)
                 hipLaunchKernelGGL((k_sn_tri<2, 32, false>), dim3((unsigned)(t.mc * nblk)), dim3(128), sn_tri_lds<32>(), s, D.medium, t.m0,
-                                   P->vs_a, P->vs_w, L->p, L->x, (const double *)nullptr, D.part_ptr, P->partial, X, nrhs);
+                                   P->vs_a, P->vs_w, L->p, L->x, (const double *)nullptr, (const int32_t *)nullptr, P->partial, X, nrhs);
             if (t.bc > 0)
                 hipLaunchKernelGGL((k_sn_tri<4, SN_CHUNK, false>), dim3((unsigned)(t.bc * nblk)), dim3(256), sn_tri_lds<SN_CHUNK>(), s, D.wide,
-                                   t.b0, P->vs_a, P->vs_w, L->p, L->x, (const double *)nullptr, D.part_ptr, P->partial, X, nrhs);
+                                   t.b0, P->vs_a, P->vs_w, L->p, L->x, (const double *)nullptr, (const int32_t *)nullptr, P->partial, X, nrhs);
         }
     }
     if (!forward && P->nleaf) {
@@ -813,8 +853,13 @@ int sn_solve(SnPlan *P, bool forward, const int32_t *Gp, const int32_t *Gi, cons
         if (waves > 0)
             hipLaunchKernelGGL(k_sn_outside, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, P->leaf_tasks, 0, P->nleaftasks, L->i,
                                L->x, X, P->partial, nrhs);
+        if (P->nleafslots > 0) {                                // the leaf columns that were cut into pieces
+            const int64_t cw = (int64_t)P->nleafcols * nblk;
+            hipLaunchKernelGGL(k_sn_combine, dim3((unsigned)((cw + 3) / 4)), dim3(256), 0, s, P->leaf_cols, 0, P->nleafcols, P->lslot_ptr, 1,
+                               P->partial + (int64_t)P->bwd.nslots * nrhs, X, nrhs);
+        }
         hipLaunchKernelGGL(k_sn_leaf<false>, dim3((unsigned)(P->nleaf * nblk)), dim3(64), 0, s, P->leaf_ptr, P->leaf_cols, P->lb_ptr,
-                           P->lb_idx, P->lb_val, P->ldiag, P->lslot_ptr, P->partial + (int64_t)P->bwd.nslots * nrhs, X, nrhs);
+                           P->lb_idx, P->lb_val, P->ldiag, (const int32_t *)nullptr, (const double *)nullptr, X, nrhs);
     }
     CSX_LAUNCH_CHECK();
     return CSX_OK;
