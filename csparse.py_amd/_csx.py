@@ -134,17 +134,21 @@ class NotPositiveDefinite(ArithmeticError):
 
 def _share_torch_hip_runtime():
     """One HIP runtime per process.  PyTorch bundles its own libamdhip64.so (same soname as /opt/rocm's).
-    A process that uses both libcsx and torch (the multi-GPU path: torch.distributed over RCCL) must have
-    them on ONE runtime, or device pointers of one are foreign to the other.  Loading torch's copy by path
-    BEFORE libcsx makes the dynamic loader satisfy libcsx's DT_NEEDED libamdhip64.so.7 with it, whatever
-    order `import torch` and `_csx.load()` then come in.  Nothing is initialised and torch is not imported.
-    Taken when WORLD_SIZE > 1 or CSX_SHARE_TORCH_HIP=1; a torch that is already imported has already
-    loaded its runtime, and libcsx then binds to it with no help."""
+    A process that uses both libcsx and torch on the device must have them on ONE runtime, or device pointers of one
+    are foreign to the other.  Loading torch's copy by path BEFORE libcsx makes the dynamic loader satisfy libcsx's
+    DT_NEEDED libamdhip64.so.7 with it, whatever order `import torch` and `_csx.load()` then come in.  Nothing is
+    initialised and torch is not imported.
+    Taken when CSX_SHARE_TORCH_HIP=1, or at WORLD_SIZE > 1 with the gloo stand-in as the transport
+    (CSX_COMM_BACKEND=gloo: shard.Comm imports torch there).  The RCCL transport (the default at WORLD_SIZE > 1) has no
+    torch in the process: libcsx, librccl and libamdhip64 all come from the ROCm installation, the combination
+    tests/test_gpu_comm.py runs.  A torch that is already imported has already loaded its runtime, and libcsx then
+    binds to it with no help."""
     import sys
     if "torch" in sys.modules:
         return "torch (already imported)"
     want = os.environ.get("CSX_SHARE_TORCH_HIP")
-    if want == "0" or (want is None and int(os.environ.get("WORLD_SIZE", "1")) <= 1):
+    if want == "0" or (want is None and (int(os.environ.get("WORLD_SIZE", "1")) <= 1
+                                         or os.environ.get("CSX_COMM_BACKEND") != "gloo")):
         return None
     import importlib.util
     spec = importlib.util.find_spec("torch")

@@ -160,7 +160,8 @@ def test_sharded_solve_and_sharded_gaxpy_at_world_size_two_and_three(tmp_path, w
     for rk in range(world):
         procs.append(subprocess.Popen([sys.executable, str(script)],
                                       env=_env(RANK=str(rk), LOCAL_RANK=str(rk), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                                               MASTER_PORT=str(29713 + world), CSX_SINGLE_DEVICE="1"),
+                                               MASTER_PORT=str(29713 + world), CSX_SINGLE_DEVICE="1",
+                                               CSX_COMM_BACKEND="gloo"),
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=600) for p in procs]
     for p, (so, se) in zip(procs, outs):
