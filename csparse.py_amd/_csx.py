@@ -36,6 +36,7 @@ _PROTOS = {
     "csx_norm1": [H, _f64p],
     "csx_cholsol_set_order": [H, C.c_int],
     "csx_cholsol_growth": [H, _f64p],
+    "csx_cholsol_sn_info": [H, _i32p, _i32p, _i32p, _i32p, _f64p],
     "csx_csc_invalidate": [H],
     "csx_set_option": [C.c_char_p, C.c_int],
     "csx_get_option": [C.c_char_p, C.POINTER(C.c_int)],

@@ -1994,6 +1994,24 @@ extern "C" int csx_cholsol_growth(csx_handle_t h, double *growth) {
     return CSX_OK;
 }
 
+extern "C" int csx_cholsol_sn_info(csx_handle_t h, int32_t *supernodes, int32_t *steps, int32_t *max_width, int32_t *matrix_cores,
+                                   double *growth) {
+    CholPlan *P = (CholPlan *)get(h, K_CHOLPLAN);
+    if (!P) return CSX_EINVAL;
+    int32_t a = 0, b = 0, c = 0, mc = 0;
+    double g = 0.0;
+    if (P->sn) {
+        sn_info(P->sn, &a, &b, &c);
+        sn_info2(P->sn, &mc, &g);
+    }
+    if (supernodes) *supernodes = a;
+    if (steps) *steps = b;
+    if (max_width) *max_width = c;
+    if (matrix_cores) *matrix_cores = mc;
+    if (growth) *growth = g;
+    return CSX_OK;
+}
+
 extern "C" int csx_cholsol_solve(csx_handle_t h, csx_handle_t hB, int32_t nrhs) {
     CSX_TRY(require_ready());
     CholPlan *P = (CholPlan *)get(h, K_CHOLPLAN);

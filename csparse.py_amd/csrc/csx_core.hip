@@ -547,7 +547,7 @@ const OptSlot kOptSlots[] = {
     {"tri.components", &Options::tri_components, 0},     {"tri.columns", &Options::tri_columns, 0},
     {"gaxpy.keys24", &Options::gaxpy_keys24, 0},         {"gaxpy.tune_shape", &Options::gaxpy_tune_shape, 0},
     {"tri.row_waves", &Options::tri_row_waves, 0},       {"tri.push", &Options::tri_push, 0},
-    {"tri.levels_where", &Options::tri_levels_where, 3}, {"tri.supernodes", &Options::tri_supernodes, 0},
+    {"tri.levels_where", &Options::tri_levels_where, 3}, {"tri.supernodes", &Options::tri_supernodes, 5},
     {"spgemm.ordered", &Options::spgemm_ordered, 0},     {"spgemm.chunks", &Options::spgemm_chunks, 4},
     {"lu.etree", &Options::lu_etree, 5},                 {"cholsol.exact_variant", &Options::cholsol_exact_variant, 4},
 };

@@ -135,7 +135,8 @@ struct Options {
     int gaxpy_tune_shape = 0;    // tiled cs_gaxpy plan: time the launch shapes when the plan is built and keep the fastest
     int tri_row_waves = 1;        // level-scheduled solves: a wave per row for few right-hand sides and long rows
     int tri_levels_where = 0;         // level analysis: 0 = device for big factors, host for small; 1 = host; 2 = device
-    int tri_supernodes = 1;           // cholsol: dense-block (supernodal) forward / backward solves on factors with supernodes
+    int tri_supernodes = 1;           // cholsol: supernodal forward / backward solves on factors with supernodes (0 never, 1 yes,
+                                      // 2 yes but the triangles by substitution out of LDS instead of on the matrix cores)
     int spgemm_ordered = 0;           // cs_multiply: sum every entry's products in the reference's order (bit-identical x)
     int spgemm_chunks = 1;            // cs_multiply: column chunks whose compaction overlaps the next chunk's hashing on a second stream
                                       // (1 = off, the default: measured slower, profiles/r03_ablation.md section 2)
@@ -185,6 +186,7 @@ int sn_build(const Csc *L, const int32_t *parent, const int32_t *Lp_h, const int
 int sn_solve(SnPlan *P, bool forward, const int32_t *Gp, const int32_t *Gi, const double *Gx, const double *Gd, const Csc *L,
              double *X, int32_t nrhs);
 void sn_info(const SnPlan *P, int32_t *nsn, int32_t *levels, int32_t *max_w);
+void sn_info2(const SnPlan *P, int32_t *matrix_cores, double *growth);
 
 // Device temporaries of a host function with several exits: freed when the guard leaves scope.
 struct DevScope {

@@ -31,6 +31,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <utility>
 #include <vector>
 
@@ -55,6 +56,7 @@ struct SnStep {
     int32_t s0, sc;   // narrow virtual supernodes (at most 16 columns: one wave each)
     int32_t m0, mc;   // up to 32 columns: two waves, a quarter of the LDS of the wide ones
     int32_t b0, bc;   // the others (four waves each)
+    int32_t q0, qc;   // all of them in one list for the matrix-core kernel (SnDir::tri4)
 };
 
 struct SnDir {
@@ -65,6 +67,7 @@ struct SnDir {
     int32_t *medium = nullptr;       // device
     int32_t *wide = nullptr;         // device
     int32_t *part_ptr = nullptr;     // device [n + 1]: partial slots of a row / column
+    int4 *tri4 = nullptr;            // device: (first column, width, first fragment, 0) of every virtual supernode, by step
     int32_t nslots = 0;
 };
 
@@ -81,13 +84,16 @@ struct SnPlan {
     SnDir fwd, bwd;
     double *partial = nullptr;
     int64_t partial_len = 0;
+    double *frags = nullptr;                    // matrix-core fragments of every virtual supernode's triangle (k_sn_frags)
+    bool mfma = false;                          // fragments built and every block inverse tame: k_sn_mfma solves the triangles
+    double growth = 0.0;                        // the guard's measure (k_sn_frags)
 };
 
 void free_snplan(SnPlan *P) {
     if (!P) return;
     for (void *p : {(void *)P->vs_a, (void *)P->vs_w, (void *)P->leaf_ptr, (void *)P->leaf_cols, (void *)P->lf_ptr, (void *)P->lf_idx,
                     (void *)P->lb_ptr, (void *)P->lb_idx, (void *)P->lf_val, (void *)P->lb_val, (void *)P->ldiag, (void *)P->leaf_tasks,
-                    (void *)P->lslot_ptr, (void *)P->partial})
+                    (void *)P->lslot_ptr, (void *)P->partial, (void *)P->frags})
         dfree(p);
     for (SnDir *d : {&P->fwd, &P->bwd}) {
         dfree(d->tasks);
@@ -96,6 +102,7 @@ void free_snplan(SnPlan *P) {
         dfree(d->medium);
         dfree(d->wide);
         dfree(d->part_ptr);
+        dfree(d->tri4);
     }
     delete P;
 }
@@ -321,6 +328,194 @@ __global__ __launch_bounds__(64 * NW) void k_sn_tri(const int32_t *__restrict__ 
 template <int W>
 constexpr size_t sn_tri_lds() {
     return (size_t)(W * (W + 1) + W * 64 + W) * sizeof(double);
+}
+
+// ---- B on the matrix cores --------------------------------------------------------------------------------------
+// The triangle of a virtual supernode (w <= 64 columns) as a blocked TRSM on 16 x 16 tiles, the scheme of the dense-block
+// cholsol kernel (csx_chol.hip, k_cholsol_mfma):  forward X_i <- W_ii (X_i - sum_{j<i} L_ij X_j), backward
+// X_i <- W_ii' (X_i - sum_{j>i} L_ji' X_j), W_ii = inv(L_ii) formed with the plan.  One wave per (virtual supernode, 64
+// right-hand sides): the nb x 4 tiles of X live in registers (accumulator layout = B-operand layout, so a finished tile
+// feeds the next product as it stands), a tile of L reaches the pipe as one double per lane from a fragment array that
+// is read once, coalesced.  What it replaces (k_sn_tri) stages the triangle in LDS and walks 64 dependent rows: 33 - 47 us
+// per 64-column chunk on bcsstk16 against ~10 here, and that chain of steps IS the solve time of such a factor.
+// Fragments of a virtual supernode: tiles in the order (0,0) (1,0) (1,1) (2,0) .. of its nb = ceil(w / 16) block rows,
+// four k-steps of 64 doubles each; off-diagonal tiles hold -L_ij, diagonal ones W_ii; rows and columns past w are
+// those of the identity.  The backward sweep reads the same fragments transposed (lane and k-step exchange roles).
+typedef double sn_f64x4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ constexpr int sn_tiles(int nb) { return nb * (nb + 1) / 2; }
+
+// one wave per virtual supernode: list entry (a, w, first fragment, -)
+__global__ __launch_bounds__(64) void k_sn_frags(const int4 *__restrict__ list, int32_t count, const int32_t *__restrict__ Lp,
+                                                 const double *__restrict__ Lx, double *__restrict__ frags,
+                                                 unsigned long long *cond_bits) {
+    __shared__ double Ls[64][65];
+    __shared__ double Wm[4][16][17];
+    const int lane = threadIdx.x;
+    if ((int32_t)blockIdx.x >= count) return;
+    const int4 ent = list[blockIdx.x];
+    const int32_t a = ent.x, w = ent.y;
+    const int nb = (w + 15) >> 4;
+    for (int e = lane; e < 64 * 64; e += 64) {
+        const int i = e >> 6, t = e & 63;               // row i, column t of the triangle
+        double v = i == t ? 1.0 : 0.0;
+        if (i < w && t <= i) v = Lx[Lp[a + t] + (i - t)];   // column a + t: diagonal, then rows a + t + 1 .. (dense inside a supernode)
+        Ls[i][t] = v;
+    }
+    __syncthreads();
+    __shared__ double rsum[64];
+    {
+        const int blk = lane >> 4, col = lane & 15;
+        double rs = 0.0;                                    // row sum of |L_ii| for row `col` of diagonal block blk
+        if (blk < nb) {
+            double wcol[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                double sres = r == col ? 1.0 : 0.0;
+#pragma unroll
+                for (int q = 0; q < r; q++) sres -= Ls[16 * blk + r][16 * blk + q] * (q >= col ? wcol[q] : 0.0);
+                wcol[r] = r >= col ? sres / Ls[16 * blk + r][16 * blk + r] : 0.0;
+                Wm[blk][r][col] = wcol[r];
+                rs += fabs(Ls[16 * blk + col][16 * blk + r]);
+            }
+        }
+        rsum[lane] = rs;
+    }
+    __syncthreads();
+    // What an explicit inverse costs in accuracy: X_i <- W_ii r with r = L_ii x carries a relative error of about
+    // eps || |W_ii| |L_ii| ||_inf (the condition of the 16 x 16 diagonal block alone, whatever the scaling of its rows;
+    // off-diagonal tiles enter as plain products).  Row `col` of that matrix sums to sum_k |W(col, k)| rsum(k).
+    double growth = 0.0;
+    {
+        const int blk = lane >> 4, col = lane & 15;
+        if (blk < nb)
+#pragma unroll
+            for (int k = 0; k < 16; k++) growth += fabs(Wm[blk][col][k]) * rsum[16 * blk + k];
+    }
+    const int m = lane & 15, kq = lane >> 4;
+    double *F = frags + (size_t)ent.z * 64 + lane;
+    int f = 0;
+    for (int i = 0; i < nb; i++) {
+        for (int j = 0; j < i; j++)
+            for (int sx = 0; sx < 4; sx++) F[64 * f++] = -Ls[16 * i + m][16 * j + 4 * sx + kq];
+        for (int sx = 0; sx < 4; sx++) F[64 * f++] = Wm[i][m][4 * sx + kq];
+    }
+    if (!(growth >= 0.0)) growth = __longlong_as_double(0x7ff0000000000000ll);   // a NaN (zero pivot): refuse
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) growth = fmax(growth, __shfl_xor(growth, d, 64));
+    if (lane == 0) atomicMax(cond_bits, (unsigned long long)__double_as_longlong(growth));   // ordered bits of a non-negative double
+}
+
+template <bool FWD>
+__global__ __launch_bounds__(64) void k_sn_mfma(const int4 *__restrict__ list, int32_t first, const double *__restrict__ frags,
+                                                double *X, int nrhs) {
+    const int lane = threadIdx.x;
+    const int nblk = (nrhs + 63) >> 6;
+    const int4 ent = list[first + blockIdx.x / nblk];
+    const int h = (int)(blockIdx.x % nblk);
+    const int32_t a = ent.x, w = ent.y;
+    const int nb = (w + 15) >> 4;                       // uniform
+    const int col = lane & 15, rq = lane >> 4;
+    bool live[4];
+    int32_t cidx[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const int32_t rhs = h * 64 + 16 * c + col;
+        live[c] = rhs < nrhs;
+        cidx[c] = live[c] ? rhs : nrhs - 1;             // clamped: loaded, never stored
+    }
+    // lane (rq, col), register r of tile (i, c): row 16 i + rq + 4 r of the supernode, right-hand side 16 c + col
+    sn_f64x4 Xt[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) Xt[i][c] = sn_f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        if (i < nb) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = 16 * i + rq + 4 * r;
+                const double *src = X + (int64_t)(a + (row < w ? row : 0)) * nrhs;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const double v = src[cidx[c]];
+                    Xt[i][c][r] = row < w ? v : 0.0;    // rows past w: those of the identity block, kept at zero
+                }
+            }
+        }
+    const double *F = frags + (size_t)ent.z * 64 + lane;
+    // transposed read of a stored tile: the A operand of tile' for (lane = (m, kq), k-step sx) is element (4 sx + kq, m) of
+    // the tile, which the forward layout keeps in k-step m >> 2 at lane (m & 3) * 16 + 4 sx + kq
+    const double *Ft = frags + (size_t)ent.z * 64 + (size_t)(col >> 2) * 64 + (col & 3) * 16 + rq;
+    auto tile_at = [](int p, int q) { return (p * (p + 1) / 2 + q) * 4; };   // first of the tile's four fragments
+    if (FWD) {
+        int f = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (i < nb) {
+#pragma unroll
+                for (int j = 0; j < i; j++)
+#pragma unroll
+                    for (int sx = 0; sx < 4; sx++) {
+                        const double av = F[64 * f++];
+#pragma unroll
+                        for (int c = 0; c < 4; c++) Xt[i][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Xt[j][c][sx], Xt[i][c], 0, 0, 0);
+                    }
+                sn_f64x4 Y[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) Y[c] = sn_f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int sx = 0; sx < 4; sx++) {
+                    const double av = F[64 * f++];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) Y[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Xt[i][c][sx], Y[c], 0, 0, 0);
+                }
+#pragma unroll
+                for (int c = 0; c < 4; c++) Xt[i][c] = Y[c];
+            }
+    } else {
+#pragma unroll
+        for (int i = 3; i >= 0; i--)
+            if (i < nb) {
+#pragma unroll
+                for (int j = i + 1; j < 4; j++)
+                    if (j < nb) {
+#pragma unroll
+                        for (int sx = 0; sx < 4; sx++) {
+                            const double av = Ft[(size_t)tile_at(j, i) * 64 + 4 * sx];   // -L_ji' from the stored -L_ji
+#pragma unroll
+                            for (int c = 0; c < 4; c++)
+                                Xt[i][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Xt[j][c][sx], Xt[i][c], 0, 0, 0);
+                        }
+                    }
+                sn_f64x4 Y[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) Y[c] = sn_f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int sx = 0; sx < 4; sx++) {
+                    const double av = Ft[(size_t)tile_at(i, i) * 64 + 4 * sx];           // W_ii' from the stored W_ii
+#pragma unroll
+                    for (int c = 0; c < 4; c++) Y[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Xt[i][c][sx], Y[c], 0, 0, 0);
+                }
+#pragma unroll
+                for (int c = 0; c < 4; c++) Xt[i][c] = Y[c];
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        if (i < nb) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = 16 * i + rq + 4 * r;
+                if (row < w) {
+                    double *dst = X + (int64_t)(a + row) * nrhs;
+#pragma unroll
+                    for (int c = 0; c < 4; c++)
+                        if (live[c]) dst[cidx[c]] = Xt[i][c][r];
+                }
+            }
+        }
 }
 
 // Leaf subtrees: one wave per (subtree, 64 right-hand sides), the subtree's x in LDS (position in the subtree * 64 + lane),
@@ -679,6 +874,8 @@ int sn_build(const Csc *L, const int32_t *parent, const int32_t *Lp_h, const int
         }
     }
     vs0[(size_t)nsn] = (int32_t)vs_a.size();
+    std::vector<int32_t> vs_f(vs_a.size() + 1, 0);      // first fragment (64 doubles each) of every virtual supernode
+    for (size_t c = 0; c < vs_a.size(); c++) vs_f[c + 1] = vs_f[c] + sn_tiles((vs_w[c] + 15) / 16) * 4;
     if (st == CSX_OK) st = up(&P->vs_a, vs_a);
     if (st == CSX_OK) st = up(&P->vs_w, vs_w);
     auto build = [&](SnDir &D, const std::vector<int32_t> &level, bool forward) -> int {
@@ -688,6 +885,7 @@ int sn_build(const Csc *L, const int32_t *parent, const int32_t *Lp_h, const int
         for (int32_t S = 0; S < nsn; S++) by[(size_t)level[(size_t)S]].push_back(S);
         std::vector<SnTask> tasks;
         std::vector<int32_t> comb, narrow, medium, wide, part((size_t)n + 1, 0);
+        std::vector<int4> tri;
         // terms of line a + v (v: position in its supernode of width w) that lie outside the supernode
         auto outside = [&](int32_t line, int32_t v, int32_t w, int32_t *b, int32_t *e) {
             if (forward) {                       // row: [Gp[row], Gp[row + 1] - v)
@@ -712,7 +910,7 @@ int sn_build(const Csc *L, const int32_t *parent, const int32_t *Lp_h, const int
             for (int32_t S : by[(size_t)l]) nsub = std::max(nsub, vs0[(size_t)S + 1] - vs0[(size_t)S]);
             for (int32_t q = 0; q < nsub; q++) {
                 SnStep stp{(int32_t)tasks.size(), 0, (int32_t)comb.size(), 0, (int32_t)narrow.size(), 0, (int32_t)medium.size(), 0,
-                           (int32_t)wide.size(), 0};
+                           (int32_t)wide.size(), 0, (int32_t)tri.size(), 0};
                 for (int32_t S : by[(size_t)l]) {
                     const int32_t a = first[(size_t)S], w = width[(size_t)S], nch = vs0[(size_t)S + 1] - vs0[(size_t)S];
                     if (q >= nch) continue;
@@ -748,12 +946,16 @@ int sn_build(const Csc *L, const int32_t *parent, const int32_t *Lp_h, const int
                     const int32_t chunk = vs0[(size_t)S] + (forward ? q : nch - 1 - q);
                     const int32_t cw = vs_w[(size_t)chunk];
                     (cw > 32 ? wide : cw > SN_PANEL ? medium : narrow).push_back(chunk);
+                    tri.push_back(make_int4(vs_a[(size_t)chunk], cw, vs_f[(size_t)chunk], 0));
                 }
                 stp.tc = (int32_t)tasks.size() - stp.t0;
                 stp.cc = (int32_t)comb.size() - stp.c0;
                 stp.sc = (int32_t)narrow.size() - stp.s0;
                 stp.mc = (int32_t)medium.size() - stp.m0;
                 stp.bc = (int32_t)wide.size() - stp.b0;
+                stp.qc = (int32_t)tri.size() - stp.q0;
+                // the widest first: a launch is as long as its longest wave
+                std::stable_sort(tri.begin() + stp.q0, tri.end(), [](const int4 &x, const int4 &y) { return x.y > y.y; });
                 D.steps.push_back(stp);
             }
         }
@@ -763,6 +965,7 @@ int sn_build(const Csc *L, const int32_t *parent, const int32_t *Lp_h, const int
         CSX_TRY(up(&D.medium, medium));
         CSX_TRY(up(&D.wide, wide));
         CSX_TRY(up(&D.part_ptr, part));
+        CSX_TRY(up(&D.tri4, tri));
         return CSX_OK;
     };
     if (st == CSX_OK) st = build(P->fwd, height, true);
@@ -771,12 +974,45 @@ int sn_build(const Csc *L, const int32_t *parent, const int32_t *Lp_h, const int
         set_error("sn_build: slot count mismatch (%d / %d)", P->bwd.nslots, bwd_slots);
         st = CSX_ERUNTIME;
     }
+    // ---- matrix-core fragments of every triangle (every virtual supernode is in exactly one forward step) ----
+    double growth = 0.0;
+    if (st == CSX_OK && ctx().opt.tri_supernodes == 1) {
+        const size_t nfrag = (size_t)vs_f.back(), nv = vs_a.size();
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+        if (nfrag * 512 <= free_b / 4) {
+            DevScope tmp;
+            unsigned long long *d_cond = nullptr, h_cond = 0;
+            st = dalloc(&P->frags, nfrag * 64 + 64);
+            if (st == CSX_OK) st = tmp.alloc(&d_cond, 1);
+            if (st == CSX_OK && hipMemsetAsync(d_cond, 0, sizeof(unsigned long long), s) != hipSuccess) st = CSX_ERUNTIME;
+            if (st == CSX_OK) {
+                hipLaunchKernelGGL(k_sn_frags, dim3((unsigned)nv), dim3(64), 0, s, P->fwd.tri4, (int32_t)nv, L->p, L->x, P->frags, d_cond);
+                if (hipMemcpyAsync(&h_cond, d_cond, sizeof(h_cond), hipMemcpyDeviceToHost, s) != hipSuccess ||
+                    hipStreamSynchronize(s) != hipSuccess)
+                    st = CSX_ERUNTIME;
+            }
+            if (st == CSX_OK) {
+                std::memcpy(&growth, &h_cond, sizeof(double));
+                // the largest || |W_ii| |L_ii| ||_inf over all diagonal blocks (k_sn_frags): past 1e3 -- an error of
+                // ~1e-13 per block -- the triangles stay with substitution (k_sn_tri); a zero pivot reports infinity
+                P->growth = growth;
+                P->mfma = growth <= 1e3;
+                if (!P->mfma) {
+                    dfree(P->frags);
+                    P->frags = nullptr;
+                }
+            }
+        }
+    }
     if (st == CSX_OK && hipStreamSynchronize(s) != hipSuccess) st = CSX_ERUNTIME;
     if (st != CSX_OK) {
         free_snplan(P);
         return st;
     }
-    if (say) std::fprintf(stderr, "sn_build: %d forward steps, %d backward steps\n", (int)P->fwd.steps.size(), (int)P->bwd.steps.size());
+    if (say)
+        std::fprintf(stderr, "sn_build: %d forward steps, %d backward steps, triangles %s (largest || |W_ii| |L_ii| || = %.3g)\n", (int)P->fwd.steps.size(),
+                     (int)P->bwd.steps.size(), P->mfma ? "on the matrix cores" : "by substitution", growth);
     *out = P;
     return CSX_OK;
 }
@@ -785,6 +1021,11 @@ void sn_info(const SnPlan *P, int32_t *nsn, int32_t *levels, int32_t *max_w) {
     if (nsn) *nsn = P->nsn;
     if (levels) *levels = (int32_t)P->fwd.steps.size();
     if (max_w) *max_w = P->max_w;
+}
+
+void sn_info2(const SnPlan *P, int32_t *matrix_cores, double *growth) {
+    if (matrix_cores) *matrix_cores = P->mfma && ctx().opt.tri_supernodes == 1 ? 1 : 0;
+    if (growth) *growth = P->growth;
 }
 
 /* X (n x nrhs, row-major) <- inv(L) X (forward) or inv(L') X.  G*: the forward plan's row-major copy of L (off-diagonal
@@ -826,7 +1067,14 @@ int sn_solve(SnPlan *P, bool forward, const int32_t *Gp, const int32_t *Gi, cons
             hipLaunchKernelGGL(k_sn_combine, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, D.comb, t.c0, t.cc, D.part_ptr, 0,
                                P->partial, X, nrhs);
         }
-        if (forward) {
+        if (P->mfma && ctx().opt.tri_supernodes == 1) {
+            if (t.qc > 0) {
+                if (forward)
+                    hipLaunchKernelGGL(k_sn_mfma<true>, dim3((unsigned)(t.qc * nblk)), dim3(64), 0, s, D.tri4, t.q0, P->frags, X, nrhs);
+                else
+                    hipLaunchKernelGGL(k_sn_mfma<false>, dim3((unsigned)(t.qc * nblk)), dim3(64), 0, s, D.tri4, t.q0, P->frags, X, nrhs);
+            }
+        } else if (forward) {
             if (t.sc > 0)
                 hipLaunchKernelGGL((k_sn_tri<1, SN_PANEL, true>), dim3((unsigned)(t.sc * nblk)), dim3(64), sn_tri_lds<SN_PANEL>(), s, D.narrow,
                                    t.s0, P->vs_a, P->vs_w, Gp, Gx, Gd, (const int32_t *)nullptr, P->partial, X, nrhs);

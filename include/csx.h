@@ -204,6 +204,14 @@ int csx_cholsol_solve(csx_handle_t plan, csx_handle_t B, int32_t nrhs);
  * csx_cholsol_growth the guard's measure (0 before the first exact = 0). */
 int csx_cholsol_set_order(csx_handle_t plan, int exact);
 int csx_cholsol_growth(csx_handle_t plan, double *growth);
+/* The supernodal schedule of a plan in the rounding-equal order (path 4 of csx_cholsol_info; zeros when the plan has
+ * none): number of supernodes outside the leaf subtrees, dependent steps of the forward solve, widest supernode,
+ * whether the triangles of the supernodes are solved on the matrix cores (blocked TRSM with explicit inverses of the
+ * 16 x 16 diagonal blocks) and the guard's measure for that: the largest || |inv(L_ii)| |L_ii| ||_inf over all diagonal
+ * blocks; past 1e3, or with "tri.supernodes" = 2, the triangles are solved by substitution out of LDS.  Any pointer
+ * may be NULL. */
+int csx_cholsol_sn_info(csx_handle_t plan, int32_t *supernodes, int32_t *steps, int32_t *max_width, int32_t *matrix_cores,
+                        double *growth);
 
 /* ---- assembly and reshaping around the hot path ---------
  * Every function returns a NEW matrix handle.  p[] / i[] bit-identical to the reference's result.

@@ -663,6 +663,68 @@ def test_supernodal_solves_in_the_rounding_equal_order(cs, case):
     X3 = cs.dvec(synth.rhs(n, 3, 2))
     assert Fr.solve(X3)
     assert np.max(np.abs(X0.numpy() - X3.numpy())) <= 1e-10 * np.max(np.abs(X3.numpy()))
+    # the triangles of the supernodes: on the matrix cores when every 16 x 16 diagonal block is tame (the grids), by
+    # substitution out of LDS otherwise or on request ("tri.supernodes" = 2); both inside the same tolerance
+    nsn, steps, wmax, mc, growth = [_csx.C.c_int32(-1) for _ in range(4)] + [_csx.C.c_double(-1.0)]
+    _csx.check(_csx.lib().csx_cholsol_sn_info(Fr.plan_handle, nsn, steps, wmax, mc, growth))
+    assert nsn.value > 0 and steps.value > 0 and wmax.value >= 16 and growth.value >= 1.0
+    assert mc.value == (1 if growth.value <= 1e3 else 0)
+    if case != "bcsstk16":
+        assert mc.value == 1
+    with _csx.option("tri.supernodes", 2):
+        F2 = cs.cholsol_factor(A, order=1, exact=False)
+        _csx.check(_csx.lib().csx_cholsol_info(F2.plan_handle, path, None, None))
+        assert path.value == 4
+        _csx.check(_csx.lib().csx_cholsol_sn_info(F2.plan_handle, None, None, None, mc, None))
+        assert mc.value == 0
+        X2 = cs.dvec(synth.rhs(n, 3, 2))
+        assert F2.solve(X2)
+    assert np.max(np.abs(X2.numpy() - X3.numpy())) <= 1e-10 * np.max(np.abs(X3.numpy()))
+
+
+@pytest.mark.parametrize("strength, cores", [(0.3, 1), (0.9, 0)])
+def test_supernodal_triangles_leave_the_matrix_cores_when_a_diagonal_block_is_ill_conditioned(cs, strength, cores):
+    """The matrix-core triangles multiply by explicit inverses of the 16 x 16 diagonal blocks; the plan measures
+    || |inv(L_ii)| |L_ii| ||_inf for every block and keeps substitution when the largest exceeds 1e3.  A dense lower
+    triangle (one supernode of 536 columns above a leaf subtree of 64; more than the 512 columns a fused per-tree
+    kernel takes) that is I + small noise, except for one diagonal
+    block whose off-diagonal entries are all -`strength`: 0.3 -> growth ~ 1e2 (matrix cores), 0.9 -> ~ 1e4 (substitution).
+    Either way the solution agrees with the plain-C oracle at 1e-10."""
+    import _csx
+    lib = _csx.lib()
+    n = 600
+    rng = np.random.default_rng(11)
+    Ld = np.tril(0.003 * rng.uniform(-1, 1, (n, n)), -1) + np.eye(n)
+    blk = slice(96, 112)                                   # rows 32 .. 47 of the supernode that starts at column 64
+    Ld[blk, blk] = np.tril(np.full((16, 16), -strength), -1) + np.eye(16)   # inverse entries grow like (1 + s)^k
+    Lp = np.zeros(n + 1, np.int32)
+    Li, Lx = [], []
+    for j in range(n):
+        Li.append(np.arange(j, n, dtype=np.int32))
+        Lx.append(Ld[j:, j].copy())
+        Lp[j + 1] = Lp[j] + n - j
+    Li, Lx = np.concatenate(Li), np.concatenate(Lx)
+    hL = _csx.new_handle()
+    _csx.check(lib.csx_csc_upload(n, n, _csx.pi(Lp), _csx.pi(Li), _csx.pd(Lx), hL))
+    plan = _csx.new_handle()
+    _csx.check(lib.csx_cholsol_plan(hL, None, plan))
+    _csx.check(lib.csx_cholsol_set_order(plan, 0))
+    path, mc, growth = _csx.C.c_int32(-1), _csx.C.c_int32(-1), _csx.C.c_double(-1.0)
+    _csx.check(lib.csx_cholsol_info(plan, path, None, None))
+    assert path.value == 4
+    _csx.check(lib.csx_cholsol_sn_info(plan, None, None, None, mc, growth))
+    assert mc.value == cores
+    assert (growth.value <= 1e3) == bool(cores) and growth.value > 10
+    for k in (1, 5):
+        B = synth.rhs(n, k, 4)
+        X = cs.dvec(B)
+        _csx.check(lib.csx_cholsol_solve(plan, X.handle, k))
+        Xn = X.numpy().reshape(n, k)
+        for r in range(k):
+            ref = CO.ltsolve(n, Lp, Li, Lx, CO.lsolve(n, Lp, Li, Lx, B[:, r].copy()))
+            assert np.max(np.abs(Xn[:, r] - ref)) <= 1e-10 * np.max(np.abs(ref))
+    _csx.check(lib.csx_free(plan))
+    _csx.check(lib.csx_free(hL))
 
 
 def test_supernodal_schedule_refuses_a_triangle_that_is_not_a_cholesky_factor(cs):
