@@ -84,7 +84,8 @@ struct SnPlan {
     SnDir fwd, bwd;
     double *partial = nullptr;
     int64_t partial_len = 0;
-    double *frags = nullptr;                    // matrix-core fragments of every virtual supernode's triangle (k_sn_frags)
+    int4 *leaf4 = nullptr;                      // (first position in leaf_cols, columns, first fragment, 0) of every leaf subtree
+    double *frags = nullptr;                    // matrix-core fragments of every virtual supernode's and leaf subtree's triangle
     bool mfma = false;                          // fragments built and every block inverse tame: k_sn_mfma solves the triangles
     double growth = 0.0;                        // the guard's measure (k_sn_frags)
 };
@@ -93,7 +94,7 @@ void free_snplan(SnPlan *P) {
     if (!P) return;
     for (void *p : {(void *)P->vs_a, (void *)P->vs_w, (void *)P->leaf_ptr, (void *)P->leaf_cols, (void *)P->lf_ptr, (void *)P->lf_idx,
                     (void *)P->lb_ptr, (void *)P->lb_idx, (void *)P->lf_val, (void *)P->lb_val, (void *)P->ldiag, (void *)P->leaf_tasks,
-                    (void *)P->lslot_ptr, (void *)P->partial, (void *)P->frags})
+                    (void *)P->lslot_ptr, (void *)P->partial, (void *)P->frags, (void *)P->leaf4})
         dfree(p);
     for (SnDir *d : {&P->fwd, &P->bwd}) {
         dfree(d->tasks);
@@ -345,9 +346,16 @@ typedef double sn_f64x4 __attribute__((ext_vector_type(4)));
 
 __host__ __device__ constexpr int sn_tiles(int nb) { return nb * (nb + 1) / 2; }
 
-// one wave per virtual supernode: list entry (a, w, first fragment, -)
+// one wave per triangle: list entry (a, w, first fragment, -).
+// LEAF == false: a virtual supernode, columns a .. a + w - 1 of L (dense inside a supernode: column a + t is its diagonal, then
+// rows a + t + 1 ..).  LEAF == true: a leaf subtree, positions a .. a + w - 1 of leaf_cols; column k's in-subtree entries come
+// from the packed backward program (position of the row in the subtree, value) -- the subtree's triangle made dense, the
+// entries its pattern lacks being zeros.
+template <bool LEAF>
 __global__ __launch_bounds__(64) void k_sn_frags(const int4 *__restrict__ list, int32_t count, const int32_t *__restrict__ Lp,
-                                                 const double *__restrict__ Lx, double *__restrict__ frags,
+                                                 const double *__restrict__ Lx, const int32_t *__restrict__ lb_ptr,
+                                                 const int32_t *__restrict__ lb_idx, const double *__restrict__ lb_val,
+                                                 const double *__restrict__ ldiag, double *__restrict__ frags,
                                                  unsigned long long *cond_bits) {
     __shared__ double Ls[64][65];
     __shared__ double Wm[4][16][17];
@@ -356,11 +364,21 @@ __global__ __launch_bounds__(64) void k_sn_frags(const int4 *__restrict__ list, 
     const int4 ent = list[blockIdx.x];
     const int32_t a = ent.x, w = ent.y;
     const int nb = (w + 15) >> 4;
-    for (int e = lane; e < 64 * 64; e += 64) {
-        const int i = e >> 6, t = e & 63;               // row i, column t of the triangle
-        double v = i == t ? 1.0 : 0.0;
-        if (i < w && t <= i) v = Lx[Lp[a + t] + (i - t)];   // column a + t: diagonal, then rows a + t + 1 .. (dense inside a supernode)
-        Ls[i][t] = v;
+    if (LEAF) {
+        for (int e = lane; e < 64 * 64; e += 64) Ls[e >> 6][e & 63] = (e >> 6) == (e & 63) ? 1.0 : 0.0;
+        __syncthreads();
+        for (int k = 0; k < w; k++) {                   // column k of the subtree: distinct rows, so no two lanes meet
+            const int32_t b = lb_ptr[a + k], l = lb_ptr[a + k + 1] - b;
+            if (lane < l) Ls[lb_idx[b + lane]][k] = lb_val[b + lane];
+            if (lane == 0) Ls[k][k] = ldiag[a + k];
+        }
+    } else {
+        for (int e = lane; e < 64 * 64; e += 64) {
+            const int i = e >> 6, t = e & 63;               // row i, column t of the triangle
+            double v = i == t ? 1.0 : 0.0;
+            if (i < w && t <= i) v = Lx[Lp[a + t] + (i - t)];
+            Ls[i][t] = v;
+        }
     }
     __syncthreads();
     __shared__ double rsum[64];
@@ -406,9 +424,10 @@ __global__ __launch_bounds__(64) void k_sn_frags(const int4 *__restrict__ list, 
     if (lane == 0) atomicMax(cond_bits, (unsigned long long)__double_as_longlong(growth));   // ordered bits of a non-negative double
 }
 
-template <bool FWD>
-__global__ __launch_bounds__(64) void k_sn_mfma(const int4 *__restrict__ list, int32_t first, const double *__restrict__ frags,
-                                                double *X, int nrhs) {
+// GATHER: the rows of X are rows[a .. a + w) (a leaf subtree's columns) instead of a .. a + w - 1
+template <bool FWD, bool GATHER>
+__global__ __launch_bounds__(64) void k_sn_mfma(const int4 *__restrict__ list, int32_t first, const int32_t *__restrict__ rows,
+                                                const double *__restrict__ frags, double *X, int nrhs) {
     const int lane = threadIdx.x;
     const int nblk = (nrhs + 63) >> 6;
     const int4 ent = list[first + blockIdx.x / nblk];
@@ -430,13 +449,22 @@ __global__ __launch_bounds__(64) void k_sn_mfma(const int4 *__restrict__ list, i
     for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int c = 0; c < 4; c++) Xt[i][c] = sn_f64x4{0.0, 0.0, 0.0, 0.0};
+    int64_t roff[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = 16 * i + rq + 4 * r;
+            const int32_t at = a + (row < w ? row : 0);
+            roff[i][r] = (int64_t)(GATHER ? (i < nb ? rows[at] : 0) : at) * nrhs;
+        }
 #pragma unroll
     for (int i = 0; i < 4; i++)
         if (i < nb) {
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int row = 16 * i + rq + 4 * r;
-                const double *src = X + (int64_t)(a + (row < w ? row : 0)) * nrhs;
+                const double *src = X + roff[i][r];
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
                     const double v = src[cidx[c]];
@@ -509,7 +537,7 @@ __global__ __launch_bounds__(64) void k_sn_mfma(const int4 *__restrict__ list, i
             for (int r = 0; r < 4; r++) {
                 const int row = 16 * i + rq + 4 * r;
                 if (row < w) {
-                    double *dst = X + (int64_t)(a + row) * nrhs;
+                    double *dst = X + roff[i][r];
 #pragma unroll
                     for (int c = 0; c < 4; c++)
                         if (live[c]) dst[cidx[c]] = Xt[i][c][r];
@@ -977,17 +1005,31 @@ int sn_build(const Csc *L, const int32_t *parent, const int32_t *Lp_h, const int
     // ---- matrix-core fragments of every triangle (every virtual supernode is in exactly one forward step) ----
     double growth = 0.0;
     if (st == CSX_OK && ctx().opt.tri_supernodes == 1) {
-        const size_t nfrag = (size_t)vs_f.back(), nv = vs_a.size();
+        const size_t nv = vs_a.size();
+        std::vector<int4> leaf4((size_t)nleaf);
+        int64_t at = vs_f.back();
+        for (int32_t t = 0; t < nleaf; t++) {
+            const int32_t cnt = leaf_ptr[(size_t)t + 1] - leaf_ptr[(size_t)t];
+            leaf4[(size_t)t] = make_int4(leaf_ptr[(size_t)t], cnt, (int32_t)at, 0);
+            at += sn_tiles((cnt + 15) / 16) * 4;
+        }
+        const size_t nfrag = (size_t)at;
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
-        if (nfrag * 512 <= free_b / 4) {
+        if (nfrag * 512 <= free_b / 4 && at < 0x7fffffff) {
             DevScope tmp;
             unsigned long long *d_cond = nullptr, h_cond = 0;
             st = dalloc(&P->frags, nfrag * 64 + 64);
+            if (st == CSX_OK) st = up(&P->leaf4, leaf4);
             if (st == CSX_OK) st = tmp.alloc(&d_cond, 1);
             if (st == CSX_OK && hipMemsetAsync(d_cond, 0, sizeof(unsigned long long), s) != hipSuccess) st = CSX_ERUNTIME;
             if (st == CSX_OK) {
-                hipLaunchKernelGGL(k_sn_frags, dim3((unsigned)nv), dim3(64), 0, s, P->fwd.tri4, (int32_t)nv, L->p, L->x, P->frags, d_cond);
+                hipLaunchKernelGGL(k_sn_frags<false>, dim3((unsigned)nv), dim3(64), 0, s, P->fwd.tri4, (int32_t)nv, L->p, L->x,
+                                   (const int32_t *)nullptr, (const int32_t *)nullptr, (const double *)nullptr, (const double *)nullptr,
+                                   P->frags, d_cond);
+                if (nleaf > 0)
+                    hipLaunchKernelGGL(k_sn_frags<true>, dim3((unsigned)nleaf), dim3(64), 0, s, P->leaf4, nleaf, L->p, L->x, P->lb_ptr,
+                                       P->lb_idx, P->lb_val, P->ldiag, P->frags, d_cond);
                 if (hipMemcpyAsync(&h_cond, d_cond, sizeof(h_cond), hipMemcpyDeviceToHost, s) != hipSuccess ||
                     hipStreamSynchronize(s) != hipSuccess)
                     st = CSX_ERUNTIME;
@@ -1053,7 +1095,11 @@ int sn_solve(SnPlan *P, bool forward, const int32_t *Gp, const int32_t *Gi, cons
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sn_tri_lds<SN_CHUNK>()));
         lds_set = true;
     }
-    if (forward && P->nleaf)
+    const bool cores = P->mfma && ctx().opt.tri_supernodes == 1;
+    if (forward && P->nleaf && cores)
+        hipLaunchKernelGGL((k_sn_mfma<true, true>), dim3((unsigned)(P->nleaf * nblk)), dim3(64), 0, s, P->leaf4, 0, P->leaf_cols, P->frags,
+                           X, nrhs);
+    else if (forward && P->nleaf)
         hipLaunchKernelGGL(k_sn_leaf<true>, dim3((unsigned)(P->nleaf * nblk)), dim3(64), 0, s, P->leaf_ptr, P->leaf_cols, P->lf_ptr,
                            P->lf_idx, P->lf_val, P->ldiag, (const int32_t *)nullptr, (const double *)nullptr, X, nrhs);
     for (const SnStep &t : D.steps) {
@@ -1067,12 +1113,14 @@ int sn_solve(SnPlan *P, bool forward, const int32_t *Gp, const int32_t *Gi, cons
             hipLaunchKernelGGL(k_sn_combine, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, D.comb, t.c0, t.cc, D.part_ptr, 0,
                                P->partial, X, nrhs);
         }
-        if (P->mfma && ctx().opt.tri_supernodes == 1) {
+        if (cores) {
             if (t.qc > 0) {
                 if (forward)
-                    hipLaunchKernelGGL(k_sn_mfma<true>, dim3((unsigned)(t.qc * nblk)), dim3(64), 0, s, D.tri4, t.q0, P->frags, X, nrhs);
+                    hipLaunchKernelGGL((k_sn_mfma<true, false>), dim3((unsigned)(t.qc * nblk)), dim3(64), 0, s, D.tri4, t.q0,
+                                       (const int32_t *)nullptr, P->frags, X, nrhs);
                 else
-                    hipLaunchKernelGGL(k_sn_mfma<false>, dim3((unsigned)(t.qc * nblk)), dim3(64), 0, s, D.tri4, t.q0, P->frags, X, nrhs);
+                    hipLaunchKernelGGL((k_sn_mfma<false, false>), dim3((unsigned)(t.qc * nblk)), dim3(64), 0, s, D.tri4, t.q0,
+                                       (const int32_t *)nullptr, P->frags, X, nrhs);
             }
         } else if (forward) {
             if (t.sc > 0)
@@ -1106,8 +1154,12 @@ int sn_solve(SnPlan *P, bool forward, const int32_t *Gp, const int32_t *Gi, cons
             hipLaunchKernelGGL(k_sn_combine, dim3((unsigned)((cw + 3) / 4)), dim3(256), 0, s, P->leaf_cols, 0, P->nleafcols, P->lslot_ptr, 1,
                                P->partial + (int64_t)P->bwd.nslots * nrhs, X, nrhs);
         }
-        hipLaunchKernelGGL(k_sn_leaf<false>, dim3((unsigned)(P->nleaf * nblk)), dim3(64), 0, s, P->leaf_ptr, P->leaf_cols, P->lb_ptr,
-                           P->lb_idx, P->lb_val, P->ldiag, (const int32_t *)nullptr, (const double *)nullptr, X, nrhs);
+        if (cores)
+            hipLaunchKernelGGL((k_sn_mfma<false, true>), dim3((unsigned)(P->nleaf * nblk)), dim3(64), 0, s, P->leaf4, 0, P->leaf_cols,
+                               P->frags, X, nrhs);
+        else
+            hipLaunchKernelGGL(k_sn_leaf<false>, dim3((unsigned)(P->nleaf * nblk)), dim3(64), 0, s, P->leaf_ptr, P->leaf_cols, P->lb_ptr,
+                               P->lb_idx, P->lb_val, P->ldiag, (const int32_t *)nullptr, (const double *)nullptr, X, nrhs);
     }
     CSX_LAUNCH_CHECK();
     return CSX_OK;
