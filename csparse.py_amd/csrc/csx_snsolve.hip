@@ -32,6 +32,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -68,6 +69,7 @@ struct SnDir {
     int32_t *wide = nullptr;         // device
     int32_t *part_ptr = nullptr;     // device [n + 1]: partial slots of a row / column
     int4 *tri4 = nullptr;            // device: (first column, width, first fragment, 0) of every virtual supernode, by step
+    std::vector<int4> tri_h;         // the same on the host: a step of one triangle passes its entry with the launch
     int32_t nslots = 0;
 };
 
@@ -425,30 +427,37 @@ __global__ __launch_bounds__(64) void k_sn_frags(const int4 *__restrict__ list, 
 }
 
 // GATHER: the rows of X are rows[a .. a + w) (a leaf subtree's columns) instead of a .. a + w - 1
-template <bool FWD, bool GATHER>
-__global__ __launch_bounds__(64) void k_sn_mfma(const int4 *__restrict__ list, int32_t first, const int32_t *__restrict__ rows,
-                                                const double *__restrict__ frags, double *X, int nrhs) {
-    const int lane = threadIdx.x;
+// CT = 4: one wave per (triangle, 64 right-hand sides), four column tiles in its registers.  CT = 1: a wave per column tile of
+// 16 right-hand sides (a workgroup of up to four waves per block of 64): each wave's chain of dependent matrix
+// instructions is a quarter as long, which is what a step with a handful of triangles is made of.
+// use0: the step has ONE triangle and its descriptor came with the launch (ent0) instead of through a load.
+template <bool FWD, bool GATHER, int CT>
+__global__ __launch_bounds__(256) void k_sn_mfma(const int4 *__restrict__ list, int32_t first, const int4 ent0, const int use0,
+                                                 const int32_t *__restrict__ rows, const double *__restrict__ frags, double *X,
+                                                 int nrhs) {
+    const int lane = threadIdx.x & 63;
+    const int cbase = CT == 4 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nblk = (nrhs + 63) >> 6;
-    const int4 ent = list[first + blockIdx.x / nblk];
     const int h = (int)(blockIdx.x % nblk);
+    if (h * 64 + 16 * cbase >= nrhs) return;            // a column tile past the last right-hand side
+    const int4 ent = use0 ? ent0 : list[first + blockIdx.x / nblk];
     const int32_t a = ent.x, w = ent.y;
     const int nb = (w + 15) >> 4;                       // uniform
     const int col = lane & 15, rq = lane >> 4;
-    bool live[4];
-    int32_t cidx[4];
+    bool live[CT];
+    int32_t cidx[CT];
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
-        const int32_t rhs = h * 64 + 16 * c + col;
+    for (int c = 0; c < CT; c++) {
+        const int32_t rhs = h * 64 + 16 * (cbase + c) + col;
         live[c] = rhs < nrhs;
         cidx[c] = live[c] ? rhs : nrhs - 1;             // clamped: loaded, never stored
     }
     // lane (rq, col), register r of tile (i, c): row 16 i + rq + 4 r of the supernode, right-hand side 16 c + col
-    sn_f64x4 Xt[4][4];
+    sn_f64x4 Xt[4][CT];
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int c = 0; c < 4; c++) Xt[i][c] = sn_f64x4{0.0, 0.0, 0.0, 0.0};
+        for (int c = 0; c < CT; c++) Xt[i][c] = sn_f64x4{0.0, 0.0, 0.0, 0.0};
     int64_t roff[4][4];
 #pragma unroll
     for (int i = 0; i < 4; i++)
@@ -466,7 +475,7 @@ __global__ __launch_bounds__(64) void k_sn_mfma(const int4 *__restrict__ list, i
                 const int row = 16 * i + rq + 4 * r;
                 const double *src = X + roff[i][r];
 #pragma unroll
-                for (int c = 0; c < 4; c++) {
+                for (int c = 0; c < CT; c++) {
                     const double v = src[cidx[c]];
                     Xt[i][c][r] = row < w ? v : 0.0;    // rows past w: those of the identity block, kept at zero
                 }
@@ -488,19 +497,19 @@ __global__ __launch_bounds__(64) void k_sn_mfma(const int4 *__restrict__ list, i
                     for (int sx = 0; sx < 4; sx++) {
                         const double av = F[64 * f++];
 #pragma unroll
-                        for (int c = 0; c < 4; c++) Xt[i][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Xt[j][c][sx], Xt[i][c], 0, 0, 0);
+                        for (int c = 0; c < CT; c++) Xt[i][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Xt[j][c][sx], Xt[i][c], 0, 0, 0);
                     }
-                sn_f64x4 Y[4];
+                sn_f64x4 Y[CT];
 #pragma unroll
-                for (int c = 0; c < 4; c++) Y[c] = sn_f64x4{0.0, 0.0, 0.0, 0.0};
+                for (int c = 0; c < CT; c++) Y[c] = sn_f64x4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int sx = 0; sx < 4; sx++) {
                     const double av = F[64 * f++];
 #pragma unroll
-                    for (int c = 0; c < 4; c++) Y[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Xt[i][c][sx], Y[c], 0, 0, 0);
+                    for (int c = 0; c < CT; c++) Y[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Xt[i][c][sx], Y[c], 0, 0, 0);
                 }
 #pragma unroll
-                for (int c = 0; c < 4; c++) Xt[i][c] = Y[c];
+                for (int c = 0; c < CT; c++) Xt[i][c] = Y[c];
             }
     } else {
 #pragma unroll
@@ -513,21 +522,21 @@ __global__ __launch_bounds__(64) void k_sn_mfma(const int4 *__restrict__ list, i
                         for (int sx = 0; sx < 4; sx++) {
                             const double av = Ft[(size_t)tile_at(j, i) * 64 + 4 * sx];   // -L_ji' from the stored -L_ji
 #pragma unroll
-                            for (int c = 0; c < 4; c++)
+                            for (int c = 0; c < CT; c++)
                                 Xt[i][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Xt[j][c][sx], Xt[i][c], 0, 0, 0);
                         }
                     }
-                sn_f64x4 Y[4];
+                sn_f64x4 Y[CT];
 #pragma unroll
-                for (int c = 0; c < 4; c++) Y[c] = sn_f64x4{0.0, 0.0, 0.0, 0.0};
+                for (int c = 0; c < CT; c++) Y[c] = sn_f64x4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int sx = 0; sx < 4; sx++) {
                     const double av = Ft[(size_t)tile_at(i, i) * 64 + 4 * sx];           // W_ii' from the stored W_ii
 #pragma unroll
-                    for (int c = 0; c < 4; c++) Y[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Xt[i][c][sx], Y[c], 0, 0, 0);
+                    for (int c = 0; c < CT; c++) Y[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Xt[i][c][sx], Y[c], 0, 0, 0);
                 }
 #pragma unroll
-                for (int c = 0; c < 4; c++) Xt[i][c] = Y[c];
+                for (int c = 0; c < CT; c++) Xt[i][c] = Y[c];
             }
     }
 #pragma unroll
@@ -539,7 +548,7 @@ __global__ __launch_bounds__(64) void k_sn_mfma(const int4 *__restrict__ list, i
                 if (row < w) {
                     double *dst = X + roff[i][r];
 #pragma unroll
-                    for (int c = 0; c < 4; c++)
+                    for (int c = 0; c < CT; c++)
                         if (live[c]) dst[cidx[c]] = Xt[i][c][r];
                 }
             }
@@ -994,6 +1003,7 @@ int sn_build(const Csc *L, const int32_t *parent, const int32_t *Lp_h, const int
         CSX_TRY(up(&D.wide, wide));
         CSX_TRY(up(&D.part_ptr, part));
         CSX_TRY(up(&D.tri4, tri));
+        D.tri_h = std::move(tri);
         return CSX_OK;
     };
     if (st == CSX_OK) st = build(P->fwd, height, true);
@@ -1096,9 +1106,23 @@ int sn_solve(SnPlan *P, bool forward, const int32_t *Gp, const int32_t *Gi, cons
         lds_set = true;
     }
     const bool cores = P->mfma && ctx().opt.tri_supernodes == 1;
+    // `count` triangles of a list from `first` on: few of them -> a wave per column tile of 16 right-hand sides (the dependent
+    // chain of a step is what counts), many -> a wave per 64 (fewer workgroups, every fragment read once)
+    auto triangles = [&](auto fwd_tag, auto gather_tag, const int4 *list, const std::vector<int4> *host, int32_t first, int32_t count,
+                         const int32_t *rows) {
+        constexpr bool F = decltype(fwd_tag)::value, G = decltype(gather_tag)::value;
+        const int4 ent0 = host && count == 1 ? (*host)[(size_t)first] : make_int4(0, 0, 0, 0);
+        const int use0 = host && count == 1 ? 1 : 0;
+        const unsigned grid = (unsigned)((int64_t)count * nblk);
+        if ((int64_t)count * nblk <= 512) {
+            const int tiles = std::min(4, (nrhs + 15) / 16);
+            hipLaunchKernelGGL((k_sn_mfma<F, G, 1>), dim3(grid), dim3(64 * tiles), 0, s, list, first, ent0, use0, rows, P->frags, X, nrhs);
+        } else {
+            hipLaunchKernelGGL((k_sn_mfma<F, G, 4>), dim3(grid), dim3(64), 0, s, list, first, ent0, use0, rows, P->frags, X, nrhs);
+        }
+    };
     if (forward && P->nleaf && cores)
-        hipLaunchKernelGGL((k_sn_mfma<true, true>), dim3((unsigned)(P->nleaf * nblk)), dim3(64), 0, s, P->leaf4, 0, P->leaf_cols, P->frags,
-                           X, nrhs);
+        triangles(std::true_type{}, std::true_type{}, P->leaf4, nullptr, 0, P->nleaf, P->leaf_cols);
     else if (forward && P->nleaf)
         hipLaunchKernelGGL(k_sn_leaf<true>, dim3((unsigned)(P->nleaf * nblk)), dim3(64), 0, s, P->leaf_ptr, P->leaf_cols, P->lf_ptr,
                            P->lf_idx, P->lf_val, P->ldiag, (const int32_t *)nullptr, (const double *)nullptr, X, nrhs);
@@ -1115,12 +1139,8 @@ int sn_solve(SnPlan *P, bool forward, const int32_t *Gp, const int32_t *Gi, cons
         }
         if (cores) {
             if (t.qc > 0) {
-                if (forward)
-                    hipLaunchKernelGGL((k_sn_mfma<true, false>), dim3((unsigned)(t.qc * nblk)), dim3(64), 0, s, D.tri4, t.q0,
-                                       (const int32_t *)nullptr, P->frags, X, nrhs);
-                else
-                    hipLaunchKernelGGL((k_sn_mfma<false, false>), dim3((unsigned)(t.qc * nblk)), dim3(64), 0, s, D.tri4, t.q0,
-                                       (const int32_t *)nullptr, P->frags, X, nrhs);
+                if (forward) triangles(std::true_type{}, std::false_type{}, D.tri4, &D.tri_h, t.q0, t.qc, nullptr);
+                else triangles(std::false_type{}, std::false_type{}, D.tri4, &D.tri_h, t.q0, t.qc, nullptr);
             }
         } else if (forward) {
             if (t.sc > 0)
@@ -1155,8 +1175,7 @@ int sn_solve(SnPlan *P, bool forward, const int32_t *Gp, const int32_t *Gi, cons
                                P->partial + (int64_t)P->bwd.nslots * nrhs, X, nrhs);
         }
         if (cores)
-            hipLaunchKernelGGL((k_sn_mfma<false, true>), dim3((unsigned)(P->nleaf * nblk)), dim3(64), 0, s, P->leaf4, 0, P->leaf_cols,
-                               P->frags, X, nrhs);
+            triangles(std::false_type{}, std::true_type{}, P->leaf4, nullptr, 0, P->nleaf, P->leaf_cols);
         else
             hipLaunchKernelGGL(k_sn_leaf<false>, dim3((unsigned)(P->nleaf * nblk)), dim3(64), 0, s, P->leaf_ptr, P->leaf_cols, P->lb_ptr,
                                P->lb_idx, P->lb_val, P->ldiag, (const int32_t *)nullptr, (const double *)nullptr, X, nrhs);
