@@ -36,6 +36,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
+#include <utility>
 
 #include "csx_internal.h"
 #include "csx_sweep.h"
@@ -1301,6 +1303,77 @@ __device__ __forceinline__ void dense_exact_pass(double (&x)[R][BS], const doubl
 #undef CSX_XI
 }
 
+// The same pass with the L values delivered by DPP instead of by broadcast reads.  What bounds the passes above is the LDS
+// return path: a broadcast read hands 64 x 16 bytes to the wave to deliver TWO doubles (8 clk per read on a path the four
+// SIMDs of a CU share: 4.2 ms per 128 right-hand sides at blocks of 64, twice the 2.1 ms the fp64 operations need).  The
+// 64-bit move of this chip takes one DPP control, row_newbcast:k -- every lane receives the value lane k of its ROW of 16
+// lanes holds.  So the 16 lanes of a row read 16 consecutive L values of the matrix row being solved (one ds_read_b64 per
+// 16 terms, the four rows reading the same 128 bytes), and term k is
+//     v_mov_b64_dpp b, Lv row_newbcast:k ;  v_mul_f64 t, b, x_k ;  v_add_f64 acc, acc, -t
+// -- the reference's two separately rounded operations plus one register move; no broadcast read, no v_readlane, no scalar
+// load.  (v_mul_f64 / v_add_f64 are VOP3 and have no DPP form on this ISA; v_fmac_f64 has one, but it fuses.)  A row's L
+// values and diagonal are requested while the previous row is being solved.
+template <int K>
+__device__ __forceinline__ double dpp_row_bcast(const double v) {
+    return __longlong_as_double(__builtin_amdgcn_mov_dpp(__double_as_longlong(v), 0x150 + K, 0xf, 0xf, true));
+}
+
+// term E of sweep row SP; the L values of a group of 16 terms die with the group's last term, and the same group of the
+// NEXT row is requested there: four values live instead of eight (168 VGPRs is three waves per SIMD at blocks of 64)
+template <int BS, bool BACKWARD, int SP, int E>
+__device__ __forceinline__ void dense_exact_term_dpp(const double (&x)[BS], const double *Ml, const double (&lv)[4], double (&nxt)[4],
+                                                     double &acc) {
+    constexpr int G = E >> 4, NS = SP + 1;
+    const double t = dpp_row_bcast<(E & 15)>(lv[G]) * x[BACKWARD ? BS - 1 - E : E];
+    acc = acc - t;
+    constexpr bool last_of_group = BACKWARD ? (E & 15) == 0 : ((E & 15) == 15 || E == SP - 1);
+    if constexpr (last_of_group && NS < BS) nxt[G] = Ml[NS * (NS - 1) / 2 + 16 * G];
+    // a row's products are independent of each other: left alone the scheduler forms dozens of them ahead of the
+    // subtraction chain and spills; four at a time is ahead enough
+    if constexpr ((E & 3) == (BACKWARD ? 0 : 3) || last_of_group) __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int BS, bool BACKWARD, int SP, int... I>
+__device__ __forceinline__ void dense_exact_terms_dpp(const double (&x)[BS], const double *Ml, const double (&lv)[4], double (&nxt)[4],
+                                                      double &acc, std::integer_sequence<int, I...>) {
+    // the reference's order: ascending columns forward, descending (in sweep numbering) backward
+    (dense_exact_term_dpp<BS, BACKWARD, SP, (BACKWARD ? SP - 1 - I : I)>(x, Ml, lv, nxt, acc), ...);
+}
+
+// sweep row SP: cur = its L values (lane l: entry 16 g + (l & 15) of the packed row), dv its diagonal; requests row SP + 1
+template <int BS, bool BACKWARD, int SP>
+__device__ __forceinline__ void dense_exact_row_dpp(double (&x)[BS], const double *Ml, const double *D, const double (&cur)[4],
+                                                    double (&nxt)[4], const double dv, double &dnext) {
+    constexpr int NS = SP + 1;
+    if constexpr (NS < BS) {
+        // a group the next row has and this one has not (its first term is this row's unknown)
+        if constexpr ((NS + 15) / 16 > (SP + 15) / 16) nxt[(SP + 15) / 16] = Ml[NS * (NS - 1) / 2 + 16 * ((SP + 15) / 16)];
+        dnext = D[NS];
+    }
+    double acc = x[BACKWARD ? BS - 1 - SP : SP];
+    dense_exact_terms_dpp<BS, BACKWARD, SP>(x, Ml, cur, nxt, acc, std::make_integer_sequence<int, SP>{});
+    double xr = acc / dv;
+    // the row's arithmetic is pure: nothing but its data dependences holds it in place, and the instruction selector sank
+    // whole rows of it behind the moves of later rows (256 VGPRs and spills at blocks of 16).  An empty volatile asm that
+    // "rewrites" the row's result ties the arithmetic to this point; the memory clobber does the same for the LDS reads.
+    asm volatile("" : "+v"(xr) : : "memory");
+    x[BACKWARD ? BS - 1 - SP : SP] = xr;
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int BS, bool BACKWARD, int... SP>
+__device__ __forceinline__ void dense_exact_rows_dpp(double (&x)[BS], const double *Ml, const double *D,
+                                                     std::integer_sequence<int, SP...>) {
+    double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};   // L values of the even / odd sweep rows
+    double da = D[0], db = 1.0;                                         // and their diagonals
+    (dense_exact_row_dpp<BS, BACKWARD, SP>(x, Ml, D, (SP & 1) ? b : a, (SP & 1) ? a : b, (SP & 1) ? db : da, (SP & 1) ? da : db), ...);
+}
+
+template <int BS, bool BACKWARD>
+__device__ __forceinline__ void dense_exact_pass_dpp(double (&x)[BS], const double *M, const double *D, const int lane) {
+    dense_exact_rows_dpp<BS, BACKWARD>(x, M + (lane & 15), D, std::make_integer_sequence<int, BS>{});
+}
+
 // second launch-bound argument = waves per SIMD the register allocation must leave room for: without it the
 // scheduler spends 284-512 VGPRs on hoisted loads (one wave per SIMD, spills at BS = 32).  R = 2 (two right-hand sides
 // per lane, a task = a block x 128 right-hand sides): one wave per SIMD, 2 x BS unknowns in registers.
@@ -1385,6 +1458,71 @@ __global__ __launch_bounds__(256, (RING || R == 2 ? 1 : 2)) void k_cholsol_dense
 #pragma unroll
         for (int r = 0; r < R; r++)
             if (live[r]) B[(int64_t)row * nrhs + rhs[r]] = x[r][a];
+    }
+}
+// The DPP form as a kernel of its own.  Its 158 VGPRs allow three waves per SIMD at blocks of 64, the LDS copy of the block
+// (16.6 KB) does not if every wave stages its own (4 x 16.6 KB per workgroup: two workgroups per CU).  Waves of a
+// workgroup that solve the SAME block for different right-hand sides share one copy: SHARE = blocks per workgroup
+// (4, 2 or 1), 4 / SHARE waves per block, each staging its share of the DMA; two workgroup barriers per pass.
+template <int BS, int SHARE>
+__global__ __launch_bounds__(256, 3) void k_cholsol_dense_exact_dpp(const Tree *__restrict__ trees, int32_t ntrees,
+                                                                    const int32_t *__restrict__ nodes, const int32_t *__restrict__ perm,
+                                                                    const int32_t *__restrict__ f_ptr, const double *__restrict__ f_val,
+                                                                    const int32_t *__restrict__ b_ptr, const double *__restrict__ b_val,
+                                                                    const double *__restrict__ diagf, const double *__restrict__ diagb,
+                                                                    double *B, int32_t nrhs, int32_t chunks) {
+    constexpr int NT = BS * (BS - 1) / 2;
+    constexpr int MSZ = ((NT + 127) / 128 * 128 > NT + BS) ? (NT + 127) / 128 * 128 : NT + BS;
+    constexpr int WPT = 4 / SHARE;                          // waves per block
+    __shared__ __attribute__((aligned(16))) double s_m[SHARE][MSZ];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int slot = w / WPT, sub = w % WPT;
+    const int32_t cgroups = chunks / WPT;                   // the host launches this SHARE only when WPT divides chunks
+    const int32_t tg = (int32_t)(blockIdx.x / cgroups), cg = (int32_t)(blockIdx.x % cgroups);
+    const int32_t t_raw = tg * SHARE + slot, h = cg * WPT + sub;
+    const bool valid = t_raw < ntrees;                      // a workgroup past the last block still meets the barriers
+    const int32_t t = valid ? t_raw : ntrees - 1;
+    const int32_t first = trees[t].first;
+    const int32_t rhs = h * 64 + lane;
+    const bool live = valid && rhs < nrhs;
+    const int32_t rhs_ld = rhs < nrhs ? rhs : nrhs - 1;
+    double *M = s_m[slot], *DG = s_m[slot] + NT;            // DG overlaps the DMA overrun and is written after it
+    int32_t jrow = 0;
+    if (lane < BS) {
+        jrow = nodes[first + lane];
+        if (perm) jrow = perm[jrow];
+    }
+    double x[BS];
+#pragma unroll
+    for (int a = 0; a < BS; a++) {
+        const int32_t row = __builtin_amdgcn_readlane(jrow, a);
+        x[a] = B[(int64_t)row * nrhs + rhs_ld];
+    }
+    auto run_pass = [&](auto pass_tag) {
+        constexpr int pass = decltype(pass_tag)::value;
+        const int32_t *ptr = pass ? b_ptr : f_ptr;
+        const double *val = pass ? b_val : f_val;           // b_val here is the row-reversed dense copy
+        const double *dg = pass ? diagb : diagf;
+        const int32_t base = ptr[first];
+        const double dv = lane < BS ? dg[first + lane] : 1.0;
+        if (pass) __syncthreads();                          // every wave of the block is done with the forward copy
+#pragma unroll
+        for (int k = 0; k < (NT + 127) / 128; k++)
+            if (k % WPT == sub)
+                __builtin_amdgcn_global_load_lds((csx_gptr)(val + base + k * 128 + 2 * lane), (csx_lptr)(M + k * 128), 16, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                    // all shares of the copy have landed
+        if (sub == 0 && lane < BS) DG[lane] = dv;           // behind the DMA overrun of the last chunk
+        __syncthreads();
+        dense_exact_pass_dpp<BS, pass == 1>(x, M, DG, lane);
+    };
+    run_pass(std::integral_constant<int, 0>{});
+    run_pass(std::integral_constant<int, 1>{});
+#pragma unroll
+    for (int a = 0; a < BS; a++) {
+        const int32_t row = __builtin_amdgcn_readlane(jrow, a);
+        if (live) B[(int64_t)row * nrhs + rhs] = x[a];
     }
 }
 #pragma clang fp contract(fast)
@@ -1815,17 +1953,40 @@ static int cholsol_solve(CholPlan *P, double *B, int32_t nrhs) {
         if (st != CSX_OK) return st;
         // Forests of dense blocks: the default (exact) order runs the substitution kernel that keeps the reference's
         // operations and their order; the rounding-equal order the FMA / matrix-core kernels.
-        // (blocks of 32: every register-resident variant of the substitution kernel compiles to heavy spilling -- 40 ms per
-        // 128 right-hand sides on 5M rows against 9.6 ms for the fused per-tree kernel below, which is just as exact)
-        if (P->dense_bs && !P->relaxed && ctx().opt.cholsol_dense_blocks &&
-            (P->dense_bs != 32 || ctx().opt.cholsol_exact_variant != 0)) {
-            // Variants, chosen per block size from measurements on G-spd (5M rows, 128 right-hand sides, ms per batch;
-            // profiles/r03_ablation.md section 3): the L values through a ring of registers filled 12 terms ahead (RING)
-            // against one fence per row; one or two right-hand sides per lane ("cholsol.exact_variant": 0 = the table
-            // below, 1 = rows / 1, 2 = ring / 1, 3 = rows / 2, 4 = ring / 2; two per lane only for blocks <= 32).
+        if (P->dense_bs && !P->relaxed && ctx().opt.cholsol_dense_blocks) {
+            // Variants ("cholsol.exact_variant"; measurements on G-spd, 5M rows, 128 right-hand sides, in
+            // profiles/r03_ablation.md section 3): 0 / 5 = the L values by DPP row broadcast (the default for every block
+            // size: 5.1 / 3.1 / 2.2 / 2.0 ms at blocks of 64 / 32 / 16 / 8); the LDS-broadcast forms it replaced: 1 = one
+            // fence per row / one right-hand side per lane, 2 = the L values through a ring of registers, 3 = rows / two per
+            // lane, 4 = ring / two per lane (two per lane only for blocks <= 32; at blocks of 32 these four compile to scratch).
             const int want = ctx().opt.cholsol_exact_variant;
-            int variant = P->dense_bs == 64 ? 1 : 2;
-            if (want >= 1 && want <= 4) variant = want;
+            int variant = 5;
+            if (want >= 1 && want <= 5) variant = want;
+            if (variant == 5) {
+                // the L values by DPP row broadcast: one right-hand side per lane; waves that solve the same block share its
+                // LDS copy (as many as divide the number of 64-wide chunks of right-hand sides)
+                const int32_t chunks = (nrhs + 63) / 64;
+                const int share = chunks % 4 == 0 ? 1 : chunks % 2 == 0 ? 2 : 4;
+                const int64_t groups = ((int64_t)P->ntrees + share - 1) / share * (chunks / (4 / share));
+                const dim3 grid((unsigned)groups);
+#define CSX_DPP_X(BS, SH)                                                                                                          \
+    hipLaunchKernelGGL((k_cholsol_dense_exact_dpp<BS, SH>), grid, dim3(256), 0, s, P->trees, P->ntrees, P->tree_nodes, P->perm, \
+                       P->f_ptr, P->f_val, P->b_ptr, P->dense_b, P->diagk, P->diagb, B, nrhs, chunks)
+#define CSX_DPP_V(BS)                          \
+    if (share == 1) CSX_DPP_X(BS, 1);          \
+    else if (share == 2) CSX_DPP_X(BS, 2);     \
+    else CSX_DPP_X(BS, 4)
+                switch (P->dense_bs) {
+                    case 8: CSX_DPP_V(8); break;
+                    case 16: CSX_DPP_V(16); break;
+                    case 32: CSX_DPP_V(32); break;
+                    default: CSX_DPP_V(64); break;
+                }
+#undef CSX_DPP_V
+#undef CSX_DPP_X
+                CSX_LAUNCH_CHECK();
+                return CSX_OK;
+            }
             if (P->dense_bs == 64 && variant > 2) variant -= 2;
             if (nrhs <= 64 && variant > 2) variant -= 2;
             const int R = variant > 2 ? 2 : 1;

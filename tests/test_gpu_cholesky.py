@@ -766,9 +766,9 @@ def test_supernodal_schedule_refuses_a_triangle_that_is_not_a_cholesky_factor(cs
 
 @pytest.mark.parametrize("bs", [8, 16, 32, 64])
 def test_exact_dense_block_kernel_variants_all_have_the_reference_bits(cs, bs):
-    """The default (exact) order on forests of dense blocks has four kernel variants (one fence per row or the L values
-    through a register ring; one or two right-hand sides per lane), picked per block size from measurements
-    ("cholsol.exact_variant" forces one).  Each must be bit-identical to cs_lsolve + cs_ltsolve of the oracle, for 130
+    """The default (exact) order on forests of dense blocks has five kernel variants (the L values by DPP row broadcast --
+    the default -- or by LDS broadcast with one fence per row or through a register ring, one or two right-hand sides
+    per lane; "cholsol.exact_variant" forces one).  Each must be bit-identical to cs_lsolve + cs_ltsolve of the oracle, for 130
     right-hand sides (two full groups and a partial one; a partial pair for the two-per-lane variants)."""
     import _csx
     nblocks, k = 9, 130
@@ -781,10 +781,24 @@ def test_exact_dense_block_kernel_variants_all_have_the_reference_bits(cs, bs):
     Lp, Li, Lx = CO.chol(n, Ap, Ai, Ax, parent, cp)
     B = synth.rhs(n, k, 3)
     ref = {r: CO.ltsolve(n, Lp, Li, Lx, CO.lsolve(n, Lp, Li, Lx, B[:, r])) for r in (0, 63, 64, 127, 128, 129)}
-    for variant in (0, 1, 2, 3, 4):
+    for variant in (0, 1, 2, 3, 4, 5):
         with _csx.option("cholsol.exact_variant", variant):
             dB = cs.dvec(B)
             assert F.solve(dB)
             X = dB.numpy()
         for r, v in ref.items():
             assert X[:, r].tobytes() == v.tobytes(), (variant, r)
+    # the default (5: L values by DPP row broadcast) lets the waves that solve one block share its LDS copy: four, two or
+    # one block(s) per workgroup as the number of 64-wide groups of right-hand sides allows (130 -> 3 groups: four blocks,
+    # 128 -> 2: two, 256 -> 4: one); 9 blocks leave the last workgroup partly empty in every case.  A right-hand side
+    # with zeros and negative zeros in it: the products' signs of zero must come out as the reference's.
+    for kk in (128, 256, 1):
+        Bk = synth.rhs(n, kk, 5)
+        Bk[::3, 0] = 0.0
+        Bk[1::7, 0] = -0.0
+        dB = cs.dvec(Bk)
+        assert F.solve(dB)
+        X = dB.numpy().reshape(n, kk)
+        for r in sorted({0, kk // 2, kk - 1}):
+            v = CO.ltsolve(n, Lp, Li, Lx, CO.lsolve(n, Lp, Li, Lx, Bk[:, r].copy()))
+            assert X[:, r].tobytes() == v.tobytes(), (kk, r)
