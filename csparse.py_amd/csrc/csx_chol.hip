@@ -2078,7 +2078,7 @@ static int cholsol_solve(CholPlan *P, double *B, int32_t nrhs) {
         X = P->scratch;
         hipLaunchKernelGGL(k_perm_rows, dim3((unsigned)((need + 255) / 256)), dim3(256), 0, s, P->perm, B, X, n, nrhs, 1);
     }
-    if (P->relaxed && P->sn && ctx().opt.tri_supernodes) {
+    if (P->relaxed && P->sn && ctx().opt.tri_supernodes && sn_usable(P->sn)) {
         CSX_TRY(tri_solve_raw(P->fwd, X, 0, false));          // a zero pivot found by the analysis: ZeroDivisionError
         CSX_TRY(sn_solve(P->sn, true, Gp, Gi, Gx, Gd, P->L, X, nrhs));
         CSX_TRY(sn_solve(P->sn, false, Gp, Gi, Gx, Gd, P->L, X, nrhs));
@@ -2132,7 +2132,7 @@ extern "C" int csx_cholsol_info(csx_handle_t h, int32_t *local, int32_t *ntrees,
     CholPlan *P = (CholPlan *)get(h, K_CHOLPLAN);
     if (!P) return CSX_EINVAL;
     // 0 level-scheduled, 1 fused in LDS, 2 dense blocks (substitution), 3 dense blocks on the matrix cores
-    if (local) *local = P->local ? (P->dense_bs ? (P->relaxed && P->frag_f ? 3 : 2) : 1) : (P->relaxed && P->sn ? 4 : 0);
+    if (local) *local = P->local ? (P->dense_bs ? (P->relaxed && P->frag_f ? 3 : 2) : 1) : (P->relaxed && P->sn && sn_usable(P->sn) ? 4 : 0);
     if (ntrees) *ntrees = P->ntrees;
     if (max_nodes) *max_nodes = P->max_nodes;
     return CSX_OK;

@@ -187,6 +187,7 @@ int sn_solve(SnPlan *P, bool forward, const int32_t *Gp, const int32_t *Gi, cons
              double *X, int32_t nrhs);
 void sn_info(const SnPlan *P, int32_t *nsn, int32_t *levels, int32_t *max_w);
 void sn_info2(const SnPlan *P, int32_t *matrix_cores, double *growth);
+bool sn_usable(const SnPlan *P);   // with the options in force (a plan with relaxed supernodes needs the matrix-core triangles)
 
 // Device temporaries of a host function with several exits: freed when the guard leaves scope.
 struct DevScope {

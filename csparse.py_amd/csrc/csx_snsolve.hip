@@ -41,6 +41,8 @@
 namespace csx {
 
 constexpr int SN_SEG = 256;      // terms per piece of a long row / column
+constexpr int SN_WHOLE = 512;    // a supernode's line of up to this many outside terms stays one task (no partial slots, no combine
+                                 // launch: a banded chain's rows of 300 terms were cut in two in every one of its n / 64 steps)
 constexpr int SN_PANEL = 16;
 constexpr int SN_CHUNK = 64;     // columns per chunk of a wide supernode
 constexpr int SN_LEAF = 64;      // columns of a leaf subtree (its x tile: SN_LEAF x 64 doubles of LDS per wave)
@@ -90,6 +92,7 @@ struct SnPlan {
     double *frags = nullptr;                    // matrix-core fragments of every virtual supernode's and leaf subtree's triangle
     bool mfma = false;                          // fragments built and every block inverse tame: k_sn_mfma solves the triangles
     double growth = 0.0;                        // the guard's measure (k_sn_frags)
+    bool has_relaxed = false;                   // some supernodes are runs of a chain, not dense trapezoids: matrix cores only
 };
 
 void free_snplan(SnPlan *P) {
@@ -150,18 +153,17 @@ __device__ __forceinline__ double sn_dot(int32_t b, int32_t e, const int32_t *__
                 acc1 = fma(v1, xv[u + 1], acc1);
             }
         };
+        // all the loads of the 64 terms first (a line of a banded chain is five such rounds, each a memory round trip,
+        // and the step waits for the longest line), then the sums in term order
+        double xc[16], xd[16];
         gather(0, xa);
         if (cnt > 16) gather(16, xb);
+        if (cnt > 32) gather(32, xc);
+        if (cnt > 48) gather(48, xd);
         fma16(0, xa);
-        if (cnt > 16) {
-            if (cnt > 32) gather(32, xa);
-            fma16(16, xb);
-            if (cnt > 32) {
-                if (cnt > 48) gather(48, xb);
-                fma16(32, xa);
-                if (cnt > 48) fma16(48, xb);
-            }
-        }
+        if (cnt > 16) fma16(16, xb);
+        if (cnt > 32) fma16(32, xc);
+        if (cnt > 48) fma16(48, xd);
         ci = cin;
         cv = cvn;
     }
@@ -185,6 +187,30 @@ __global__ __launch_bounds__(256) void k_sn_outside(const SnTask *__restrict__ t
     if (!live) return;
     if (t.out < 0) X[(int64_t)t.line * nrhs + r] -= d;
     else partial[(int64_t)t.out * nrhs + r] = d;
+}
+
+// A for steps of few tasks: a WORKGROUP per (task, 64 right-hand sides).  The task's terms are dealt to the four waves in
+// runs of 64 (wave w: runs w, w + 4, ...), the four sums meet in LDS and are added in wave order.  A task of 300 terms --
+// a row of a banded chain -- is then two memory round trips deep instead of five, and in such a factor the step waits for
+// exactly that.  (Steps with thousands of tasks keep a wave per task: there the chip is full either way.)
+__global__ __launch_bounds__(256) void k_sn_outside_wg(const SnTask *__restrict__ tasks, int32_t first, int32_t count,
+                                                       const int32_t *__restrict__ idx, const double *__restrict__ val, double *X,
+                                                       double *partial, int nrhs) {
+    __shared__ double part[4][64];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nblk = (nrhs + 63) >> 6;
+    const SnTask t = tasks[first + blockIdx.x / nblk];
+    const int r = (int)(blockIdx.x % nblk) * 64 + lane;
+    const bool live = r < nrhs;
+    const int rr = live ? r : nrhs - 1;
+    double d = 0.0;
+    for (int32_t q = t.b + 64 * w; q < t.e; q += 256) d += sn_dot(q, q + 64 < t.e ? q + 64 : t.e, idx, val, X, nrhs, rr, lane);
+    part[w][lane] = d;
+    __syncthreads();
+    if (w != 0 || !live || t.e <= t.b) return;
+    const double sum = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+    if (t.out < 0) X[(int64_t)t.line * nrhs + r] -= sum;
+    else partial[(int64_t)t.out * nrhs + r] = sum;
 }
 
 // Between A and B: a line cut into pieces takes its partial sums, in piece order, eight loads in flight at a time
@@ -355,7 +381,8 @@ __host__ __device__ constexpr int sn_tiles(int nb) { return nb * (nb + 1) / 2; }
 // entries its pattern lacks being zeros.
 template <bool LEAF>
 __global__ __launch_bounds__(64) void k_sn_frags(const int4 *__restrict__ list, int32_t count, const int32_t *__restrict__ Lp,
-                                                 const double *__restrict__ Lx, const int32_t *__restrict__ lb_ptr,
+                                                 const int32_t *__restrict__ Li, const double *__restrict__ Lx,
+                                                 const int32_t *__restrict__ lb_ptr,
                                                  const int32_t *__restrict__ lb_idx, const double *__restrict__ lb_val,
                                                  const double *__restrict__ ldiag, double *__restrict__ frags,
                                                  unsigned long long *cond_bits) {
@@ -375,11 +402,14 @@ __global__ __launch_bounds__(64) void k_sn_frags(const int4 *__restrict__ list, 
             if (lane == 0) Ls[k][k] = ldiag[a + k];
         }
     } else {
-        for (int e = lane; e < 64 * 64; e += 64) {
-            const int i = e >> 6, t = e & 63;               // row i, column t of the triangle
-            double v = i == t ? 1.0 : 0.0;
-            if (i < w && t <= i) v = Lx[Lp[a + t] + (i - t)];
-            Ls[i][t] = v;
+        for (int e = lane; e < 64 * 64; e += 64) Ls[e >> 6][e & 63] = (e >> 6) == (e & 63) ? 1.0 : 0.0;
+        __syncthreads();
+        for (int t = 0; t < w; t++) {                   // column a + t: diagonal, then its rows inside the triangle (at most 63,
+            const int32_t b = Lp[a + t], cnt = Lp[a + t + 1] - b;   // the first of the column: rows ascend)
+            if (lane < cnt) {
+                const int32_t i = Li[b + lane] - a;     // a fundamental supernode has all of t .. w - 1, a relaxed one some
+                if (i < w) Ls[i][t] = Lx[b + lane];
+            }
         }
     }
     __syncthreads();
@@ -710,7 +740,7 @@ __global__ __launch_bounds__(256) void k_sn_verify(int32_t n, const int32_t *__r
     const int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (j >= n) return;
     const int32_t b = Lp[j], e = Lp[j + 1], S = sn[j];
-    const bool jn = joins[j] != 0;
+    const bool jn = joins[j] == 1;                   // (2: a relaxed join -- the columns need not share their rows)
     const int32_t pb = jn ? Lp[j - 1] : 0;
     bool wrong = e - b < 1 || Li[b] != (int32_t)j;
     for (int32_t q = b + lane; q < e; q += 64) {
@@ -727,6 +757,40 @@ __global__ __launch_bounds__(256) void k_sn_verify(int32_t n, const int32_t *__r
         }
     }
     if (wrong) atomicOr(bad, 1);
+}
+
+// Line j of a supernode with columns [a, e): fin[j] = terms of row j (forward plan's row-major copy, ascending columns) that
+// lie inside the supernode (columns >= a: the tail of the row); bin[j] = entries of column j below its diagonal that lie
+// inside (rows < e: the head of the column).  In a fundamental supernode these are j - a and e - 1 - j; in a relaxed one
+// (a run of a chain of the tree whose columns do not share their rows) they have to be looked up.
+__global__ void k_sn_incount(int32_t n, const int32_t *__restrict__ sn_a, const int32_t *__restrict__ sn_e,
+                             const int32_t *__restrict__ Gp, const int32_t *__restrict__ Gi, const int32_t *__restrict__ Lp,
+                             const int32_t *__restrict__ Li, int32_t *fin, int32_t *bin) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int32_t a = sn_a[j], e = sn_e[j];
+    if (a < 0) {
+        fin[j] = 0;
+        bin[j] = 0;
+        return;
+    }
+    int32_t lo = Gp[j], hi = Gp[j + 1];               // first term with column >= a
+    const int32_t gend = hi;
+    while (lo < hi) {
+        const int32_t mid = (lo + hi) >> 1;
+        if (Gi[mid] < a) lo = mid + 1;
+        else hi = mid;
+    }
+    fin[j] = gend - lo;
+    lo = Lp[j] + 1;                                   // first row >= e
+    hi = Lp[j + 1];
+    const int32_t cb = lo;
+    while (lo < hi) {
+        const int32_t mid = (lo + hi) >> 1;
+        if (Li[mid] < e) lo = mid + 1;
+        else hi = mid;
+    }
+    bin[j] = lo - cb;
 }
 
 }  // namespace
@@ -767,14 +831,38 @@ int sn_build(const Csc *L, const int32_t *parent, const int32_t *Lp_h, const int
             }
     }
     // ---- supernodes of the columns outside the leaf subtrees ----
+    // A column joins the supernode of its predecessor when it is that column's parent and
+    //   (1) FUNDAMENTAL: its count is the predecessor's less one -- the two share their rows, the supernode is a dense
+    //       trapezoid of any width (cut into chunks of 64 columns below); or
+    //   (2) RELAXED (only with the matrix-core triangles): nothing more -- a run of at most 64 columns of a CHAIN of the
+    //       tree.  Its triangle is made dense in the fragments (zeros where the pattern has none), the split of a row /
+    //       column into its part inside and outside the run is looked up (k_sn_incount).  This is what gives a banded
+    //       factor in natural order (one chain, no two columns with the same rows) a schedule of n / 64 steps.
+    // A supernode is of one kind: a fundamental one does not continue with relaxed joins, nor the other way round.
+    const bool allow_relaxed = ctx().opt.tri_supernodes == 1;
     std::vector<int32_t> first, sn_of((size_t)n, -1), joins((size_t)n, 0);
-    for (int32_t j = 0; j < n; j++) {
-        if (sub_of[(size_t)j] >= 0) continue;
-        const bool jn = j > 0 && sub_of[(size_t)j - 1] < 0 && parent[j - 1] == j &&
-                        (Lp_h[j + 1] - Lp_h[j]) == (Lp_h[j] - Lp_h[j - 1]) - 1;
-        if (!jn) first.push_back(j);
-        joins[(size_t)j] = jn ? 1 : 0;
-        sn_of[(size_t)j] = (int32_t)first.size() - 1;
+    bool any_relaxed = false;
+    {
+        int kind = 0, w = 0;                                     // of the supernode being grown
+        for (int32_t j = 0; j < n; j++) {
+            if (sub_of[(size_t)j] >= 0) continue;
+            const bool chain = j > 0 && sub_of[(size_t)j - 1] < 0 && parent[j - 1] == j;
+            const bool fund = chain && (Lp_h[j + 1] - Lp_h[j]) == (Lp_h[j] - Lp_h[j - 1]) - 1;
+            int jn = 0;
+            if (fund && kind != 2) jn = 1;
+            else if (chain && allow_relaxed && kind != 1 && w < SN_CHUNK) jn = 2;
+            if (!jn) {
+                first.push_back(j);
+                kind = 0;
+                w = 1;
+            } else {
+                kind = jn;
+                w++;
+                any_relaxed |= jn == 2;
+            }
+            joins[(size_t)j] = jn;
+            sn_of[(size_t)j] = (int32_t)first.size() - 1;
+        }
     }
     const int32_t nsn = (int32_t)first.size();
     if (nsn == 0) return CSX_OK;                       // a forest of small trees: the fused per-tree kernels' business
@@ -847,13 +935,50 @@ int sn_build(const Csc *L, const int32_t *parent, const int32_t *Lp_h, const int
             return st;
         }
     }
+    // how much of every row / column lies inside its supernode
+    std::vector<int32_t> fin_h((size_t)n, 0), bin_h((size_t)n, 0);
+    P->has_relaxed = any_relaxed;
+    if (!any_relaxed) {
+        for (int32_t S = 0; S < nsn; S++)
+            for (int32_t v = 0; v < width[(size_t)S]; v++) {
+                fin_h[(size_t)(first[(size_t)S] + v)] = v;
+                bin_h[(size_t)(first[(size_t)S] + v)] = width[(size_t)S] - v - 1;
+            }
+    } else {
+        std::vector<int32_t> sa((size_t)n, -1), se((size_t)n, -1);
+        for (int32_t S = 0; S < nsn; S++)
+            for (int32_t v = 0; v < width[(size_t)S]; v++) {
+                sa[(size_t)(first[(size_t)S] + v)] = first[(size_t)S];
+                se[(size_t)(first[(size_t)S] + v)] = first[(size_t)S] + width[(size_t)S];
+            }
+        DevScope tmp;
+        int32_t *d_a = nullptr, *d_e = nullptr, *d_f = nullptr, *d_b = nullptr;
+        for (int32_t **a : {&d_a, &d_e, &d_f, &d_b})
+            if (st == CSX_OK) st = tmp.alloc(a, (size_t)n);
+        if (st == CSX_OK &&
+            (hipMemcpyAsync(d_a, sa.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, s) != hipSuccess ||
+             hipMemcpyAsync(d_e, se.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, s) != hipSuccess))
+            st = CSX_ERUNTIME;
+        if (st == CSX_OK) {
+            hipLaunchKernelGGL(k_sn_incount, dim3((unsigned)(((int64_t)n + 255) / 256)), dim3(256), 0, s, n, d_a, d_e, Gp, Gi, L->p, L->i, d_f,
+                               d_b);
+            if (hipMemcpyAsync(fin_h.data(), d_f, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess ||
+                hipMemcpyAsync(bin_h.data(), d_b, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess ||
+                hipStreamSynchronize(s) != hipSuccess)
+                st = CSX_ERUNTIME;
+        }
+        if (st != CSX_OK) {
+            free_snplan(P);
+            return st;
+        }
+    }
     // partial slots of the backward schedule (a column whose rows below its supernode are cut into pieces): counted here
     // because the leaf columns' slots are numbered behind them
     int32_t bwd_slots = 0;
     for (int32_t S = 0; S < nsn; S++)
         for (int32_t v = 0; v < width[(size_t)S]; v++) {
-            const int32_t col = first[(size_t)S] + v, c = Lp_h[col + 1] - (Lp_h[col] + (width[(size_t)S] - v));
-            if (c > SN_SEG) bwd_slots += (c + SN_SEG - 1) / SN_SEG;
+            const int32_t col = first[(size_t)S] + v, c = Lp_h[col + 1] - (Lp_h[col] + 1 + bin_h[(size_t)col]);
+            if (c > SN_WHOLE) bwd_slots += (c + SN_SEG - 1) / SN_SEG;
         }
     // ---- leaf subtrees: packed programs ----
     st = up(&P->leaf_ptr, leaf_ptr);
@@ -925,11 +1050,13 @@ int sn_build(const Csc *L, const int32_t *parent, const int32_t *Lp_h, const int
         std::vector<int4> tri;
         // terms of line a + v (v: position in its supernode of width w) that lie outside the supernode
         auto outside = [&](int32_t line, int32_t v, int32_t w, int32_t *b, int32_t *e) {
-            if (forward) {                       // row: [Gp[row], Gp[row + 1] - v)
+            (void)v;
+            (void)w;
+            if (forward) {                       // row: all but its terms inside the supernode (fundamental: the last v)
                 *b = Gp_h[line];
-                *e = Gp_h[line + 1] - v;
-            } else {                             // column: the rows below the supernode [Lp[col] + (w - v), Lp[col + 1])
-                *b = Lp_h[line] + (w - v);
+                *e = Gp_h[line + 1] - fin_h[(size_t)line];
+            } else {                             // column: the rows below the supernode (fundamental: from Lp[col] + (w - v) on)
+                *b = Lp_h[line] + 1 + bin_h[(size_t)line];
                 *e = Lp_h[line + 1];
             }
         };
@@ -938,7 +1065,7 @@ int sn_build(const Csc *L, const int32_t *parent, const int32_t *Lp_h, const int
                 int32_t b, e;
                 outside(first[(size_t)S] + v, v, width[(size_t)S], &b, &e);
                 const int32_t c = e - b;
-                part[(size_t)(first[(size_t)S] + v) + 1] = c > SN_SEG ? (c + SN_SEG - 1) / SN_SEG : 0;
+                part[(size_t)(first[(size_t)S] + v) + 1] = c > SN_WHOLE ? (c + SN_SEG - 1) / SN_SEG : 0;
             }
         for (int32_t j = 0; j < n; j++) part[(size_t)j + 1] += part[(size_t)j];
         D.nslots = part[(size_t)n];
@@ -957,7 +1084,7 @@ int sn_build(const Csc *L, const int32_t *parent, const int32_t *Lp_h, const int
                             int32_t b, e;
                             outside(a + v, v, w, &b, &e);
                             if (e <= b) continue;
-                            if (e - b <= SN_SEG) {
+                            if (e - b <= SN_WHOLE) {
                                 tasks.push_back({a + v, b, e, -1});
                             } else {
                                 int32_t slot = part[(size_t)(a + v)];
@@ -1034,12 +1161,12 @@ int sn_build(const Csc *L, const int32_t *parent, const int32_t *Lp_h, const int
             if (st == CSX_OK) st = tmp.alloc(&d_cond, 1);
             if (st == CSX_OK && hipMemsetAsync(d_cond, 0, sizeof(unsigned long long), s) != hipSuccess) st = CSX_ERUNTIME;
             if (st == CSX_OK) {
-                hipLaunchKernelGGL(k_sn_frags<false>, dim3((unsigned)nv), dim3(64), 0, s, P->fwd.tri4, (int32_t)nv, L->p, L->x,
+                hipLaunchKernelGGL(k_sn_frags<false>, dim3((unsigned)nv), dim3(64), 0, s, P->fwd.tri4, (int32_t)nv, L->p, L->i, L->x,
                                    (const int32_t *)nullptr, (const int32_t *)nullptr, (const double *)nullptr, (const double *)nullptr,
                                    P->frags, d_cond);
                 if (nleaf > 0)
-                    hipLaunchKernelGGL(k_sn_frags<true>, dim3((unsigned)nleaf), dim3(64), 0, s, P->leaf4, nleaf, L->p, L->x, P->lb_ptr,
-                                       P->lb_idx, P->lb_val, P->ldiag, P->frags, d_cond);
+                    hipLaunchKernelGGL(k_sn_frags<true>, dim3((unsigned)nleaf), dim3(64), 0, s, P->leaf4, nleaf, L->p, L->i, L->x,
+                                       P->lb_ptr, P->lb_idx, P->lb_val, P->ldiag, P->frags, d_cond);
                 if (hipMemcpyAsync(&h_cond, d_cond, sizeof(h_cond), hipMemcpyDeviceToHost, s) != hipSuccess ||
                     hipStreamSynchronize(s) != hipSuccess)
                     st = CSX_ERUNTIME;
@@ -1058,6 +1185,13 @@ int sn_build(const Csc *L, const int32_t *parent, const int32_t *Lp_h, const int
         }
     }
     if (st == CSX_OK && hipStreamSynchronize(s) != hipSuccess) st = CSX_ERUNTIME;
+    if (st == CSX_OK && P->has_relaxed && !P->mfma) {
+        // relaxed supernodes exist only as matrix-core fragments (the substitution kernel reads dense trapezoids): without
+        // them -- a diagonal block past the guard, no memory for the fragments -- the level-scheduled plans keep the factor
+        if (say) std::fprintf(stderr, "sn_build: relaxed supernodes but no matrix-core triangles (%.3g): no supernodal plan\n", growth);
+        free_snplan(P);
+        return CSX_OK;
+    }
     if (st != CSX_OK) {
         free_snplan(P);
         return st;
@@ -1074,6 +1208,8 @@ void sn_info(const SnPlan *P, int32_t *nsn, int32_t *levels, int32_t *max_w) {
     if (levels) *levels = (int32_t)P->fwd.steps.size();
     if (max_w) *max_w = P->max_w;
 }
+
+bool sn_usable(const SnPlan *P) { return !P->has_relaxed || (P->mfma && ctx().opt.tri_supernodes == 1); }
 
 void sn_info2(const SnPlan *P, int32_t *matrix_cores, double *growth) {
     if (matrix_cores) *matrix_cores = P->mfma && ctx().opt.tri_supernodes == 1 ? 1 : 0;
@@ -1127,7 +1263,10 @@ int sn_solve(SnPlan *P, bool forward, const int32_t *Gp, const int32_t *Gi, cons
         hipLaunchKernelGGL(k_sn_leaf<true>, dim3((unsigned)(P->nleaf * nblk)), dim3(64), 0, s, P->leaf_ptr, P->leaf_cols, P->lf_ptr,
                            P->lf_idx, P->lf_val, P->ldiag, (const int32_t *)nullptr, (const double *)nullptr, X, nrhs);
     for (const SnStep &t : D.steps) {
-        if (t.tc > 0) {
+        if (t.tc > 0 && t.tc <= 512) {      // (by the step's size alone: the same sums for any number of right-hand sides)
+            hipLaunchKernelGGL(k_sn_outside_wg, dim3((unsigned)((int64_t)t.tc * nblk)), dim3(256), 0, s, D.tasks, t.t0, t.tc, idx, val, X,
+                               P->partial, nrhs);
+        } else if (t.tc > 0) {
             const int64_t waves = (int64_t)t.tc * nblk;
             hipLaunchKernelGGL(k_sn_outside, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, D.tasks, t.t0, t.tc, idx, val, X,
                                P->partial, nrhs);

@@ -614,7 +614,7 @@ def test_solver_keeps_its_factor_alive_and_follows_updown(cs):
         assert np.asarray(x2).tobytes() == ref2.tobytes()
 
 
-@pytest.mark.parametrize("case", ["grid_120x120", "grid_75x131", "bcsstk16"])
+@pytest.mark.parametrize("case", ["grid_120x120", "grid_75x131", "bcsstk16", "grid_60x47@natural", "band_3000x90@natural"])
 def test_supernodal_solves_in_the_rounding_equal_order(cs, case):
     """cholsol_factor(A, order=1, exact=False) on a connected nested-dissection factor: the solves are scheduled by
     SUPERNODE (csx_snsolve.hip: outside terms by a wave per piece of a row, the dense triangle in panels of 16) instead
@@ -622,23 +622,45 @@ def test_supernodal_solves_in_the_rounding_equal_order(cs, case):
     for 1, 3, 64 and 70 right-hand sides (a partial second chunk); the exact order of the same factor stays bit-identical;
     the same bits from run to run (partial sums are added in a fixed order); switched off -> the level-scheduled path."""
     import _csx
+    # "@natural": order 0 -- the factor of a banded matrix is ONE chain of the elimination tree in which no two columns share
+    # their rows: the schedule is made of RELAXED supernodes (runs of 64 columns of the chain, their triangles made dense
+    # in the matrix-core fragments, the in / out split of every row and column looked up)
+    order = 0 if case.endswith("@natural") else 1
+    case = case.split("@")[0]
     if case == "bcsstk16":
         g = golden("bcsstk16")
         A = cs.cs_pin(unpack(cs, g, "C"))
         n = A.n
+    elif case.startswith("band_"):
+        import scipy.sparse as sp
+        n, band = (int(v) for v in case[5:].split("x"))
+        rng = np.random.default_rng(17)
+        rows, cols = [], []
+        for d in range(1, band + 1):
+            keep = rng.random(n - d) < 0.4                      # a band with holes: the triangles of the runs are sparse
+            rows.append(np.nonzero(keep)[0] + d)
+            cols.append(np.nonzero(keep)[0])
+        rows, cols = np.concatenate(rows), np.concatenate(cols)
+        Lw = sp.coo_matrix((rng.uniform(-1, 1, len(rows)), (rows, cols)), shape=(n, n))
+        Sm = (Lw + Lw.T).tocsc()
+        Sm = (Sm + sp.diags(np.asarray(abs(Sm).sum(axis=0)).ravel() + 1.0)).tocsc()
+        Sm.sort_indices()
+        A = cs.cs_spalloc(n, n, Sm.nnz, True, False)
+        A.p, A.i, A.x = Sm.indptr.tolist(), Sm.indices.tolist(), Sm.data.tolist()
+        cs.cs_pin(A)
     else:
         gx, gy = (int(v) for v in case[5:].split("x"))
         n, p, i, x = _grid_laplacian(gx, gy)
         A = cs.cs_spalloc(n, n, len(i), True, False)
         A.p, A.i, A.x = p.tolist(), i.tolist(), x.tolist()
         cs.cs_pin(A)
-    Fr = cs.cholsol_factor(A, order=1, exact=False)
+    Fr = cs.cholsol_factor(A, order=order, exact=False)
     path = _csx.C.c_int32(-1)
     _csx.check(_csx.lib().csx_cholsol_info(Fr.plan_handle, path, None, None))
     assert path.value == 4                                            # the supernodal schedule is in charge
-    Fe = cs.cholsol_factor(A, order=1)
+    Fe = cs.cholsol_factor(A, order=order)
     Lp, Li, Lx = _arr(Fr.L)
-    pinv = np.asarray(Fr.symbolic.pinv)
+    pinv = np.asarray(Fr.symbolic.pinv) if Fr.symbolic.pinv is not None else np.arange(n)
     for k in (1, 3, 64, 70):
         B = synth.rhs(n, k, 2)
         Xr, Xr2, Xe = cs.dvec(B), cs.dvec(B), cs.dvec(B)
@@ -655,7 +677,7 @@ def test_supernodal_solves_in_the_rounding_equal_order(cs, case):
             scale = np.maximum(np.abs(ref), 1e-3 * np.max(np.abs(ref)))
             assert np.max(np.abs(Xr[:, r] - ref) / scale) <= 1e-9
     with _csx.option("tri.supernodes", 0):
-        F0 = cs.cholsol_factor(A, order=1, exact=False)
+        F0 = cs.cholsol_factor(A, order=order, exact=False)
         _csx.check(_csx.lib().csx_cholsol_info(F0.plan_handle, path, None, None))
         assert path.value == 0
         X0 = cs.dvec(synth.rhs(n, 3, 2))
@@ -672,9 +694,9 @@ def test_supernodal_solves_in_the_rounding_equal_order(cs, case):
     if case != "bcsstk16":
         assert mc.value == 1
     with _csx.option("tri.supernodes", 2):
-        F2 = cs.cholsol_factor(A, order=1, exact=False)
+        F2 = cs.cholsol_factor(A, order=order, exact=False)
         _csx.check(_csx.lib().csx_cholsol_info(F2.plan_handle, path, None, None))
-        assert path.value == 4
+        assert path.value == (4 if order == 1 else 0)     # a chain has no dense supernodes: without relaxed ones, no schedule
         _csx.check(_csx.lib().csx_cholsol_sn_info(F2.plan_handle, None, None, None, mc, None))
         assert mc.value == 0
         X2 = cs.dvec(synth.rhs(n, 3, 2))

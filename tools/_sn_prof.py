@@ -6,7 +6,7 @@ import numpy as np, scipy.sparse as sp
 import _csx, csparse as cs
 from conftest import golden, unpack
 _csx.init(0)
-g = int(sys.argv[1]); k = int(sys.argv[2])
+g = int(sys.argv[1]); k = int(sys.argv[2]); order = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 if g == 0:
     M = cs.cs_pin(unpack(cs, golden("bcsstk16"), "C")); n = M.n
 else:
@@ -16,7 +16,7 @@ else:
     M = cs.cs_spalloc(n, n, A.nnz, True, False)
     M.p, M.i, M.x = A.indptr.tolist(), A.indices.tolist(), A.data.tolist()
     cs.cs_pin(M)
-F = cs.cholsol_factor(M, 1, exact=False)
+F = cs.cholsol_factor(M, order, exact=False)
 B = cs.dvec(np.ones((n, k)))
 for _ in range(4):
     F.solve(B)
