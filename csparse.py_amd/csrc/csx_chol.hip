@@ -918,6 +918,9 @@ static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, c
 
 // ---- solve phase ----------------------------------------------------------------------------------
 struct CholPlan {
+    hipGraphExec_t g_exec = nullptr;   // "tri.graph": the supernodal solve's launches, captured for the block g_X / g_nrhs
+    double *g_X = nullptr;
+    int32_t g_nrhs = 0;
     int32_t n = 0;
     const Csc *L = nullptr;  // not owned; must outlive the plan
     TriPlan *fwd = nullptr, *bwd = nullptr;
@@ -954,6 +957,7 @@ struct CholPlan {
 
 void free_cholplan(CholPlan *P) {
     if (!P) return;
+    if (P->g_exec) (void)hipGraphExecDestroy(P->g_exec);
     free_snplan(P->sn);
     free_triplan(P->fwd);
     free_triplan(P->bwd);
@@ -2080,8 +2084,37 @@ static int cholsol_solve(CholPlan *P, double *B, int32_t nrhs) {
     }
     if (P->relaxed && P->sn && ctx().opt.tri_supernodes && sn_usable(P->sn)) {
         CSX_TRY(tri_solve_raw(P->fwd, X, 0, false));          // a zero pivot found by the analysis: ZeroDivisionError
-        CSX_TRY(sn_solve(P->sn, true, Gp, Gi, Gx, Gd, P->L, X, nrhs));
-        CSX_TRY(sn_solve(P->sn, false, Gp, Gi, Gx, Gd, P->L, X, nrhs));
+        if (ctx().opt.tri_graph) {
+            // the two sweeps' launches as one graph, re-used while the block of right-hand sides stays where it is
+            if (!(P->g_exec && P->g_X == X && P->g_nrhs == nrhs)) {
+                if (P->g_exec) (void)hipGraphExecDestroy(P->g_exec);
+                P->g_exec = nullptr;
+                CSX_TRY(sn_prepare(P->sn, nrhs));
+                hipGraph_t graph = nullptr;
+                CSX_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+                int st = sn_solve(P->sn, true, Gp, Gi, Gx, Gd, P->L, X, nrhs);
+                if (st == CSX_OK) st = sn_solve(P->sn, false, Gp, Gi, Gx, Gd, P->L, X, nrhs);
+                const hipError_t ec = hipStreamEndCapture(s, &graph);
+                if (st != CSX_OK || ec != hipSuccess) {
+                    if (graph) (void)hipGraphDestroy(graph);
+                    set_error("cholsol: capturing the supernodal solve failed");
+                    return st != CSX_OK ? st : CSX_ERUNTIME;
+                }
+                const hipError_t ei = hipGraphInstantiate(&P->g_exec, graph, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(graph);
+                if (ei != hipSuccess) {
+                    P->g_exec = nullptr;
+                    set_error("cholsol: hipGraphInstantiate: %s", hipGetErrorString(ei));
+                    return CSX_ERUNTIME;
+                }
+                P->g_X = X;
+                P->g_nrhs = nrhs;
+            }
+            CSX_HIP(hipGraphLaunch(P->g_exec, s));
+        } else {
+            CSX_TRY(sn_solve(P->sn, true, Gp, Gi, Gx, Gd, P->L, X, nrhs));
+            CSX_TRY(sn_solve(P->sn, false, Gp, Gi, Gx, Gd, P->L, X, nrhs));
+        }
     } else {
         CSX_TRY(tri_solve_raw(P->fwd, X, nrhs, P->relaxed));
         CSX_TRY(tri_solve_raw(P->bwd, X, nrhs, P->relaxed));

@@ -549,7 +549,8 @@ const OptSlot kOptSlots[] = {
     {"tri.row_waves", &Options::tri_row_waves, 0},       {"tri.push", &Options::tri_push, 0},
     {"tri.levels_where", &Options::tri_levels_where, 3}, {"tri.supernodes", &Options::tri_supernodes, 5},
     {"spgemm.ordered", &Options::spgemm_ordered, 0},     {"spgemm.chunks", &Options::spgemm_chunks, 4},
-    {"lu.etree", &Options::lu_etree, 5},                 {"cholsol.exact_variant", &Options::cholsol_exact_variant, 4},
+    {"lu.etree", &Options::lu_etree, 5},                 {"tri.graph", &Options::tri_graph, 0},
+                    {"cholsol.exact_variant", &Options::cholsol_exact_variant, 4},
 };
 int normalise(int kind, int value) {
     switch (kind) {

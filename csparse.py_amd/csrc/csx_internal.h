@@ -135,6 +135,7 @@ struct Options {
     int gaxpy_tune_shape = 0;    // tiled cs_gaxpy plan: time the launch shapes when the plan is built and keep the fastest
     int tri_row_waves = 1;        // level-scheduled solves: a wave per row for few right-hand sides and long rows
     int tri_levels_where = 0;         // level analysis: 0 = device for big factors, host for small; 1 = host; 2 = device
+    int tri_graph = 0;                // supernodal solves: replay the launches of a solve as a hipGraph while the block of right-hand sides stays in place
     int tri_supernodes = 1;           // cholsol: supernodal forward / backward solves on factors with supernodes (0 never, 1 yes,
                                       // 2 yes but the triangles by substitution out of LDS instead of on the matrix cores)
     int spgemm_ordered = 0;           // cs_multiply: sum every entry's products in the reference's order (bit-identical x)
@@ -185,6 +186,7 @@ int sn_build(const Csc *L, const int32_t *parent, const int32_t *Lp_h, const int
              const double *Gx, int32_t col_levels, SnPlan **out);
 int sn_solve(SnPlan *P, bool forward, const int32_t *Gp, const int32_t *Gi, const double *Gx, const double *Gd, const Csc *L,
              double *X, int32_t nrhs);
+int sn_prepare(SnPlan *P, int32_t nrhs);   // work space of a solve with nrhs right-hand sides (sn_solve calls it; a capture calls it first)
 void sn_info(const SnPlan *P, int32_t *nsn, int32_t *levels, int32_t *max_w);
 void sn_info2(const SnPlan *P, int32_t *matrix_cores, double *growth);
 bool sn_usable(const SnPlan *P);   // with the options in force (a plan with relaxed supernodes needs the matrix-core triangles)

@@ -1218,10 +1218,7 @@ void sn_info2(const SnPlan *P, int32_t *matrix_cores, double *growth) {
 
 /* X (n x nrhs, row-major) <- inv(L) X (forward) or inv(L') X.  G*: the forward plan's row-major copy of L (off-diagonal
  * terms of every row in ascending column order, diagonal apart); L: the factor. */
-int sn_solve(SnPlan *P, bool forward, const int32_t *Gp, const int32_t *Gi, const double *Gx, const double *Gd, const Csc *L,
-             double *X, int32_t nrhs) {
-    hipStream_t s = ctx().stream;
-    const SnDir &D = forward ? P->fwd : P->bwd;
+int sn_prepare(SnPlan *P, int32_t nrhs) {
     const int64_t need = (int64_t)std::max(P->fwd.nslots, P->bwd.nslots + P->nleafslots) * nrhs;
     if (P->partial_len < need) {
         dfree(P->partial);
@@ -1230,9 +1227,6 @@ int sn_solve(SnPlan *P, bool forward, const int32_t *Gp, const int32_t *Gi, cons
         CSX_TRY(dalloc(&P->partial, (size_t)need));
         P->partial_len = need;
     }
-    const int nblk = (nrhs + 63) / 64;
-    const int32_t *idx = forward ? Gi : L->i;
-    const double *val = forward ? Gx : L->x;
     static bool lds_set = false;
     if (!lds_set) {     // the 64-column triangle + its rows of X: 66 KB of LDS, past the static limit
         CSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sn_tri<4, SN_CHUNK, true>),
@@ -1241,6 +1235,17 @@ int sn_solve(SnPlan *P, bool forward, const int32_t *Gp, const int32_t *Gi, cons
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sn_tri_lds<SN_CHUNK>()));
         lds_set = true;
     }
+    return CSX_OK;
+}
+
+int sn_solve(SnPlan *P, bool forward, const int32_t *Gp, const int32_t *Gi, const double *Gx, const double *Gd, const Csc *L,
+             double *X, int32_t nrhs) {
+    hipStream_t s = ctx().stream;
+    const SnDir &D = forward ? P->fwd : P->bwd;
+    CSX_TRY(sn_prepare(P, nrhs));
+    const int nblk = (nrhs + 63) / 64;
+    const int32_t *idx = forward ? Gi : L->i;
+    const double *val = forward ? Gx : L->x;
     const bool cores = P->mfma && ctx().opt.tri_supernodes == 1;
     // `count` triangles of a list from `first` on: few of them -> a wave per column tile of 16 right-hand sides (the dependent
     // chain of a step is what counts), many -> a wave per 64 (fewer workgroups, every fragment read once)

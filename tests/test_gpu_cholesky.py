@@ -704,6 +704,34 @@ def test_supernodal_solves_in_the_rounding_equal_order(cs, case):
     assert np.max(np.abs(X2.numpy() - X3.numpy())) <= 1e-10 * np.max(np.abs(X3.numpy()))
 
 
+def test_supernodal_solve_replayed_as_a_graph_gives_the_same_bits(cs):
+    """"tri.graph" = 1: the launches of a supernodal solve (both sweeps) are captured once into a hipGraph and replayed while
+    the block of right-hand sides stays where it is -- the host then enqueues a solve in microseconds.  Same bits as the
+    direct launches; another block (or another number of right-hand sides) is captured anew."""
+    import _csx
+    n, p, i, x = _grid_laplacian(70, 53)
+    A = cs.cs_spalloc(n, n, len(i), True, False)
+    A.p, A.i, A.x = p.tolist(), i.tolist(), x.tolist()
+    cs.cs_pin(A)
+    F = cs.cholsol_factor(A, order=1, exact=False)
+    path = _csx.C.c_int32(-1)
+    _csx.check(_csx.lib().csx_cholsol_info(F.plan_handle, path, None, None))
+    assert path.value == 4
+    B = synth.rhs(n, 5, 9)
+    X0 = cs.dvec(B)
+    assert F.solve(X0)
+    with _csx.option("tri.graph", 1):
+        X1, X2 = cs.dvec(B), cs.dvec(B[:, :3].copy())
+        assert F.solve(X1)                                   # captured here
+        again = cs.dvec(B)
+        X1h = X1.numpy().copy()
+        assert F.solve(X2)                                   # another block, three right-hand sides: a new capture
+        assert F.solve(again)                                # and back to five
+    assert X1h.tobytes() == X0.numpy().tobytes()
+    assert again.numpy().tobytes() == X0.numpy().tobytes()
+    assert X2.numpy().reshape(n, 3).tobytes() == X0.numpy().reshape(n, 5)[:, :3].copy().tobytes()
+
+
 @pytest.mark.parametrize("strength, cores", [(0.3, 1), (0.9, 0)])
 def test_supernodal_triangles_leave_the_matrix_cores_when_a_diagonal_block_is_ill_conditioned(cs, strength, cores):
     """The matrix-core triangles multiply by explicit inverses of the 16 x 16 diagonal blocks; the plan measures

@@ -20,8 +20,12 @@ for g, order in ((0, 1), (300, 1), (700, 1), (300, 0)):
     F = cs.cholsol_factor(M, order, exact=False)
     B = cs.dvec(np.ones((n, 8)))
     F.solve(B); _csx.sync()
-    enq, tot = [], []
-    for _ in range(5):
-        t0 = time.perf_counter(); F.solve(B); t1 = time.perf_counter(); _csx.sync(); t2 = time.perf_counter()
-        enq.append((t1 - t0) * 1e3); tot.append((t2 - t0) * 1e3)
-    print("grid %d order %d: enqueue %.3f ms, complete %.3f ms" % (g, order, min(enq), min(tot)), flush=True)
+    for graph in (0, 1):
+        _csx.check(_csx.lib().csx_set_option(b"tri.graph", graph))
+        F.solve(B); _csx.sync()
+        enq, tot = [], []
+        for _ in range(5):
+            t0 = time.perf_counter(); F.solve(B); t1 = time.perf_counter(); _csx.sync(); t2 = time.perf_counter()
+            enq.append((t1 - t0) * 1e3); tot.append((t2 - t0) * 1e3)
+        print("grid %d order %d graph %d: enqueue %.3f ms, complete %.3f ms" % (g, order, graph, min(enq), min(tot)), flush=True)
+    _csx.check(_csx.lib().csx_set_option(b"tri.graph", 0))
