@@ -1268,7 +1268,7 @@ int sn_solve(SnPlan *P, bool forward, const int32_t *Gp, const int32_t *Gi, cons
         hipLaunchKernelGGL(k_sn_leaf<true>, dim3((unsigned)(P->nleaf * nblk)), dim3(64), 0, s, P->leaf_ptr, P->leaf_cols, P->lf_ptr,
                            P->lf_idx, P->lf_val, P->ldiag, (const int32_t *)nullptr, (const double *)nullptr, X, nrhs);
     for (const SnStep &t : D.steps) {
-        if (t.tc > 0 && t.tc <= 512) {      // (by the step's size alone: the same sums for any number of right-hand sides)
+        if (t.tc > 0 && t.tc <= 16384) {      // (by the step's size alone: the same sums for any number of right-hand sides)
             hipLaunchKernelGGL(k_sn_outside_wg, dim3((unsigned)((int64_t)t.tc * nblk)), dim3(256), 0, s, D.tasks, t.t0, t.tc, idx, val, X,
                                P->partial, nrhs);
         } else if (t.tc > 0) {
