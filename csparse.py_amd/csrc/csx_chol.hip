@@ -921,6 +921,7 @@ struct CholPlan {
     hipGraphExec_t g_exec = nullptr;   // "tri.graph": the supernodal solve's launches, captured for the block g_X / g_nrhs
     double *g_X = nullptr;
     int32_t g_nrhs = 0;
+    int64_t g_gen = -1;                // the work-space generation of the supernodal plan the capture saw
     int32_t n = 0;
     const Csc *L = nullptr;  // not owned; must outlive the plan
     TriPlan *fwd = nullptr, *bwd = nullptr;
@@ -2086,10 +2087,10 @@ static int cholsol_solve(CholPlan *P, double *B, int32_t nrhs) {
         CSX_TRY(tri_solve_raw(P->fwd, X, 0, false));          // a zero pivot found by the analysis: ZeroDivisionError
         if (ctx().opt.tri_graph) {
             // the two sweeps' launches as one graph, re-used while the block of right-hand sides stays where it is
-            if (!(P->g_exec && P->g_X == X && P->g_nrhs == nrhs)) {
+            CSX_TRY(sn_prepare(P->sn, nrhs));              // (may move the work space: the captured launches hold its address)
+            if (!(P->g_exec && P->g_X == X && P->g_nrhs == nrhs && P->g_gen == sn_generation(P->sn))) {
                 if (P->g_exec) (void)hipGraphExecDestroy(P->g_exec);
                 P->g_exec = nullptr;
-                CSX_TRY(sn_prepare(P->sn, nrhs));
                 hipGraph_t graph = nullptr;
                 CSX_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
                 int st = sn_solve(P->sn, true, Gp, Gi, Gx, Gd, P->L, X, nrhs);
@@ -2109,6 +2110,7 @@ static int cholsol_solve(CholPlan *P, double *B, int32_t nrhs) {
                 }
                 P->g_X = X;
                 P->g_nrhs = nrhs;
+                P->g_gen = sn_generation(P->sn);
             }
             CSX_HIP(hipGraphLaunch(P->g_exec, s));
         } else {

@@ -186,6 +186,7 @@ int sn_build(const Csc *L, const int32_t *parent, const int32_t *Lp_h, const int
              const double *Gx, int32_t col_levels, SnPlan **out);
 int sn_solve(SnPlan *P, bool forward, const int32_t *Gp, const int32_t *Gi, const double *Gx, const double *Gd, const Csc *L,
              double *X, int32_t nrhs);
+int64_t sn_generation(const SnPlan *P);   // changes whenever sn_prepare moved the work space
 int sn_prepare(SnPlan *P, int32_t nrhs);   // work space of a solve with nrhs right-hand sides (sn_solve calls it; a capture calls it first)
 void sn_info(const SnPlan *P, int32_t *nsn, int32_t *levels, int32_t *max_w);
 void sn_info2(const SnPlan *P, int32_t *matrix_cores, double *growth);

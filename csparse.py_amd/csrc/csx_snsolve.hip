@@ -93,6 +93,7 @@ struct SnPlan {
     bool mfma = false;                          // fragments built and every block inverse tame: k_sn_mfma solves the triangles
     double growth = 0.0;                        // the guard's measure (k_sn_frags)
     bool has_relaxed = false;                   // some supernodes are runs of a chain, not dense trapezoids: matrix cores only
+    int64_t generation = 0;                     // counts the moves of `partial` (a captured solve holds its address)
 };
 
 void free_snplan(SnPlan *P) {
@@ -1218,6 +1219,8 @@ void sn_info2(const SnPlan *P, int32_t *matrix_cores, double *growth) {
 
 /* X (n x nrhs, row-major) <- inv(L) X (forward) or inv(L') X.  G*: the forward plan's row-major copy of L (off-diagonal
  * terms of every row in ascending column order, diagonal apart); L: the factor. */
+int64_t sn_generation(const SnPlan *P) { return P->generation; }
+
 int sn_prepare(SnPlan *P, int32_t nrhs) {
     const int64_t need = (int64_t)std::max(P->fwd.nslots, P->bwd.nslots + P->nleafslots) * nrhs;
     if (P->partial_len < need) {
@@ -1226,6 +1229,7 @@ int sn_prepare(SnPlan *P, int32_t nrhs) {
         P->partial_len = 0;
         CSX_TRY(dalloc(&P->partial, (size_t)need));
         P->partial_len = need;
+        P->generation++;
     }
     static bool lds_set = false;
     if (!lds_set) {     // the 64-column triangle + its rows of X: 66 KB of LDS, past the static limit

@@ -729,6 +729,16 @@ def test_supernodal_solve_replayed_as_a_graph_gives_the_same_bits(cs):
         assert F.solve(again)                                # and back to five
     assert X1h.tobytes() == X0.numpy().tobytes()
     assert again.numpy().tobytes() == X0.numpy().tobytes()
+    # a direct solve with many more right-hand sides in between moves the plan's work space: the capture must notice
+    with _csx.option("tri.graph", 1):
+        Y = cs.dvec(B)
+        assert F.solve(Y)
+    Big = cs.dvec(synth.rhs(n, 300, 1))
+    assert F.solve(Big)
+    with _csx.option("tri.graph", 1):
+        Y.assign(B)                                          # the same buffer, the same number of right-hand sides
+        assert F.solve(Y)
+    assert Y.numpy().tobytes() == X0.numpy().tobytes()
     assert X2.numpy().reshape(n, 3).tobytes() == X0.numpy().reshape(n, 5)[:, :3].copy().tobytes()
 
 
