@@ -1315,8 +1315,8 @@ __device__ __forceinline__ void dense_exact_pass(double (&x)[R][BS], const doubl
 // lanes holds.  So the 16 lanes of a row read 16 consecutive L values of the matrix row being solved (one ds_read_b64 per
 // 16 terms, the four rows reading the same 128 bytes), and term k is
 //     v_mov_b64_dpp b, Lv row_newbcast:k ;  v_mul_f64 t, b, x_k ;  v_add_f64 acc, acc, -t
-// -- the reference's two separately rounded operations plus one register move; no broadcast read, no v_readlane, no scalar
-// load.  (v_mul_f64 / v_add_f64 are VOP3 and have no DPP form on this ISA; v_fmac_f64 has one, but it fuses.)  A row's L
+// -- the reference's two separately rounded operations plus one register move; no v_readlane, no scalar load, and a
+// broadcast read for one term in four only (see dense_exact_term_dpp).  (v_mul_f64 / v_add_f64 are VOP3 and have no DPP form on this ISA; v_fmac_f64 has one, but it fuses.)  A row's L
 // values and diagonal are requested while the previous row is being solved.
 template <int K>
 __device__ __forceinline__ double dpp_row_bcast(const double v) {
@@ -1325,11 +1325,16 @@ __device__ __forceinline__ double dpp_row_bcast(const double v) {
 
 // term E of sweep row SP; the L values of a group of 16 terms die with the group's last term, and the same group of the
 // NEXT row is requested there: four values live instead of eight (168 VGPRs is three waves per SIMD at blocks of 64)
-template <int BS, bool BACKWARD, int SP, int E>
-__device__ __forceinline__ void dense_exact_term_dpp(const double (&x)[BS], const double *Ml, const double (&lv)[4], double (&nxt)[4],
-                                                     double &acc) {
+template <int BS, bool BACKWARD, int MIX, int SP, int E>
+__device__ __forceinline__ void dense_exact_term_dpp(const double (&x)[BS], const double *Ml, const double *Mu, const double (&lv)[4],
+                                                     double (&nxt)[4], double &acc) {
     constexpr int G = E >> 4, NS = SP + 1;
-    const double t = dpp_row_bcast<(E & 15)>(lv[G]) * x[BACKWARD ? BS - 1 - E : E];
+    // One term in four takes its L value by a broadcast LDS read instead: two VALU instructions instead of three, on the LDS
+    // path the DPP form left idle.  Measured at blocks of 64 (ms per 128 right-hand sides): none 4.81, one in four 4.59, two
+    // in four 4.93 -- at half the terms the return path (4 clk per broadcast value and CU) is 80 % busy and its latency shows.
+    constexpr bool via_lds = (E & 3) < MIX;
+    const double lb = via_lds ? Mu[SP * (SP - 1) / 2 + E] : dpp_row_bcast<(E & 15)>(lv[G]);
+    const double t = lb * x[BACKWARD ? BS - 1 - E : E];
     acc = acc - t;
     constexpr bool last_of_group = BACKWARD ? (E & 15) == 0 : ((E & 15) == 15 || E == SP - 1);
     if constexpr (last_of_group && NS < BS) nxt[G] = Ml[NS * (NS - 1) / 2 + 16 * G];
@@ -1338,16 +1343,16 @@ __device__ __forceinline__ void dense_exact_term_dpp(const double (&x)[BS], cons
     if constexpr ((E & 3) == (BACKWARD ? 0 : 3) || last_of_group) __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int BS, bool BACKWARD, int SP, int... I>
-__device__ __forceinline__ void dense_exact_terms_dpp(const double (&x)[BS], const double *Ml, const double (&lv)[4], double (&nxt)[4],
-                                                      double &acc, std::integer_sequence<int, I...>) {
+template <int BS, bool BACKWARD, int MIX, int SP, int... I>
+__device__ __forceinline__ void dense_exact_terms_dpp(const double (&x)[BS], const double *Ml, const double *Mu, const double (&lv)[4],
+                                                      double (&nxt)[4], double &acc, std::integer_sequence<int, I...>) {
     // the reference's order: ascending columns forward, descending (in sweep numbering) backward
-    (dense_exact_term_dpp<BS, BACKWARD, SP, (BACKWARD ? SP - 1 - I : I)>(x, Ml, lv, nxt, acc), ...);
+    (dense_exact_term_dpp<BS, BACKWARD, MIX, SP, (BACKWARD ? SP - 1 - I : I)>(x, Ml, Mu, lv, nxt, acc), ...);
 }
 
 // sweep row SP: cur = its L values (lane l: entry 16 g + (l & 15) of the packed row), dv its diagonal; requests row SP + 1
-template <int BS, bool BACKWARD, int SP>
-__device__ __forceinline__ void dense_exact_row_dpp(double (&x)[BS], const double *Ml, const double *D, const double (&cur)[4],
+template <int BS, bool BACKWARD, int MIX, int SP>
+__device__ __forceinline__ void dense_exact_row_dpp(double (&x)[BS], const double *Ml, const double *Mu, const double *D, const double (&cur)[4],
                                                     double (&nxt)[4], const double dv, double &dnext) {
     constexpr int NS = SP + 1;
     if constexpr (NS < BS) {
@@ -1356,7 +1361,7 @@ __device__ __forceinline__ void dense_exact_row_dpp(double (&x)[BS], const doubl
         dnext = D[NS];
     }
     double acc = x[BACKWARD ? BS - 1 - SP : SP];
-    dense_exact_terms_dpp<BS, BACKWARD, SP>(x, Ml, cur, nxt, acc, std::make_integer_sequence<int, SP>{});
+    dense_exact_terms_dpp<BS, BACKWARD, MIX, SP>(x, Ml, Mu, cur, nxt, acc, std::make_integer_sequence<int, SP>{});
     double xr = acc / dv;
     // the row's arithmetic is pure: nothing but its data dependences holds it in place, and the instruction selector sank
     // whole rows of it behind the moves of later rows (256 VGPRs and spills at blocks of 16).  An empty volatile asm that
@@ -1366,17 +1371,17 @@ __device__ __forceinline__ void dense_exact_row_dpp(double (&x)[BS], const doubl
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int BS, bool BACKWARD, int... SP>
-__device__ __forceinline__ void dense_exact_rows_dpp(double (&x)[BS], const double *Ml, const double *D,
+template <int BS, bool BACKWARD, int MIX, int... SP>
+__device__ __forceinline__ void dense_exact_rows_dpp(double (&x)[BS], const double *Ml, const double *Mu, const double *D,
                                                      std::integer_sequence<int, SP...>) {
     double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};   // L values of the even / odd sweep rows
     double da = D[0], db = 1.0;                                         // and their diagonals
-    (dense_exact_row_dpp<BS, BACKWARD, SP>(x, Ml, D, (SP & 1) ? b : a, (SP & 1) ? a : b, (SP & 1) ? db : da, (SP & 1) ? da : db), ...);
+    (dense_exact_row_dpp<BS, BACKWARD, MIX, SP>(x, Ml, Mu, D, (SP & 1) ? b : a, (SP & 1) ? a : b, (SP & 1) ? db : da, (SP & 1) ? da : db), ...);
 }
 
-template <int BS, bool BACKWARD>
+template <int BS, bool BACKWARD, int MIX>
 __device__ __forceinline__ void dense_exact_pass_dpp(double (&x)[BS], const double *M, const double *D, const int lane) {
-    dense_exact_rows_dpp<BS, BACKWARD>(x, M + (lane & 15), D, std::make_integer_sequence<int, BS>{});
+    dense_exact_rows_dpp<BS, BACKWARD, MIX>(x, M + (lane & 15), M, D, std::make_integer_sequence<int, BS>{});
 }
 
 // second launch-bound argument = waves per SIMD the register allocation must leave room for: without it the
@@ -1469,7 +1474,7 @@ __global__ __launch_bounds__(256, (RING || R == 2 ? 1 : 2)) void k_cholsol_dense
 // (16.6 KB) does not if every wave stages its own (4 x 16.6 KB per workgroup: two workgroups per CU).  Waves of a
 // workgroup that solve the SAME block for different right-hand sides share one copy: SHARE = blocks per workgroup
 // (4, 2 or 1), 4 / SHARE waves per block, each staging its share of the DMA; two workgroup barriers per pass.
-template <int BS, int SHARE>
+template <int BS, int SHARE, int MIX>
 __global__ __launch_bounds__(256, 3) void k_cholsol_dense_exact_dpp(const Tree *__restrict__ trees, int32_t ntrees,
                                                                     const int32_t *__restrict__ nodes, const int32_t *__restrict__ perm,
                                                                     const int32_t *__restrict__ f_ptr, const double *__restrict__ f_val,
@@ -1520,7 +1525,7 @@ __global__ __launch_bounds__(256, 3) void k_cholsol_dense_exact_dpp(const Tree *
         __syncthreads();                                    // all shares of the copy have landed
         if (sub == 0 && lane < BS) DG[lane] = dv;           // behind the DMA overrun of the last chunk
         __syncthreads();
-        dense_exact_pass_dpp<BS, pass == 1>(x, M, DG, lane);
+        dense_exact_pass_dpp<BS, pass == 1, MIX>(x, M, DG, lane);
     };
     run_pass(std::integral_constant<int, 0>{});
     run_pass(std::integral_constant<int, 1>{});
@@ -1960,27 +1965,31 @@ static int cholsol_solve(CholPlan *P, double *B, int32_t nrhs) {
         // operations and their order; the rounding-equal order the FMA / matrix-core kernels.
         if (P->dense_bs && !P->relaxed && ctx().opt.cholsol_dense_blocks) {
             // Variants ("cholsol.exact_variant"; measurements on G-spd, 5M rows, 128 right-hand sides, in
-            // profiles/r03_ablation.md section 3): 0 / 5 = the L values by DPP row broadcast (the default for every block
-            // size: 5.1 / 3.1 / 2.2 / 2.0 ms at blocks of 64 / 32 / 16 / 8); the LDS-broadcast forms it replaced: 1 = one
-            // fence per row / one right-hand side per lane, 2 = the L values through a ring of registers, 3 = rows / two per
-            // lane, 4 = ring / two per lane (two per lane only for blocks <= 32; at blocks of 32 these four compile to scratch).
+            // profiles/r03_ablation.md section 3): 0 / 5 = the L values by DPP row broadcast, one term in four by an LDS
+            // broadcast read (the default for every block size: 4.6 - 4.8 / 3.0 / 2.2 / 2.0 ms at blocks of 64 / 32 / 16 / 8);
+            // 6 = by DPP only; the LDS-broadcast forms they replaced: 1 = one fence per row / one right-hand side per
+            // lane, 2 = the L values through a ring of registers, 3 = rows / two per lane, 4 = ring / two per lane (two per
+            // lane only for blocks <= 32; at blocks of 32 these four compile to scratch).
             const int want = ctx().opt.cholsol_exact_variant;
             int variant = 5;
-            if (want >= 1 && want <= 5) variant = want;
-            if (variant == 5) {
+            if (want >= 1 && want <= 6) variant = want;
+            if (variant >= 5) {
                 // the L values by DPP row broadcast: one right-hand side per lane; waves that solve the same block share its
                 // LDS copy (as many as divide the number of 64-wide chunks of right-hand sides)
                 const int32_t chunks = (nrhs + 63) / 64;
                 const int share = chunks % 4 == 0 ? 1 : chunks % 2 == 0 ? 2 : 4;
                 const int64_t groups = ((int64_t)P->ntrees + share - 1) / share * (chunks / (4 / share));
                 const dim3 grid((unsigned)groups);
-#define CSX_DPP_X(BS, SH)                                                                                                          \
-    hipLaunchKernelGGL((k_cholsol_dense_exact_dpp<BS, SH>), grid, dim3(256), 0, s, P->trees, P->ntrees, P->tree_nodes, P->perm, \
+#define CSX_DPP_X(BS, SH, MX)                                                                                                          \
+    hipLaunchKernelGGL((k_cholsol_dense_exact_dpp<BS, SH, MX>), grid, dim3(256), 0, s, P->trees, P->ntrees, P->tree_nodes, P->perm, \
                        P->f_ptr, P->f_val, P->b_ptr, P->dense_b, P->diagk, P->diagb, B, nrhs, chunks)
+#define CSX_DPP_S(BS, MX)                      \
+    if (share == 1) CSX_DPP_X(BS, 1, MX);      \
+    else if (share == 2) CSX_DPP_X(BS, 2, MX); \
+    else CSX_DPP_X(BS, 4, MX)
 #define CSX_DPP_V(BS)                          \
-    if (share == 1) CSX_DPP_X(BS, 1);          \
-    else if (share == 2) CSX_DPP_X(BS, 2);     \
-    else CSX_DPP_X(BS, 4)
+    if (variant == 5) { CSX_DPP_S(BS, 1); }    \
+    else { CSX_DPP_S(BS, 0); }
                 switch (P->dense_bs) {
                     case 8: CSX_DPP_V(8); break;
                     case 16: CSX_DPP_V(16); break;
@@ -1988,6 +1997,7 @@ static int cholsol_solve(CholPlan *P, double *B, int32_t nrhs) {
                     default: CSX_DPP_V(64); break;
                 }
 #undef CSX_DPP_V
+#undef CSX_DPP_S
 #undef CSX_DPP_X
                 CSX_LAUNCH_CHECK();
                 return CSX_OK;

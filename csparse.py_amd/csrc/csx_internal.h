@@ -141,7 +141,7 @@ struct Options {
     int spgemm_ordered = 0;           // cs_multiply: sum every entry's products in the reference's order (bit-identical x)
     int spgemm_chunks = 1;            // cs_multiply: column chunks whose compaction overlaps the next chunk's hashing on a second stream
                                       // (1 = off, the default: measured slower, profiles/r03_ablation.md section 2)
-    int cholsol_exact_variant = 0;    // exact dense-block cholsol: 0 = the measured choice per block size, 1 - 5 force a variant (tests, ablation)
+    int cholsol_exact_variant = 0;    // exact dense-block cholsol: 0 = the measured choice per block size, 1 - 6 force a variant (tests, ablation)
     int lu_etree = 1;                 // cs_lu of one connected matrix on the device, columns scheduled by the column etree
                                       // (0 never, 1 when the tree is shallow enough for its size, 2 always)
 };

@@ -826,8 +826,8 @@ def test_supernodal_schedule_refuses_a_triangle_that_is_not_a_cholesky_factor(cs
 
 @pytest.mark.parametrize("bs", [8, 16, 32, 64])
 def test_exact_dense_block_kernel_variants_all_have_the_reference_bits(cs, bs):
-    """The default (exact) order on forests of dense blocks has five kernel variants (the L values by DPP row broadcast --
-    the default -- or by LDS broadcast with one fence per row or through a register ring, one or two right-hand sides
+    """The default (exact) order on forests of dense blocks has six kernel variants (the L values by DPP row broadcast, with or
+    without one term in four by an LDS broadcast read -- the default is with -- or by LDS broadcast with one fence per row or through a register ring, one or two right-hand sides
     per lane; "cholsol.exact_variant" forces one).  Each must be bit-identical to cs_lsolve + cs_ltsolve of the oracle, for 130
     right-hand sides (two full groups and a partial one; a partial pair for the two-per-lane variants)."""
     import _csx
@@ -841,7 +841,7 @@ def test_exact_dense_block_kernel_variants_all_have_the_reference_bits(cs, bs):
     Lp, Li, Lx = CO.chol(n, Ap, Ai, Ax, parent, cp)
     B = synth.rhs(n, k, 3)
     ref = {r: CO.ltsolve(n, Lp, Li, Lx, CO.lsolve(n, Lp, Li, Lx, B[:, r])) for r in (0, 63, 64, 127, 128, 129)}
-    for variant in (0, 1, 2, 3, 4, 5):
+    for variant in (0, 1, 2, 3, 4, 5, 6):
         with _csx.option("cholsol.exact_variant", variant):
             dB = cs.dvec(B)
             assert F.solve(dB)

@@ -1,5 +1,5 @@
 """Exact-order dense-block cholsol (the default of every plan) on G-spd, 5M rows, 128 right-hand sides: the four kernel
-variants ("cholsol.exact_variant": 1 = one fence per row / one RHS per lane, 2 = ring / one, 3 = rows / two, 4 = ring / two, 5 = L values by DPP row broadcast / one)
+variants ("cholsol.exact_variant": 1 = one fence per row / one RHS per lane, 2 = ring / one, 3 = rows / two, 4 = ring / two, 5 = L values by DPP row broadcast, one term in four by LDS broadcast / one, 6 = DPP only / one)
 per block size, ms per batch, and that every variant gives the same bits."""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "csparse.py_amd"))
@@ -14,7 +14,7 @@ for bs in [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "64,32,16,8").
     hL = _csx.new_handle(); _csx.check(lib.csx_chol(hA, _csx.pi(parent), _csx.pi(cp), None, hL))
     plan = _csx.new_handle(); _csx.check(lib.csx_cholsol_plan(hL, None, plan))
     ref = None
-    for variant in (1, 2, 3, 4, 5):
+    for variant in (1, 2, 3, 4, 5, 6, 5, 6):     # 5 and 6 twice: their difference is inside the run-to-run noise of one pass
         if bs == 64 and variant in (3, 4):
             continue
         _csx.check(lib.csx_set_option(b"cholsol.exact_variant", variant))
