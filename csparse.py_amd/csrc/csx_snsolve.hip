@@ -7,24 +7,25 @@
 // ~2 000 levels, each a launch or a workgroup barrier, each row's thousands of terms walked one dependent subtraction at
 // a time).  Here the schedule has three kinds of unit:
 //   * LEAF SUBTREES: maximal subtrees of the elimination tree with at most 64 columns (the small regions nested
-//     dissection stops at: most of the columns, almost none of the work).  One wave per (subtree, 64 right-hand sides)
-//     walks the subtree's rows with its x in LDS, from a packed program (local index, value) built with the plan: first
-//     of all in the forward solve, last of all in the backward one (after one launch has taken every leaf column's
-//     terms of rows OUTSIDE its subtree -- ancestors, final by then).
-//   * SUPERNODES of the rest, by height (forward) / depth (backward) in the supernodal elimination tree.  Per level,
+//     dissection stops at: most of the columns, almost none of the work), all of them in one launch: first of all in the
+//     forward solve, last of all in the backward one (after one launch has taken every leaf column's terms of rows
+//     OUTSIDE its subtree -- ancestors, final by then).  A subtree is a triangle of at most 64 x 64 made dense and solved on
+//     the matrix cores like B below, or (when the guard refuses that) a packed program walked out of LDS (k_sn_leaf).
+//   * SUPERNODES of the rest, by height (forward) / depth (backward) in the supernodal elimination tree: FUNDAMENTAL ones
+//     (dense trapezoids) and RELAXED ones (runs of at most 64 columns of a chain of the tree; see sn_build).  Per level,
 //       A: every row (column) of the level's supernodes takes its terms from OUTSIDE its supernode -- all final: they
-//          belong to descendants (ancestors) -- one wave per (piece of a row, 64 right-hand sides); a long row is cut
-//          into pieces of SN_SEG terms whose partial sums are added in a fixed order (reproducible bits);
-//       B: one workgroup per (supernode, 64 right-hand sides) stages the w x w triangle and the w rows of X in LDS and
-//          solves it there in panels of 16 (one wave the 16 x 16 triangle with its rows in registers, then all waves
-//          update the remaining rows).
+//          belong to descendants (ancestors) -- as tasks, a wave or a workgroup each per 64 right-hand sides; a line of
+//          more than SN_WHOLE terms is cut into pieces of SN_SEG whose partial sums are added in a fixed order;
+//       B: the triangle of every (chunk of a) supernode: a blocked TRSM on the matrix cores with explicit inverses of the
+//          16 x 16 diagonal blocks (k_sn_mfma; fragments built with the plan, guarded by the blocks' condition), or by
+//          substitution out of LDS in panels of 16 (k_sn_tri: "tri.supernodes" = 2, or a block past the guard).
 //   * WIDE supernodes (w > 64) are cut into chunks of 64 columns that are solved one after the other (a blocked,
 //     right-looking dense triangular solve): after chunk q, every remaining row of the supernode takes its 64 terms of
 //     that chunk in one launch across the chip (the same kernel as A), then chunk q + 1 is solved.
 // Forward reads the row-major copy of L the forward plan holds (terms of a row in ascending column order, so the terms
 // inside the row's own supernode are its LAST ones); backward reads L itself (a column: diagonal, the rows inside its
-// supernode, the rows below it).  Lane = right-hand side throughout: a term is one coalesced 512-byte load of a row of
-// X and one FMA.
+// supernode, the rows below it).  In A a lane is a right-hand side: a term is one coalesced 512-byte load of a row of X
+// and one FMA.
 //
 // Equal to the reference to rounding (the sums are regrouped), never used by the exact order; the same bits on every
 // run.  tests/test_gpu_cholesky.py compares with the plain-C restatement of the reference at 1e-10 and with the exact order.
