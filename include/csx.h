@@ -79,7 +79,16 @@ int csx_mem_info(int64_t *cached_bytes, int64_t *live_bytes, int64_t *device_fre
  * "chol.wband" (blocked dense-band cs_chol for chain-like factors: default 1 = for half-widths above 80, 0 = never,
  * 2 = whenever the tree is chain-like) and "chol.wband_nb" (columns per step: 16 (default) or 32; negative: two
  * launches per step instead of one); "chol.supernodes" (default 1); "pool.limit_mb" (cap of the device-memory cache in MB,
- * 0 = the default quarter of the device).  Unknown name: CSX_EINVAL. */
+ * 0 = the default quarter of the device).  Round 3: "tri.supernodes" (supernodal schedule of a cholsol plan in the
+ * rounding-equal order: 1 = yes, triangles on the matrix cores where their guard allows (default); 2 = yes, triangles by
+ * substitution out of LDS, no relaxed supernodes; 0 = never), "tri.graph" (default 0; 1 = the launches of a supernodal
+ * solve are captured into a hipGraph and replayed while the block of right-hand sides stays in place),
+ * "cholsol.exact_variant" (the exact dense-block kernel: 0 = default = 5: L values by DPP row broadcast, one term in four
+ * by an LDS broadcast read; 6: by DPP only; 1 - 4: the LDS-broadcast forms), "spgemm.ordered" (default 0; 1 = cs_multiply
+ * sums every entry's products in the reference's order: bit-identical values, about twenty times the time),
+ * "spgemm.chunks" (default 1; >= 2: hash and compaction of column chunks on two streams -- measured slower),
+ * "lu.etree" (cs_lu inside one connected matrix by levels of the column elimination tree: 1 = where the planner expects
+ * a gain (default), 2 = always, 0 = never).  Unknown name: CSX_EINVAL. */
 int csx_set_option(const char *name, int value);
 int csx_get_option(const char *name, int *value);   /* the value in force (after csx_set_option's normalisation) */
 int csx_timer_start(void);                /* hipEvent on the context's stream */
