@@ -1,7 +1,7 @@
 """Run ON THE GPU BOX: a longer randomised campaign than tests/test_gpu_fuzz.py (many seeds, shapes drawn at random) for
 the kernels rewritten in round 2: the radix sort behind cs_transpose, the one-pass cs_multiply kernels, csx_spsolve,
 the list-level cs_gaxpy.  Everything is checked against the C / Python oracles.  Progress goes to gpurun_out/fuzz.log.
-  python tools/fuzz_campaign.py [seconds]"""
+  python tools/fuzz_campaign.py [seconds] [first seed, default 0: a later run with another value draws other cases]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
@@ -41,7 +41,7 @@ def ragged(rng, m, n, mean_len, maxlen=None):
 
 
 t_end = time.time() + budget
-seed = 0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 counts = {"transpose": 0, "multiply": 0, "spsolve": 0, "trisolve": 0, "cholesky": 0, "band_trisolve": 0, "band_cholesky": 0,
           "nd_cholesky": 0}
 
