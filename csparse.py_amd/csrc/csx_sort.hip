@@ -436,10 +436,26 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const RsArgs g) {
         }
     }
     lds_barrier();
+    // Counting and ranking share one multi-split per round: the lanes of a round that hold the same digit are found by
+    // ballots (one per digit bit); the first of them adds the whole group to the wave's histogram, every lane keeps its
+    // rank in the group for the placement below.  (One LDS atomic per lane instead -- the earlier form -- serialises when a
+    // round's keys are clustered: the last pass of a transpose sees runs of 64 equal rows, 64 lanes on one counter.)
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    int rk[RS_ROUNDS];   // rank in the group | group size << 8
 #pragma unroll
     for (int r = 0; r < RS_ROUNDS; r++) {
         const int64_t idx = wbase + r * 64 + lane;
-        if (idx < count) atomicAdd(&wh[w][(kreg[r] >> shift) & mask], 1);
+        const bool valid = idx < count;
+        const uint32_t d = (kreg[r] >> shift) & mask;
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            unsigned long long bal = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? bal : ~bal;
+        }
+        const int rank = __popcll(peers & lt), cnt = __popcll(peers);
+        rk[r] = rank | (cnt << 8);
+        if (valid && rank == 0) atomicAdd(&wh[w][d], cnt);
     }
     lds_barrier();
     {
@@ -470,25 +486,17 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const RsArgs g) {
         }
     }
     lds_barrier();
-    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
     for (int r = 0; r < RS_ROUNDS; r++) {
         int64_t idx = wbase + r * 64 + lane;
         bool valid = idx < count;
         uint32_t k = kreg[r];
         uint32_t d = (k >> shift) & mask;
-        // lanes holding the same digit (multi-split by ballots, one per digit bit)
-        unsigned long long peers = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < 8; b++) {
-            unsigned long long bal = __ballot((d >> b) & 1u);
-            peers &= ((d >> b) & 1u) ? bal : ~bal;
-        }
-        int rank = __popcll(peers & lt);
+        const int rank = rk[r] & 255;
         int pos = 0;
         if (valid) pos = wh[w][d] + rank;
         __builtin_amdgcn_wave_barrier();
-        if (valid && rank == 0) wh[w][d] = pos + __popcll(peers);
+        if (valid && rank == 0) wh[w][d] = pos + (rk[r] >> 8);
         __builtin_amdgcn_wave_barrier();
         if (valid) {
             s_key[pos] = k;
