@@ -90,9 +90,11 @@ struct SnPlan {
     double *partial = nullptr;
     int64_t partial_len = 0;
     int4 *leaf4 = nullptr;                      // (first position in leaf_cols, columns, first fragment, 0) of every leaf subtree
+    int64_t frag_toff = 0;                      // the transposed tiles (backward sweep) lie this many doubles behind the forward ones
     double *frags = nullptr;                    // matrix-core fragments of every virtual supernode's and leaf subtree's triangle
     bool mfma = false;                          // fragments built and every block inverse tame: k_sn_mfma solves the triangles
     double growth = 0.0;                        // the guard's measure (k_sn_frags)
+    int chunk = 64;                             // columns per chunk of a wide supernode / per relaxed run (128: matrix cores only)
     bool has_relaxed = false;                   // some supernodes are runs of a chain, not dense trapezoids: matrix cores only
     int64_t generation = 0;                     // counts the moves of `partial` (a captured solve holds its address)
 };
@@ -381,43 +383,48 @@ __host__ __device__ constexpr int sn_tiles(int nb) { return nb * (nb + 1) / 2; }
 // rows a + t + 1 ..).  LEAF == true: a leaf subtree, positions a .. a + w - 1 of leaf_cols; column k's in-subtree entries come
 // from the packed backward program (position of the row in the subtree, value) -- the subtree's triangle made dense, the
 // entries its pattern lacks being zeros.
-template <bool LEAF>
+// MAXW: the widest triangle of the list (64; 128 for the chunks of a plan built with chunks of 128 columns)
+template <int MAXW>
+constexpr size_t sn_frags_lds() {
+    return (size_t)(MAXW * (MAXW + 1) + (MAXW / 16) * 16 * 17 + MAXW) * sizeof(double);
+}
+
+template <bool LEAF, int MAXW>
 __global__ __launch_bounds__(64) void k_sn_frags(const int4 *__restrict__ list, int32_t count, const int32_t *__restrict__ Lp,
                                                  const int32_t *__restrict__ Li, const double *__restrict__ Lx,
                                                  const int32_t *__restrict__ lb_ptr,
                                                  const int32_t *__restrict__ lb_idx, const double *__restrict__ lb_val,
                                                  const double *__restrict__ ldiag, double *__restrict__ frags,
-                                                 unsigned long long *cond_bits) {
-    __shared__ double Ls[64][65];
-    __shared__ double Wm[4][16][17];
+                                                 const int64_t t_off, unsigned long long *cond_bits) {
+    extern __shared__ __attribute__((aligned(16))) double sn_fr_smem[];     // sn_frags_lds<MAXW>() bytes
+    double(*Ls)[MAXW + 1] = reinterpret_cast<double(*)[MAXW + 1]>(sn_fr_smem);
+    double(*Wm)[16][17] = reinterpret_cast<double(*)[16][17]>(sn_fr_smem + MAXW * (MAXW + 1));
+    double *rsum = sn_fr_smem + MAXW * (MAXW + 1) + (MAXW / 16) * 16 * 17;
     const int lane = threadIdx.x;
     if ((int32_t)blockIdx.x >= count) return;
     const int4 ent = list[blockIdx.x];
     const int32_t a = ent.x, w = ent.y;
     const int nb = (w + 15) >> 4;
+    for (int e = lane; e < MAXW * MAXW; e += 64) Ls[e / MAXW][e % MAXW] = (e / MAXW) == (e % MAXW) ? 1.0 : 0.0;
+    __syncthreads();
     if (LEAF) {
-        for (int e = lane; e < 64 * 64; e += 64) Ls[e >> 6][e & 63] = (e >> 6) == (e & 63) ? 1.0 : 0.0;
-        __syncthreads();
         for (int k = 0; k < w; k++) {                   // column k of the subtree: distinct rows, so no two lanes meet
             const int32_t b = lb_ptr[a + k], l = lb_ptr[a + k + 1] - b;
             if (lane < l) Ls[lb_idx[b + lane]][k] = lb_val[b + lane];
             if (lane == 0) Ls[k][k] = ldiag[a + k];
         }
     } else {
-        for (int e = lane; e < 64 * 64; e += 64) Ls[e >> 6][e & 63] = (e >> 6) == (e & 63) ? 1.0 : 0.0;
-        __syncthreads();
-        for (int t = 0; t < w; t++) {                   // column a + t: diagonal, then its rows inside the triangle (at most 63,
-            const int32_t b = Lp[a + t], cnt = Lp[a + t + 1] - b;   // the first of the column: rows ascend)
-            if (lane < cnt) {
-                const int32_t i = Li[b + lane] - a;     // a fundamental supernode has all of t .. w - 1, a relaxed one some
-                if (i < w) Ls[i][t] = Lx[b + lane];
+        for (int t = 0; t < w; t++) {                   // column a + t: diagonal, then its rows inside the triangle (fewer
+            const int32_t b = Lp[a + t], cnt = Lp[a + t + 1] - b;   // than MAXW, the first of the column: rows ascend)
+            for (int q = lane; q < cnt && q < MAXW; q += 64) {
+                const int32_t i = Li[b + q] - a;        // a fundamental supernode has all of t .. w - 1, a relaxed one some
+                if (i < w) Ls[i][t] = Lx[b + q];
             }
         }
     }
     __syncthreads();
-    __shared__ double rsum[64];
-    {
-        const int blk = lane >> 4, col = lane & 15;
+    for (int pass = 0; pass < MAXW / 64; pass++) {
+        const int blk = (lane >> 4) + 4 * pass, col = lane & 15;
         double rs = 0.0;                                    // row sum of |L_ii| for row `col` of diagonal block blk
         if (blk < nb) {
             double wcol[16];
@@ -431,26 +438,37 @@ __global__ __launch_bounds__(64) void k_sn_frags(const int4 *__restrict__ list, 
                 rs += fabs(Ls[16 * blk + col][16 * blk + r]);
             }
         }
-        rsum[lane] = rs;
+        rsum[lane + 64 * pass] = rs;
     }
     __syncthreads();
     // What an explicit inverse costs in accuracy: X_i <- W_ii r with r = L_ii x carries a relative error of about
     // eps || |W_ii| |L_ii| ||_inf (the condition of the 16 x 16 diagonal block alone, whatever the scaling of its rows;
     // off-diagonal tiles enter as plain products).  Row `col` of that matrix sums to sum_k |W(col, k)| rsum(k).
     double growth = 0.0;
-    {
-        const int blk = lane >> 4, col = lane & 15;
+    for (int pass = 0; pass < MAXW / 64; pass++) {
+        const int blk = (lane >> 4) + 4 * pass, col = lane & 15;
+        double g = 0.0;
         if (blk < nb)
 #pragma unroll
-            for (int k = 0; k < 16; k++) growth += fabs(Wm[blk][col][k]) * rsum[16 * blk + k];
+            for (int k = 0; k < 16; k++) g += fabs(Wm[blk][col][k]) * rsum[16 * blk + k];
+        growth = (g > growth || !(g >= 0.0)) ? g : growth;   // a NaN wins
     }
     const int m = lane & 15, kq = lane >> 4;
-    double *F = frags + (size_t)ent.z * 64 + lane;
+    // forward fragments, and at the same tile positions t_off doubles further on the TRANSPOSED tiles for the backward sweep
+    // (read out of the forward ones with lane and k-step exchanged they cost a 16-way LDS bank conflict per read: 21 us
+    // against 11 for a 128-column triangle)
+    double *F = frags + (size_t)ent.z * 64 + lane, *T = F + t_off;
     int f = 0;
     for (int i = 0; i < nb; i++) {
         for (int j = 0; j < i; j++)
-            for (int sx = 0; sx < 4; sx++) F[64 * f++] = -Ls[16 * i + m][16 * j + 4 * sx + kq];
-        for (int sx = 0; sx < 4; sx++) F[64 * f++] = Wm[i][m][4 * sx + kq];
+            for (int sx = 0; sx < 4; sx++) {
+                F[64 * f] = -Ls[16 * i + m][16 * j + 4 * sx + kq];
+                T[64 * f++] = -Ls[16 * i + 4 * sx + kq][16 * j + m];
+            }
+        for (int sx = 0; sx < 4; sx++) {
+            F[64 * f] = Wm[i][m][4 * sx + kq];
+            T[64 * f++] = Wm[i][4 * sx + kq][m];
+        }
     }
     if (!(growth >= 0.0)) growth = __longlong_as_double(0x7ff0000000000000ll);   // a NaN (zero pivot): refuse
 #pragma unroll
@@ -463,15 +481,21 @@ __global__ __launch_bounds__(64) void k_sn_frags(const int4 *__restrict__ list, 
 // 16 right-hand sides (a workgroup of up to four waves per block of 64): each wave's chain of dependent matrix
 // instructions is a quarter as long, which is what a step with a handful of triangles is made of.
 // use0: the step has ONE triangle and its descriptor came with the launch (ent0) instead of through a load.
-template <bool FWD, bool GATHER, int CT>
+// NBMAX: block rows of 16 a triangle can have (4; 8 for the 128-column chunks of a plan built with such chunks, CT = 1 then).
+template <bool FWD, bool GATHER, int CT, int NBMAX>
 __global__ __launch_bounds__(256) void k_sn_mfma(const int4 *__restrict__ list, int32_t first, const int4 ent0, const int use0,
-                                                 const int32_t *__restrict__ rows, const double *__restrict__ frags, double *X,
-                                                 int nrhs) {
+                                                 const int32_t *__restrict__ rows, const double *__restrict__ frags,
+                                                 const int64_t t_off, double *X, int nrhs) {
+    // The triangle's fragments are staged in LDS by global -> LDS DMA, all of them requested at once by the workgroup's
+    // waves together: read straight into registers they came in a dozen dependent batches (as many as the registers held),
+    // each a memory round trip -- 15 - 24 us for the 72 KB of a 128-column triangle, 7 - 9 us for the 20 KB of a 64-column one.
+    extern __shared__ __attribute__((aligned(16))) double sn_fr[];      // sn_tiles(nb) * 256 doubles
     const int lane = threadIdx.x & 63;
-    const int cbase = CT == 4 ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nwv = (int)(blockDim.x >> 6);
+    const int cbase = CT == 4 ? 0 : wv;
     const int nblk = (nrhs + 63) >> 6;
     const int h = (int)(blockIdx.x % nblk);
-    if (h * 64 + 16 * cbase >= nrhs) return;            // a column tile past the last right-hand side
+    const bool active = h * 64 + 16 * cbase < nrhs;     // (a column tile past the last right-hand side still helps to stage)
     const int4 ent = use0 ? ent0 : list[first + blockIdx.x / nblk];
     const int32_t a = ent.x, w = ent.y;
     const int nb = (w + 15) >> 4;                       // uniform
@@ -485,14 +509,14 @@ __global__ __launch_bounds__(256) void k_sn_mfma(const int4 *__restrict__ list, 
         cidx[c] = live[c] ? rhs : nrhs - 1;             // clamped: loaded, never stored
     }
     // lane (rq, col), register r of tile (i, c): row 16 i + rq + 4 r of the supernode, right-hand side 16 c + col
-    sn_f64x4 Xt[4][CT];
+    sn_f64x4 Xt[NBMAX][CT];
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < NBMAX; i++)
 #pragma unroll
         for (int c = 0; c < CT; c++) Xt[i][c] = sn_f64x4{0.0, 0.0, 0.0, 0.0};
-    int64_t roff[4][4];
+    int64_t roff[NBMAX][4];
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < NBMAX; i++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int row = 16 * i + rq + 4 * r;
@@ -500,7 +524,7 @@ __global__ __launch_bounds__(256) void k_sn_mfma(const int4 *__restrict__ list, 
             roff[i][r] = (int64_t)(GATHER ? (i < nb ? rows[at] : 0) : at) * nrhs;
         }
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < NBMAX; i++)
         if (i < nb) {
 #pragma unroll
             for (int r = 0; r < 4; r++) {
@@ -513,15 +537,23 @@ __global__ __launch_bounds__(256) void k_sn_mfma(const int4 *__restrict__ list, 
                 }
             }
         }
-    const double *F = frags + (size_t)ent.z * 64 + lane;
-    // transposed read of a stored tile: the A operand of tile' for (lane = (m, kq), k-step sx) is element (4 sx + kq, m) of
-    // the tile, which the forward layout keeps in k-step m >> 2 at lane (m & 3) * 16 + 4 sx + kq
-    const double *Ft = frags + (size_t)ent.z * 64 + (size_t)(col >> 2) * 64 + (col & 3) * 16 + rq;
+    {
+        typedef __attribute__((address_space(1))) const void *gptr_t;
+        typedef __attribute__((address_space(3))) void *lptr_t;
+        const double *gF = frags + (FWD ? 0 : t_off) + (size_t)ent.z * 64;   // backward: the transposed tiles
+        const int nk = sn_tiles(nb) * 2;                // pieces of 128 doubles (64 lanes x 16 bytes)
+        for (int k = wv; k < nk; k += nwv)
+            __builtin_amdgcn_global_load_lds((gptr_t)(gF + k * 128 + 2 * lane), (lptr_t)(sn_fr + k * 128), 16, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    if (!active) return;
+    const double *F = sn_fr + lane;
     auto tile_at = [](int p, int q) { return (p * (p + 1) / 2 + q) * 4; };   // first of the tile's four fragments
     if (FWD) {
         int f = 0;
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+        for (int i = 0; i < NBMAX; i++)
             if (i < nb) {
 #pragma unroll
                 for (int j = 0; j < i; j++)
@@ -545,14 +577,14 @@ __global__ __launch_bounds__(256) void k_sn_mfma(const int4 *__restrict__ list, 
             }
     } else {
 #pragma unroll
-        for (int i = 3; i >= 0; i--)
+        for (int i = NBMAX - 1; i >= 0; i--)
             if (i < nb) {
 #pragma unroll
-                for (int j = i + 1; j < 4; j++)
+                for (int j = i + 1; j < NBMAX; j++)
                     if (j < nb) {
 #pragma unroll
                         for (int sx = 0; sx < 4; sx++) {
-                            const double av = Ft[(size_t)tile_at(j, i) * 64 + 4 * sx];   // -L_ji' from the stored -L_ji
+                            const double av = F[64 * (tile_at(j, i) + sx)];            // -L_ji'
 #pragma unroll
                             for (int c = 0; c < CT; c++)
                                 Xt[i][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Xt[j][c][sx], Xt[i][c], 0, 0, 0);
@@ -563,7 +595,7 @@ __global__ __launch_bounds__(256) void k_sn_mfma(const int4 *__restrict__ list, 
                 for (int c = 0; c < CT; c++) Y[c] = sn_f64x4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int sx = 0; sx < 4; sx++) {
-                    const double av = Ft[(size_t)tile_at(i, i) * 64 + 4 * sx];           // W_ii' from the stored W_ii
+                    const double av = F[64 * (tile_at(i, i) + sx)];                    // W_ii'
 #pragma unroll
                     for (int c = 0; c < CT; c++) Y[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Xt[i][c][sx], Y[c], 0, 0, 0);
                 }
@@ -572,7 +604,7 @@ __global__ __launch_bounds__(256) void k_sn_mfma(const int4 *__restrict__ list, 
             }
     }
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < NBMAX; i++)
         if (i < nb) {
 #pragma unroll
             for (int r = 0; r < 4; r++) {
@@ -800,8 +832,8 @@ __global__ void k_sn_incount(int32_t n, const int32_t *__restrict__ sn_a, const 
 /* Build the supernodal schedule of a Cholesky factor.  parent: elimination tree (host, n), Lp_h / Gp_h: host copies of
  * L's column pointers and of the forward plan's row pointers (off-diagonal terms of each row); G*: that row-major copy
  * on the device.  *out = nullptr when the factor gains nothing from it (no supernodes to speak of, or a chain). */
-int sn_build(const Csc *L, const int32_t *parent, const int32_t *Lp_h, const int32_t *Gp_h, const int32_t *Gp, const int32_t *Gi,
-             const double *Gx, int32_t col_levels, SnPlan **out) {
+static int sn_build_with(const Csc *L, const int32_t *parent, const int32_t *Lp_h, const int32_t *Gp_h, const int32_t *Gp,
+                         const int32_t *Gi, const double *Gx, int32_t col_levels, const int chunk, SnPlan **out) {
     const int32_t n = L->n;
     *out = nullptr;
     if (n < 2) return CSX_OK;
@@ -852,7 +884,7 @@ int sn_build(const Csc *L, const int32_t *parent, const int32_t *Lp_h, const int
             const bool fund = chain && (Lp_h[j + 1] - Lp_h[j]) == (Lp_h[j] - Lp_h[j - 1]) - 1;
             int jn = 0;
             if (fund && kind != 2) jn = 1;
-            else if (chain && allow_relaxed && kind != 1 && w < SN_CHUNK) jn = 2;
+            else if (chain && allow_relaxed && kind != 1 && w < chunk) jn = 2;
             if (!jn) {
                 first.push_back(j);
                 kind = 0;
@@ -889,7 +921,7 @@ int sn_build(const Csc *L, const int32_t *parent, const int32_t *Lp_h, const int
     {
         std::vector<int32_t> lev_w((size_t)nlev, 0);
         for (int32_t S = 0; S < nsn; S++) lev_w[(size_t)height[(size_t)S]] = std::max(lev_w[(size_t)height[(size_t)S]], width[(size_t)S]);
-        for (int32_t l = 0; l < nlev; l++) est_steps += (lev_w[(size_t)l] + SN_CHUNK - 1) / SN_CHUNK;
+        for (int32_t l = 0; l < nlev; l++) est_steps += (lev_w[(size_t)l] + chunk - 1) / chunk;
     }
     if (say)
         std::fprintf(stderr, "sn_build: n %d: %d leaf subtrees (%d columns), %d supernodes in %d levels, ~%d steps (column levels: %d), max width %d\n",
@@ -899,6 +931,7 @@ int sn_build(const Csc *L, const int32_t *parent, const int32_t *Lp_h, const int
     if (est_steps * 8 > col_levels) return CSX_OK;
     SnPlan *P = new SnPlan();
     P->n = n;
+    P->chunk = chunk;
     P->nsn = nsn;
     P->max_w = max_w;
     P->nleaf = nleaf;
@@ -1028,13 +1061,13 @@ int sn_build(const Csc *L, const int32_t *parent, const int32_t *Lp_h, const int
             if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) st = CSX_ERUNTIME;
         }
     }
-    // ---- virtual supernodes: every supernode cut into chunks of SN_CHUNK columns ----
+    // ---- virtual supernodes: every supernode cut into chunks of `chunk` columns ----
     std::vector<int32_t> vs_a, vs_w, vs0((size_t)nsn + 1, 0);
     for (int32_t S = 0; S < nsn; S++) {
         vs0[(size_t)S] = (int32_t)vs_a.size();
-        for (int32_t c = 0; c < width[(size_t)S]; c += SN_CHUNK) {
+        for (int32_t c = 0; c < width[(size_t)S]; c += chunk) {
             vs_a.push_back(first[(size_t)S] + c);
-            vs_w.push_back(std::min(SN_CHUNK, width[(size_t)S] - c));
+            vs_w.push_back(std::min(chunk, width[(size_t)S] - c));
         }
     }
     vs0[(size_t)nsn] = (int32_t)vs_a.size();
@@ -1096,14 +1129,14 @@ int sn_build(const Csc *L, const int32_t *parent, const int32_t *Lp_h, const int
                         }
                     } else if (forward) {
                         // chunk q - 1 is solved: every later row takes its terms of that chunk's columns
-                        const int32_t c0 = (q - 1) * SN_CHUNK;
-                        for (int32_t v = q * SN_CHUNK; v < w; v++) {
+                        const int32_t c0 = (q - 1) * chunk;
+                        for (int32_t v = q * chunk; v < w; v++) {
                             const int32_t in0 = Gp_h[a + v + 1] - v;
-                            tasks.push_back({a + v, in0 + c0, in0 + c0 + SN_CHUNK, -1});
+                            tasks.push_back({a + v, in0 + c0, in0 + c0 + chunk, -1});
                         }
                     } else {
                         // chunk c = nch - q is solved: every earlier column takes its terms of that chunk's rows
-                        const int32_t c = nch - q, r0 = c * SN_CHUNK, r1 = std::min(w, r0 + SN_CHUNK);
+                        const int32_t c = nch - q, r0 = c * chunk, r1 = std::min(w, r0 + chunk);
                         for (int32_t v = 0; v < r0; v++) {
                             const int32_t base = Lp_h[a + v] - v;
                             tasks.push_back({a + v, base + r0, base + r1, -1});
@@ -1155,20 +1188,36 @@ int sn_build(const Csc *L, const int32_t *parent, const int32_t *Lp_h, const int
         const size_t nfrag = (size_t)at;
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
-        if (nfrag * 512 <= free_b / 4 && at < 0x7fffffff) {
+        if (nfrag * 1024 <= free_b / 4 && at < 0x7fffffff) {
             DevScope tmp;
             unsigned long long *d_cond = nullptr, h_cond = 0;
-            st = dalloc(&P->frags, nfrag * 64 + 64);
+            st = dalloc(&P->frags, 2 * nfrag * 64 + 64);
+            P->frag_toff = (int64_t)nfrag * 64;
             if (st == CSX_OK) st = up(&P->leaf4, leaf4);
             if (st == CSX_OK) st = tmp.alloc(&d_cond, 1);
             if (st == CSX_OK && hipMemsetAsync(d_cond, 0, sizeof(unsigned long long), s) != hipSuccess) st = CSX_ERUNTIME;
             if (st == CSX_OK) {
-                hipLaunchKernelGGL(k_sn_frags<false>, dim3((unsigned)nv), dim3(64), 0, s, P->fwd.tri4, (int32_t)nv, L->p, L->i, L->x,
-                                   (const int32_t *)nullptr, (const int32_t *)nullptr, (const double *)nullptr, (const double *)nullptr,
-                                   P->frags, d_cond);
+                static bool frag_lds_set = false;
+                if (!frag_lds_set) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sn_frags<false, 64>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              (int)sn_frags_lds<64>());
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sn_frags<true, 64>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              (int)sn_frags_lds<64>());
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sn_frags<false, 128>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              (int)sn_frags_lds<128>());
+                    frag_lds_set = true;
+                }
+                if (chunk > 64)
+                    hipLaunchKernelGGL((k_sn_frags<false, 128>), dim3((unsigned)nv), dim3(64), sn_frags_lds<128>(), s, P->fwd.tri4, (int32_t)nv,
+                                       L->p, L->i, L->x, (const int32_t *)nullptr, (const int32_t *)nullptr, (const double *)nullptr,
+                                       (const double *)nullptr, P->frags, P->frag_toff, d_cond);
+                else
+                    hipLaunchKernelGGL((k_sn_frags<false, 64>), dim3((unsigned)nv), dim3(64), sn_frags_lds<64>(), s, P->fwd.tri4, (int32_t)nv,
+                                       L->p, L->i, L->x, (const int32_t *)nullptr, (const int32_t *)nullptr, (const double *)nullptr,
+                                       (const double *)nullptr, P->frags, P->frag_toff, d_cond);
                 if (nleaf > 0)
-                    hipLaunchKernelGGL(k_sn_frags<true>, dim3((unsigned)nleaf), dim3(64), 0, s, P->leaf4, nleaf, L->p, L->i, L->x,
-                                       P->lb_ptr, P->lb_idx, P->lb_val, P->ldiag, P->frags, d_cond);
+                    hipLaunchKernelGGL((k_sn_frags<true, 64>), dim3((unsigned)nleaf), dim3(64), sn_frags_lds<64>(), s, P->leaf4, nleaf, L->p,
+                                       L->i, L->x, P->lb_ptr, P->lb_idx, P->lb_val, P->ldiag, P->frags, P->frag_toff, d_cond);
                 if (hipMemcpyAsync(&h_cond, d_cond, sizeof(h_cond), hipMemcpyDeviceToHost, s) != hipSuccess ||
                     hipStreamSynchronize(s) != hipSuccess)
                     st = CSX_ERUNTIME;
@@ -1187,7 +1236,7 @@ int sn_build(const Csc *L, const int32_t *parent, const int32_t *Lp_h, const int
         }
     }
     if (st == CSX_OK && hipStreamSynchronize(s) != hipSuccess) st = CSX_ERUNTIME;
-    if (st == CSX_OK && P->has_relaxed && !P->mfma) {
+    if (st == CSX_OK && (P->has_relaxed || P->chunk > 64) && !P->mfma) {
         // relaxed supernodes exist only as matrix-core fragments (the substitution kernel reads dense trapezoids): without
         // them -- a diagonal block past the guard, no memory for the fragments -- the level-scheduled plans keep the factor
         if (say) std::fprintf(stderr, "sn_build: relaxed supernodes but no matrix-core triangles (%.3g): no supernodal plan\n", growth);
@@ -1205,13 +1254,24 @@ int sn_build(const Csc *L, const int32_t *parent, const int32_t *Lp_h, const int
     return CSX_OK;
 }
 
+/* Chunks (and relaxed runs) of 128 columns when the triangles can go to the matrix cores -- half the steps of a chain, a
+ * step costing half as much again -- else of 64, the widest the substitution kernel stages in LDS. */
+int sn_build(const Csc *L, const int32_t *parent, const int32_t *Lp_h, const int32_t *Gp_h, const int32_t *Gp, const int32_t *Gi,
+             const double *Gx, int32_t col_levels, SnPlan **out) {
+    if (ctx().opt.tri_supernodes == 1) {
+        CSX_TRY(sn_build_with(L, parent, Lp_h, Gp_h, Gp, Gi, Gx, col_levels, 128, out));
+        if (*out) return CSX_OK;
+    }
+    return sn_build_with(L, parent, Lp_h, Gp_h, Gp, Gi, Gx, col_levels, SN_CHUNK, out);
+}
+
 void sn_info(const SnPlan *P, int32_t *nsn, int32_t *levels, int32_t *max_w) {
     if (nsn) *nsn = P->nsn;
     if (levels) *levels = (int32_t)P->fwd.steps.size();
     if (max_w) *max_w = P->max_w;
 }
 
-bool sn_usable(const SnPlan *P) { return !P->has_relaxed || (P->mfma && ctx().opt.tri_supernodes == 1); }
+bool sn_usable(const SnPlan *P) { return !(P->has_relaxed || P->chunk > 64) || (P->mfma && ctx().opt.tri_supernodes == 1); }
 
 void sn_info2(const SnPlan *P, int32_t *matrix_cores, double *growth) {
     if (matrix_cores) *matrix_cores = P->mfma && ctx().opt.tri_supernodes == 1 ? 1 : 0;
@@ -1238,6 +1298,11 @@ int sn_prepare(SnPlan *P, int32_t nrhs) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sn_tri_lds<SN_CHUNK>()));
         CSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sn_tri<4, SN_CHUNK, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sn_tri_lds<SN_CHUNK>()));
+        // the fragments of a 128-column triangle: 72 KB
+        CSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sn_mfma<true, false, 1, 8>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sn_tiles(8) * 256 * sizeof(double))));
+        CSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sn_mfma<false, false, 1, 8>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sn_tiles(8) * 256 * sizeof(double))));
         lds_set = true;
     }
     return CSX_OK;
@@ -1260,11 +1325,16 @@ int sn_solve(SnPlan *P, bool forward, const int32_t *Gp, const int32_t *Gi, cons
         const int4 ent0 = host && count == 1 ? (*host)[(size_t)first] : make_int4(0, 0, 0, 0);
         const int use0 = host && count == 1 ? 1 : 0;
         const unsigned grid = (unsigned)((int64_t)count * nblk);
-        if ((int64_t)count * nblk <= 512) {
-            const int tiles = std::min(4, (nrhs + 15) / 16);
-            hipLaunchKernelGGL((k_sn_mfma<F, G, 1>), dim3(grid), dim3(64 * tiles), 0, s, list, first, ent0, use0, rows, P->frags, X, nrhs);
+        const int tiles = std::min(4, (nrhs + 15) / 16);
+        constexpr size_t lds4 = (size_t)sn_tiles(4) * 256 * sizeof(double), lds8 = (size_t)sn_tiles(8) * 256 * sizeof(double);
+        if (!G && P->chunk > 64) {          // triangles of up to 128 columns: eight block rows of X, one column tile per wave
+            hipLaunchKernelGGL((k_sn_mfma<F, false, 1, 8>), dim3(grid), dim3(64 * tiles), lds8, s, list, first, ent0, use0, rows, P->frags,
+                               P->frag_toff, X, nrhs);
+        } else if ((int64_t)count * nblk <= 512) {
+            hipLaunchKernelGGL((k_sn_mfma<F, G, 1, 4>), dim3(grid), dim3(64 * tiles), lds4, s, list, first, ent0, use0, rows, P->frags, P->frag_toff,
+                               X, nrhs);
         } else {
-            hipLaunchKernelGGL((k_sn_mfma<F, G, 4>), dim3(grid), dim3(64), 0, s, list, first, ent0, use0, rows, P->frags, X, nrhs);
+            hipLaunchKernelGGL((k_sn_mfma<F, G, 4, 4>), dim3(grid), dim3(64), lds4, s, list, first, ent0, use0, rows, P->frags, P->frag_toff, X, nrhs);
         }
     };
     if (forward && P->nleaf && cores)
