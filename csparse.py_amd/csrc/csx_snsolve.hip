@@ -12,14 +12,14 @@
 //     OUTSIDE its subtree -- ancestors, final by then).  A subtree is a triangle of at most 64 x 64 made dense and solved on
 //     the matrix cores like B below, or (when the guard refuses that) a packed program walked out of LDS (k_sn_leaf).
 //   * SUPERNODES of the rest, by height (forward) / depth (backward) in the supernodal elimination tree: FUNDAMENTAL ones
-//     (dense trapezoids) and RELAXED ones (runs of at most 64 columns of a chain of the tree; see sn_build).  Per level,
+//     (dense trapezoids) and RELAXED ones (runs of at most 128 columns of a chain of the tree; see sn_build).  Per level,
 //       A: every row (column) of the level's supernodes takes its terms from OUTSIDE its supernode -- all final: they
 //          belong to descendants (ancestors) -- as tasks, a wave or a workgroup each per 64 right-hand sides; a line of
 //          more than SN_WHOLE terms is cut into pieces of SN_SEG whose partial sums are added in a fixed order;
 //       B: the triangle of every (chunk of a) supernode: a blocked TRSM on the matrix cores with explicit inverses of the
 //          16 x 16 diagonal blocks (k_sn_mfma; fragments built with the plan, guarded by the blocks' condition), or by
 //          substitution out of LDS in panels of 16 (k_sn_tri: "tri.supernodes" = 2, or a block past the guard).
-//   * WIDE supernodes (w > 64) are cut into chunks of 64 columns that are solved one after the other (a blocked,
+//   * WIDE supernodes are cut into chunks of 128 columns (64 with the substitution triangles) that are solved one after the other (a blocked,
 //     right-looking dense triangular solve): after chunk q, every remaining row of the supernode takes its 64 terms of
 //     that chunk in one launch across the chip (the same kernel as A), then chunk q + 1 is solved.
 // Forward reads the row-major copy of L the forward plan holds (terms of a row in ascending column order, so the terms
@@ -867,8 +867,8 @@ static int sn_build_with(const Csc *L, const int32_t *parent, const int32_t *Lp_
     // ---- supernodes of the columns outside the leaf subtrees ----
     // A column joins the supernode of its predecessor when it is that column's parent and
     //   (1) FUNDAMENTAL: its count is the predecessor's less one -- the two share their rows, the supernode is a dense
-    //       trapezoid of any width (cut into chunks of 64 columns below); or
-    //   (2) RELAXED (only with the matrix-core triangles): nothing more -- a run of at most 64 columns of a CHAIN of the
+    //       trapezoid of any width (cut into chunks of `chunk` columns below); or
+    //   (2) RELAXED (only with the matrix-core triangles): nothing more -- a run of at most `chunk` columns of a CHAIN of the
     //       tree.  Its triangle is made dense in the fragments (zeros where the pattern has none), the split of a row /
     //       column into its part inside and outside the run is looked up (k_sn_incount).  This is what gives a banded
     //       factor in natural order (one chain, no two columns with the same rows) a schedule of n / 64 steps.
