@@ -838,6 +838,9 @@ static int sn_build_with(const Csc *L, const int32_t *parent, const int32_t *Lp_
     *out = nullptr;
     if (n < 2) return CSX_OK;
     const bool say = std::getenv("CSX_CHOL_TIMING") != nullptr;
+    const bool allow_relaxed = ctx().opt.tri_supernodes == 1;
+    // (twigs of fewer than eight columns are left to the relaxed ranges below: as leaves they would cut the chain they hang off)
+    const int32_t leaf_min = allow_relaxed ? 8 : 1;
     // ---- leaf subtrees: maximal subtrees of at most SN_LEAF columns ----
     std::vector<int32_t> size((size_t)n, 1), sub_of((size_t)n, -1), local_of((size_t)n, -1);
     for (int32_t j = 0; j < n; j++)
@@ -847,7 +850,7 @@ static int sn_build_with(const Csc *L, const int32_t *parent, const int32_t *Lp_
     for (int32_t j = n - 1; j >= 0; j--) {            // parents before children
         const int32_t pj = parent[j];
         if (pj >= 0 && sub_of[(size_t)pj] >= 0) sub_of[(size_t)j] = sub_of[(size_t)pj];
-        else if (size[(size_t)j] <= SN_LEAF) sub_of[(size_t)j] = nleaf++;
+        else if (size[(size_t)j] <= SN_LEAF && size[(size_t)j] >= leaf_min) sub_of[(size_t)j] = nleaf++;
     }
     {
         std::vector<int32_t> cnt((size_t)nleaf + 1, 0);
@@ -873,25 +876,47 @@ static int sn_build_with(const Csc *L, const int32_t *parent, const int32_t *Lp_
     //       column into its part inside and outside the run is looked up (k_sn_incount).  This is what gives a banded
     //       factor in natural order (one chain, no two columns with the same rows) a schedule of n / 64 steps.
     // A supernode is of one kind: a fundamental one does not continue with relaxed joins, nor the other way round.
-    const bool allow_relaxed = ctx().opt.tri_supernodes == 1;
+    // (The relaxed kind is a RANGE of consecutive columns [a, e), e - a <= chunk, every one of which but the last has its
+    // parent inside the range: a chain, or a chain with the twigs that hang off it -- bcsstk16 in natural order is 4 810
+    // levels of chain for 4 884 columns with twigs of one to three columns every few steps.  Inside such a range every
+    // source of a row with index >= a is in the range, so the in / out split of k_sn_incount holds.  A fundamental run of 32
+    // or more columns stays fundamental (its chunks then need no looking up), shorter ones may end up inside a range.)
     std::vector<int32_t> first, sn_of((size_t)n, -1), joins((size_t)n, 0);
     bool any_relaxed = false;
     {
-        int kind = 0, w = 0;                                     // of the supernode being grown
+        auto fund_join = [&](int32_t j) {                        // column j continues a fundamental supernode of j - 1
+            return j > 0 && sub_of[(size_t)j] < 0 && sub_of[(size_t)j - 1] < 0 && parent[j - 1] == j &&
+                   (Lp_h[j + 1] - Lp_h[j]) == (Lp_h[j] - Lp_h[j - 1]) - 1;
+        };
+        std::vector<int8_t> frun((size_t)n + 1, 1);              // width of the fundamental run that starts at a column, capped at 32
+        for (int32_t c = n - 2; c >= 0; c--) frun[(size_t)c] = fund_join(c + 1) ? (int8_t)std::min(32, frun[(size_t)c + 1] + 1) : (int8_t)1;
+        int kind = 0;                                            // of the supernode being grown
+        int32_t rel_end = -1;                                    // end of the relaxed range being filled
         for (int32_t j = 0; j < n; j++) {
             if (sub_of[(size_t)j] >= 0) continue;
-            const bool chain = j > 0 && sub_of[(size_t)j - 1] < 0 && parent[j - 1] == j;
-            const bool fund = chain && (Lp_h[j + 1] - Lp_h[j]) == (Lp_h[j] - Lp_h[j - 1]) - 1;
             int jn = 0;
-            if (fund && kind != 2) jn = 1;
-            else if (chain && allow_relaxed && kind != 1 && w < chunk) jn = 2;
+            if (j < rel_end) jn = 2;
+            else if (kind != 2 && fund_join(j)) jn = 1;
             if (!jn) {
                 first.push_back(j);
                 kind = 0;
-                w = 1;
+                rel_end = -1;
+                if (allow_relaxed) {
+                    if (frun[(size_t)j] < 32) {
+                        // the longest range [j, e) whose columns before the last all have their parent inside; it stops
+                        // short of a wide fundamental supernode
+                        int32_t best = j + 1, maxpar = parent[j];
+                        for (int32_t c = j + 1; c < n && c - j < chunk && sub_of[(size_t)c] < 0 && maxpar >= 0; c++) {
+                            if (frun[(size_t)c] >= 32 && !fund_join(c)) break;
+                            if (maxpar <= c) best = c + 1;       // [j, c + 1): the parents of j .. c - 1 lie at or before c
+                            maxpar = std::max(maxpar, parent[c] < 0 ? 0x7fffffff : parent[c]);
+                            if (parent[c] < 0) break;            // a root: nothing can follow it inside a range
+                        }
+                        if (best > j + 1) rel_end = best;
+                    }
+                }
             } else {
                 kind = jn;
-                w++;
                 any_relaxed |= jn == 2;
             }
             joins[(size_t)j] = jn;

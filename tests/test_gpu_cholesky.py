@@ -809,18 +809,23 @@ def test_supernodal_schedule_refuses_a_triangle_that_is_not_a_cholesky_factor(cs
     Lp, Li, Lx = np.asarray(Ap, np.int32), np.concatenate(cols_i), np.concatenate(cols_x)
     hL = _csx.new_handle()
     _csx.check(lib.csx_csc_upload(n, n, _csx.pi(Lp), _csx.pi(Li), _csx.pd(Lx), hL))
-    plan = _csx.new_handle()
-    _csx.check(lib.csx_cholsol_plan(hL, None, plan))
-    _csx.check(lib.csx_cholsol_set_order(plan, 0))
-    path = _csx.C.c_int32(-1)
-    _csx.check(lib.csx_cholsol_info(plan, path, None, None))
-    assert path.value == 0
     b = synth.rhs(n, 1, 0)[:, 0]
-    X = cs.dvec(b)
-    _csx.check(lib.csx_cholsol_solve(plan, X.handle, 1))
     ref = CO.ltsolve(n, Lp, Li, Lx, CO.lsolve(n, Lp, Li, Lx, b))
-    assert np.max(np.abs(X.numpy() - ref)) <= 1e-10 * np.max(np.abs(ref))
-    _csx.free(plan)
+    # "tri.supernodes" = 2: fundamental supernodes only -- the columns' counts say "supernode", their rows do not: refused.
+    # Default: the tree is a chain, every later row IS an ancestor, so runs of the chain as RELAXED supernodes (which ask
+    # nothing of the rows) are a valid schedule -- accepted, and the answer has to be right either way.
+    for mode, want_path in ((2, 0), (1, 4)):
+        with _csx.option("tri.supernodes", mode):
+            plan = _csx.new_handle()
+            _csx.check(lib.csx_cholsol_plan(hL, None, plan))
+            _csx.check(lib.csx_cholsol_set_order(plan, 0))
+            path = _csx.C.c_int32(-1)
+            _csx.check(lib.csx_cholsol_info(plan, path, None, None))
+            assert path.value == want_path, mode
+            X = cs.dvec(b)
+            _csx.check(lib.csx_cholsol_solve(plan, X.handle, 1))
+            assert np.max(np.abs(X.numpy() - ref)) <= 1e-10 * np.max(np.abs(ref)), mode
+            _csx.free(plan)
     _csx.free(hL)
 
 
