@@ -193,6 +193,43 @@ __global__ __launch_bounds__(256) void k_sn_outside(const SnTask *__restrict__ t
     else partial[(int64_t)t.out * nrhs + r] = d;
 }
 
+// A for MANY tasks and FEW right-hand sides: R lanes per task (R = the number of right-hand sides rounded up to a power of
+// two, at most 32), 64 / R tasks per wave, every lane walking its task's terms itself.  With a wave per task the launch of
+// the leaf columns' outside terms on the 700 x 700 grid -- 378 000 tasks of a handful of terms -- is bound by the rate at
+// which waves can be started (375 us for one right-hand side); this form starts 64 / R times fewer.  The sum is formed
+// exactly as sn_dot forms it (even terms into one accumulator, odd ones into the other, the last group of 16 padded with
+// zero products), so a right-hand side gets the same bits whichever kernel ran.
+template <int R>
+__global__ __launch_bounds__(256) void k_sn_outside_thin(const SnTask *__restrict__ tasks, int32_t first, int32_t count,
+                                                         const int32_t *__restrict__ idx, const double *__restrict__ val, double *X,
+                                                         double *partial, int nrhs) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t task = gid / R;
+    const int r = (int)(gid % R);
+    if (task >= count || r >= nrhs) return;
+    const SnTask t = tasks[first + task];
+    if (t.e <= t.b) return;
+    double acc0 = 0.0, acc1 = 0.0;
+    int32_t q = t.b;
+    for (; q + 1 < t.e; q += 2) {
+        acc0 = fma(val[q], X[(int64_t)idx[q] * nrhs + r], acc0);
+        acc1 = fma(val[q + 1], X[(int64_t)idx[q + 1] * nrhs + r], acc1);
+    }
+    if (q < t.e) {
+        acc0 = fma(val[q], X[(int64_t)idx[q] * nrhs + r], acc0);
+        q++;
+        if ((q - t.b) & 15) acc1 = fma(0.0, X[r], acc1);     // sn_dot's padding: pairs (0.0, row 0) up to the end of the group of 16
+        q++;
+    }
+    for (; (q - t.b) & 15; q += 2) {
+        acc0 = fma(0.0, X[r], acc0);
+        acc1 = fma(0.0, X[r], acc1);
+    }
+    const double d = acc0 + acc1;
+    if (t.out < 0) X[(int64_t)t.line * nrhs + r] -= d;
+    else partial[(int64_t)t.out * nrhs + r] = d;
+}
+
 // A for steps of few tasks: a WORKGROUP per (task, 64 right-hand sides).  The task's terms are dealt to the four waves in
 // runs of 64 (wave w: runs w, w + 4, ...), the four sums meet in LDS and are added in wave order.  A task of 300 terms --
 // a row of a banded chain -- is then two memory round trips deep instead of five, and in such a factor the step waits for
@@ -1342,6 +1379,25 @@ int sn_solve(SnPlan *P, bool forward, const int32_t *Gp, const int32_t *Gi, cons
     const int32_t *idx = forward ? Gi : L->i;
     const double *val = forward ? Gx : L->x;
     const bool cores = P->mfma && ctx().opt.tri_supernodes == 1;
+    // a launch of many tasks: a wave per (task, 64 right-hand sides), or R lanes per task for up to 32 right-hand sides
+    auto many_tasks = [&](const SnTask *tasks, int32_t t0, int32_t tc, const int32_t *ti, const double *tv) {
+        if (nrhs <= 32 && tc >= 8192) {      // (few tasks: their length counts, not their number -- a wave each)
+            int R = 1;
+            while (R < nrhs) R *= 2;
+            const unsigned grid = (unsigned)(((int64_t)tc * R + 255) / 256);
+            switch (R) {
+                case 1: hipLaunchKernelGGL(k_sn_outside_thin<1>, dim3(grid), dim3(256), 0, s, tasks, t0, tc, ti, tv, X, P->partial, nrhs); break;
+                case 2: hipLaunchKernelGGL(k_sn_outside_thin<2>, dim3(grid), dim3(256), 0, s, tasks, t0, tc, ti, tv, X, P->partial, nrhs); break;
+                case 4: hipLaunchKernelGGL(k_sn_outside_thin<4>, dim3(grid), dim3(256), 0, s, tasks, t0, tc, ti, tv, X, P->partial, nrhs); break;
+                case 8: hipLaunchKernelGGL(k_sn_outside_thin<8>, dim3(grid), dim3(256), 0, s, tasks, t0, tc, ti, tv, X, P->partial, nrhs); break;
+                case 16: hipLaunchKernelGGL(k_sn_outside_thin<16>, dim3(grid), dim3(256), 0, s, tasks, t0, tc, ti, tv, X, P->partial, nrhs); break;
+                default: hipLaunchKernelGGL(k_sn_outside_thin<32>, dim3(grid), dim3(256), 0, s, tasks, t0, tc, ti, tv, X, P->partial, nrhs); break;
+            }
+        } else {
+            const int64_t waves = (int64_t)tc * nblk;
+            hipLaunchKernelGGL(k_sn_outside, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, tasks, t0, tc, ti, tv, X, P->partial, nrhs);
+        }
+    };
     // `count` triangles of a list from `first` on: few of them -> a wave per column tile of 16 right-hand sides (the dependent
     // chain of a step is what counts), many -> a wave per 64 (fewer workgroups, every fragment read once)
     auto triangles = [&](auto fwd_tag, auto gather_tag, const int4 *list, const std::vector<int4> *host, int32_t first, int32_t count,
@@ -1372,9 +1428,7 @@ int sn_solve(SnPlan *P, bool forward, const int32_t *Gp, const int32_t *Gi, cons
             hipLaunchKernelGGL(k_sn_outside_wg, dim3((unsigned)((int64_t)t.tc * nblk)), dim3(256), 0, s, D.tasks, t.t0, t.tc, idx, val, X,
                                P->partial, nrhs);
         } else if (t.tc > 0) {
-            const int64_t waves = (int64_t)t.tc * nblk;
-            hipLaunchKernelGGL(k_sn_outside, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, D.tasks, t.t0, t.tc, idx, val, X,
-                               P->partial, nrhs);
+            many_tasks(D.tasks, t.t0, t.tc, idx, val);
         }
         if (t.cc > 0) {
             const int64_t waves = (int64_t)t.cc * nblk;
@@ -1410,9 +1464,7 @@ int sn_solve(SnPlan *P, bool forward, const int32_t *Gp, const int32_t *Gi, cons
     }
     if (!forward && P->nleaf) {
         const int64_t waves = (int64_t)P->nleaftasks * nblk;    // every leaf column's rows outside its subtree (ancestors: final)
-        if (waves > 0)
-            hipLaunchKernelGGL(k_sn_outside, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, P->leaf_tasks, 0, P->nleaftasks, L->i,
-                               L->x, X, P->partial, nrhs);
+        if (waves > 0) many_tasks(P->leaf_tasks, 0, P->nleaftasks, L->i, L->x);
         if (P->nleafslots > 0) {                                // the leaf columns that were cut into pieces
             const int64_t cw = (int64_t)P->nleafcols * nblk;
             hipLaunchKernelGGL(k_sn_combine, dim3((unsigned)((cw + 3) / 4)), dim3(256), 0, s, P->leaf_cols, 0, P->nleafcols, P->lslot_ptr, 1,

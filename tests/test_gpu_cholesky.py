@@ -676,6 +676,16 @@ def test_supernodal_solves_in_the_rounding_equal_order(cs, case):
             assert np.max(np.abs(Xr[:, r] - ref)) <= 1e-10 * np.max(np.abs(ref))
             scale = np.maximum(np.abs(ref), 1e-3 * np.max(np.abs(ref)))
             assert np.max(np.abs(Xr[:, r] - ref) / scale) <= 1e-9
+    # a right-hand side gets the same bits however many others are solved with it (the kernels that take few
+    # right-hand sides -- lanes per task instead of a wave per task -- form every sum in the same order)
+    B64 = synth.rhs(n, 64, 7)
+    X64 = cs.dvec(B64)
+    assert Fr.solve(X64)
+    X64 = X64.numpy().reshape(n, 64)
+    for kk in (1, 3, 8, 20, 33):
+        Xk = cs.dvec(np.ascontiguousarray(B64[:, :kk]))
+        assert Fr.solve(Xk)
+        assert Xk.numpy().reshape(n, kk).tobytes() == np.ascontiguousarray(X64[:, :kk]).tobytes(), kk
     with _csx.option("tri.supernodes", 0):
         F0 = cs.cholsol_factor(A, order=order, exact=False)
         _csx.check(_csx.lib().csx_cholsol_info(F0.plan_handle, path, None, None))
