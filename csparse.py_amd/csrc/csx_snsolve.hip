@@ -61,6 +61,7 @@ struct SnStep {
     int32_t m0, mc;   // up to 32 columns: two waves, a quarter of the LDS of the wide ones
     int32_t b0, bc;   // the others (four waves each)
     int32_t q0, qc;   // all of them in one list for the matrix-core kernel (SnDir::tri4)
+    int64_t terms;    // terms of the step's tasks together
 };
 
 struct SnDir {
@@ -1171,7 +1172,7 @@ static int sn_build_with(const Csc *L, const int32_t *parent, const int32_t *Lp_
             for (int32_t S : by[(size_t)l]) nsub = std::max(nsub, vs0[(size_t)S + 1] - vs0[(size_t)S]);
             for (int32_t q = 0; q < nsub; q++) {
                 SnStep stp{(int32_t)tasks.size(), 0, (int32_t)comb.size(), 0, (int32_t)narrow.size(), 0, (int32_t)medium.size(), 0,
-                           (int32_t)wide.size(), 0, (int32_t)tri.size(), 0};
+                           (int32_t)wide.size(), 0, (int32_t)tri.size(), 0, 0};
                 for (int32_t S : by[(size_t)l]) {
                     const int32_t a = first[(size_t)S], w = width[(size_t)S], nch = vs0[(size_t)S + 1] - vs0[(size_t)S];
                     if (q >= nch) continue;
@@ -1210,6 +1211,7 @@ static int sn_build_with(const Csc *L, const int32_t *parent, const int32_t *Lp_
                     tri.push_back(make_int4(vs_a[(size_t)chunk], cw, vs_f[(size_t)chunk], 0));
                 }
                 stp.tc = (int32_t)tasks.size() - stp.t0;
+                for (int32_t t = stp.t0; t < stp.t0 + stp.tc; t++) stp.terms += tasks[(size_t)t].e - tasks[(size_t)t].b;
                 stp.cc = (int32_t)comb.size() - stp.c0;
                 stp.sc = (int32_t)narrow.size() - stp.s0;
                 stp.mc = (int32_t)medium.size() - stp.m0;
@@ -1380,8 +1382,11 @@ int sn_solve(SnPlan *P, bool forward, const int32_t *Gp, const int32_t *Gi, cons
     const double *val = forward ? Gx : L->x;
     const bool cores = P->mfma && ctx().opt.tri_supernodes == 1;
     // a launch of many tasks: a wave per (task, 64 right-hand sides), or R lanes per task for up to 32 right-hand sides
-    auto many_tasks = [&](const SnTask *tasks, int32_t t0, int32_t tc, const int32_t *ti, const double *tv) {
-        if (nrhs <= 32 && tc >= 8192) {      // (few tasks: their length counts, not their number -- a wave each)
+    auto many_tasks = [&](const SnTask *tasks, int32_t t0, int32_t tc, const int32_t *ti, const double *tv, bool short_tasks) {
+        // (lanes per task pay when the tasks are many and SHORT: a lane walks its task one dependent gather after the other --
+        // 22 528 tasks of up to 512 terms took 100 us that way against 35 - 60 with a wave each)
+        // (and when there are so many that a wave each is bound by the rate at which waves start, whatever their length)
+        if (nrhs <= 32 && tc >= 8192 && (short_tasks || tc >= 50000)) {
             int R = 1;
             while (R < nrhs) R *= 2;
             const unsigned grid = (unsigned)(((int64_t)tc * R + 255) / 256);
@@ -1428,7 +1433,7 @@ int sn_solve(SnPlan *P, bool forward, const int32_t *Gp, const int32_t *Gi, cons
             hipLaunchKernelGGL(k_sn_outside_wg, dim3((unsigned)((int64_t)t.tc * nblk)), dim3(256), 0, s, D.tasks, t.t0, t.tc, idx, val, X,
                                P->partial, nrhs);
         } else if (t.tc > 0) {
-            many_tasks(D.tasks, t.t0, t.tc, idx, val);
+            many_tasks(D.tasks, t.t0, t.tc, idx, val, t.terms <= (int64_t)48 * t.tc);
         }
         if (t.cc > 0) {
             const int64_t waves = (int64_t)t.cc * nblk;
@@ -1464,7 +1469,7 @@ int sn_solve(SnPlan *P, bool forward, const int32_t *Gp, const int32_t *Gi, cons
     }
     if (!forward && P->nleaf) {
         const int64_t waves = (int64_t)P->nleaftasks * nblk;    // every leaf column's rows outside its subtree (ancestors: final)
-        if (waves > 0) many_tasks(P->leaf_tasks, 0, P->nleaftasks, L->i, L->x);
+        if (waves > 0) many_tasks(P->leaf_tasks, 0, P->nleaftasks, L->i, L->x, true);   // a leaf column's few rows above its subtree
         if (P->nleafslots > 0) {                                // the leaf columns that were cut into pieces
             const int64_t cw = (int64_t)P->nleafcols * nblk;
             hipLaunchKernelGGL(k_sn_combine, dim3((unsigned)((cw + 3) / 4)), dim3(256), 0, s, P->leaf_cols, 0, P->nleafcols, P->lslot_ptr, 1,
