@@ -1323,8 +1323,12 @@ static int sn_build_with(const Csc *L, const int32_t *parent, const int32_t *Lp_
 int sn_build(const Csc *L, const int32_t *parent, const int32_t *Lp_h, const int32_t *Gp_h, const int32_t *Gp, const int32_t *Gi,
              const double *Gx, int32_t col_levels, SnPlan **out) {
     if (ctx().opt.tri_supernodes == 1) {
-        CSX_TRY(sn_build_with(L, parent, Lp_h, Gp_h, Gp, Gi, Gx, col_levels, 128, out));
-        if (*out) return CSX_OK;
+        const int st = sn_build_with(L, parent, Lp_h, Gp_h, Gp, Gi, Gx, col_levels, 128, out);
+        if (st == CSX_OK && *out) return CSX_OK;
+        if (st != CSX_OK) {                 // (its fragment builder wants 150 KB of LDS: should a device refuse, chunks of 64 remain)
+            (void)hipGetLastError();
+            *out = nullptr;
+        }
     }
     return sn_build_with(L, parent, Lp_h, Gp_h, Gp, Gi, Gx, col_levels, SN_CHUNK, out);
 }
