@@ -135,6 +135,7 @@ struct Options {
     int gaxpy_tune_shape = 0;    // tiled cs_gaxpy plan: time the launch shapes when the plan is built and keep the fastest
     int tri_row_waves = 1;        // level-scheduled solves: a wave per row for few right-hand sides and long rows
     int tri_levels_where = 0;         // level analysis: 0 = device for big factors, host for small; 1 = host; 2 = device
+    int sort_short_keys = 1;          // cs_transpose: 16-bit keys between the radix passes where the matrix allows (0: always 32-bit)
     int tri_graph = 0;                // supernodal solves: replay the launches of a solve as a hipGraph while the block of right-hand sides stays in place
     int tri_supernodes = 1;           // cholsol: supernodal forward / backward solves on factors with supernodes (0 never, 1 yes,
                                       // 2 yes but the triangles by substitution out of LDS instead of on the matrix cores)

@@ -182,6 +182,39 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint32_t *key, int
     hist[(size_t)blockIdx.x * RS_BINS + threadIdx.x] = h[threadIdx.x];
 }
 
+// the same for 16-bit keys (the short-key mode of a transpose, see stable_sort_by_key_ex): eight keys per 16-byte load
+__global__ __launch_bounds__(RS_THREADS) void k_rs_hist16(const uint16_t *key, int64_t count, int shift, uint32_t mask,
+                                                          int32_t *hist) {
+    __shared__ int h[RS_BINS];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * RS_TILE;
+    if (base + RS_TILE <= count && (reinterpret_cast<uintptr_t>(key) & 15) == 0) {
+        typedef uint32_t u32x4h __attribute__((ext_vector_type(4)));
+        const u32x4h *k4 = reinterpret_cast<const u32x4h *>(key + base);
+        u32x4h v[RS_ROUNDS / 8];
+#pragma unroll
+        for (int r = 0; r < RS_ROUNDS / 8; r++) v[r] = k4[r * RS_THREADS + threadIdx.x];
+#pragma unroll
+        for (int r = 0; r < RS_ROUNDS / 8; r++) {
+            const uint32_t w4[4] = {v[r].x, v[r].y, v[r].z, v[r].w};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                atomicAdd(&h[((w4[q] & 0xffffu) >> shift) & mask], 1);
+                atomicAdd(&h[((w4[q] >> 16) >> shift) & mask], 1);
+            }
+        }
+    } else {
+#pragma unroll 4
+        for (int r = 0; r < RS_ROUNDS; r++) {
+            int64_t idx = base + (int64_t)r * RS_THREADS + threadIdx.x;
+            if (idx < count) atomicAdd(&h[((uint32_t)key[idx] >> shift) & mask], 1);
+        }
+    }
+    __syncthreads();
+    hist[(size_t)blockIdx.x * RS_BINS + threadIdx.x] = h[threadIdx.x];
+}
+
 // hist[tile][digit] -> goff[tile][digit] = records with a smaller digit + records with this digit in earlier tiles,
 // i.e. the exclusive scan in (digit, tile) order, done on the tile-major matrix in three small steps: sums over
 // chunks of tiles, one workgroup that scans the chunk sums in (digit, chunk) order, running sums inside a chunk.
@@ -308,13 +341,21 @@ struct RsArgs {
     int shift;
     uint32_t mask, nblocks;
     int flat;
+    // short-key mode (KM != 0): 16-bit keys between the passes, the first digit riding in the top bits of `a`
+    const uint16_t *key16;
+    uint16_t *okey16;
+    int k16_w0;                // bits of the first digit
 };
 
 // Stable scatter of one workgroup tile (4096 records).  Ranks follow (wave, round, lane) = source
 // order.  Records are first placed in LDS in their sorted order inside the tile, then written out
 // position by position: consecutive threads write consecutive slots of a bucket, so the stores are
 // runs of whole 64/128-byte pieces instead of 4/8-byte singles.
-template <bool HAS_A, bool HAS_V, bool IN_AOS, bool OUT_AOS>
+// KM (short-key mode of a three-pass sort with derived columns -- a transpose): 0 = off; 1 = first pass: 32-bit keys in,
+// key >> w0 out as 16 bits, the first digit packed into the top w0 bits of the column; 2 = middle pass: 16-bit keys in and
+// out; 3 = last pass: 16-bit keys in, the column unpacked, the full key rebuilt for the pointer array.  Saves 2 bytes of
+// every key read and written after the first digit is spent: 12 bytes per record over the three passes and their histograms.
+template <bool HAS_A, bool HAS_V, bool IN_AOS, bool OUT_AOS, int KM = 0>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const RsArgs g) {
     static_assert(!(IN_AOS || OUT_AOS) || (HAS_A && HAS_V), "packed records carry both payloads");
     __shared__ int wh[RS_WAVES][RS_BINS];
@@ -358,7 +399,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const RsArgs g) {
 #pragma unroll
     for (int r = 0; r < RS_ROUNDS; r++) {
         const int64_t idx = wbase + r * 64 + lane;
-        kreg[r] = g.key[idx < count ? idx : count - 1];   // clamped: count > 0
+        kreg[r] = KM >= 2 ? (uint32_t)g.key16[idx < count ? idx : count - 1] : g.key[idx < count ? idx : count - 1];   // clamped: count > 0
     }
 #pragma unroll
     for (int r = 0; r < RS_ROUNDS; r++) {
@@ -434,6 +475,10 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const RsArgs g) {
                 areg[r] = (uint32_t)lo;
             }
         }
+    }
+    if (KM == 1) {
+#pragma unroll
+        for (int r = 0; r < RS_ROUNDS; r++) areg[r] |= (kreg[r] & mask) << (32 - g.k16_w0);   // the digit this pass spends
     }
     lds_barrier();
     // Counting and ranking share one multi-split per round: the lanes of a round that hold the same digit are found by
@@ -517,15 +562,24 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const RsArgs g) {
     for (int i = threadIdx.x; i < tcount; i += RS_THREADS) {
         const uint32_t k = s_key[i];
         const int64_t gp = (int64_t)gbase[(k >> shift) & mask] + i;
-        if (g.okey) g.okey[gp] = k;
+        if (KM == 1) g.okey16[gp] = (uint16_t)(k >> g.k16_w0);
+        else if (KM == 2) g.okey16[gp] = (uint16_t)k;
+        else if (KM == 0 && g.okey) g.okey[gp] = k;
         if (OUT_AOS) {
             g.opay[gp] = s_pay[i];
+        } else if (KM == 3) {
+            // the column without the packed digit; the full key = the 16 bits that travelled and that digit
+            const int ps = 32 - g.k16_w0;
+            const uint32_t a = s_a[i], full = (k << g.k16_w0) | (a >> ps);
+            g.oa[gp] = a & ((1u << ps) - 1u);
+            if (HAS_V) g.ov[gp] = s_v[i];
+            if (g.optr && (i == 0 || s_key[i - 1] != k || (s_a[i - 1] >> ps) != (a >> ps))) atomicMin(&g.optr[full], (int32_t)gp);
         } else {
             if (HAS_A) g.oa[gp] = s_a[i];
             if (HAS_V) g.ov[gp] = s_v[i];
         }
         // last pass: equal keys are neighbours in a bucket; the first of each group in this tile proposes its slot
-        if (g.optr && (i == 0 || s_key[i - 1] != k)) atomicMin(&g.optr[k], (int32_t)gp);
+        if (KM == 0 && g.optr && (i == 0 || s_key[i - 1] != k)) atomicMin(&g.optr[k], (int32_t)gp);
     }
 }
 
@@ -645,6 +699,11 @@ int stable_sort_by_key_ex(const uint32_t *key, const uint32_t *a, const double *
     const uint32_t nchunks = (nblocks + chunk - 1) / chunk;
     const bool has_a = a != nullptr || xp != nullptr, has_v = v != nullptr;
     const bool packed = has_a && has_v;   // (a, v) travel as 12-byte records between passes
+    // Short keys (a transpose with values of a matrix with fewer than 2^(32 - w0) columns and 17 .. 24 key bits): after the
+    // first pass has spent its digit the keys travel as 16 bits, that digit in the top bits of the column word.
+    const int w0 = bits / passes + (0 < bits % passes ? 1 : 0);
+    const bool k16 = xp != nullptr && packed && passes == 3 && optr != nullptr && out_key == nullptr && bits - w0 <= 16 &&
+                     (uint64_t)ex->expand_n <= (1ull << (32 - w0)) && ctx().opt.sort_short_keys;
 
     DevScope scope;
     int32_t *hist = nullptr, *part = nullptr;
@@ -657,8 +716,10 @@ int stable_sort_by_key_ex(const uint32_t *key, const uint32_t *a, const double *
     int32_t *const dbase = part + (size_t)RS_BINS * nchunks;
     if (st == CSX_OK && xp) st = scope.alloc(&desc, (size_t)nblocks * RS_DESC_WORDS);
     const int ntmp = passes > 2 ? 2 : passes - 1;
+    uint16_t *tk16[2] = {nullptr, nullptr};
     for (int t = 0; t < ntmp && st == CSX_OK; t++) {
-        st = scope.alloc(&tk[t], (size_t)count);
+        if (k16) st = scope.alloc(&tk16[t], (size_t)count + 8);
+        else st = scope.alloc(&tk[t], (size_t)count);
         if (packed) {
             if (st == CSX_OK) st = scope.alloc(&tp[t], (size_t)count);
         } else {
@@ -696,16 +757,27 @@ int stable_sort_by_key_ex(const uint32_t *key, const uint32_t *a, const double *
         g.opay = last ? nullptr : tp[ps & 1];
         g.optr = last ? optr : nullptr;
         g.goff = hist;
-        hipLaunchKernelGGL(k_rs_hist, dim3(nblocks), dim3(RS_THREADS), 0, s, g.key, count, g.shift, g.mask, hist);
+        if (k16) {
+            g.k16_w0 = w0;
+            g.okey16 = last ? nullptr : tk16[ps & 1];
+            g.okey = nullptr;
+            if (ps > 0) g.shift = shift - w0;            // in the 16-bit key the first digit is gone
+        }
+        if (k16 && ps > 0) hipLaunchKernelGGL(k_rs_hist16, dim3(nblocks), dim3(RS_THREADS), 0, s, g.key16, count, g.shift, g.mask, hist);
+        else hipLaunchKernelGGL(k_rs_hist, dim3(nblocks), dim3(RS_THREADS), 0, s, g.key, count, g.shift, g.mask, hist);
         hipLaunchKernelGGL(k_rs_colsum, dim3(nchunks), dim3(RS_BINS), 0, s, hist, nblocks, chunk, part);
         hipLaunchKernelGGL(k_rs_chunkscan, dim3(1), dim3(RS_BINS * RS_SEGS), 0, s, part, nchunks, dbase);
         hipLaunchKernelGGL(k_rs_tileprefix, dim3(nchunks), dim3(RS_BINS), 0, s, hist, part, dbase, nblocks, chunk);
-        if (has_a && has_v) launch_scatter<true, true>(in_aos, out_aos, dim3(nblocks), s, g);
+        if (k16 && ps == 0) hipLaunchKernelGGL((k_rs_scatter<true, true, false, true, 1>), dim3(nblocks), dim3(RS_THREADS), 0, s, g);
+        else if (k16 && !last) hipLaunchKernelGGL((k_rs_scatter<true, true, true, true, 2>), dim3(nblocks), dim3(RS_THREADS), 0, s, g);
+        else if (k16) hipLaunchKernelGGL((k_rs_scatter<true, true, true, false, 3>), dim3(nblocks), dim3(RS_THREADS), 0, s, g);
+        else if (has_a && has_v) launch_scatter<true, true>(in_aos, out_aos, dim3(nblocks), s, g);
         else if (has_a) launch_scatter<true, false>(false, false, dim3(nblocks), s, g);
         else if (has_v) launch_scatter<false, true>(false, false, dim3(nblocks), s, g);
         else launch_scatter<false, false>(false, false, dim3(nblocks), s, g);
         if (hipGetLastError() != hipSuccess) st = CSX_ERUNTIME;
         g.key = g.okey;
+        g.key16 = g.okey16;
         g.a = g.oa;
         g.v = g.ov;
         g.pay = g.opay;

@@ -87,6 +87,7 @@ int csx_mem_info(int64_t *cached_bytes, int64_t *live_bytes, int64_t *device_fre
  * by an LDS broadcast read; 6: by DPP only; 1 - 4: the LDS-broadcast forms), "spgemm.ordered" (default 0; 1 = cs_multiply
  * sums every entry's products in the reference's order: bit-identical values, about twenty times the time),
  * "spgemm.chunks" (default 1; >= 2: hash and compaction of column chunks on two streams -- measured slower),
+ * "sort.short_keys" (default 1: a transpose with values carries 16-bit keys between its radix passes where the matrix allows),
  * "lu.etree" (cs_lu inside one connected matrix by levels of the column elimination tree: 1 = where the planner expects
  * a gain (default), 2 = always, 0 = never).  Unknown name: CSX_EINVAL. */
 int csx_set_option(const char *name, int value);

@@ -207,6 +207,12 @@ def test_transpose_wide_keys_three_radix_passes(cs):
     AT = cs.cs_transpose(A, True)
     assert AT.m == n and AT.n == m
     assert AT.p == Tp.tolist() and AT.i == Ti.tolist() and np.asarray(AT.x).tobytes() == Tx.tobytes()
+    # (with values and 17 .. 24 key bits the keys travel as 16 bits after the first pass, the spent digit in the top bits
+    # of the column word; "sort.short_keys" = 0 keeps them 32 bits wide: the same result)
+    import _csx
+    with _csx.option("sort.short_keys", 0):
+        AT0 = cs.cs_transpose(A, True)
+    assert AT0.p == Tp.tolist() and AT0.i == Ti.tolist() and np.asarray(AT0.x).tobytes() == Tx.tobytes()
 
 
 def _transpose_abi(A_np, values=True):
