@@ -138,7 +138,7 @@ int expand_columns(const int32_t *Ap, int32_t n, int32_t nnz, int32_t *col) {
 // ---------------------------------------------------------- radix sort ----
 constexpr int RS_THREADS = 256;
 constexpr int RS_WAVES = RS_THREADS / 64;
-constexpr int RS_ROUNDS = 16;
+constexpr int RS_ROUNDS = 8;
 constexpr int RS_TILE = RS_THREADS * RS_ROUNDS;  // records per workgroup
 constexpr int RS_BINS = 256;
 
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint32_t *key, int
     hist[(size_t)blockIdx.x * RS_BINS + threadIdx.x] = h[threadIdx.x];
 }
 
-// the same for 16-bit keys (the short-key mode of a transpose, see stable_sort_by_key_ex): eight keys per 16-byte load
+// the same for 16-bit keys (the short-key mode of a transpose, see stable_sort_by_key_ex)
 __global__ __launch_bounds__(RS_THREADS) void k_rs_hist16(const uint16_t *key, int64_t count, int shift, uint32_t mask,
                                                           int32_t *hist) {
     __shared__ int h[RS_BINS];
@@ -190,18 +190,18 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist16(const uint16_t *key, i
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * RS_TILE;
     if (base + RS_TILE <= count && (reinterpret_cast<uintptr_t>(key) & 15) == 0) {
-        typedef uint32_t u32x4h __attribute__((ext_vector_type(4)));
-        const u32x4h *k4 = reinterpret_cast<const u32x4h *>(key + base);
-        u32x4h v[RS_ROUNDS / 8];
+        typedef uint32_t u32x2h __attribute__((ext_vector_type(2)));
+        const u32x2h *k2 = reinterpret_cast<const u32x2h *>(key + base);      // four keys per load
+        u32x2h v[RS_ROUNDS / 4];
 #pragma unroll
-        for (int r = 0; r < RS_ROUNDS / 8; r++) v[r] = k4[r * RS_THREADS + threadIdx.x];
+        for (int r = 0; r < RS_ROUNDS / 4; r++) v[r] = k2[r * RS_THREADS + threadIdx.x];
 #pragma unroll
-        for (int r = 0; r < RS_ROUNDS / 8; r++) {
-            const uint32_t w4[4] = {v[r].x, v[r].y, v[r].z, v[r].w};
+        for (int r = 0; r < RS_ROUNDS / 4; r++) {
+            const uint32_t w2[2] = {v[r].x, v[r].y};
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                atomicAdd(&h[((w4[q] & 0xffffu) >> shift) & mask], 1);
-                atomicAdd(&h[((w4[q] >> 16) >> shift) & mask], 1);
+            for (int q = 0; q < 2; q++) {
+                atomicAdd(&h[((w2[q] & 0xffffu) >> shift) & mask], 1);
+                atomicAdd(&h[((w2[q] >> 16) >> shift) & mask], 1);
             }
         }
     } else {
@@ -360,9 +360,9 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const RsArgs g) {
     static_assert(!(IN_AOS || OUT_AOS) || (HAS_A && HAS_V), "packed records carry both payloads");
     __shared__ int wh[RS_WAVES][RS_BINS];
     __shared__ int gbase[RS_BINS];  // global slot of a bucket's first record minus its local start
-    __shared__ int wsum[RS_WAVES];
     __shared__ uint32_t s_key[RS_TILE];
-    __shared__ __attribute__((aligned(16))) unsigned char s_raw[(HAS_A ? 4 : 0) * RS_TILE + (HAS_V ? 8 : 0) * RS_TILE + 16];
+    int *const wsum = reinterpret_cast<int *>(s_key);   // (the scan's wave totals: s_key is idle between the counting and the placement)
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[(HAS_A || HAS_V) ? (HAS_A ? 4 : 0) * RS_TILE + (HAS_V ? 8 : 0) * RS_TILE : 16];
     uint32_t *const s_a = reinterpret_cast<uint32_t *>(s_raw);
     double *const s_v = reinterpret_cast<double *>(s_raw + (HAS_A ? 4 * RS_TILE : 0));
     Pay *const s_pay = reinterpret_cast<Pay *>(s_raw);
