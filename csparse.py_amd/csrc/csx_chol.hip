@@ -41,6 +41,7 @@
 
 #include "csx_internal.h"
 #include "csx_sweep.h"
+#include "csx_cholclique.h"
 
 namespace csx {
 
@@ -656,6 +657,43 @@ static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, c
         fprintf(stderr, "[cs_chol] %-18s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
         t0 = t1;
     };
+    if (ctx().opt.chol_clique && ctx().opt.chol_dense_trees && !pinv) {
+        // A forest of cliques on consecutive columns (csx_cholclique.hip): L.p / L.i follow from the counts, the values are
+        // one read of A's upper part and one write of L, a block to a wave.  The caller's S must be that forest's.
+        CliqueForest F;
+        bool ok = false, same = false;
+        int st = clique_forest(A, &F, &ok);
+        if (st == CSX_OK && ok && F.ascending && F.max_bs <= CLIQUE_MAX_BLOCK) {
+            lap("clique forest");
+            st = clique_matches_host(F, parent, cp, &same);
+            int *d_notspd = nullptr;
+            int hflag = 0x7fffffff;
+            if (st == CSX_OK && !same) st = CSX_EINVAL;        // S.cp / S.parent do not belong to A
+            if (st == CSX_OK) st = dalloc(&L->i, (size_t)L->nnz);
+            if (st == CSX_OK) st = dalloc(&L->x, (size_t)L->nnz);
+            if (st == CSX_OK) st = dalloc(&d_notspd, 1);
+            if (st == CSX_OK) {
+                L->p = F.cp;
+                F.cp = nullptr;
+                lap("S compared");
+                if (hipMemcpyAsync(d_notspd, &hflag, sizeof(int), hipMemcpyHostToDevice, s) != hipSuccess) st = CSX_ERUNTIME;
+            }
+            if (st == CSX_OK) st = chol_clique_numeric(A, F, L, d_notspd);
+            if (st == CSX_OK && (hipMemcpyAsync(&hflag, d_notspd, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
+                                 hipStreamSynchronize(s) != hipSuccess)) {
+                set_error("cs_chol: %s", hipGetErrorString(hipGetLastError()));
+                st = CSX_ERUNTIME;
+            }
+            lap("numeric (blocks)");
+            dfree(d_notspd);
+            free_clique(&F);
+            if (st != CSX_OK) return st;
+            return hflag != 0x7fffffff ? CSX_ENOTSPD : CSX_OK;
+        }
+        free_clique(&F);
+        if (st != CSX_OK) return st;
+        lap("no clique forest");
+    }
     int32_t *d_rp = nullptr, *d_rc = nullptr, *d_rpos = nullptr, *d_pinv = nullptr, *d_win = nullptr;
     int32_t *d_small_cols = nullptr, *d_level_cols = nullptr, *d_level_ptr = nullptr;
     Tree *d_trees = nullptr, *d_dense = nullptr;
@@ -947,6 +985,9 @@ struct CholPlan {
     // (csx_cholsol_set_order(plan, 0)): results equal to rounding; dense 16/32/64 blocks go to the matrix cores
     // (explicit block inverses, built then), the chain walker may take out-of-block terms first.
     bool relaxed = false;
+    // forest of equal dense blocks recognised from L itself (cholsol_plan_clique): no triangular-solve plans, the dense
+    // programs cut straight out of L.x; f_idx / b_idx / b_val (the fused per-tree kernel's) are made when first needed
+    bool clique = false, clique_zero_pivot = false;
     bool mfma_tried = false;  // fragments were built, or refused by the growth guard
     double mfma_growth = 0.0; // max|inv(L_ii)| max|L| over the forest (the guard's measure)
     // big trees, rounding-equal order: supernodal schedule (csx_snsolve.hip), built the first time the plan is relaxed
@@ -1750,6 +1791,112 @@ __global__ __launch_bounds__(256) void k_perm_rows(const int32_t *__restrict__ p
     else dst[k * nrhs + r] = src[t];             // b[perm[j]] = x[j]
 }
 
+// ---- plan of a forest of EQUAL DENSE BLOCKS, straight from L ------------------------------------------------------
+// What the dense-block kernels read (k_cholsol_dense_exact_dpp, k_cholsol_dense, k_mfma_frags) is a re-arrangement of
+// the block's packed triangle: forward program = rows of the strictly lower triangle, row-major (f_val); backward program
+// = for sweep position sp (row bs - 1 - sp) the column below the diagonal REVERSED (dense_b); the diagonals in both
+// orders.  The general plan gets there through two triangular-solve analyses (a stable transpose of L each), the forest
+// partition on the host and two packing kernels: 61 ms at 5M rows.  Here a workgroup stages its block's triangle in LDS
+// (one coalesced read of L.x) and writes the four arrays (coalesced): L.x read once, 2 x lnz values written.
+template <bool LOCAL>
+__global__ __launch_bounds__(256) void k_clique_plan(int32_t ntrees, int32_t bs, const int32_t *__restrict__ Lp,
+                                                     const double *__restrict__ Lx, Tree *trees, int32_t *tree_nodes,
+                                                     int32_t *f_ptr, int32_t *b_ptr, double *f_val, double *dense_b,
+                                                     double *diagk, double *diagb, int32_t *f_idx, int32_t *b_idx,
+                                                     double *b_val, int *zero) {
+    __shared__ double tri[64 * 65 / 2];
+    const int32_t t = blockIdx.x;
+    const int32_t first = t * bs, NT = bs * (bs - 1) / 2, nent = bs * (bs + 1) / 2;
+    const int64_t base = Lp[first];
+    for (int e = threadIdx.x; e < nent; e += 256) tri[e] = Lx[base + e];
+    __syncthreads();
+    const int64_t po = (int64_t)t * NT;
+    // element (a, c), a >= c, of the block: tri[c bs - c (c - 1) / 2 + a - c]
+    for (int idx = threadIdx.x; idx < bs * bs; idx += 256) {
+        const int a = idx / bs, c = idx % bs;
+        if (c < a) {
+            const int64_t fo = po + a * (a - 1) / 2 + c;
+            const double v = tri[c * bs - c * (c - 1) / 2 + a - c];
+            if (!LOCAL) f_val[fo] = v;
+            else f_idx[fo] = c * 64;
+            // backward: sweep position sp = a, term q = c: L(bs - 1 - q, bs - 1 - sp); the fused kernel's order: L(col + 1 + q, col)
+            const int col = bs - 1 - a;
+            if (!LOCAL) {
+                const int row = bs - 1 - c;
+                dense_b[fo] = tri[col * bs - col * (col - 1) / 2 + row - col];
+            } else {
+                const int row = col + 1 + c;
+                b_idx[fo] = row * 64;
+                b_val[fo] = tri[col * bs - col * (col - 1) / 2 + row - col];
+            }
+        }
+    }
+    if (LOCAL) return;
+    if (threadIdx.x < bs) {
+        const int a = threadIdx.x;
+        const double d = tri[a * bs - a * (a - 1) / 2];
+        if (d == 0.0) *zero = 1;
+        diagk[first + a] = d;
+        diagb[first + bs - 1 - a] = d;
+        f_ptr[first + a] = (int32_t)(po + a * (a - 1) / 2);
+        b_ptr[first + a] = (int32_t)(po + a * (a - 1) / 2);
+        tree_nodes[first + a] = first + a;
+    }
+    if (threadIdx.x == 0) {
+        trees[t] = Tree{first, bs};
+        if (t == ntrees - 1) f_ptr[first + bs] = b_ptr[first + bs] = (int32_t)(po + NT);
+    }
+}
+
+static int cholsol_plan_clique(CholPlan *P, int32_t bs) {
+    hipStream_t s = ctx().stream;
+    const Csc *L = P->L;
+    const int32_t n = P->n, ntrees = n / bs;
+    const int64_t tot = (int64_t)ntrees * (bs * (bs - 1) / 2);
+    DevScope tmp;
+    int *zero = nullptr;
+    CSX_TRY(tmp.alloc(&zero, 1));
+    CSX_HIP(hipMemsetAsync(zero, 0, sizeof(int), s));
+    CSX_TRY(dalloc(&P->trees, (size_t)ntrees));
+    CSX_TRY(dalloc(&P->tree_nodes, (size_t)n));
+    CSX_TRY(dalloc(&P->f_ptr, (size_t)n + 1));
+    CSX_TRY(dalloc(&P->b_ptr, (size_t)n + 1));
+    CSX_TRY(dalloc(&P->diagk, (size_t)n));
+    CSX_TRY(dalloc(&P->diagb, (size_t)n));
+    CSX_TRY(dalloc(&P->f_val, (size_t)tot + 128));
+    CSX_TRY(dalloc(&P->dense_b, (size_t)tot + 128));
+    hipLaunchKernelGGL(k_clique_plan<false>, dim3((unsigned)ntrees), dim3(256), 0, s, ntrees, bs, L->p, L->x, P->trees,
+                       P->tree_nodes, P->f_ptr, P->b_ptr, P->f_val, P->dense_b, P->diagk, P->diagb, nullptr, nullptr, nullptr,
+                       zero);
+    CSX_LAUNCH_CHECK();
+    int hz = 0;
+    CSX_HIP(hipMemcpyAsync(&hz, zero, sizeof hz, hipMemcpyDeviceToHost, s));
+    CSX_HIP(hipStreamSynchronize(s));
+    P->clique = true;
+    P->clique_zero_pivot = hz != 0;
+    P->ntrees = ntrees;
+    P->max_nodes = bs;
+    P->local = true;
+    P->dense_bs = bs;
+    return CSX_OK;
+}
+
+// the fused per-tree kernel's programs for such a plan ("cholsol.dense_blocks" = 0 at solve time)
+static int cholsol_clique_local(CholPlan *P) {
+    if (P->f_idx) return CSX_OK;
+    hipStream_t s = ctx().stream;
+    const int32_t bs = P->dense_bs;
+    const int64_t tot = (int64_t)P->ntrees * (bs * (bs - 1) / 2);
+    CSX_TRY(dalloc(&P->f_idx, (size_t)tot + 8));
+    CSX_TRY(dalloc(&P->b_idx, (size_t)tot + 8));
+    CSX_TRY(dalloc(&P->b_val, (size_t)tot + 128));
+    hipLaunchKernelGGL(k_clique_plan<true>, dim3((unsigned)P->ntrees), dim3(256), 0, s, P->ntrees, bs, P->L->p, P->L->x, P->trees,
+                       P->tree_nodes, P->f_ptr, P->b_ptr, P->f_val, P->dense_b, P->diagk, P->diagb, P->f_idx, P->b_idx, P->b_val,
+                       nullptr);
+    CSX_LAUNCH_CHECK();
+    return CSX_OK;
+}
+
 static int cholsol_plan(const Csc *L, const int32_t *pinv, CholPlan **out) {
     hipStream_t s = ctx().stream;
     CholPlan *P = new CholPlan();
@@ -1764,6 +1911,11 @@ static int cholsol_plan(const Csc *L, const int32_t *pinv, CholPlan **out) {
             perm[(size_t)pinv[k]] = k;
         }
         CSX_TRY(upload(&P->perm, perm));
+    }
+    if (n > 0 && ctx().opt.chol_clique && ctx().opt.cholsol_dense_blocks) {
+        int32_t bs = 0;
+        CSX_TRY(clique_factor_block_size(L, &bs));
+        if (bs == 8 || bs == 16 || bs == 32 || bs == 64) return cholsol_plan_clique(P, bs);
     }
     CSX_TRY(tri_analyse_raw(L, CSX_TRI_L, &P->fwd));
     CSX_TRY(tri_analyse_raw(L, CSX_TRI_LT, &P->bwd));
@@ -1952,15 +2104,18 @@ static int cholsol_solve(CholPlan *P, double *B, int32_t nrhs) {
     hipStream_t s = ctx().stream;
     const int32_t n = P->n;
     if (n == 0 || nrhs == 0) return CSX_OK;
-    const int32_t *Gp, *Gi;
-    const double *Gx, *Gd;
-    tri_gather_arrays(P->fwd, &Gp, &Gi, &Gx, &Gd);
-    if (P->local && Gd != nullptr) {
-        int zero = 0;
-        (void)zero;
+    const int32_t *Gp = nullptr, *Gi = nullptr;
+    const double *Gx = nullptr, *Gd = nullptr;
+    if (!P->clique) tri_gather_arrays(P->fwd, &Gp, &Gi, &Gx, &Gd);
+    if (P->local && (Gd != nullptr || P->clique)) {
         // zero pivots were detected by the analysis; report like the reference (ZeroDivisionError)
-        int st = tri_solve_raw(P->fwd, B, 0, false);
-        if (st != CSX_OK) return st;
+        if (P->clique) {
+            if (P->clique_zero_pivot) return CSX_EZEROPIVOT;
+            if (!ctx().opt.cholsol_dense_blocks) CSX_TRY(cholsol_clique_local(P));
+        } else {
+            int st = tri_solve_raw(P->fwd, B, 0, false);
+            if (st != CSX_OK) return st;
+        }
         // Forests of dense blocks: the default (exact) order runs the substitution kernel that keeps the reference's
         // operations and their order; the rounding-equal order the FMA / matrix-core kernels.
         if (P->dense_bs && !P->relaxed && ctx().opt.cholsol_dense_blocks) {

@@ -1,0 +1,34 @@
+// Forests of cliques on consecutive columns (csx_cholclique.hip): symbolic analysis and numeric factorisation of
+// block-diagonal SPD matrices with dense blocks without the general pattern machine.
+#ifndef CSX_CHOLCLIQUE_H
+#define CSX_CHOLCLIQUE_H
+
+#include <cstring>
+
+#include "csx_internal.h"
+
+namespace csx {
+
+struct CliqueForest {
+    int32_t n = 0;
+    int32_t nblocks = 0, max_bs = 0;
+    int64_t lnz = 0;
+    bool ascending = true;       // the upper part of every column is strictly ascending (what k_chol_clique needs)
+    int32_t *parent = nullptr;   // device [n]: elimination tree (csparse.py:1136-1169)
+    int32_t *cp = nullptr;       // device [n + 1]: column pointers of L (csparse.py:2069-2071)
+    int32_t *start = nullptr;    // device [nblocks + 1]: first column of every block, then n
+};
+
+void free_clique(CliqueForest *F);
+// *ok = A's elimination forest is a set of cliques on consecutive columns (F filled; the caller frees it)
+int clique_forest(const Csc *A, CliqueForest *F, bool *ok);
+// *same = the host arrays parent[n], cp[n + 1] equal F's
+int clique_matches_host(const CliqueForest &F, const int32_t *parent, const int32_t *cp, bool *same);
+// values and row indices of L (L->p = F.cp already in place, L->i / L->x allocated); blocks of at most 64 columns
+int chol_clique_numeric(const Csc *A, const CliqueForest &F, Csc *L, int *d_notspd);
+constexpr int CLIQUE_MAX_BLOCK = 64;
+// *bs = the block size when L is the factor of a forest of equal dense blocks on consecutive columns, else 0
+int clique_factor_block_size(const Csc *L, int32_t *bs);
+
+}  // namespace csx
+#endif

@@ -27,6 +27,7 @@
 
 #include "csx_internal.h"
 #include "csx_sweep.h"
+#include "csx_cholclique.h"
 
 namespace csx {
 
@@ -416,6 +417,21 @@ extern "C" int csx_schol(csx_handle_t hA, int32_t *parent, int32_t *cp) {
         return CSX_OK;
     }
     hipStream_t s = ctx().stream;
+    if (ctx().opt.chol_clique) {
+        // a forest of cliques on consecutive columns (block-diagonal with dense blocks): tree and counts follow from the
+        // smallest upper row of every column, one pass over A's pattern (csx_cholclique.hip)
+        CliqueForest F;
+        bool ok = false;
+        int st = clique_forest(A, &F, &ok);
+        if (st == CSX_OK && ok) {
+            if (hipMemcpyAsync(parent, F.parent, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess ||
+                hipMemcpyAsync(cp, F.cp, ((size_t)n + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess ||
+                hipStreamSynchronize(s) != hipSuccess)
+                st = CSX_ERUNTIME;
+        }
+        free_clique(&F);
+        if (st != CSX_OK || ok) return st;
+    }
     bool on_device = false, bad_index = false;
     CSX_TRY(etree_by_components(A, parent, &on_device, &bad_index));
     if (bad_index) return CSX_EINVAL;

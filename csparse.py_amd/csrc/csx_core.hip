@@ -550,7 +550,7 @@ const OptSlot kOptSlots[] = {
     {"tri.levels_where", &Options::tri_levels_where, 3}, {"tri.supernodes", &Options::tri_supernodes, 5},
     {"spgemm.ordered", &Options::spgemm_ordered, 0},     {"spgemm.chunks", &Options::spgemm_chunks, 4},
     {"lu.etree", &Options::lu_etree, 5},                 {"tri.graph", &Options::tri_graph, 0},
-    {"sort.short_keys", &Options::sort_short_keys, 0},
+    {"sort.short_keys", &Options::sort_short_keys, 0},   {"chol.clique", &Options::chol_clique, 0},
                     {"cholsol.exact_variant", &Options::cholsol_exact_variant, 4},
 };
 int normalise(int kind, int value) {

@@ -125,6 +125,8 @@ struct Options {
     int chol_wband_nb = 16;           // ... columns per step (16 or 32)
     int chol_supernodes = 1;      // cs_chol: fundamental supernodes of >= 8 columns factored as dense trapezoids in place
     int chol_dense_trees = 1;     // cs_chol: LDS dense-block kernel for trees that are dense blocks
+    int chol_clique = 1;          // cs_schol / cs_chol / cholsol plan: forests of cliques on consecutive columns recognised from
+                                  // A (or L) itself and handled without the general pattern machine (csx_cholclique.hip)
     int cholsol_dense_blocks = 1; // cholsol: dense-block kernels (false: the fused per-tree kernel)
     int spgemm_one_pass = 1;      // cs_multiply: one-walk LDS hash kernel (false: the two-pass kernel)
     int tri_chain_walker = 1;     // tri-solve: blocked chain walker for runs of narrow levels

@@ -1,0 +1,219 @@
+"""Forests of cliques on consecutive columns (csx_cholclique.hip): cs_schol / cs_chol / the cholsol plan recognise
+block-diagonal matrices with dense blocks from the matrix itself and skip the general pattern machine.  Everything is
+compared with the plain-C oracle (cs_schol :2051-2072, cs_chol :561-619) and with the general path ("chol.clique" = 0)."""
+import numpy as np
+import pytest
+
+import c_oracle as CO
+import synth
+from test_gpu_parity import _host_cs, cs  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+def _arr(A):
+    nnz = A.p[A.n]
+    return (np.asarray(A.p, np.int32), np.asarray(A.i[:nnz], np.int32), np.asarray(A.x[:nnz], np.float64))
+
+
+def _blocks(sizes, seed, density=1.0, shuffle_lower=False, extra=None):
+    """Block-diagonal SPD matrix, full symmetric storage.  Block b: R R' / bs + bs I with entries dropped to `density`
+    (never from the block's first row / column, so the factor's block stays a clique).  Columns ascending unless
+    shuffle_lower (then the rows BELOW the diagonal come in a random order: cs_chol never reads them)."""
+    rng = np.random.default_rng(seed)
+    n = int(sum(sizes))
+    cols_i, cols_x = [], []
+    a = 0
+    for bs in sizes:
+        R = rng.uniform(-1.0, 1.0, (bs, bs))
+        B = R @ R.T / bs + bs * np.eye(bs)
+        keep = rng.uniform(size=(bs, bs)) < density
+        keep = np.triu(keep) | np.triu(keep).T
+        keep[0, :] = keep[:, 0] = True
+        keep[np.arange(bs), np.arange(bs)] = True
+        B = B * keep
+        for c in range(bs):
+            rows = np.nonzero(keep[:, c])[0]
+            if shuffle_lower:
+                lo = rows[rows > c]
+                rng.shuffle(lo)
+                rows = np.concatenate([rows[rows <= c], lo])
+            cols_i.append(rows + a)
+            cols_x.append(B[rows, c])
+        a += bs
+    if extra:
+        extra(cols_i, cols_x)
+    Ap = np.zeros(n + 1, np.int32)
+    Ap[1:] = np.cumsum([len(r) for r in cols_i])
+    return n, Ap, np.concatenate(cols_i).astype(np.int32), np.concatenate(cols_x)
+
+
+def _factor_both_ways(cs, n, Ap, Ai, Ax):
+    import _csx
+    A = cs.cs_pin(_host_cs(cs, n, n, Ap, Ai, Ax))
+    S = cs.cs_schol(0, A)
+    N = cs.cs_chol(A, S)
+    with _csx.option("chol.clique", 0):
+        S0 = cs.cs_schol(0, A)
+        N0 = cs.cs_chol(A, S0)
+    return A, S, N, S0, N0
+
+
+@pytest.mark.parametrize("case", ["mixed", "sparse_blocks", "ones", "one_block_64", "lower_shuffled"])
+def test_clique_forest_factor_has_the_oracle_bits(cs, case):
+    rng = np.random.default_rng(7)
+    if case == "mixed":
+        sizes, dens, shuf = list(rng.integers(1, 65, 300)) + [64, 63, 1, 2, 17], 1.0, False
+    elif case == "sparse_blocks":
+        sizes, dens, shuf = list(rng.integers(2, 65, 200)), 0.3, False
+    elif case == "ones":
+        sizes, dens, shuf = [1] * 500, 1.0, False
+    elif case == "one_block_64":
+        sizes, dens, shuf = [64], 1.0, False
+    else:
+        sizes, dens, shuf = list(rng.integers(1, 50, 150)), 0.6, True
+    n, Ap, Ai, Ax = _blocks(sizes, 11, dens, shuf)
+    A, S, N, S0, N0 = _factor_both_ways(cs, n, Ap, Ai, Ax)
+    parent, cp = CO.schol(n, Ap, Ai)
+    assert S.parent == parent.tolist() == S0.parent and S.cp == cp.tolist() == S0.cp and S.lnz == int(cp[n])
+    # the forest really is one chain per block with full columns
+    assert int(cp[n]) == sum(b * (b + 1) // 2 for b in sizes)
+    Lp, Li, Lx = CO.chol(n, Ap, Ai, Ax, parent, cp)
+    gp, gi, gx = _arr(N.L)
+    assert gp.tolist() == Lp.tolist() and gi.tolist() == Li.tolist()
+    assert gx.tobytes() == Lx.tobytes()                      # block kernel: the reference's operation order
+    g0p, g0i, g0x = _arr(N0.L)
+    assert g0p.tolist() == Lp.tolist() and g0i.tolist() == Li.tolist()
+    assert np.max(np.abs(g0x - Lx)) <= 1e-13 * np.abs(Lx).max()
+
+
+@pytest.mark.parametrize("case", ["duplicates", "upper_unsorted", "block_of_100", "reaches_back", "not_full"])
+def test_what_is_not_a_clique_forest_takes_the_general_path(cs, case):
+    """Same answers either way: the recognition must refuse (or hand over) and the general machine runs."""
+    rng = np.random.default_rng(3)
+    sizes = list(rng.integers(2, 40, 60))
+
+    def extra(cols_i, cols_x):
+        if case == "duplicates":            # A(0, 5) stored twice in column 5 of the first big block
+            b = int(np.argmax(np.asarray(sizes) >= 8))
+            c = int(sum(sizes[:b])) + 5
+            cols_i[c] = np.concatenate([cols_i[c][:1], cols_i[c][:1], cols_i[c][1:]])
+            cols_x[c] = np.concatenate([cols_x[c][:1] * 0.25, cols_x[c][:1] * 0.75, cols_x[c][1:]])
+        elif case == "upper_unsorted":
+            for c in range(len(cols_i)):
+                order = rng.permutation(len(cols_i[c]))
+                cols_i[c], cols_x[c] = cols_i[c][order], cols_x[c][order]
+        elif case == "reaches_back":        # one entry links the third block to the first: trees merge
+            a2 = sizes[0] + sizes[1]
+            cols_i[a2] = np.concatenate([[0], cols_i[a2]])
+            cols_x[a2] = np.concatenate([[1e-3], cols_x[a2]])
+            cols_i[0] = np.concatenate([cols_i[0], [a2]])
+            cols_x[0] = np.concatenate([cols_x[0], [1e-3]])
+        elif case == "not_full":            # A(first, last) of a block dropped: its first column of L is not full
+            b = int(np.argmax(np.asarray(sizes) >= 4))
+            a, bs = sum(sizes[:b]), sizes[b]
+            last = a + bs - 1
+            keep = cols_i[last] != a
+            cols_i[last], cols_x[last] = cols_i[last][keep], cols_x[last][keep]
+            keep = cols_i[a] != last
+            cols_i[a], cols_x[a] = cols_i[a][keep], cols_x[a][keep]
+
+    if case == "block_of_100":
+        sizes = [100, 3, 70]
+    n, Ap, Ai, Ax = _blocks(sizes, 5, 1.0, False, extra if case != "block_of_100" else None)
+    A, S, N, S0, N0 = _factor_both_ways(cs, n, Ap, Ai, Ax)
+    parent, cp = CO.schol(n, Ap, Ai)
+    assert S.parent == parent.tolist() == S0.parent and S.cp == cp.tolist() == S0.cp
+    Lp, Li, Lx = CO.chol(n, Ap, Ai, Ax, parent, cp)
+    for M in (N, N0):
+        gp, gi, gx = _arr(M.L)
+        assert gp.tolist() == Lp.tolist() and gi.tolist() == Li.tolist()
+        assert np.max(np.abs(gx - Lx)) <= 1e-13 * np.abs(Lx).max()
+    assert _arr(N.L)[2].tobytes() == _arr(N0.L)[2].tobytes()
+
+
+def test_clique_forest_not_positive_definite_and_foreign_symbolic(cs):
+    import _csx
+    sizes = [5, 64, 9, 33]
+    n, Ap, Ai, Ax = _blocks(sizes, 2)
+    A = cs.cs_pin(_host_cs(cs, n, n, Ap, Ai, Ax))
+    S = cs.cs_schol(0, A)
+    assert cs.cs_chol(A, S) is not None
+    # a negative pivot in the third block (csparse.py:612 -> None)
+    c = 5 + 64 + 4
+    Ax2 = Ax.copy()
+    Ax2[Ap[c] + 4] = -1.0
+    A2 = cs.cs_pin(_host_cs(cs, n, n, Ap, Ai, Ax2))
+    assert cs.cs_chol(A2, S) is None
+    with _csx.option("chol.clique", 0):
+        assert cs.cs_chol(A2, S) is None
+    # an S that belongs to another matrix: both paths refuse it the same way
+    n3, Ap3, Ai3, Ax3 = _blocks([5, 64, 10, 32], 2)
+    assert n3 == n
+    S3 = cs.cs_schol(0, cs.cs_pin(_host_cs(cs, n, n, Ap3, Ai3, Ax3)))
+    outcomes = []
+    for clique in (1, 0):
+        with _csx.option("chol.clique", clique):
+            try:
+                outcomes.append(cs.cs_chol(A, S3) is None)
+            except Exception as e:           # noqa: BLE001
+                outcomes.append(type(e).__name__)
+    assert outcomes[0] == outcomes[1]
+
+
+@pytest.mark.parametrize("bs", [8, 16, 32, 64])
+def test_plan_cut_straight_out_of_the_factor(cs, bs):
+    """The plan of a forest of equal dense blocks is made from L alone -- also from an L that went through the host (a
+    received or re-uploaded factor) -- and solves with the bits of the general plan and of cs_lsolve + cs_ltsolve."""
+    import _csx
+    nblocks, k = 37, 70
+    Ap, Ai, Ax = synth.gspd(nblocks, bs, 99)
+    n = nblocks * bs
+    A = cs.cs_pin(_host_cs(cs, n, n, Ap, Ai, Ax))
+    F = cs.cholsol_factor(A)
+    assert F.info() == {"fused_local": True, "dense_block": bs, "matrix_cores": False, "trees": nblocks, "max_nodes": bs}
+    gLp, gLi, gLx = _arr(F.L)
+    B = synth.rhs(n, k, 0)
+    dB = cs.dvec(B)
+    assert F.solve(dB) is True
+    X = dB.numpy()
+    for r in (0, 31, k - 1):
+        ref = CO.ltsolve(n, gLp, gLi, gLx, CO.lsolve(n, gLp, gLi, gLx, B[:, r]))
+        assert X[:, r].tobytes() == ref.tobytes()
+    with _csx.option("cholsol.dense_blocks", 0):     # the fused per-tree kernel on the same plan: programs made on demand
+        dB1 = cs.dvec(B)
+        assert F.solve(dB1) is True
+        assert dB1.numpy().tobytes() == X.tobytes()
+    with _csx.option("chol.clique", 0):              # the general plan (two triangular analyses, host partition)
+        F0 = cs.cholsol_factor(A)
+        assert F0.info() == F.info()
+        dB0 = cs.dvec(B)
+        assert F0.solve(dB0) is True
+        assert dB0.numpy().tobytes() == X.tobytes()
+        F0r = cs.cholsol_factor(A, exact=False)
+        dB0r = cs.dvec(B)
+        assert F0r.solve(dB0r) is True
+    Fr = cs.cholsol_factor(A, exact=False)            # matrix cores / FMA substitution from the clique plan's arrays
+    dBr = cs.dvec(B)
+    assert Fr.solve(dBr) is True
+    assert dBr.numpy().tobytes() == dB0r.numpy().tobytes()
+    assert np.max(np.abs(dBr.numpy() - X) / np.abs(X)) < 1e-13
+    # a factor uploaded from host arrays
+    L2 = cs.cs_pin(_host_cs(cs, n, n, gLp, gLi, gLx))
+    plan = _csx.new_handle()
+    _csx.check(_csx.lib().csx_cholsol_plan(L2._dev.handle, None, plan))
+    a, b, c = _csx.C.c_int32(), _csx.C.c_int32(), _csx.C.c_int32()
+    _csx.check(_csx.lib().csx_cholsol_info(plan, a, b, c))
+    assert (a.value, b.value, c.value) == (2, nblocks, bs)
+    dB2 = cs.dvec(B)
+    _csx.check(_csx.lib().csx_cholsol_solve(plan, dB2.handle, k))
+    assert dB2.numpy().tobytes() == X.tobytes()
+    _csx.free(plan)
+    # a zero on the diagonal: ZeroDivisionError, as cs_lsolve raises
+    gLx0 = gLx.copy()
+    gLx0[gLp[n // 2]] = 0.0
+    L3 = cs.cs_pin(_host_cs(cs, n, n, gLp, gLi, gLx0))
+    plan = _csx.new_handle()
+    _csx.check(_csx.lib().csx_cholsol_plan(L3._dev.handle, None, plan))
+    assert _csx.lib().csx_cholsol_solve(plan, cs.dvec(B).handle, k) == _csx.EZEROPIVOT
+    _csx.free(plan)
