@@ -657,7 +657,7 @@ static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, c
         fprintf(stderr, "[cs_chol] %-18s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
         t0 = t1;
     };
-    if (ctx().opt.chol_clique && ctx().opt.chol_dense_trees && !pinv) {
+    if (ctx().opt.chol_clique && ctx().opt.chol_dense_trees && !pinv && A->nnz > 0) {
         // A forest of cliques on consecutive columns (csx_cholclique.hip): L.p / L.i follow from the counts, the values are
         // one read of A's upper part and one write of L, a block to a wave.  The caller's S must be that forest's.
         CliqueForest F;

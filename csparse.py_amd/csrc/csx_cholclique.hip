@@ -13,7 +13,7 @@
 // Then parent[k] = k + 1 inside a block, -1 at its end; column k of L holds rows k .. end of the block (cs_chol appends
 // rows in ascending order, the diagonal first: L.i follows from cp alone); and the values are one read of A's upper part
 // and one write of L: k_chol_clique keeps a whole block (<= 64 columns) in the registers of one wave.
-#include <chrono>
+#include <algorithm>
 #include <cstdio>
 
 #include "csx_internal.h"
@@ -26,32 +26,59 @@ static inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256
 // ---- recognition ---------------------------------------------------------------------------------------------------
 // one wave per column: u[k]; flags[0] |= the upper part of some column is not strictly ascending (duplicates, unsorted,
 // a negative row) -- the block kernel scatters a column's entries in parallel and needs them distinct
-__global__ __launch_bounds__(256) void k_clique_min(int32_t n, const int32_t *__restrict__ Ap, const int32_t *__restrict__ Ai,
-                                                    int32_t *__restrict__ u, int *flags) {
-    const int lane = threadIdx.x & 63;
-    const int64_t k = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (k >= n) return;
+// 16 lanes per column, four entries per lane and step through one aligned 16-byte load (a wave instruction moves 1 KB:
+// the load pipeline tracks instructions, not bytes -- with a wave per column and 4 bytes per lane this pass ran at 1.1 TB/s).
+// (Arrays of a wrapped matrix end where they end: the last quad of the array is read element by element.)
+__device__ __forceinline__ int4 cq_load4(const int32_t *__restrict__ idx, int32_t p, int32_t nnz) {
+    if (p + 4 <= nnz) return *(const int4 *)(idx + p);
+    int4 v = make_int4(0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff);   // the array's last, partial quad: element by element
+    if (p < nnz) v.x = idx[p];
+    if (p + 1 < nnz) v.y = idx[p + 1];
+    if (p + 2 < nnz) v.z = idx[p + 2];
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_clique_min(int32_t n, int32_t nnz, const int32_t *__restrict__ Ap,
+                                                    const int32_t *__restrict__ Ai, int32_t *__restrict__ u, int *flags) {
+    const int t = threadIdx.x & 15;
+    const int64_t k64 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int32_t k = (int32_t)(k64 < n ? k64 : n - 1);          // the spare groups of the last wave repeat column n - 1
     const int32_t b = Ap[k], e = Ap[k + 1];
-    int32_t mn = (int32_t)k, last = -1;
+    int32_t mn = k, run = -1;          // smallest upper row; largest upper row of the steps before
     bool bad = false;
-    for (int32_t p0 = b; p0 < e; p0 += 64) {
-        const int32_t p = p0 + lane;
-        int32_t i = 0x7fffffff;
-        if (p < e) i = Ai[p];
-        const bool up = i <= (int32_t)k;
-        const unsigned long long bal = __ballot(up);
-        if (bal == 0ull) continue;
-        const unsigned long long below = bal & ((1ull << lane) - 1ull);
-        const int prevlane = below ? 63 - __clzll((long long)below) : 0;
-        int32_t prev = __shfl(i, prevlane);
-        if (!below) prev = last;
-        if (up && i <= prev) bad = true;
-        last = __shfl(i, 63 - __clzll((long long)bal));
-        if (up) mn = min(mn, i);
+    for (int32_t p0 = b & ~3; p0 < e; p0 += 64) {
+        const int32_t p = p0 + 4 * t;
+        int4 v = make_int4(0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff);
+        if (p < e) v = cq_load4(Ai, p, nnz);
+        const int32_t r[4] = {v.x, v.y, v.z, v.w};
+        int32_t lmax = -1, first = 0x7fffffff;   // of this lane's upper entries
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const bool up = p + c >= b && p + c < e && r[c] <= k;
+            if (up) {
+                if (r[c] <= lmax) bad = true;
+                if (first == 0x7fffffff) first = r[c];
+                lmax = max(lmax, r[c]);
+                mn = min(mn, r[c]);
+            }
+        }
+        // largest upper row of the lanes before this one (exclusive prefix maximum over the 16 lanes), and of earlier steps
+        int32_t pre = lmax;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            const int32_t other = __shfl_up(pre, o, 16);
+            if (t >= o) pre = max(pre, other);
+        }
+        int32_t excl = __shfl_up(pre, 1, 16);
+        if (t == 0) excl = -1;
+        excl = max(excl, run);
+        if (first != 0x7fffffff && first <= excl) bad = true;
+        run = max(run, __shfl(pre, 15, 16));
     }
-    for (int o = 32; o > 0; o >>= 1) mn = min(mn, __shfl_xor(mn, o));
-    if (__ballot(bad) != 0ull && lane == 0) flags[0] = 1;
-    if (lane == 0) u[k] = mn;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) mn = min(mn, __shfl_xor(mn, o, 16));
+    if (bad) flags[0] = 1;
+    if (t == 0 && k64 < n) u[k] = mn;
 }
 
 // thread per column: the rule above (flags[1] |= broken), block starts, parent, the last column of every block
@@ -73,22 +100,40 @@ __global__ __launch_bounds__(256) void k_clique_mark(int32_t n, const int32_t *_
     if (last) end_of[uk] = (int32_t)k;
 }
 
-// thread per column: column counts of L; block list; size statistics (stats[0] = widest block, lnz in *lnz)
+// thread per column: column counts of L; block list; size statistics (stats[0] = widest block, lnz in *lnz) reduced per
+// workgroup first (an atomic per block of the matrix on ONE address took 1.8 ms at 78 125 blocks)
 __global__ __launch_bounds__(256) void k_clique_counts(int32_t n, const int32_t *__restrict__ u, const int32_t *__restrict__ is_start,
                                                        const int32_t *__restrict__ block_id, const int32_t *__restrict__ end_of,
                                                        int32_t *__restrict__ count, int32_t *__restrict__ start, int *stats,
                                                        unsigned long long *lnz) {
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    const int32_t a = u[k], e = end_of[a];
-    count[k] = e - (int32_t)k + 1;
-    if (is_start[k]) {
-        const int32_t bs = e - a + 1;
-        start[block_id[k]] = (int32_t)k;
-        atomicMax(&stats[0], bs);
-        atomicAdd(lnz, (unsigned long long)bs * (unsigned long long)(bs + 1) / 2ull);
+    __shared__ int s_max[4];
+    __shared__ unsigned long long s_sum[4];
+    int mx = 0;
+    unsigned long long sum = 0ull;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t a = u[k], e = end_of[a];
+        count[k] = e - (int32_t)k + 1;
+        if (is_start[k]) {
+            const int32_t bs = e - a + 1;
+            start[block_id[k]] = (int32_t)k;
+            mx = max(mx, bs);
+            sum += (unsigned long long)bs * (unsigned long long)(bs + 1) / 2ull;
+        }
+        if (k == n - 1) start[block_id[k] + is_start[k]] = n;
     }
-    if (k == n - 1) start[block_id[k] + is_start[k]] = n;
+    for (int o = 32; o > 0; o >>= 1) {
+        mx = max(mx, __shfl_xor(mx, o));
+        sum += __shfl_xor(sum, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_max[threadIdx.x >> 6] = mx;
+        s_sum[threadIdx.x >> 6] = sum;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicMax(&stats[0], max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3])));
+        atomicAdd(lnz, s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]);
+    }
 }
 
 void free_clique(CliqueForest *F) {
@@ -114,7 +159,7 @@ int clique_forest(const Csc *A, CliqueForest *F, bool *ok) {
     CSX_TRY(tmp.alloc(&flags, 8));
     CSX_TRY(dalloc(&F->parent, (size_t)n));
     CSX_HIP(hipMemsetAsync(flags, 0, 8 * sizeof(int), s));
-    hipLaunchKernelGGL(k_clique_min, dim3(blocks_for((int64_t)n * 64)), dim3(256), 0, s, n, A->p, A->i, u, flags);
+    hipLaunchKernelGGL(k_clique_min, dim3(blocks_for((int64_t)n * 16)), dim3(256), 0, s, n, A->nnz, A->p, A->i, u, flags);
     hipLaunchKernelGGL(k_clique_mark, dim3(blocks_for(n)), dim3(256), 0, s, n, u, is_start, F->parent, end_of, flags);
     int h[8] = {0};
     CSX_HIP(hipMemcpyAsync(h, flags, sizeof h, hipMemcpyDeviceToHost, s));
@@ -127,7 +172,7 @@ int clique_forest(const Csc *A, CliqueForest *F, bool *ok) {
     CSX_TRY(scan_exclusive_i32(is_start, block_id, n, &nblocks));
     CSX_TRY(dalloc(&F->start, (size_t)nblocks + 1));
     CSX_TRY(dalloc(&F->cp, (size_t)n + 1));
-    hipLaunchKernelGGL(k_clique_counts, dim3(blocks_for(n)), dim3(256), 0, s, n, u, is_start, block_id, end_of, count,
+    hipLaunchKernelGGL(k_clique_counts, dim3(std::min(blocks_for(n), 1024u)), dim3(256), 0, s, n, u, is_start, block_id, end_of, count,
                        F->start, flags + 2, (unsigned long long *)(flags + 4));
     CSX_TRY(scan_exclusive_i32(count, F->cp, n, nullptr));
     CSX_HIP(hipMemcpyAsync(h, flags, sizeof h, hipMemcpyDeviceToHost, s));
@@ -197,6 +242,7 @@ int clique_matches_host(const CliqueForest &F, const int32_t *parent, const int3
 constexpr int CQ_WAVES = 4;
 constexpr int CQ_CH = 16;     // columns staged at a time
 constexpr int CQ_LD = 65;     // doubles per staged column
+constexpr int CQ_G = 8;       // columns whose loads are in flight together
 
 __device__ __forceinline__ double cq_bcast(double v, int src) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
@@ -204,12 +250,14 @@ __device__ __forceinline__ double cq_bcast(double v, int src) {
     return __hiloint2double(hi, lo);
 }
 
-__global__ __launch_bounds__(64 * CQ_WAVES, 3) void k_chol_clique(const int32_t *__restrict__ start, int32_t nblocks, int32_t n,
+// PARTS: 1 load, 2 factor, 4 store -- 7 is the kernel; the others exist in the ablation build only (what each phase costs)
+template <int PARTS>
+__global__ __launch_bounds__(64 * CQ_WAVES, 3) void k_chol_clique(const int32_t *__restrict__ start, int32_t nblocks, int32_t n, int32_t nnz,
                                                                  const int32_t *__restrict__ Ap, const int32_t *__restrict__ Ai,
                                                                  const double *__restrict__ Ax, const int32_t *__restrict__ Lp,
                                                                  int32_t *__restrict__ Li, double *__restrict__ Lx, int *notspd) {
 #pragma clang fp contract(off)
-    __shared__ double s_tile[CQ_WAVES][CQ_CH * CQ_LD];
+    __shared__ __attribute__((aligned(16))) double s_tile[CQ_WAVES][CQ_CH * CQ_LD + 2];   // + the spare slot rejected entries go to
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t t = (int64_t)blockIdx.x * CQ_WAVES + w;
@@ -220,62 +268,89 @@ __global__ __launch_bounds__(64 * CQ_WAVES, 3) void k_chol_clique(const int32_t 
     double a[64];
 #pragma unroll
     for (int c = 0; c < 64; c++) a[c] = 0.0;
+    if (!(PARTS & 1)) {
+#pragma unroll
+        for (int c = 0; c < 64; c++) a[c] = c == lane ? 64.0 : 0.0078125;
+    }
     // ---- load ----
-#pragma unroll 1
-    for (int q0 = 0; q0 < bs; q0 += CQ_CH) {
-        for (int e = lane; e < CQ_CH * CQ_LD; e += 64) tile[e] = 0.0;
-        const int32_t colp = Ap[min(c0 + q0 + lane, n)];   // lanes 0 .. 16 matter
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll 1
-        for (int kk0 = 0; kk0 < CQ_CH; kk0 += 4) {
-            int32_t ii[4], pb[4], pe[4];
-            double vv[4];
+    // (what is NOT done here matters as much as what is: the kernel is bound by instruction issue -- 7 000 vector
+    // instructions per block at 2.2 ns each -- so the loads are unconditional (clamped addresses, no exec juggling), the
+    // scatter writes rejected entries to a spare slot instead of branching, and the read-back runs under one exec mask)
+    if (PARTS & 1) {
+        const int32_t apb = Ap[min(c0 + lane, n)], ape = Ap[min(c0 + lane + 1, n)];      // lane l: column c0 + l
+        const bool lng = lane < bs && ape - apb > 64;
+        const bool any_long = __ballot(lng) != 0ull;
 #pragma unroll
-            for (int uu = 0; uu < 4; uu++) {
-                pb[uu] = __builtin_amdgcn_readlane(colp, kk0 + uu);
-                pe[uu] = __builtin_amdgcn_readlane(colp, kk0 + uu + 1);
-                if (q0 + kk0 + uu >= bs) pe[uu] = pb[uu];
-                const int32_t p = pb[uu] + lane;
-                ii[uu] = p < pe[uu] ? Ai[p] : 0x7fffffff;
-            }
+        for (int q = 0; q < 64 / CQ_CH; q++) {
+            if (CQ_CH * q < bs) {
+                {
+                    typedef double d2 __attribute__((ext_vector_type(2)));
+                    d2 *t2 = (d2 *)tile;
 #pragma unroll
-            for (int uu = 0; uu < 4; uu++) {
-                const int32_t col = c0 + q0 + kk0 + uu;
-                const bool up = ii[uu] <= col && ii[uu] >= c0;
-                vv[uu] = up ? Ax[pb[uu] + lane] : 0.0;
-                ii[uu] = up ? ii[uu] - c0 : -1;
-            }
-#pragma unroll
-            for (int uu = 0; uu < 4; uu++)
-                if (ii[uu] >= 0) tile[(kk0 + uu) * CQ_LD + ii[uu]] = vv[uu];
-#pragma unroll
-            for (int uu = 0; uu < 4; uu++) {   // columns of more than 64 entries (a lower part with duplicates, say)
-                const int32_t col = c0 + q0 + kk0 + uu;
-                for (int32_t p0 = pb[uu] + 64; p0 < pe[uu]; p0 += 64) {
-                    const int32_t p = p0 + lane;
-                    const int32_t i = p < pe[uu] ? Ai[p] : 0x7fffffff;
-                    if (i <= col && i >= c0) tile[(kk0 + uu) * CQ_LD + i - c0] = Ax[p];
+                    for (int e = 0; e < (CQ_CH * CQ_LD / 2 + 63) / 64; e++)
+                        if (e * 64 + lane < CQ_CH * CQ_LD / 2) t2[e * 64 + lane] = d2{0.0, 0.0};
                 }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int kk0 = 0; kk0 < CQ_CH; kk0 += CQ_G) {
+                    // CQ_G columns at a time, index and value of every column requested before anything is used
+                    int32_t ii[CQ_G];
+                    double vv[CQ_G];
+                    bool in[CQ_G];
+#pragma unroll
+                    for (int uu = 0; uu < CQ_G; uu++) {
+                        const int k = CQ_CH * q + kk0 + uu;
+                        const int32_t pb = __builtin_amdgcn_readlane(apb, k);
+                        const int32_t pe = k < bs ? __builtin_amdgcn_readlane(ape, k) : pb;
+                        const int32_t p = pb + lane;
+                        in[uu] = p < pe;
+                        const int32_t pc = min(p, nnz - 1);
+                        ii[uu] = Ai[pc];
+                        vv[uu] = Ax[pc];
+                    }
+#pragma unroll
+                    for (int uu = 0; uu < CQ_G; uu++) {
+                        const int k = CQ_CH * q + kk0 + uu;
+                        const uint32_t rel = (uint32_t)(ii[uu] - c0);          // rows c0 .. c0 + k are the upper part
+                        const bool okk = in[uu] && rel <= (uint32_t)k;
+                        tile[okk ? (kk0 + uu) * CQ_LD + (int)rel : CQ_CH * CQ_LD] = vv[uu];
+                    }
+                }
+                if (any_long) {   // columns of more than 64 entries (a lower part with duplicates, say)
+                    for (int kk = 0; kk < CQ_CH && CQ_CH * q + kk < bs; kk++) {
+                        const int k = CQ_CH * q + kk;
+                        const int32_t pb = __builtin_amdgcn_readlane(apb, k), pe = __builtin_amdgcn_readlane(ape, k);
+                        for (int32_t p0 = pb + 64; p0 < pe; p0 += 64) {
+                            const int32_t p = p0 + lane;
+                            const int32_t i = p < pe ? Ai[p] : 0x7fffffff;
+                            if (i <= c0 + k && i >= c0) tile[kk * CQ_LD + i - c0] = Ax[p];
+                        }
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                if ((lane >> 4) == q) {   // the 16 lanes whose rows these columns are; what lies right of the diagonal stays 0
+                    const double *row = tile + (lane & 15) * CQ_LD;
+#pragma unroll
+                    for (int c = 0; c < CQ_CH * (q + 1); c++) a[c] = row[c];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        const bool mine = (lane >> 4) == (q0 >> 4);
-        const double *row = tile + (lane & 15) * CQ_LD;
-#pragma unroll
-        for (int c = 0; c < 64; c++) {
-            const double v = row[c];
-            if (mine) a[c] = v;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
     }
     // ---- factor ----
+    // L(c, j) reaches the lanes through LDS: the panel's finished columns are written there (one ds_write per lane and
+    // column) and an update reads its factor with a BROADCAST read -- measured on this chip (tools/ubench/valu_rate.hip, every
+    // SIMD busy): v_readlane_b32 3.6 ns per wave instruction and SIMD, two of them per fp64 value; a broadcast ds_read_b64
+    // 4.0 ns, in the LDS pipe beside the vector ALU; v_mul_f64 / v_add_f64 2.2 ns each.  With v_readlane the factor phase
+    // took 2.2 ms at 5M rows, 62 % of it the readlanes.
     const int64_t base = Lp[c0];
+    double *colbuf = tile;   // [8][64]
 #pragma unroll 1
     for (int J = 0; J < bs; J += 8) {
 #pragma unroll
-        for (int jw = 0; jw < 8; jw++) {
+        for (int jw = 0; (PARTS & 2) && jw < 8; jw++) {
             const int g = J + jw;
             if (g < bs) {
                 const double d = cq_bcast(a[jw], g);
@@ -283,31 +358,41 @@ __global__ __launch_bounds__(64 * CQ_WAVES, 3) void k_chol_clique(const int32_t 
                 const double ljj = sqrt(d);
                 const double l = a[jw] / ljj;
                 a[jw] = lane == g ? ljj : l;
+                colbuf[jw * 64 + lane] = a[jw];
+                if (jw < 7) {
+                    double sc[8];
 #pragma unroll
-                for (int cw = jw + 1; cw < 8; cw++) {
-                    const double pr = a[jw] * cq_bcast(a[jw], J + cw);
-                    a[cw] = a[cw] - pr;
-                }
-            }
-        }
+                    for (int cw = jw + 1; cw < 8; cw++) sc[cw] = colbuf[jw * 64 + J + cw];
 #pragma unroll
-        for (int gq = 1; gq < 8; gq++) {
-            if (J + 8 * gq < bs) {
-#pragma unroll
-                for (int cc = 0; cc < 8; cc++) {
-                    const int cw = 8 * gq + cc;
-#pragma unroll
-                    for (int jw = 0; jw < 8; jw++) {
-                        const double pr = a[jw] * cq_bcast(a[jw], J + cw);
+                    for (int cw = jw + 1; cw < 8; cw++) {
+                        const double pr = a[jw] * sc[cw];
                         a[cw] = a[cw] - pr;
                     }
                 }
             }
         }
 #pragma unroll
+        for (int gq = 1; (PARTS & 2) && gq < 8; gq++) {
+            if (J + 8 * gq < bs) {
+                // a group of eight columns takes the panel's columns one after the other; the eight updates by one panel
+                // column are independent of each other
+#pragma unroll
+                for (int jw = 0; jw < 8; jw++) {
+                    double sc[8], pr[8];
+                    const double *src = colbuf + jw * 64 + J + 8 * gq;
+#pragma unroll
+                    for (int cc = 0; cc < 8; cc++) sc[cc] = (PARTS & 8) ? a[(jw + cc) & 63] : src[cc];
+#pragma unroll
+                    for (int cc = 0; cc < 8; cc++) pr[cc] = a[jw] * sc[cc];
+#pragma unroll
+                    for (int cc = 0; cc < 8; cc++) a[8 * gq + cc] = a[8 * gq + cc] - pr[cc];
+                }
+            }
+        }
+#pragma unroll
         for (int jw = 0; jw < 8; jw++) {
             const int g = J + jw;
-            if (g < bs && lane >= g && lane < bs) {
+            if (g < bs && lane >= g && lane < bs && ((PARTS & 4) || a[jw] == 12345.678)) {
                 const int64_t q = base + (int64_t)g * bs - (int64_t)g * (g - 1) / 2 + (lane - g);
                 Lx[q] = a[jw];
                 Li[q] = c0 + lane;
@@ -320,33 +405,59 @@ __global__ __launch_bounds__(64 * CQ_WAVES, 3) void k_chol_clique(const int32_t 
 
 int chol_clique_numeric(const Csc *A, const CliqueForest &F, Csc *L, int *d_notspd) {
     hipStream_t s = ctx().stream;
-    if (F.nblocks == 0) return CSX_OK;
-    hipLaunchKernelGGL(k_chol_clique, dim3((unsigned)((F.nblocks + CQ_WAVES - 1) / CQ_WAVES)), dim3(64 * CQ_WAVES), 0, s, F.start,
-                       F.nblocks, A->n, A->p, A->i, A->x, L->p, L->i, L->x, d_notspd);
+    if (F.nblocks == 0 || A->nnz == 0) return CSX_OK;
+    const dim3 grid((unsigned)((F.nblocks + CQ_WAVES - 1) / CQ_WAVES));
+#define CSX_CQ(PARTS)                                                                                                       \
+    hipLaunchKernelGGL(k_chol_clique<PARTS>, grid, dim3(64 * CQ_WAVES), 0, s, F.start, F.nblocks, A->n, A->nnz, A->p, A->i, A->x, L->p, \
+                       L->i, L->x, d_notspd)
+    int parts = 7;
+#ifdef CSX_ABLATION
+    if (const char *e = ablation_env("CSX_CQ_PARTS")) parts = atoi(e);
+    switch (parts) {
+        case 1: CSX_CQ(1); break;
+        case 2: CSX_CQ(2); break;
+        case 3: CSX_CQ(3); break;
+        case 5: CSX_CQ(5); break;
+        case 6: CSX_CQ(6); break;
+        case 10: CSX_CQ(10); break;
+        default: CSX_CQ(7); break;
+    }
+#else
+    (void)parts;
+    CSX_CQ(7);
+#endif
+#undef CSX_CQ
     CSX_LAUNCH_CHECK();
     return CSX_OK;
 }
 
 // ---- is this L the factor of a forest of equal dense blocks?  (cholsol plan) ------------------------------------------
-// one wave per column: rows j, j + 1, ... contiguous; the count falls by one from column to column inside a block;
-// stats[0] |= no, stats[1] = max over block starts of the count, stats[2] = min
-__global__ __launch_bounds__(256) void k_clique_factor_shape(int32_t n, const int32_t *__restrict__ Lp,
+// 16 lanes per column (aligned 16-byte loads, as k_clique_min): rows j, j + 1, ... contiguous; the count falls by one from
+// column to column inside a block and every block starts with the count of column 0;  stats[0] |= no, stats[1] = that count
+__global__ __launch_bounds__(256) void k_clique_factor_shape(int32_t n, int32_t nnz, const int32_t *__restrict__ Lp,
                                                              const int32_t *__restrict__ Li, int *stats) {
-    const int lane = threadIdx.x & 63;
-    const int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (j >= n) return;
+    const int t = threadIdx.x & 15;
+    const int64_t j64 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    if (j64 >= n) return;
+    const int32_t j = (int32_t)j64;
     const int32_t b = Lp[j], cnt = Lp[j + 1] - b;
-    bool bad = cnt < 1 || cnt > n - (int32_t)j;
+    bool bad = cnt < 1 || cnt > n - j;
     if (!bad) {
-        for (int32_t q = lane; q < cnt; q += 64)
-            if (Li[b + q] != (int32_t)j + q) bad = true;
-        if (lane == 0) {
+        const int32_t e = b + cnt;
+        for (int32_t p0 = b & ~3; p0 < e; p0 += 64) {
+            const int32_t p = p0 + 4 * t;
+            if (p >= e) continue;
+            const int4 v = cq_load4(Li, p, nnz);
+            const int32_t r[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                if (p + c >= b && p + c < e && r[c] != j + (p + c - b)) bad = true;
+        }
+        if (t == 0) {
             const bool first = j == 0 || Lp[j] - Lp[j - 1] == 1;     // the column before ended its block
             if (!first && Lp[j] - Lp[j - 1] != cnt + 1) bad = true;
-            if (first) {
-                atomicMax(&stats[1], cnt);
-                atomicMin(&stats[2], cnt);
-            }
+            if (first && cnt != Lp[1] - Lp[0]) bad = true;
+            if (j == 0) stats[1] = cnt;
         }
     }
     if (bad) stats[0] = 1;
@@ -360,12 +471,12 @@ int clique_factor_block_size(const Csc *L, int32_t *bs) {
     DevScope tmp;
     int *stats = nullptr;
     CSX_TRY(tmp.alloc(&stats, 4));
-    int h[4] = {0, 0, 0x7fffffff, 0};
-    CSX_HIP(hipMemcpyAsync(stats, h, sizeof h, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_clique_factor_shape, dim3(blocks_for((int64_t)n * 64)), dim3(256), 0, s, n, L->p, L->i, stats);
+    int h[4] = {0, 0, 0, 0};
+    CSX_HIP(hipMemsetAsync(stats, 0, sizeof h, s));
+    hipLaunchKernelGGL(k_clique_factor_shape, dim3(blocks_for((int64_t)n * 16)), dim3(256), 0, s, n, L->nnz, L->p, L->i, stats);
     CSX_HIP(hipMemcpyAsync(h, stats, sizeof h, hipMemcpyDeviceToHost, s));
     CSX_HIP(hipStreamSynchronize(s));
-    if (h[0] == 0 && h[1] == h[2] && h[1] >= 1 && n % h[1] == 0) *bs = h[1];
+    if (h[0] == 0 && h[1] >= 1 && n % h[1] == 0) *bs = h[1];
     return CSX_OK;
 }
 
