@@ -610,6 +610,8 @@ def cholsol_section(args, lib, cs, comm, hB, nb, bs, barrier, max_over_ranks):
     _csx.check(lib.csx_chol(hB, _csx.pi(parent), _csx.pi(cp), None, hL), "chol")
     _csx.sync()
     t_numeric = time.perf_counter() - t0
+    chol_path, chol_kernel_ms = C.c_int32(-1), C.c_double(0.0)
+    _csx.check(lib.csx_chol_info(chol_path, chol_kernel_ms), "chol_info")
     t0 = time.perf_counter()
     plan = _csx.new_handle()
     _csx.check(lib.csx_cholsol_plan(hL, None, plan), "cholsol_plan")
@@ -648,6 +650,10 @@ def cholsol_section(args, lib, cs, comm, hB, nb, bs, barrier, max_over_ranks):
     wall = max_over_ranks(time.perf_counter() - t0)
     ms = max_over_ranks(ev.value / steps)
     fused_bytes = 12 * lnz + 4 * (n + 1) + 16 * n * k  # L read once, B read once, X written once
+    # cs_chol: read the upper triangle of A (index + value), write L (index + value)
+    nnz_triu = n * (bs + 1) // 2
+    chol_bytes = 12 * nnz_triu + 12 * lnz
+    t_factor = t_symbolic + t_numeric + t_plan
     out = {"workload": "batched cs_cholsol solve phase on G-spd (n=%d, lnz=%d): %d right-hand sides per GPU, "
                        "factor once per GPU, row-major n x k block" % (n, lnz, k),
            "solves_per_s": round(k * world * steps / wall, 1), "nrhs_per_gpu": k, "ms_per_batch": round(ms, 4),
@@ -661,8 +667,20 @@ def cholsol_section(args, lib, cs, comm, hB, nb, bs, barrier, max_over_ranks):
                         "unit": "GB/s", "frac": round(fused_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                         "traffic": (measured_traffic("k_cholsol_", n=n, nrhs_per_gpu=k) or {}).get("bytes")},
            "survey_bytes_unfused": cholsol_bytes(lnz, n, k),
-           "factor_s": {"symbolic_cs_schol": round(t_symbolic, 3), "numeric_device_incl_pattern_of_L": round(t_numeric, 3),
-                        "solve_plan": round(t_plan, 3), "matrix_core_fragments": round(t_plan_mfma, 3)},
+           "factor_s": {"symbolic_cs_schol": round(t_symbolic, 4), "numeric_device_incl_pattern_of_L": round(t_numeric, 4),
+                        "solve_plan": round(t_plan, 4), "matrix_core_fragments": round(t_plan_mfma, 4),
+                        "schol_chol_plan_total": round(t_factor, 4)},
+           "chol_roofline": {"bound": "hbm", "kernel": {1: "k_chol_clique (forest of cliques: a block in the registers of a wave)",
+                                                        0: "general path (pattern of L + column kernels)"}.get(chol_path.value),
+                             "algorithmic_bytes": chol_bytes, "numeric_kernel_ms": round(chol_kernel_ms.value, 4),
+                             "achieved": round(chol_bytes / (chol_kernel_ms.value * 1e-3) / 1e9, 2) if chol_kernel_ms.value > 0 else None,
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(chol_bytes / (chol_kernel_ms.value * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if chol_kernel_ms.value > 0 else None,
+                             "csx_chol_call_ms": round(t_numeric * 1e3, 3),
+                             "frac_whole_call": round(chol_bytes / t_numeric / 1e9 / HBM_PEAK_GBS, 4),
+                             "traffic": (measured_traffic("k_chol_clique", n=n) or {}).get("bytes")},
+           "end_to_end_solves_per_s_per_gpu": round(k / (t_factor + ms * 1e-3), 1),
+           "end_to_end_note": "cs_schol + cs_chol + plan + ONE batch of %d right-hand sides (the solve phase alone: solves_per_s)" % k,
            "exact_order": {"ms_per_batch": round(ms_exact, 4), "solves_per_s_per_gpu": round(k / (ms_exact * 1e-3), 1),
                            "note": "default order of every plan: bit-identical to cs_lsolve + cs_ltsolve"}}
     if rank == 0 and world == 1 and not args.skip_cpu:

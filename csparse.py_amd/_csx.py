@@ -75,6 +75,7 @@ _PROTOS = {
     "csx_permute_vec": [H, H, H, C.c_int32, C.c_int32, C.c_int],
     "csx_schol_host": [C.c_int32, _i32p, _i32p, _i32p, _i32p],
     "csx_chol": [H, _i32p, _i32p, _i32p, C.POINTER(H)],
+    "csx_chol_info": [_i32p, _f64p],
     "csx_cholsol_plan": [H, _i32p, C.POINTER(H)],
     "csx_cholsol_solve": [H, H, C.c_int32],
     "csx_cholsol_info": [H, _i32p, _i32p, _i32p],

@@ -634,8 +634,28 @@ static void partition_forest(int32_t n, const int32_t *parent, Forest &F) {
         if (slot[(size_t)root[(size_t)j]] < 0) F.level_cols[(size_t)fill[(size_t)level[(size_t)j]]++] = j;
 }
 
+// what the last csx_chol did (csx_chol_info): 1 = forest of cliques (csx_cholclique.hip), 0 = the general path; HIP-event
+// time of its numeric part (k_chol_clique alone / everything after the pattern of L on the general path)
+static int g_chol_path = -1;
+static double g_chol_numeric_ms = 0.0;
+
 static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, const int32_t *pinv, Csc *L) {
     hipStream_t s = ctx().stream;
+    g_chol_path = -1;
+    g_chol_numeric_ms = 0.0;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    struct EvGuard {
+        hipEvent_t &a, &b;
+        ~EvGuard() {
+            if (a) (void)hipEventDestroy(a);
+            if (b) (void)hipEventDestroy(b);
+        }
+    } ev_guard{ev_a, ev_b};
+    if (hipEventCreate(&ev_a) != hipSuccess || hipEventCreate(&ev_b) != hipSuccess) return CSX_ERUNTIME;
+    auto numeric_ms = [&]() {   // after the stream has been synchronised
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, ev_a, ev_b) == hipSuccess) g_chol_numeric_ms = ms;
+    };
     const int32_t n = A->n;
     L->m = L->n = n;
     L->nnz = cp[n];
@@ -678,13 +698,19 @@ static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, c
                 lap("S compared");
                 if (hipMemcpyAsync(d_notspd, &hflag, sizeof(int), hipMemcpyHostToDevice, s) != hipSuccess) st = CSX_ERUNTIME;
             }
+            if (st == CSX_OK) (void)hipEventRecord(ev_a, s);
             if (st == CSX_OK) st = chol_clique_numeric(A, F, L, d_notspd);
+            if (st == CSX_OK) (void)hipEventRecord(ev_b, s);
             if (st == CSX_OK && (hipMemcpyAsync(&hflag, d_notspd, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
                                  hipStreamSynchronize(s) != hipSuccess)) {
                 set_error("cs_chol: %s", hipGetErrorString(hipGetLastError()));
                 st = CSX_ERUNTIME;
             }
             lap("numeric (blocks)");
+            if (st == CSX_OK) {
+                numeric_ms();
+                g_chol_path = 1;
+            }
             dfree(d_notspd);
             free_clique(&F);
             if (st != CSX_OK) return st;
@@ -815,6 +841,7 @@ static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, c
     }
     int hflags[2] = {0, 0x7fffffff};
     if (st == CSX_OK) {
+        (void)hipEventRecord(ev_a, s);
         (void)hipMemsetAsync(d_win, 0xff, (size_t)L->nnz * sizeof(int32_t), s);
         (void)hipMemcpyAsync(d_flags, hflags, sizeof hflags, hipMemcpyHostToDevice, s);
         hipLaunchKernelGGL(k_chol_winner, dim3((unsigned)(((int64_t)n + 3) / 4)), dim3(256), 0, s, n, A->p, A->i, d_pinv,
@@ -924,11 +951,15 @@ static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, c
             }
             l = e;
         }
+        (void)hipEventRecord(ev_b, s);
         if (hipGetLastError() != hipSuccess ||
             hipMemcpyAsync(hflags, d_flags, sizeof hflags, hipMemcpyDeviceToHost, s) != hipSuccess ||
             hipStreamSynchronize(s) != hipSuccess) {
             set_error("cs_chol: %s", hipGetErrorString(hipGetLastError()));
             st = CSX_ERUNTIME;
+        } else {
+            numeric_ms();
+            g_chol_path = 0;
         }
     }
     lap("numeric (device)");
@@ -2311,6 +2342,13 @@ extern "C" int csx_chol(csx_handle_t hA, const int32_t *parent, const int32_t *c
         return st;
     }
     *out = put(K_CSC, L);
+    return CSX_OK;
+}
+
+extern "C" int csx_chol_info(int32_t *path, double *numeric_ms) {
+    if (g_chol_path < 0) return CSX_EINVAL;   // no csx_chol has completed yet
+    if (path) *path = g_chol_path;
+    if (numeric_ms) *numeric_ms = g_chol_numeric_ms;
     return CSX_OK;
 }
 

@@ -294,7 +294,7 @@ __global__ __launch_bounds__(64 * CQ_WAVES, 3) void k_chol_clique(const int32_t 
 #pragma unroll
                 for (int kk0 = 0; kk0 < CQ_CH; kk0 += CQ_G) {
                     // CQ_G columns at a time, index and value of every column requested before anything is used
-                    int32_t ii[CQ_G];
+                    int32_t ii[CQ_G], slot[CQ_G];
                     double vv[CQ_G];
                     bool in[CQ_G];
 #pragma unroll
@@ -304,17 +304,30 @@ __global__ __launch_bounds__(64 * CQ_WAVES, 3) void k_chol_clique(const int32_t 
                         const int32_t pe = k < bs ? __builtin_amdgcn_readlane(ape, k) : pb;
                         const int32_t p = pb + lane;
                         in[uu] = p < pe;
-                        const int32_t pc = min(p, nnz - 1);
-                        ii[uu] = Ai[pc];
-                        vv[uu] = Ax[pc];
+                        ii[uu] = Ai[min(p, nnz - 1)];
+                        // the value is wanted for upper entries only; in an ascending column those are the first k + 1: the
+                        // lanes past them ask for entry k again (no new line; an upper entry further back -- lower entries
+                        // stored in front of it -- is fetched below): half of A.x is never read
+                        vv[uu] = Ax[min(min(p, pb + k), nnz - 1)];
                     }
+                    bool late = false;
 #pragma unroll
                     for (int uu = 0; uu < CQ_G; uu++) {
                         const int k = CQ_CH * q + kk0 + uu;
                         const uint32_t rel = (uint32_t)(ii[uu] - c0);          // rows c0 .. c0 + k are the upper part
                         const bool okk = in[uu] && rel <= (uint32_t)k;
-                        tile[okk ? (kk0 + uu) * CQ_LD + (int)rel : CQ_CH * CQ_LD] = vv[uu];
+                        slot[uu] = okk ? (kk0 + uu) * CQ_LD + (int)rel : CQ_CH * CQ_LD;
+                        late |= okk && lane > k;
                     }
+                    if (__ballot(late) != 0ull) {
+#pragma unroll
+                        for (int uu = 0; uu < CQ_G; uu++) {
+                            const int k = CQ_CH * q + kk0 + uu;
+                            if (slot[uu] != CQ_CH * CQ_LD && lane > k) vv[uu] = Ax[__builtin_amdgcn_readlane(apb, k) + lane];
+                        }
+                    }
+#pragma unroll
+                    for (int uu = 0; uu < CQ_G; uu++) tile[slot[uu]] = vv[uu];
                 }
                 if (any_long) {   // columns of more than 64 entries (a lower part with duplicates, say)
                     for (int kk = 0; kk < CQ_CH && CQ_CH * q + kk < bs; kk++) {

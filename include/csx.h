@@ -194,6 +194,13 @@ int csx_order_nd_host(int32_t n, const int32_t *Ap, const int32_t *Ai, int32_t *
  * Output L (device CSC, diagonal first, rows ascending). */
 int csx_chol(csx_handle_t A, const int32_t *parent, const int32_t *cp, const int32_t *pinv,
              csx_handle_t *L);
+/* What the last successful csx_chol of this process did.  *path: 1 = A's elimination forest is a set of cliques on
+ * consecutive columns (block-diagonal with dense blocks of <= 64 columns; recognised from A itself, L.p / L.i follow from
+ * the counts, every block factored in the registers of one wave, L.x bit-identical to csparse.py:587-617), 0 = the general
+ * path (pattern of L by row-subtree walks and sorts, column kernels by tree level).  *numeric_ms: HIP-event time of the
+ * numeric part (path 1: the block kernel alone; path 0: everything after the pattern of L).  Either pointer may be NULL;
+ * CSX_EINVAL before the first csx_chol.  "chol.clique" = 0 (csx_set_option) forces path 0. */
+int csx_chol_info(int32_t *path, double *numeric_ms);
 
 /* The solve phase of cs_cholsol, csparse.py:640-643, for nrhs right-hand sides:
  * B (n-by-nrhs, row-major) is overwritten with the solutions. */

@@ -7,6 +7,7 @@ import pytest
 import c_oracle as CO
 import csparse_oracle as O
 import synth
+import tol
 from conftest import golden, unpack
 from test_gpu_parity import RTOL, _host_cs, cs  # noqa: F401
 
@@ -39,8 +40,12 @@ def test_chol_and_cholsol_reference_matrices(cs, name):
     b = g["b"].tolist()
     alias = b
     assert cs.cs_cholsol(0, C, b) is True and alias is b
+    # x against the oracle's solves on the ORACLE's L (which differs from the device's by 1e-13): two factorisations of
+    # one matrix, so the componentwise bound carries its conditioning (tests/tol.py); the bit-for-bit check on the build's
+    # own L is the last assertion of this test
     ref = CO.ltsolve(n, Lp, Li, Lx, CO.lsolve(n, Lp, Li, Lx, g["b"]))
-    assert np.max(np.abs(np.asarray(b) - ref) / np.abs(ref)) < 1e-9
+    assert tol.normwise(b, ref) < tol.X_RTOL
+    assert tol.componentwise(b, ref) < tol.cross_bound(tol.cond1(tol.csc(n, Cp, Ci, Cx)))
     if name == "bcsstk01":
         # csparse_test.py:505-516 (0.0005) and the unmodified reference's own LU answer
         assert max(abs(v) for v in b) == pytest.approx(0.0005, abs=1e-4)
@@ -254,10 +259,12 @@ def test_lusol_matches_reference(cs, name, meta):
     b = g["b"].tolist()
     assert cs.cs_lusol(0, C, b, tol) is True
     ref = g["x_lusol"]  # unmodified reference cs_lusol(0, ...)
-    assert np.max(np.abs(np.asarray(b) - ref)) / np.max(np.abs(ref)) < RTOL
-    nz = np.abs(ref) > 1e-3 * np.max(np.abs(ref))
-    assert np.max(np.abs(np.asarray(b)[nz] - ref[nz]) / np.abs(ref[nz])) < 1e-9
-    assert max(abs(v) for v in b) == pytest.approx(meta[name]["lusol_norm_inf"], rel=1e-9)
+    assert tol.normwise(b, ref) < tol.X_RTOL
+    # componentwise: terms of the last substitution of cs_usolve on the reference's own U are not at hand for the
+    # build's (different, D7) factors, so |ref| alone is the scale -- the build's LU takes the reference's pivots and
+    # operation order, and the answers agree far inside the conditioning of fs_183_1 (1.5e13)
+    assert tol.componentwise(b, ref) < tol.X_RTOL
+    assert max(abs(v) for v in b) == pytest.approx(meta[name]["lusol_norm_inf"], rel=tol.X_RTOL)
 
 
 @pytest.mark.parametrize("name", ["bcsstk01", "bcsstk16", "gspd", "arrow", "random"])
@@ -673,9 +680,10 @@ def test_supernodal_solves_in_the_rounding_equal_order(cs, case):
             y = CO.ltsolve(n, Lp, Li, Lx, CO.lsolve(n, Lp, Li, Lx, pb))
             ref = y[pinv]                                             # cs_pvec
             assert Xe[:, r].tobytes() == ref.tobytes()                # exact order: the reference's bits
-            assert np.max(np.abs(Xr[:, r] - ref)) <= 1e-10 * np.max(np.abs(ref))
-            scale = np.maximum(np.abs(ref), 1e-3 * np.max(np.abs(ref)))
-            assert np.max(np.abs(Xr[:, r] - ref) / scale) <= 1e-9
+            assert tol.normwise(Xr[:, r], ref) <= tol.X_RTOL
+            # SURVEY 8d's componentwise measure, the terms those of the last substitution (cs_ltsolve on this L)
+            terms = tol.cholsolve_terms(n, Lp, Li, Lx, CO.lsolve(n, Lp, Li, Lx, pb), y)[pinv]
+            assert tol.componentwise(Xr[:, r], ref, terms) <= tol.X_RTOL
     # a right-hand side gets the same bits however many others are solved with it (the kernels that take few
     # right-hand sides -- lanes per task instead of a wave per task -- form every sum in the same order)
     B64 = synth.rhs(n, 64, 7)

@@ -167,11 +167,14 @@ def test_cholsol_5m_block_spd_residual(cs, lib):
         _csx.free(h)
 
 
-def test_multiply_1m_identity(cs, lib):
+@pytest.mark.parametrize("draw", ["uniform", "stratified"])
+def test_multiply_1m_identity(cs, lib, draw):
+    """Config 4 at full size.  "uniform" is the matrix bench_configs.py times (csx_gen_grand_uniform, seed 20240605: 32
+    distinct uniform rows per column, ragged rows, more hash collisions); "stratified" round 1's draw."""
     import _csx
     n, per_col = 1000000, 32
     hA = _csx.new_handle()
-    _csx.check(lib.csx_gen_grand(n, per_col, 20240605, hA))
+    _csx.check((lib.csx_gen_grand_uniform if draw == "uniform" else lib.csx_gen_grand)(n, per_col, 20240605, hA))
     hB = _csx.new_handle()
     _csx.check(lib.csx_transpose(hA, 1, hB))
     hC = _csx.new_handle()

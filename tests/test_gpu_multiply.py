@@ -64,10 +64,13 @@ def test_multiply_edge_cases(cs):
             assert cs.cs_multiply(A, A) is None
 
 
-@pytest.mark.parametrize("n,per_col", [(20000, 32), (9000, 5), (70000, 12)])
-def test_multiply_hash_paths_against_c_oracle(cs, n, per_col):
-    """m > 8192 rows: the LDS hash accumulators (and, for the dense column below, the global one)."""
-    Ap, Ai, Ax = synth.grand(n, per_col, 31)
+@pytest.mark.parametrize("n,per_col,draw", [(20000, 32, "stratified"), (9000, 5, "stratified"), (70000, 12, "stratified"),
+                                              (60000, 32, "uniform"), (9000, 32, "uniform")])
+def test_multiply_hash_paths_against_c_oracle(cs, n, per_col, draw):
+    """m > 8192 rows: the LDS hash accumulators (and, for the dense column below, the global one).  "uniform" is the draw
+    of BASELINE config 4's matrix S as bench_configs.py generates it (csx_gen_grand_uniform: ragged rows, colliding
+    products); at n = 9 000 a column of A A' collects ~1 000 products on ~950 rows: collisions in every column."""
+    Ap, Ai, Ax = (synth.grand if draw == "stratified" else synth.grand_uniform)(n, per_col, 31)
     Tp, Ti, Tx = CO.transpose(n, n, Ap, Ai, Ax)
     A = _host_cs(cs, n, n, Ap, Ai, Ax)
     AT = _host_cs(cs, n, n, Tp, Ti, Tx)
