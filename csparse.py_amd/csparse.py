@@ -977,6 +977,64 @@ def cs_updown(L, sigma, C, parent):
     return bool(ok.value)
 
 
+def _solve_blocks_sharded(comm, b, nrhs, rows_in, rows_out, solve_block):
+    """A batch of right-hand sides sharded by column block over the ranks of `comm` (independent units, no
+    collective inside a block's solve).  The root (rank 0) passes b, a dvec rows_in-by-K block (or a list: K = 1); the
+    other ranks pass None and nrhs = K.  Rank r gets columns [r k, (r + 1) k), k = ceil(K / world), of b
+    (csx_block_cols + csx_comm_scatter_blocks), solve_block(block: dvec rows_in-by-k) returns its dvec rows_out-by-k
+    solutions (the same object when the solve is in place), which return to the root (csx_comm_gather_blocks).
+    Returns on the root the rows_out-by-K block (b itself, overwritten, when rows_in == rows_out; a new dvec otherwise)
+    and the host list to write back to, if b was one; (None, None) elsewhere.  Every column has the bits of the
+    unsharded solve: a sharded solve IS the unsharded one column by column."""
+    lib = _csx.lib()
+    root = comm.rank == 0
+    K = comm.broadcast_object((b.k if isinstance(b, dvec) else 1) if root else None, 0)
+    if nrhs is not None and nrhs != K:
+        raise ValueError("solve: nrhs does not match the root's block")
+    db = bhost = None
+    if root:
+        db, bhost = _vec_in(b, rows_in, "b")
+    k = (K + comm.world - 1) // comm.world
+    mine = dvec(rows_in, k)
+    packed = dvec(rows_in * k * comm.world) if root else None     # world blocks of rows_in x k, rank order; pad columns = 0
+
+    def _slot(buf, rows, r):
+        h = _csx.new_handle()
+        _csx.check(lib.csx_vec_wrap(_csx.C.c_void_p(buf.device_ptr() + 8 * rows * k * r), rows * k, h), "csx_vec_wrap")
+        return h
+
+    if root:
+        for r in range(comm.world):
+            c0 = r * k
+            kk = max(0, min(k, K - c0))
+            if kk <= 0:
+                continue
+            # columns [c0, c0 + kk) of B -> block r of `packed` (its first kk columns when the last block is short)
+            tmp = dvec(rows_in, kk)
+            _csx.check(lib.csx_block_cols(db.handle, rows_in, K, c0, kk, tmp.handle, 0), "csx_block_cols")
+            slot = _slot(packed, rows_in, r)
+            _csx.check(lib.csx_block_cols(slot, rows_in, k, 0, kk, tmp.handle, 1), "csx_block_cols")
+            _csx.free(slot)
+    comm.scatter_vec_blocks(packed.handle if root else None, mine.handle, rows_in * k, 0)
+    sol = solve_block(mine)
+    back = packed if rows_out == rows_in else (dvec(rows_out * k * comm.world) if root else None)
+    comm.gather_vec_blocks(sol.handle, back.handle if root else None, rows_out * k, 0)
+    if not root:
+        return None, None
+    out = db if rows_out == rows_in else dvec(rows_out, K)
+    for r in range(comm.world):
+        c0 = r * k
+        kk = max(0, min(k, K - c0))
+        if kk <= 0:
+            continue
+        slot = _slot(back, rows_out, r)
+        tmp = dvec(rows_out, kk)
+        _csx.check(lib.csx_block_cols(slot, rows_out, k, 0, kk, tmp.handle, 0), "csx_block_cols")
+        _csx.check(lib.csx_block_cols(out.handle, rows_out, K, c0, kk, tmp.handle, 1), "csx_block_cols")
+        _csx.free(slot)
+    return out, bhost
+
+
 def cs_cholsol(order, A, b):
     """Solve A x = b, A symmetric positive definite, upper triangle used; b is
     overwritten (csparse.py:622-644).  b may be a list (one system) or a dvec
@@ -1073,48 +1131,15 @@ def cholsol_factor(A, order=0, exact=True):
             return True
 
         def _solve_sharded(self, b, comm, nrhs):
-            lib = _csx.lib()
-            root = comm.rank == 0
-            K = comm.broadcast_object((b.k if isinstance(b, dvec) else 1) if root else None, 0)
-            if nrhs is not None and nrhs != K:
-                raise ValueError("solve: nrhs does not match the root's block")
-            db = bhost = None
-            if root:
-                db, bhost = _vec_in(b, n, "b")
-            k = (K + comm.world - 1) // comm.world
-            mine = dvec(n, k)
-            packed = dvec(n * k * comm.world) if root else None       # world blocks of n x k, rank order; pad columns = 0
-            if root:
-                for r in range(comm.world):
-                    c0 = r * k
-                    kk = max(0, min(k, K - c0))
-                    if kk <= 0:
-                        continue
-                    # columns [c0, c0 + kk) of B -> block r of `packed` (its first kk columns when the last block is short)
-                    tmp = dvec(n, kk)
-                    _csx.check(lib.csx_block_cols(db.handle, n, K, c0, kk, tmp.handle, 0), "csx_block_cols")
-                    slot = _csx.new_handle()
-                    _csx.check(lib.csx_vec_wrap(_csx.C.c_void_p(packed.device_ptr() + 8 * n * k * r), n * k, slot),
-                               "csx_vec_wrap")
-                    _csx.check(lib.csx_block_cols(slot, n, k, 0, kk, tmp.handle, 1), "csx_block_cols")
-                    _csx.free(slot)
-            comm.scatter_vec_blocks(packed.handle if root else None, mine.handle, n * k, 0)
-            _csx.check(lib.csx_cholsol_solve(self._current(), mine.handle, k), "csx_cholsol_solve")
-            comm.gather_vec_blocks(mine.handle, packed.handle if root else None, n * k, 0)
-            if root:
-                for r in range(comm.world):
-                    c0 = r * k
-                    kk = max(0, min(k, K - c0))
-                    if kk <= 0:
-                        continue
-                    ptr = packed.device_ptr() + 8 * n * k * r
-                    slot = _csx.new_handle()
-                    _csx.check(lib.csx_vec_wrap(_csx.C.c_void_p(ptr), n * k, slot), "csx_vec_wrap")
-                    tmp = dvec(n, kk)
-                    _csx.check(lib.csx_block_cols(slot, n, k, 0, kk, tmp.handle, 0), "csx_block_cols")
-                    _csx.check(lib.csx_block_cols(db.handle, n, K, c0, kk, tmp.handle, 1), "csx_block_cols")
-                    _csx.free(slot)
-                _write_back(bhost, db, n * K)
+            plan = self._current()
+
+            def block(mine):
+                _csx.check(_csx.lib().csx_cholsol_solve(plan, mine.handle, mine.k), "csx_cholsol_solve")
+                return mine
+
+            out, bhost = _solve_blocks_sharded(comm, b, nrhs, n, n, block)
+            if out is not None:
+                _write_back(bhost, out, n * out.k)
             return True
 
     return _Solver()
@@ -1150,19 +1175,18 @@ def cs_lu(A, S, tol):
         # one workgroup per block; anything else comes back with done = 0 and takes the host code below
         pinv = np.empty(max(n, 1), dtype=np.int32)
         hL, hU, done = _csx.new_handle(), _csx.new_handle(), _csx.C.c_int(0)
-        with _Resident(A) as dA:
+        with _Resident(A) as dA:             # ONE residency for both device attempts (an unpinned A is uploaded once)
             st = _csx.lib().csx_lu_blocks(dA.handle, float(tol), hL, hU, _csx.pi(pinv), done)
-        if st == _csx.ENOTSPD:
-            return None
-        _csx.check(st, "csx_lu_blocks")
-        if not done.value:
-            # one connected matrix: columns scheduled by the column elimination tree, a lane per column (csx_lu_etree);
-            # done = 0 again for a chain-like tree, which stays with the host loop
-            with _Resident(A) as dA:
-                st = _csx.lib().csx_lu_etree(dA.handle, float(tol), hL, hU, _csx.pi(pinv), done)
             if st == _csx.ENOTSPD:
                 return None
-            _csx.check(st, "csx_lu_etree")
+            _csx.check(st, "csx_lu_blocks")
+            if not done.value:
+                # one connected matrix: columns scheduled by the column elimination tree, a lane per column (csx_lu_etree);
+                # done = 0 again for anything but a shallow tree with short columns, which stays with the host loop
+                st = _csx.lib().csx_lu_etree(dA.handle, float(tol), hL, hU, _csx.pi(pinv), done)
+                if st == _csx.ENOTSPD:
+                    return None
+                _csx.check(st, "csx_lu_etree")
         if done.value:
             N = csn()
             N.L = _from_device(hL, lambda nnz: max(nnz, 1))
@@ -1211,7 +1235,7 @@ def cs_lusol(order, A, b, tol):
     N = cs_lu(A, S, tol) if S is not None else None
     if S is None or N is None:
         return False
-    x = xalloc(n)
+    x = dvec(n, b.k) if isinstance(b, dvec) else xalloc(n)      # b: a list (one system) or a dvec n-by-k block (k systems)
     cs_ipvec(N.pinv, b, x, n)
     cs_lsolve(N.L, x)
     cs_usolve(N.U, x)
@@ -1219,10 +1243,58 @@ def cs_lusol(order, A, b, tol):
     return True
 
 
+def lusol_factor(A, order=0, tol=1.0):
+    """Factor once for many solves -- the batched form of cs_lusol (csparse.py:1456-1478): cs_sqr + cs_lu once, then
+    solve(b) runs the reference's sequence x = b(p); L \\ x; U \\ x; b(q) = x (:1474-1477) on the device for a list (one
+    system) or a dvec n-by-k block (k systems, overwritten): csx_permute_vec, csx_tri_solve on L and on U,
+    csx_permute_vec.  Every column is bit-identical to cs_lusol on that column.  solve(b, comm=..., nrhs=K) shards the
+    block by right-hand-side block over the ranks of a shard.Comm, every rank holding this factor; see
+    cholsol_factor.  None when A is not square CSC or singular."""
+    if not CS_CSC(A) or A.m != A.n:
+        return None
+    S = cs_sqr(order, A, False)
+    N = cs_lu(A, S, tol) if S is not None else None
+    if N is None:
+        return None
+    n = A.n
+    L, U = cs_pin(N.L), cs_pin(N.U)
+    hp, keep_p = _perm_handle(N.pinv, n)
+    hq, keep_q = _perm_handle(S.q, n)
+
+    class _Solver(object):
+        factors, symbolic = N, S
+
+        def __init__(self):
+            self._fin = weakref.finalize(self, lambda hs: [_csx.free(h) for h in hs if h is not None], [keep_p, keep_q])
+
+        def _block(self, blk):
+            lib = _csx.lib()
+            x = dvec(n, blk.k)
+            _csx.check(lib.csx_permute_vec(hp, blk.handle, x.handle, n, blk.k, 1), "csx_permute_vec")     # x(pinv) = b
+            with _Resident(L) as dL:
+                _csx.check(lib.csx_tri_solve(_plan(dL, TRI_L), x.handle, blk.k), "csx_tri_solve")
+            with _Resident(U) as dU:
+                _csx.check(lib.csx_tri_solve(_plan(dU, TRI_U), x.handle, blk.k), "csx_tri_solve")
+            _csx.check(lib.csx_permute_vec(hq, x.handle, blk.handle, n, blk.k, 1), "csx_permute_vec")     # b(q) = x
+            return blk
+
+        def solve(self, b, comm=None, nrhs=None):
+            if comm is not None and comm.world > 1:
+                out, bhost = _solve_blocks_sharded(comm, b, nrhs, n, n, self._block)
+                if out is not None:
+                    _write_back(bhost, out, n * out.k)
+                return True
+            db, bhost = _vec_in(b, n, "b")
+            self._block(db)
+            _write_back(bhost, db, n * db.k)
+            return True
+
+    return _Solver()
+
+
 # -------------------------------------------------------------------- QR ----
-# Host Python, like the reference: Householder QR is serial, data dependent and outside the
-# accelerated path.  It exists so that cs_qrsol -- the driver that reaches
-# cs_usolve / cs_utsolve from the least-squares side -- is a drop-in too.
+# cs_qr: host C++ (csx_qr_host), on the device for batches of small independent blocks (csx_qr_blocks); the Q' x step of
+# the solve (cs_happly for every reflection) and the triangular solves on the device (SURVEY 8f N4).
 
 def cs_etree(A, ata):
     """Elimination tree of A (ata False; upper triangle used) or of A'A (csparse.py:1136-1169)."""
@@ -1477,17 +1549,32 @@ def qrsol_factor(A, order=0):
     class _Solver(object):
         factors, symbolic = N, S
 
-        def solve(self, b):
-            host = None if isinstance(b, dvec) else b
-            db = b if isinstance(b, dvec) else dvec(np.asarray(b[:m], dtype=np.float64))
-            if db.n < m:
-                raise IndexError("list index out of range")
+        def _block(self, db):
             X = dvec(m2, db.k)                       # zeros: the fictitious rows stay zero
             cs_ipvec(S.pinv, db, X, m)               # x(pinv) = b
             apply_q(N, X, True)
             cs_usolve(R, X)                          # the first n rows of the block
             out = dvec(n, db.k)
             cs_ipvec(S.q, X, out, n)
+            return out
+
+        def solve(self, b, comm=None, nrhs=None):
+            """comm (a shard.Comm of more than one rank, every rank holding these factors): the block is sharded by
+            right-hand-side block (see cholsol_factor) -- the root passes the m-by-K block and gets the n-by-K
+            solutions, the other ranks pass None and nrhs = K and get None."""
+            if comm is not None and comm.world > 1:
+                host = b if (comm.rank == 0 and not isinstance(b, dvec)) else None
+                src = dvec(np.asarray(b[:m], dtype=np.float64)) if host is not None else b
+                out, _ = _solve_blocks_sharded(comm, src, nrhs, m, n, self._block)
+                if host is not None:
+                    host[:n] = out.numpy().reshape(-1)[:n].tolist()
+                    return True
+                return out
+            host = None if isinstance(b, dvec) else b
+            db = b if isinstance(b, dvec) else dvec(np.asarray(b[:m], dtype=np.float64))
+            if db.n < m:
+                raise IndexError("list index out of range")
+            out = self._block(db)
             if host is not None:
                 host[:n] = out.numpy().reshape(-1)[:n].tolist()
                 return True

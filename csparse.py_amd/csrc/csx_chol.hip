@@ -991,6 +991,7 @@ struct CholPlan {
     double *g_X = nullptr;
     int32_t g_nrhs = 0;
     int64_t g_gen = -1;                // the work-space generation of the supernodal plan the capture saw
+    int g_opt = -1;                    // "tri.supernodes" at capture time: sn_solve picks its kernels by it
     int32_t n = 0;
     const Csc *L = nullptr;  // not owned; must outlive the plan
     TriPlan *fwd = nullptr, *bwd = nullptr;
@@ -2284,7 +2285,8 @@ static int cholsol_solve(CholPlan *P, double *B, int32_t nrhs) {
         if (ctx().opt.tri_graph) {
             // the two sweeps' launches as one graph, re-used while the block of right-hand sides stays where it is
             CSX_TRY(sn_prepare(P->sn, nrhs));              // (may move the work space: the captured launches hold its address)
-            if (!(P->g_exec && P->g_X == X && P->g_nrhs == nrhs && P->g_gen == sn_generation(P->sn))) {
+            if (!(P->g_exec && P->g_X == X && P->g_nrhs == nrhs && P->g_gen == sn_generation(P->sn) &&
+                  P->g_opt == ctx().opt.tri_supernodes)) {
                 if (P->g_exec) (void)hipGraphExecDestroy(P->g_exec);
                 P->g_exec = nullptr;
                 hipGraph_t graph = nullptr;
@@ -2307,6 +2309,7 @@ static int cholsol_solve(CholPlan *P, double *B, int32_t nrhs) {
                 P->g_X = X;
                 P->g_nrhs = nrhs;
                 P->g_gen = sn_generation(P->sn);
+                P->g_opt = ctx().opt.tri_supernodes;
             }
             CSX_HIP(hipGraphLaunch(P->g_exec, s));
         } else {

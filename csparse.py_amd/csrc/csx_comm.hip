@@ -145,8 +145,9 @@ __global__ void k_block_cols(const double *__restrict__ B, int64_t n, int32_t K,
 // One SpMV sharded by columns over the ranks: this rank's m x count block, split by rows into the pieces each rank
 // will own of y.
 struct ShardPlan {
-    Csc *block = nullptr;                // not owned: the rank's column block (m x count)
-    int32_t m = 0, chunk = 0;            // rows; rows per rank = ceil(m / world)
+    csx_handle_t hblock = 0;             // the rank's column block (m x count): NOT owned, so kept as its handle and resolved
+                                         // at every call -- a block freed behind the plan's back is CSX_EINVAL, not a dangling pointer
+    int32_t m = 0, n = 0, chunk = 0;     // rows, columns; rows per rank = ceil(m / world)
     std::vector<Csc *> pieces;           // world row pieces of the block (owned; empty when world == 1)
     double *work = nullptr;              // world * chunk partial y
     double *recv = nullptr;              // (world - 1) * chunk pieces received
@@ -180,25 +181,40 @@ int csx_comm_unique_id(uint8_t *id128) {
 int csx_comm_init(int rank, int world, const uint8_t *id128) {
     CSX_TRY(require_ready());
     if (g_comm.up) {
-        if (g_comm.rank == rank && g_comm.world == world) return CSX_OK;
-        set_error("csx_comm_init: already initialised as rank %d of %d", g_comm.rank, g_comm.world);
+        // the same call again is fine; another rank / world, or the other transport (a local world of one is up and RCCL is
+        // asked for, or the reverse), is not: csx_comm_finalize first
+        if (g_comm.rank == rank && g_comm.world == world && g_comm.rccl == (id128 != nullptr)) return CSX_OK;
+        set_error("csx_comm_init: already initialised as rank %d of %d (%s); csx_comm_finalize first", g_comm.rank, g_comm.world,
+                  g_comm.rccl ? "RCCL" : "local");
         return CSX_EINVAL;
     }
     if (world < 1 || rank < 0 || rank >= world || (world > 1 && !id128)) return CSX_EINVAL;
     Comm c;
     c.rank = rank;
     c.world = world;
-    if (id128) {
-        CSX_TRY(load_rccl());
-        ncclUniqueId id;
-        std::memcpy(&id, id128, 128);
-        CSX_NCCL(g_rccl.CommInitRank(&c.comm, world, id, rank));
-        c.rccl = true;
+    auto build = [&]() -> int {
+        if (id128) {
+            CSX_TRY(load_rccl());
+            ncclUniqueId id;
+            std::memcpy(&id, id128, 128);
+            CSX_NCCL(g_rccl.CommInitRank(&c.comm, world, id, rank));
+            c.rccl = true;
+        }
+        CSX_HIP(hipStreamCreateWithFlags(&c.xs, hipStreamNonBlocking));
+        CSX_HIP(hipEventCreateWithFlags(&c.ev_k, hipEventDisableTiming));
+        CSX_HIP(hipEventCreateWithFlags(&c.ev_x, hipEventDisableTiming));
+        CSX_TRY(dalloc(&c.stage_d, 1024));
+        return CSX_OK;
+    };
+    const int st = build();
+    if (st != CSX_OK) {   // whatever was made before the failing step goes back
+        if (c.rccl && c.comm) (void)g_rccl.CommDestroy(c.comm);
+        if (c.ev_k) (void)hipEventDestroy(c.ev_k);
+        if (c.ev_x) (void)hipEventDestroy(c.ev_x);
+        if (c.xs) (void)hipStreamDestroy(c.xs);
+        dfree(c.stage_d);
+        return st;
     }
-    CSX_HIP(hipStreamCreateWithFlags(&c.xs, hipStreamNonBlocking));
-    CSX_HIP(hipEventCreateWithFlags(&c.ev_k, hipEventDisableTiming));
-    CSX_HIP(hipEventCreateWithFlags(&c.ev_x, hipEventDisableTiming));
-    CSX_TRY(dalloc(&c.stage_d, 1024));
     c.up = true;
     g_comm = c;
     return CSX_OK;
@@ -410,8 +426,9 @@ static int sharded_plan(csx_handle_t hblock, int W, csx_handle_t *out) {
     Csc *A = csc(hblock);
     if (!A || !out || !A->x) return CSX_EINVAL;
     ShardPlan *P = new ShardPlan();
-    P->block = A;
+    P->hblock = hblock;
     P->m = A->m;
+    P->n = A->n;
     P->chunk = (A->m + W - 1) / W;
     int st = dalloc(&P->work, (size_t)std::max<int64_t>((int64_t)P->chunk * W, 1));
     if (st == CSX_OK && W > 1) st = dalloc(&P->recv, (size_t)std::max<int64_t>((int64_t)P->chunk * (W - 1), 1));
@@ -466,17 +483,20 @@ int csx_gaxpy_sharded(csx_handle_t hplan, csx_handle_t hx, csx_handle_t hy, int 
     CSX_TRY(require_comm());
     ShardPlan *P = (ShardPlan *)get(hplan, K_SHARDPLAN);
     Vec *x = vec(hx), *y = vec(hy);
-    if (!P || !x || !y || x->len < P->block->n || y->len < P->chunk || (how != 0 && how != 1)) return CSX_EINVAL;
+    Csc *block = P ? csc(P->hblock) : nullptr;      // handles carry a generation: a freed (or recycled) block resolves to null
+    if (!P || !block || block->m != P->m || block->n != P->n || !x || !y || x->len < P->n || y->len < P->chunk ||
+        (how != 0 && how != 1))
+        return CSX_EINVAL;
     const int W = g_comm.world, rank = g_comm.rank;
     hipStream_t s = ctx().stream;
     const double *xd = (const double *)x->d;
     double *yd = (double *)y->d;
     const int64_t chunk = P->chunk;
     const int32_t mine = (int32_t)std::min<int64_t>(chunk, std::max<int64_t>(0, (int64_t)P->m - (int64_t)rank * chunk));
-    if (W == 1 && !g_comm.rccl) return gaxpy_device(P->block, xd, yd, CSX_GAXPY_AUTO);   // nothing to exchange
+    if (W == 1 && !g_comm.rccl) return gaxpy_device(block, xd, yd, CSX_GAXPY_AUTO);   // nothing to exchange
     CSX_HIP(hipMemsetAsync(P->work, 0, (size_t)(chunk * W) * sizeof(double), s));
     if (how == 0 || W == 1) {
-        CSX_TRY(gaxpy_device(P->block, xd, P->work, CSX_GAXPY_AUTO));
+        CSX_TRY(gaxpy_device(block, xd, P->work, CSX_GAXPY_AUTO));
         double *piece = P->recv ? P->recv : P->work;     // world of one under RCCL: in place
         CSX_NCCL(g_rccl.ReduceScatter(P->work, piece, (size_t)chunk, ncclDouble, ncclSum, g_comm.comm, s));
         if (mine) {
@@ -519,7 +539,7 @@ int csx_gaxpy_sharded_piece(csx_handle_t hplan, int q, csx_handle_t hx) {
     CSX_TRY(require_comm());
     ShardPlan *P = (ShardPlan *)get(hplan, K_SHARDPLAN);
     Vec *x = vec(hx);
-    if (!P || !x || x->len < P->block->n || q < 0 || q >= (int)P->pieces.size()) return CSX_EINVAL;
+    if (!P || !x || x->len < P->n || q < 0 || q >= (int)P->pieces.size()) return CSX_EINVAL;
     double *dst = P->work + (int64_t)q * P->chunk;
     CSX_HIP(hipMemsetAsync(dst, 0, (size_t)P->chunk * sizeof(double), ctx().stream));
     return gaxpy_device(P->pieces[q], (const double *)x->d, dst, CSX_GAXPY_AUTO);

@@ -821,9 +821,12 @@ static int launch_hash2(int slots, const Csc *A, const Csc *B, const int4 *info,
     return CSX_OK;
 }
 
-// one wave per column: move its rows (and sums) from the product-order buffer to their place in C
+// one wave per column: move its rows (and sums) from the product-order buffer to their place in C.  A column's length is
+// count[j] when `count` is given (the chunked path: the NEXT chunk's scan is rewriting Cp[j + 1] of a chunk's last column
+// while that chunk is compacted on the second stream), else Cp[j + 1] - Cp[j].
 __global__ __launch_bounds__(256) void k_sg_compact(const uint32_t *__restrict__ cols, int32_t ncols,
                                                     const int32_t *__restrict__ toff, const int32_t *__restrict__ Cp,
+                                                    const int32_t *__restrict__ count,
                                                     const int32_t *__restrict__ tmp_i, const double *__restrict__ tmp_x,
                                                     int32_t *__restrict__ Ci, double *__restrict__ Cx) {
     const int lane = threadIdx.x & 63;
@@ -831,7 +834,7 @@ __global__ __launch_bounds__(256) void k_sg_compact(const uint32_t *__restrict__
     if (w >= ncols) return;
     const int32_t j = (int32_t)cols[w];
     const int64_t src = toff[j], dst = Cp[j];
-    const int32_t cnt = Cp[j + 1] - Cp[j];
+    const int32_t cnt = count ? count[j] : Cp[j + 1] - Cp[j];
     int32_t k = lane;
     for (; k + 192 < cnt; k += 256) {   // four loads of each array in flight per lane
         int32_t ri[4];
@@ -1035,7 +1038,7 @@ static int multiply_chunked(const Csc *A, const Csc *B, Csc *C, bool values, con
         const int32_t lo = pc[SG_BIN_HASH0], nh = pc[SG_BIN_NARROW0 + SG_NARROW_BINS] - lo;
         if (nh > 0)
             hipLaunchKernelGGL(k_sg_compact, dim3((unsigned)(((int64_t)nh + 3) / 4)), dim3(256), 0, g_sg_stream, scol + lo, nh, toff,
-                               C->p, tmp_i, tmp_x, Ci, Cx);
+                               C->p, count, tmp_i, tmp_x, Ci, Cx);
     }
     // the context's stream continues behind the last copy (and nothing is freed before it has finished)
     if (hipEventRecord(done, g_sg_stream) != hipSuccess || hipStreamWaitEvent(s, done, 0) != hipSuccess) st = CSX_ERUNTIME;
@@ -1339,7 +1342,7 @@ int multiply_device(const Csc *A, const Csc *B, Csc *C) {
     }
     if (st == CSX_OK && onepass) {
         hipLaunchKernelGGL(k_sg_compact, dim3((unsigned)(((int64_t)nhash + 3) / 4)), dim3(256), 0, s, scol + hash_lo,
-                           nhash, toff, C->p, tmp_i, tmp_x, C->i, C->x);
+                           nhash, toff, C->p, nullptr, tmp_i, tmp_x, C->i, C->x);
         if (hipGetLastError() != hipSuccess) st = CSX_ERUNTIME;
     }
     if (st == CSX_OK) {

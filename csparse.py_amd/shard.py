@@ -60,14 +60,24 @@ class Rendezvous(object):
     """Carries one small blob (the RCCL unique id) from rank 0 to the other ranks of THIS launch.
 
     Rank 0 listens on the first free port of MASTER_PORT + 1 ... + 16 and serves world - 1 clients; a client tries
-    the candidates in turn until a server answers the hand-shake with this launch's token (the launcher's pid, which
-    every rank has as its parent, and the world size), so a stranger on one of the ports is skipped, not believed."""
+    the candidates in turn until a server answers the hand-shake with this launch's token, so a stranger on one of the
+    ports is skipped, not believed.  The token is something every rank of ONE launch shares, whatever started them:
+    CSX_RDV_TOKEN, else the launcher's run id (TORCHELASTIC_RUN_ID; torchrun, also across nodes), else MASTER_ADDR :
+    MASTER_PORT when the launcher set them (srun / mpirun wrappers), else -- ranks forked by one parent on one host, as
+    bench.py and the tests do -- the parent's pid; always with the world size.  A server that sees ANOTHER token says
+    whose port it is, and a client that finds only such servers names both tokens in its error."""
 
     def __init__(self, rank, world, addr=None, port=None, token=None, timeout=300.0):
         self.rank, self.world = rank, world
         self.addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
         self.port = int(port if port is not None else os.environ.get("MASTER_PORT", "29500"))
-        tok = token if token is not None else os.environ.get("CSX_RDV_TOKEN") or "%d" % os.getppid()
+        tok = token if token is not None else os.environ.get("CSX_RDV_TOKEN")
+        if tok is None and os.environ.get("TORCHELASTIC_RUN_ID"):
+            tok = "run:" + os.environ["TORCHELASTIC_RUN_ID"]
+        if tok is None and "MASTER_ADDR" in os.environ and "MASTER_PORT" in os.environ and addr is None and port is None:
+            tok = "master:%s:%s" % (os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"])
+        if tok is None:
+            tok = "ppid:%d" % os.getppid()
         self.token = ("%s/%d" % (tok, world)).encode()
         self.timeout = timeout
 
@@ -108,26 +118,29 @@ class Rendezvous(object):
                     srv = None
             if srv is None:
                 raise RuntimeError("shard.Rendezvous: no free port in %s" % self._candidates())
-            srv.listen(self.world)
-            srv.settimeout(self.timeout)
-            served = 0
-            while served < self.world - 1:
-                conn, _ = srv.accept()
-                try:
-                    conn.settimeout(10.0)
-                    hello = self._recv(conn)
-                    if hello == _MAGIC + self.token:
-                        self._send(conn, _MAGIC + blob)
-                        served += 1
-                    else:
-                        self._send(conn, b"NOPE")
-                except (OSError, ConnectionError, struct.error):
-                    pass
-                finally:
-                    conn.close()
-            srv.close()
+            try:
+                srv.listen(self.world)
+                srv.settimeout(self.timeout)
+                served = 0
+                while served < self.world - 1:
+                    conn, _ = srv.accept()             # socket.timeout after self.timeout: srv is closed below
+                    try:
+                        conn.settimeout(10.0)
+                        hello = self._recv(conn)
+                        if hello == _MAGIC + self.token:
+                            self._send(conn, _MAGIC + blob)
+                            served += 1
+                        else:                          # a client of another launch (or a stranger): tell it whose port this is
+                            self._send(conn, b"NOPE" + self.token)
+                    except (OSError, ConnectionError, struct.error):
+                        pass
+                    finally:
+                        conn.close()
+            finally:
+                srv.close()
             return blob
         deadline = time.time() + self.timeout
+        refused = None
         while time.time() < deadline:
             for port in self._candidates():
                 try:
@@ -137,9 +150,17 @@ class Rendezvous(object):
                         ans = self._recv(sk)
                         if ans[:4] == _MAGIC:
                             return ans[4:]
+                        if ans[:4] == b"NOPE":
+                            refused = (port, ans[4:])
                 except (OSError, ConnectionError, struct.error):
                     continue
             time.sleep(0.05)
+        if refused is not None:
+            # the only csx servers found belong to another launch: the ranks of this job do not share a token (started by
+            # different parents without a common run id?)
+            raise TimeoutError("shard.Rendezvous: rank %d's token %r is not the token %r of the rank 0 listening on %s:%d, and no "
+                               "other rank 0 answered; set CSX_RDV_TOKEN to one value for all ranks of the job"
+                               % (self.rank, self.token, refused[1], self.addr, refused[0]))
         raise TimeoutError("shard.Rendezvous: rank 0 did not answer on %s:%s" % (self.addr, self._candidates()))
 
 

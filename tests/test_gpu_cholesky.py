@@ -7,7 +7,7 @@ import pytest
 import c_oracle as CO
 import csparse_oracle as O
 import synth
-import tol
+import tol as TOL
 from conftest import golden, unpack
 from test_gpu_parity import RTOL, _host_cs, cs  # noqa: F401
 
@@ -44,8 +44,8 @@ def test_chol_and_cholsol_reference_matrices(cs, name):
     # one matrix, so the componentwise bound carries its conditioning (tests/tol.py); the bit-for-bit check on the build's
     # own L is the last assertion of this test
     ref = CO.ltsolve(n, Lp, Li, Lx, CO.lsolve(n, Lp, Li, Lx, g["b"]))
-    assert tol.normwise(b, ref) < tol.X_RTOL
-    assert tol.componentwise(b, ref) < tol.cross_bound(tol.cond1(tol.csc(n, Cp, Ci, Cx)))
+    assert TOL.normwise(b, ref) < TOL.X_RTOL
+    assert TOL.componentwise(b, ref) < TOL.cross_bound(TOL.cond1(TOL.csc(n, Cp, Ci, Cx)))
     if name == "bcsstk01":
         # csparse_test.py:505-516 (0.0005) and the unmodified reference's own LU answer
         assert max(abs(v) for v in b) == pytest.approx(0.0005, abs=1e-4)
@@ -259,12 +259,12 @@ def test_lusol_matches_reference(cs, name, meta):
     b = g["b"].tolist()
     assert cs.cs_lusol(0, C, b, tol) is True
     ref = g["x_lusol"]  # unmodified reference cs_lusol(0, ...)
-    assert tol.normwise(b, ref) < tol.X_RTOL
+    assert TOL.normwise(b, ref) < TOL.X_RTOL
     # componentwise: terms of the last substitution of cs_usolve on the reference's own U are not at hand for the
     # build's (different, D7) factors, so |ref| alone is the scale -- the build's LU takes the reference's pivots and
     # operation order, and the answers agree far inside the conditioning of fs_183_1 (1.5e13)
-    assert tol.componentwise(b, ref) < tol.X_RTOL
-    assert max(abs(v) for v in b) == pytest.approx(meta[name]["lusol_norm_inf"], rel=tol.X_RTOL)
+    assert TOL.componentwise(b, ref) < TOL.X_RTOL
+    assert max(abs(v) for v in b) == pytest.approx(meta[name]["lusol_norm_inf"], rel=TOL.X_RTOL)
 
 
 @pytest.mark.parametrize("name", ["bcsstk01", "bcsstk16", "gspd", "arrow", "random"])
@@ -680,10 +680,10 @@ def test_supernodal_solves_in_the_rounding_equal_order(cs, case):
             y = CO.ltsolve(n, Lp, Li, Lx, CO.lsolve(n, Lp, Li, Lx, pb))
             ref = y[pinv]                                             # cs_pvec
             assert Xe[:, r].tobytes() == ref.tobytes()                # exact order: the reference's bits
-            assert tol.normwise(Xr[:, r], ref) <= tol.X_RTOL
+            assert TOL.normwise(Xr[:, r], ref) <= TOL.X_RTOL
             # SURVEY 8d's componentwise measure, the terms those of the last substitution (cs_ltsolve on this L)
-            terms = tol.cholsolve_terms(n, Lp, Li, Lx, CO.lsolve(n, Lp, Li, Lx, pb), y)[pinv]
-            assert tol.componentwise(Xr[:, r], ref, terms) <= tol.X_RTOL
+            terms = TOL.cholsolve_terms(n, Lp, Li, Lx, CO.lsolve(n, Lp, Li, Lx, pb), y)[pinv]
+            assert TOL.componentwise(Xr[:, r], ref, terms) <= TOL.X_RTOL
     # a right-hand side gets the same bits however many others are solved with it (the kernels that take few
     # right-hand sides -- lanes per task instead of a wave per task -- form every sum in the same order)
     B64 = synth.rhs(n, 64, 7)

@@ -92,6 +92,43 @@ TWO_RANKS = HEAD + textwrap.dedent("""
         Lp, Li, Lx = CO.chol(n, Ap, Ai, Ax, parent, cp)
         ref = np.stack([CO.ltsolve(n, Lp, Li, Lx, CO.lsolve(n, Lp, Li, Lx, B[:, r])) for r in range(K)], axis=1)
         out["solve_bit_identical"] = dB.numpy().tobytes() == ref.tobytes()
+    # ---- lusol_factor / qrsol_factor: the same sharding for cs_lusol (csparse.py:1474-1477) and cs_qrsol (:1893-1897) ----
+    from conftest import golden, unpack
+    import csparse_oracle as O
+    gw = golden("west0067")
+    W = cs.cs_pin(unpack(cs, gw, "C"))
+    nw = W.n
+    FL = cs.lusol_factor(W, 0, 1.0)
+    BW = synth.rhs(nw, K, 3)
+    dW = cs.dvec(BW) if rank == 0 else None
+    assert FL.solve(dW, comm=comm, nrhs=K)
+    if rank == 0:
+        ok = True
+        for r in range(K):
+            col = BW[:, r].tolist()
+            assert O.cs_lusol(0, unpack(O, gw, "C"), col, 1.0)
+            ok = ok and np.asarray(col).tobytes() == np.ascontiguousarray(dW.numpy().reshape(nw, K)[:, r]).tobytes()
+        one = BW[:, 1].tolist()                          # ... and the unsharded solver on a list, and cs_lusol on a block
+        assert FL.solve(one)
+        ok = ok and np.asarray(one).tobytes() == np.ascontiguousarray(dW.numpy().reshape(nw, K)[:, 1]).tobytes()
+        dW2 = cs.dvec(BW)
+        assert cs.cs_lusol(0, W, dW2, 1.0)
+        out["lusol_bit_identical"] = ok and dW2.numpy().tobytes() == dW.numpy().tobytes()
+    ga = golden("ash219")
+    Q = cs.cs_pin(unpack(cs, ga, "C"))
+    mq, nq = Q.m, Q.n
+    FQ = cs.qrsol_factor(Q, 0)
+    BQ = synth.rhs(mq, K, 1)
+    XQ = FQ.solve(cs.dvec(BQ) if rank == 0 else None, comm=comm, nrhs=K)
+    if rank == 0:
+        ok = True
+        for r in range(K):
+            col = BQ[:, r].tolist()
+            assert cs.cs_qrsol(0, Q, col)
+            ok = ok and np.asarray(col[:nq]).tobytes() == np.ascontiguousarray(XQ.numpy().reshape(nq, K)[:, r]).tobytes()
+        out["qrsol_bit_identical"] = ok
+    else:
+        assert XQ is None
     # ---- the factor shipped from rank 0 instead of factored twice ----
     hL = comm.bcast_csc(F.L._dev.handle if rank == 0 else None, 0)
     p, i, x = np.empty(n + 1, np.int32), np.empty(F.L.p[n], np.int32), np.empty(F.L.p[n])
@@ -168,6 +205,7 @@ def test_sharded_solve_and_sharded_gaxpy_at_world_size_two_and_three(tmp_path, w
         assert p.returncode == 0, se[-3000:]
     res = {d["rank"]: d for d in (_result(so) for so, _ in outs)}
     assert res[0]["solve_bit_identical"] is True
+    assert res[0]["lusol_bit_identical"] is True and res[0]["qrsol_bit_identical"] is True
     assert all(res[r]["factor_arrived"] for r in range(world))
     assert [res[r]["gaxpy_rows"] for r in range(world)] == [list(shard.row_chunk(r, world, 3001)) for r in range(world)]
     assert max(e for r in range(world) for e in res[r]["gaxpy_err"]) < 1e-12

@@ -250,3 +250,35 @@ def test_multiply_in_column_chunks_gives_the_same_matrix(cs):
             C1 = cs.cs_multiply(A, AT)
         assert C1.p == C0.p and C1.i == C0.i and C1.nzmax == C0.nzmax
         assert np.max(np.abs(np.asarray(C1.x) - np.asarray(C0.x)) / np.abs(np.asarray(C0.x))) < 1e-13
+
+
+def test_multiply_in_column_chunks_while_the_copy_overlaps(cs):
+    """The same on a matrix big enough for a chunk's compaction (second stream) to still be running when the next chunk's
+    counts are scanned into C.p: the copy takes a column's length from the counts, not from C.p[j + 1], which the next
+    chunk's scan is rewriting at that moment (round-3 advisor finding).  p, i bit for bit, x to rounding, 2 .. 8 chunks."""
+    import ctypes as C
+    import _csx
+    lib = _csx.lib()
+    n, per_col = 120000, 32
+    hA, hT = _csx.new_handle(), _csx.new_handle()
+    _csx.check(lib.csx_gen_grand_uniform(n, per_col, 77, hA))
+    _csx.check(lib.csx_transpose(hA, 1, hT))
+
+    def product():
+        hC = _csx.new_handle()
+        _csx.check(lib.csx_multiply(hA, hT, hC))
+        m_, n_, z_, hv = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int()
+        _csx.check(lib.csx_csc_info(hC, m_, n_, z_, hv))
+        p, i, x = np.empty(n + 1, np.int32), np.empty(z_.value, np.int32), np.empty(z_.value)
+        _csx.check(lib.csx_csc_download(hC, _csx.pi(p), _csx.pi(i), _csx.pd(x)))
+        _csx.free(hC)
+        return p, i, x
+
+    p0, i0, x0 = product()
+    for chunks in (2, 3, 5, 8):
+        with _csx.option("spgemm.chunks", chunks):
+            p1, i1, x1 = product()
+        assert p1.tobytes() == p0.tobytes() and i1.tobytes() == i0.tobytes(), chunks
+        assert np.max(np.abs(x1 - x0) / np.abs(x0)) < 1e-13, chunks
+    _csx.free(hA)
+    _csx.free(hT)

@@ -5,7 +5,7 @@ in the reference's test file (csparse_test.py:496, :564, :578, :592; absolute de
 import numpy as np
 import pytest
 
-import tol
+import tol as TOL
 from conftest import golden, unpack
 from test_gpu_parity import RTOL, cs  # noqa: F401
 
@@ -20,11 +20,11 @@ def test_qrsol_square_matches_reference(cs, name, meta):
     alias = b
     assert cs.cs_qrsol(0, C, b) is True and alias is b
     ref = g["x_qrsol"]
-    assert tol.normwise(b, ref) < tol.X_RTOL       # same algorithm, same operation order as the reference's cs_qrsol
-    assert max(abs(v) for v in b) == pytest.approx(meta[name]["qrsol_norm_inf"], rel=tol.X_RTOL)
+    assert TOL.normwise(b, ref) < TOL.X_RTOL       # same algorithm, same operation order as the reference's cs_qrsol
+    assert max(abs(v) for v in b) == pytest.approx(meta[name]["qrsol_norm_inf"], rel=TOL.X_RTOL)
     # and it agrees with the LU answer of the same system: another factorisation, so to the conditioning of the matrix
-    A = tol.csc(C.n, g["C_p"], g["C_i"], g["C_x"])
-    assert tol.normwise(b, g["x_lusol"]) < tol.cross_bound(tol.cond1(A))
+    A = TOL.csc(C.n, g["C_p"], g["C_i"], g["C_x"])
+    assert TOL.normwise(b, g["x_lusol"]) < TOL.cross_bound(TOL.cond1(A))
 
 
 EXPECTED = {"ash219": 1.0052, "ibm32a": 5.5800, "ibm32b": 5.3348, "lp_afiro": 2.4534}

@@ -155,6 +155,53 @@ def test_rendezvous_carries_the_unique_id_and_skips_strangers():
     assert shard.row_chunk(1, 2, 3001) == (1501, 1500) and shard.row_chunk(7, 8, 10) == (10, 0)
 
 
+def test_rendezvous_token_comes_from_the_launcher_and_a_mismatch_names_both_tokens(monkeypatch):
+    """Ranks started by DIFFERENT parents (torchrun across nodes, per-rank wrapper shells) share the launcher's run id or
+    MASTER_ADDR:MASTER_PORT, not a parent pid; a client that only finds a rank 0 of another launch says whose port it met."""
+    import threading
+    sys.path.insert(0, os.path.join(ROOT, "csparse.py_amd"))
+    import shard
+    for k in ("CSX_RDV_TOKEN", "TORCHELASTIC_RUN_ID", "MASTER_ADDR", "MASTER_PORT"):
+        monkeypatch.delenv(k, raising=False)
+    assert shard.Rendezvous(0, 2).token == b"ppid:%d/2" % os.getppid()
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29411")
+    assert shard.Rendezvous(1, 4).token == b"master:127.0.0.1:29411/4"
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "job-7")
+    assert shard.Rendezvous(1, 4).token == b"run:job-7/4"
+    monkeypatch.setenv("CSX_RDV_TOKEN", "mine")
+    assert shard.Rendezvous(1, 4).token == b"mine/4"
+    import socket
+    with socket.socket() as probe:
+        probe.bind(("127.0.0.1", 0))
+        base = probe.getsockname()[1]
+    res = {}
+
+    def server():
+        try:
+            shard.Rendezvous(0, 2, addr="127.0.0.1", port=base, token="launch-A", timeout=6).share(b"id")
+        except Exception as e:               # noqa: BLE001 -- nobody of its own launch comes: accept() times out
+            res["server"] = type(e).__name__
+
+    def client():
+        try:
+            shard.Rendezvous(1, 2, addr="127.0.0.1", port=base, token="launch-B", timeout=3).share(None)
+        except Exception as e:               # noqa: BLE001
+            res["client"] = str(e)
+
+    ts = [threading.Thread(target=server), threading.Thread(target=client)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(20)
+    assert "launch-B/2" in res["client"] and "launch-A/2" in res["client"] and "CSX_RDV_TOKEN" in res["client"]
+    assert res["server"] in ("timeout", "TimeoutError")
+    # the server socket was closed on the way out: the port can be bound again at once
+    with socket.socket() as again:
+        again.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        again.bind(("127.0.0.1", base + 1))
+
+
 def _run_bench(extra, env=None, timeout=300):
     e = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):

@@ -88,6 +88,60 @@ while time.time() < t_end:
                 assert Xk[:, r].tobytes() == ofn(n, Tp, Ti, Tx, B[:, r]).tobytes(), ("band trisolve", seed, fn.__name__, n, band, keep, k, r)
         counts["band_trisolve"] += 1
         continue
+    if seed % 7 == 1:  # forests of cliques (csx_cholclique.hip): block-diagonal, random block sizes and densities, entries of
+        sizes = rng.integers(1, int(rng.choice([9, 33, 65, 90])), size=int(rng.choice([1, 40, 600]))).tolist()   # the lower part shuffled,
+        dens = float(rng.choice([1.0, 0.5, 0.15]))                 # now and then a duplicate or a block of more than 64 columns (the
+        n = int(sum(sizes))                                        # general path must take over): schol, chol bit for bit, cholsol
+        cols_i, cols_x, a = [], [], 0
+        for bsz in sizes:
+            R = rng.uniform(-1.0, 1.0, (bsz, bsz))
+            Bm = R @ R.T / bsz + bsz * np.eye(bsz)
+            keep = np.triu(rng.uniform(size=(bsz, bsz)) < dens)
+            keep = keep | keep.T
+            if rng.random() < 0.8:
+                keep[0, :] = keep[:, 0] = True                     # the block's factor is a clique; otherwise whatever comes
+            keep[np.arange(bsz), np.arange(bsz)] = True
+            for c in range(bsz):
+                rws = np.nonzero(keep[:, c])[0]
+                lo = rws[rws > c]
+                rng.shuffle(lo)
+                rws = np.concatenate([rws[rws <= c], lo])
+                cols_i.append(rws + a); cols_x.append(Bm[rws, c] * keep[rws, c])
+            a += bsz
+        if rng.random() < 0.15 and n > 3:                          # a duplicate in some upper part: last one wins (csparse.py:594)
+            c = int(rng.integers(1, n))
+            if len(cols_i[c]) and cols_i[c][0] < c:
+                cols_i[c] = np.concatenate([cols_i[c][:1], cols_i[c]]); cols_x[c] = np.concatenate([[0.125], cols_x[c]])
+        Cp = np.zeros(n + 1, np.int32); Cp[1:] = np.cumsum([len(c) for c in cols_i])
+        Ci, Cx = np.concatenate(cols_i).astype(np.int32), np.concatenate(cols_x)
+        parent, cp = CO.schol(n, Cp, Ci)
+        Lp, Li, Lx = CO.chol(n, Cp, Ci, Cx, parent, cp)
+        A = cs.cs_pin(host(cs, n, n, Cp, Ci, Cx))
+        S = cs.cs_schol(0, A)
+        assert S is not None and list(S.parent) == parent.tolist() and list(S.cp) == cp.tolist(), ("clique schol", seed, n)
+        N = cs.cs_chol(A, S)
+        assert N is not None, ("clique chol returned None", seed, n)
+        lnz = int(Lp[-1])
+        assert N.L.p == Lp.tolist() and N.L.i[:lnz] == Li.tolist(), ("clique chol pattern", seed, n)
+        got = np.asarray(N.L.x[:lnz])
+        path = _csx.C.c_int32(-1)
+        _csx.check(_csx.lib().csx_chol_info(path, None))
+        if path.value == 1:
+            assert got.tobytes() == Lx.tobytes(), ("clique chol values", seed, n)
+        else:
+            assert float(np.max(np.abs(got - Lx))) <= 1e-13 * max(1.0, float(np.max(np.abs(Lx)))), ("chol values", seed, n)
+        k = int(rng.choice([1, 3, 70]))
+        B = rng.uniform(-1, 1, size=(n, k))
+        F = cs.cholsol_factor(A)
+        X = cs.dvec(B if k > 1 else B[:, 0].copy())
+        assert F.solve(X) is True
+        Xn = X.numpy().reshape(n, k)
+        gLp, gLi, gLx = np.asarray(F.L.p, np.int32), np.asarray(F.L.i[:lnz], np.int32), np.asarray(F.L.x[:lnz])
+        for r in sorted({0, k - 1}):
+            z = CO.ltsolve(n, gLp, gLi, gLx, CO.lsolve(n, gLp, gLi, gLx, B[:, r]))
+            assert Xn[:, r].tobytes() == z.tobytes(), ("clique cholsol", seed, n, k, r)
+        counts["clique_cholesky"] = counts.get("clique_cholesky", 0) + 1
+        continue
     if seed % 7 == 5:  # order 1 (nested dissection) on grids with random holes: supernodes as dense trapezoids, level hints from
         import scipy.sparse as sp                       # the tree, wave-per-row solves; L against the oracle on the permuted matrix
         gx, gy = int(rng.integers(20, 160)), int(rng.integers(20, 160))
