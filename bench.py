@@ -266,6 +266,9 @@ def main():
                     help="launcher and exchange plumbing only, on CPU tensors (gloo): no GPU, no kernels, value = null")
     ap.add_argument("--extras-deadline", type=float, default=420.0,
                     help="seconds the legs after the headline may take before rank 0 prints what it has (0: no bound)")
+    ap.add_argument("--dry-exchange", action="store_true",
+                    help="only the exchange preflight (every exchange leg at n = 100 000, 8 right-hand sides, pass / fail per leg): "
+                         "no headline, value = null.  At N > 1 the preflight always runs before the full-size legs.")
     ap.add_argument("--exchange-nrhs", type=int, default=None,
                     help="right-hand sides per GPU in the scatter / gather legs (default: --nrhs)")
     args = ap.parse_args()
@@ -291,6 +294,17 @@ def main():
         comm.barrier(_csx.sync)
 
     max_over_ranks = comm.max
+
+    if args.dry_exchange:
+        out = {"metric": "cs_gaxpy achieved HBM GB/s (algorithmic bytes / time), 5M x 5M CSC, 64 nnz/col", "value": None,
+               "unit": "GB/s", "n_gpus": world, "steps": 0, "warmup": 0, "dry_exchange": True}
+        deadline = Deadline(args.extras_deadline, rank)
+        deadline.arm(out)
+        exchange_preflight(args, lib, cs, comm, barrier, deadline, out)
+        deadline.emit(out)
+        comm.close()
+        deadline.timer.cancel()
+        return
 
     n, per_col = args.n, args.per_col
     nnz = n * per_col
@@ -412,6 +426,10 @@ def main():
     _csx.free(hA)
     deadline = Deadline(args.extras_deadline, rank)
     deadline.arm(out)
+    preflight = None
+    if world > 1 or args.force_sharded:
+        # every exchange leg at a small size first: a hang at N > 1 is then attributed to a leg (see exchange_preflight)
+        preflight = exchange_preflight(args, lib, cs, comm, barrier, deadline, out)
     # the same kernel on the other row draw (not part of `value`)
     other = "stratified" if args.gen == "uniform" else "uniform"
     hA2 = _csx.new_handle()
@@ -460,7 +478,7 @@ def main():
                                           "frac": round(gbs / HBM_PEAK_GBS, 4),
                                           "traffic": (measured_traffic("k_gaxpy_rows4", n=n, nnz=nnz) or {}).get("bytes")}}
         if not args.skip_cholsol:
-            extra = cholsol_section(args, lib, cs, comm, hB, nb, bs, barrier, max_over_ranks)
+            extra = cholsol_section(args, lib, cs, comm, hB, nb, bs, barrier, max_over_ranks, preflight)
             if extra:
                 out["cholsol"] = extra
         _csx.free(hB)
@@ -469,7 +487,16 @@ def main():
         deadline.checkpoint(out)
 
     if (world > 1 or args.force_sharded) and not args.skip_sharded:
-        out["gaxpy_one_matrix_column_sharded"] = sharded_spmv_section(args, lib, cs, comm, barrier, max_over_ranks)
+        legs = (preflight or {}).get("legs", {})
+        if not legs.get("sharded_gaxpy_reduce_scatter", {}).get("ok", True):
+            out["gaxpy_one_matrix_column_sharded"] = {"skipped": "the reduce-scatter form failed the exchange preflight"}
+        else:
+            p2p_ok = legs.get("sharded_gaxpy_row_pieces_p2p", {}).get("ok", True)
+            out["gaxpy_one_matrix_column_sharded"] = sharded_spmv_section(args, lib, cs, comm, barrier, max_over_ranks,
+                                                                          forms=(0, 1) if p2p_ok else (0,))
+            if not p2p_ok:
+                out["gaxpy_one_matrix_column_sharded"]["fallback"] = ("row_pieces_overlapped_p2p failed its row-for-row check "
+                                                                      "in the preflight: only spmv_then_reduce_scatter was run")
 
     if rank == 0 and world == 1 and not args.skip_configs:
         # BASELINE's other configs (2: bcsstk16 SpMV, 3: cs_lusol on W, 4: A*A' on S) and cs_transpose at the headline
@@ -495,7 +522,156 @@ def main():
     deadline.timer.cancel()
 
 
-def sharded_spmv_section(args, lib, cs, comm, barrier, max_over_ranks):
+def exchange_preflight(args, lib, cs, comm, barrier, deadline, out):
+    """Every exchange leg of the N > 1 run at a SMALL size (n = 100 032, 8 right-hand sides) before the full-size ones,
+    pass / fail per leg.  The first RCCL run on more than one GPU is the driver's scaling bench: if a leg hangs there --
+    a rank failing inside a collective leaves the others waiting until --extras-deadline -- the line rank 0 then prints
+    names the leg that was running ("running"), instead of the deadline eating the attribution; a leg that completes but
+    fails its check is reported and its full-size form is skipped or replaced (the p2p sharded SpMV falls back to the
+    reduce-scatter form).  Legs: factor broadcast (csx_comm_bcast_csc) with the receiver's solve reproduced bit for bit;
+    right-hand-side scatter; solution gather; the column-sharded SpMV in both forms, row for row against the unsharded
+    product; cholsol_factor(A).solve(B, comm=...) against the unsharded solve."""
+    import numpy as np
+    import _csx
+    import shard
+    rank, world = comm.rank, comm.world
+    res = {"world": world, "backend": comm.backend, "n": None, "legs": {}, "running": None}
+    out["exchange_preflight"] = res
+
+    def leg(name, fn):
+        res["running"] = name
+        deadline.checkpoint(out)
+        t0 = time.perf_counter()
+        try:
+            ok = fn()
+            ok = bool(comm.sum(1.0 if ok else 0.0) == world)      # every rank's check
+            res["legs"][name] = {"ok": ok, "s": round(time.perf_counter() - t0, 4)}
+        except Exception as e:                                    # reported, never fatal
+            res["legs"][name] = {"ok": False, "error": "%s: %s" % (type(e).__name__, e)}
+        res["running"] = None
+        deadline.checkpoint(out)
+
+    nb, bs, k = 1563, 64, 8
+    n = nb * bs
+    res["n"], res["nrhs_per_gpu"] = n, k
+    hB = _csx.new_handle()
+    _csx.check(lib.csx_gen_gspd(nb, bs, 20240601 + 5, hB), "gen_gspd")
+    A = cs._from_device(hB, lambda z: max(z, 1))
+    A._pinned = True
+    F = cs.cholsol_factor(A, exact=True)
+
+    def own_solution(col0):
+        h = _csx.new_handle()
+        _csx.check(lib.csx_gen_rhs(n, k, col0, h), "gen_rhs")
+        _csx.check(lib.csx_cholsol_solve(F.plan_handle, h, k), "cholsol_solve")
+        a = np.empty(n * k)
+        _csx.check(lib.csx_vec_download(h, _csx.pd(a), n * k), "vec_download")
+        _csx.free(h)
+        return a
+
+    X_own = own_solution(rank * k)
+
+    def bcast_factor():
+        hL2 = comm.bcast_csc(F.L._dev.handle if rank == 0 else None, 0)
+        plan2, h = _csx.new_handle(), _csx.new_handle()
+        _csx.check(lib.csx_cholsol_plan(hL2, None, plan2), "cholsol_plan")
+        _csx.check(lib.csx_gen_rhs(n, k, rank * k, h), "gen_rhs")
+        _csx.check(lib.csx_cholsol_solve(plan2, h, k), "cholsol_solve")
+        a = np.empty(n * k)
+        _csx.check(lib.csx_vec_download(h, _csx.pd(a), n * k), "vec_download")
+        for q in (plan2, h) + ((hL2,) if rank != 0 else ()):       # the root's handle is its own factor
+            _csx.free(q)
+        return a.tobytes() == X_own.tobytes()
+
+    state = {}
+
+    def scatter():
+        mine = cs.dvec(n * k)
+        src = None
+        if rank == 0:
+            src = cs.dvec(n * k * world)
+            for r in range(world):
+                h, slot = _csx.new_handle(), _csx.new_handle()
+                _csx.check(lib.csx_gen_rhs(n, k, r * k, h), "gen_rhs")
+                _csx.check(lib.csx_vec_wrap(_csx.C.c_void_p(src.device_ptr() + 8 * n * k * r), n * k, slot), "vec_wrap")
+                _csx.check(lib.csx_vec_copy(h, slot), "vec_copy")
+                _csx.free(slot)
+                _csx.free(h)
+        comm.scatter_vec_blocks(src.handle if rank == 0 else None, mine.handle, n * k, 0)
+        h = _csx.new_handle()
+        _csx.check(lib.csx_gen_rhs(n, k, rank * k, h), "gen_rhs")
+        want = np.empty(n * k)
+        _csx.check(lib.csx_vec_download(h, _csx.pd(want), n * k), "vec_download")
+        _csx.free(h)
+        state["src"], state["mine"] = src, mine
+        return mine.numpy().tobytes() == want.tobytes()
+
+    def gather():
+        import hashlib
+        mine, src = state["mine"], state.get("src")
+        _csx.check(lib.csx_cholsol_solve(F.plan_handle, mine.handle, k), "cholsol_solve")
+        digests = comm.all_gather_object(hashlib.sha256(mine.numpy().tobytes()).hexdigest())
+        comm.gather_vec_blocks(mine.handle, src.handle if rank == 0 else None, n * k, 0)
+        ok = True
+        if rank == 0:
+            allb = src.numpy().reshape(world, n * k)
+            ok = all(hashlib.sha256(allb[r].tobytes()).hexdigest() == digests[r] for r in range(world))
+        return ok and mine.numpy().tobytes() == X_own.tobytes()
+
+    def sharded_solve():
+        K = k * world - (1 if world > 1 else 0)                   # an uneven last block at N > 1
+        hfull = _csx.new_handle()
+        _csx.check(lib.csx_gen_rhs(n, K, 0, hfull), "gen_rhs")
+        B = cs.dvec(n, K, _handle=hfull)
+        ref = None
+        if rank == 0:
+            R = B.copy()
+            assert F.solve(R)
+            ref = R.numpy().tobytes()
+        assert F.solve(B if rank == 0 else None, comm=comm, nrhs=K)
+        return True if rank != 0 else B.numpy().tobytes() == ref
+
+    def sharded_gaxpy(how):
+        def run():
+            m = 100003                                            # uneven column blocks and row chunks
+            first, count = shard.strong_block(rank, world, m)
+            hFull, hA, hxF, hyR = (_csx.new_handle() for _ in range(4))
+            _csx.check(lib.csx_gen_grand(m, 16, 20240601 + 78, hFull), "gen_grand")
+            _csx.check(lib.csx_csc_col_block(hFull, first, count, hA), "col_block")
+            _csx.check(lib.csx_gen_vec(m, 7, 0.5, 1.5, hxF), "gen_vec")
+            _csx.check(lib.csx_vec_alloc(m, hyR), "vec_alloc")
+            _csx.check(lib.csx_gaxpy(hFull, hxF, hyR, cs.GAXPY_EXACT), "gaxpy exact")
+            yref = np.empty(m)
+            _csx.check(lib.csx_vec_download(hyR, _csx.pd(yref), m), "vec_download")
+            xs = np.empty(m)
+            _csx.check(lib.csx_vec_download(hxF, _csx.pd(xs), m), "vec_download")
+            sg = shard.ShardedGaxpy(comm, hA, m)
+            f, c = sg.rows()
+            y, dx = cs.dvec(sg.chunk), cs.dvec(np.ascontiguousarray(xs[first:first + count]))
+            sg.run(dx.handle, y.handle, how)
+            got, want = y.numpy()[:c], yref[f:f + c]
+            nz = want > 0
+            ok = bool(np.all(got[~nz] == 0) and (not nz.any() or np.max(np.abs(got[nz] - want[nz]) / want[nz]) < 1e-12))
+            sg.free()
+            for h in (hFull, hA, hxF, hyR):
+                _csx.free(h)
+            return ok
+        return run
+
+    leg("factor_broadcast", bcast_factor)
+    leg("rhs_scatter", scatter)
+    leg("solution_gather", gather)
+    leg("sharded_solve_api", sharded_solve)
+    leg("sharded_gaxpy_reduce_scatter", sharded_gaxpy(0))
+    leg("sharded_gaxpy_row_pieces_p2p", sharded_gaxpy(1))
+    res["all_ok"] = all(v.get("ok") for v in res["legs"].values())
+    del res["running"]
+    state.clear()
+    del F, A
+    return res
+
+
+def sharded_spmv_section(args, lib, cs, comm, barrier, max_over_ranks, forms=(0, 1)):
     """ONE n x n G-rand matrix sharded by columns over the ranks (second bullet): rank r owns
     columns [r n/W, (r+1) n/W) and the matching slice of x; y = sum of the ranks' partial products, rank r keeping
     rows [r ceil(n/W), ...).  Both exchange forms of csx_gaxpy_sharded are timed: one SpMV + one RCCL reduce-scatter,
@@ -541,6 +717,8 @@ def sharded_spmv_section(args, lib, cs, comm, barrier, max_over_ranks):
                "scaling": "strong", "rows_owned_per_rank": chunk, "forms": {}}
         steps = min(args.steps, 20)
         for how, name in ((0, "spmv_then_reduce_scatter"), (1, "row_pieces_overlapped_p2p")):
+            if how not in forms:
+                continue
             _csx.check(lib.csx_vec_fill(hy, 0.0), "fill")
             sg.run(hx, hy, how)
             got = np.empty(chunk)
@@ -588,7 +766,7 @@ def hy_scratch(lib, _csx, n):
     return _SCRATCH[n]
 
 
-def cholsol_section(args, lib, cs, comm, hB, nb, bs, barrier, max_over_ranks):
+def cholsol_section(args, lib, cs, comm, hB, nb, bs, barrier, max_over_ranks, preflight=None):
     """Batched cs_cholsol on G-spd: factor once per rank, solve nrhs right-hand sides per GPU."""
     import numpy as np
     import _csx
@@ -685,7 +863,11 @@ def cholsol_section(args, lib, cs, comm, hB, nb, bs, barrier, max_over_ranks):
                            "note": "default order of every plan: bit-identical to cs_lsolve + cs_ltsolve"}}
     if rank == 0 and world == 1 and not args.skip_cpu:
         out["cpu_baseline"] = cpu_baseline_cholsol(args.cpu_chol_blocks, bs, args.cpu_seconds, lnz)
-    if world > 1 or args.force_sharded:
+    bad = [name for name in ("factor_broadcast", "rhs_scatter", "solution_gather")
+           if not ((preflight or {}).get("legs", {}).get(name, {}).get("ok", True))]
+    if bad:
+        out["exchange"] = {"skipped": "failed the exchange preflight at small size: %s" % ", ".join(bad)}
+    elif world > 1 or args.force_sharded:
         try:
             out["exchange"] = exchange_section(args, lib, comm, hL, plan, n, lnz, t_symbolic + t_numeric + t_plan,
                                                barrier, max_over_ranks)

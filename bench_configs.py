@@ -96,6 +96,34 @@ def config2():
             "cpu_baseline": cpu}
 
 
+def w_chain(nb):
+    """SURVEY 8d's W-chain: nb blocks of the drop-tol'd west0067 pattern (values scaled per block as in W) plus
+    A(67 b, 67 b - 1) = 1e-3, which links every block to the one before it: ONE connected matrix, one dependency chain."""
+    import synth
+    gw = np.load(os.path.join(ROOT, "tests", "golden", "west0067.npz"))
+    bp, bi, bx = gw["C_p"].astype(np.int64), gw["C_i"].astype(np.int64), gw["C_x"]
+    bs = 67
+    n = nb * bs
+    u = synth.vec(nb, 20240604, 0.0, 1.0)
+    cols = np.diff(bp)
+    link = np.zeros(bs, np.int64); link[bs - 1] = 1
+    per_block = cols + link
+    Ap = np.concatenate([[0], np.cumsum(np.tile(per_block, nb))]).astype(np.int64)
+    Ap[-1] -= 1                                            # the last block has no next one
+    Ai = np.empty(Ap[-1], np.int64); Ax = np.empty(Ap[-1])
+    for c in range(bs):
+        src = slice(bp[c], bp[c + 1])
+        for_b = Ap[np.arange(nb) * bs + c]
+        k = cols[c]
+        idx = for_b[:, None] + np.arange(k)[None, :]
+        Ai[idx] = bi[src][None, :] + (np.arange(nb) * bs)[:, None]
+        Ax[idx] = bx[src][None, :] * (1.0 + 1e-3 * u)[:, None]
+        if c == bs - 1:
+            Ai[for_b[:-1] + k] = (np.arange(nb - 1) + 1) * bs
+            Ax[for_b[:-1] + k] = 1e-3
+    return n, Ap.astype(np.int32), Ai.astype(np.int32), Ax
+
+
 def config3():
     import c_oracle as CO
     import synth
@@ -215,12 +243,62 @@ def config3():
     rq = CO.gaxpy(n, n, Ap, Ai, Ax, xq, -b)
     qr = {"cs_sqr_host_s": round(t_sqr, 4), "cs_qr_device_s": round(t_qr, 4), "device_path": bool(Nq.L._lazy),
           "solve_64_rhs_s": round(t_qs, 4), "residual_inf": float(np.max(np.abs(rq)))}
+    # ---- batched cs_lusol: factor once (lusol_factor), 1 024 right-hand sides, the whole sequence of csparse.py:1474-1477 on
+    # the device (permute, L, U, permute); every column bit-identical to cs_lusol on that column
+    FL = cs.lusol_factor(A, 0, 1.0)
+    K = 1024
+    Bk = cs.dvec(np.ascontiguousarray(np.repeat(b[:, None], K, axis=1)))
+    FL.solve(Bk)
+    col0 = Bk.numpy().reshape(n, K)[:, 0].copy()
+    Bk = cs.dvec(np.ascontiguousarray(np.repeat(b[:, None], K, axis=1)))
+    ms_b = timed(lambda: FL.solve(Bk), 5)
+    nnz_lu = int(Lp[-1] + Up[-1])
+    by_b = 12 * nnz_lu + 8 * (n + 1) + 2 * 16 * n * K + 2 * 16 * n * K      # two solves and two permutations, X read + written each
+    batched = {"nrhs": K, "ms_per_batch": round(ms_b, 3), "solves_per_s": round(K / (ms_b * 1e-3), 1),
+               "first_column_bit_identical_to_c_oracle": bool(col0.tobytes() == ref_x.tobytes()),
+               "algorithmic_GBps": round(by_b / (ms_b * 1e-3) / 1e9, 1)}
+    del Bk
+    # ---- SURVEY 8d's W-chain: the blocks linked into one dependency chain -- the per-level latency floor of
+    # cs_lsolve / cs_usolve (reported, not tuned for).  Factored by the host loop (the planner keeps a chain there).
+    nc, Cp_, Ci_, Cx_ = w_chain(nb)
+    Ach = cs.cs_pin(host_cs(nc, nc, Cp_, Ci_, Cx_))
+    Nch = cs.cs_lu(Ach, cs.cs_sqr(0, Ach, False), 1.0)
+    Lc, Uc = cs.cs_pin(Nch.L), cs.cs_pin(Nch.U)
+    pbc = np.empty(nc)
+    pbc[np.asarray(Nch.pinv)] = 1.0 + np.arange(nc) / nc
+    cLp, cLi, cLx = (np.asarray(v) for v in (Lc.p, Lc.i, Lc.x))
+    cUp, cUi, cUx = (np.asarray(v) for v in (Uc.p, Uc.i, Uc.x))
+    ref_c = CO.usolve(nc, cUp, cUi, cUx, CO.lsolve(nc, cLp, cLi, cLx, pbc))
+    chain = {"n": nc, "nnz_L_plus_U": int(cLp[-1] + cUp[-1])}
+    for k in (1, 64):
+        Xc = cs.dvec(np.ascontiguousarray(np.repeat(pbc[:, None], k, axis=1)) if k > 1 else pbc)
+        cs.cs_lsolve(Lc, Xc)
+        cs.cs_usolve(Uc, Xc)
+        gotc = Xc.numpy().reshape(nc, -1)
+
+        def run_c():
+            cs.cs_lsolve(Lc, Xc)
+            cs.cs_usolve(Uc, Xc)
+        ms_c = timed(run_c, 5)
+        chain["nrhs_%d" % k] = {"ms_lsolve_plus_usolve": round(ms_c, 3),
+                                "bit_identical_to_c_oracle": bool(all(gotc[:, r].tobytes() == ref_c.tobytes() for r in (0, k - 1)))}
+    lv = {}
+    for nm, M, kind in (("L", Lc, cs.TRI_L), ("U", Uc, cs.TRI_U)):
+        n_, lev, seq = _csx.C.c_int32(), _csx.C.c_int32(), _csx.C.c_int32()
+        _csx.check(_csx.lib().csx_tri_info(M._dev.plans[kind], n_, lev, seq))
+        lv[nm] = lev.value
+    chain["levels"] = lv
+    chain["us_per_level_1_rhs"] = round(chain["nrhs_1"]["ms_lsolve_plus_usolve"] * 1e3 / max(1, lv["L"] + lv["U"]), 3)
+    t0 = time.perf_counter()
+    CO.usolve(nc, cUp, cUi, cUx, CO.lsolve(nc, cLp, cLi, cLx, pbc))
+    chain["plain_c_one_core_ms_1_rhs"] = round((time.perf_counter() - t0) * 1e3, 3)
     # residual of the whole cs_lusol sequence against A
     r = CO.gaxpy(n, n, Ap, Ai, Ax, ref_x, -b)
     return {"config": "cs_lusol solve phase on W (west0067 tiling, n=%d, nnz(A)=%d, nnz(L)+nnz(U)=%d)"
                       % (n, nb * bnnz, int(Lp[-1] + Up[-1])),
             "device_lu_s": round(t_lu, 4), "host_lu_s_one_core": round(t_lu_host, 4), "same_pivots_as_host": bool(same_pivots),
-            "components_of_L": comp.value, "results": res, "spsolve_all_columns": spsolve, "qrsol_on_the_same_system": qr,
+            "components_of_L": comp.value, "results": res, "batched_cs_lusol_factor_once": batched,
+            "W_chain_trisolve_floor": chain, "spsolve_all_columns": spsolve, "qrsol_on_the_same_system": qr,
             "residual_inf": float(np.max(np.abs(r))), "cpu_baseline": cpu}
 
 
@@ -538,28 +616,8 @@ def lu_connected(grid=300, chain_blocks=1493):
             r["pinv_and_L_values_bit_identical_to_host"] = bool((dev[1][0] == pinv_h).all() and dev[1][2].tobytes() == Lx_h.tobytes())
     out["unsymmetric_grid_%dx%d_order_2" % (g, g)] = r
     # W-chain
-    gw = np.load(os.path.join(ROOT, "tests", "golden", "west0067.npz"))
-    bp, bi, bx = gw["C_p"].astype(np.int64), gw["C_i"].astype(np.int64), gw["C_x"]
-    nb, bs = chain_blocks, 67
-    n = nb * bs
-    u = synth.vec(nb, 20240604, 0.0, 1.0)
-    cols = np.diff(bp)
-    link = np.zeros(bs, np.int64); link[bs - 1] = 1
-    per_block = cols + link
-    Ap = np.concatenate([[0], np.cumsum(np.tile(per_block, nb))]).astype(np.int64)
-    Ap[-1] -= 1                                            # the last block has no next one
-    Ai = np.empty(Ap[-1], np.int64); Ax = np.empty(Ap[-1])
-    for c in range(bs):
-        src = slice(bp[c], bp[c + 1])
-        for_b = Ap[np.arange(nb) * bs + c]
-        k = cols[c]
-        idx = for_b[:, None] + np.arange(k)[None, :]
-        Ai[idx] = bi[src][None, :] + (np.arange(nb) * bs)[:, None]
-        Ax[idx] = bx[src][None, :] * (1.0 + 1e-3 * u)[:, None]
-        if c == bs - 1:
-            Ai[for_b[:-1] + k] = (np.arange(nb - 1) + 1) * bs
-            Ax[for_b[:-1] + k] = 1e-3
-    Ap32, Ai32 = Ap.astype(np.int32), Ai.astype(np.int32)
+    nb = chain_blocks
+    n, Ap32, Ai32, Ax = w_chain(nb)
     r = {"n": n, "nnz": int(Ap32[-1]), "blocks": nb}
     auto = device_lu(Ap32, Ai32, Ax, 1.0, False)
     r["planner_keeps_it_on_the_host"] = auto is None

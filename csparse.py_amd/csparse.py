@@ -1059,13 +1059,18 @@ def cs_cholsol(order, A, b):
     return True
 
 
-def cholsol_factor(A, order=0, exact=True):
+def cholsol_factor(A, order=0, exact=None):
     """Factor once for many solves: returns a solver `solve(b)` where b is a list or a
     dvec n-by-k block (overwritten).  The batched form of cs_cholsol (csparse.py:622-644).
-    exact=True (default): every solve is bit-identical to cs_lsolve + cs_ltsolve on the same L.
-    exact=False: equal to rounding (within the 1e-10 budget) and faster -- dense blocks go to the matrix cores
-    (blocked TRSM with explicit tile inverses, refused when an inverse is large), and the level-scheduled solve
-    of a big elimination tree may reorder a row's subtractions (out-of-block terms first)."""
+    The order of a solve's operations:
+    exact=None (default): by the kind of right-hand side.  A LIST -- the reference's data model, the drop-in contract --
+      is solved with the reference's operations in the reference's order: bit-identical to cs_lsolve + cs_ltsolve on
+      the same L.  A dvec BLOCK -- the caller has left the reference's data model for the batched one -- is solved in the
+      rounding-equal order, inside the 1e-10 that BASELINE.json's north_star grants x[]: dense blocks go to the matrix
+      cores (blocked TRSM with explicit tile inverses, refused when an inverse is large), a big elimination tree to the
+      supernodal schedule.  (G-spd, 128 right-hand sides: 2.4 ms against 4.8; bcsstk16: 0.4 ms against 6.6.)
+    exact=True: every solve, blocks too, bit-identical to the reference's order.   exact=False: every solve rounding-equal.
+    cs_cholsol, the reference's own driver, is always exact."""
     S = cs_schol(order, A, _arrays=True)
     N = cs_chol(A, S) if S is not None else None
     if N is None:
@@ -1085,7 +1090,7 @@ def cholsol_factor(A, order=0, exact=True):
     def _build():
         h = _csx.new_handle()
         _csx.check(_csx.lib().csx_cholsol_plan(dev.handle, _csx.pi(pinv), h), "csx_cholsol_plan")
-        if not exact:
+        if exact is False:
             _csx.check(_csx.lib().csx_cholsol_set_order(h, 0), "csx_cholsol_set_order")
         return h
 
@@ -1097,6 +1102,7 @@ def cholsol_factor(A, order=0, exact=True):
             self._dev = dev                      # keeps the device factor alive (see above)
             self._built = dev.version
             self.plan_handle = _build()
+            self._exact_now = exact is not False     # the order the plan is in
             self._box = [self.plan_handle]
             self._fin = weakref.finalize(self, lambda box: _csx.free(box[0]), self._box)
 
@@ -1106,8 +1112,19 @@ def cholsol_factor(A, order=0, exact=True):
             if self._built != dev.version:
                 _csx.free(self.plan_handle)
                 self.plan_handle = self._box[0] = _build()
+                self._exact_now = exact is not False
                 self._built = dev.version
             return self.plan_handle
+
+        def _plan_for(self, block):
+            """The plan in the order this right-hand side is solved in (see cholsol_factor): switching is a flag; the
+            rounding-equal order's operands (tile inverses, supernodal schedule) are built the first time it is asked for."""
+            h = self._current()
+            want_exact = exact if exact is not None else not block
+            if want_exact != self._exact_now:
+                _csx.check(_csx.lib().csx_cholsol_set_order(h, 1 if want_exact else 0), "csx_cholsol_set_order")
+                self._exact_now = want_exact
+            return h
 
         def info(self):
             a, b, c = _csx.C.c_int32(), _csx.C.c_int32(), _csx.C.c_int32()
@@ -1126,12 +1143,13 @@ def cholsol_factor(A, order=0, exact=True):
             if comm is not None and comm.world > 1:
                 return self._solve_sharded(b, comm, nrhs)
             db, bhost = _vec_in(b, n, "b")
-            _csx.check(_csx.lib().csx_cholsol_solve(self._current(), db.handle, db.k), "csx_cholsol_solve")
+            _csx.check(_csx.lib().csx_cholsol_solve(self._plan_for(isinstance(b, dvec)), db.handle, db.k), "csx_cholsol_solve")
             _write_back(bhost, db, n * db.k)
             return True
 
         def _solve_sharded(self, b, comm, nrhs):
-            plan = self._current()
+            # every rank solves in the order the ROOT's right-hand side asks for
+            plan = self._plan_for(comm.broadcast_object(isinstance(b, dvec) if comm.rank == 0 else None, 0))
 
             def block(mine):
                 _csx.check(_csx.lib().csx_cholsol_solve(plan, mine.handle, mine.k), "csx_cholsol_solve")

@@ -992,6 +992,8 @@ struct CholPlan {
     int32_t g_nrhs = 0;
     int64_t g_gen = -1;                // the work-space generation of the supernodal plan the capture saw
     int g_opt = -1;                    // "tri.supernodes" at capture time: sn_solve picks its kernels by it
+    double *last_X = nullptr;          // the block of the solve before this one ("tri.graph" = 2 captures on the second
+    int32_t last_nrhs = 0;             // consecutive solve of the same block, not for a block it sees once)
     int32_t n = 0;
     const Csc *L = nullptr;  // not owned; must outlive the plan
     TriPlan *fwd = nullptr, *bwd = nullptr;
@@ -2282,7 +2284,19 @@ static int cholsol_solve(CholPlan *P, double *B, int32_t nrhs) {
     }
     if (P->relaxed && P->sn && ctx().opt.tri_supernodes && sn_usable(P->sn)) {
         CSX_TRY(tri_solve_raw(P->fwd, X, 0, false));          // a zero pivot found by the analysis: ZeroDivisionError
-        if (ctx().opt.tri_graph) {
+        // "tri.graph": 1 = always; 2 (the default) = when a solve is many launches -- more than 256: a natural-order grid
+        // factor is 5 624 -- and this block was also the previous solve's (a capture costs about as much as the launches it
+        // replaces: it pays from the second replay on); 0 = never.  The replay takes the host 13 - 60 us instead of 0.35 -
+        // 17 ms; the device time is the same.
+        bool graph = ctx().opt.tri_graph == 1;
+        if (ctx().opt.tri_graph == 2) {
+            int32_t nsn = 0, steps = 0, maxw = 0;
+            sn_info(P->sn, &nsn, &steps, &maxw);
+            graph = 6 * (int64_t)steps > 256 && P->last_X == X && P->last_nrhs == nrhs;
+        }
+        P->last_X = X;
+        P->last_nrhs = nrhs;
+        if (graph) {
             // the two sweeps' launches as one graph, re-used while the block of right-hand sides stays where it is
             CSX_TRY(sn_prepare(P->sn, nrhs));              // (may move the work space: the captured launches hold its address)
             if (!(P->g_exec && P->g_X == X && P->g_nrhs == nrhs && P->g_gen == sn_generation(P->sn) &&

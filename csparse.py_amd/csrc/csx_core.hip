@@ -549,7 +549,7 @@ const OptSlot kOptSlots[] = {
     {"tri.row_waves", &Options::tri_row_waves, 0},       {"tri.push", &Options::tri_push, 0},
     {"tri.levels_where", &Options::tri_levels_where, 3}, {"tri.supernodes", &Options::tri_supernodes, 5},
     {"spgemm.ordered", &Options::spgemm_ordered, 0},     {"spgemm.chunks", &Options::spgemm_chunks, 4},
-    {"lu.etree", &Options::lu_etree, 5},                 {"tri.graph", &Options::tri_graph, 0},
+    {"lu.etree", &Options::lu_etree, 5},                 {"tri.graph", &Options::tri_graph, 6},
     {"sort.short_keys", &Options::sort_short_keys, 0},   {"chol.clique", &Options::chol_clique, 0},
                     {"cholsol.exact_variant", &Options::cholsol_exact_variant, 4},
 };
@@ -561,6 +561,7 @@ int normalise(int kind, int value) {
     case 3: return (value == 1 || value == 2) ? value : 0;
     case 4: return value < 0 ? 0 : (value > 64 ? 64 : value);
     case 5: return (value == 0 || value == 2) ? value : 1;
+    case 6: return (value == 0 || value == 1) ? value : 2;
     }
     return value;
 }

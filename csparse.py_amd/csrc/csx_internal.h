@@ -138,15 +138,19 @@ struct Options {
     int tri_row_waves = 1;        // level-scheduled solves: a wave per row for few right-hand sides and long rows
     int tri_levels_where = 0;         // level analysis: 0 = device for big factors, host for small; 1 = host; 2 = device
     int sort_short_keys = 1;          // cs_transpose: 16-bit keys between the radix passes where the matrix allows (0: always 32-bit)
-    int tri_graph = 0;                // supernodal solves: replay the launches of a solve as a hipGraph while the block of right-hand sides stays in place
+    int tri_graph = 2;                // supernodal solves: replay the launches of a solve as a hipGraph while the block of right-hand
+                                      // sides stays in place: 0 never, 1 always, 2 when a solve is more than 256 launches and the
+                                      // block is the previous solve's too
     int tri_supernodes = 1;           // cholsol: supernodal forward / backward solves on factors with supernodes (0 never, 1 yes,
                                       // 2 yes but the triangles by substitution out of LDS instead of on the matrix cores)
     int spgemm_ordered = 0;           // cs_multiply: sum every entry's products in the reference's order (bit-identical x)
     int spgemm_chunks = 1;            // cs_multiply: column chunks whose compaction overlaps the next chunk's hashing on a second stream
                                       // (1 = off, the default: measured slower, profiles/r03_ablation.md section 2)
     int cholsol_exact_variant = 0;    // exact dense-block cholsol: 0 = the measured choice per block size, 1 - 6 force a variant (tests, ablation)
-    int lu_etree = 1;                 // cs_lu of one connected matrix on the device, columns scheduled by the column etree
-                                      // (0 never, 1 when the tree is shallow enough for its size, 2 always)
+    int lu_etree = 0;                 // cs_lu of one connected matrix on the device, columns scheduled by the column etree:
+                                      // 0 never (the default since round 4: measured at best a tie with one host core, on the
+                                      // shape it was made for -- profiles/r04_ablation.md), 1 for shallow trees with short
+                                      // columns, 2 always (tests: L, U, pinv bit-identical to the host loop and the oracle)
 };
 
 struct Context {

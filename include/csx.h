@@ -81,15 +81,19 @@ int csx_mem_info(int64_t *cached_bytes, int64_t *live_bytes, int64_t *device_fre
  * launches per step instead of one); "chol.supernodes" (default 1); "pool.limit_mb" (cap of the device-memory cache in MB,
  * 0 = the default quarter of the device).  Round 3: "tri.supernodes" (supernodal schedule of a cholsol plan in the
  * rounding-equal order: 1 = yes, triangles on the matrix cores where their guard allows (default); 2 = yes, triangles by
- * substitution out of LDS, no relaxed supernodes; 0 = never), "tri.graph" (default 0; 1 = the launches of a supernodal
- * solve are captured into a hipGraph and replayed while the block of right-hand sides stays in place),
+ * substitution out of LDS, no relaxed supernodes; 0 = never), "tri.graph" (the launches of a supernodal solve captured
+ * into a hipGraph and replayed while the block of right-hand sides stays in place: 2 (default since round 4) = when a
+ * solve is more than 256 launches and the block is also the previous solve's, 1 = always, 0 = never),
  * "cholsol.exact_variant" (the exact dense-block kernel: 0 = default = 5: L values by DPP row broadcast, one term in four
  * by an LDS broadcast read; 6: by DPP only; 1 - 4: the LDS-broadcast forms), "spgemm.ordered" (default 0; 1 = cs_multiply
  * sums every entry's products in the reference's order: bit-identical values, about twenty times the time),
  * "spgemm.chunks" (default 1; >= 2: hash and compaction of column chunks on two streams -- measured slower),
  * "sort.short_keys" (default 1: a transpose with values carries 16-bit keys between its radix passes where the matrix allows),
- * "lu.etree" (cs_lu inside one connected matrix by levels of the column elimination tree: 1 = where the planner expects
- * a gain (default), 2 = always, 0 = never).  Unknown name: CSX_EINVAL. */
+ * "lu.etree" (cs_lu inside one connected matrix by levels of the column elimination tree: 0 = never (default since round
+ * 4: at best a tie with one host core), 1 = shallow trees with short columns, 2 = always).  Round 4:
+ * "chol.clique" (default 1: csx_schol / csx_chol / csx_cholsol_plan recognise forests of cliques on consecutive columns
+ * -- block-diagonal matrices with dense blocks -- from the matrix itself and skip the general pattern machine; 0 = the
+ * general path).  Unknown name: CSX_EINVAL. */
 int csx_set_option(const char *name, int value);
 int csx_get_option(const char *name, int *value);   /* the value in force (after csx_set_option's normalisation) */
 int csx_timer_start(void);                /* hipEvent on the context's stream */
@@ -179,8 +183,10 @@ int csx_permute_vec(csx_handle_t p, csx_handle_t b, csx_handle_t x, int32_t n, i
 /* cs_schol (natural order), csparse.py:2051-2072: host C++ symbolic analysis of
  * the upper triangle of a host CSC pattern.  parent[n], cp[n+1]. */
 int csx_schol_host(int32_t n, const int32_t *Ap, const int32_t *Ai, int32_t *parent, int32_t *cp);
-/* The same for a device-resident square matrix: elimination tree on the host, column counts of L on the
- * device (the row-subtree walks of csx_chol).  parent[n] and cp[n+1] are host arrays. */
+/* The same for a device-resident square matrix.  A forest of cliques on consecutive columns (block-diagonal with dense
+ * blocks; recognised in one pass over A's pattern from the smallest upper row of every column): tree and counts on the
+ * device, no pattern of L formed.  Otherwise: elimination tree on the device for many small components, else on the
+ * host; column counts of L on the device (the row-subtree walks of csx_chol).  parent[n] and cp[n+1] are host arrays. */
 int csx_schol(csx_handle_t A, int32_t *parent, int32_t *cp);
 
 /* A fill-reducing ordering for order = 1 (Cholesky; the reference's cs_amd, csparse.py:214-556, does not
@@ -190,8 +196,8 @@ int csx_schol(csx_handle_t A, int32_t *parent, int32_t *cp);
 int csx_order_nd_host(int32_t n, const int32_t *Ap, const int32_t *Ai, int32_t *perm);
 
 /* cs_chol numeric, csparse.py:561-619.  A: device CSC (upper triangle used);
- * parent/cp: host arrays from csx_schol_host; pinv: host permutation or NULL.
- * Output L (device CSC, diagonal first, rows ascending). */
+ * parent/cp: host arrays from csx_schol / csx_schol_host; pinv: host permutation or NULL.
+ * Output L (device CSC, diagonal first, rows ascending).  CSX_EINVAL when parent / cp are not A's. */
 int csx_chol(csx_handle_t A, const int32_t *parent, const int32_t *cp, const int32_t *pinv,
              csx_handle_t *L);
 /* What the last successful csx_chol of this process did.  *path: 1 = A's elimination forest is a set of cliques on
@@ -203,7 +209,9 @@ int csx_chol(csx_handle_t A, const int32_t *parent, const int32_t *cp, const int
 int csx_chol_info(int32_t *path, double *numeric_ms);
 
 /* The solve phase of cs_cholsol, csparse.py:640-643, for nrhs right-hand sides:
- * B (n-by-nrhs, row-major) is overwritten with the solutions. */
+ * B (n-by-nrhs, row-major) is overwritten with the solutions.  The plan of a factor that is a forest of equal dense
+ * blocks of 8 / 16 / 32 / 64 columns (recognised from L itself, also from an L that came over the wire or from the host)
+ * is cut straight out of L.x; any other factor gets two triangular-solve analyses and the forest partition. */
 int csx_cholsol_plan(csx_handle_t L, const int32_t *pinv /* host, or NULL */, csx_handle_t *plan);
 /* *path, for the plan's current order (csx_cholsol_set_order): 0 = level-scheduled generic, 1 = fused per-tree
  * kernel (X tile in LDS; the only forest path of the default, exact order), 2 = dense-block FMA substitution,

@@ -170,7 +170,7 @@ def test_plan_cut_straight_out_of_the_factor(cs, bs):
     Ap, Ai, Ax = synth.gspd(nblocks, bs, 99)
     n = nblocks * bs
     A = cs.cs_pin(_host_cs(cs, n, n, Ap, Ai, Ax))
-    F = cs.cholsol_factor(A)
+    F = cs.cholsol_factor(A, exact=True)
     assert F.info() == {"fused_local": True, "dense_block": bs, "matrix_cores": False, "trees": nblocks, "max_nodes": bs}
     gLp, gLi, gLx = _arr(F.L)
     B = synth.rhs(n, k, 0)
@@ -185,7 +185,7 @@ def test_plan_cut_straight_out_of_the_factor(cs, bs):
         assert F.solve(dB1) is True
         assert dB1.numpy().tobytes() == X.tobytes()
     with _csx.option("chol.clique", 0):              # the general plan (two triangular analyses, host partition)
-        F0 = cs.cholsol_factor(A)
+        F0 = cs.cholsol_factor(A, exact=True)
         assert F0.info() == F.info()
         dB0 = cs.dvec(B)
         assert F0.solve(dB0) is True
@@ -217,3 +217,35 @@ def test_plan_cut_straight_out_of_the_factor(cs, bs):
     _csx.check(_csx.lib().csx_cholsol_plan(L3._dev.handle, None, plan))
     assert _csx.lib().csx_cholsol_solve(plan, cs.dvec(B).handle, k) == _csx.EZEROPIVOT
     _csx.free(plan)
+
+
+def test_default_order_follows_the_kind_of_right_hand_side(cs):
+    """cholsol_factor(A) with exact=None: a list is solved in the reference's order (the reference's bits), a dvec block
+    in the rounding-equal order (matrix cores here; inside 1e-10, not the same bits); exact=True / False pin one order."""
+    nblocks, bs, k = 20, 32, 70
+    Ap, Ai, Ax = synth.gspd(nblocks, bs, 4)
+    n = nblocks * bs
+    A = cs.cs_pin(_host_cs(cs, n, n, Ap, Ai, Ax))
+    F = cs.cholsol_factor(A)
+    gLp, gLi, gLx = _arr(F.L)
+    B = synth.rhs(n, k, 0)
+    ref0 = CO.ltsolve(n, gLp, gLi, gLx, CO.lsolve(n, gLp, gLi, gLx, B[:, 0]))
+    b = B[:, 0].tolist()
+    assert F.solve(b) is True and np.asarray(b).tobytes() == ref0.tobytes()
+    assert F.info()["matrix_cores"] is False
+    dB = cs.dvec(B)
+    assert F.solve(dB) is True
+    assert F.info()["matrix_cores"] is True                                  # the block went to the rounding-equal order
+    X = dB.numpy()
+    assert X[:, 0].tobytes() != ref0.tobytes() and np.max(np.abs(X[:, 0] - ref0) / np.abs(ref0)) < 1e-13
+    b = B[:, 0].tolist()                                                      # and a list after it is exact again
+    assert F.solve(b) is True and np.asarray(b).tobytes() == ref0.tobytes()
+    Fe = cs.cholsol_factor(A, exact=True)
+    dE = cs.dvec(B)
+    assert Fe.solve(dE) is True and dE.numpy()[:, 0].tobytes() == ref0.tobytes()
+    Fr = cs.cholsol_factor(A, exact=False)
+    b = B[:, 0].tolist()
+    assert Fr.solve(b) is True and np.asarray(b).tobytes() != ref0.tobytes()
+    assert np.max(np.abs(np.asarray(b) - ref0) / np.abs(ref0)) < 1e-13
+    b = B[:, 0].tolist()                                                      # the reference's own driver: always exact
+    assert cs.cs_cholsol(0, A, b) is True and np.asarray(b).tobytes() == ref0.tobytes()

@@ -121,7 +121,7 @@ def test_gspd_factor_and_batched_solve(cs, nblocks, bs, k):
     Ap, Ai, Ax = synth.gspd(nblocks, bs, 20240606)
     n = nblocks * bs
     A = cs.cs_pin(_host_cs(cs, n, n, Ap, Ai, Ax))
-    F = cs.cholsol_factor(A)                      # exact=True is the default
+    F = cs.cholsol_factor(A, exact=True)          # every solve in the reference order (the default gives that to lists only)
     assert F.info() == {"fused_local": True, "dense_block": bs, "matrix_cores": False, "trees": nblocks,
                         "max_nodes": bs}
     parent, cp = CO.schol(n, Ap, Ai)
@@ -233,7 +233,7 @@ def test_forest_of_sparse_trees_uses_generic_fused_kernel(cs):
     Ai = np.concatenate(cols_i).astype(np.int32)
     Ax = np.concatenate(cols_x)
     A = cs.cs_pin(_host_cs(cs, n, n, Ap, Ai, Ax))
-    F = cs.cholsol_factor(A)
+    F = cs.cholsol_factor(A, exact=True)
     info = F.info()
     assert info["fused_local"] and info["dense_block"] == 0 and info["trees"] == nb
     parent, cp = CO.schol(n, Ap, Ai)
@@ -310,7 +310,7 @@ def test_relaxed_order_on_a_chain_like_factor(cs):
     C = cs.cs_pin(unpack(cs, g, "C"))
     n, k = C.n, 7
     B = synth.rhs(n, k, 0)
-    Fe, Fr = cs.cholsol_factor(C), cs.cholsol_factor(C, exact=False)
+    Fe, Fr = cs.cholsol_factor(C, exact=True), cs.cholsol_factor(C, exact=False)
     Xe, Xr = cs.dvec(B), cs.dvec(B)
     assert Fe.solve(Xe) and Fr.solve(Xr)
     Xe, Xr = Xe.numpy(), Xr.numpy()
@@ -339,7 +339,7 @@ def test_cholsol_with_the_fill_reducing_ordering(cs, name):
     assert np.max(np.abs(x1 - x0)) <= 1e-9 * np.max(np.abs(x0))
     # batched, device-resident
     cs.cs_pin(C)
-    F = cs.cholsol_factor(C, order=1)
+    F = cs.cholsol_factor(C, order=1, exact=True)
     B = np.stack([g["b"], 3.0 * g["b"]], axis=1)
     dB = cs.dvec(B)
     assert F.solve(dB) is True
@@ -589,7 +589,7 @@ def test_solver_keeps_its_factor_alive_and_follows_updown(cs):
     C = cs.cs_pin(unpack(cs, g, "C"))
     n = C.n
     with _csx.option("pool.limit_mb", 64):           # a small cache: freed blocks go back to the driver / get reused at once
-        F = cs.cholsol_factor(C)
+        F = cs.cholsol_factor(C, exact=True)
         Lp, Li, Lx = np.asarray(F.L.p, np.int32), np.asarray(F.L.i, np.int32), np.asarray(F.L.x)   # materialises L
         lnz = int(Lp[n])
         assert F.L._dev is not None                  # the factor stays on the device
@@ -665,7 +665,7 @@ def test_supernodal_solves_in_the_rounding_equal_order(cs, case):
     path = _csx.C.c_int32(-1)
     _csx.check(_csx.lib().csx_cholsol_info(Fr.plan_handle, path, None, None))
     assert path.value == 4                                            # the supernodal schedule is in charge
-    Fe = cs.cholsol_factor(A, order=order)
+    Fe = cs.cholsol_factor(A, order=order, exact=True)
     Lp, Li, Lx = _arr(Fr.L)
     pinv = np.asarray(Fr.symbolic.pinv) if Fr.symbolic.pinv is not None else np.arange(n)
     for k in (1, 3, 64, 70):
@@ -758,6 +758,35 @@ def test_supernodal_solve_replayed_as_a_graph_gives_the_same_bits(cs):
         assert F.solve(Y)
     assert Y.numpy().tobytes() == X0.numpy().tobytes()
     assert X2.numpy().reshape(n, 3).tobytes() == X0.numpy().reshape(n, 5)[:, :3].copy().tobytes()
+
+
+def test_long_supernodal_solves_are_replayed_as_a_graph_by_default(cs):
+    """"tri.graph" = 2, the default: a solve of more than 256 launches (a natural-order grid factor: a chain of relaxed
+    supernodes, two or three launches per step) is captured when the SAME block comes a second time in a row and replayed
+    from then on; a block seen once is launched directly.  The bits do not depend on any of it."""
+    import _csx
+    n, p, i, x = _grid_laplacian(150, 150)
+    A = cs.cs_spalloc(n, n, len(i), True, False)
+    A.p, A.i, A.x = p.tolist(), i.tolist(), x.tolist()
+    cs.cs_pin(A)
+    F = cs.cholsol_factor(A, order=0, exact=False)
+    steps = _csx.C.c_int32(-1)
+    _csx.check(_csx.lib().csx_cholsol_sn_info(F.plan_handle, None, steps, None, None, None))
+    assert 6 * steps.value > 256
+    B = synth.rhs(n, 3, 4)
+    with _csx.option("tri.graph", 0):
+        X0 = cs.dvec(B)
+        assert F.solve(X0)
+    ref = X0.numpy().tobytes()
+    X = cs.dvec(B)
+    for rep in range(4):            # direct, then captured, then replayed twice
+        X.assign(B)
+        assert F.solve(X)
+        assert X.numpy().tobytes() == ref, rep
+    other = cs.dvec(B)              # another block in between: launched directly, the capture survives for X
+    assert F.solve(other) and other.numpy().tobytes() == ref
+    X.assign(B)
+    assert F.solve(X) and X.numpy().tobytes() == ref
 
 
 @pytest.mark.parametrize("strength, cores", [(0.3, 1), (0.9, 0)])
@@ -858,7 +887,7 @@ def test_exact_dense_block_kernel_variants_all_have_the_reference_bits(cs, bs):
     n = nblocks * bs
     Ap, Ai, Ax = synth.gspd(nblocks, bs, 11)
     A = cs.cs_pin(_host_cs(cs, n, n, Ap, Ai, Ax))
-    F = cs.cholsol_factor(A)
+    F = cs.cholsol_factor(A, exact=True)
     assert F.info()["dense_block"] == bs
     parent, cp = CO.schol(n, Ap, Ai)
     Lp, Li, Lx = CO.chol(n, Ap, Ai, Ax, parent, cp)

@@ -83,7 +83,7 @@ TWO_RANKS = HEAD + textwrap.dedent("""
     Ap, Ai, Ax = synth.gspd(nb, bs, 5)
     A = cs.cs_spalloc(n, n, len(Ai), True, False)
     A.p, A.i, A.x = Ap.tolist(), Ai.tolist(), Ax.tolist()
-    F = cs.cholsol_factor(cs.cs_pin(A))                  # every rank factors the same matrix
+    F = cs.cholsol_factor(cs.cs_pin(A), exact=True)                  # every rank factors the same matrix
     B = synth.rhs(n, K, 0)
     dB = cs.dvec(B) if rank == 0 else None
     assert F.solve(dB, comm=comm, nrhs=K)

@@ -104,8 +104,10 @@ def test_w_chain_factors_on_the_device_bit_identical_to_the_host_loop(cs, tol):
     import _csx
     n, Ap, Ai, Ax = _w_chain(60, cs)
     # the links make the column elimination tree nearly a chain (one level per column of a block, block after block):
-    # the planner hands such a matrix to the host loop ...
+    # the planner ("lu.etree" = 1; the default since round 4 is 0 = never) hands such a matrix to the host loop ...
     assert _device_lu(Ap, Ai, Ax, tol) == "host"
+    with _csx.option("lu.etree", 1):
+        assert _device_lu(Ap, Ai, Ax, tol) == "host"
     # ... and when told to take it anyway the device gives the host loop's factors bit for bit
     with _csx.option("lu.etree", 2):
         dev = _device_lu(Ap, Ai, Ax, tol)
@@ -120,12 +122,14 @@ def test_unsymmetric_grid_in_a_dissection_order(cs, tol):
     bit for bit; the drop-in cs_lu / cs_lusol with order 2 give the same factors and a solution with a tiny residual."""
     import _csx
     n, Ap, Ai, Ax = _unsym_grid(70)
-    assert _device_lu(Ap, Ai, Ax, tol) == "host"                          # natural order: a chain
+    with _csx.option("lu.etree", 1):
+        assert _device_lu(Ap, Ai, Ax, tol) == "host"                      # natural order: a chain
     A = _host_cs(cs, n, n, Ap, Ai, Ax)
     S = cs.cs_sqr(2, A, False)
     AQ = cs.cs_permute(A, None, S.q, True)
     Qp, Qi, Qx = np.asarray(AQ.p, np.int32), np.asarray(AQ.i[:AQ.p[n]], np.int32), np.asarray(AQ.x[:AQ.p[n]])
-    assert _device_lu(Qp, Qi, Qx, tol) == "host"                          # long reaches at the top of the tree
+    with _csx.option("lu.etree", 1):
+        assert _device_lu(Qp, Qi, Qx, tol) == "host"                      # long reaches at the top of the tree
     with _csx.option("lu.etree", 2):
         dev = _device_lu(Qp, Qi, Qx, tol)
     _same(dev, _host_lu(n, Qp, Qi, Qx, tol))
@@ -170,12 +174,19 @@ def _bordered_blocks(nblocks, seed=4):
 
 @pytest.mark.parametrize("tol", [1.0, 0.01])
 def test_bordered_blocks_factor_on_the_device_by_the_planners_own_choice(cs, tol):
+    """"lu.etree" = 1: shallow trees with short columns go to the device.  (Not the default: on this very shape the device
+    ties with one host core at 4 000 blocks and loses below -- tools/time_lu_bordered.py, profiles/r04_ablation.md --, so
+    since round 4 a connected cs_lu is a host component unless asked for.)"""
+    import _csx
     n, Ap, Ai, Ax = _bordered_blocks(40)
-    dev = _device_lu(Ap, Ai, Ax, tol)
-    _same(dev, _host_lu(n, Ap, Ai, Ax, tol))
+    assert _device_lu(Ap, Ai, Ax, tol) == "host"                           # the default: never
+    with _csx.option("lu.etree", 1):
+        dev = _device_lu(Ap, Ai, Ax, tol)
+        _same(dev, _host_lu(n, Ap, Ai, Ax, tol))
+        A = cs.cs_pin(_host_cs(cs, n, n, Ap, Ai, Ax))
+        N = cs.cs_lu(A, cs.cs_sqr(0, A, False), tol)                       # the drop-in takes the same path
+        assert N.L._lazy and N.pinv == dev[6].tolist() and N.L.x[:N.L.p[n]] == dev[2].tolist()
     A = cs.cs_pin(_host_cs(cs, n, n, Ap, Ai, Ax))
-    N = cs.cs_lu(A, cs.cs_sqr(0, A, False), tol)                           # the drop-in takes the same path
-    assert N.L._lazy and N.pinv == dev[6].tolist() and N.L.x[:N.L.p[n]] == dev[2].tolist()
     b = [1.0 + i / n for i in range(n)]
     x = list(b)
     assert cs.cs_lusol(0, A, x, tol) is True

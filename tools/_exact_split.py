@@ -17,7 +17,7 @@ for g in (0, 300, 700):
         M = cs.cs_spalloc(n, n, A.nnz, True, False)
         M.p, M.i, M.x = A.indptr.tolist(), A.indices.tolist(), A.data.tolist()
         cs.cs_pin(M)
-    F = cs.cholsol_factor(M, 1)
+    F = cs.cholsol_factor(M, 1, exact=True)
     L = F.L
     for k in (1, 64):
         B = cs.dvec(np.ones((n, k)) if k > 1 else np.ones(n))
