@@ -1193,9 +1193,163 @@ __global__ __launch_bounds__(64) void k_sg_values_ordered(int32_t n, int32_t m, 
     }
 }
 
-__global__ void k_sg_any_long(int32_t n, const int32_t *__restrict__ Cp, int *flag) {
+// ---- the same for columns of at most 2 048 entries, round 4 -------------------------------------------------------------
+// The kernel above takes 250 ms on S (1M columns of ~990 entries): 48 KB of LDS per wave leave three waves to a CU, every
+// batch of products pays its own memory round trip, and the test for equal rows inside a batch -- 63 readlanes -- runs for
+// every batch although a column of A almost never holds a row twice.  Here: (1) whether a column of A holds a row twice
+// inside one of its batches of 64 is found ONCE per column of A (k_sg_dup_cols); batches of clean columns update their 64
+// sums at once; (2) the table is sized to the column (512 / 2 048 / 4 096 slots for up to 256 / 1 024 / 2 048 entries: 7 / 27 /
+// 54 KB per wave), sums are kept per SLOT, so no position array; (3) a wave keeps its column of B in registers (entry l in
+// lane l), requests the A columns of eight entries together and looks up their slots side by side before the updates,
+// which go in order.  S: 250 -> 42 ms for the pass (cs_multiply with "spgemm.ordered": 265 -> 57 ms).  Same operation order per entry of C, so still bit-identical to the reference.
+__global__ __launch_bounds__(256) void k_sg_dup_cols(int32_t nA, int nbits, const int32_t *__restrict__ Ap,
+                                                     const int32_t *__restrict__ Ai, uint8_t *__restrict__ dup) {
+    const int lane = threadIdx.x & 63;
+    const int64_t k = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (k >= nA) return;
+    bool any = false;
+    for (int32_t a0 = Ap[k]; a0 < Ap[k + 1]; a0 += 64) {
+        const bool active = a0 + lane < Ap[k + 1];
+        const uint32_t row = active ? (uint32_t)Ai[a0 + lane] : 0u;
+        unsigned long long peers = __ballot(active);
+        for (int b = 0; b < nbits; b++) {
+            const unsigned long long bal = __ballot((row >> b) & 1u);
+            peers &= ((row >> b) & 1u) ? bal : ~bal;
+        }
+        if (active && __popcll(peers) > 1) any = true;
+    }
+    if (lane == 0) dup[k] = 0;
+    if (__ballot(any) != 0ull && lane == 0) dup[k] = 1;
+}
+
+// slot of a row in a table of SLOTS entries (any size: the high half of a 32 x 32 bit product)
+template <int SLOTS>
+__device__ __forceinline__ uint32_t sgo_slot(int32_t row) {
+    return __umulhi((uint32_t)row * 0x9E3779B1u, (uint32_t)SLOTS);
+}
+
+template <int SLOTS, int MAXCNT>
+__global__ __launch_bounds__(64) void k_sg_values_ordered2(int32_t n, int32_t lo_cnt, const int32_t *__restrict__ Ap,
+                                                           const int32_t *__restrict__ Ai, const double *__restrict__ Ax,
+                                                           const uint8_t *__restrict__ dupA, const int32_t *__restrict__ Bp,
+                                                           const int32_t *__restrict__ Bi, const double *__restrict__ Bx,
+                                                           const int32_t *__restrict__ Cp, const int32_t *__restrict__ Ci,
+                                                           double *__restrict__ Cx) {
+#pragma clang fp contract(off)
+    constexpr int G = 8;   // entries of B whose A columns are requested together
+    __shared__ int32_t hkey[SLOTS];
+    __shared__ double acc[SLOTS];
+    __shared__ uint16_t slotq[MAXCNT];
+    __shared__ unsigned long long seen[(SLOTS + 63) / 64];
+    const int lane = threadIdx.x;
+    for (int32_t j = blockIdx.x; j < n; j += gridDim.x) {
+        const int32_t c0 = Cp[j], cnt = Cp[j + 1] - c0;
+        if (cnt <= lo_cnt || cnt > MAXCNT) continue;
+        for (int sl = lane; sl < SLOTS; sl += 64) hkey[sl] = -1;
+        for (int sl = lane; sl < (SLOTS + 63) / 64; sl += 64) seen[sl] = 0ull;
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        for (int32_t q = lane; q < cnt; q += 64) {
+            const int32_t row = Ci[c0 + q];
+            uint32_t sl = sgo_slot<SLOTS>(row);
+            for (;;) {
+                const int32_t prev = atomicCAS(&hkey[sl], -1, row);
+                if (prev == -1) break;
+                sl = sl + 1 == SLOTS ? 0 : sl + 1;
+            }
+            slotq[q] = (uint16_t)sl;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        const int32_t b0 = Bp[j], b1 = Bp[j + 1];
+        for (int32_t pb0 = b0; pb0 < b1; pb0 += 64) {                 // B(:,j) in storage order, 64 entries to a round
+            const int nbe = min(64, b1 - pb0);
+            int32_t ka = 0, kb = 0, kd = 0;
+            double beta_l = 0.0;
+            if (lane < nbe) {
+                const int32_t k = Bi[pb0 + lane];
+                beta_l = Bx[pb0 + lane];
+                ka = Ap[k];
+                kb = Ap[k + 1];
+                kd = dupA[k];
+            }
+            for (int e0 = 0; e0 < nbe; e0 += G) {
+                int32_t rows[G];
+                double vals[G];
+#pragma unroll
+                for (int u = 0; u < G; u++) {                         // the first batch of each of the next G columns of A
+                    const int ee = min(e0 + u, nbe - 1);
+                    const int32_t a0 = __builtin_amdgcn_readlane(ka, ee), a1 = __builtin_amdgcn_readlane(kb, ee);
+                    const bool in = e0 + u < nbe && a0 + lane < a1;
+                    rows[u] = in ? Ai[a0 + lane] : -1;
+                    vals[u] = in ? Ax[a0 + lane] : 0.0;
+                }
+                // the slots of all G batches first (independent probe chains side by side), then the updates in order
+                uint32_t sls[G];
+#pragma unroll
+                for (int u = 0; u < G; u++) {
+                    sls[u] = 0;
+                    if (rows[u] >= 0) {
+                        uint32_t sl = sgo_slot<SLOTS>(rows[u]);
+                        while (hkey[sl] != rows[u]) sl = sl + 1 == SLOTS ? 0 : sl + 1;
+                        sls[u] = sl;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < G; u++) {
+                    if (e0 + u >= nbe) break;
+                    const int32_t a0 = __builtin_amdgcn_readlane(ka, e0 + u), a1 = __builtin_amdgcn_readlane(kb, e0 + u);
+                    const bool dupk = __builtin_amdgcn_readlane(kd, e0 + u) != 0;
+                    const double beta = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(beta_l), e0 + u),
+                                                         __builtin_amdgcn_readlane(__double2loint(beta_l), e0 + u));
+                    for (int32_t a = a0; a < a1; a += 64) {           // A(:,k) in storage order, 64 entries at a time
+                        int32_t row = rows[u];
+                        double val = vals[u];
+                        uint32_t sl = sls[u];
+                        if (a != a0) {                                // a long column of A: its later batches come as they are needed
+                            const bool in = a + lane < a1;
+                            row = in ? Ai[a + lane] : -1;
+                            val = in ? Ax[a + lane] : 0.0;
+                            if (in) {
+                                sl = sgo_slot<SLOTS>(row);
+                                while (hkey[sl] != row) sl = sl + 1 == SLOTS ? 0 : sl + 1;
+                            }
+                        }
+                        const bool active = row >= 0;
+                        const double prod = beta * val;
+                        int rounds = 1, before = 0;
+                        if (dupk) before = sgo_rank_of_equal_rows(row, active, lane, &rounds);
+                        for (int r = 0; r < rounds; r++) {
+                            if (active && before == r) {
+                                const unsigned long long bit = 1ull << (sl & 63);
+                                const unsigned long long old = atomicOr(&seen[sl >> 6], bit);
+                                acc[sl] = (old & bit) ? acc[sl] + prod : prod;   // the first product is assigned (csparse.py:1986)
+                            }
+                            if (rounds > 1) {
+                                __builtin_amdgcn_s_waitcnt(0xc07f);
+                                __builtin_amdgcn_wave_barrier();
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        for (int32_t q = lane; q < cnt; q += 64) Cx[c0 + q] = acc[slotq[q]];
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// flag[c] |= some column of C falls into class c: 0: 1 .. 256 entries, 1: .. 1 024, 2: .. 2 048, 3: more
+__global__ void k_sg_count_classes(int32_t n, const int32_t *__restrict__ Cp, int *flag) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < n && Cp[j + 1] - Cp[j] > SGO_MAX) atomicOr(flag, 1);
+    if (j >= n) return;
+    const int32_t cnt = Cp[j + 1] - Cp[j];
+    if (cnt == 0) return;
+    const int c = cnt <= 256 ? 0 : (cnt <= 1024 ? 1 : (cnt <= SGO_MAX ? 2 : 3));
+    if (!flag[c]) flag[c] = 1;
 }
 
 static int values_in_reference_order(const Csc *A, const Csc *B, Csc *C) {
@@ -1203,23 +1357,35 @@ static int values_in_reference_order(const Csc *A, const Csc *B, Csc *C) {
     hipStream_t s = ctx().stream;
     const int32_t n = C->n, m = C->m;
     DevScope tmp;
-    int *flag = nullptr, h = 0;
-    CSX_TRY(tmp.alloc(&flag, 1));
-    CSX_HIP(hipMemsetAsync(flag, 0, sizeof(int), s));
-    hipLaunchKernelGGL(k_sg_any_long, dim3((unsigned)(((int64_t)n + 255) / 256)), dim3(256), 0, s, n, C->p, flag);
-    CSX_HIP(hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, s));
-    const int64_t grid = std::min<int64_t>(n, (int64_t)ctx().cus * 16);
-    hipLaunchKernelGGL(k_sg_values_ordered<false>, dim3((unsigned)grid), dim3(64), 0, s, n, m, A->p, A->i, A->x, B->p, B->i, B->x,
-                       C->p, C->i, C->x, (int32_t *)nullptr);
+    int *flag = nullptr, h[4] = {0, 0, 0, 0};
+    uint8_t *dup = nullptr;
+    CSX_TRY(tmp.alloc(&flag, 4));
+    CSX_TRY(tmp.alloc(&dup, (size_t)A->n + 1));
+    CSX_HIP(hipMemsetAsync(flag, 0, 4 * sizeof(int), s));
+    hipLaunchKernelGGL(k_sg_count_classes, dim3((unsigned)(((int64_t)n + 255) / 256)), dim3(256), 0, s, n, C->p, flag);
+    CSX_HIP(hipMemcpyAsync(h, flag, sizeof h, hipMemcpyDeviceToHost, s));
+    int nbits = 1;
+    while (nbits < 31 && (1ll << nbits) < (long long)m) nbits++;
+    hipLaunchKernelGGL(k_sg_dup_cols, dim3((unsigned)(((int64_t)A->n + 3) / 4)), dim3(256), 0, s, A->n, nbits, A->p, A->i, dup);
     CSX_HIP(hipStreamSynchronize(s));
-    if (h) {
+    const int cus = ctx().cus;
+#define CSX_ORD(SLOTS, MAXCNT, LO, WAVES)                                                                                      \
+    hipLaunchKernelGGL((k_sg_values_ordered2<SLOTS, MAXCNT>), dim3((unsigned)std::min<int64_t>(n, (int64_t)cus * (WAVES))), dim3(64), \
+                       0, s, n, LO, A->p, A->i, A->x, dup, B->p, B->i, B->x, C->p, C->i, C->x)
+    // (tables at most half full: with linear probing a wave waits for its LONGEST probe chain, and at two thirds full --
+    // 1 536 slots for 1 024 entries, seven waves to a CU instead of five -- that made the pass six times slower, not faster)
+    if (h[0]) CSX_ORD(512, 256, 0, 20);          //  7 KB of LDS per wave
+    if (h[1]) CSX_ORD(2048, 1024, 256, 5);       // 27 KB: five waves to a CU
+    if (h[2]) CSX_ORD(4096, 2048, 1024, 2);      // 54 KB
+#undef CSX_ORD
+    if (h[3]) {
         const int64_t waves = std::min<int64_t>(n, 128);
         int32_t *gmap = nullptr;
         CSX_TRY(tmp.alloc(&gmap, (size_t)waves * (size_t)m));
         hipLaunchKernelGGL(k_sg_values_ordered<true>, dim3((unsigned)waves), dim3(64), 0, s, n, m, A->p, A->i, A->x, B->p, B->i, B->x,
                            C->p, C->i, C->x, gmap);
-        CSX_HIP(hipStreamSynchronize(s));
     }
+    CSX_HIP(hipStreamSynchronize(s));
     CSX_LAUNCH_CHECK();
     return CSX_OK;
 }
