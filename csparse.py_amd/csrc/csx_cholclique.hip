@@ -244,6 +244,17 @@ constexpr int CQ_CH = 16;     // columns staged at a time
 constexpr int CQ_LD = 65;     // doubles per staged column
 constexpr int CQ_G = 8;       // columns whose loads are in flight together
 
+// Lanes of ONE wave talk through LDS here: a store by one lane, a load of that slot by the others.  The hardware keeps a
+// wave's LDS operations in order, but the language is per thread: without a fence the compiler may let the other lanes'
+// load run before the storing lane's branch (it did, in an experiment that sent the pivot this way: the readers got the
+// previous column's value).  A wavefront-scope
+// release / acquire pair around a wave barrier tells it; it costs no instruction.
+__device__ __forceinline__ void cq_wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ double cq_bcast(double v, int src) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
@@ -366,12 +377,14 @@ __global__ __launch_bounds__(64 * CQ_WAVES, 3) void k_chol_clique(const int32_t 
         for (int jw = 0; (PARTS & 2) && jw < 8; jw++) {
             const int g = J + jw;
             if (g < bs) {
-                const double d = cq_bcast(a[jw], g);
+                const double d = cq_bcast(a[jw], g);    // (the pivot through LDS instead -- a store by its lane, a broadcast read --
+                                                        // saves 7 ns of issue and costs an LDS round trip on the chain: no gain, 1.72 ms either way)
                 if (d <= 0.0 && lane == 0) atomicMin(notspd, c0 + g);   // csparse.py:612
                 const double ljj = sqrt(d);
                 const double l = a[jw] / ljj;
                 a[jw] = lane == g ? ljj : l;
                 colbuf[jw * 64 + lane] = a[jw];
+                cq_wave_sync_lds();
                 if (jw < 7) {
                     double sc[8];
 #pragma unroll

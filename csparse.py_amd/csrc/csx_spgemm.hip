@@ -1198,7 +1198,7 @@ __global__ __launch_bounds__(64) void k_sg_values_ordered(int32_t n, int32_t m, 
 // batch of products pays its own memory round trip, and the test for equal rows inside a batch -- 63 readlanes -- runs for
 // every batch although a column of A almost never holds a row twice.  Here: (1) whether a column of A holds a row twice
 // inside one of its batches of 64 is found ONCE per column of A (k_sg_dup_cols); batches of clean columns update their 64
-// sums at once; (2) the table is sized to the column (512 / 2 048 / 4 096 slots for up to 256 / 1 024 / 2 048 entries: 7 / 27 /
+// sums at once; (2) the table is sized to the column (512 / 2 560 / 4 096 slots for up to 256 / 1 280 / 2 048 entries: 7 / 34 /
 // 54 KB per wave), sums are kept per SLOT, so no position array; (3) a wave keeps its column of B in registers (entry l in
 // lane l), requests the A columns of eight entries together and looks up their slots side by side before the updates,
 // which go in order.  S: 250 -> 42 ms for the pass (cs_multiply with "spgemm.ordered": 265 -> 57 ms).  Same operation order per entry of C, so still bit-identical to the reference.
@@ -1342,13 +1342,13 @@ __global__ __launch_bounds__(64) void k_sg_values_ordered2(int32_t n, int32_t lo
     }
 }
 
-// flag[c] |= some column of C falls into class c: 0: 1 .. 256 entries, 1: .. 1 024, 2: .. 2 048, 3: more
+// flag[c] |= some column of C falls into class c: 0: 1 .. 256 entries, 1: .. 1 280, 2: .. 2 048, 3: more
 __global__ void k_sg_count_classes(int32_t n, const int32_t *__restrict__ Cp, int *flag) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     const int32_t cnt = Cp[j + 1] - Cp[j];
     if (cnt == 0) return;
-    const int c = cnt <= 256 ? 0 : (cnt <= 1024 ? 1 : (cnt <= SGO_MAX ? 2 : 3));
+    const int c = cnt <= 256 ? 0 : (cnt <= 1280 ? 1 : (cnt <= SGO_MAX ? 2 : 3));
     if (!flag[c]) flag[c] = 1;
 }
 
@@ -1375,8 +1375,9 @@ static int values_in_reference_order(const Csc *A, const Csc *B, Csc *C) {
     // (tables at most half full: with linear probing a wave waits for its LONGEST probe chain, and at two thirds full --
     // 1 536 slots for 1 024 entries, seven waves to a CU instead of five -- that made the pass six times slower, not faster)
     if (h[0]) CSX_ORD(512, 256, 0, 20);          //  7 KB of LDS per wave
-    if (h[1]) CSX_ORD(2048, 1024, 256, 5);       // 27 KB: five waves to a CU
-    if (h[2]) CSX_ORD(4096, 2048, 1024, 2);      // 54 KB
+    if (h[1]) CSX_ORD(2560, 1280, 256, 4);       // 34 KB: four waves to a CU (S: 1 024 +- 100 entries per column -- with the
+                                                 // class cut at 1 024 a quarter of S went to the 54 KB class: 32 of 49 ms)
+    if (h[2]) CSX_ORD(4096, 2048, 1280, 2);      // 54 KB
 #undef CSX_ORD
     if (h[3]) {
         const int64_t waves = std::min<int64_t>(n, 128);

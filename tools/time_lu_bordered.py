@@ -8,6 +8,7 @@ for p in ("csparse.py_amd", "oracle", "tests"):
 import numpy as np
 import _csx
 _csx.init(0)
+_csx.check(_csx.lib().csx_set_option(b"lu.etree", 1))     # the planner's own criteria (the default since round 4 is 0: never)
 from test_gpu_lu_etree import _bordered_blocks, _device_lu, _host_lu
 for nb in [int(v) for v in sys.argv[1:]] or [40, 400, 4000]:
     n, Ap, Ai, Ax = _bordered_blocks(nb)
