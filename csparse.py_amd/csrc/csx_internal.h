@@ -150,7 +150,7 @@ struct Options {
     int lu_etree = 0;                 // cs_lu of one connected matrix on the device, columns scheduled by the column etree:
                                       // 0 never (the default since round 4: measured at best a tie with one host core, on the
                                       // shape it was made for -- profiles/r04_ablation.md), 1 for shallow trees with short
-                                      // columns, 2 always (tests: L, U, pinv bit-identical to the host loop and the oracle)
+                                      // columns, 2 always (tests: L, U, pinv bit-identical to the host loop and the CPU restatement of the reference loop)
 };
 
 struct Context {

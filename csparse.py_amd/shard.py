@@ -73,7 +73,8 @@ class Rendezvous(object):
         self.port = int(port if port is not None else os.environ.get("MASTER_PORT", "29500"))
         tok = token if token is not None else os.environ.get("CSX_RDV_TOKEN")
         if tok is None and os.environ.get("TORCHELASTIC_RUN_ID"):
-            tok = "run:" + os.environ["TORCHELASTIC_RUN_ID"]
+            # (torchrun without --rdzv-id gives every job the id "none": the master address and port tell two such jobs apart)
+            tok = "run:%s@%s:%s" % (os.environ["TORCHELASTIC_RUN_ID"], os.environ.get("MASTER_ADDR", ""), os.environ.get("MASTER_PORT", ""))
         if tok is None and "MASTER_ADDR" in os.environ and "MASTER_PORT" in os.environ and addr is None and port is None:
             tok = "master:%s:%s" % (os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"])
         if tok is None:

@@ -168,7 +168,7 @@ def test_rendezvous_token_comes_from_the_launcher_and_a_mismatch_names_both_toke
     monkeypatch.setenv("MASTER_PORT", "29411")
     assert shard.Rendezvous(1, 4).token == b"master:127.0.0.1:29411/4"
     monkeypatch.setenv("TORCHELASTIC_RUN_ID", "job-7")
-    assert shard.Rendezvous(1, 4).token == b"run:job-7/4"
+    assert shard.Rendezvous(1, 4).token == b"run:job-7@127.0.0.1:29411/4"
     monkeypatch.setenv("CSX_RDV_TOKEN", "mine")
     assert shard.Rendezvous(1, 4).token == b"mine/4"
     import socket
