@@ -682,7 +682,16 @@ static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, c
         // one read of A's upper part and one write of L, a block to a wave.  The caller's S must be that forest's.
         CliqueForest F;
         bool ok = false, same = false;
-        int st = clique_forest(A, &F, &ok);
+        int st = CSX_OK;
+        const bool cached = A->clique != nullptr;
+        if (cached) {
+            // csx_schol's finding for this matrix (dropped by csx_csc_invalidate when the arrays change): a shallow copy; L.p is
+            // copied out of it below instead of taken
+            F = *A->clique;
+            ok = true;
+        } else {
+            st = clique_forest(A, &F, &ok);
+        }
         if (st == CSX_OK && ok && F.ascending && F.max_bs <= CLIQUE_MAX_BLOCK) {
             lap("clique forest");
             st = clique_matches_host(F, parent, cp, &same);
@@ -692,9 +701,16 @@ static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, c
             if (st == CSX_OK) st = dalloc(&L->i, (size_t)L->nnz);
             if (st == CSX_OK) st = dalloc(&L->x, (size_t)L->nnz);
             if (st == CSX_OK) st = dalloc(&d_notspd, 1);
+            if (st == CSX_OK && cached) {
+                st = dalloc(&L->p, (size_t)n + 1);
+                if (st == CSX_OK && hipMemcpyAsync(L->p, F.cp, ((size_t)n + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, s) != hipSuccess)
+                    st = CSX_ERUNTIME;
+            }
             if (st == CSX_OK) {
-                L->p = F.cp;
-                F.cp = nullptr;
+                if (!cached) {
+                    L->p = F.cp;
+                    F.cp = nullptr;
+                }
                 lap("S compared");
                 if (hipMemcpyAsync(d_notspd, &hflag, sizeof(int), hipMemcpyHostToDevice, s) != hipSuccess) st = CSX_ERUNTIME;
             }
@@ -712,11 +728,11 @@ static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, c
                 g_chol_path = 1;
             }
             dfree(d_notspd);
-            free_clique(&F);
+            if (!cached) free_clique(&F);
             if (st != CSX_OK) return st;
             return hflag != 0x7fffffff ? CSX_ENOTSPD : CSX_OK;
         }
-        free_clique(&F);
+        if (!cached) free_clique(&F);
         if (st != CSX_OK) return st;
         lap("no clique forest");
     }

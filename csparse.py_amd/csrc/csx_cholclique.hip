@@ -143,6 +143,12 @@ void free_clique(CliqueForest *F) {
     F->parent = F->cp = F->start = nullptr;
 }
 
+void free_clique_cache(CliqueForest *F) {
+    if (!F) return;
+    free_clique(F);
+    delete F;
+}
+
 int clique_forest(const Csc *A, CliqueForest *F, bool *ok) {
     *ok = false;
     const int32_t n = A->n;

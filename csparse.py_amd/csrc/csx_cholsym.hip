@@ -429,8 +429,13 @@ extern "C" int csx_schol(csx_handle_t hA, int32_t *parent, int32_t *cp) {
                 hipStreamSynchronize(s) != hipSuccess)
                 st = CSX_ERUNTIME;
         }
+        if (st == CSX_OK && ok) {             // kept on the matrix for the csx_chol that follows (csx_csc_invalidate drops it)
+            free_clique_cache(A->clique);
+            A->clique = new CliqueForest(F);
+            return CSX_OK;
+        }
         free_clique(&F);
-        if (st != CSX_OK || ok) return st;
+        if (st != CSX_OK) return st;
     }
     bool on_device = false, bad_index = false;
     CSX_TRY(etree_by_components(A, parent, &on_device, &bad_index));

@@ -251,6 +251,7 @@ void free_csc(Csc *A) {
         dfree(A->house->cols);
         delete A->house;
     }
+    free_clique_cache(A->clique);
     delete A;
 }
 
@@ -617,6 +618,8 @@ int csx_csc_invalidate(csx_handle_t h) {
         delete A->house;
         A->house = nullptr;
     }
+    free_clique_cache(A->clique);
+    A->clique = nullptr;
     return CSX_OK;
 }
 

@@ -86,6 +86,8 @@ struct HouseLevels {
     int32_t *cols = nullptr;       // device: columns ordered by level, ascending inside a level
 };
 
+struct CliqueForest;   // csx_cholclique.h
+
 struct Csc {
     int32_t m = 0, n = 0, nnz = 0;
     int32_t *p = nullptr;
@@ -97,6 +99,8 @@ struct Csc {
     Gather *rows = nullptr;   // stable transpose = rows of A in ascending column order
     TiledPlan *tiled = nullptr;
     HouseLevels *house = nullptr;   // csx_happly's level schedule (pattern only; dropped by csx_csc_invalidate too)
+    CliqueForest *clique = nullptr; // csx_schol's finding "a forest of cliques on consecutive columns" (tree, counts, block list on the
+                                    // device), kept for the csx_chol that follows; pattern only, dropped by csx_csc_invalidate too
 };
 
 struct Vec {
@@ -182,6 +186,7 @@ void pool_stats(size_t *cached, size_t *live);  // bytes idle in the cache / han
 void pool_set_limit(size_t bytes);              // cap of the cache (0: the default quarter of the device)
 
 void free_gather(Gather *g);
+void free_clique_cache(CliqueForest *F);   // csx_cholclique.hip
 void free_tiled(TiledPlan *t);
 void free_csc(Csc *A);
 void free_triplan(TriPlan *t);
