@@ -249,3 +249,42 @@ def test_default_order_follows_the_kind_of_right_hand_side(cs):
     assert np.max(np.abs(np.asarray(b) - ref0) / np.abs(ref0)) < 1e-13
     b = B[:, 0].tolist()                                                      # the reference's own driver: always exact
     assert cs.cs_cholsol(0, A, b) is True and np.asarray(b).tobytes() == ref0.tobytes()
+
+
+def test_the_finding_of_csx_schol_stays_on_the_matrix_until_it_is_invalidated(cs):
+    """csx_schol leaves tree, counts and block list on the device matrix; the csx_chol that follows uses them instead of
+    recognising the forest again.  Same factor with the finding, after csx_csc_invalidate (recognised anew) and for a
+    matrix csx_schol never saw (csx_schol_host's S)."""
+    import ctypes as C
+    import _csx
+    lib = _csx.lib()
+    n, Ap, Ai, Ax = _blocks([64, 3, 17, 40, 1, 64], 8)
+    parent, cp = CO.schol(n, Ap, Ai)
+    Lp, Li, Lx = CO.chol(n, Ap, Ai, Ax, parent, cp)
+
+    def factor(hA, par, cpp):
+        hL = _csx.new_handle()
+        _csx.check(lib.csx_chol(hA, _csx.pi(par), _csx.pi(cpp), None, hL))
+        path = C.c_int32(-1)
+        _csx.check(lib.csx_chol_info(path, None))
+        x = np.empty(int(Lp[n]))
+        _csx.check(lib.csx_csc_download(hL, None, None, _csx.pd(x)))
+        _csx.free(hL)
+        return path.value, x
+
+    hA = _csx.new_handle()
+    _csx.check(lib.csx_csc_upload(n, n, _csx.pi(Ap), _csx.pi(Ai), _csx.pd(Ax), hA))
+    p1, x1 = factor(hA, parent, cp)
+    par2, cp2 = np.empty(n, np.int32), np.empty(n + 1, np.int32)
+    _csx.check(lib.csx_schol(hA, _csx.pi(par2), _csx.pi(cp2)))           # leaves its finding on the matrix
+    assert par2.tolist() == parent.tolist() and cp2.tolist() == cp.tolist()
+    p2, x2 = factor(hA, par2, cp2)
+    _csx.check(lib.csx_csc_invalidate(hA))
+    p3, x3 = factor(hA, par2, cp2)
+    assert (p1, p2, p3) == (1, 1, 1)
+    assert x1.tobytes() == Lx.tobytes() and x2.tobytes() == Lx.tobytes() and x3.tobytes() == Lx.tobytes()
+    bad = cp2.copy()
+    bad[3] += 1                                                             # an S that is not this matrix's: refused either way
+    hL = _csx.new_handle()
+    assert lib.csx_chol(hA, _csx.pi(par2), _csx.pi(bad), None, hL) == _csx.EINVAL
+    _csx.free(hA)
