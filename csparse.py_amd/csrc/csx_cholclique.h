@@ -14,6 +14,7 @@ struct CliqueForest {
     int32_t nblocks = 0, max_bs = 0;
     int64_t lnz = 0;
     bool ascending = true;       // the upper part of every column is strictly ascending (what k_chol_clique needs)
+    bool dense_in_front = false; // ... and is rows u[k] .. k, one each, stored before any lower entry: k_chol_clique skips A.i
     int32_t *parent = nullptr;   // device [n]: elimination tree (csparse.py:1136-1169)
     int32_t *cp = nullptr;       // device [n + 1]: column pointers of L (csparse.py:2069-2071)
     int32_t *start = nullptr;    // device [nblocks + 1]: first column of every block, then n

@@ -45,6 +45,7 @@ __global__ __launch_bounds__(256) void k_clique_min(int32_t n, int32_t nnz, cons
     const int32_t k = (int32_t)(k64 < n ? k64 : n - 1);          // the spare groups of the last wave repeat column n - 1
     const int32_t b = Ap[k], e = Ap[k + 1];
     int32_t mn = k, run = -1;          // smallest upper row; largest upper row of the steps before
+    int32_t nup = 0, lastpos = -1;     // upper entries of this lane; position (in the column) of its last one
     bool bad = false;
     for (int32_t p0 = b & ~3; p0 < e; p0 += 64) {
         const int32_t p = p0 + 4 * t;
@@ -60,6 +61,8 @@ __global__ __launch_bounds__(256) void k_clique_min(int32_t n, int32_t nnz, cons
                 if (first == 0x7fffffff) first = r[c];
                 lmax = max(lmax, r[c]);
                 mn = min(mn, r[c]);
+                nup++;
+                lastpos = p + c - b;
             }
         }
         // largest upper row of the lanes before this one (exclusive prefix maximum over the 16 lanes), and of earlier steps
@@ -76,8 +79,15 @@ __global__ __launch_bounds__(256) void k_clique_min(int32_t n, int32_t nnz, cons
         run = max(run, __shfl(pre, 15, 16));
     }
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) mn = min(mn, __shfl_xor(mn, o, 16));
+    for (int o = 8; o > 0; o >>= 1) {
+        mn = min(mn, __shfl_xor(mn, o, 16));
+        nup += __shfl_xor(nup, o, 16);
+        lastpos = max(lastpos, __shfl_xor(lastpos, o, 16));
+    }
     if (bad) flags[0] = 1;
+    // flags[3] |= not "dense and in front": the upper part of a column is then rows u[k] .. k, one each, stored first -- entry t of
+    // the column IS row u[k] + t, and the block kernel need not read the row indices at all
+    if (nup != k - mn + 1 || lastpos != nup - 1) flags[3] = 1;
     if (t == 0 && k64 < n) u[k] = mn;
 }
 
@@ -194,6 +204,7 @@ int clique_forest(const Csc *A, CliqueForest *F, bool *ok) {
     F->max_bs = h[2];
     F->lnz = (int64_t)lnz;
     F->ascending = h[0] == 0;
+    F->dense_in_front = h[0] == 0 && h[3] == 0;
     *ok = true;
     return CSX_OK;
 }
@@ -261,6 +272,17 @@ __device__ __forceinline__ void cq_wave_sync_lds() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// A column of A (or of L) starts at a wave-uniform place: it is addressed through a BUFFER RESOURCE -- scalar base, size in
+// bytes -- and a lane's 32-bit byte offset, computed once per kernel (lane * 4, lane * 8).  No 64-bit address per lane and
+// load (that arithmetic was a quarter of the load phase's instructions, and the kernel is bound by instruction issue), and the
+// hardware's range check returns zero for the lanes past the column's end instead of clamps and exec masks around the load.
+typedef unsigned int cq_u32x2 __attribute__((ext_vector_type(2)));
+constexpr int CQ_RSRC_FLAGS = 0x00020000;   // raw buffer of 32-bit data, gfx9 family
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t cq_rsrc(const void *base, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, CQ_RSRC_FLAGS);
+}
+
 __device__ __forceinline__ double cq_bcast(double v, int src) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
@@ -268,7 +290,7 @@ __device__ __forceinline__ double cq_bcast(double v, int src) {
 }
 
 // PARTS: 1 load, 2 factor, 4 store -- 7 is the kernel; the others exist in the ablation build only (what each phase costs)
-template <int PARTS>
+template <int PARTS, bool SMALL, bool DENSE>
 __global__ __launch_bounds__(64 * CQ_WAVES, 3) void k_chol_clique(const int32_t *__restrict__ start, int32_t nblocks, int32_t n, int32_t nnz,
                                                                  const int32_t *__restrict__ Ap, const int32_t *__restrict__ Ai,
                                                                  const double *__restrict__ Ax, const int32_t *__restrict__ Lp,
@@ -293,6 +315,8 @@ __global__ __launch_bounds__(64 * CQ_WAVES, 3) void k_chol_clique(const int32_t 
     // (what is NOT done here matters as much as what is: the kernel is bound by instruction issue -- 7 000 vector
     // instructions per block at 2.2 ns each -- so the loads are unconditional (clamped addresses, no exec juggling), the
     // scatter writes rejected entries to a spare slot instead of branching, and the read-back runs under one exec mask)
+    const int lane4 = lane * 4, lane8 = lane * 8;
+    const __amdgpu_buffer_rsrc_t ri_all = cq_rsrc(Ai, SMALL ? nnz * 4 : 0), rx_all = cq_rsrc(Ax, SMALL ? nnz * 8 : 0);
     if (PARTS & 1) {
         const int32_t apb = Ap[min(c0 + lane, n)], ape = Ap[min(c0 + lane + 1, n)];      // lane l: column c0 + l
         const bool lng = lane < bs && ape - apb > 64;
@@ -319,13 +343,21 @@ __global__ __launch_bounds__(64 * CQ_WAVES, 3) void k_chol_clique(const int32_t 
                         const int k = CQ_CH * q + kk0 + uu;
                         const int32_t pb = __builtin_amdgcn_readlane(apb, k);
                         const int32_t pe = k < bs ? __builtin_amdgcn_readlane(ape, k) : pb;
-                        const int32_t p = pb + lane;
-                        in[uu] = p < pe;
-                        ii[uu] = Ai[min(p, nnz - 1)];
+                        const int32_t len = min(pe - pb, 64);                              // uniform; longer columns: below
+                        in[uu] = lane < len;
                         // the value is wanted for upper entries only; in an ascending column those are the first k + 1: the
-                        // lanes past them ask for entry k again (no new line; an upper entry further back -- lower entries
-                        // stored in front of it -- is fetched below): half of A.x is never read
-                        vv[uu] = Ax[min(min(p, pb + k), nnz - 1)];
+                        // lanes past them get zero without a request (an upper entry further back -- lower entries stored in
+                        // front of it -- is fetched below): half of A.x is never read
+                        if (SMALL) {   // ONE resource per array, the column's start as the instruction's scalar offset
+                            if (!DENSE) ii[uu] = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(ri_all, lane4, pb * 4, 0);
+                            vv[uu] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rx_all, min(lane8, 8 * k), pb * 8, 0));   // (the lanes past entry k ask for it again: no new line)
+                        } else {       // 2^29 entries or more: byte offsets past 32 bits -- a resource per column
+                            if (!DENSE) ii[uu] = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(cq_rsrc(Ai + pb, len * 4), lane4, 0, 0);
+                            vv[uu] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(cq_rsrc(Ax + pb, min(len, k + 1) * 8), lane8, 0, 0));
+                        }
+                        // DENSE (found by k_clique_min for the whole matrix): entry t of the column is row c0 + t, t <= k -- the
+                        // row indices are not read: a third of the kernel's fetches
+                        if (DENSE) ii[uu] = c0 + lane;
                     }
                     bool late = false;
 #pragma unroll
@@ -336,7 +368,7 @@ __global__ __launch_bounds__(64 * CQ_WAVES, 3) void k_chol_clique(const int32_t 
                         slot[uu] = okk ? (kk0 + uu) * CQ_LD + (int)rel : CQ_CH * CQ_LD;
                         late |= okk && lane > k;
                     }
-                    if (__ballot(late) != 0ull) {
+                    if (!DENSE && __ballot(late) != 0ull) {
 #pragma unroll
                         for (int uu = 0; uu < CQ_G; uu++) {
                             const int k = CQ_CH * q + kk0 + uu;
@@ -424,10 +456,12 @@ __global__ __launch_bounds__(64 * CQ_WAVES, 3) void k_chol_clique(const int32_t 
 #pragma unroll
         for (int jw = 0; jw < 8; jw++) {
             const int g = J + jw;
-            if (g < bs && lane >= g && lane < bs && ((PARTS & 4) || a[jw] == 12345.678)) {
-                const int64_t q = base + (int64_t)g * bs - (int64_t)g * (g - 1) / 2 + (lane - g);
-                Lx[q] = a[jw];
-                Li[q] = c0 + lane;
+            if (g < bs) {   // uniform; the column's place in L is a scalar base, a lane adds its row
+                const int64_t colbase = base + (int64_t)g * bs - (int64_t)g * (g - 1) / 2 - g;
+                if (lane >= g && lane < bs && ((PARTS & 4) || a[jw] == 12345.678)) {
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(cq_u32x2, a[jw]), cq_rsrc(Lx + colbase, bs * 8), lane8, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32((unsigned int)(c0 + lane), cq_rsrc(Li + colbase, bs * 4), lane4, 0, 0);
+                }
             }
         }
 #pragma unroll
@@ -440,8 +474,15 @@ int chol_clique_numeric(const Csc *A, const CliqueForest &F, Csc *L, int *d_nots
     if (F.nblocks == 0 || A->nnz == 0) return CSX_OK;
     const dim3 grid((unsigned)((F.nblocks + CQ_WAVES - 1) / CQ_WAVES));
 #define CSX_CQ(PARTS)                                                                                                       \
-    hipLaunchKernelGGL(k_chol_clique<PARTS>, grid, dim3(64 * CQ_WAVES), 0, s, F.start, F.nblocks, A->n, A->nnz, A->p, A->i, A->x, L->p, \
-                       L->i, L->x, d_notspd)
+    if (A->nnz < (1 << 29) && F.dense_in_front)                                                                                 \
+        hipLaunchKernelGGL((k_chol_clique<PARTS, true, true>), grid, dim3(64 * CQ_WAVES), 0, s, F.start, F.nblocks, A->n, A->nnz, A->p, \
+                           A->i, A->x, L->p, L->i, L->x, d_notspd);                                                              \
+    else if (A->nnz < (1 << 29))                                                                                                \
+        hipLaunchKernelGGL((k_chol_clique<PARTS, true, false>), grid, dim3(64 * CQ_WAVES), 0, s, F.start, F.nblocks, A->n, A->nnz,      \
+                           A->p, A->i, A->x, L->p, L->i, L->x, d_notspd);                                                        \
+    else                                                                                                                        \
+        hipLaunchKernelGGL((k_chol_clique<PARTS, false, false>), grid, dim3(64 * CQ_WAVES), 0, s, F.start, F.nblocks, A->n, A->nnz,     \
+                           A->p, A->i, A->x, L->p, L->i, L->x, d_notspd)
     int parts = 7;
 #ifdef CSX_ABLATION
     if (const char *e = ablation_env("CSX_CQ_PARTS")) parts = atoi(e);

@@ -59,8 +59,12 @@ def _factor_both_ways(cs, n, Ap, Ai, Ax):
     return A, S, N, S0, N0
 
 
-@pytest.mark.parametrize("case", ["mixed", "sparse_blocks", "ones", "one_block_64", "lower_shuffled"])
+@pytest.mark.parametrize("case", ["mixed", "sparse_blocks", "ones", "one_block_64", "lower_shuffled", "lower_in_front"])
 def test_clique_forest_factor_has_the_oracle_bits(cs, case):
+    """"mixed", "ones", "one_block_64": dense blocks with sorted columns -- the block kernel does not even read the row indices
+    (k_clique_min found every upper part dense and stored in front); "lower_in_front": the same blocks with a lower entry
+    moved to the front of some columns -- that shortcut must be refused; "sparse_blocks", "lower_shuffled": fill inside the
+    blocks, lower parts in any order."""
     rng = np.random.default_rng(7)
     if case == "mixed":
         sizes, dens, shuf = list(rng.integers(1, 65, 300)) + [64, 63, 1, 2, 17], 1.0, False
@@ -70,9 +74,21 @@ def test_clique_forest_factor_has_the_oracle_bits(cs, case):
         sizes, dens, shuf = [1] * 500, 1.0, False
     elif case == "one_block_64":
         sizes, dens, shuf = [64], 1.0, False
+    elif case == "lower_in_front":
+        sizes, dens, shuf = list(rng.integers(2, 65, 120)), 1.0, False
     else:
         sizes, dens, shuf = list(rng.integers(1, 50, 150)), 0.6, True
-    n, Ap, Ai, Ax = _blocks(sizes, 11, dens, shuf)
+
+    def lower_first(cols_i, cols_x):
+        moved = 0
+        for c in range(len(cols_i)):
+            if c % 5 == 0 and len(cols_i[c]) and cols_i[c][-1] > c:        # the column's last entry is a lower one: to the front
+                cols_i[c] = np.concatenate([cols_i[c][-1:], cols_i[c][:-1]])
+                cols_x[c] = np.concatenate([cols_x[c][-1:], cols_x[c][:-1]])
+                moved += 1
+        assert moved > 10
+
+    n, Ap, Ai, Ax = _blocks(sizes, 11, dens, shuf, lower_first if case == "lower_in_front" else None)
     A, S, N, S0, N0 = _factor_both_ways(cs, n, Ap, Ai, Ax)
     parent, cp = CO.schol(n, Ap, Ai)
     assert S.parent == parent.tolist() == S0.parent and S.cp == cp.tolist() == S0.cp and S.lnz == int(cp[n])
