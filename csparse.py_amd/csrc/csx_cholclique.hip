@@ -408,7 +408,7 @@ __global__ __launch_bounds__(64 * CQ_WAVES, 3) void k_chol_clique(const int32_t 
     // 4.0 ns, in the LDS pipe beside the vector ALU; v_mul_f64 / v_add_f64 2.2 ns each.  With v_readlane the factor phase
     // took 2.2 ms at 5M rows, 62 % of it the readlanes.
     const int64_t base = Lp[c0];
-    double *colbuf = tile;   // [8][64]
+    double *colbuf = tile;   // [8][64]   (s_setprio around the phases -- loading waves first, or factoring waves first -- 1.61-1.65 ms: no gain)
 #pragma unroll 1
     for (int J = 0; J < bs; J += 8) {
 #pragma unroll
