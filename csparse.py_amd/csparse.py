@@ -1076,10 +1076,8 @@ def cholsol_factor(A, order=0, exact=None):
     if N is None:
         return None
     pinv = None if S.pinv is None else _csx.i32(S.pinv)
-    for name in ("parent", "cp", "pinv"):                  # the solver exposes S: lists, as cs_schol returns them
-        v = getattr(S, name)
-        if v is not None and not isinstance(v, list):
-            setattr(S, name, v.tolist())
+    # (the solver exposes S with lists, as cs_schol returns them -- made when `symbolic` is first read: at 5M columns the
+    # three conversions take 0.3 s, sixty times the analysis itself)
     # The C plan BORROWS L's device arrays (CholPlan::L is not owned; the L' plan reads L.p / L.i / L.x directly),
     # so the factor must stay on the device for as long as the solver lives: N.L is pinned (reading F.L.p / .i / .x
     # copies to the host but keeps the device matrix), and the solver holds the _DevMatrix itself.
@@ -1096,7 +1094,14 @@ def cholsol_factor(A, order=0, exact=None):
 
     class _Solver(object):
         L = N.L
-        symbolic = S
+
+        @property
+        def symbolic(self):
+            for name in ("parent", "cp", "pinv"):
+                v = getattr(S, name)
+                if v is not None and not isinstance(v, list):
+                    setattr(S, name, v.tolist())
+            return S
 
         def __init__(self):
             self._dev = dev                      # keeps the device factor alive (see above)
