@@ -52,6 +52,31 @@ def test_lusol_with_a_fill_reducing_ordering(cs, name, order, meta):
         assert np.max(np.abs(x - ref)) <= 1e-8 * np.max(np.abs(ref))
 
 
+@pytest.mark.parametrize("order", [0, 1, 2])
+@pytest.mark.parametrize("name", ["west0067", "fs_183_1"])
+def test_lusol_factor_solves_lists_and_blocks_with_the_bits_of_cs_lusol(cs, name, order, meta):
+    """lusol_factor (factor once; permute, L, U, permute on the device) against the driver cs_lusol, column by column, at
+    every ordering: the same factors, the same operation order, so the same bits."""
+    g = golden(name)
+    C = cs.cs_pin(unpack(cs, g, "C"))
+    n, k = C.n, 5
+    tol = 0.001 if meta[name]["sym"] else 1.0
+    F = cs.lusol_factor(C, order, tol)
+    B = np.stack([np.asarray(_rhs(n)) * (1.0 + 0.25 * r) + r for r in range(k)], axis=1)
+    dB = cs.dvec(np.ascontiguousarray(B))
+    assert F.solve(dB) is True
+    X = dB.numpy().reshape(n, k)
+    for r in range(k):
+        col = B[:, r].tolist()
+        assert cs.cs_lusol(order, C, col, tol) is True
+        assert np.asarray(col).tobytes() == np.ascontiguousarray(X[:, r]).tobytes(), (name, order, r)
+    one = B[:, 2].tolist()
+    assert F.solve(one) is True and np.asarray(one).tobytes() == np.ascontiguousarray(X[:, 2]).tobytes()
+    blk = cs.dvec(np.ascontiguousarray(B))
+    assert cs.cs_lusol(order, C, blk, tol) is True and blk.numpy().tobytes() == dB.numpy().tobytes()
+    assert cs.lusol_factor(unpack(cs, golden("ash219"), "C")) is None          # not square
+
+
 @pytest.mark.parametrize("name", ["t1", "bcsstk01", "west0067", "fs_183_1", "ash219", "ibm32a", "ibm32b", "lp_afiro"])
 def test_qrsol_order_3(cs, name):
     g = golden(name)
