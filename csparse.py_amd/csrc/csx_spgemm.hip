@@ -652,7 +652,9 @@ __device__ __forceinline__ uint32_t h2_exclusive(uint32_t v, int lane) {   // ex
 // ahead of its turn and rides along with the work on earlier columns: descriptors three columns ahead, B entries two,
 // the extents of the A columns they name between one and two, and the products themselves (rows and values of A, the
 // only loads that depend on data) ONE column ahead -- issued before the current column's inserts, used after its
-// copy-out.  (Gathered just in time they cost 4.6 of 11 ms.)
+// copy-out.  (Gathered just in time they cost 4.6 of 11 ms.)  (Round 4: the three barriers of the column loop as LDS-only
+// barriers -- __syncthreads() also waits for the global loads in flight, i.e. for the next column's products -- 9.8 ms either
+// way: the prefetch is not what the loop waits for.)
 template <bool VALUES>
 __global__ __launch_bounds__(256) void k_sg_hash2(int slots_, const int4 *__restrict__ info, int32_t ncols,
                                                   const int32_t *__restrict__ Ap, const int32_t *__restrict__ Ai,
