@@ -249,13 +249,16 @@ int clique_matches_host(const CliqueForest &F, const int32_t *parent, const int3
 // Factoring: right-looking, in panels of 8 columns.  Every element receives its updates - L(r, j) L(c, j) for j = 0, 1, ...
 // in ascending order, multiply then subtract, then one division by the pivot: the operation sequence of cs_chol's up-looking
 // row solve on a chain (csparse.py:598-612; cs_ereach hands the columns over in ascending order), so L.x is bit-identical to
-// it.  L(c, j) comes from lane c by v_readlane and enters the multiplication as a scalar operand.  The register file has no
-// dynamic index, and the whole triangle unrolled would be 90 KB of code against 64 KB of instruction cache: the loop body is
+// it.  L(c, j) reaches the lanes through LDS (the panel's finished columns are written there once, an update reads its factor
+// with a broadcast read; see "factor" below for why not v_readlane).  The register file has no dynamic index, and the whole triangle unrolled would be 90 KB of code against 64 KB of instruction cache: the loop body is
 // written for a WINDOW whose first eight registers are the current panel -- factor those, update the rest of the window by
 // them (groups of eight columns, skipped when they lie beyond the block), store the panel, slide the window by eight
 // registers -- 18 KB of code, executed bs / 8 times, no update outside the triangle's rectangle of live groups.
 //
 // Storing: column g of the block goes to L.x / L.i at Lp[c0] + g bs - g (g - 1) / 2, rows ascending: runs of up to 512 / 256 bytes.
+//
+// SMALL: fewer than 2^29 entries in A -- one buffer resource per array and the column's start as the scalar offset of the load;
+// DENSE: every upper part is rows c0 .. c0 + k stored in front (k_clique_min) -- the row indices are not read.
 constexpr int CQ_WAVES = 4;
 constexpr int CQ_CH = 16;     // columns staged at a time
 constexpr int CQ_LD = 65;     // doubles per staged column
