@@ -166,7 +166,7 @@ int clique_forest(const Csc *A, CliqueForest *F, bool *ok) {
     hipStream_t s = ctx().stream;
     DevScope tmp;
     int32_t *u = nullptr, *is_start = nullptr, *block_id = nullptr, *end_of = nullptr, *count = nullptr;
-    int *flags = nullptr;   // [0] not ascending, [1] not a clique forest, [2] widest block; [4..5] lnz (64 bits)
+    int *flags = nullptr;   // [0] not ascending, [1] not a clique forest, [2] widest block, [3] not "dense and in front"; [4..5] lnz (64 bits)
     CSX_TRY(tmp.alloc(&u, (size_t)n));
     CSX_TRY(tmp.alloc(&is_start, (size_t)n + 1));
     CSX_TRY(tmp.alloc(&block_id, (size_t)n + 1));
