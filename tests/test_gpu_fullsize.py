@@ -121,6 +121,49 @@ def test_gaxpy_5m_uniform_draw_the_benchmarked_matrix(cs, lib):
         _csx.free(h)
 
 
+def test_clique_forest_at_5m_equals_the_general_path_bit_for_bit(cs, lib):
+    """Config 5's matrix at full size: csx_schol and csx_chol through the clique-forest path (csx_cholclique.hip) against the
+    general path ("chol.clique" = 0: pattern machine, k_chol_dense_trees).  Both keep the reference's operation order on
+    dense blocks, and both are bit-identical to the plain-C port at sizes it reaches (tests/test_gpu_cholesky.py,
+    tests/test_gpu_cholclique.py): at 5M rows parent, cp, L.p, L.i and L.x must be EQUAL, byte for byte (digests), and the
+    solve plans must give the same bits."""
+    import hashlib
+    import _csx
+    nb, bs, k = 78125, 64, 8
+    n = nb * bs
+    hA = _csx.new_handle()
+    _csx.check(lib.csx_gen_gspd(nb, bs, 20240606, hA))
+    lnz = nb * bs * (bs + 1) // 2
+
+    def run():
+        parent, cp = np.empty(n, np.int32), np.empty(n + 1, np.int32)
+        _csx.check(lib.csx_schol(hA, _csx.pi(parent), _csx.pi(cp)))
+        hL = _csx.new_handle()
+        _csx.check(lib.csx_chol(hA, _csx.pi(parent), _csx.pi(cp), None, hL))
+        path = C.c_int32(-1)
+        _csx.check(lib.csx_chol_info(path, None))
+        Lp, Li, Lx = np.empty(n + 1, np.int32), np.empty(lnz, np.int32), np.empty(lnz)
+        _csx.check(lib.csx_csc_download(hL, _csx.pi(Lp), _csx.pi(Li), _csx.pd(Lx)))
+        plan, hB = _csx.new_handle(), _csx.new_handle()
+        _csx.check(lib.csx_cholsol_plan(hL, None, plan))
+        _csx.check(lib.csx_gen_rhs(n, k, 3, hB))
+        _csx.check(lib.csx_cholsol_solve(plan, hB, k))
+        X = np.empty(n * k)
+        _csx.check(lib.csx_vec_download(hB, _csx.pd(X), n * k))
+        dig = [hashlib.sha256(a.tobytes()).hexdigest() for a in (parent, cp, Lp, Li, Lx, X)]
+        for h in (plan, hB, hL):
+            _csx.free(h)
+        return path.value, dig
+
+    p1, d1 = run()
+    with _csx.option("chol.clique", 0):
+        _csx.check(lib.csx_csc_invalidate(hA))               # drop the finding csx_schol left on the matrix
+        p0, d0 = run()
+    _csx.free(hA)
+    assert (p1, p0) == (1, 0)
+    assert d1 == d0
+
+
 def test_cholsol_5m_block_spd_residual(cs, lib):
     import _csx
     nb, bs, k = 78125, 64, 128
