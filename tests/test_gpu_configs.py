@@ -87,6 +87,23 @@ def test_config3_lusol_on_W_full_size(cs):
     bl = b.tolist()
     assert cs.cs_lusol(0, A, bl, 1.0) is True
     assert np.asarray(bl).tobytes() == ref_x.tobytes()
+    # the batched form (factor once; permute, L, U, permute on the device): 70 right-hand sides, scaled copies of b, every column
+    # against the plain-C oracle's solves on the same factors
+    F = cs.lusol_factor(A, 0, 1.0)
+    scales = 1.0 + 0.5 * np.arange(70)
+    dB = cs.dvec(np.ascontiguousarray(b[:, None] * scales[None, :]))
+    assert F.solve(dB) is True
+    Xb = dB.numpy().reshape(n, 70)
+    FL, FU = F.factors.L, F.factors.U
+    fLp, fLi, fLx = (np.asarray(v) for v in (FL.p, FL.i, FL.x))
+    fUp, fUi, fUx = (np.asarray(v) for v in (FU.p, FU.i, FU.x))
+    fpinv = np.asarray(F.factors.pinv)
+    for r in (0, 33, 69):
+        pbr = np.empty(n)
+        pbr[fpinv] = b * scales[r]
+        want = CO.usolve(n, fUp.astype(np.int32), fUi.astype(np.int32), fUx,
+                         CO.lsolve(n, fLp.astype(np.int32), fLi.astype(np.int32), fLx, pbr))
+        assert Xb[:, r].tobytes() == want.tobytes(), r
     res = CO.gaxpy(n, n, Ap, Ai, Ax, ref_x, -b)
     norm1 = float(np.max(np.add.reduceat(np.abs(Ax), Ap[:-1])))
     assert np.max(np.abs(res)) <= 1e-12 * (norm1 * np.max(np.abs(ref_x)) + np.max(np.abs(b)))
