@@ -109,7 +109,8 @@ int csx_csc_info(csx_handle_t A, int32_t *m, int32_t *n, int32_t *nnz, int *has_
 int csx_csc_download(csx_handle_t A, int32_t *p, int32_t *i, double *x /* or NULL */);
 int csx_csc_ptrs(csx_handle_t A, void **d_p, void **d_i, void **d_x);
 /* csx_gaxpy caches plans on the matrix (a row-major copy, the LDS-tiled regrouping) that hold COPIES of its
- * values and structure.  Arrays handed out by csx_csc_ptrs, or wrapped by csx_csc_wrap, must not be changed
+ * values and structure; csx_schol leaves its finding there when the matrix is a forest of cliques (tree, counts, block list: pattern
+ * only), for the csx_chol that follows.  Arrays handed out by csx_csc_ptrs, or wrapped by csx_csc_wrap, must not be changed
  * in place without telling the library: call csx_csc_invalidate afterwards (drops the cached plans; the next
  * csx_gaxpy rebuilds them).  Plans that are handles of their own (csx_tri_analyse, csx_cholsol_plan) also copy
  * the values they need: rebuild them after a change. */
