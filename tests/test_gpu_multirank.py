@@ -34,6 +34,10 @@ def test_bench_two_ranks_on_one_device():
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and "cpu_baseline" not in d
+    pre = d["exchange_preflight"]                      # every exchange leg at a small size first, pass / fail per leg
+    assert pre["world"] == 2 and pre["all_ok"] is True and "running" not in pre
+    assert set(pre["legs"]) == {"factor_broadcast", "rhs_scatter", "solution_gather", "sharded_solve_api",
+                                "sharded_gaxpy_reduce_scatter", "sharded_gaxpy_row_pieces_p2p"}
     ex = d["cholsol"]["exchange"]
     assert "error" not in ex, ex
     assert ex["world"] == 2
@@ -55,6 +59,7 @@ def test_exchange_legs_on_a_real_rccl_group_of_one():
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["exchange_preflight"]["all_ok"] is True and d["exchange_preflight"]["backend"] == "rccl (libcsx)"
     ex = d["cholsol"]["exchange"]
     assert "error" not in ex, ex
     assert ex["backend"] == "rccl (libcsx)"                  # csx_comm_*: RCCL bound inside the library, no torch
@@ -63,3 +68,14 @@ def test_exchange_legs_on_a_real_rccl_group_of_one():
     assert ex["solutions_gather_to_root"]["checksums_match"] is True
     sh = d["gaxpy_one_matrix_column_sharded"]
     assert "error" not in sh and sh["rows_equal_unsharded"] is True
+
+
+def test_dry_exchange_alone_on_three_ranks():
+    """bench.py --gpus 3 --dry-exchange: only the preflight (no headline, value null), three ranks on the one device."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--dry-exchange"],
+                       env=_clean_env(CSX_SINGLE_DEVICE="1", CSX_COMM_BACKEND="gloo"),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["value"] is None and d["dry_exchange"] is True and d["n_gpus"] == 3
+    assert d["exchange_preflight"]["all_ok"] is True and len(d["exchange_preflight"]["legs"]) == 6
