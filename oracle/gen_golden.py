@@ -390,7 +390,39 @@ def sqr_fixture():
     return meta
 
 
+def batch_fixture():
+    """Blocks of right-hand sides for the batched solvers (lusol_factor, qrsol_factor: factor once, many columns): the
+    UNMODIFIED reference's cs_lusol(0, C, b, tol) and cs_qrsol(0, C, b) column by column on the square problem matrices of
+    its tests.  Column r of B is rhs(n) * (1 + r / 2) + r (csparse_test.py:123-127 scaled and shifted)."""
+    d, meta = {}, {}
+    for name in ("t1", "bcsstk01", "west0067", "fs_183_1"):
+        T, A, C, sym = get_problem(name)
+        n, k = C.n, 4
+        tol = 0.001 if sym else 1.0
+        b0 = rhs(n)
+        B = np.stack([F(b0) * (1.0 + 0.5 * r) + r for r in range(k)], axis=1)
+        XL, XQ = np.empty((n, k)), np.empty((n, k))
+        for r in range(k):
+            v = B[:, r].tolist()
+            assert R.cs_lusol(0, C, v, tol)
+            XL[:, r] = v
+            v = B[:, r].tolist()
+            assert R.cs_qrsol(0, C, v)
+            XQ[:, r] = v[:n]
+        d[name + "_B"], d[name + "_x_lusol"], d[name + "_x_qrsol"] = B, XL, XQ
+        meta[name] = dict(n=n, k=k, tol=tol)
+    np.savez_compressed(os.path.join(OUT, "solve_batches.npz"), **d)
+    return meta
+
+
 def main():
+    if sys.argv[1:] == ["batch"]:      # added to an existing fixture set without regenerating the others
+        with open(os.path.join(OUT, "meta.json")) as f:
+            meta = json.load(f)
+        meta["solve_batches"] = batch_fixture()
+        with open(os.path.join(OUT, "meta.json"), "w") as f:
+            json.dump(meta, f, indent=1, sort_keys=True)
+        return
     if sys.argv[1:] == ["sqr"]:
         print(json.dumps(sqr_fixture(), indent=1))
         return
@@ -422,6 +454,7 @@ def main():
     meta["config2_bcsstk16"] = config2_fixture()
     meta["updown"] = updown_fixture()
     meta["sqr_qr"] = sqr_fixture()
+    meta["solve_batches"] = batch_fixture()
     with open(os.path.join(OUT, "meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)
 
