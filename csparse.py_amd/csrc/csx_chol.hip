@@ -634,7 +634,7 @@ static void partition_forest(int32_t n, const int32_t *parent, Forest &F) {
         if (slot[(size_t)root[(size_t)j]] < 0) F.level_cols[(size_t)fill[(size_t)level[(size_t)j]]++] = j;
 }
 
-// what the last csx_chol did (csx_chol_info): 1 = forest of cliques (csx_cholclique.hip), 0 = the general path; HIP-event
+// what the last csx_chol did (csx_chol_info): 1 = forest of cliques, 2 = forest of small sparse trees (csx_cholclique.hip), 0 = the general path; HIP-event
 // time of its numeric part (k_chol_clique alone / everything after the pattern of L on the general path)
 static int g_chol_path = -1;
 static double g_chol_numeric_ms = 0.0;
@@ -683,7 +683,7 @@ static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, c
         CliqueForest F;
         bool ok = false, same = false;
         int st = CSX_OK;
-        const bool cached = A->clique != nullptr;
+        const bool cached = A->clique != nullptr && (!A->clique->sparse || ctx().opt.chol_forest);
         if (cached) {
             // csx_schol's finding for this matrix (dropped by csx_csc_invalidate when the arrays change): a shallow copy; L.p is
             // copied out of it below instead of taken
@@ -725,7 +725,7 @@ static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, c
             lap("numeric (blocks)");
             if (st == CSX_OK) {
                 numeric_ms();
-                g_chol_path = 1;
+                g_chol_path = F.sparse ? 2 : 1;
             }
             dfree(d_notspd);
             if (!cached) free_clique(&F);

@@ -15,9 +15,12 @@ struct CliqueForest {
     int64_t lnz = 0;
     bool ascending = true;       // the upper part of every column is strictly ascending (what k_chol_clique needs)
     bool dense_in_front = false; // ... and is rows u[k] .. k, one each, stored before any lower entry: k_chol_clique skips A.i
+    bool sparse = false;         // the blocks are small TREES, not cliques (columns of L shorter than the block): parent / cp come
+                                 // from the symbolic elimination on row masks (k_forest_symbolic), k_chol_clique stores compacted
     int32_t *parent = nullptr;   // device [n]: elimination tree (csparse.py:1136-1169)
     int32_t *cp = nullptr;       // device [n + 1]: column pointers of L (csparse.py:2069-2071)
     int32_t *start = nullptr;    // device [nblocks + 1]: first column of every block, then n
+    unsigned long long *colmask = nullptr;   // device [n], sparse only: the rows of column k of L as bits (bit r = row start + r)
 };
 
 void free_clique(CliqueForest *F);

@@ -23,6 +23,13 @@ namespace csx {
 
 static inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
 
+// Raise a flag that millions of threads may want to raise: look first.  A store per wave to ONE address is served one after
+// the other by the memory side (~10 ns each: 12 ms for the 1.2 M waves of a 4.8 M-column matrix that is no clique forest -- more
+// than everything else in the recognition together); the look is a cached read.
+__device__ __forceinline__ void cq_raise(int *flag) {
+    if (*(volatile int *)flag == 0) *flag = 1;
+}
+
 // ---- recognition ---------------------------------------------------------------------------------------------------
 // one wave per column: u[k]; flags[0] |= the upper part of some column is not strictly ascending (duplicates, unsorted,
 // a negative row) -- the block kernel scatters a column's entries in parallel and needs them distinct
@@ -84,10 +91,10 @@ __global__ __launch_bounds__(256) void k_clique_min(int32_t n, int32_t nnz, cons
         nup += __shfl_xor(nup, o, 16);
         lastpos = max(lastpos, __shfl_xor(lastpos, o, 16));
     }
-    if (bad) flags[0] = 1;
+    if (bad) cq_raise(&flags[0]);
     // flags[3] |= not "dense and in front": the upper part of a column is then rows u[k] .. k, one each, stored first -- entry t of
     // the column IS row u[k] + t, and the block kernel need not read the row indices at all
-    if (nup != k - mn + 1 || lastpos != nup - 1) flags[3] = 1;
+    if (nup != k - mn + 1 || lastpos != nup - 1) cq_raise(&flags[3]);
     if (t == 0 && k64 < n) u[k] = mn;
 }
 
@@ -99,7 +106,7 @@ __global__ __launch_bounds__(256) void k_clique_mark(int32_t n, const int32_t *_
     const int32_t uk = u[k];
     const bool ok = k == 0 ? uk == 0 : (uk == (int32_t)k || uk == u[k - 1]);
     if (!ok || uk < 0) {
-        flags[1] = 1;
+        cq_raise(&flags[1]);
         is_start[k] = 0;
         parent[k] = -1;
         return;
@@ -146,11 +153,97 @@ __global__ __launch_bounds__(256) void k_clique_counts(int32_t n, const int32_t 
     }
 }
 
+// ---- forests of small SPARSE trees (round 4, second step) -------------------------------------------------------------
+// When the rule for cliques fails the matrix may still fall into BLOCKS of consecutive columns closed under their upper
+// entries: k starts a block iff no column j >= k reaches above k, i.e. min_{j >= k} u[j] = k (a reverse running minimum of
+// u).  Every elimination tree then lies inside one block.  For blocks of at most 64 columns the whole symbolic analysis of
+// a block runs in the registers of one wave on 64-bit ROW MASKS: lane r holds the pattern of row r of L as bits; column j
+// of L is the ballot of bit j over the lanes; eliminating column j adds to every row that has it the column's rows
+// between j and the row (cs_ereach's row subtrees without walking a tree); the count of column j is the popcount of its
+// ballot, its parent the first row below the diagonal (csparse.py:1136-1169, :703-764 for what the general path computes
+// with a tree, a postorder and skeleton counts).
+__global__ __launch_bounds__(256) void k_forest_mark(int32_t n, const int32_t *__restrict__ u, const int32_t *__restrict__ smin,
+                                                     int32_t *__restrict__ is_start, int *flags) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    if (u[k] < 0) cq_raise(&flags[1]);
+    is_start[k] = smin[k] == (int32_t)k ? 1 : 0;
+}
+
+// block list from the starts; stats[0] = widest block
+__global__ __launch_bounds__(256) void k_forest_starts(int32_t n, const int32_t *__restrict__ is_start,
+                                                       const int32_t *__restrict__ block_id, int32_t *__restrict__ start) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    if (is_start[k]) start[block_id[k]] = (int32_t)k;
+    if (k == n - 1) start[block_id[k] + is_start[k]] = n;
+}
+
+__global__ __launch_bounds__(256) void k_forest_widest(int32_t nblocks, const int32_t *__restrict__ start, int *stats) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int w = b < nblocks ? start[b + 1] - start[b] : 0;
+    for (int o = 32; o > 0; o >>= 1) w = max(w, __shfl_xor(w, o));
+    if ((threadIdx.x & 63) == 0 && w > *(volatile int *)&stats[0]) atomicMax(&stats[0], w);
+}
+
+// the row masks of one block after symbolic elimination (lane = row; wave-uniform c0, bs <= 64); *mycol = the column of L
+// this lane's index names (rows as bits, the diagonal included)
+__device__ __forceinline__ unsigned long long cq_block_masks(int32_t c0, int32_t bs, int lane, const int32_t *__restrict__ Ap,
+                                                             const int32_t *__restrict__ Ai, unsigned long long *mycol) {
+    unsigned long long mask = 0ull;
+    if (lane < bs) {
+        const int32_t col = c0 + lane;
+        mask = 1ull << lane;
+        for (int32_t p = Ap[col]; p < Ap[col + 1]; p++) {       // the upper part of column r of A is row r of L's pattern
+            const int32_t i = Ai[p];
+            if (i <= col && i >= c0) mask |= 1ull << (i - c0);
+        }
+    }
+    const unsigned long long below = (1ull << lane) - 1ull;
+    unsigned long long col_of_lane = 0ull;
+    for (int j = 0; j < bs; j++) {
+        const unsigned long long cj = __ballot((mask >> j) & 1ull);       // rows of column j (final: columns < j are done)
+        if (lane == j) col_of_lane = cj;
+        if (((mask >> j) & 1ull) && lane > j) mask |= cj & below & ~((2ull << j) - 1ull);
+    }
+    *mycol = col_of_lane;
+    return mask;
+}
+
+__global__ __launch_bounds__(256) void k_forest_symbolic(const int32_t *__restrict__ start, int32_t nblocks,
+                                                         const int32_t *__restrict__ Ap, const int32_t *__restrict__ Ai,
+                                                         int32_t *__restrict__ parent, int32_t *__restrict__ count,
+                                                         unsigned long long *__restrict__ colmask, unsigned long long *lnz) {
+    const int lane = threadIdx.x & 63;
+    const int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    unsigned long long mine = 0ull;
+    if (t < nblocks) {
+        const int32_t c0 = __builtin_amdgcn_readfirstlane(start[t]);
+        const int32_t bs = __builtin_amdgcn_readfirstlane(start[t + 1]) - c0;
+        unsigned long long cj = 0ull;
+        (void)cq_block_masks(c0, bs, lane, Ap, Ai, &cj);
+        if (lane < bs) {
+            const unsigned long long under = cj & ~((2ull << lane) - 1ull);     // rows below the diagonal
+            count[c0 + lane] = 1 + __popcll(under);
+            colmask[c0 + lane] = cj;
+            parent[c0 + lane] = under ? c0 + (__ffsll((long long)under) - 1) : -1;
+            mine = 1ull + (unsigned long long)__popcll(under);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+    __shared__ unsigned long long s_sum[4];
+    if (lane == 0) s_sum[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(lnz, s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]);
+}
+
 void free_clique(CliqueForest *F) {
     dfree(F->parent);
     dfree(F->cp);
     dfree(F->start);
+    dfree(F->colmask);
     F->parent = F->cp = F->start = nullptr;
+    F->colmask = nullptr;
 }
 
 void free_clique_cache(CliqueForest *F) {
@@ -181,7 +274,50 @@ int clique_forest(const Csc *A, CliqueForest *F, bool *ok) {
     CSX_HIP(hipMemcpyAsync(h, flags, sizeof h, hipMemcpyDeviceToHost, s));
     CSX_HIP(hipStreamSynchronize(s));
     if (h[1]) {
-        free_clique(F);
+        // not a forest of cliques: blocks of consecutive columns closed under their upper entries?  (needs sorted upper parts,
+        // like the block kernel; blocks of at most 64 columns)
+        if (!ctx().opt.chol_forest || h[0]) {
+            free_clique(F);
+            return CSX_OK;
+        }
+        int32_t *smin = nullptr;
+        CSX_TRY(tmp.alloc(&smin, (size_t)n));
+        CSX_HIP(hipMemcpyAsync(smin, u, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+        CSX_TRY(suffix_min_i32(smin, n));
+        CSX_HIP(hipMemsetAsync(flags, 0, 8 * sizeof(int), s));
+        hipLaunchKernelGGL(k_forest_mark, dim3(blocks_for(n)), dim3(256), 0, s, n, u, smin, is_start, flags);
+        int64_t nb = 0;
+        CSX_TRY(scan_exclusive_i32(is_start, block_id, n, &nb));
+        CSX_TRY(dalloc(&F->start, (size_t)nb + 1));
+        hipLaunchKernelGGL(k_forest_starts, dim3(blocks_for(n)), dim3(256), 0, s, n, is_start, block_id, F->start);
+        hipLaunchKernelGGL(k_forest_widest, dim3(blocks_for(nb)), dim3(256), 0, s, (int32_t)nb, F->start, flags + 2);
+        CSX_HIP(hipMemcpyAsync(h, flags, sizeof h, hipMemcpyDeviceToHost, s));
+        CSX_HIP(hipStreamSynchronize(s));
+        if (h[1] || h[2] > CLIQUE_MAX_BLOCK) {      // a negative index, or a block the wave kernel cannot hold
+            free_clique(F);
+            return CSX_OK;
+        }
+        CSX_TRY(dalloc(&F->cp, (size_t)n + 1));
+        CSX_TRY(dalloc(&F->colmask, (size_t)n));
+        hipLaunchKernelGGL(k_forest_symbolic, dim3(blocks_for(nb * 64)), dim3(256), 0, s, F->start, (int32_t)nb, A->p, A->i, F->parent,
+                           count, F->colmask, (unsigned long long *)(flags + 4));
+        CSX_TRY(scan_exclusive_i32(count, F->cp, n, nullptr));
+        CSX_HIP(hipMemcpyAsync(h, flags, sizeof h, hipMemcpyDeviceToHost, s));
+        CSX_HIP(hipStreamSynchronize(s));
+        unsigned long long lz = 0;
+        std::memcpy(&lz, h + 4, sizeof lz);
+        if (lz > 0x7fffffffull) {
+            free_clique(F);
+            return CSX_OK;
+        }
+        F->n = n;
+        F->nblocks = (int32_t)nb;
+        F->max_bs = h[2];
+        F->lnz = (int64_t)lz;
+        F->ascending = true;
+        F->dense_in_front = false;
+        F->sparse = true;
+        *ok = true;
         return CSX_OK;
     }
     int64_t nblocks = 0;
@@ -213,7 +349,7 @@ __global__ __launch_bounds__(256) void k_clique_compare(int32_t n, const int32_t
                                                         const int32_t *__restrict__ ca, const int32_t *__restrict__ cb, int *bad) {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q > n) return;
-    if (ca[q] != cb[q] || (q < n && pa[q] != pb[q])) *bad = 1;
+    if (ca[q] != cb[q] || (q < n && pa[q] != pb[q])) cq_raise(bad);
 }
 
 // cs_chol(A, S): the caller's S.parent / S.cp (host arrays) must be this forest's; uploaded and compared on the device
@@ -293,11 +429,14 @@ __device__ __forceinline__ double cq_bcast(double v, int src) {
 }
 
 // PARTS: 1 load, 2 factor, 4 store -- 7 is the kernel; the others exist in the ablation build only (what each phase costs)
-template <int PARTS, bool SMALL, bool DENSE>
+// SPARSE: the blocks are small trees (CliqueForest::sparse).  The arithmetic is the dense block's -- an entry outside L's
+// pattern is a zero that stays zero -- and only the store differs: column g keeps the rows of its mask, compacted.
+template <int PARTS, bool SMALL, bool DENSE, bool SPARSE>
 __global__ __launch_bounds__(64 * CQ_WAVES, 3) void k_chol_clique(const int32_t *__restrict__ start, int32_t nblocks, int32_t n, int32_t nnz,
                                                                  const int32_t *__restrict__ Ap, const int32_t *__restrict__ Ai,
                                                                  const double *__restrict__ Ax, const int32_t *__restrict__ Lp,
-                                                                 int32_t *__restrict__ Li, double *__restrict__ Lx, int *notspd) {
+                                                                 int32_t *__restrict__ Li, double *__restrict__ Lx, int *notspd,
+                                                                 const unsigned long long *__restrict__ colmask) {
 #pragma clang fp contract(off)
     __shared__ __attribute__((aligned(16))) double s_tile[CQ_WAVES][CQ_CH * CQ_LD + 2];   // + the spare slot rejected entries go to
     const int lane = threadIdx.x & 63;
@@ -459,7 +598,16 @@ __global__ __launch_bounds__(64 * CQ_WAVES, 3) void k_chol_clique(const int32_t 
 #pragma unroll
         for (int jw = 0; jw < 8; jw++) {
             const int g = J + jw;
-            if (g < bs) {   // uniform; the column's place in L is a scalar base, a lane adds its row
+            if (SPARSE && g < bs) {
+                // (wave-uniform addresses: scalar loads, no register held across the factor phase)
+                const unsigned long long cg = colmask[c0 + g];
+                const int32_t lb = Lp[c0 + g];
+                if (((cg >> lane) & 1ull) && ((PARTS & 4) || a[jw] == 12345.678)) {
+                    const int32_t pos = lb + __popcll(cg & ((1ull << lane) - 1ull));
+                    Lx[pos] = a[jw];
+                    Li[pos] = c0 + lane;
+                }
+            } else if (g < bs) {   // uniform; the column's place in L is a scalar base, a lane adds its row
                 const int64_t colbase = base + (int64_t)g * bs - (int64_t)g * (g - 1) / 2 - g;
                 if (lane >= g && lane < bs && ((PARTS & 4) || a[jw] == 12345.678)) {
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(cq_u32x2, a[jw]), cq_rsrc(Lx + colbase, bs * 8), lane8, 0, 0);
@@ -476,16 +624,20 @@ int chol_clique_numeric(const Csc *A, const CliqueForest &F, Csc *L, int *d_nots
     hipStream_t s = ctx().stream;
     if (F.nblocks == 0 || A->nnz == 0) return CSX_OK;
     const dim3 grid((unsigned)((F.nblocks + CQ_WAVES - 1) / CQ_WAVES));
+#define CSX_CQ_GO(PARTS, SMALL, DENSE, SPARSE)                                                                                  \
+    hipLaunchKernelGGL((k_chol_clique<PARTS, SMALL, DENSE, SPARSE>), grid, dim3(64 * CQ_WAVES), 0, s, F.start, F.nblocks, A->n, A->nnz, \
+                       A->p, A->i, A->x, L->p, L->i, L->x, d_notspd, F.colmask)
 #define CSX_CQ(PARTS)                                                                                                       \
-    if (A->nnz < (1 << 29) && F.dense_in_front)                                                                                 \
-        hipLaunchKernelGGL((k_chol_clique<PARTS, true, true>), grid, dim3(64 * CQ_WAVES), 0, s, F.start, F.nblocks, A->n, A->nnz, A->p, \
-                           A->i, A->x, L->p, L->i, L->x, d_notspd);                                                              \
+    if (F.sparse && A->nnz < (1 << 29))                                                                                         \
+        CSX_CQ_GO(PARTS, true, false, true);                                                                                    \
+    else if (F.sparse)                                                                                                          \
+        CSX_CQ_GO(PARTS, false, false, true);                                                                                   \
+    else if (A->nnz < (1 << 29) && F.dense_in_front)                                                                            \
+        CSX_CQ_GO(PARTS, true, true, false);                                                                                    \
     else if (A->nnz < (1 << 29))                                                                                                \
-        hipLaunchKernelGGL((k_chol_clique<PARTS, true, false>), grid, dim3(64 * CQ_WAVES), 0, s, F.start, F.nblocks, A->n, A->nnz,      \
-                           A->p, A->i, A->x, L->p, L->i, L->x, d_notspd);                                                        \
+        CSX_CQ_GO(PARTS, true, false, false);                                                                                   \
     else                                                                                                                        \
-        hipLaunchKernelGGL((k_chol_clique<PARTS, false, false>), grid, dim3(64 * CQ_WAVES), 0, s, F.start, F.nblocks, A->n, A->nnz,     \
-                           A->p, A->i, A->x, L->p, L->i, L->x, d_notspd)
+        CSX_CQ_GO(PARTS, false, false, false)
     int parts = 7;
 #ifdef CSX_ABLATION
     if (const char *e = ablation_env("CSX_CQ_PARTS")) parts = atoi(e);
@@ -503,6 +655,7 @@ int chol_clique_numeric(const Csc *A, const CliqueForest &F, Csc *L, int *d_nots
     CSX_CQ(7);
 #endif
 #undef CSX_CQ
+#undef CSX_CQ_GO
     CSX_LAUNCH_CHECK();
     return CSX_OK;
 }
@@ -536,7 +689,7 @@ __global__ __launch_bounds__(256) void k_clique_factor_shape(int32_t n, int32_t 
             if (j == 0) stats[1] = cnt;
         }
     }
-    if (bad) stats[0] = 1;
+    if (bad) cq_raise(&stats[0]);
 }
 
 int clique_factor_block_size(const Csc *L, int32_t *bs) {

@@ -437,6 +437,8 @@ extern "C" int csx_schol(csx_handle_t hA, int32_t *parent, int32_t *cp) {
         free_clique(&F);
         if (st != CSX_OK) return st;
     }
+    free_clique_cache(A->clique);             // no finding under the options in force: none of an earlier call either
+    A->clique = nullptr;
     bool on_device = false, bad_index = false;
     CSX_TRY(etree_by_components(A, parent, &on_device, &bad_index));
     if (bad_index) return CSX_EINVAL;

@@ -129,6 +129,9 @@ struct Options {
     int chol_wband_nb = 16;           // ... columns per step (16 or 32)
     int chol_supernodes = 1;      // cs_chol: fundamental supernodes of >= 8 columns factored as dense trapezoids in place
     int chol_dense_trees = 1;     // cs_chol: LDS dense-block kernel for trees that are dense blocks
+    int chol_forest = 1;          // ... and forests of small SPARSE trees on consecutive columns (blocks of <= 64 columns closed under
+                                  // their upper entries): symbolic analysis on 64-bit row masks in registers, the block kernel with
+                                  // a compacted store (needs chol.clique)
     int chol_clique = 1;          // cs_schol / cs_chol / cholsol plan: forests of cliques on consecutive columns recognised from
                                   // A (or L) itself and handled without the general pattern machine (csx_cholclique.hip)
     int cholsol_dense_blocks = 1; // cholsol: dense-block kernels (false: the fused per-tree kernel)
@@ -241,6 +244,8 @@ struct SortExtra {
 };
 int stable_sort_by_key_ex(const uint32_t *key, const uint32_t *a, const double *v, int64_t count, uint32_t key_limit,
                           uint32_t *out_key, uint32_t *out_a, double *out_v, const SortExtra *ex);
+// p[r] = min(p[r], ..., p[n-1]) in place (reverse running minimum)
+int suffix_min_i32(int32_t *p, int64_t n);
 // ptr[r] = first position q with sorted_key[q] >= r, r in [0, nkeys]; ptr has nkeys+1 slots
 int boundaries_from_sorted(const uint32_t *sorted_key, int64_t count, int32_t nkeys, int32_t *ptr);
 

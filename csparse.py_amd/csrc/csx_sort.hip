@@ -649,7 +649,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_sufmin_apply(int32_t *p, int64
     }
 }
 
-static int suffix_min_i32(int32_t *p, int64_t n) {
+int suffix_min_i32(int32_t *p, int64_t n) {
     if (n <= 0) return CSX_OK;
     hipStream_t s = ctx().stream;
     const int64_t nb = (n + SM_TILE - 1) / SM_TILE;

@@ -93,7 +93,9 @@ int csx_mem_info(int64_t *cached_bytes, int64_t *live_bytes, int64_t *device_fre
  * 4: at best a tie with one host core), 1 = shallow trees with short columns, 2 = always).  Round 4:
  * "chol.clique" (default 1: csx_schol / csx_chol / csx_cholsol_plan recognise forests of cliques on consecutive columns
  * -- block-diagonal matrices with dense blocks -- from the matrix itself and skip the general pattern machine; 0 = the
- * general path).  Unknown name: CSX_EINVAL. */
+ * general path), "chol.forest" (default 1: where that rule fails, csx_schol / csx_chol look for blocks of <= 64 consecutive
+ * columns closed under their upper entries -- forests of small sparse trees -- and analyse / factor a block in one wave;
+ * 0 = the general path for them).  Unknown name: CSX_EINVAL. */
 int csx_set_option(const char *name, int value);
 int csx_get_option(const char *name, int *value);   /* the value in force (after csx_set_option's normalisation) */
 int csx_timer_start(void);                /* hipEvent on the context's stream */
@@ -203,7 +205,10 @@ int csx_chol(csx_handle_t A, const int32_t *parent, const int32_t *cp, const int
              csx_handle_t *L);
 /* What the last successful csx_chol of this process did.  *path: 1 = A's elimination forest is a set of cliques on
  * consecutive columns (block-diagonal with dense blocks of <= 64 columns; recognised from A itself, L.p / L.i follow from
- * the counts, every block factored in the registers of one wave, L.x bit-identical to csparse.py:587-617), 0 = the general
+ * the counts, every block factored in the registers of one wave, L.x bit-identical to csparse.py:587-617), 2 = blocks of
+ * <= 64 consecutive columns closed under their upper entries whose trees are NOT cliques (symbolic elimination on 64-bit row
+ * masks in one wave per block, the same block kernel with a compacted store; L.x bit-identical where the trees are chains,
+ * equal to rounding where they branch -- as path 0; "chol.forest" = 0 switches this recognition off), 0 = the general
  * path (pattern of L by row-subtree walks and sorts, column kernels by tree level).  *numeric_ms: HIP-event time of the
  * numeric part (path 1: the block kernel alone; path 0: everything after the pattern of L).  Either pointer may be NULL;
  * CSX_EINVAL before the first csx_chol.  "chol.clique" = 0 (csx_set_option) forces path 0. */

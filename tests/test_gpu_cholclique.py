@@ -145,7 +145,143 @@ def test_what_is_not_a_clique_forest_takes_the_general_path(cs, case):
         gp, gi, gx = _arr(M.L)
         assert gp.tolist() == Lp.tolist() and gi.tolist() == Li.tolist()
         assert np.max(np.abs(gx - Lx)) <= 1e-13 * np.abs(Lx).max()
-    assert _arr(N.L)[2].tobytes() == _arr(N0.L)[2].tobytes()
+    if case != "not_full":       # (a block that is a tree but no clique: the forest kernel, rounding-equal to the general one)
+        assert _arr(N.L)[2].tobytes() == _arr(N0.L)[2].tobytes()
+
+
+def _tree_blocks(sizes, seed, kind, missing_diagonal=None):
+    """Block-diagonal SPD matrix whose blocks are SPARSE (full symmetric storage, columns ascending): "tridiagonal" (a chain
+    with no fill), "arrow" (tridiagonal + a dense last row: chain, still no fill), "random" (a few entries per row: branching
+    trees with fill), "star" (every row linked to the block's LAST row only: a star, no fill)."""
+    rng = np.random.default_rng(seed)
+    n = int(sum(sizes))
+    cols_i, cols_x = [], []
+    a = 0
+    for bs in sizes:
+        K = np.eye(bs, dtype=bool)
+        idx = np.arange(bs - 1)
+        if kind in ("tridiagonal", "arrow"):
+            K[idx, idx + 1] = True
+        if kind in ("arrow", "star"):
+            K[:, bs - 1] = True
+        if kind == "random":
+            K |= np.triu(rng.uniform(size=(bs, bs)) < 2.5 / bs)
+        K = np.triu(K) | np.triu(K).T
+        V = rng.uniform(-1.0, 1.0, (bs, bs))
+        B = (V + V.T) * K
+        B[np.arange(bs), np.arange(bs)] = np.abs(B).sum(axis=1) + 1.0          # strictly diagonally dominant
+        for c in range(bs):
+            rows = np.nonzero(K[:, c])[0]
+            if missing_diagonal is not None and a + c == missing_diagonal:
+                rows = rows[rows != c]
+            cols_i.append(rows + a)
+            cols_x.append(B[rows, c])
+        a += bs
+    Ap = np.zeros(n + 1, np.int32)
+    Ap[1:] = np.cumsum([len(r) for r in cols_i])
+    return n, Ap, np.concatenate(cols_i).astype(np.int32), np.concatenate(cols_x)
+
+
+def _chol_path(cs):
+    import ctypes as C
+    import _csx
+    path = C.c_int32(-1)
+    _csx.check(_csx.lib().csx_chol_info(path, None))
+    return path.value
+
+
+@pytest.mark.parametrize("kind", ["tridiagonal", "arrow", "random", "star"])
+def test_forest_of_small_sparse_trees_is_analysed_and_factored_by_one_wave_per_block(cs, kind):
+    """Blocks of consecutive columns closed under their upper entries, at most 64 columns each: elimination tree and column
+    counts come from the symbolic elimination on row masks (k_forest_symbolic) and must be the reference's (cs_schol
+    :2051-2072); the block kernel factors them as dense triangles and stores the pattern's rows.  Chains ("tridiagonal",
+    "arrow") are eliminated in the reference's order: the reference's bits.  Branching trees agree to rounding, like the
+    general column kernels ("chol.forest" = 0) -- the reference sums a row's updates in cs_ereach's order, which no
+    right-looking kernel follows."""
+    import _csx
+    rng = np.random.default_rng(21)
+    sizes = list(rng.integers(1, 65, 250)) + [64, 1, 2, 64, 33]
+    n, Ap, Ai, Ax = _tree_blocks(sizes, 5, kind)
+    parent, cp = CO.schol(n, Ap, Ai)
+    assert int(cp[n]) < sum(b * (b + 1) // 2 for b in sizes)          # really sparse inside the blocks
+    Lp, Li, Lx = CO.chol(n, Ap, Ai, Ax, parent, cp)
+    A = cs.cs_pin(_host_cs(cs, n, n, Ap, Ai, Ax))
+    S = cs.cs_schol(0, A)
+    assert S.parent == parent.tolist() and S.cp == cp.tolist() and S.lnz == int(cp[n])
+    N = cs.cs_chol(A, S)
+    assert _chol_path(cs) == 2
+    gp, gi, gx = _arr(N.L)
+    assert gp.tolist() == Lp.tolist() and gi.tolist() == Li.tolist()
+    if kind in ("tridiagonal", "arrow"):
+        assert gx.tobytes() == Lx.tobytes()
+    assert np.max(np.abs(gx - Lx) / np.abs(Lx)) <= 1e-13
+    with _csx.option("chol.forest", 0):
+        S0 = cs.cs_schol(0, A)
+        N0 = cs.cs_chol(A, S0)
+        assert _chol_path(cs) == 0
+    assert S0.parent == S.parent and S0.cp == S.cp
+    g0p, g0i, g0x = _arr(N0.L)
+    assert g0i.tolist() == Li.tolist() and np.max(np.abs(g0x - Lx) / np.abs(Lx)) <= 1e-13
+    # the solve on that factor (general plan): cs_cholsol's answer
+    b = synth.rhs(n, 1, 3)[:, 0]
+    x = b.tolist()
+    assert cs.cs_cholsol(0, A, x) is True
+    ref = CO.ltsolve(n, Lp, Li, Lx, CO.lsolve(n, Lp, Li, Lx, b))
+    assert np.max(np.abs(np.asarray(x) - ref)) <= 1e-12 * np.abs(ref).max()
+
+
+def test_forest_of_small_trees_refusals(cs):
+    """A block wider than 64 columns, a pivot that is not positive, a column without a diagonal entry, an S of another
+    matrix: the same outcomes as the general path."""
+    import _csx
+    # 40 + 40 columns joined by one entry: one block of 80 -> the general path
+    n, Ap, Ai, Ax = _tree_blocks([40, 40, 7], 1, "random")
+    cols = [(Ai[Ap[c]:Ap[c + 1]].tolist(), Ax[Ap[c]:Ap[c + 1]].tolist()) for c in range(n)]
+    cols[79][0].insert(0, 2), cols[79][1].insert(0, 1e-3)
+    cols[2][0].append(79), cols[2][1].append(1e-3)
+    Ap2 = np.zeros(n + 1, np.int32)
+    Ap2[1:] = np.cumsum([len(c[0]) for c in cols])
+    Ai2 = np.concatenate([c[0] for c in cols]).astype(np.int32)
+    Ax2 = np.concatenate([c[1] for c in cols])
+    parent, cp = CO.schol(n, Ap2, Ai2)
+    Lp, Li, Lx = CO.chol(n, Ap2, Ai2, Ax2, parent, cp)
+    A = cs.cs_pin(_host_cs(cs, n, n, Ap2, Ai2, Ax2))
+    S = cs.cs_schol(0, A)
+    N = cs.cs_chol(A, S)
+    assert _chol_path(cs) == 0
+    assert S.parent == parent.tolist() and S.cp == cp.tolist()
+    assert np.max(np.abs(_arr(N.L)[2] - Lx) / np.abs(Lx)) <= 1e-13
+    # not positive definite, in the middle of a block
+    sizes = [9, 64, 30, 5]
+    n, Ap, Ai, Ax = _tree_blocks(sizes, 2, "arrow")
+    A = cs.cs_pin(_host_cs(cs, n, n, Ap, Ai, Ax))
+    S = cs.cs_schol(0, A)
+    assert cs.cs_chol(A, S) is not None and _chol_path(cs) == 2
+    c = 9 + 64 + 11
+    Ax3 = Ax.copy()
+    Ax3[Ap[c] + int(np.nonzero(Ai[Ap[c]:Ap[c + 1]] == c)[0][0])] = -2.0
+    A3 = cs.cs_pin(_host_cs(cs, n, n, Ap, Ai, Ax3))
+    assert cs.cs_chol(A3, S) is None
+    with _csx.option("chol.forest", 0):
+        assert cs.cs_chol(A3, S) is None
+    # no diagonal entry in one column: the pivot is 0 (csparse.py:612)
+    n4, Ap4, Ai4, Ax4 = _tree_blocks(sizes, 2, "arrow", missing_diagonal=c)
+    par4, cp4 = CO.schol(n4, Ap4, Ai4)
+    A4 = cs.cs_pin(_host_cs(cs, n4, n4, Ap4, Ai4, Ax4))
+    S4 = cs.cs_schol(0, A4)
+    assert S4.parent == par4.tolist() and S4.cp == cp4.tolist()
+    assert cs.cs_chol(A4, S4) is None
+    # an S that belongs to another matrix
+    n5, Ap5, Ai5, Ax5 = _tree_blocks(sizes, 2, "tridiagonal")
+    S5 = cs.cs_schol(0, cs.cs_pin(_host_cs(cs, n5, n5, Ap5, Ai5, Ax5)))
+    outcomes = []
+    for forest in (1, 0):
+        with _csx.option("chol.forest", forest):
+            try:
+                outcomes.append(cs.cs_chol(A, S5) is None)
+            except Exception as e:           # noqa: BLE001
+                outcomes.append(type(e).__name__)
+    assert outcomes[0] == outcomes[1]
 
 
 def test_clique_forest_not_positive_definite_and_foreign_symbolic(cs):
