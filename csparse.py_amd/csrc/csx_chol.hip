@@ -1086,6 +1086,69 @@ __global__ __launch_bounds__(256) void k_parent_of_sorted_L(int32_t n, const int
     }
 }
 
+// ---- the plan's partition on the device, for forests whose trees sit on consecutive columns -----------------------------
+// k starts a BLOCK when no column before it reaches row k or below: max_{j < k} (last row of column j) < k -- a prefix
+// maximum, taken as a reverse running minimum of the negated, reversed array (suffix_min_i32).  A block is closed under
+// L's pattern; with as many roots as blocks every block is exactly one tree, and the host's partition (trees by ascending
+// root, a tree's columns ascending: partition_forest) is the identity node list cut at the block starts.
+__global__ __launch_bounds__(256) void k_plan_reach(int32_t n, const int32_t *__restrict__ Lp, const int32_t *__restrict__ Li,
+                                                    int32_t *__restrict__ neg_rev) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const int32_t b = Lp[j], e = Lp[j + 1];
+    neg_rev[n - 1 - j] = e > b ? -Li[e - 1] : -(int32_t)j;   // rows ascending (k_parent_of_sorted_L checks): the last is the largest
+}
+
+// stats[1] += roots
+__global__ __launch_bounds__(256) void k_plan_starts(int32_t n, const int32_t *__restrict__ neg_rev_min,
+                                                     const int32_t *__restrict__ parent, int32_t *__restrict__ is_start, int *stats) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int root = 0;
+    if (k < n) {
+        is_start[k] = (k == 0 || -neg_rev_min[n - k] < (int32_t)k) ? 1 : 0;
+        root = parent[k] < 0 ? 1 : 0;
+    }
+    for (int o = 32; o > 0; o >>= 1) root += __shfl_xor(root, o);
+    __shared__ int s_roots[4];
+    if ((threadIdx.x & 63) == 0) s_roots[threadIdx.x >> 6] = root;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&stats[1], s_roots[0] + s_roots[1] + s_roots[2] + s_roots[3]);
+}
+
+__global__ __launch_bounds__(256) void k_plan_block_first(int32_t n, const int32_t *__restrict__ is_start,
+                                                          const int32_t *__restrict__ block_id, int32_t *__restrict__ start) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    if (is_start[k]) start[block_id[k]] = (int32_t)k;
+    if (k == n - 1) start[block_id[k] + is_start[k]] = n;
+}
+
+// stats[2] = widest block
+__global__ __launch_bounds__(256) void k_plan_trees(int32_t nblocks, const int32_t *__restrict__ start, Tree *__restrict__ trees,
+                                                    int *stats) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int w = 0;
+    if (b < nblocks) {
+        w = start[b + 1] - start[b];
+        trees[b] = Tree{start[b], w};
+    }
+    for (int o = 32; o > 0; o >>= 1) w = max(w, __shfl_xor(w, o));
+    if ((threadIdx.x & 63) == 0 && w > *(volatile int *)&stats[2]) atomicMax(&stats[2], w);
+}
+
+__global__ __launch_bounds__(256) void k_plan_nodes(int32_t n, const int32_t *__restrict__ is_start,
+                                                    const int32_t *__restrict__ block_id, const int32_t *__restrict__ start,
+                                                    int32_t *__restrict__ nodes, int32_t *__restrict__ local_id,
+                                                    int32_t *__restrict__ rev_pos) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int32_t b = block_id[k] + is_start[k] - 1;
+    const int32_t first = start[b], next = start[b + 1];
+    nodes[k] = (int32_t)k;
+    local_id[k] = (int32_t)k - first;
+    rev_pos[k] = first + next - 1 - (int32_t)k;
+}
+
 // ---- packing the per-tree programs (plan time) ----
 __global__ __launch_bounds__(256) void k_pack_len(int32_t n, const int32_t *__restrict__ nodes,
                                                   const int32_t *__restrict__ rev_pos,
@@ -1954,6 +2017,15 @@ static int cholsol_plan(const Csc *L, const int32_t *pinv, CholPlan **out) {
     const int32_t n = L->n;
     P->n = n;
     P->L = L;
+    const bool timing = getenv("CSX_CHOL_TIMING") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(s);
+        auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[cholsol_plan] %-22s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    };
     if (pinv) {
         std::vector<int32_t> perm((size_t)n);
         for (int32_t k = 0; k < n; k++) {
@@ -1968,7 +2040,9 @@ static int cholsol_plan(const Csc *L, const int32_t *pinv, CholPlan **out) {
         if (bs == 8 || bs == 16 || bs == 32 || bs == 64) return cholsol_plan_clique(P, bs);
     }
     CSX_TRY(tri_analyse_raw(L, CSX_TRI_L, &P->fwd));
+    lap("analysis of L");
     CSX_TRY(tri_analyse_raw(L, CSX_TRI_LT, &P->bwd));
+    lap("analysis of L'");
     tri_set_mate(P->bwd, P->fwd);   // the rounding-equal order may run L' in push form on the rows of L
     if (n == 0) return CSX_OK;
     // forest of small trees?  (needs a Cholesky-shaped L: diagonal first, rows ascending)
@@ -1980,46 +2054,100 @@ static int cholsol_plan(const Csc *L, const int32_t *pinv, CholPlan **out) {
     CSX_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), s));
     hipLaunchKernelGGL(k_parent_of_sorted_L, dim3((unsigned)(((int64_t)n + 3) / 4)), dim3(256), 0, s, n, L->p, L->i,
                        d_parent, d_flag);
-    std::vector<int32_t> parent((size_t)n);
-    int unsorted = 0;
-    CSX_HIP(hipMemcpyAsync(parent.data(), d_parent, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    CSX_HIP(hipMemcpyAsync(&unsorted, d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
-    CSX_HIP(hipStreamSynchronize(s));
-    if (unsorted) return CSX_OK;
+    // trees on consecutive columns (block-diagonal factors in their natural order): the partition without the host
+    int32_t ntrees = 0, max_tree = 0;
+    bool on_device = false;
     Forest F;
-    partition_forest(n, parent.data(), F);
-    if (!F.level_cols.empty() || F.max_tree > 256) {   // some tree is too big for LDS: the level-scheduled solves
-    {
-            // The level sets of the two solves with a Cholesky factor are heights (L x = b) and depths (L' x = b) in its
-            // elimination tree: proposed to the plans, which verify them in one pass over the pattern instead of finding
-            // them level by level (a nested-dissection factor of a 700 x 700 grid has ~3 000 levels).
-            bool tree = true;
-            for (int32_t j = 0; j < n && tree; j++) tree = parent[(size_t)j] < 0 || (parent[(size_t)j] > j && parent[(size_t)j] < n);
-            if (tree) {
-                std::vector<int32_t> height((size_t)n, 0), depth((size_t)n, 0);
-                for (int32_t j = 0; j < n; j++)
-                    if (parent[(size_t)j] >= 0)
-                        height[(size_t)parent[(size_t)j]] = std::max(height[(size_t)parent[(size_t)j]], height[(size_t)j] + 1);
-                for (int32_t j = n - 1; j >= 0; j--)
-                    if (parent[(size_t)j] >= 0) depth[(size_t)j] = depth[(size_t)parent[(size_t)j]] + 1;
-                for (int32_t j = 0; j < n; j++) P->col_levels = std::max(P->col_levels, height[(size_t)j] + 1);
-                P->parent_h = parent;
-                tri_set_level_hint(P->fwd, std::move(height));
-                tri_set_level_hint(P->bwd, std::move(depth));
+    if (ctx().opt.chol_clique && ctx().opt.chol_forest) {
+        int32_t *nrm = nullptr, *is_start = nullptr, *block_id = nullptr, *start = nullptr;
+        int *stats = nullptr;   // [0] spare, [1] roots, [2] widest block
+        CSX_TRY(tmp.alloc(&nrm, (size_t)n));
+        CSX_TRY(tmp.alloc(&is_start, (size_t)n + 1));
+        CSX_TRY(tmp.alloc(&block_id, (size_t)n + 1));
+        CSX_TRY(tmp.alloc(&stats, 4));
+        CSX_HIP(hipMemsetAsync(stats, 0, 4 * sizeof(int), s));
+        const unsigned nbk = (unsigned)(((int64_t)n + 255) / 256);
+        hipLaunchKernelGGL(k_plan_reach, dim3(nbk), dim3(256), 0, s, n, L->p, L->i, nrm);
+        CSX_TRY(suffix_min_i32(nrm, n));
+        hipLaunchKernelGGL(k_plan_starts, dim3(nbk), dim3(256), 0, s, n, nrm, d_parent, is_start, stats);
+        int64_t nblocks = 0;
+        CSX_TRY(scan_exclusive_i32(is_start, block_id, n, &nblocks));
+        int hs[4] = {0, 0, 0, 0}, unsorted = 0;
+        CSX_HIP(hipMemcpyAsync(hs, stats, sizeof hs, hipMemcpyDeviceToHost, s));
+        CSX_HIP(hipMemcpyAsync(&unsorted, d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+        CSX_HIP(hipStreamSynchronize(s));
+        if (unsorted) return CSX_OK;
+        if (hs[1] == nblocks) {                  // one root to a block: the blocks ARE the trees
+            CSX_TRY(tmp.alloc(&start, (size_t)nblocks + 1));
+            CSX_TRY(dalloc(&P->trees, (size_t)nblocks));
+            hipLaunchKernelGGL(k_plan_block_first, dim3(nbk), dim3(256), 0, s, n, is_start, block_id, start);
+            hipLaunchKernelGGL(k_plan_trees, dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, s, (int32_t)nblocks, start, P->trees,
+                               stats);
+            CSX_HIP(hipMemcpyAsync(hs, stats, sizeof hs, hipMemcpyDeviceToHost, s));
+            CSX_HIP(hipStreamSynchronize(s));
+            if (hs[2] <= 256) {
+                CSX_TRY(dalloc(&P->tree_nodes, (size_t)n));
+                CSX_TRY(dalloc(&P->local_id, (size_t)n));
+                CSX_TRY(dalloc(&P->rev_pos, (size_t)n));
+                hipLaunchKernelGGL(k_plan_nodes, dim3(nbk), dim3(256), 0, s, n, is_start, block_id, start, P->tree_nodes, P->local_id,
+                                   P->rev_pos);
+                CSX_LAUNCH_CHECK();
+                ntrees = (int32_t)nblocks;
+                max_tree = hs[2];
+                on_device = true;
+                lap("partition (device)");
+            } else {
+                dfree(P->trees);
+                P->trees = nullptr;
             }
         }
-        return CSX_OK;
     }
-    std::vector<int32_t> local((size_t)n, 0);
-    for (const Tree &t : F.small)
-        for (int32_t a = 0; a < t.count; a++) local[(size_t)F.small_cols[(size_t)(t.first + a)]] = a;
-    CSX_TRY(upload(&P->trees, F.small));
-    CSX_TRY(upload(&P->tree_nodes, F.small_cols));
-    CSX_TRY(upload(&P->local_id, local));
-    std::vector<int32_t> rev((size_t)n, 0);
-    for (const Tree &t : F.small)
-        for (int32_t a = 0; a < t.count; a++) rev[(size_t)(t.first + a)] = t.first + t.count - 1 - a;
-    CSX_TRY(upload(&P->rev_pos, rev));
+    if (!on_device) {
+        std::vector<int32_t> parent((size_t)n);
+        int unsorted = 0;
+        CSX_HIP(hipMemcpyAsync(parent.data(), d_parent, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        CSX_HIP(hipMemcpyAsync(&unsorted, d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+        CSX_HIP(hipStreamSynchronize(s));
+        if (unsorted) return CSX_OK;
+        lap("parent of L");
+        partition_forest(n, parent.data(), F);
+        lap("partition (host)");
+        if (!F.level_cols.empty() || F.max_tree > 256) {   // some tree is too big for LDS: the level-scheduled solves
+        {
+                // The level sets of the two solves with a Cholesky factor are heights (L x = b) and depths (L' x = b) in its
+                // elimination tree: proposed to the plans, which verify them in one pass over the pattern instead of finding
+                // them level by level (a nested-dissection factor of a 700 x 700 grid has ~3 000 levels).
+                bool tree = true;
+                for (int32_t j = 0; j < n && tree; j++) tree = parent[(size_t)j] < 0 || (parent[(size_t)j] > j && parent[(size_t)j] < n);
+                if (tree) {
+                    std::vector<int32_t> height((size_t)n, 0), depth((size_t)n, 0);
+                    for (int32_t j = 0; j < n; j++)
+                        if (parent[(size_t)j] >= 0)
+                            height[(size_t)parent[(size_t)j]] = std::max(height[(size_t)parent[(size_t)j]], height[(size_t)j] + 1);
+                    for (int32_t j = n - 1; j >= 0; j--)
+                        if (parent[(size_t)j] >= 0) depth[(size_t)j] = depth[(size_t)parent[(size_t)j]] + 1;
+                    for (int32_t j = 0; j < n; j++) P->col_levels = std::max(P->col_levels, height[(size_t)j] + 1);
+                    P->parent_h = parent;
+                    tri_set_level_hint(P->fwd, std::move(height));
+                    tri_set_level_hint(P->bwd, std::move(depth));
+                }
+            }
+            return CSX_OK;
+        }
+        std::vector<int32_t> local((size_t)n, 0);
+        for (const Tree &t : F.small)
+            for (int32_t a = 0; a < t.count; a++) local[(size_t)F.small_cols[(size_t)(t.first + a)]] = a;
+        CSX_TRY(upload(&P->trees, F.small));
+        CSX_TRY(upload(&P->tree_nodes, F.small_cols));
+        CSX_TRY(upload(&P->local_id, local));
+        std::vector<int32_t> rev((size_t)n, 0);
+        for (const Tree &t : F.small)
+            for (int32_t a = 0; a < t.count; a++) rev[(size_t)(t.first + a)] = t.first + t.count - 1 - a;
+        CSX_TRY(upload(&P->rev_pos, rev));
+        lap("node lists (host)");
+        ntrees = (int32_t)F.small.size();
+        max_tree = F.max_tree;
+    }
     const int32_t *Gp, *Gi;
     const double *Gx, *Gd;
     tri_gather_arrays(P->fwd, &Gp, &Gi, &Gx, &Gd);
@@ -2045,11 +2173,13 @@ static int cholsol_plan(const Csc *L, const int32_t *pinv, CholPlan **out) {
                        P->b_idx, P->b_val, P->diagk, P->diagb);
     CSX_LAUNCH_CHECK();
     CSX_HIP(hipStreamSynchronize(s));
-    P->ntrees = (int32_t)F.small.size();
-    P->max_nodes = F.max_tree;
+    P->ntrees = ntrees;
+    P->max_nodes = max_tree;
     P->local = true;
+    lap("programs packed");
     // dense blocks? same size, contiguous rows, column c of a block holding exactly bs - c entries
-    const int32_t bs = F.max_tree;
+    // (a forest partitioned on the device is no forest of equal dense blocks: cholsol_plan_clique would have taken it)
+    const int32_t bs = on_device ? 0 : F.max_tree;
     if (bs == 8 || bs == 16 || bs == 32 || bs == 64) {
         std::vector<int32_t> hLp((size_t)n + 1);
         CSX_HIP(hipMemcpyAsync(hLp.data(), L->p, ((size_t)n + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s));

@@ -230,6 +230,46 @@ def test_forest_of_small_sparse_trees_is_analysed_and_factored_by_one_wave_per_b
     assert np.max(np.abs(np.asarray(x) - ref)) <= 1e-12 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("kind", ["tridiagonal", "arrow", "star", "random", "wide"])
+def test_plan_partition_on_the_device_equals_the_hosts(cs, kind):
+    """csx_cholsol_plan partitions a factor whose trees sit on consecutive columns without the host (block starts from a
+    prefix maximum of the columns' last rows; one root to a block).  Same trees, same node lists, same programs as the
+    host's partition_forest ("chol.forest" = 0): csx_cholsol_info equal and every solution bit for bit; "random" has
+    blocks holding several trees (the device hands over to the host), "wide" a tree of 300 columns (level-scheduled)."""
+    import _csx
+    lib = _csx.lib()
+    rng = np.random.default_rng(4)
+    sizes = list(rng.integers(1, 65, 120)) + [1, 64, 2]
+    if kind == "wide":
+        sizes = [300, 5, 40]
+    n, Ap, Ai, Ax = _tree_blocks(sizes, 9, "arrow" if kind == "wide" else kind)
+    A = cs.cs_pin(_host_cs(cs, n, n, Ap, Ai, Ax))
+    S = cs.cs_schol(0, A)
+    N = cs.cs_chol(A, S)
+    gLp, gLi, gLx = _arr(N.L)
+    L2 = cs.cs_pin(_host_cs(cs, n, n, gLp, gLi, gLx))
+    k = 70
+    B = synth.rhs(n, k, 1)
+    out = []
+    for forest in (1, 0):
+        with _csx.option("chol.forest", forest):
+            plan = _csx.new_handle()
+            _csx.check(lib.csx_cholsol_plan(L2._dev.handle, None, plan))
+            a, b, c = _csx.C.c_int32(), _csx.C.c_int32(), _csx.C.c_int32()
+            _csx.check(lib.csx_cholsol_info(plan, a, b, c))
+            dB = cs.dvec(B)
+            _csx.check(lib.csx_cholsol_solve(plan, dB.handle, k))
+            out.append(((a.value, b.value, c.value), dB.numpy().copy()))
+            _csx.free(plan)
+    assert out[0][0] == out[1][0]
+    if kind in ("tridiagonal", "arrow", "star"):
+        assert out[0][0] == (1, len(sizes), max(sizes))
+    assert out[0][1].tobytes() == out[1][1].tobytes()
+    for r in (0, 33, k - 1):
+        ref = CO.ltsolve(n, gLp, gLi, gLx, CO.lsolve(n, gLp, gLi, gLx, B[:, r]))
+        assert out[0][1][:, r].tobytes() == ref.tobytes()
+
+
 def test_forest_of_small_trees_refusals(cs):
     """A block wider than 64 columns, a pivot that is not positive, a column without a diagonal entry, an S of another
     matrix: the same outcomes as the general path."""

@@ -126,6 +126,7 @@ while time.time() < t_end:
         got = np.asarray(N.L.x[:lnz])
         path = _csx.C.c_int32(-1)
         _csx.check(_csx.lib().csx_chol_info(path, None))
+        counts["chol_path_%d" % path.value] = counts.get("chol_path_%d" % path.value, 0) + 1   # 1 cliques, 2 small trees, 0 general
         if path.value == 1:
             assert got.tobytes() == Lx.tobytes(), ("clique chol values", seed, n)
         else:
