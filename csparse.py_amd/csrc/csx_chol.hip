@@ -1689,6 +1689,15 @@ __global__ __launch_bounds__(256, 3) void k_cholsol_dense_exact_dpp(const Tree *
         if (live) B[(int64_t)row * nrhs + rhs] = x[a];
     }
 }
+// (Round 4 tried the L values as SCALAR operands: a lane is a right-hand side, so an L value is the same for the whole wave,
+// v_mul_f64 takes a scalar register, and a term is then the reference's two operations and nothing else.  The packed rows read
+// with s_load_dwordx16 off a wave-uniform base, every line of the block touched by one vector load first so that the scalar
+// loads find it in L2; bit-identical, 8.3 ms at blocks of 64 against 4.7 for the DPP form, 3.0 against 2.9 at blocks of 32: a
+// scalar load that misses the 16 KB scalar cache returns after ~650 cycles, all of a wave's scalar loads share ONE counter that
+// can only be waited down to zero, and ~100 scalar registers hold 16 values to wait behind -- 250 exposed round trips per
+// wave.  The division by the diagonal as a multiplication by its correctly rounded reciprocal with two exact corrections
+// (Markstein) was built with it, bit-identical, and saves nothing: the compiler's IEEE division is 13 instructions here, not
+// 35.  Removed; profiles/r04_ablation.md section 7.)
 #pragma clang fp contract(fast)
 
 // ---- dense blocks on the matrix cores -------------------------------------------------------------------
