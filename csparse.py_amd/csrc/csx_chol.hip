@@ -2411,14 +2411,13 @@ static int cholsol_solve(CholPlan *P, double *B, int32_t nrhs) {
             return CSX_OK;
         }
         const size_t per_wave = (size_t)P->max_nodes * 64 * sizeof(double);
-        int waves = (int)std::min<size_t>(CH_WAVES, (128 * 1024) / per_wave);
-        if (waves < 1) waves = 1;
+        const int waves = tile_waves_per_workgroup(per_wave, CH_WAVES);
         const int32_t chunks = (nrhs + 63) / 64;
         const int64_t tasks = (int64_t)P->ntrees * chunks;
         const size_t lds = per_wave * (size_t)waves;
         CSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cholsol_local),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-        hipLaunchKernelGGL(k_cholsol_local, dim3((unsigned)((tasks + waves - 1) / waves)), dim3(64 * CH_WAVES), lds, s,
+        hipLaunchKernelGGL(k_cholsol_local, dim3((unsigned)((tasks + waves - 1) / waves)), dim3(64 * waves), lds, s,
                            P->trees, P->ntrees, P->tree_nodes, P->perm, P->f_ptr, P->f_idx, P->f_val, P->b_ptr, P->b_idx,
                            P->b_val, P->diagk, P->diagb, B, nrhs, chunks, P->max_nodes, waves);
         CSX_LAUNCH_CHECK();

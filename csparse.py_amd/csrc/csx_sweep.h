@@ -22,6 +22,25 @@ int connected_components(int32_t n, const int32_t *ptr, const int32_t *idx, int 
 int group_by_root(int32_t n, const int32_t *root, uint32_t *nodes, int32_t *comp_of_pos, Tree **comps_out,
                   int32_t *ncomp_out, int32_t *max_count);
 
+// A wave of the fused sweeps owns an X tile of `per_wave` bytes of LDS.  Waves per workgroup (1 .. maxw) that put the most
+// waves on a CU (160 KB of LDS); of equal choices the smallest workgroup (the last round of a launch fills better).  W's
+// 67-row components (34 KB a wave): 1 x 4 workgroups instead of 3 x 1 -- the old rule capped a workgroup at 128 KB.
+inline int tile_waves_per_workgroup(size_t per_wave, int maxw) {
+    const size_t cu = 160 * 1024 - 1024;
+    int best = 1;
+    size_t best_total = 0;
+    for (int w = 1; w <= maxw; w++) {
+        const size_t per_wg = per_wave * (size_t)w;
+        if (per_wg > cu) break;
+        const size_t total = (cu / per_wg) * (size_t)w;
+        if (total > best_total) {
+            best_total = total;
+            best = w;
+        }
+    }
+    return best;
+}
+
 #pragma clang fp contract(off)
 struct TermRegs {  // up to 64 terms of one row, one per lane
     int32_t i;

@@ -1755,8 +1755,7 @@ static int solve_components(TriPlan *P, double *X, int32_t nrhs) {
         return CSX_OK;
     }
     const size_t per_wave = (size_t)P->comp_max * 64 * sizeof(double);
-    int waves = (int)std::min<size_t>(TL_WAVES_MAX, (128 * 1024) / per_wave);
-    if (waves < 1) waves = 1;
+    const int waves = tile_waves_per_workgroup(per_wave, TL_WAVES_MAX);
     const int32_t chunks = (nrhs + 63) / 64;
     const int64_t tasks = (int64_t)P->ncomp * chunks;
     const size_t lds = per_wave * (size_t)waves;
@@ -1764,12 +1763,12 @@ static int solve_components(TriPlan *P, double *X, int32_t nrhs) {
     if (P->forward) {
         CSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tri_local<true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-        hipLaunchKernelGGL(k_tri_local<true>, grid, dim3(64 * TL_WAVES_MAX), lds, s, P->comps, P->ncomp, P->comp_nodes,
+        hipLaunchKernelGGL(k_tri_local<true>, grid, dim3(64 * waves), lds, s, P->comps, P->ncomp, P->comp_nodes,
                            P->prog_ptr, P->prog_idx, P->prog_val, P->prog_diag, X, nrhs, chunks, P->comp_max, waves);
     } else {
         CSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tri_local<false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-        hipLaunchKernelGGL(k_tri_local<false>, grid, dim3(64 * TL_WAVES_MAX), lds, s, P->comps, P->ncomp, P->comp_nodes,
+        hipLaunchKernelGGL(k_tri_local<false>, grid, dim3(64 * waves), lds, s, P->comps, P->ncomp, P->comp_nodes,
                            P->prog_ptr, P->prog_idx, P->prog_val, P->prog_diag, X, nrhs, chunks, P->comp_max, waves);
     }
     CSX_LAUNCH_CHECK();

@@ -47,5 +47,21 @@ for rep in range(reps):
     _csx.sync()
     t3 = time.perf_counter()
     print("csx_schol %.1f ms  csx_chol %.1f ms  csx_cholsol_plan %.1f ms  lnz %d" % (1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (t3 - t2), int(cp[n])), flush=True)
+    if rep == reps - 1:      # the solve phase on that plan: 128 right-hand sides, both orders
+        k = 128
+        for exact in (1, 0):
+            _csx.check(lib.csx_cholsol_set_order(plan, exact))
+            hB = _csx.new_handle()
+            _csx.check(lib.csx_gen_rhs(n, k, 0, hB))
+            _csx.check(lib.csx_cholsol_solve(plan, hB, k))
+            with _csx.Timer() as tm:
+                for _ in range(5):
+                    _csx.check(lib.csx_cholsol_solve(plan, hB, k))
+            a, b, c = _csx.C.c_int32(), _csx.C.c_int32(), _csx.C.c_int32()
+            _csx.check(lib.csx_cholsol_info(plan, a, b, c))
+            gb = (12.0 * int(cp[n]) * 2 + 16.0 * n * k) / 1e9
+            print("cholsol solve, %d right-hand sides, exact=%d: %.3f ms (path %d, %d trees, widest %d; %.2f GB fused count -> %.0f GB/s)"
+                  % (k, exact, tm.ms / 5, a.value, b.value, c.value, gb, gb / (tm.ms / 5 / 1e3)), flush=True)
+            _csx.free(hB)
     _csx.free(plan)
     _csx.free(hL)

@@ -13,7 +13,7 @@ n, Ap, Ai, Ax = _w_matrix(1493)
 A = _host_cs(cs, n, n, Ap, Ai, Ax)
 N = cs.cs_lu(A, cs.cs_sqr(0, A, False), 1.0)
 L, U = cs.cs_pin(N.L), cs.cs_pin(N.U)
-for k in (1, 8, 64, 256):
+for k in (1, 8, 64, 256, 1024):
     X = cs.dvec(np.ones((n, k)) if k > 1 else np.ones(n))
     cs.cs_lsolve(L, X); cs.cs_usolve(U, X)
     pl, pu = L._dev.plans[cs.TRI_L], U._dev.plans[cs.TRI_U]
