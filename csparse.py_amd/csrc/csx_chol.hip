@@ -1209,7 +1209,7 @@ __global__ __launch_bounds__(64 * CH_WAVES) void k_cholsol_local(
     const bool live = rhs < nrhs;
     double *X = xt + (size_t)w * max_nodes * 64;
     // rows of B owned by this tree: ids fetched coalesced (64 at a time), handed out by v_readlane;
-    // eight row loads are kept in flight
+    // sixteen row loads are kept in flight
     for (int32_t c0 = 0; c0 < tr.count; c0 += 64) {
         const int32_t crow = min(64, tr.count - c0);
         int32_t jrow = 0;
@@ -1217,15 +1217,15 @@ __global__ __launch_bounds__(64 * CH_WAVES) void k_cholsol_local(
             jrow = nodes[tr.first + c0 + lane];
             if (perm) jrow = perm[jrow];
         }
-        for (int32_t r0 = 0; r0 < crow; r0 += 8) {
-            double tmp[8];
+        for (int32_t r0 = 0; r0 < crow; r0 += 16) {
+            double tmp[16];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
+            for (int u = 0; u < 16; u++) {
                 const int32_t row = __builtin_amdgcn_readlane(jrow, min(r0 + u, crow - 1));
                 tmp[u] = B[(int64_t)row * nrhs + (live ? rhs : nrhs - 1)];  // clamped: safe unpredicated
             }
 #pragma unroll
-            for (int u = 0; u < 8; u++)
+            for (int u = 0; u < 16; u++)
                 if (r0 + u < crow) X[(c0 + r0 + u) * 64 + lane] = tmp[u];
         }
     }

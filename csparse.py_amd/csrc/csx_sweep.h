@@ -121,12 +121,15 @@ __device__ __forceinline__ void sweep(const Tree tr, const int32_t *__restrict__
     }
     for (int32_t w0 = tbase; w0 < tend; w0 += 64 * SW_SLOTS) {
         TermRegs T[SW_SLOTS];
+        // (slots past the program's end are skipped by a wave-uniform branch, not by 64 idle lanes: a tree of 45 terms has one)
 #pragma unroll
-        for (int sl = 0; sl < SW_SLOTS; sl++) T[sl] = load_terms(idx, val, w0 + 64 * sl, tend, lane);
+        for (int sl = 0; sl < SW_SLOTS; sl++)
+            if (w0 + 64 * sl < tend) T[sl] = load_terms(idx, val, w0 + 64 * sl, tend, lane);
 #pragma unroll
         for (int sl = 0; sl < SW_SLOTS; sl++) {
             const int32_t s0 = w0 + 64 * sl;
-            const int ulim = min(64, tend - s0);  // <= 0 past the end: nothing to do
+            if (s0 >= tend) break;
+            const int ulim = min(64, tend - s0);
             int u = 0;
             while (u < ulim) {
                 while (s0 + u == rend) CSX_FINALIZE_ROW

@@ -545,15 +545,15 @@ __global__ __launch_bounds__(64 * TL_WAVES_MAX) void k_tri_local(const Tree *__r
     for (int32_t c0 = 0; c0 < tr.count; c0 += 64) {
         const int32_t crow = min(64, tr.count - c0);
         const int32_t jrow = lane < crow ? nodes[tr.first + c0 + lane] : 0;
-        for (int32_t r0 = 0; r0 < crow; r0 += 8) {
-            double tmp[8];
+        for (int32_t r0 = 0; r0 < crow; r0 += 16) {
+            double tmp[16];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
+            for (int u = 0; u < 16; u++) {
                 const int32_t row = __builtin_amdgcn_readlane(jrow, min(r0 + u, crow - 1));
                 tmp[u] = B[(int64_t)row * nrhs + rl];
             }
 #pragma unroll
-            for (int u = 0; u < 8; u++)
+            for (int u = 0; u < 16; u++)
                 if (r0 + u < crow) X[(c0 + r0 + u) * 64 + lane] = tmp[u];
         }
     }
