@@ -31,7 +31,10 @@ for rep in range(reps):
     _csx.check(lib.csx_cholsol_plan(hL, None, plan), "plan")
     _csx.sync()
     t3 = time.perf_counter()
-    print("clique %d  csx_schol %.1f ms  csx_chol %.1f ms  csx_cholsol_plan %.1f ms  total %.1f ms  lnz %d" %
-          (clique, 1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (t3 - t2), 1e3 * (t3 - t0), int(cp[n])), flush=True)
+    _csx.check(lib.csx_cholsol_set_order(plan, 0), "order")      # the rounding-equal order: matrix-core fragments are built here
+    _csx.sync()
+    t4 = time.perf_counter()
+    print("clique %d  csx_schol %.1f ms  csx_chol %.1f ms  csx_cholsol_plan %.1f ms  total %.1f ms  lnz %d   (+ csx_cholsol_set_order(0) %.1f ms)" %
+          (clique, 1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (t3 - t2), 1e3 * (t3 - t0), int(cp[n]), 1e3 * (t4 - t3)), flush=True)
     _csx.free(plan)
     _csx.free(hL)
