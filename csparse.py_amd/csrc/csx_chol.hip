@@ -1072,15 +1072,17 @@ void free_cholplan(CholPlan *P) {
     delete P;
 }
 
+// G lanes to a column (4 where the columns are short)
+template <int G>
 __global__ __launch_bounds__(256) void k_parent_of_sorted_L(int32_t n, const int32_t *__restrict__ Lp,
                                                             const int32_t *__restrict__ Li, int32_t *parent,
                                                             int *unsorted) {
-    const int lane = threadIdx.x & 63;
-    const int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & (G - 1);
+    const int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     if (j >= n) return;
     const int32_t b = Lp[j], e = Lp[j + 1];
     if (lane == 0) parent[j] = e - b > 1 ? Li[b + 1] : -1;
-    for (int32_t p = b + lane; p < e; p += 64) {
+    for (int32_t p = b + lane; p < e; p += G) {
         const int32_t r = Li[p];
         if ((p == b && r != j) || (p > b && r <= Li[p - 1])) *unsorted = 1;
     }
@@ -1161,6 +1163,7 @@ __global__ __launch_bounds__(256) void k_pack_len(int32_t n, const int32_t *__re
     blen[rev_pos[k]] = Lp[j + 1] - Lp[j] - 1;  // the backward sweep visits a tree's rows in reverse
 }
 
+template <int G>
 __global__ __launch_bounds__(256) void k_pack_fill(int32_t n, const int32_t *__restrict__ nodes,
                                                    const int32_t *__restrict__ rev_pos,
                                                    const int32_t *__restrict__ local_id,
@@ -1170,17 +1173,17 @@ __global__ __launch_bounds__(256) void k_pack_fill(int32_t n, const int32_t *__r
                                                    const int32_t *__restrict__ f_ptr, int32_t *f_idx, double *f_val,
                                                    const int32_t *__restrict__ b_ptr, int32_t *b_idx, double *b_val,
                                                    double *diagf, double *diagb) {
-    const int lane = threadIdx.x & 63;
-    const int64_t k = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & (G - 1);
+    const int64_t k = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     if (k >= n) return;
     const int32_t j = nodes[k], kb = rev_pos[k];
     const int32_t gb = Gp[j], fl = Gp[j + 1] - gb, fo = f_ptr[k];
-    for (int32_t q = lane; q < fl; q += 64) {
+    for (int32_t q = lane; q < fl; q += G) {
         f_idx[fo + q] = local_id[Gi[gb + q]] * 64;  // premultiplied: X tile is [node][64 lanes]
         f_val[fo + q] = Gx[gb + q];
     }
     const int32_t lb = Lp[j] + 1, bl = Lp[j + 1] - lb, bo = b_ptr[kb];
-    for (int32_t q = lane; q < bl; q += 64) {
+    for (int32_t q = lane; q < bl; q += G) {
         b_idx[bo + q] = local_id[Li[lb + q]] * 64;
         b_val[bo + q] = Lx[lb + q];
     }
@@ -2074,8 +2077,13 @@ static int cholsol_plan(const Csc *L, const int32_t *pinv, CholPlan **out) {
     CSX_TRY(tmp.alloc(&d_parent, (size_t)n));
     CSX_TRY(tmp.alloc(&d_flag, 1));
     CSX_HIP(hipMemsetAsync(d_flag, 0, sizeof(int), s));
-    hipLaunchKernelGGL(k_parent_of_sorted_L, dim3((unsigned)(((int64_t)n + 3) / 4)), dim3(256), 0, s, n, L->p, L->i,
-                       d_parent, d_flag);
+    const bool short_cols = (int64_t)L->nnz < 8 * (int64_t)n;     // a wave per column of three entries is 61 idle lanes
+    if (short_cols)
+        hipLaunchKernelGGL(k_parent_of_sorted_L<4>, dim3((unsigned)(((int64_t)n + 63) / 64)), dim3(256), 0, s, n, L->p, L->i, d_parent,
+                           d_flag);
+    else
+        hipLaunchKernelGGL(k_parent_of_sorted_L<64>, dim3((unsigned)(((int64_t)n + 3) / 4)), dim3(256), 0, s, n, L->p, L->i, d_parent,
+                           d_flag);
     // trees on consecutive columns (block-diagonal factors in their natural order): the partition without the host
     int32_t ntrees = 0, max_tree = 0;
     bool on_device = false;
@@ -2190,9 +2198,14 @@ static int cholsol_plan(const Csc *L, const int32_t *pinv, CholPlan **out) {
     CSX_TRY(dalloc(&P->f_val, (size_t)ftot + 128));
     CSX_TRY(dalloc(&P->b_idx, (size_t)btot + 8));
     CSX_TRY(dalloc(&P->b_val, (size_t)btot + 128));
-    hipLaunchKernelGGL(k_pack_fill, dim3((unsigned)(((int64_t)n + 3) / 4)), dim3(256), 0, s, n, P->tree_nodes,
-                       P->rev_pos, P->local_id, Gp, Gi, Gx, L->p, L->i, L->x, P->f_ptr, P->f_idx, P->f_val, P->b_ptr,
-                       P->b_idx, P->b_val, P->diagk, P->diagb);
+    if (short_cols)
+        hipLaunchKernelGGL(k_pack_fill<4>, dim3((unsigned)(((int64_t)n + 63) / 64)), dim3(256), 0, s, n, P->tree_nodes, P->rev_pos,
+                           P->local_id, Gp, Gi, Gx, L->p, L->i, L->x, P->f_ptr, P->f_idx, P->f_val, P->b_ptr, P->b_idx, P->b_val,
+                           P->diagk, P->diagb);
+    else
+        hipLaunchKernelGGL(k_pack_fill<64>, dim3((unsigned)(((int64_t)n + 3) / 4)), dim3(256), 0, s, n, P->tree_nodes, P->rev_pos,
+                           P->local_id, Gp, Gi, Gx, L->p, L->i, L->x, P->f_ptr, P->f_idx, P->f_val, P->b_ptr, P->b_idx, P->b_val,
+                           P->diagk, P->diagb);
     CSX_LAUNCH_CHECK();
     CSX_HIP(hipStreamSynchronize(s));
     P->ntrees = ntrees;

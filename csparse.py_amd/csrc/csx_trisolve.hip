@@ -124,12 +124,14 @@ __global__ __launch_bounds__(256) void k_check_columns(int32_t n, const int32_t 
     if (j < n && Tp[j + 1] <= Tp[j]) *bad = 1;
 }
 
-// out = T without the first entry of each column (same column order)
+// out = T without the first entry of each column (same column order); G lanes to a column (4 where columns are short: a wave
+// per column of three entries is 61 idle lanes, 1.05 ms at 4.8M columns)
+template <int G>
 __global__ __launch_bounds__(256) void k_strip_first(int32_t n, const int32_t *Tp, const int32_t *Ti, const double *Tx,
                                                      int32_t *op, int32_t *oi, double *ox, double *diag) {
-    const int lane = threadIdx.x & 63;
-    int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int lane = threadIdx.x & (G - 1);
+    int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) / G;
     for (int64_t j = wave; j <= n; j += nwaves) {
         if (j == n) {
             if (lane == 0) op[n] = Tp[n] - n;
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(256) void k_strip_first(int32_t n, const int32_t *T
             op[j] = ob;
             diag[j] = Tx[b];
         }
-        for (int32_t p = b + 1 + lane; p < e; p += 64) {
+        for (int32_t p = b + 1 + lane; p < e; p += G) {
             oi[ob + (p - b - 1)] = Ti[p];
             ox[ob + (p - b - 1)] = Tx[p];
         }
@@ -1844,8 +1846,12 @@ static int analyse(const Csc *T, int kind, TriPlan **out) {
         if (st == CSX_OK) st = dalloc(&S.x, (size_t)S.nnz);
         if (st == CSX_OK) {
             int64_t blocks = std::min<int64_t>(((int64_t)n + 4) / 4, 65536);
-            if (kind == CSX_TRI_L)
-                hipLaunchKernelGGL(k_strip_first, dim3((unsigned)blocks), dim3(256), 0, s, n, T->p, T->i, T->x, S.p, S.i,
+            const bool short_cols = (int64_t)T->nnz < 8 * (int64_t)n;
+            if (kind == CSX_TRI_L && short_cols)
+                hipLaunchKernelGGL(k_strip_first<4>, dim3((unsigned)std::min<int64_t>(((int64_t)n + 64) / 64, 65536)), dim3(256), 0, s, n,
+                                   T->p, T->i, T->x, S.p, S.i, S.x, P->diag);
+            else if (kind == CSX_TRI_L)
+                hipLaunchKernelGGL(k_strip_first<64>, dim3((unsigned)blocks), dim3(256), 0, s, n, T->p, T->i, T->x, S.p, S.i,
                                    S.x, P->diag);
             else
                 hipLaunchKernelGGL(k_strip_last_reverse, dim3((unsigned)blocks), dim3(256), 0, s, n, T->p, T->i, T->x,
