@@ -164,6 +164,86 @@ def test_clique_forest_at_5m_equals_the_general_path_bit_for_bit(cs, lib):
     assert d1 == d0
 
 
+def test_forest_of_small_sparse_trees_at_4_8m_rows(cs, lib):
+    """200 000 blocks of 24 columns, tridiagonal plus a full last row (small elimination trees that are chains but no cliques):
+    csx_schol / csx_chol through the sparse-forest path (symbolic elimination on row masks, the block kernel with a compacted
+    store; csx_chol_info path 2) and the plan partitioned on the device, against the general machines ("chol.forest" = 0):
+    parent, cp, L.p, L.i EQUAL (digests); L.x of both equal to rounding, and -- chains are eliminated in the reference's order --
+    the forest path's first and last 2 000 columns byte for byte the plain-C port's (blocks are independent, so the port runs on
+    slices); the exact-order solutions of the two plans' own factors satisfy A x = b to 1e-12."""
+    import hashlib
+    import _csx
+    import c_oracle as CO
+    nb, bs, k = 200000, 24, 8
+    n = nb * bs
+    cols = []
+    for c in range(bs):
+        rows = {c, bs - 1} | ({c - 1} if c > 0 else set()) | ({c + 1} if c + 1 < bs else set())
+        cols.append(sorted(range(bs)) if c == bs - 1 else sorted(rows))
+    bi = np.concatenate([np.asarray(r, np.int64) for r in cols])
+    bp = np.concatenate([[0], np.cumsum([len(r) for r in cols])])
+    rng = np.random.default_rng(5)
+    Ap = np.concatenate([(np.arange(nb)[:, None] * bp[-1] + bp[None, :-1]).reshape(-1), [nb * bp[-1]]]).astype(np.int32)
+    Ai = (bi[None, :] + (np.arange(nb) * bs)[:, None]).reshape(-1).astype(np.int32)
+    # symmetric values: entry (r, c) of block b = -u(b, min, max) / (1 + |r - c|), the diagonal 8 + u
+    colof = np.repeat(np.arange(bs), np.diff(bp))
+    lo, hi = np.minimum(bi, colof), np.maximum(bi, colof)
+    U = rng.uniform(0.5, 1.0, size=(nb, bs))
+    Ax = np.where(lo[None, :] == hi[None, :], 8.0 + U[:, lo], -U[:, lo] * U[:, hi] / (1.0 + (hi - lo)[None, :])).reshape(-1)
+    hA = _csx.new_handle()
+    _csx.check(lib.csx_csc_upload(n, n, _csx.pi(Ap), _csx.pi(Ai), _csx.pd(Ax), hA))
+
+    def run():
+        parent, cp = np.empty(n, np.int32), np.empty(n + 1, np.int32)
+        _csx.check(lib.csx_schol(hA, _csx.pi(parent), _csx.pi(cp)))
+        hL = _csx.new_handle()
+        _csx.check(lib.csx_chol(hA, _csx.pi(parent), _csx.pi(cp), None, hL))
+        path = C.c_int32(-1)
+        _csx.check(lib.csx_chol_info(path, None))
+        lnz = int(cp[n])
+        Lp, Li, Lx = np.empty(n + 1, np.int32), np.empty(lnz, np.int32), np.empty(lnz)
+        _csx.check(lib.csx_csc_download(hL, _csx.pi(Lp), _csx.pi(Li), _csx.pd(Lx)))
+        plan, hB = _csx.new_handle(), _csx.new_handle()
+        _csx.check(lib.csx_cholsol_plan(hL, None, plan))
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        _csx.check(lib.csx_cholsol_info(plan, a, b, c))
+        _csx.check(lib.csx_gen_rhs(n, k, 3, hB))
+        B0 = np.empty(n * k)
+        _csx.check(lib.csx_vec_download(hB, _csx.pd(B0), n * k))
+        _csx.check(lib.csx_cholsol_solve(plan, hB, k))
+        X = np.empty(n * k)
+        _csx.check(lib.csx_vec_download(hB, _csx.pd(X), n * k))
+        dig = [hashlib.sha256(v.tobytes()).hexdigest() for v in (parent, cp, Lp, Li)]
+        for h in (plan, hB, hL):
+            _csx.free(h)
+        return path.value, (a.value, b.value, c.value), dig, (parent, cp, Lp, Li, Lx), B0.reshape(n, k), X.reshape(n, k)
+
+    p1, i1, d1, f1, B1, X1 = run()
+    with _csx.option("chol.forest", 0):
+        _csx.check(lib.csx_csc_invalidate(hA))
+        p0, i0, d0, f0, B0, X0 = run()
+    _csx.free(hA)
+    assert (p1, p0) == (2, 0)
+    assert i1 == i0 == (1, nb, bs)
+    assert d1 == d0
+    assert np.max(np.abs(f1[4] - f0[4]) / np.abs(f0[4])) <= 1e-13
+    # the port on the first and the last 2 000 columns
+    for c0, c1 in ((0, 2016), (n - 2016, n)):
+        sp = Ap[c0:c1 + 1] - Ap[c0]
+        si, sx = Ai[Ap[c0]:Ap[c1]] - c0, Ax[Ap[c0]:Ap[c1]]
+        par, cpp = CO.schol(c1 - c0, sp, si)
+        Lp, Li, Lx = CO.chol(c1 - c0, sp, si, sx, par, cpp)
+        got = f1[4][f1[2][c0]:f1[2][c1]]
+        assert (f1[3][f1[2][c0]:f1[2][c1]] - c0).tolist() == Li.tolist()
+        assert got.tobytes() == Lx.tobytes()
+    # residual of both solves (A is symmetric: a column of A is a row)
+    import scipy.sparse as sps
+    A = sps.csc_matrix((Ax, Ai, Ap), shape=(n, n))
+    for B, X in ((B1, X1), (B0, X0)):
+        R = A @ X - B
+        assert np.max(np.abs(R)) <= 1e-12 * np.max(np.abs(B))
+
+
 def test_cholsol_5m_block_spd_residual(cs, lib):
     import _csx
     nb, bs, k = 78125, 64, 128
