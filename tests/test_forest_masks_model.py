@@ -91,3 +91,40 @@ def test_a_column_of_L_is_its_mask_and_an_entrys_place_a_popcount():
             assert rows == Li[Lp[g]:Lp[g + 1]].tolist()          # diagonal first, rows ascending
             for r in rows:                                        # the store's address: popcount of the mask below the lane
                 assert Li[Lp[g] + bin(cg & ((1 << (r - c0)) - 1)).count("1")] == r
+
+
+def test_the_clique_rule_is_an_iff():
+    """k_clique_mark's rule -- u[0] = 0 and u[k] in {k, u[k - 1]} -- holds exactly when the elimination forest is a set of
+    cliques on consecutive columns: every tree a chain of consecutive columns and every column of L full inside its block
+    (parent[k] = k + 1 or -1, count[k] = block end - k), checked against the plain-C port's cs_schol on random patterns, some
+    built to satisfy the rule (first row / column of every block full), some arbitrary."""
+    rng = np.random.default_rng(29)
+    seen = {True: 0, False: 0}
+    for trial in range(60):
+        sizes = [int(v) for v in rng.integers(1, 20, 12)]
+        cols, a = [], 0
+        full_first = trial % 2 == 0
+        for bs in sizes:
+            K = np.triu(rng.uniform(size=(bs, bs)) < rng.choice([0.2, 0.6, 1.0])) | np.eye(bs, dtype=bool)
+            if full_first:
+                K[0, :] = True
+            K = K | K.T
+            for c in range(bs):
+                cols.append(np.nonzero(K[:, c])[0] + a)
+            a += bs
+        n = int(a)
+        Ap = np.zeros(n + 1, np.int32)
+        Ap[1:] = np.cumsum([len(c) for c in cols])
+        Ai = np.concatenate(cols).astype(np.int32)
+        u = [min([int(i) for i in Ai[Ap[k]:Ap[k + 1]] if i <= k] + [k]) for k in range(n)]
+        rule = u[0] == 0 and all(u[k] == k or u[k] == u[k - 1] for k in range(1, n))
+        parent, cp = CO.schol(n, Ap, Ai)
+        count = np.diff(cp)
+        # cliques on consecutive columns, read off the reference's tree and counts
+        ends = [k for k in range(n) if parent[k] < 0]
+        starts = [0] + [e + 1 for e in ends[:-1]]
+        cliques = all(parent[k] in (-1, k + 1) for k in range(n)) and all(
+            count[k] == e - k + 1 for s0, e in zip(starts, ends) for k in range(s0, e + 1))
+        assert rule == cliques, (trial, sizes)
+        seen[rule] += 1
+    assert seen[True] >= 20 and seen[False] >= 10
