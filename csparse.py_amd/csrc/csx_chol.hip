@@ -694,10 +694,17 @@ static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, c
         }
         if (st == CSX_OK && ok && F.ascending && F.max_bs <= CLIQUE_MAX_BLOCK) {
             lap("clique forest");
-            st = clique_matches_host(F, parent, cp, &same);
+            // The block kernel is started FIRST; the caller's S (host arrays) is uploaded and compared with the forest's beside it
+            // on a stream of its own.  An S that is not A's costs a factor that is thrown away.
+            // (the kernel writes L through the forest's own column pointers: an S with another lnz is refused before anything runs)
+            if ((int64_t)L->nnz != F.lnz) {
+                if (!cached) free_clique(&F);
+                return CSX_EINVAL;
+            }
+            CliqueCompare cmp;
+            st = clique_matches_begin(F, parent, cp, &cmp);
             int *d_notspd = nullptr;
             int hflag = 0x7fffffff;
-            if (st == CSX_OK && !same) st = CSX_EINVAL;        // S.cp / S.parent do not belong to A
             if (st == CSX_OK) st = dalloc(&L->i, (size_t)L->nnz);
             if (st == CSX_OK) st = dalloc(&L->x, (size_t)L->nnz);
             if (st == CSX_OK) st = dalloc(&d_notspd, 1);
@@ -706,23 +713,30 @@ static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, c
                 if (st == CSX_OK && hipMemcpyAsync(L->p, F.cp, ((size_t)n + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, s) != hipSuccess)
                     st = CSX_ERUNTIME;
             }
+            int32_t *own_cp = nullptr;                  // not cached: L takes the forest's column pointers
             if (st == CSX_OK) {
                 if (!cached) {
                     L->p = F.cp;
-                    F.cp = nullptr;
+                    own_cp = F.cp;
                 }
-                lap("S compared");
                 if (hipMemcpyAsync(d_notspd, &hflag, sizeof(int), hipMemcpyHostToDevice, s) != hipSuccess) st = CSX_ERUNTIME;
             }
             if (st == CSX_OK) (void)hipEventRecord(ev_a, s);
             if (st == CSX_OK) st = chol_clique_numeric(A, F, L, d_notspd);
             if (st == CSX_OK) (void)hipEventRecord(ev_b, s);
+            if (st == CSX_OK) st = clique_matches_run(&cmp);
             if (st == CSX_OK && (hipMemcpyAsync(&hflag, d_notspd, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
                                  hipStreamSynchronize(s) != hipSuccess)) {
                 set_error("cs_chol: %s", hipGetErrorString(hipGetLastError()));
                 st = CSX_ERUNTIME;
             }
-            lap("numeric (blocks)");
+            {
+                const int st2 = clique_matches_end(&cmp, &same);    // (always: it waits for the side stream and frees)
+                if (st == CSX_OK) st = st2;
+            }
+            if (own_cp) F.cp = nullptr;                 // L owns it now (the caller frees L on any error)
+            lap("numeric (blocks) + S compared");
+            if (st == CSX_OK && !same) st = CSX_EINVAL;        // S.cp / S.parent do not belong to A
             if (st == CSX_OK) {
                 numeric_ms();
                 g_chol_path = F.sparse ? 2 : 1;

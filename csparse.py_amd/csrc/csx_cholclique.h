@@ -26,8 +26,18 @@ struct CliqueForest {
 void free_clique(CliqueForest *F);
 // *ok = A's elimination forest is a set of cliques on consecutive columns (F filled; the caller frees it)
 int clique_forest(const Csc *A, CliqueForest *F, bool *ok);
-// *same = the host arrays parent[n], cp[n + 1] equal F's
-int clique_matches_host(const CliqueForest &F, const int32_t *parent, const int32_t *cp, bool *same);
+// Are the host arrays parent[n], cp[n + 1] F's?  Three steps so that the caller's kernel runs beside the upload: _begin takes
+// the temporaries, _run (after the caller has queued its own work) uploads and compares on a side stream, _end waits and answers.
+struct CliqueCompare {
+    const CliqueForest *F = nullptr;
+    const int32_t *parent = nullptr, *cp = nullptr;
+    int32_t *dp = nullptr, *dc = nullptr;
+    int *bad = nullptr;
+    int h = 1;
+};
+int clique_matches_begin(const CliqueForest &F, const int32_t *parent, const int32_t *cp, CliqueCompare *c);
+int clique_matches_run(CliqueCompare *c);
+int clique_matches_end(CliqueCompare *c, bool *same);
 // values and row indices of L (L->p = F.cp already in place, L->i / L->x allocated); blocks of at most 64 columns
 int chol_clique_numeric(const Csc *A, const CliqueForest &F, Csc *L, int *d_notspd);
 constexpr int CLIQUE_MAX_BLOCK = 64;
