@@ -1,3 +1,4 @@
+# round 4: the fused-sweep tests and the two timing tools (W, the sparse forest)
 set -e
 mkdir -p gpurun_out/r04s
 timeout -k 10 600 python -m pytest tests/test_gpu_trisolve.py tests/test_gpu_cholesky.py tests/test_gpu_configs.py tests/test_gpu_cholclique.py tests/test_gpu_comm.py -x -q -m gpu > gpurun_out/r04s/tests.log 2>&1 || { tail -40 gpurun_out/r04s/tests.log; exit 1; }
