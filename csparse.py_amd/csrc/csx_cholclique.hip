@@ -354,12 +354,9 @@ __global__ __launch_bounds__(256) void k_clique_compare(int32_t n, const int32_t
 
 // cs_chol(A, S): the caller's S.parent / S.cp (host arrays) must be this forest's; uploaded and compared on the device
 // The upload of S (40 MB at 5M columns, from pageable memory: 0.8 ms of host time) and the comparison run on a stream of their
-// own, so that csx_chol can start the block kernel first and pay only for the longer of the two.
-static hipStream_t g_side_stream = nullptr;
-
+// own (the context's side stream), so that csx_chol can start the block kernel first and pay only for the longer of the two.
 int clique_matches_begin(const CliqueForest &F, const int32_t *parent, const int32_t *cp, CliqueCompare *c) {
     const int32_t n = F.n;
-    if (!g_side_stream && hipStreamCreateWithFlags(&g_side_stream, hipStreamNonBlocking) != hipSuccess) return CSX_ERUNTIME;
     // (the temporaries come from the pool while the context's stream is idle: no block of it is still in use by work in flight)
     CSX_TRY(dalloc(&c->dp, (size_t)n));
     CSX_TRY(dalloc(&c->dc, (size_t)n + 1));
@@ -372,7 +369,7 @@ int clique_matches_begin(const CliqueForest &F, const int32_t *parent, const int
 
 // after the caller has put its own work on the context's stream
 int clique_matches_run(CliqueCompare *c) {
-    hipStream_t s = g_side_stream;
+    hipStream_t s = ctx().side;
     const int32_t n = c->F->n;
     CSX_HIP(hipMemsetAsync(c->bad, 0, sizeof(int), s));
     CSX_HIP(hipMemcpyAsync(c->dp, c->parent, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, s));
@@ -385,7 +382,7 @@ int clique_matches_run(CliqueCompare *c) {
 int clique_matches_end(CliqueCompare *c, bool *same) {
     *same = false;
     int st = CSX_OK;
-    if (g_side_stream && hipStreamSynchronize(g_side_stream) != hipSuccess) st = CSX_ERUNTIME;
+    if (hipStreamSynchronize(ctx().side) != hipSuccess) st = CSX_ERUNTIME;
     dfree(c->dp);
     dfree(c->dc);
     dfree(c->bad);

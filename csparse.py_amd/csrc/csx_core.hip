@@ -287,6 +287,8 @@ using namespace csx;
 
 extern "C" {
 
+__global__ void k_warm(int *p) { if (threadIdx.x == 0) *p += 1; }
+
 int csx_init(int device) {
     Context &c = ctx();
     if (c.ready) {
@@ -306,6 +308,18 @@ int csx_init(int device) {
     c.cus = prop.multiProcessorCount;
     CSX_HIP(hipStreamCreateWithFlags(&c.own_stream, hipStreamNonBlocking));
     c.stream = c.own_stream;
+    CSX_HIP(hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking));
+    {
+        // the first LARGE copy from pageable memory on a stream sets up its copy path (6 ms seen inside the first csx_chol)
+        std::vector<int> warm((size_t)1 << 20, 0);
+        int *d_warm = nullptr;
+        CSX_HIP(hipMalloc(&d_warm, warm.size() * sizeof(int)));
+        CSX_HIP(hipMemcpyAsync(d_warm, warm.data(), warm.size() * sizeof(int), hipMemcpyHostToDevice, c.side));
+        hipLaunchKernelGGL(k_warm, dim3(1), dim3(64), 0, c.side, d_warm);      // (and a stream's first kernel makes its queue)
+        CSX_HIP(hipMemcpyAsync(warm.data(), d_warm, warm.size() * sizeof(int), hipMemcpyDeviceToHost, c.side));
+        CSX_HIP(hipStreamSynchronize(c.side));
+        CSX_HIP(hipFree(d_warm));
+    }
     CSX_HIP(hipEventCreate(&c.ev0));
     CSX_HIP(hipEventCreate(&c.ev1));
     c.device = device;
@@ -327,6 +341,7 @@ int csx_finalize(void) {
     (void)hipEventDestroy(c.ev0);
     (void)hipEventDestroy(c.ev1);
     (void)hipStreamDestroy(c.own_stream);
+    (void)hipStreamDestroy(c.side);
     c = Context();
     return CSX_OK;
 }

@@ -166,6 +166,8 @@ struct Context {
     int device = -1;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    hipStream_t side = nullptr;      // a second stream for copies that run beside a kernel of `stream` (csx_chol's check of S); made
+                                     // and used once in csx_init: a stream's first copy from pageable memory costs tens of ms
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int cus = 0;
     std::vector<Object> objects;  // handle = generation << 32 | index + 1 (csx_core.hip: put / get)
