@@ -13,6 +13,12 @@
 // Then parent[k] = k + 1 inside a block, -1 at its end; column k of L holds rows k .. end of the block (cs_chol appends
 // rows in ascending order, the diagonal first: L.i follows from cp alone); and the values are one read of A's upper part
 // and one write of L: k_chol_clique keeps a whole block (<= 64 columns) in the registers of one wave.
+//
+// Second form (round 4, "chol.forest"): where that rule fails the same u[] gives BLOCKS of consecutive columns closed under
+// their upper entries (k starts one iff min_{j >= k} u[j] = k); for blocks of <= 64 columns tree, counts and the pattern of L
+// come from a symbolic elimination on 64-bit row masks in the registers of one wave (k_forest_symbolic, further down) and
+// the same block kernel factors them, storing only the pattern's rows -- forests of small SPARSE trees.  Both rules are
+// restated on integers and checked against the plain-C port without a GPU in tests/test_forest_masks_model.py.
 #include <algorithm>
 #include <cstdio>
 
