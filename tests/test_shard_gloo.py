@@ -211,18 +211,20 @@ def _run_bench(extra, env=None, timeout=300):
                           stderr=subprocess.PIPE, text=True, timeout=timeout)
 
 
-def test_bench_gpus_2_really_starts_two_ranks():
-    """`python bench.py --gpus 2` must start two ranks itself (no outer launcher) and say n_gpus = 2;
-    --rehearse keeps it off the GPU: launcher, world check and every exchange leg on CPU tensors over gloo."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_gpus_n_really_starts_n_ranks(world):
+    """`python bench.py --gpus N` must start N ranks itself (no outer launcher) and say n_gpus = N;
+    --rehearse keeps it off the GPU: launcher, world check and every exchange leg on CPU tensors over gloo.  N = 8 is the
+    node the driver's scaling run uses: uneven blocks of right-hand sides and columns over eight ranks."""
     import json
-    r = _run_bench(["--gpus", "2", "--rehearse"])
+    r = _run_bench(["--gpus", str(world), "--rehearse"])
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout                       # rank 0 alone prints
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["rehearsal"] is True and d["value"] is None
+    assert d["n_gpus"] == world and d["rehearsal"] is True and d["value"] is None
     assert d["exchange"] == {"broadcast_ok": True, "scatter_ok": True, "gather_ok": True}
-    assert d["slowest_rank"] == 1.0
+    assert d["slowest_rank"] == float(world - 1)
 
 
 def test_bench_refuses_a_world_of_another_size():
