@@ -721,10 +721,13 @@ static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, c
                 }
                 if (hipMemcpyAsync(d_notspd, &hflag, sizeof(int), hipMemcpyHostToDevice, s) != hipSuccess) st = CSX_ERUNTIME;
             }
+            lap("allocations");
             if (st == CSX_OK) (void)hipEventRecord(ev_a, s);
             if (st == CSX_OK) st = chol_clique_numeric(A, F, L, d_notspd);
             if (st == CSX_OK) (void)hipEventRecord(ev_b, s);
+            lap("block kernel");
             if (st == CSX_OK) st = clique_matches_run(&cmp);
+            lap("S uploaded");
             if (st == CSX_OK && (hipMemcpyAsync(&hflag, d_notspd, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
                                  hipStreamSynchronize(s) != hipSuccess)) {
                 set_error("cs_chol: %s", hipGetErrorString(hipGetLastError()));

@@ -157,8 +157,12 @@ int dmalloc(void **p, size_t bytes) {
     pool_configure();
     const size_t want = pool_round(bytes + 64);   // every block has >= 64 readable bytes past its logical end
     if (g_pool.enabled) {
+        // an idle block of at most 25 % more; for a big request (>= 64 MB) up to three times as much: fresh gigabytes from the
+        // driver cost tens of milliseconds (30 ms for the 2 GB of a 5M-row factor inside its first csx_chol when the pool
+        // happened to hold nothing of that size), and a block that idles in the cache serves nobody
         auto it = g_pool.idle.lower_bound(want);
-        if (it != g_pool.idle.end() && it->first <= want + want / 4) {   // at most 25 % slack
+        const size_t most = want >= ((size_t)64 << 20) ? 3 * want : want + want / 4;
+        if (it != g_pool.idle.end() && it->first <= most) {
             *p = it->second.p;
             g_pool.cached -= it->first;
             g_pool.live += it->first;
