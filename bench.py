@@ -775,30 +775,69 @@ def cholsol_section(args, lib, cs, comm, hB, nb, bs, barrier, max_over_ranks, pr
     n = nb * bs
     nnz = n * bs
     k = args.nrhs
-    # symbolic analysis (cs_schol, natural order): elimination tree on the host, column counts on the device
-    t0 = time.perf_counter()
-    parent = np.empty(n, dtype=np.int32)
-    cp = np.empty(n + 1, dtype=np.int32)
-    _csx.check(lib.csx_schol(hB, _csx.pi(parent), _csx.pi(cp)), "schol")
-    t_symbolic = time.perf_counter() - t0
-    lnz = int(cp[n])
-    # numeric factorisation on the device: pattern of L (postorder walks + sorts), values, dense-block factor
-    t0 = time.perf_counter()
-    hL = _csx.new_handle()
-    _csx.check(lib.csx_chol(hB, _csx.pi(parent), _csx.pi(cp), None, hL), "chol")
-    _csx.sync()
-    t_numeric = time.perf_counter() - t0
+    # The product's flow for a batch (round 5): ONE library call -- cs_schol + cs_chol + the solve plan, S never leaving the device
+    # (csx_cholsol_factor; csparse.cholsol_factor(A) / cs_cholsol(0, A, b) go through it).  Called three times (factor and plan
+    # freed in between, as a refactorisation loop would): every call is reported, schol_chol_plan_total is their median.
+    fused_ms, fused_info = [], None
+    hL = plan = None
+    for rep in range(3):
+        if hL is not None:
+            _csx.free(plan)
+            _csx.free(hL)
+        hL, plan = _csx.new_handle(), _csx.new_handle()
+        _csx.sync()
+        t0 = time.perf_counter()
+        _csx.check(lib.csx_cholsol_factor(hB, 0, hL, plan), "cholsol_factor")
+        _csx.sync()
+        fused_ms.append((time.perf_counter() - t0) * 1e3)
+        fpath, fa, fn, fc = C.c_int32(-1), C.c_double(0.0), C.c_double(0.0), C.c_double(0.0)
+        _csx.check(lib.csx_cholsol_factor_info(fpath, fa, fn, fc), "cholsol_factor_info")
+        fused_info = {"path": fpath.value, "analysis_ms": round(fa.value, 3), "numeric_kernel_ms": round(fn.value, 4),
+                      "call_ms_library_clock": round(fc.value, 3)}
+    t_fused = sorted(fused_ms)[1] * 1e-3
     chol_path, chol_kernel_ms = C.c_int32(-1), C.c_double(0.0)
     _csx.check(lib.csx_chol_info(chol_path, chol_kernel_ms), "chol_info")
-    t0 = time.perf_counter()
-    plan = _csx.new_handle()
-    _csx.check(lib.csx_cholsol_plan(hL, None, plan), "cholsol_plan")
-    _csx.sync()
-    t_plan = time.perf_counter() - t0
+    nL_m, nL_n, nL_nnz, nL_hv = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int()
+    _csx.check(lib.csx_csc_info(hL, nL_m, nL_n, nL_nnz, nL_hv), "csc_info")
+    lnz = nL_nnz.value
+    # The same through round 4's three calls (csx_schol hands parent / cp to the host, csx_chol takes them back and compares,
+    # csx_cholsol_plan re-reads L): kept as the C ABI's separate steps and timed beside the fused call.
+    sep = {}
+    try:
+        t0 = time.perf_counter()
+        parent = np.empty(n, dtype=np.int32)
+        cp = np.empty(n + 1, dtype=np.int32)
+        _csx.check(lib.csx_schol(hB, _csx.pi(parent), _csx.pi(cp)), "schol")
+        sep["symbolic_cs_schol"] = round(time.perf_counter() - t0, 4)
+        t0 = time.perf_counter()
+        hL2 = _csx.new_handle()
+        _csx.check(lib.csx_chol(hB, _csx.pi(parent), _csx.pi(cp), None, hL2), "chol")
+        _csx.sync()
+        sep["numeric_cs_chol"] = round(time.perf_counter() - t0, 4)
+        t0 = time.perf_counter()
+        plan2 = _csx.new_handle()
+        _csx.check(lib.csx_cholsol_plan(hL2, None, plan2), "cholsol_plan")
+        _csx.sync()
+        sep["solve_plan"] = round(time.perf_counter() - t0, 4)
+        t0 = time.perf_counter()
+        _csx.check(lib.csx_cholsol_set_order(plan2, 0), "cholsol_set_order")
+        _csx.sync()
+        sep["matrix_core_fragments"] = round(time.perf_counter() - t0, 4)
+        sep["total"] = round(sum(sep.values()), 4)
+        assert int(cp[n]) == lnz
+        _csx.free(plan2)
+        _csx.free(hL2)
+        del parent, cp
+    except Exception as e:                                # a comparison figure: never take the section down
+        sep["error"] = "%s: %s" % (type(e).__name__, e)
     # exact (default) order first: bit-identical to cs_lsolve + cs_ltsolve, substitution kernels
     hR0 = _csx.new_handle()
     _csx.check(lib.csx_gen_rhs(n, k, rank * k, hR0), "gen_rhs")
-    _csx.check(lib.csx_cholsol_solve(plan, hR0, k), "cholsol_solve")
+    t0 = time.perf_counter()
+    _csx.check(lib.csx_cholsol_set_order(plan, 1), "cholsol_set_order")
+    _csx.check(lib.csx_cholsol_solve(plan, hR0, k), "cholsol_solve")    # (the substitution programs are cut out of L.x here)
+    _csx.sync()
+    t_first_exact = time.perf_counter() - t0
     with _csx.Timer() as tm0:
         for _ in range(5):
             _csx.check(lib.csx_cholsol_solve(plan, hR0, k), "cholsol_solve")
@@ -831,7 +870,7 @@ def cholsol_section(args, lib, cs, comm, hB, nb, bs, barrier, max_over_ranks, pr
     # cs_chol: read the upper triangle of A (index + value), write L (index + value)
     nnz_triu = n * (bs + 1) // 2
     chol_bytes = 12 * nnz_triu + 12 * lnz
-    t_factor = t_symbolic + t_numeric + t_plan
+    t_factor = t_fused
     out = {"workload": "batched cs_cholsol solve phase on G-spd (n=%d, lnz=%d): %d right-hand sides per GPU, "
                        "factor once per GPU, row-major n x k block" % (n, lnz, k),
            "solves_per_s": round(k * world * steps / wall, 1), "nrhs_per_gpu": k, "ms_per_batch": round(ms, 4),
@@ -845,17 +884,24 @@ def cholsol_section(args, lib, cs, comm, hB, nb, bs, barrier, max_over_ranks, pr
                         "unit": "GB/s", "frac": round(fused_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                         "traffic": (measured_traffic("k_cholsol_", n=n, nrhs_per_gpu=k) or {}).get("bytes")},
            "survey_bytes_unfused": cholsol_bytes(lnz, n, k),
-           "factor_s": {"symbolic_cs_schol": round(t_symbolic, 4), "numeric_device_incl_pattern_of_L": round(t_numeric, 4),
-                        "solve_plan": round(t_plan, 4), "matrix_core_fragments": round(t_plan_mfma, 4),
-                        "schol_chol_plan_total": round(t_factor, 4)},
+           "factor_s": {"schol_chol_plan_total": round(t_factor, 5),
+                        "note": "csx_cholsol_factor: cs_schol + cs_chol + the solve plan (matrix-core operands included) in one "
+                                "call, median of the three calls listed; the end-to-end figure below uses it",
+                        "fused_calls_ms": [round(v, 3) for v in fused_ms], "fused_info_last_call": fused_info,
+                        "first_exact_solve_incl_programs_s": round(t_first_exact, 5),
+                        "set_order_rounding_equal_s": round(t_plan_mfma, 5),
+                        "separate_calls_round4_flow": sep},
            "chol_roofline": {"bound": "hbm", "kernel": {1: "k_chol_clique (forest of cliques: a block in the registers of a wave)",
+                                                        2: "k_chol_clique (forest of small sparse trees)",
                                                         0: "general path (pattern of L + column kernels)"}.get(chol_path.value),
                              "algorithmic_bytes": chol_bytes, "numeric_kernel_ms": round(chol_kernel_ms.value, 4),
                              "achieved": round(chol_bytes / (chol_kernel_ms.value * 1e-3) / 1e9, 2) if chol_kernel_ms.value > 0 else None,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(chol_bytes / (chol_kernel_ms.value * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if chol_kernel_ms.value > 0 else None,
-                             "csx_chol_call_ms": round(t_numeric * 1e3, 3),
-                             "frac_whole_call": round(chol_bytes / t_numeric / 1e9 / HBM_PEAK_GBS, 4),
+                             "note": "inside csx_cholsol_factor the kernel writes the matrix-core solve's operands (1.6 GB) beside "
+                                     "L.x and leaves L.i to be made on demand; algorithmic bytes stay SURVEY 8d's 12 nnz(triu A) + 12 lnz",
+                             "factor_call_ms": round(t_factor * 1e3, 3),
+                             "frac_whole_call": round(chol_bytes / t_factor / 1e9 / HBM_PEAK_GBS, 4),
                              "traffic": (measured_traffic("k_chol_clique", n=n) or {}).get("bytes")},
            "end_to_end_solves_per_s_per_gpu": round(k / (t_factor + ms * 1e-3), 1),
            "end_to_end_note": "cs_schol + cs_chol + plan + ONE batch of %d right-hand sides (the solve phase alone: solves_per_s)" % k,
@@ -869,7 +915,7 @@ def cholsol_section(args, lib, cs, comm, hB, nb, bs, barrier, max_over_ranks, pr
         out["exchange"] = {"skipped": "failed the exchange preflight at small size: %s" % ", ".join(bad)}
     elif world > 1 or args.force_sharded:
         try:
-            out["exchange"] = exchange_section(args, lib, comm, hL, plan, n, lnz, t_symbolic + t_numeric + t_plan,
+            out["exchange"] = exchange_section(args, lib, comm, hL, plan, n, lnz, t_factor,
                                                barrier, max_over_ranks)
         except Exception as e:                            # never take the headline down with it
             out["exchange"] = {"error": "%s: %s" % (type(e).__name__, e)}

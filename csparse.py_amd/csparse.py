@@ -1042,6 +1042,20 @@ def cs_cholsol(order, A, b):
     if not CS_CSC(A) or b is None:
         return False
     n = A.n
+    if order == 0 and A.m == n and _meta(A)[1]:
+        # natural order: S = cs_schol, N = cs_chol and the solve plan in one library call, S never leaving the device
+        # (csx_cholsol_factor); the reference's driver is always exact
+        fused = _cholsol_factor_fused(A, True)
+        if fused is None:
+            return False
+        L, plan = fused
+        db, bhost = _vec_in(b, n, "b")
+        try:
+            _csx.check(_csx.lib().csx_cholsol_solve(plan, db.handle, db.k), "csx_cholsol_solve")
+        finally:
+            _csx.free(plan)
+        _write_back(bhost, db, n * db.k)
+        return True
     S = cs_schol(order, A, _arrays=True)
     N = cs_chol(A, S) if S is not None else None
     if S is None or N is None:
@@ -1059,6 +1073,37 @@ def cs_cholsol(order, A, b):
     return True
 
 
+def _cholsol_factor_fused(A, exact):
+    """csx_cholsol_factor: (L as a device-backed cs, plan handle), or None when A is not positive definite."""
+    hL, hP = _csx.new_handle(), _csx.new_handle()
+    with _Resident(A) as dA:
+        st = _csx.lib().csx_cholsol_factor(dA.handle, 1 if exact else 0, hL, hP)
+    if st in (_csx.ENOTSPD, _csx.EINVAL):        # not positive definite; an index out of range (cs_schol gives None for it)
+        return None
+    _csx.check(st, "csx_cholsol_factor")
+    return _from_device(hL, lambda nnz: max(nnz, 1)), hP
+
+
+def _symbolic_of_factor(L):
+    """cs_schol(0, A)'s result read off the factor: S.cp = L.p; S.parent[j] = the first row below the diagonal of column j of L
+    (csparse.py:1136-1169 builds the same tree from A); as int32 arrays."""
+    dev = L._dev
+    m, n, nnz, hv = dev.info()
+    p = np.empty(n + 1, dtype=np.int32)
+    i = np.empty(max(nnz, 1), dtype=np.int32)
+    _csx.check(_csx.lib().csx_csc_download(dev.handle, _csx.pi(p), _csx.pi(i), None), "csx_csc_download")
+    parent = np.full(n, -1, dtype=np.int32)
+    has = np.diff(p) > 1
+    parent[has] = i[p[:-1][has] + 1]
+    S = css()
+    S.pinv = None
+    S.q = None
+    S.parent = parent
+    S.cp = p
+    S.unz = S.lnz = int(p[n])
+    return S
+
+
 def cholsol_factor(A, order=0, exact=None):
     """Factor once for many solves: returns a solver `solve(b)` where b is a list or a
     dvec n-by-k block (overwritten).  The batched form of cs_cholsol (csparse.py:622-644).
@@ -1071,11 +1116,28 @@ def cholsol_factor(A, order=0, exact=None):
       supernodal schedule.  (G-spd, 128 right-hand sides: 2.4 ms against 4.8; bcsstk16: 0.4 ms against 6.6.)
     exact=True: every solve, blocks too, bit-identical to the reference's order.   exact=False: every solve rounding-equal.
     cs_cholsol, the reference's own driver, is always exact."""
-    S = cs_schol(order, A, _arrays=True)
-    N = cs_chol(A, S) if S is not None else None
-    if N is None:
+    if not CS_CSC(A):
         return None
-    pinv = None if S.pinv is None else _csx.i32(S.pinv)
+    first_plan = None
+    if order == 0 and A.m == A.n and _meta(A)[1]:
+        # natural order: analysis, factorisation and plan in ONE library call, S never leaving the device (csx_cholsol_factor:
+        # round 4's flow handed 40 MB of parent / cp to the host, back again, and re-read L twice to re-arrange it).  The plan
+        # starts in the order blocks are solved in unless every solve is to be exact; a list switches it (a flag, and the
+        # substitution programs cut out of L.x at that moment).
+        fused = _cholsol_factor_fused(A, exact is True)
+        if fused is None:
+            return None
+        N = csn()
+        N.L, first_plan = fused
+        N.U, N.pinv, N.B = None, None, None
+        S = None                                 # read off the factor when `symbolic` is asked for
+        pinv = None
+    else:
+        S = cs_schol(order, A, _arrays=True)
+        N = cs_chol(A, S) if S is not None else None
+        if N is None:
+            return None
+        pinv = None if S.pinv is None else _csx.i32(S.pinv)
     # (the solver exposes S with lists, as cs_schol returns them -- made when `symbolic` is first read: at 5M columns the
     # three conversions take 0.3 s, sixty times the analysis itself)
     # The C plan BORROWS L's device arrays (CholPlan::L is not owned; the L' plan reads L.p / L.i / L.x directly),
@@ -1084,11 +1146,12 @@ def cholsol_factor(A, order=0, exact=None):
     cs_pin(N.L)
     dev = N.L._dev
     n = A.n
+    start_exact = exact is True if first_plan is not None else exact is not False
 
     def _build():
         h = _csx.new_handle()
         _csx.check(_csx.lib().csx_cholsol_plan(dev.handle, _csx.pi(pinv), h), "csx_cholsol_plan")
-        if exact is False:
+        if not start_exact:
             _csx.check(_csx.lib().csx_cholsol_set_order(h, 0), "csx_cholsol_set_order")
         return h
 
@@ -1097,6 +1160,9 @@ def cholsol_factor(A, order=0, exact=None):
 
         @property
         def symbolic(self):
+            nonlocal S
+            if S is None:
+                S = _symbolic_of_factor(N.L)
             for name in ("parent", "cp", "pinv"):
                 v = getattr(S, name)
                 if v is not None and not isinstance(v, list):
@@ -1106,8 +1172,8 @@ def cholsol_factor(A, order=0, exact=None):
         def __init__(self):
             self._dev = dev                      # keeps the device factor alive (see above)
             self._built = dev.version
-            self.plan_handle = _build()
-            self._exact_now = exact is not False     # the order the plan is in
+            self.plan_handle = first_plan if first_plan is not None else _build()
+            self._exact_now = start_exact            # the order the plan is in
             self._box = [self.plan_handle]
             self._fin = weakref.finalize(self, lambda box: _csx.free(box[0]), self._box)
 
@@ -1117,7 +1183,7 @@ def cholsol_factor(A, order=0, exact=None):
             if self._built != dev.version:
                 _csx.free(self.plan_handle)
                 self.plan_handle = self._box[0] = _build()
-                self._exact_now = exact is not False
+                self._exact_now = start_exact
                 self._built = dev.version
             return self.plan_handle
 

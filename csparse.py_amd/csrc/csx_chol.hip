@@ -704,7 +704,9 @@ static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, c
             CliqueCompare cmp;
             st = clique_matches_begin(F, parent, cp, &cmp);
             int *d_notspd = nullptr;
-            int hflag = 0x7fffffff;
+            constexpr int NOTSPD_NONE = 0x7f7f7f7f;     // the flag's idle value: set by a byte fill on the device, no host slot in flight
+            int hflag = NOTSPD_NONE;
+            bool queued = false;                        // device work of this call may be in flight
             if (st == CSX_OK) st = dalloc(&L->i, (size_t)L->nnz);
             if (st == CSX_OK) st = dalloc(&L->x, (size_t)L->nnz);
             if (st == CSX_OK) st = dalloc(&d_notspd, 1);
@@ -719,7 +721,8 @@ static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, c
                     L->p = F.cp;
                     own_cp = F.cp;
                 }
-                if (hipMemcpyAsync(d_notspd, &hflag, sizeof(int), hipMemcpyHostToDevice, s) != hipSuccess) st = CSX_ERUNTIME;
+                if (hipMemsetAsync(d_notspd, 0x7f, sizeof(int), s) != hipSuccess) st = CSX_ERUNTIME;
+                queued = true;
             }
             lap("allocations");
             if (st == CSX_OK) (void)hipEventRecord(ev_a, s);
@@ -738,6 +741,9 @@ static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, c
                 if (st == CSX_OK) st = st2;
             }
             if (own_cp) F.cp = nullptr;                 // L owns it now (the caller frees L on any error)
+            // on a failure after work was queued the block kernel may still be writing L.i / L.x, which the caller hands back to
+            // the pool: nothing is released before the stream has drained
+            if (st != CSX_OK && queued) (void)hipStreamSynchronize(s);
             lap("numeric (blocks) + S compared");
             if (st == CSX_OK && !same) st = CSX_EINVAL;        // S.cp / S.parent do not belong to A
             if (st == CSX_OK) {
@@ -747,7 +753,7 @@ static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, c
             dfree(d_notspd);
             if (!cached) free_clique(&F);
             if (st != CSX_OK) return st;
-            return hflag != 0x7fffffff ? CSX_ENOTSPD : CSX_OK;
+            return hflag != NOTSPD_NONE ? CSX_ENOTSPD : CSX_OK;
         }
         if (!cached) free_clique(&F);
         if (st != CSX_OK) return st;
@@ -1775,12 +1781,9 @@ __global__ __launch_bounds__(64) void k_mfma_frags(const Tree *__restrict__ tree
         const int blk = lane >> 4, col = lane & 15;
         if (blk < NB) {
             double wcol[16];
+            tile_inverse_column(&Ls[16 * blk][16 * blk], BS + 1, col, wcol);
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                double sres = r == col ? 1.0 : 0.0;
-#pragma unroll
-                for (int q = 0; q < r; q++) sres -= Ls[16 * blk + r][16 * blk + q] * (q >= col ? wcol[q] : 0.0);
-                wcol[r] = r >= col ? sres / Ls[16 * blk + r][16 * blk + r] : 0.0;
                 W[blk][r][col] = wcol[r];
                 wmax = fmax(wmax, fabs(wcol[r]));
             }
@@ -2012,8 +2015,8 @@ static int cholsol_plan_clique(CholPlan *P, int32_t bs) {
     int *zero = nullptr;
     CSX_TRY(tmp.alloc(&zero, 1));
     CSX_HIP(hipMemsetAsync(zero, 0, sizeof(int), s));
-    CSX_TRY(dalloc(&P->trees, (size_t)ntrees));
-    CSX_TRY(dalloc(&P->tree_nodes, (size_t)n));
+    if (!P->trees) CSX_TRY(dalloc(&P->trees, (size_t)ntrees));          // (a plan csx_cholsol_factor made has its block list already)
+    if (!P->tree_nodes) CSX_TRY(dalloc(&P->tree_nodes, (size_t)n));
     CSX_TRY(dalloc(&P->f_ptr, (size_t)n + 1));
     CSX_TRY(dalloc(&P->b_ptr, (size_t)n + 1));
     CSX_TRY(dalloc(&P->diagk, (size_t)n));
@@ -2342,6 +2345,10 @@ static int cholsol_solve(CholPlan *P, double *B, int32_t nrhs) {
     if (P->local && (Gd != nullptr || P->clique)) {
         // zero pivots were detected by the analysis; report like the reference (ZeroDivisionError)
         if (P->clique) {
+            // a plan csx_cholsol_factor made holds the matrix-core operands only (written by the block kernel beside L.x); what the
+            // substitution kernels read is cut out of L.x the first time one of them is asked for
+            const bool cores = P->dense_bs && P->relaxed && P->frag_f && ctx().opt.cholsol_dense_blocks;
+            if (!cores && !P->f_val) CSX_TRY(cholsol_plan_clique(P, P->dense_bs));
             if (P->clique_zero_pivot) return CSX_EZEROPIVOT;
             if (!ctx().opt.cholsol_dense_blocks) CSX_TRY(cholsol_clique_local(P));
         } else {
@@ -2556,6 +2563,182 @@ extern "C" int csx_chol(csx_handle_t hA, const int32_t *parent, const int32_t *c
         return st;
     }
     *out = put(K_CSC, L);
+    return CSX_OK;
+}
+
+namespace csx {
+// cs_cholsol's factor sequence, natural order (csparse.py:636-639: S = cs_schol(0, A); N = cs_chol(A, S)), and the solve plan of
+// csparse.py:640-643 in ONE call with S never leaving the device.  A forest of cliques / of small sparse trees on consecutive columns:
+// one wait for the analysis (clique_forest), the block kernel, one wait for its flags; for EQUAL dense blocks of 16 / 32 / 64 columns
+// in the rounding-equal order the block kernel writes the matrix-core solve's operands itself (CliqueEmit) and the plan is complete
+// when it ends.  Anything else: csx_schol + csx_chol + csx_cholsol_plan behind this one entry, S in host vectors the caller never sees.
+static int g_factor_path = -1;
+static double g_factor_ms[3] = {0.0, 0.0, 0.0};   // analysis / numeric kernel (HIP events) / whole call (host clock)
+
+static int cholsol_factor_device(csx_handle_t hA, Csc *A, bool exact, Csc *L, CholPlan **Pout) {
+    hipStream_t s = ctx().stream;
+    const int32_t n = A->n;
+    const auto t_call = std::chrono::steady_clock::now();
+    g_factor_path = -1;
+    g_factor_ms[0] = g_factor_ms[1] = g_factor_ms[2] = 0.0;
+    auto since = [&](std::chrono::steady_clock::time_point t0) {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    };
+    if (n > 0 && A->nnz > 0 && ctx().opt.chol_clique && ctx().opt.chol_dense_trees) {
+        CliqueForest F;
+        bool ok = false;
+        const bool cached = A->clique != nullptr && (!A->clique->sparse || ctx().opt.chol_forest);
+        if (cached) {
+            F = *A->clique;
+            ok = true;
+        } else {
+            CSX_TRY(clique_forest(A, &F, &ok));
+        }
+        g_factor_ms[0] = since(t_call);
+        struct Release {   // the forest's arrays, unless L took them
+            CliqueForest *F;
+            bool on;
+            ~Release() {
+                if (on) free_clique(F);
+            }
+        } release{&F, ok && !cached};
+        if (ok && F.ascending && F.max_bs <= CLIQUE_MAX_BLOCK) {
+            const int32_t bs = F.max_bs;
+            const bool emit = !exact && !F.sparse && F.min_bs == bs && (bs == 16 || bs == 32 || bs == 64) && ctx().opt.cholsol_dense_blocks;
+            L->m = L->n = n;
+            L->nnz = (int32_t)F.lnz;
+            L->owns = true;
+            if (cached) {
+                CSX_TRY(dalloc(&L->p, (size_t)n + 1));
+                CSX_HIP(hipMemcpyAsync(L->p, F.cp, ((size_t)n + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+            } else {
+                L->p = F.cp;          // L takes the forest's column pointers
+                F.cp = nullptr;
+            }
+            CSX_TRY(dalloc(&L->x, (size_t)L->nnz));
+            if (!emit) CSX_TRY(dalloc(&L->i, (size_t)L->nnz));
+            CholPlan *P = nullptr;
+            CliqueEmit em;
+            DevScope tmp;
+            int *d_flags = nullptr;          // [0] first column with a non-positive pivot, [2..3] the guard's measure
+            CSX_TRY(tmp.alloc(&d_flags, 4));
+            CSX_HIP(hipMemsetAsync(d_flags, 0x7f, sizeof(int), s));
+            CSX_HIP(hipMemsetAsync(d_flags + 2, 0, 2 * sizeof(int), s));
+            if (emit) {
+                P = new CholPlan();
+                *Pout = P;            // (the caller frees it on any error)
+                P->n = n;
+                P->L = L;
+                const size_t per_block = (size_t)clique_frags_per_block(bs / 16) * 64;
+                CSX_TRY(dalloc(&P->frag_f, (size_t)F.nblocks * per_block));
+                CSX_TRY(dalloc(&P->trees, (size_t)F.nblocks));
+                CSX_TRY(dalloc(&P->tree_nodes, (size_t)n));
+                em.frag = P->frag_f;
+                em.cond_bits = (unsigned long long *)(d_flags + 2);
+                em.trees = P->trees;
+                em.tree_nodes = P->tree_nodes;
+            }
+            hipEvent_t ev_a = nullptr, ev_b = nullptr;
+            if (hipEventCreate(&ev_a) != hipSuccess || hipEventCreate(&ev_b) != hipSuccess) {
+                if (ev_a) (void)hipEventDestroy(ev_a);
+                return CSX_ERUNTIME;
+            }
+            (void)hipEventRecord(ev_a, s);
+            int st = chol_clique_numeric(A, F, L, d_flags, emit ? &em : nullptr);
+            (void)hipEventRecord(ev_b, s);
+            int h[4] = {0, 0, 0, 0};
+            if (hipMemcpyAsync(h, d_flags, sizeof h, hipMemcpyDeviceToHost, s) != hipSuccess) st = st == CSX_OK ? CSX_ERUNTIME : st;
+            if (hipStreamSynchronize(s) != hipSuccess) st = st == CSX_OK ? CSX_ERUNTIME : st;   // (also on failure: L's arrays go back to the pool)
+            float ms = 0.0f;
+            if (st == CSX_OK && hipEventElapsedTime(&ms, ev_a, ev_b) == hipSuccess) g_factor_ms[1] = ms;
+            (void)hipEventDestroy(ev_a);
+            (void)hipEventDestroy(ev_b);
+            CSX_TRY(st);
+            if (h[0] != 0x7f7f7f7f) return CSX_ENOTSPD;
+            g_chol_path = F.sparse ? 2 : 1;
+            g_chol_numeric_ms = g_factor_ms[1];
+            if (emit) {
+                L->rows_pending = true;       // rows j, j + 1, ... in every column: made from L.p when a handle to L is resolved
+                double growth = 0.0;
+                std::memcpy(&growth, h + 2, sizeof growth);
+                P->clique = true;
+                P->clique_zero_pivot = false;  // every pivot is a square root of a positive number
+                P->ntrees = F.nblocks;
+                P->max_nodes = bs;
+                P->local = true;
+                P->dense_bs = bs;
+                P->relaxed = true;
+                P->mfma_tried = true;
+                P->mfma_growth = growth;
+                if (!(growth <= MFMA_GROWTH_LIMIT)) {     // the guard refuses the explicit inverses (a NaN too): substitution, from L.x
+                    dfree(P->frag_f);
+                    P->frag_f = nullptr;
+                }
+                g_factor_path = 3;
+            } else {
+                if (!F.sparse && F.min_bs == bs && (bs == 8 || bs == 16 || bs == 32 || bs == 64) && ctx().opt.cholsol_dense_blocks) {
+                    // equal dense blocks (the forest's record says so: no k_clique_factor_shape over L.i): the programs straight from L.x
+                    P = new CholPlan();
+                    *Pout = P;
+                    P->n = n;
+                    P->L = L;
+                    CSX_TRY(cholsol_plan_clique(P, bs));
+                } else {
+                    CSX_TRY(cholsol_plan(L, nullptr, Pout));
+                    P = *Pout;
+                }
+                if (!exact) {
+                    P->relaxed = true;
+                    CSX_TRY(cholsol_build_mfma(P));
+                    CSX_TRY(cholsol_build_sn(P));
+                }
+                g_factor_path = F.sparse ? 2 : 1;
+            }
+            g_factor_ms[2] = since(t_call);
+            return CSX_OK;
+        }
+    }
+    // the general path: the three calls behind one entry
+    std::vector<int32_t> parent((size_t)std::max(n, 1)), cp((size_t)n + 1);
+    CSX_TRY(csx_schol(hA, parent.data(), cp.data()));
+    g_factor_ms[0] = since(t_call);
+    CSX_TRY(chol_device(A, parent.data(), cp.data(), nullptr, L));
+    g_factor_ms[1] = g_chol_numeric_ms;
+    CSX_TRY(cholsol_plan(L, nullptr, Pout));
+    if (!exact) {
+        (*Pout)->relaxed = true;
+        CSX_TRY(cholsol_build_mfma(*Pout));
+        CSX_TRY(cholsol_build_sn(*Pout));
+    }
+    g_factor_path = 0;
+    g_factor_ms[2] = since(t_call);
+    return CSX_OK;
+}
+}  // namespace csx
+
+extern "C" int csx_cholsol_factor(csx_handle_t hA, int exact, csx_handle_t *outL, csx_handle_t *outPlan) {
+    CSX_TRY(require_ready());
+    Csc *A = csc(hA);
+    if (!A || !A->x || A->m != A->n || !outL || !outPlan) return CSX_EINVAL;
+    Csc *L = new Csc();
+    CholPlan *P = nullptr;
+    const int st = cholsol_factor_device(hA, A, exact != 0, L, &P);
+    if (st != CSX_OK) {
+        free_cholplan(P);
+        free_csc(L);
+        return st;
+    }
+    *outL = put(K_CSC, L);
+    *outPlan = put(K_CHOLPLAN, P);
+    return CSX_OK;
+}
+
+extern "C" int csx_cholsol_factor_info(int32_t *path, double *analysis_ms, double *numeric_ms, double *call_ms) {
+    if (g_factor_path < 0) return CSX_EINVAL;   // no csx_cholsol_factor has completed yet
+    if (path) *path = g_factor_path;
+    if (analysis_ms) *analysis_ms = g_factor_ms[0];
+    if (numeric_ms) *numeric_ms = g_factor_ms[1];
+    if (call_ms) *call_ms = g_factor_ms[2];
     return CSX_OK;
 }
 

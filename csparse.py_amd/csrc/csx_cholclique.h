@@ -12,6 +12,7 @@ namespace csx {
 struct CliqueForest {
     int32_t n = 0;
     int32_t nblocks = 0, max_bs = 0;
+    int32_t min_bs = 0;          // narrowest block (min_bs == max_bs: a forest of EQUAL blocks, what the dense-block solve kernels want)
     int64_t lnz = 0;
     bool ascending = true;       // the upper part of every column is strictly ascending (what k_chol_clique needs)
     bool dense_in_front = false; // ... and is rows u[k] .. k, one each, stored before any lower entry: k_chol_clique skips A.i
@@ -34,12 +35,39 @@ struct CliqueCompare {
     int32_t *dp = nullptr, *dc = nullptr;
     int *bad = nullptr;
     int h = 1;
+    hipEvent_t ev = nullptr;     // recorded on the context's stream when the temporaries were taken: the side stream waits for it
 };
 int clique_matches_begin(const CliqueForest &F, const int32_t *parent, const int32_t *cp, CliqueCompare *c);
 int clique_matches_run(CliqueCompare *c);
 int clique_matches_end(CliqueCompare *c, bool *same);
+// What the block kernel can write BESIDE L.x while it has a finished block in registers (csx_cholsol_factor: factor -> plan in one
+// kernel instead of k_clique_factor_shape + k_clique_plan + k_mfma_frags reading L back): the matrix-core solve's operands for a forest
+// of EQUAL dense blocks of 16 / 32 / 64 columns -- per block the tiles -L_ij and W_ii = inv(L_ii) in k_cholsol_mfma's fragment order --
+// the guard's measure max|L| max|W| over the forest, and the plan's block list.  With `emit`, L.i is NOT written (L->i may be null:
+// Csc::rows_pending).
+struct Tree;
+struct CliqueEmit {
+    double *frag = nullptr;               // [nblocks * frags_per_block(bs / 16) * 64]
+    unsigned long long *cond_bits = nullptr;   // ordered bits of the largest max|L| max|W| of a block (zeroed by the caller)
+    Tree *trees = nullptr;                // [nblocks]  {first column, columns}
+    int32_t *tree_nodes = nullptr;        // [n]        the identity node list
+};
 // values and row indices of L (L->p = F.cp already in place, L->i / L->x allocated); blocks of at most 64 columns
-int chol_clique_numeric(const Csc *A, const CliqueForest &F, Csc *L, int *d_notspd);
+int chol_clique_numeric(const Csc *A, const CliqueForest &F, Csc *L, int *d_notspd, const CliqueEmit *emit = nullptr);
+constexpr int clique_frags_per_block(int nb16) { return (nb16 * (nb16 - 1) / 2 + nb16) * 4; }
+
+// Column `col` of the inverse of a 16 x 16 lower-triangular tile T (element (r, q) at T[r * ld + q]): w[r] = inv(T)(r, col), zero
+// above the diagonal.  Shared by k_mfma_frags (csx_chol.hip: fragments from a plan's programs) and k_chol_clique (fragments from
+// the block in registers), so that both give a plan the same bits.
+__device__ __forceinline__ void tile_inverse_column(const double *T, int ld, int col, double *w) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        double sres = r == col ? 1.0 : 0.0;
+#pragma unroll
+        for (int q = 0; q < r; q++) sres -= T[r * ld + q] * (q >= col ? w[q] : 0.0);
+        w[r] = r >= col ? sres / T[r * ld + r] : 0.0;
+    }
+}
 constexpr int CLIQUE_MAX_BLOCK = 64;
 // *bs = the block size when L is the factor of a forest of equal dense blocks on consecutive columns, else 0
 int clique_factor_block_size(const Csc *L, int32_t *bs);

@@ -23,6 +23,7 @@
 #include <cstdio>
 
 #include "csx_internal.h"
+#include "csx_sweep.h"
 #include "csx_cholclique.h"
 
 namespace csx {
@@ -128,33 +129,40 @@ __global__ __launch_bounds__(256) void k_clique_mark(int32_t n, const int32_t *_
 __global__ __launch_bounds__(256) void k_clique_counts(int32_t n, const int32_t *__restrict__ u, const int32_t *__restrict__ is_start,
                                                        const int32_t *__restrict__ block_id, const int32_t *__restrict__ end_of,
                                                        int32_t *__restrict__ count, int32_t *__restrict__ start, int *stats,
-                                                       unsigned long long *lnz) {
-    __shared__ int s_max[4];
+                                                       unsigned long long *lnz, int *min_bs, int *nblocks) {
+    __shared__ int s_max[4], s_min[4];
     __shared__ unsigned long long s_sum[4];
-    int mx = 0;
+    int mx = 0, mn = 0x7fffffff;
     unsigned long long sum = 0ull;
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
-        const int32_t a = u[k], e = end_of[a];
+        const int32_t a = u[k], e = a >= 0 ? end_of[a] : (int32_t)k;   // (a matrix that failed the rule: anything, nothing is used)
         count[k] = e - (int32_t)k + 1;
         if (is_start[k]) {
             const int32_t bs = e - a + 1;
             start[block_id[k]] = (int32_t)k;
             mx = max(mx, bs);
+            mn = min(mn, bs);
             sum += (unsigned long long)bs * (unsigned long long)(bs + 1) / 2ull;
         }
-        if (k == n - 1) start[block_id[k] + is_start[k]] = n;
+        if (k == n - 1) {
+            start[block_id[k] + is_start[k]] = n;
+            *nblocks = block_id[k] + is_start[k];
+        }
     }
     for (int o = 32; o > 0; o >>= 1) {
         mx = max(mx, __shfl_xor(mx, o));
+        mn = min(mn, __shfl_xor(mn, o));
         sum += __shfl_xor(sum, o);
     }
     if ((threadIdx.x & 63) == 0) {
         s_max[threadIdx.x >> 6] = mx;
+        s_min[threadIdx.x >> 6] = mn;
         s_sum[threadIdx.x >> 6] = sum;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         atomicMax(&stats[0], max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3])));
+        atomicMin(min_bs, min(min(s_min[0], s_min[1]), min(s_min[2], s_min[3])));
         atomicAdd(lnz, s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]);
     }
 }
@@ -258,24 +266,38 @@ void free_clique_cache(CliqueForest *F) {
     delete F;
 }
 
+__global__ void k_cq_init(int *flags) {
+    if (threadIdx.x < 8) flags[threadIdx.x] = threadIdx.x == 6 ? 0x7fffffff : 0;
+}
+
 int clique_forest(const Csc *A, CliqueForest *F, bool *ok) {
     *ok = false;
     const int32_t n = A->n;
     if (n <= 0 || A->m != A->n) return CSX_OK;
     hipStream_t s = ctx().stream;
     DevScope tmp;
-    int32_t *u = nullptr, *is_start = nullptr, *block_id = nullptr, *end_of = nullptr, *count = nullptr;
-    int *flags = nullptr;   // [0] not ascending, [1] not a clique forest, [2] widest block, [3] not "dense and in front"; [4..5] lnz (64 bits)
+    int32_t *u = nullptr, *is_start = nullptr, *block_id = nullptr, *end_of = nullptr, *count = nullptr, *start_all = nullptr;
+    int *flags = nullptr;   // [0] not ascending, [1] not a clique forest, [2] widest block, [3] not "dense and in front"; [4..5] lnz (64 bits),
+                            // [6] narrowest block, [7] number of blocks
     CSX_TRY(tmp.alloc(&u, (size_t)n));
     CSX_TRY(tmp.alloc(&is_start, (size_t)n + 1));
     CSX_TRY(tmp.alloc(&block_id, (size_t)n + 1));
     CSX_TRY(tmp.alloc(&end_of, (size_t)n));
     CSX_TRY(tmp.alloc(&count, (size_t)n + 1));
+    CSX_TRY(tmp.alloc(&start_all, (size_t)n + 1));
     CSX_TRY(tmp.alloc(&flags, 8));
     CSX_TRY(dalloc(&F->parent, (size_t)n));
-    CSX_HIP(hipMemsetAsync(flags, 0, 8 * sizeof(int), s));
+    CSX_TRY(dalloc(&F->cp, (size_t)n + 1));
+    // Everything a forest of cliques needs is queued BEFORE the host looks at a flag -- one wait for the whole analysis (round 4
+    // waited after the rule, after the block count and after lnz).  A matrix that fails the rule has paid for two scans and the counts
+    // in vain (0.2 ms at 5M columns) and goes on to the second rule below.
+    hipLaunchKernelGGL(k_cq_init, dim3(1), dim3(64), 0, s, flags);
     hipLaunchKernelGGL(k_clique_min, dim3(blocks_for((int64_t)n * 16)), dim3(256), 0, s, n, A->nnz, A->p, A->i, u, flags);
     hipLaunchKernelGGL(k_clique_mark, dim3(blocks_for(n)), dim3(256), 0, s, n, u, is_start, F->parent, end_of, flags);
+    CSX_TRY(scan_exclusive_i32(is_start, block_id, n, nullptr));
+    hipLaunchKernelGGL(k_clique_counts, dim3(std::min(blocks_for(n), 1024u)), dim3(256), 0, s, n, u, is_start, block_id, end_of, count,
+                       start_all, flags + 2, (unsigned long long *)(flags + 4), flags + 6, flags + 7);
+    CSX_TRY(scan_exclusive_i32(count, F->cp, n, nullptr));
     int h[8] = {0};
     CSX_HIP(hipMemcpyAsync(h, flags, sizeof h, hipMemcpyDeviceToHost, s));
     CSX_HIP(hipStreamSynchronize(s));
@@ -290,7 +312,7 @@ int clique_forest(const Csc *A, CliqueForest *F, bool *ok) {
         CSX_TRY(tmp.alloc(&smin, (size_t)n));
         CSX_HIP(hipMemcpyAsync(smin, u, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
         CSX_TRY(suffix_min_i32(smin, n));
-        CSX_HIP(hipMemsetAsync(flags, 0, 8 * sizeof(int), s));
+        hipLaunchKernelGGL(k_cq_init, dim3(1), dim3(64), 0, s, flags);
         hipLaunchKernelGGL(k_forest_mark, dim3(blocks_for(n)), dim3(256), 0, s, n, u, smin, is_start, flags);
         int64_t nb = 0;
         CSX_TRY(scan_exclusive_i32(is_start, block_id, n, &nb));
@@ -303,7 +325,6 @@ int clique_forest(const Csc *A, CliqueForest *F, bool *ok) {
             free_clique(F);
             return CSX_OK;
         }
-        CSX_TRY(dalloc(&F->cp, (size_t)n + 1));
         CSX_TRY(dalloc(&F->colmask, (size_t)n));
         hipLaunchKernelGGL(k_forest_symbolic, dim3(blocks_for(nb * 64)), dim3(256), 0, s, F->start, (int32_t)nb, A->p, A->i, F->parent,
                            count, F->colmask, (unsigned long long *)(flags + 4));
@@ -319,6 +340,7 @@ int clique_forest(const Csc *A, CliqueForest *F, bool *ok) {
         F->n = n;
         F->nblocks = (int32_t)nb;
         F->max_bs = h[2];
+        F->min_bs = 0;
         F->lnz = (int64_t)lz;
         F->ascending = true;
         F->dense_in_front = false;
@@ -326,24 +348,19 @@ int clique_forest(const Csc *A, CliqueForest *F, bool *ok) {
         *ok = true;
         return CSX_OK;
     }
-    int64_t nblocks = 0;
-    CSX_TRY(scan_exclusive_i32(is_start, block_id, n, &nblocks));
-    CSX_TRY(dalloc(&F->start, (size_t)nblocks + 1));
-    CSX_TRY(dalloc(&F->cp, (size_t)n + 1));
-    hipLaunchKernelGGL(k_clique_counts, dim3(std::min(blocks_for(n), 1024u)), dim3(256), 0, s, n, u, is_start, block_id, end_of, count,
-                       F->start, flags + 2, (unsigned long long *)(flags + 4));
-    CSX_TRY(scan_exclusive_i32(count, F->cp, n, nullptr));
-    CSX_HIP(hipMemcpyAsync(h, flags, sizeof h, hipMemcpyDeviceToHost, s));
-    CSX_HIP(hipStreamSynchronize(s));
     unsigned long long lnz = 0;
     std::memcpy(&lnz, h + 4, sizeof lnz);
     if (lnz > 0x7fffffffull) {   // L does not fit int32 indices: the general path reports it
         free_clique(F);
         return CSX_OK;
     }
+    const int32_t nblocks = h[7];
+    CSX_TRY(dalloc(&F->start, (size_t)nblocks + 1));
+    CSX_HIP(hipMemcpyAsync(F->start, start_all, ((size_t)nblocks + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
     F->n = n;
-    F->nblocks = (int32_t)nblocks;
+    F->nblocks = nblocks;
     F->max_bs = h[2];
+    F->min_bs = h[6];
     F->lnz = (int64_t)lnz;
     F->ascending = h[0] == 0;
     F->dense_in_front = h[0] == 0 && h[3] == 0;
@@ -363,13 +380,17 @@ __global__ __launch_bounds__(256) void k_clique_compare(int32_t n, const int32_t
 // own (the context's side stream), so that csx_chol can start the block kernel first and pay only for the longer of the two.
 int clique_matches_begin(const CliqueForest &F, const int32_t *parent, const int32_t *cp, CliqueCompare *c) {
     const int32_t n = F.n;
-    // (the temporaries come from the pool while the context's stream is idle: no block of it is still in use by work in flight)
     CSX_TRY(dalloc(&c->dp, (size_t)n));
     CSX_TRY(dalloc(&c->dc, (size_t)n + 1));
     CSX_TRY(dalloc(&c->bad, 1));
     c->parent = parent;
     c->cp = cp;
     c->F = &F;
+    // The pool's blocks are ordered on the context's stream only: whoever held these three before may still be using them in work
+    // queued there (a solve or a product the caller did not wait for).  The side stream therefore starts behind everything the
+    // context's stream holds NOW -- before the caller's block kernel goes in, so the upload still runs beside that kernel.
+    CSX_HIP(hipEventCreateWithFlags(&c->ev, hipEventDisableTiming));
+    CSX_HIP(hipEventRecord(c->ev, ctx().stream));
     return CSX_OK;
 }
 
@@ -377,6 +398,7 @@ int clique_matches_begin(const CliqueForest &F, const int32_t *parent, const int
 int clique_matches_run(CliqueCompare *c) {
     hipStream_t s = ctx().side;
     const int32_t n = c->F->n;
+    CSX_HIP(hipStreamWaitEvent(s, c->ev, 0));
     CSX_HIP(hipMemsetAsync(c->bad, 0, sizeof(int), s));
     CSX_HIP(hipMemcpyAsync(c->dp, c->parent, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, s));
     CSX_HIP(hipMemcpyAsync(c->dc, c->cp, ((size_t)n + 1) * sizeof(int32_t), hipMemcpyHostToDevice, s));
@@ -389,6 +411,8 @@ int clique_matches_end(CliqueCompare *c, bool *same) {
     *same = false;
     int st = CSX_OK;
     if (hipStreamSynchronize(ctx().side) != hipSuccess) st = CSX_ERUNTIME;
+    if (c->ev) (void)hipEventDestroy(c->ev);
+    c->ev = nullptr;
     dfree(c->dp);
     dfree(c->dc);
     dfree(c->bad);
@@ -455,14 +479,24 @@ __device__ __forceinline__ double cq_bcast(double v, int src) {
 // PARTS: 1 load, 2 factor, 4 store -- 7 is the kernel; the others exist in the ablation build only (what each phase costs)
 // SPARSE: the blocks are small trees (CliqueForest::sparse).  The arithmetic is the dense block's -- an entry outside L's
 // pattern is a zero that stays zero -- and only the store differs: column g keeps the rows of its mask, compacted.
-template <int PARTS, bool SMALL, bool DENSE, bool SPARSE>
+// EMIT (csx_cholsol_factor on a forest of EQUAL blocks of 16 / 32 / 64 columns): the kernel also writes what the matrix-core solve
+// reads -- the block's tiles -L_ij (as a panel of eight columns is finished: the lanes of tile row i hold them) and W_ii = inv(L_ii)
+// (the diagonal tiles are kept in LDS as their panels finish; after the last panel lane (tile, column) inverts its column, the
+// arithmetic of k_mfma_frags) in k_cholsol_mfma's fragment order, the guard's measure and the plan's block list -- and does NOT
+// write L.i (rows j, j + 1, ... in every column: csc_fill_rows makes them from L.p when somebody asks).  L.x is written as always.
+constexpr int CQ_DIAG = 16 * 17;      // doubles per kept diagonal tile (odd stride)
+constexpr int CQ_TILE = CQ_CH * CQ_LD + 2;                 // the staging tile + the spare slot rejected entries go to
+constexpr int CQ_TILE_EMIT = 8 * 64 + 4 * CQ_DIAG;         // colbuf + four diagonal tiles (>= CQ_TILE)
+static_assert(CQ_TILE_EMIT >= CQ_TILE, "the staging tile must fit");
+
+template <int PARTS, bool SMALL, bool DENSE, bool SPARSE, bool EMIT>
 __global__ __launch_bounds__(64 * CQ_WAVES, 3) void k_chol_clique(const int32_t *__restrict__ start, int32_t nblocks, int32_t n, int32_t nnz,
                                                                  const int32_t *__restrict__ Ap, const int32_t *__restrict__ Ai,
                                                                  const double *__restrict__ Ax, const int32_t *__restrict__ Lp,
                                                                  int32_t *__restrict__ Li, double *__restrict__ Lx, int *notspd,
-                                                                 const unsigned long long *__restrict__ colmask) {
+                                                                 const unsigned long long *__restrict__ colmask, CliqueEmit em) {
 #pragma clang fp contract(off)
-    __shared__ __attribute__((aligned(16))) double s_tile[CQ_WAVES][CQ_CH * CQ_LD + 2];   // + the spare slot rejected entries go to
+    __shared__ __attribute__((aligned(16))) double s_tile[CQ_WAVES][EMIT ? CQ_TILE_EMIT : CQ_TILE];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t t = (int64_t)blockIdx.x * CQ_WAVES + w;
@@ -574,6 +608,14 @@ __global__ __launch_bounds__(64 * CQ_WAVES, 3) void k_chol_clique(const int32_t 
     // 4.0 ns, in the LDS pipe beside the vector ALU; v_mul_f64 / v_add_f64 2.2 ns each.  With v_readlane the factor phase
     // took 2.2 ms at 5M rows, 62 % of it the readlanes.
     const int64_t base = Lp[c0];
+    double *em_diag = tile + 8 * 64;                                   // EMIT: the diagonal tiles, beside colbuf
+    double *em_frag = nullptr;
+    double em_lmax = 0.0;
+    if (EMIT) {
+        em_frag = em.frag + (size_t)t * (size_t)(clique_frags_per_block(bs >> 4) * 64);
+        if (lane < bs) em.tree_nodes[c0 + lane] = c0 + lane;
+        if (lane == 0) em.trees[t] = Tree{c0, bs};
+    }
     double *colbuf = tile;   // [8][64]   (s_setprio around the phases -- loading waves first, or factoring waves first -- 1.61-1.65 ms: no gain)
 #pragma unroll 1
     for (int J = 0; J < bs; J += 8) {
@@ -635,33 +677,87 @@ __global__ __launch_bounds__(64 * CQ_WAVES, 3) void k_chol_clique(const int32_t 
                 const int64_t colbase = base + (int64_t)g * bs - (int64_t)g * (g - 1) / 2 - g;
                 if (lane >= g && lane < bs && ((PARTS & 4) || a[jw] == 12345.678)) {
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(cq_u32x2, a[jw]), cq_rsrc(Lx + colbase, bs * 8), lane8, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b32((unsigned int)(c0 + lane), cq_rsrc(Li + colbase, bs * 4), lane4, 0, 0);
+                    if (!EMIT) __builtin_amdgcn_raw_buffer_store_b32((unsigned int)(c0 + lane), cq_rsrc(Li + colbase, bs * 4), lane4, 0, 0);
                 }
             }
+        }
+        if (EMIT && J < bs) {
+            // columns J .. J + 7 lie in tile column tj, k-steps sx0 and sx0 + 1; lane = (tile row ti, row m of the tile).  Fragment
+            // (tile (ti, tj), k-step sx) holds element (m, 4 sx + kq) at position 16 kq + m: for one column 16 lanes write 128
+            // contiguous bytes.  (Above the diagonal a[] is +0.0: nothing of it is read.)
+            const int tj = J >> 4, ti = lane >> 4, m = lane & 15;
+            if (ti > tj && lane < bs) {
+                double *dst = em_frag + (size_t)(((ti * (ti + 1) / 2 + tj) * 4 + ((J & 8) >> 2)) * 64 + m);
+#pragma unroll
+                for (int jw = 0; jw < 8; jw++) dst[(jw >> 2) * 64 + (jw & 3) * 16] = -a[jw];
+            } else if (ti == tj) {
+                double *dd = em_diag + ti * CQ_DIAG + m * 17 + (J & 8);
+#pragma unroll
+                for (int jw = 0; jw < 8; jw++) dd[jw] = a[jw];
+            }
+#pragma unroll
+            for (int jw = 0; jw < 8; jw++) em_lmax = fmax(em_lmax, fabs(a[jw]));
         }
 #pragma unroll
         for (int c = 0; c < 56; c++) a[c] = a[c + 8];
     }
+    if (EMIT) {
+        cq_wave_sync_lds();
+        const int blk = lane >> 4, col = lane & 15;
+        double wmax = 0.0;
+        if (16 * blk < bs) {
+            double wcol[16];
+            tile_inverse_column(em_diag + blk * CQ_DIAG, 17, col, wcol);
+            // fragment (tile (blk, blk), k-step col >> 2), positions 16 (col & 3) + r: this lane's sixteen values are contiguous
+            typedef double d2 __attribute__((ext_vector_type(2)));
+            d2 *dst = (d2 *)(em_frag + (size_t)(((blk * (blk + 1) / 2 + blk) * 4 + (col >> 2)) * 64 + (col & 3) * 16));
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                dst[r >> 1] = d2{wcol[r], wcol[r + 1]};
+                wmax = fmax(wmax, fmax(fabs(wcol[r]), fabs(wcol[r + 1])));
+            }
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            em_lmax = fmax(em_lmax, __shfl_xor(em_lmax, d, 64));
+            wmax = fmax(wmax, __shfl_xor(wmax, d, 64));
+        }
+        if (lane == 0) {   // (look first: after the first blocks hardly any raises the maximum, and an atomic per block on one address is served one after the other)
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(em_lmax * wmax);
+            if (!(bits <= *(volatile unsigned long long *)em.cond_bits)) atomicMax(em.cond_bits, bits);
+        }
+    }
 }
 
-int chol_clique_numeric(const Csc *A, const CliqueForest &F, Csc *L, int *d_notspd) {
+int chol_clique_numeric(const Csc *A, const CliqueForest &F, Csc *L, int *d_notspd, const CliqueEmit *emit) {
     hipStream_t s = ctx().stream;
     if (F.nblocks == 0 || A->nnz == 0) return CSX_OK;
     const dim3 grid((unsigned)((F.nblocks + CQ_WAVES - 1) / CQ_WAVES));
-#define CSX_CQ_GO(PARTS, SMALL, DENSE, SPARSE)                                                                                  \
-    hipLaunchKernelGGL((k_chol_clique<PARTS, SMALL, DENSE, SPARSE>), grid, dim3(64 * CQ_WAVES), 0, s, F.start, F.nblocks, A->n, A->nnz, \
-                       A->p, A->i, A->x, L->p, L->i, L->x, d_notspd, F.colmask)
+    if (emit) {
+        // what k_cholsol_mfma can take: equal dense blocks of 16 / 32 / 64 columns
+        if (F.sparse || F.min_bs != F.max_bs || (F.max_bs != 16 && F.max_bs != 32 && F.max_bs != 64)) return CSX_EINVAL;
+    }
+    const CliqueEmit em = emit ? *emit : CliqueEmit();
+#define CSX_CQ_GO(PARTS, SMALL, DENSE, SPARSE, EMIT)                                                                                  \
+    hipLaunchKernelGGL((k_chol_clique<PARTS, SMALL, DENSE, SPARSE, EMIT>), grid, dim3(64 * CQ_WAVES), 0, s, F.start, F.nblocks, A->n, \
+                       A->nnz, A->p, A->i, A->x, L->p, L->i, L->x, d_notspd, F.colmask, em)
 #define CSX_CQ(PARTS)                                                                                                       \
-    if (F.sparse && A->nnz < (1 << 29))                                                                                         \
-        CSX_CQ_GO(PARTS, true, false, true);                                                                                    \
+    if (emit && A->nnz < (1 << 29) && F.dense_in_front)                                                                         \
+        CSX_CQ_GO(PARTS, true, true, false, true);                                                                              \
+    else if (emit && A->nnz < (1 << 29))                                                                                        \
+        CSX_CQ_GO(PARTS, true, false, false, true);                                                                             \
+    else if (emit)                                                                                                              \
+        CSX_CQ_GO(PARTS, false, false, false, true);                                                                            \
+    else if (F.sparse && A->nnz < (1 << 29))                                                                                    \
+        CSX_CQ_GO(PARTS, true, false, true, false);                                                                             \
     else if (F.sparse)                                                                                                          \
-        CSX_CQ_GO(PARTS, false, false, true);                                                                                   \
+        CSX_CQ_GO(PARTS, false, false, true, false);                                                                            \
     else if (A->nnz < (1 << 29) && F.dense_in_front)                                                                            \
-        CSX_CQ_GO(PARTS, true, true, false);                                                                                    \
+        CSX_CQ_GO(PARTS, true, true, false, false);                                                                             \
     else if (A->nnz < (1 << 29))                                                                                                \
-        CSX_CQ_GO(PARTS, true, false, false);                                                                                   \
+        CSX_CQ_GO(PARTS, true, false, false, false);                                                                            \
     else                                                                                                                        \
-        CSX_CQ_GO(PARTS, false, false, false)
+        CSX_CQ_GO(PARTS, false, false, false, false)
     int parts = 7;
 #ifdef CSX_ABLATION
     if (const char *e = ablation_env("CSX_CQ_PARTS")) parts = atoi(e);
@@ -681,6 +777,27 @@ int chol_clique_numeric(const Csc *A, const CliqueForest &F, Csc *L, int *d_nots
 #undef CSX_CQ
 #undef CSX_CQ_GO
     CSX_LAUNCH_CHECK();
+    return CSX_OK;
+}
+
+// ---- row indices on demand (Csc::rows_pending) -------------------------------------------------------------------------
+// every column j holds the rows j, j + 1, ..., j + count - 1: 16 lanes per column
+__global__ __launch_bounds__(256) void k_fill_rows(int32_t n, const int32_t *__restrict__ Lp, int32_t *__restrict__ Li) {
+    const int t = threadIdx.x & 15;
+    const int64_t j64 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    if (j64 >= n) return;
+    const int32_t j = (int32_t)j64, b = Lp[j], e = Lp[j + 1];
+    for (int32_t p = b + t; p < e; p += 16) Li[p] = j + (p - b);
+}
+
+int csc_fill_rows(Csc *A) {
+    if (!A->rows_pending) return CSX_OK;
+    if (!A->i) CSX_TRY(dalloc(&A->i, (size_t)A->nnz));
+    if (A->n > 0) {
+        hipLaunchKernelGGL(k_fill_rows, dim3(blocks_for((int64_t)A->n * 16)), dim3(256), 0, ctx().stream, A->n, A->p, A->i);
+        CSX_LAUNCH_CHECK();
+    }
+    A->rows_pending = false;
     return CSX_OK;
 }
 

@@ -101,6 +101,9 @@ struct Csc {
     HouseLevels *house = nullptr;   // csx_happly's level schedule (pattern only; dropped by csx_csc_invalidate too)
     CliqueForest *clique = nullptr; // csx_schol's finding "a forest of cliques on consecutive columns" (tree, counts, block list on the
                                     // device), kept for the csx_chol that follows; pattern only, dropped by csx_csc_invalidate too
+    bool rows_pending = false;      // i == nullptr ON PURPOSE: every column holds the consecutive rows j, j + 1, ... (the factor of a
+                                    // forest of cliques, csx_cholsol_factor), so i[] follows from p[] alone and is written by
+                                    // csc_fill_rows the first time a handle to the matrix is resolved (csc() below)
 };
 
 struct Vec {
@@ -177,7 +180,12 @@ Context &ctx();
 int require_ready();
 csx_handle_t put(Kind k, void *ptr);
 void *get(csx_handle_t h, Kind k);
-inline Csc *csc(csx_handle_t h) { return (Csc *)get(h, K_CSC); }
+int csc_fill_rows(Csc *A);   // csx_cholclique.hip: the row indices of a matrix with rows_pending
+inline Csc *csc(csx_handle_t h) {
+    Csc *A = (Csc *)get(h, K_CSC);
+    if (A && A->rows_pending && csc_fill_rows(A) != CSX_OK) return nullptr;
+    return A;
+}
 inline Vec *vec(csx_handle_t h) { return (Vec *)get(h, K_VEC); }
 inline Vec *ivec(csx_handle_t h) { return (Vec *)get(h, K_IVEC); }
 

@@ -108,10 +108,8 @@ int scan_exclusive_i32(const int32_t *in, int32_t *out, int64_t n, int64_t *tota
         CSX_HIP(hipMemcpyAsync(&t, out + n, sizeof t, hipMemcpyDeviceToHost, s));
         CSX_HIP(hipStreamSynchronize(s));
         *total_host = t;
-    } else if (sums) {
-        CSX_HIP(hipStreamSynchronize(s));  // sums is freed below
     }
-    dfree(sums);
+    dfree(sums);   // (no wait: the pool's blocks are used on the context's stream only, whoever gets this one next queues behind the scan)
     return CSX_OK;
 }
 

@@ -219,6 +219,21 @@ int csx_chol_info(int32_t *path, double *numeric_ms);
  * blocks of 8 / 16 / 32 / 64 columns (recognised from L itself, also from an L that came over the wire or from the host)
  * is cut straight out of L.x; any other factor gets two triangular-solve analyses and the forest partition. */
 int csx_cholsol_plan(csx_handle_t L, const int32_t *pinv /* host, or NULL */, csx_handle_t *plan);
+/* cs_cholsol's factor sequence in natural order -- S = cs_schol(0, A); N = cs_chol(A, S), csparse.py:636-639 -- and the solve
+ * plan of csparse.py:640-643 in ONE call, the symbolic analysis never leaving the device (round 5; replaces csx_schol's 40 MB of
+ * parent / cp going to the host at 5M columns, csx_chol's upload-and-compare of the same arrays, and for forests of equal dense
+ * blocks the three kernels that read L back to re-arrange it).  A: device CSC, square, upper triangle used.  exact: the order the
+ * plan starts in (csx_cholsol_set_order changes it later).  *L: the factor (device CSC, diagonal first, rows ascending; for a forest
+ * of equal dense blocks factored with exact = 0 the row indices are written when a handle to L is first used, its values and
+ * column pointers at once); *plan: the solve plan, which borrows L's arrays -- free the plan before L.  CSX_ENOTSPD as csx_chol.
+ * The analysis it implies is cs_schol(0, A)'s: S.cp = L.p, S.parent[j] = the first row below the diagonal of column j of L. */
+int csx_cholsol_factor(csx_handle_t A, int exact, csx_handle_t *L, csx_handle_t *plan);
+/* What the last successful csx_cholsol_factor did.  *path: 3 = forest of equal dense blocks of 16 / 32 / 64 columns, rounding-equal
+ * order: the block kernel wrote the matrix-core solve's operands beside L.x, no other kernel touched L; 1 = forest of cliques (block
+ * kernel, then the plan cut out of L.x); 2 = forest of small sparse trees; 0 = the general path (csx_schol + csx_chol +
+ * csx_cholsol_plan behind the one entry).  *analysis_ms: host clock up to the end of the symbolic analysis; *numeric_ms: HIP-event
+ * time of the numeric kernel(s); *call_ms: host clock of the whole call.  Any pointer may be NULL. */
+int csx_cholsol_factor_info(int32_t *path, double *analysis_ms, double *numeric_ms, double *call_ms);
 /* *path, for the plan's current order (csx_cholsol_set_order): 0 = level-scheduled generic, 1 = fused per-tree
  * kernel (X tile in LDS; the only forest path of the default, exact order), 2 = dense-block FMA substitution,
  * 3 = dense blocks as a blocked TRSM on the matrix cores (fp64 MFMA; blocks of 16/32/64 whose block inverses
