@@ -74,12 +74,14 @@ _PROTOS = {
     "csx_tri_components": [H, _i32p],
     "csx_permute_vec": [H, H, H, C.c_int32, C.c_int32, C.c_int],
     "csx_schol_host": [C.c_int32, _i32p, _i32p, _i32p, _i32p],
+    "csx_counts_host": [C.c_int32, C.c_int32, _i32p, _i32p, _i32p, _i32p, C.c_int, _i32p],
     "csx_chol": [H, _i32p, _i32p, _i32p, C.POINTER(H)],
     "csx_chol_info": [_i32p, _f64p],
     "csx_cholsol_plan": [H, _i32p, C.POINTER(H)],
     "csx_cholsol_factor": [H, C.c_int, C.POINTER(H), C.POINTER(H)],
     "csx_cholsol_factor_info": [C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "csx_cholsol_solve": [H, H, C.c_int32],
+    "csx_cholsol_graph_info": [H, _i32p, _f64p],
     "csx_cholsol_info": [H, _i32p, _i32p, _i32p],
     "csx_qr_host": [C.c_int32, C.c_int32, C.c_int32, _i32p, _i32p, _f64p, _i32p, _i32p, _i32p, _i32p, C.c_int32, C.c_int32,
                     _i32p, _i32p, _f64p, _i32p, _i32p, _f64p, _f64p],

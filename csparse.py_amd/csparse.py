@@ -1433,6 +1433,27 @@ def cs_post(parent, n):
     return post
 
 
+def cs_counts(A, parent, post, ata):
+    """Column counts of L L' = A (ata False: the upper triangle of a square A) or L L' = A'A (ata True), given the elimination
+    tree and its postorder (csparse.py:703-764; cs_leaf :1280-1304, _init_ata :677-700).  Host C++ (csx_counts_host): a symbolic
+    step in front of the hot path.  None on bad input, like the reference."""
+    if not CS_CSC(A) or parent is None or post is None:
+        return None
+    m, n = A.m, A.n
+    if not ata and m != n:
+        return None
+    p = _csx.i32(A.p[:n + 1])
+    i = _csx.i32(A.i[:int(p[n])])
+    par, po = _csx.i32(parent[:n]), _csx.i32(post[:n])
+    if len(par) < n or len(po) < n:
+        return None
+    cnt = np.empty(max(n, 1), dtype=np.int32)
+    st = _csx.load().csx_counts_host(m, n, _csx.pi(p), _csx.pi(i), _csx.pi(par), _csx.pi(po), 1 if ata else 0, _csx.pi(cnt))
+    if st != _csx.OK:
+        return None
+    return cnt[:n].tolist()
+
+
 def cs_sqr(order, A, qr):
     """Symbolic ordering and analysis for QR or LU (csparse.py:2187-2217).  order 0 natural, 1 / 2 / 3 as cs_amd.
     LU: only the column ordering S.q and the reference's size guesses.  QR: the column elimination tree, the column

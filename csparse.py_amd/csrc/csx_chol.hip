@@ -1031,8 +1031,11 @@ struct CholPlan {
     int32_t g_nrhs = 0;
     int64_t g_gen = -1;                // the work-space generation of the supernodal plan the capture saw
     int g_opt = -1;                    // "tri.supernodes" at capture time: sn_solve picks its kernels by it
-    double *last_X = nullptr;          // the block of the solve before this one ("tri.graph" = 2 captures on the second
-    int32_t last_nrhs = 0;             // consecutive solve of the same block, not for a block it sees once)
+    double *last_X = nullptr;          // the block of the solve before this one, and how many consecutive solves it has been the
+    int32_t last_nrhs = 0;             // block of: "tri.graph" = 2 captures on the THIRD consecutive solve of one block -- a capture
+    int32_t same_block_runs = 0;       // costs several solves' worth of host time, a block seen once or twice never repays it
+    int32_t g_captures = 0;            // captures made so far, host ms of the last one (csx_cholsol_graph_info)
+    double g_capture_ms = 0.0;
     int32_t n = 0;
     const Csc *L = nullptr;  // not owned; must outlive the plan
     TriPlan *fwd = nullptr, *bwd = nullptr;
@@ -2489,14 +2492,16 @@ static int cholsol_solve(CholPlan *P, double *B, int32_t nrhs) {
     if (P->relaxed && P->sn && ctx().opt.tri_supernodes && sn_usable(P->sn)) {
         CSX_TRY(tri_solve_raw(P->fwd, X, 0, false));          // a zero pivot found by the analysis: ZeroDivisionError
         // "tri.graph": 1 = always; 2 (the default) = when a solve is many launches -- more than 256: a natural-order grid
-        // factor is 5 624 -- and this block was also the previous solve's (a capture costs about as much as the launches it
-        // replaces: it pays from the second replay on); 0 = never.  The replay takes the host 13 - 60 us instead of 0.35 -
-        // 17 ms; the device time is the same.
+        // factor is 5 624 -- and this block has been the block of the two solves before this one as well (round 4 captured on
+        // the SECOND solve of a block: 9 ms of capture + instantiate in front of a 1.8 ms solve on bcsstk16, which a caller
+        // who solves a block twice never gets back); 0 = never.  The replay takes the host 13 - 60 us instead of 0.35 -
+        // 17 ms; the device time is the same.  csx_cholsol_graph_info reports the captures and what the last one cost.
         bool graph = ctx().opt.tri_graph == 1;
         if (ctx().opt.tri_graph == 2) {
             int32_t nsn = 0, steps = 0, maxw = 0;
             sn_info(P->sn, &nsn, &steps, &maxw);
-            graph = 6 * (int64_t)steps > 256 && P->last_X == X && P->last_nrhs == nrhs;
+            P->same_block_runs = (P->last_X == X && P->last_nrhs == nrhs) ? P->same_block_runs + 1 : 0;
+            graph = 6 * (int64_t)steps > 256 && (P->same_block_runs >= 2 || (P->g_exec && P->g_X == X && P->g_nrhs == nrhs));
         }
         P->last_X = X;
         P->last_nrhs = nrhs;
@@ -2508,6 +2513,7 @@ static int cholsol_solve(CholPlan *P, double *B, int32_t nrhs) {
                 if (P->g_exec) (void)hipGraphExecDestroy(P->g_exec);
                 P->g_exec = nullptr;
                 hipGraph_t graph = nullptr;
+                const auto t_cap = std::chrono::steady_clock::now();
                 CSX_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
                 int st = sn_solve(P->sn, true, Gp, Gi, Gx, Gd, P->L, X, nrhs);
                 if (st == CSX_OK) st = sn_solve(P->sn, false, Gp, Gi, Gx, Gd, P->L, X, nrhs);
@@ -2528,6 +2534,8 @@ static int cholsol_solve(CholPlan *P, double *B, int32_t nrhs) {
                 P->g_nrhs = nrhs;
                 P->g_gen = sn_generation(P->sn);
                 P->g_opt = ctx().opt.tri_supernodes;
+                P->g_captures++;
+                P->g_capture_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_cap).count();
             }
             CSX_HIP(hipGraphLaunch(P->g_exec, s));
         } else {
@@ -2805,6 +2813,14 @@ extern "C" int csx_cholsol_sn_info(csx_handle_t h, int32_t *supernodes, int32_t 
     if (max_width) *max_width = c;
     if (matrix_cores) *matrix_cores = mc;
     if (growth) *growth = g;
+    return CSX_OK;
+}
+
+extern "C" int csx_cholsol_graph_info(csx_handle_t h, int32_t *captures, double *last_capture_ms) {
+    CholPlan *P = (CholPlan *)get(h, K_CHOLPLAN);
+    if (!P) return CSX_EINVAL;
+    if (captures) *captures = P->g_captures;
+    if (last_capture_ms) *last_capture_ms = P->g_capture_ms;
     return CSX_OK;
 }
 

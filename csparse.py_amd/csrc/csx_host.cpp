@@ -334,6 +334,91 @@ namespace csx {
 
 using namespace csx;
 
+// cs_counts (csparse.py:703-764, with cs_leaf :1280-1304 and the row lists of _init_ata :677-700): the column counts of
+// chol(A) (ata = 0: A square, its upper triangle used) or of chol(A'A) (ata != 0: A m-by-n) from the elimination tree
+// `parent` and its postorder `post` (both n entries, the caller's -- cs_etree / cs_post), without forming L.  For every node j
+// in postorder the rows of the columns filed under j (ata: the rows whose leftmost column, by postorder rank, is j; else
+// column j itself) are run through the skeleton test: A(i, j) counts where j is a leaf of row i's subtree, and the least
+// common ancestor of two consecutive leaves loses the overlap; the deltas are then summed up the tree.
+extern "C" int csx_counts_host(int32_t m, int32_t n, const int32_t *Ap, const int32_t *Ai, const int32_t *parent,
+                               const int32_t *post, int ata, int32_t *colcount) {
+    if (m < 0 || n < 0 || !Ap || (!Ai && Ap[n] > 0) || !parent || !post || !colcount) return CSX_EINVAL;
+    if (!ata && m != n) return CSX_EINVAL;
+    const int64_t nnz = Ap[n];
+    for (int64_t p = 0; p < nnz; p++)
+        if (Ai[p] < 0 || Ai[p] >= m) return CSX_EINVAL;
+    {   // parent must be a forest on n nodes with parents above their children's... any value in [-1, n); post a permutation
+        std::vector<char> seen((size_t)n, 0);
+        for (int32_t k = 0; k < n; k++) {
+            if (parent[k] < -1 || parent[k] >= n || post[k] < 0 || post[k] >= n || seen[(size_t)post[k]]) return CSX_EINVAL;
+            seen[(size_t)post[k]] = 1;
+        }
+    }
+    // the pattern of A' (row i of A lists its columns in ascending order): cs_transpose(A, False), csparse.py:721
+    std::vector<int32_t> ATp((size_t)m + 1, 0), ATi((size_t)nnz);
+    for (int64_t p = 0; p < nnz; p++) ATp[(size_t)Ai[p] + 1]++;
+    for (int32_t i = 0; i < m; i++) ATp[(size_t)i + 1] += ATp[(size_t)i];
+    {
+        std::vector<int32_t> fill(ATp.begin(), ATp.end() - 1);
+        for (int32_t k = 0; k < n; k++)
+            for (int32_t p = Ap[k]; p < Ap[k + 1]; p++) ATi[(size_t)fill[(size_t)Ai[p]]++] = k;
+    }
+    std::vector<int32_t> first((size_t)n, -1), maxfirst((size_t)n, -1), prevleaf((size_t)n, -1), anc((size_t)n);
+    int32_t *delta = colcount;
+    for (int32_t k = 0; k < n; k++) {                 // first[j] = postorder rank of the first descendant of j
+        int32_t j = post[k];
+        delta[j] = first[(size_t)j] == -1 ? 1 : 0;    // 1 for a leaf
+        int32_t guard = 0;
+        while (j != -1 && first[(size_t)j] == -1) {
+            first[(size_t)j] = k;
+            j = parent[j];
+            if (++guard > n) return CSX_EINVAL;       // a cycle in `parent`
+        }
+    }
+    std::vector<int32_t> head, nxt;
+    if (ata) {                                        // _init_ata: row i filed under the smallest postorder rank among its columns
+        std::vector<int32_t> rank((size_t)n, 0);
+        head.assign((size_t)n + 1, -1);
+        nxt.assign((size_t)m, -1);
+        for (int32_t k = 0; k < n; k++) rank[(size_t)post[k]] = k;
+        for (int32_t i = 0; i < m; i++) {
+            int32_t k = n;
+            for (int32_t p = ATp[(size_t)i]; p < ATp[(size_t)i + 1]; p++) k = std::min(k, rank[(size_t)ATi[(size_t)p]]);
+            nxt[(size_t)i] = head[(size_t)k];
+            head[(size_t)k] = i;
+        }
+    }
+    for (int32_t j = 0; j < n; j++) anc[(size_t)j] = j;
+    for (int32_t k = 0; k < n; k++) {
+        const int32_t j = post[k];
+        if (parent[j] != -1) delta[parent[j]]--;      // j is not a root
+        for (int32_t J = ata ? head[(size_t)k] : j; J != -1; J = ata ? nxt[(size_t)J] : -1) {
+            for (int32_t p = ATp[(size_t)J]; p < ATp[(size_t)J + 1]; p++) {
+                const int32_t i = ATi[(size_t)p];
+                if (i <= j || first[(size_t)j] <= maxfirst[(size_t)i]) continue;      // cs_leaf: j is not a leaf of row i's subtree
+                maxfirst[(size_t)i] = first[(size_t)j];
+                const int32_t jprev = prevleaf[(size_t)i];
+                prevleaf[(size_t)i] = j;
+                delta[j]++;                           // A(i, j) is in the skeleton
+                if (jprev != -1) {                    // a later leaf: the least common ancestor of the two loses the overlap
+                    int32_t q = jprev;
+                    while (q != anc[(size_t)q]) q = anc[(size_t)q];
+                    for (int32_t s = jprev; s != q;) {
+                        const int32_t sp = anc[(size_t)s];
+                        anc[(size_t)s] = q;
+                        s = sp;
+                    }
+                    delta[q]--;
+                }
+            }
+        }
+        if (parent[j] != -1) anc[(size_t)j] = parent[j];
+    }
+    for (int32_t j = 0; j < n; j++)
+        if (parent[j] != -1) colcount[parent[j]] += colcount[j];
+    return CSX_OK;
+}
+
 extern "C" int csx_schol_host(int32_t n, const int32_t *Ap, const int32_t *Ai, int32_t *parent, int32_t *cp) {
     if (n < 0 || !Ap || (!Ai && Ap[n] > 0) || !parent || !cp) return CSX_EINVAL;
     for (int32_t j = 0; j < n; j++)

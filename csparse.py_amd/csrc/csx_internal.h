@@ -150,7 +150,7 @@ struct Options {
     int sort_short_keys = 1;          // cs_transpose: 16-bit keys between the radix passes where the matrix allows (0: always 32-bit)
     int tri_graph = 2;                // supernodal solves: replay the launches of a solve as a hipGraph while the block of right-hand
                                       // sides stays in place: 0 never, 1 always, 2 when a solve is more than 256 launches and the
-                                      // block is the previous solve's too
+                                      // block has been the block of the two solves before it too (the third consecutive solve captures)
     int tri_supernodes = 1;           // cholsol: supernodal forward / backward solves on factors with supernodes (0 never, 1 yes,
                                       // 2 yes but the triangles by substitution out of LDS instead of on the matrix cores)
     int spgemm_ordered = 0;           // cs_multiply: sum every entry's products in the reference's order (bit-identical x)

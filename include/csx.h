@@ -82,8 +82,9 @@ int csx_mem_info(int64_t *cached_bytes, int64_t *live_bytes, int64_t *device_fre
  * 0 = the default quarter of the device).  Round 3: "tri.supernodes" (supernodal schedule of a cholsol plan in the
  * rounding-equal order: 1 = yes, triangles on the matrix cores where their guard allows (default); 2 = yes, triangles by
  * substitution out of LDS, no relaxed supernodes; 0 = never), "tri.graph" (the launches of a supernodal solve captured
- * into a hipGraph and replayed while the block of right-hand sides stays in place: 2 (default since round 4) = when a
- * solve is more than 256 launches and the block is also the previous solve's, 1 = always, 0 = never),
+ * into a hipGraph and replayed while the block of right-hand sides stays in place: 2 (default) = when a solve is more than
+ * 256 launches and the block has been the block of the two solves before it as well (round 5; round 4 captured on the second
+ * solve of a block, which cost more than it saved), 1 = always, 0 = never),
  * "cholsol.exact_variant" (the exact dense-block kernel: 0 = default = 5: L values by DPP row broadcast, one term in four
  * by an LDS broadcast read; 6: by DPP only; 1 - 4: the LDS-broadcast forms), "spgemm.ordered" (default 0; 1 = cs_multiply
  * sums every entry's products in the reference's order: bit-identical values, about twenty times the time),
@@ -186,6 +187,11 @@ int csx_permute_vec(csx_handle_t p, csx_handle_t b, csx_handle_t x, int32_t n, i
 /* cs_schol (natural order), csparse.py:2051-2072: host C++ symbolic analysis of
  * the upper triangle of a host CSC pattern.  parent[n], cp[n+1]. */
 int csx_schol_host(int32_t n, const int32_t *Ap, const int32_t *Ai, int32_t *parent, int32_t *cp);
+/* cs_counts, csparse.py:703-764: column counts of chol(A) (ata = 0; A square, upper triangle used) or chol(A'A) (ata != 0;
+ * A m-by-n) from the elimination tree parent[n] and its postorder post[n] (cs_etree / cs_post of the same matrix), host C++.
+ * colcount[n].  CSX_EINVAL for an index out of range, a parent outside [-1, n), a post that is no permutation. */
+int csx_counts_host(int32_t m, int32_t n, const int32_t *Ap, const int32_t *Ai, const int32_t *parent, const int32_t *post,
+                    int ata, int32_t *colcount);
 /* The same for a device-resident square matrix.  A forest of cliques on consecutive columns (block-diagonal with dense
  * blocks; recognised in one pass over A's pattern from the smallest upper row of every column): tree and counts on the
  * device, no pattern of L formed.  Otherwise: elimination tree on the device for many small components, else on the
@@ -258,6 +264,11 @@ int csx_cholsol_growth(csx_handle_t plan, double *growth);
  * may be NULL. */
 int csx_cholsol_sn_info(csx_handle_t plan, int32_t *supernodes, int32_t *steps, int32_t *max_width, int32_t *matrix_cores,
                         double *growth);
+
+/* "tri.graph": how many times this plan's supernodal solve has been captured into a hipGraph so far, and the host time of the
+ * last capture + instantiate in ms (the option's default, 2, captures on the third consecutive solve of one block).  Either
+ * pointer may be NULL. */
+int csx_cholsol_graph_info(csx_handle_t plan, int32_t *captures, double *last_capture_ms);
 
 /* ---- assembly and reshaping around the hot path ---------
  * Every function returns a NEW matrix handle.  p[] / i[] bit-identical to the reference's result.

@@ -390,6 +390,24 @@ def sqr_fixture():
     return meta
 
 
+def counts_fixture():
+    """cs_counts(A, parent, post, ata=True) -- the column counts of chol(A'A) -- runs unmodified (the ata=False
+    branch does not, D6) on the problem matrices C of the reference's tests (csparse_test.py:174-205), rectangular ones included, with parent =
+    cs_etree(A, True) and post = cs_post(parent, n) from the unmodified reference too."""
+    d, meta = {}, {}
+    for name in ("t1", "bcsstk01", "west0067", "ash219", "fs_183_1", "ibm32a", "ibm32b", "lp_afiro", "bcsstk16"):
+        T, A0, A, sym = get_problem(name)       # the problem matrix C of the matrix's own fixture (<name>.npz, keys C_*)
+        parent = R.cs_etree(A, True)
+        post = R.cs_post(parent, A.n)
+        cnt = R.cs_counts(A, parent, post, True)
+        assert cnt is not None and len(cnt) >= A.n
+        pre = name + "_"
+        d[pre + "parent"], d[pre + "post"], d[pre + "count"] = I(parent[:A.n]), I(post[:A.n]), I(cnt[:A.n])
+        meta[name] = dict(m=A.m, n=A.n, total=int(sum(cnt[:A.n])))
+    np.savez_compressed(os.path.join(OUT, "counts_ata.npz"), **d)
+    return meta
+
+
 def batch_fixture():
     """Blocks of right-hand sides for the batched solvers (lusol_factor, qrsol_factor: factor once, many columns): the
     UNMODIFIED reference's cs_lusol(0, C, b, tol) and cs_qrsol(0, C, b) column by column on the square problem matrices of
@@ -420,6 +438,13 @@ def main():
         with open(os.path.join(OUT, "meta.json")) as f:
             meta = json.load(f)
         meta["solve_batches"] = batch_fixture()
+        with open(os.path.join(OUT, "meta.json"), "w") as f:
+            json.dump(meta, f, indent=1, sort_keys=True)
+        return
+    if sys.argv[1:] == ["counts"]:     # added to an existing fixture set without regenerating the others
+        with open(os.path.join(OUT, "meta.json")) as f:
+            meta = json.load(f)
+        meta["counts_ata"] = counts_fixture()
         with open(os.path.join(OUT, "meta.json"), "w") as f:
             json.dump(meta, f, indent=1, sort_keys=True)
         return
@@ -455,6 +480,7 @@ def main():
     meta["updown"] = updown_fixture()
     meta["sqr_qr"] = sqr_fixture()
     meta["solve_batches"] = batch_fixture()
+    meta["counts_ata"] = counts_fixture()
     with open(os.path.join(OUT, "meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)
 

@@ -89,7 +89,13 @@ def test_chol_with_permutation(cs):
     S.pinv, S.parent, S.cp, S.lnz = pinv, So.parent, So.cp, So.lnz
     N = cs.cs_chol(C, S)
     assert N.L.p == No.L.p and N.L.i == No.L.i
-    np.testing.assert_allclose(N.L.x, No.L.x, rtol=1e-9, atol=1e-9 * max(abs(v) for v in No.L.x))
+    # ONE factorisation, the device's against the oracle's: rounding of the sums only (tests/tol.py)
+    gx, ox = np.asarray(N.L.x[:No.L.p[n]]), np.asarray(No.L.x[:No.L.p[n]])
+    assert TOL.normwise(gx, ox) <= 1e-13
+    big = np.abs(ox) > 1e-6 * np.abs(ox).max()
+    assert TOL.componentwise(gx[big], ox[big]) <= 1e-12
+    Cp_, Ci_, Cx_ = _arr(C)
+    bound = TOL.cross_bound(TOL.cond1(TOL.csc(n, Cp_, Ci_, Cx_)))      # two factorisations of one matrix: its conditioning
     # batched solve through the permutation, generic (level-scheduled) path
     b = g["b"].tolist()
     xo = list(b)
@@ -98,7 +104,7 @@ def test_chol_with_permutation(cs):
     O.cs_lsolve(No.L, y)
     O.cs_ltsolve(No.L, y)
     O.cs_pvec(pinv, y, xo, n)
-    np.testing.assert_allclose(xo, g["x_lusol"], rtol=1e-8)
+    assert TOL.normwise(xo, g["x_lusol"]) <= bound                    # the oracle's Cholesky against the unmodified reference's LU
     import _csx
     plan = _csx.new_handle()
     with cs._Resident(N.L) as dL:                # N.L's lists were read above: its device copy is gone, upload again
@@ -108,8 +114,8 @@ def test_chol_with_permutation(cs):
     _csx.check(_csx.lib().csx_cholsol_solve(plan, dB.handle, 3))
     X = dB.numpy()
     _csx.free(plan)
-    np.testing.assert_allclose(X[:, 0], xo, rtol=1e-9)
-    np.testing.assert_allclose(X[:, 1], 2 * np.asarray(xo), rtol=1e-9)
+    assert TOL.normwise(X[:, 0], xo) <= TOL.X_RTOL and TOL.componentwise(X[:, 0], xo) <= bound
+    assert TOL.normwise(X[:, 1], 2 * np.asarray(xo)) <= TOL.X_RTOL and TOL.componentwise(X[:, 1], 2 * np.asarray(xo)) <= bound
 
 
 @pytest.mark.parametrize("nblocks,bs,k", [(40, 64, 130), (300, 8, 5), (3, 32, 64), (25, 16, 70), (7, 32, 200), (50, 8, 129)])
@@ -336,7 +342,9 @@ def test_cholsol_with_the_fill_reducing_ordering(cs, name):
     b0, b1 = g["b"].tolist(), g["b"].tolist()
     assert cs.cs_cholsol(0, C, b0) is True and cs.cs_cholsol(1, C, b1) is True
     x0, x1 = np.asarray(b0), np.asarray(b1)
-    assert np.max(np.abs(x1 - x0)) <= 1e-9 * np.max(np.abs(x0))
+    Cp_, Ci_, Cx_ = _arr(C)
+    bound = TOL.cross_bound(TOL.cond1(TOL.csc(n, Cp_, Ci_, Cx_)))      # two orderings = two factorisations of one matrix (tests/tol.py)
+    assert TOL.normwise(x1, x0) <= bound
     # batched, device-resident
     cs.cs_pin(C)
     F = cs.cholsol_factor(C, order=1, exact=True)
@@ -344,8 +352,8 @@ def test_cholsol_with_the_fill_reducing_ordering(cs, name):
     dB = cs.dvec(B)
     assert F.solve(dB) is True
     X = dB.numpy()
-    assert np.max(np.abs(X[:, 0] - x0)) <= 1e-9 * np.max(np.abs(x0))
-    assert np.max(np.abs(X[:, 1] - 3.0 * x0)) <= 3e-9 * np.max(np.abs(x0))
+    assert TOL.normwise(X[:, 0], x0) <= bound
+    assert TOL.normwise(X[:, 1], 3.0 * x0) <= bound
 
 
 @pytest.mark.parametrize("shape", ["gspd_8", "mixed"])
@@ -762,8 +770,9 @@ def test_supernodal_solve_replayed_as_a_graph_gives_the_same_bits(cs):
 
 def test_long_supernodal_solves_are_replayed_as_a_graph_by_default(cs):
     """"tri.graph" = 2, the default: a solve of more than 256 launches (a natural-order grid factor: a chain of relaxed
-    supernodes, two or three launches per step) is captured when the SAME block comes a second time in a row and replayed
-    from then on; a block seen once is launched directly.  The bits do not depend on any of it."""
+    supernodes, two or three launches per step) is captured when the SAME block comes a THIRD time in a row (round 4 captured
+    on the second: 9 ms in front of a 1.8 ms solve, never repaid by a caller who solves a block twice) and replayed from then
+    on; a block seen once or twice is launched directly.  The bits do not depend on any of it."""
     import _csx
     n, p, i, x = _grid_laplacian(150, 150)
     A = cs.cs_spalloc(n, n, len(i), True, False)
@@ -778,15 +787,24 @@ def test_long_supernodal_solves_are_replayed_as_a_graph_by_default(cs):
         X0 = cs.dvec(B)
         assert F.solve(X0)
     ref = X0.numpy().tobytes()
+    def captures():
+        c, ms = _csx.C.c_int32(-1), _csx.C.c_double(-1.0)
+        _csx.check(_csx.lib().csx_cholsol_graph_info(F.plan_handle, c, ms))
+        return c.value, ms.value
+
+    assert captures() == (0, 0.0)
     X = cs.dvec(B)
-    for rep in range(4):            # direct, then captured, then replayed twice
+    for rep in range(5):            # direct twice, then captured, then replayed twice
         X.assign(B)
         assert F.solve(X)
         assert X.numpy().tobytes() == ref, rep
+        assert captures()[0] == (0 if rep < 2 else 1), rep
+    assert captures()[1] > 0.0
     other = cs.dvec(B)              # another block in between: launched directly, the capture survives for X
     assert F.solve(other) and other.numpy().tobytes() == ref
     X.assign(B)
     assert F.solve(X) and X.numpy().tobytes() == ref
+    assert captures()[0] == 1
 
 
 @pytest.mark.parametrize("strength, cores", [(0.3, 1), (0.9, 0)])

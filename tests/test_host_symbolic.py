@@ -94,3 +94,45 @@ def test_sqr_qr_host_rectangular_and_rank_deficient():
     assert S.parent == [1, 2, -1]
     assert S.m2 == 4 and sorted(S.pinv[:4]) == [0, 1, 2, 3] and S.pinv[2] == 3   # the empty row goes last
     assert S.lnz == 3 + 2 + 1 and S.unz == 3 + 2 + 1
+
+
+@pytest.mark.parametrize("name", ["t1", "bcsstk01", "west0067", "ash219", "fs_183_1", "ibm32a", "ibm32b", "lp_afiro", "bcsstk16"])
+def test_counts_ata_matches_unmodified_reference(name, meta):
+    """cs_counts(C, parent, post, True) (csparse.py:703-764; host C++, csx_counts_host) against the UNMODIFIED reference's
+    answer for the problem matrix of every matrix of its tests, rectangular ones included (tests/golden/counts_ata.npz,
+    oracle/gen_golden.py counts); the tree and the postorder fed to it are the reference's, and the product's own
+    cs_etree / cs_post must reproduce them."""
+    import csparse as cs
+    g, q = golden(name), golden("counts_ata")
+    C = unpack(cs, g, "C")
+    parent, post, want = (q[name + "_" + k].tolist() for k in ("parent", "post", "count"))
+    assert (C.m, C.n) == (meta["counts_ata"][name]["m"], meta["counts_ata"][name]["n"])
+    assert cs.cs_counts(C, parent, post, True) == want
+    assert sum(want) == meta["counts_ata"][name]["total"]
+    assert cs.cs_etree(C, True) == parent and cs.cs_post(parent, C.n) == post
+    if C.m == C.n and name != "bcsstk16":      # cs_sqr's counts of R are the same numbers (csparse.py:2206-2208)
+        assert cs.cs_sqr(0, C, True).cp[:C.n] == want
+    # bad input: None, like the reference (csparse.py:712-713)
+    assert cs.cs_counts(None, parent, post, True) is None and cs.cs_counts(C, None, post, True) is None
+    assert cs.cs_counts(C, parent, None, True) is None
+
+
+@pytest.mark.parametrize("name", ["bcsstk01", "bcsstk16"])
+def test_counts_of_a_symmetric_matrix_are_cs_schols(name):
+    """ata False does not run in the reference: pinned against the oracle's restatement and against what cs_schol
+    builds from the same counts (cp = their cumulative sum, csparse.py:2069-2071; lnz = 877 / 610 800)."""
+    import csparse as cs
+    g = golden(name)
+    C, Co = unpack(cs, g, "C"), unpack(O, g, "C")
+    Cu = O.cs_symperm(Co, None, False)                    # cs_schol analyses the upper triangle (csparse.py:2063)
+    parent = O.cs_etree(Cu, False)
+    post = O.cs_post(parent, C.n)
+    U = cs.cs_spalloc(C.n, C.n, max(len(Cu.i), 1), False, False)
+    U.p, U.i, U.x = list(Cu.p), list(Cu.i), None
+    got = cs.cs_counts(U, parent, post, False)
+    assert got == O.cs_counts(Cu, parent, post, False)
+    assert np.cumsum([0] + got).tolist() == cs.cs_schol(0, C).cp
+    assert sum(got) == {"bcsstk01": 877, "bcsstk16": 610800}[name]
+    # the full symmetric matrix gives the same counts: entries below the diagonal fail cs_leaf's i <= j test
+    assert cs.cs_counts(C, parent, post, False) == got
+    assert cs.cs_counts(unpack(cs, golden("ash219"), "C"), parent, post, False) is None      # not square

@@ -48,6 +48,18 @@ def cross_bound(cond):
     return max(X_RTOL, 8.0 * cond * EPS)
 
 
+def cond2_dense(A):
+    """2-norm condition number of a small (rectangular) sparse matrix from a dense SVD, rank-deficient directions left out."""
+    sv = np.linalg.svd(sp.csc_matrix(A).toarray(), compute_uv=False)
+    sv = sv[sv > sv[0] * max(A.shape) * EPS]
+    return float(sv[0] / sv[-1])
+
+
+def lsq_bound(cond2):
+    """two QR factorisations of one least-squares / minimum-norm problem: the solution moves with cond_2(A)^2 (Wedin)"""
+    return max(X_RTOL, 8.0 * cond2 * cond2 * EPS)
+
+
 def cholsolve_terms(n, Lp, Li, Lx, y, x):
     """sum|terms| of the LAST substitution of cs_lsolve + cs_ltsolve (csparse.py:1360-1364): x_i = (y_i - sum_j L_ji x_j) / L_ii."""
     L = csc(n, Lp, Li, Lx)
