@@ -875,7 +875,8 @@ def cholsol_section(args, lib, cs, comm, hB, nb, bs, barrier, max_over_ranks, pr
                        "factor once per GPU, row-major n x k block" % (n, lnz, k),
            "solves_per_s": round(k * world * steps / wall, 1), "nrhs_per_gpu": k, "ms_per_batch": round(ms, 4),
            "path": {0: "level-scheduled", 1: "fused per-tree (X in LDS)", 2: "dense-block substitution (X in registers)",
-                    3: "dense-block blocked TRSM, fp64 MFMA (X in registers)"}[fused.value],
+                    3: "dense-block blocked TRSM, fp64 MFMA (X in registers)", 4: "supernodal schedule",
+                    5: "small trees made dense by size class, fp64 MFMA"}.get(fused.value, str(fused.value)),
            "trees": trees.value, "max_tree": mx.value,
            "algorithmic_bytes_fused": fused_bytes,
            "achieved_GBps_per_gpu": round(fused_bytes / (ms * 1e-3) / 1e9, 2),

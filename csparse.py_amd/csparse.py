@@ -1200,8 +1200,8 @@ def cholsol_factor(A, order=0, exact=None):
         def info(self):
             a, b, c = _csx.C.c_int32(), _csx.C.c_int32(), _csx.C.c_int32()
             _csx.check(_csx.lib().csx_cholsol_info(self._current(), a, b, c), "csx_cholsol_info")
-            return {"fused_local": a.value >= 1, "dense_block": c.value if a.value >= 2 else 0,  # dense kernels in use
-                    "matrix_cores": a.value == 3, "trees": b.value, "max_nodes": c.value}
+            return {"fused_local": a.value in (1, 2, 3, 5), "dense_block": c.value if a.value in (2, 3) else 0,  # dense kernels in use
+                    "matrix_cores": a.value in (3, 5), "trees": b.value, "max_nodes": c.value}
 
         def solve(self, b, comm=None, nrhs=None):
             """b: a list (one system) or a dvec n-by-k block, overwritten with the solutions.
@@ -1332,13 +1332,18 @@ def cs_lusol(order, A, b, tol):
     return True
 
 
-def lusol_factor(A, order=0, tol=1.0):
+def lusol_factor(A, order=0, tol=1.0, exact=None):
     """Factor once for many solves -- the batched form of cs_lusol (csparse.py:1456-1478): cs_sqr + cs_lu once, then
     solve(b) runs the reference's sequence x = b(p); L \\ x; U \\ x; b(q) = x (:1474-1477) on the device for a list (one
     system) or a dvec n-by-k block (k systems, overwritten): csx_permute_vec, csx_tri_solve on L and on U,
-    csx_permute_vec.  Every column is bit-identical to cs_lusol on that column.  solve(b, comm=..., nrhs=K) shards the
-    block by right-hand-side block over the ranks of a shard.Comm, every rank holding this factor; see
-    cholsol_factor.  None when A is not square CSC or singular."""
+    csx_permute_vec.  The order of a solve's operations follows cholsol_factor's rule: exact=None (default): a LIST is
+    solved in the reference's order, bit-identical to cs_lusol; a dvec BLOCK in the rounding-equal order (x[] within the
+    1e-10 of BASELINE.json's north_star) -- which differs from the exact one only where the factors fall into many small
+    independent components of at most 80 rows (config 3's W: 1 493 of 67), solved densely on the matrix cores then
+    (csx_tri_set_order; refused when an inverse of a diagonal tile is large); exact=True: every solve bit-identical to
+    cs_lusol on that column; exact=False: every solve rounding-equal.  cs_lusol, the reference's driver, is always exact.
+    solve(b, comm=..., nrhs=K) shards the block by right-hand-side block over the ranks of a shard.Comm, every rank
+    holding this factor; see cholsol_factor.  None when A is not square CSC or singular."""
     if not CS_CSC(A) or A.m != A.n:
         return None
     S = cs_sqr(order, A, False)
@@ -1356,25 +1361,44 @@ def lusol_factor(A, order=0, tol=1.0):
         def __init__(self):
             self._fin = weakref.finalize(self, lambda hs: [_csx.free(h) for h in hs if h is not None], [keep_p, keep_q])
 
-        def _block(self, blk):
+        def _block(self, blk, in_exact_order=True):
             lib = _csx.lib()
             x = dvec(n, blk.k)
             _csx.check(lib.csx_permute_vec(hp, blk.handle, x.handle, n, blk.k, 1), "csx_permute_vec")     # x(pinv) = b
-            with _Resident(L) as dL:
-                _csx.check(lib.csx_tri_solve(_plan(dL, TRI_L), x.handle, blk.k), "csx_tri_solve")
-            with _Resident(U) as dU:
-                _csx.check(lib.csx_tri_solve(_plan(dU, TRI_U), x.handle, blk.k), "csx_tri_solve")
+            for M, kind in ((L, TRI_L), (U, TRI_U)):
+                with _Resident(M) as dM:
+                    plan = _plan(dM, kind)       # (shared with the list-level cs_lsolve / cs_usolve on this factor: the order is set per solve)
+                    try:
+                        _csx.check(lib.csx_tri_set_order(plan, 1 if in_exact_order else 0), "csx_tri_set_order")
+                        _csx.check(lib.csx_tri_solve(plan, x.handle, blk.k), "csx_tri_solve")
+                    finally:
+                        lib.csx_tri_set_order(plan, 1)
             _csx.check(lib.csx_permute_vec(hq, x.handle, blk.handle, n, blk.k, 1), "csx_permute_vec")     # b(q) = x
             return blk
 
+        def info(self):
+            """which of the two triangular solves run on the matrix cores in the rounding-equal order, and the guard's measure"""
+            out = {}
+            for name, M, kind in (("L", L, TRI_L), ("U", U, TRI_U)):
+                with _Resident(M) as dM:
+                    mc, g = _csx.C.c_int32(0), _csx.C.c_double(0.0)
+                    plan = _plan(dM, kind)
+                    _csx.check(_csx.lib().csx_tri_set_order(plan, 0), "csx_tri_set_order")
+                    _csx.check(_csx.lib().csx_tri_order_info(plan, mc, g), "csx_tri_order_info")
+                    _csx.lib().csx_tri_set_order(plan, 1)
+                    out[name] = {"matrix_cores": bool(mc.value), "growth": g.value}
+            return out
+
         def solve(self, b, comm=None, nrhs=None):
             if comm is not None and comm.world > 1:
-                out, bhost = _solve_blocks_sharded(comm, b, nrhs, n, n, self._block)
+                # every rank solves in the order the ROOT's right-hand side asks for
+                ex = comm.broadcast_object((exact if exact is not None else not isinstance(b, dvec)) if comm.rank == 0 else None, 0)
+                out, bhost = _solve_blocks_sharded(comm, b, nrhs, n, n, lambda blk: self._block(blk, ex))
                 if out is not None:
                     _write_back(bhost, out, n * out.k)
                 return True
             db, bhost = _vec_in(b, n, "b")
-            self._block(db)
+            self._block(db, exact if exact is not None else not isinstance(b, dvec))
             _write_back(bhost, db, n * db.k)
             return True
 

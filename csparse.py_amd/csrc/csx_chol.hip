@@ -42,6 +42,7 @@
 #include "csx_internal.h"
 #include "csx_sweep.h"
 #include "csx_cholclique.h"
+#include "csx_trimfma.h"
 
 namespace csx {
 
@@ -1064,6 +1065,10 @@ struct CholPlan {
     // forest of equal dense blocks recognised from L itself (cholsol_plan_clique): no triangular-solve plans, the dense
     // programs cut straight out of L.x; f_idx / b_idx / b_val (the fused per-tree kernel's) are made when first needed
     bool clique = false, clique_zero_pivot = false;
+    // forests of small trees that are NOT equal dense blocks (cliques of unequal sizes, small sparse trees), rounding-equal order:
+    // the trees made dense and bucketed by size class, solved on the matrix cores (csx_trimfma.hip); null: not built / refused
+    RaggedMfma *rag = nullptr;
+    bool rag_tried = false;
     bool mfma_tried = false;  // fragments were built, or refused by the growth guard
     double mfma_growth = 0.0; // max|inv(L_ii)| max|L| over the forest (the guard's measure)
     // big trees, rounding-equal order: supernodal schedule (csx_snsolve.hip), built the first time the plan is relaxed
@@ -1077,6 +1082,7 @@ void free_cholplan(CholPlan *P) {
     if (!P) return;
     if (P->g_exec) (void)hipGraphExecDestroy(P->g_exec);
     free_snplan(P->sn);
+    ragged_free(P->rag);
     free_triplan(P->fwd);
     free_triplan(P->bwd);
     dfree(P->perm);
@@ -2276,7 +2282,21 @@ static int cholsol_plan(const Csc *L, const int32_t *pinv, CholPlan **out) {
 // region below the guard).
 constexpr double MFMA_GROWTH_LIMIT = 1e3;
 
+// forests of small trees of any shape (max_nodes <= 80): the trees' forward programs made dense, bucketed by size, on the matrix cores
+static int cholsol_build_ragged(CholPlan *P) {
+    if (P->rag_tried || !P->local || P->dense_bs || !P->f_idx || P->max_nodes > RAG_MAX_ROWS) return CSX_OK;
+    P->rag_tried = true;
+    RaggedMfma *R = nullptr;
+    CSX_TRY(ragged_build(P->trees, P->ntrees, P->max_nodes, P->f_ptr, P->f_idx, P->f_val, P->diagk, false, &R));
+    if (!R) return CSX_OK;
+    P->mfma_growth = R->growth;
+    if (R->growth <= RAG_GROWTH_LIMIT) P->rag = R;     // (a NaN fails the comparison: the fused per-tree kernel stays)
+    else ragged_free(R);
+    return CSX_OK;
+}
+
 static int cholsol_build_mfma(CholPlan *P) {
+    if (!P->dense_bs) return cholsol_build_ragged(P);
     if (P->mfma_tried || P->dense_bs < 16) return CSX_OK;
     P->mfma_tried = true;
     hipStream_t s = ctx().stream;
@@ -2463,6 +2483,8 @@ static int cholsol_solve(CholPlan *P, double *B, int32_t nrhs) {
             CSX_LAUNCH_CHECK();
             return CSX_OK;
         }
+        if (P->relaxed && P->rag && ctx().opt.cholsol_dense_blocks)    // trees of any shape, rounding-equal order: on the matrix cores
+            return ragged_solve(P->rag, P->trees, P->tree_nodes, P->perm, false, 2, B, nrhs);
         const size_t per_wave = (size_t)P->max_nodes * 64 * sizeof(double);
         const int waves = tile_waves_per_workgroup(per_wave, CH_WAVES);
         const int32_t chunks = (nrhs + 63) / 64;
@@ -2774,8 +2796,9 @@ extern "C" int csx_cholsol_plan(csx_handle_t hL, const int32_t *pinv, csx_handle
 extern "C" int csx_cholsol_info(csx_handle_t h, int32_t *local, int32_t *ntrees, int32_t *max_nodes) {
     CholPlan *P = (CholPlan *)get(h, K_CHOLPLAN);
     if (!P) return CSX_EINVAL;
-    // 0 level-scheduled, 1 fused in LDS, 2 dense blocks (substitution), 3 dense blocks on the matrix cores
-    if (local) *local = P->local ? (P->dense_bs ? (P->relaxed && P->frag_f ? 3 : 2) : 1) : (P->relaxed && P->sn && sn_usable(P->sn) ? 4 : 0);
+    // 0 level-scheduled, 1 fused in LDS, 2 dense blocks (substitution), 3 dense blocks on the matrix cores, 4 supernodal schedule,
+    // 5 small trees of any shape made dense by size class on the matrix cores (csx_trimfma.hip)
+    if (local) *local = P->local ? (P->dense_bs ? (P->relaxed && P->frag_f ? 3 : 2) : (P->relaxed && P->rag ? 5 : 1)) : (P->relaxed && P->sn && sn_usable(P->sn) ? 4 : 0);
     if (ntrees) *ntrees = P->ntrees;
     if (max_nodes) *max_nodes = P->max_nodes;
     return CSX_OK;

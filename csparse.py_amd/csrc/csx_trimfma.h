@@ -1,0 +1,37 @@
+// Small dependency components on the matrix cores (csx_trimfma.hip): the rounding-equal order of the fused in-LDS sweeps.
+#ifndef CSX_TRIMFMA_H
+#define CSX_TRIMFMA_H
+
+#include "csx_internal.h"
+#include "csx_sweep.h"
+
+namespace csx {
+
+constexpr int RAG_MAX_ROWS = 80;           // 5 tiles of 16
+constexpr int RAG_CLASSES = RAG_MAX_ROWS / 16;
+constexpr double RAG_GROWTH_LIMIT = 1e3;   // || |inv(T_ii)| |T_ii| ||_inf of a diagonal tile (the supernodal plan's guard, csx_snsolve.hip)
+
+struct RaggedMfma {
+    int32_t ntrees = 0;
+    int32_t *list = nullptr;                     // device [ntrees]: component ids, ordered by size class (stable)
+    int32_t cls_start[RAG_CLASSES + 1] = {0};    // class c (components of 16 c + 1 .. 16 (c + 1) rows): list[cls_start[c] .. cls_start[c + 1])
+    size_t cls_frag[RAG_CLASSES + 1] = {0};      // first double of class c's fragments
+    double *frag = nullptr;
+    double growth = 0.0;                         // the guard's measure over all diagonal tiles
+};
+
+// The components' packed sweep programs (csx_sweep.h: per sweep position the terms (local row * 64, value), the diagonal) made
+// dense in POSITION order -- position sp of a component is its row sp (forward sweeps) or count - 1 - sp (backward sweeps) --
+// zero where the pattern has none, the identity on the padding, cut into 16 x 16 tiles: off-diagonal tiles negated, diagonal
+// tiles inverted, in k_cholsol_mfma's fragment order.  *out = nullptr when a component has more than RAG_MAX_ROWS rows.
+int ragged_build(const Tree *trees, int32_t ntrees, int32_t max_rows, const int32_t *ptr, const int32_t *idx, const double *val,
+                 const double *diag, bool reverse, RaggedMfma **out);
+// X (n-by-nrhs, row-major) <- the sweep applied to every component: a blocked substitution in position order on the matrix cores.
+// passes = 1: that sweep; passes = 2: then the TRANSPOSED system backwards (cs_cholsol's L then L', the fragments read transposed).
+// perm (or null): row j of the components is row perm[j] of X.
+int ragged_solve(const RaggedMfma *R, const Tree *trees, const int32_t *nodes, const int32_t *perm, bool reverse, int passes, double *X,
+                 int32_t nrhs);
+void ragged_free(RaggedMfma *R);
+
+}  // namespace csx
+#endif

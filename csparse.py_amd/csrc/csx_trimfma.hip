@@ -1,0 +1,354 @@
+// Small dependency components on the matrix cores: the ROUNDING-EQUAL order of the fused in-LDS sweeps.
+//
+// cs_lsolve / cs_ltsolve / cs_usolve / cs_utsolve (csparse.py:1330-1365, :2368-2385, :2460-2475) on a factor that falls into many
+// small independent components -- a forest of small elimination trees (cs_cholsol on batches of independent matrices), the L and
+// U of a block-diagonal cs_lu (BASELINE config 3: 1 493 components of 67 rows) -- run, in the exact order, as one wave per
+// (component, 64 right-hand sides) with the X tile in LDS and the terms applied one by one in the reference's order
+// (csx_sweep.h): a chain of dependent LDS round trips, 0.12 - 0.39 of the HBM roofline (profiles/r04_ablation.md section 8).
+// Where the caller grants rounding (x[] within 1e-10, BASELINE.json north_star) the same solve is a DENSE triangular system per
+// component: its rows in sweep-position order, zeros where the pattern has none, padded with the identity to a multiple of 16,
+// solved as a blocked substitution on 16 x 16 tiles with v_mfma_f64_16x16x4_f64 -- X_i <- W_ii (X_i - sum_{j<i} T_ij X_j),
+// W_ii = inv(T_ii) formed when the plan is built -- the scheme of k_cholsol_mfma (csx_chol.hip) for components of UNEQUAL sizes
+// and any pattern: components are bucketed by size class (16 / 32 / 48 / 64 / 80 rows), one launch per class, X in registers,
+// the fragments read once and coalesced.  A component of 67 rows costs 4.5x the flops of its sparse program and a tenth of the
+// issue slots; fp64 MFMA is chosen for how it takes its operands, not for its rate.
+#include <algorithm>
+#include <cstring>
+
+#include "csx_internal.h"
+#include "csx_sweep.h"
+#include "csx_cholclique.h"   // tile_inverse_column
+#include "csx_trimfma.h"
+
+namespace csx {
+
+typedef double rg_f64x4 __attribute__((ext_vector_type(4)));
+typedef double rg_f64x2 __attribute__((ext_vector_type(2)));
+
+template <int NB>
+constexpr int rag_frags() { return (NB * (NB - 1) / 2 + NB) * 4; }
+static inline int rag_frags_of(int nb) { return (nb * (nb - 1) / 2 + nb) * 4; }
+
+__global__ __launch_bounds__(256) void k_rag_class(const Tree *__restrict__ trees, int32_t ntrees, uint32_t *__restrict__ key,
+                                                   uint32_t *__restrict__ id) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntrees) return;
+    const int32_t c = trees[t].count;
+    key[t] = (uint32_t)(c <= 16 ? 0 : (c - 1) >> 4);
+    id[t] = (uint32_t)t;
+}
+
+// one wave per component: the dense position-order matrix in LDS, the inverses of its diagonal tiles, the fragments, the guard
+template <int NB>
+__global__ __launch_bounds__(64) void k_rag_frags(const int32_t *__restrict__ list, const Tree *__restrict__ trees,
+                                                  const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx,
+                                                  const double *__restrict__ val, const double *__restrict__ diag, int reverse,
+                                                  double *__restrict__ frag, unsigned long long *cond_bits) {
+    constexpr int BS = 16 * NB;
+    __shared__ double M[BS][BS + 1];
+    __shared__ double W[NB][16][17];
+    __shared__ int32_t rp[BS + 1];
+    const int lane = threadIdx.x;
+    const int32_t t = list[blockIdx.x], first = trees[t].first, count = trees[t].count;
+    for (int e = lane; e < BS * (BS + 1); e += 64) (&M[0][0])[e] = 0.0;
+    for (int sp = lane; sp <= count; sp += 64) rp[sp] = ptr[first + sp];
+    __syncthreads();
+    for (int sp = lane; sp < BS; sp += 64) M[sp][sp] = sp < count ? diag[first + sp] : 1.0;
+    // every term of the component, 64 at a time; its sweep position by a search over the row starts.  (A row that names a source
+    // twice -- cs_lu's L may, SURVEY D7 -- subtracts both products: the coefficients add.)
+    const int32_t tb = rp[0], te = rp[count];
+    for (int32_t q = tb + lane; q < te; q += 64) {
+        int lo = 0, hi = count;                 // largest sp with rp[sp] <= q
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (rp[mid] <= q) lo = mid;
+            else hi = mid;
+        }
+        const int32_t src = idx[q] >> 6;
+        const int32_t sp2 = reverse ? count - 1 - src : src;
+        if (sp2 >= 0 && sp2 < lo) atomicAdd(&M[lo][sp2], val[q]);
+    }
+    __syncthreads();
+    double wmax = 0.0;
+    {
+        const int blk = lane >> 4, col = lane & 15;
+        for (int b0 = 0; b0 < NB; b0 += 4) {
+            const int b = b0 + blk;
+            if (b < NB) {
+                double wcol[16];
+                tile_inverse_column(&M[16 * b][16 * b], BS + 1, col, wcol);
+#pragma unroll
+                for (int r = 0; r < 16; r++) W[b][r][col] = wcol[r];
+            }
+        }
+    }
+    __syncthreads();
+    // the guard: || |W_bb| |T_bb| ||_inf of every diagonal tile (scaling-invariant; an explicit inverse costs a relative error of
+    // about eps times this)
+    {
+        const int r = lane & 15, cg = lane >> 4;
+        for (int b = 0; b < NB; b++) {
+            double s = 0.0;
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                for (int k = 0; k < 16; k++) s += fabs(W[b][r][k]) * fabs(M[16 * b + k][16 * b + 4 * cg + c]);
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            wmax = fmax(wmax, s);
+        }
+    }
+    const int m = lane & 15, kq = lane >> 4;
+    double *F = frag + (size_t)blockIdx.x * rag_frags<NB>() * 64 + lane;
+    int f = 0;
+    for (int i = 0; i < NB; i++) {
+        for (int j = 0; j < i; j++)
+            for (int sx = 0; sx < 4; sx++) F[64 * f++] = -M[16 * i + m][16 * j + 4 * sx + kq];
+        for (int sx = 0; sx < 4; sx++) F[64 * f++] = W[i][m][4 * sx + kq];
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) wmax = fmax(wmax, __shfl_xor(wmax, d, 64));
+    if (lane == 0) {
+        // (a NaN must raise the flag too: its bits are above every finite number's)
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(wmax != wmax ? __longlong_as_double(0x7ff8000000000000ll) : wmax);
+        if (!(bits <= *(volatile unsigned long long *)cond_bits)) atomicMax(cond_bits, bits);
+    }
+}
+
+// One wave = one component x 64 right-hand sides.  Lane (rq, col): rows 16 i + rq + 4 r of the position order, right-hand sides
+// col (+ 16 c) of the chunk -- the f64 accumulator layout, which is also the B-operand layout of k-step r: a finished tile feeds
+// the next product from its registers.  Positions past the component's rows are padding: zero in X, the identity in T.
+template <int NB, int PASSES>
+__global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void k_rag_mfma(const int32_t *__restrict__ list, int32_t ncls,
+                                                                     const Tree *__restrict__ trees, const int32_t *__restrict__ nodes,
+                                                                     const int32_t *__restrict__ perm, const double *__restrict__ frag,
+                                                                     int reverse, double *B, int32_t nrhs, int32_t chunks) {
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t task = (int64_t)blockIdx.x * 4 + w;
+    if (task >= (int64_t)ncls * chunks) return;
+    const int32_t q = (int32_t)(task / chunks), h = (int32_t)(task % chunks);
+    const int32_t t = list[q];
+    const int32_t first = trees[t].first, count = trees[t].count;
+    const int col = lane & 15, rq = lane >> 4;
+    int32_t row[NB][4];      // row of X, -1: padding
+#pragma unroll
+    for (int i = 0; i < NB; i++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int p = 16 * i + rq + 4 * r;
+            int32_t jr = -1;
+            if (p < count) {
+                jr = nodes[first + (reverse ? count - 1 - p : p)];
+                if (perm) jr = perm[jr];
+            }
+            row[i][r] = jr;
+        }
+    rg_f64x4 X[NB][4];
+    bool live[4];
+    int32_t cidx[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const int32_t rhs = h * 64 + 16 * c + col;
+        live[c] = rhs < nrhs;
+        cidx[c] = live[c] ? rhs : nrhs - 1;   // clamped: loaded, never stored
+    }
+    // a chunk wholly inside the block (and an even nrhs: 16-byte alignment) moves 16 bytes per lane: lane (rq, col) takes the
+    // neighbours 32 c' + 2 col, + 1 of a row and gives them to column chunks 2 c' and 2 c' + 1 (which right-hand side a
+    // (chunk, column) pair stands for is free)
+    const bool wide = (nrhs & 1) == 0 && h * 64 + 64 <= nrhs && (reinterpret_cast<uintptr_t>(B) & 15) == 0;   // uniform
+    if (wide) {
+#pragma unroll
+        for (int i = 0; i < NB; i++)
+#pragma unroll
+            for (int cp = 0; cp < 2; cp++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    rg_f64x2 v = rg_f64x2{0.0, 0.0};
+                    if (row[i][r] >= 0) v = *reinterpret_cast<const rg_f64x2 *>(B + (int64_t)row[i][r] * nrhs + h * 64 + 32 * cp + 2 * col);
+                    X[i][2 * cp][r] = v.x;
+                    X[i][2 * cp + 1][r] = v.y;
+                }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NB; i++)
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) X[i][c][r] = row[i][r] >= 0 ? B[(int64_t)row[i][r] * nrhs + cidx[c]] : 0.0;
+    }
+    const double *F = frag + (size_t)q * rag_frags<NB>() * 64 + lane;
+    int f = 0;
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+#pragma unroll
+        for (int j = 0; j < i; j++)
+#pragma unroll
+            for (int sx = 0; sx < 4; sx++) {
+                const double a = F[64 * f++];
+#pragma unroll
+                for (int c = 0; c < 4; c++) X[i][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[j][c][sx], X[i][c], 0, 0, 0);
+            }
+        rg_f64x4 Y[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) Y[c] = rg_f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int sx = 0; sx < 4; sx++) {
+            const double a = F[64 * f++];
+#pragma unroll
+            for (int c = 0; c < 4; c++) Y[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[i][c][sx], Y[c], 0, 0, 0);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) X[i][c] = Y[c];
+    }
+    if (PASSES == 2) {
+        // the transposed system, backwards: the A fragment of tile' for (lane = (m, kq), k-step sx) is element (4 sx + kq, m) of
+        // the tile, which the forward layout keeps in k-step m >> 2 at lane (m & 3) * 16 + 4 sx + kq (k_cholsol_mfma)
+        const double *Ft = frag + (size_t)q * rag_frags<NB>() * 64 + (size_t)(col >> 2) * 64 + (col & 3) * 16 + rq;
+        auto tile_at = [](int a, int b) { return (a * (a + 1) / 2 + b) * 4; };
+#pragma unroll
+        for (int i = NB - 1; i >= 0; i--) {
+#pragma unroll
+            for (int j = i + 1; j < NB; j++)
+#pragma unroll
+                for (int sx = 0; sx < 4; sx++) {
+                    const double a = Ft[(size_t)tile_at(j, i) * 64 + 4 * sx];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) X[i][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[j][c][sx], X[i][c], 0, 0, 0);
+                }
+            rg_f64x4 Y[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) Y[c] = rg_f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int sx = 0; sx < 4; sx++) {
+                const double a = Ft[(size_t)tile_at(i, i) * 64 + 4 * sx];
+#pragma unroll
+                for (int c = 0; c < 4; c++) Y[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[i][c][sx], Y[c], 0, 0, 0);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; c++) X[i][c] = Y[c];
+        }
+    }
+    if (wide) {
+#pragma unroll
+        for (int i = 0; i < NB; i++)
+#pragma unroll
+            for (int cp = 0; cp < 2; cp++)
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    if (row[i][r] >= 0) {
+                        rg_f64x2 v;
+                        v.x = X[i][2 * cp][r];
+                        v.y = X[i][2 * cp + 1][r];
+                        *reinterpret_cast<rg_f64x2 *>(B + (int64_t)row[i][r] * nrhs + h * 64 + 32 * cp + 2 * col) = v;
+                    }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; i++)
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                if (live[c] && row[i][r] >= 0) B[(int64_t)row[i][r] * nrhs + cidx[c]] = X[i][c][r];
+}
+
+void ragged_free(RaggedMfma *R) {
+    if (!R) return;
+    dfree(R->list);
+    dfree(R->frag);
+    delete R;
+}
+
+int ragged_build(const Tree *trees, int32_t ntrees, int32_t max_rows, const int32_t *ptr, const int32_t *idx, const double *val,
+                 const double *diag, bool reverse, RaggedMfma **out) {
+    *out = nullptr;
+    if (ntrees <= 0 || max_rows > RAG_MAX_ROWS) return CSX_OK;
+    hipStream_t s = ctx().stream;
+    RaggedMfma *R = new RaggedMfma();
+    struct Guard {
+        RaggedMfma *R;
+        ~Guard() { ragged_free(R); }
+    } guard{R};
+    R->ntrees = ntrees;
+    DevScope tmp;
+    uint32_t *key = nullptr, *id = nullptr, *skey = nullptr;
+    int32_t *bounds = nullptr;
+    unsigned long long *cond = nullptr;
+    CSX_TRY(tmp.alloc(&key, (size_t)ntrees));
+    CSX_TRY(tmp.alloc(&id, (size_t)ntrees));
+    CSX_TRY(tmp.alloc(&skey, (size_t)ntrees));
+    CSX_TRY(tmp.alloc(&bounds, RAG_CLASSES + 1));
+    CSX_TRY(tmp.alloc(&cond, 1));
+    CSX_TRY(dalloc(&R->list, (size_t)ntrees));
+    hipLaunchKernelGGL(k_rag_class, dim3((unsigned)((ntrees + 255) / 256)), dim3(256), 0, s, trees, ntrees, key, id);
+    CSX_LAUNCH_CHECK();
+    CSX_TRY(stable_sort_by_key(key, id, nullptr, ntrees, RAG_CLASSES, skey, (uint32_t *)R->list, nullptr));
+    CSX_TRY(boundaries_from_sorted(skey, ntrees, RAG_CLASSES, bounds));
+    CSX_HIP(hipMemcpyAsync(R->cls_start, bounds, sizeof R->cls_start, hipMemcpyDeviceToHost, s));
+    CSX_HIP(hipStreamSynchronize(s));
+    size_t total = 0;
+    for (int c = 0; c < RAG_CLASSES; c++) {
+        R->cls_frag[c] = total;
+        total += (size_t)(R->cls_start[c + 1] - R->cls_start[c]) * (size_t)rag_frags_of(c + 1) * 64;
+    }
+    R->cls_frag[RAG_CLASSES] = total;
+    CSX_TRY(dalloc(&R->frag, total));
+    CSX_HIP(hipMemsetAsync(cond, 0, sizeof(unsigned long long), s));
+    for (int c = 0; c < RAG_CLASSES; c++) {
+        const int32_t cnt = R->cls_start[c + 1] - R->cls_start[c];
+        if (cnt <= 0) continue;
+        const int32_t *lst = R->list + R->cls_start[c];
+        double *fr = R->frag + R->cls_frag[c];
+#define CSX_RF(NB) \
+    hipLaunchKernelGGL(k_rag_frags<NB>, dim3((unsigned)cnt), dim3(64), 0, s, lst, trees, ptr, idx, val, diag, reverse ? 1 : 0, fr, cond)
+        switch (c) {
+            case 0: CSX_RF(1); break;
+            case 1: CSX_RF(2); break;
+            case 2: CSX_RF(3); break;
+            case 3: CSX_RF(4); break;
+            default: CSX_RF(5); break;
+        }
+#undef CSX_RF
+        CSX_LAUNCH_CHECK();
+    }
+    unsigned long long hcond = 0;
+    CSX_HIP(hipMemcpyAsync(&hcond, cond, sizeof hcond, hipMemcpyDeviceToHost, s));
+    CSX_HIP(hipStreamSynchronize(s));
+    std::memcpy(&R->growth, &hcond, sizeof R->growth);
+    guard.R = nullptr;
+    *out = R;
+    return CSX_OK;
+}
+
+int ragged_solve(const RaggedMfma *R, const Tree *trees, const int32_t *nodes, const int32_t *perm, bool reverse, int passes, double *X,
+                 int32_t nrhs) {
+    hipStream_t s = ctx().stream;
+    const int32_t chunks = (nrhs + 63) / 64;
+    const int rev = reverse ? 1 : 0;
+    for (int c = 0; c < RAG_CLASSES; c++) {
+        const int32_t cnt = R->cls_start[c + 1] - R->cls_start[c];
+        if (cnt <= 0) continue;
+        const int64_t tasks = (int64_t)cnt * chunks;
+        const dim3 grid((unsigned)((tasks + 3) / 4));
+        const int32_t *lst = R->list + R->cls_start[c];
+        const double *fr = R->frag + R->cls_frag[c];
+#define CSX_RS(NB, PS) \
+    hipLaunchKernelGGL((k_rag_mfma<NB, PS>), grid, dim3(256), 0, s, lst, cnt, trees, nodes, perm, fr, rev, X, nrhs, chunks)
+#define CSX_RSP(NB)                \
+    if (passes == 2) CSX_RS(NB, 2); \
+    else CSX_RS(NB, 1)
+        switch (c) {
+            case 0: CSX_RSP(1); break;
+            case 1: CSX_RSP(2); break;
+            case 2: CSX_RSP(3); break;
+            case 3: CSX_RSP(4); break;
+            default: CSX_RSP(5); break;
+        }
+#undef CSX_RSP
+#undef CSX_RS
+        CSX_LAUNCH_CHECK();
+    }
+    return CSX_OK;
+}
+
+}  // namespace csx

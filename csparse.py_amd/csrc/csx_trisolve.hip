@@ -36,6 +36,7 @@
 
 #include "csx_internal.h"
 #include "csx_sweep.h"
+#include "csx_trimfma.h"
 
 namespace csx {
 
@@ -86,6 +87,12 @@ struct TriPlan {
     int32_t push_terms = 0;          // most terms of one component (0: no push program)
     int few_cpw = 0;                 // components per wave of the all-in-LDS kernel (0: its tiles do not fit)
     int32_t few_rows = 0, few_terms = 0;
+    // rounding-equal order (csx_tri_set_order(plan, 0)): the components made dense, bucketed by size class and solved on the
+    // matrix cores (csx_trimfma.hip) -- components of at most 80 rows whose diagonal tiles pass the guard; the exact order and
+    // every other plan shape are untouched
+    bool rounding_equal = false, rag_tried = false;
+    RaggedMfma *rag = nullptr;
+    double rag_growth = 0.0;
 };
 
 void free_triplan(TriPlan *t) {
@@ -113,6 +120,7 @@ void free_triplan(TriPlan *t) {
     dfree(t->cidx);
     dfree(t->cval);
     dfree(t->cdiag);
+    ragged_free(t->rag);
     delete t;
 }
 
@@ -1690,6 +1698,20 @@ static int analyse_components(TriPlan *P) {
 
 static int solve_components(TriPlan *P, double *X, int32_t nrhs) {
     hipStream_t s = ctx().stream;
+    if (P->rounding_equal && nrhs > 8) {
+        // the caller granted rounding (csx_tri_set_order): dense components on the matrix cores, one sweep in position order
+        if (!P->rag_tried) {
+            P->rag_tried = true;
+            RaggedMfma *R = nullptr;
+            CSX_TRY(ragged_build(P->comps, P->ncomp, P->comp_max, P->prog_ptr, P->prog_idx, P->prog_val, P->prog_diag, !P->forward, &R));
+            if (R) {
+                P->rag_growth = R->growth;
+                if (R->growth <= RAG_GROWTH_LIMIT) P->rag = R;     // (a NaN fails the comparison)
+                else ragged_free(R);
+            }
+        }
+        if (P->rag) return ragged_solve(P->rag, P->comps, P->comp_nodes, nullptr, !P->forward, 1, X, nrhs);
+    }
     // L, U with up to 8 right-hand sides: one wave per component, column-push form (W, L + U pair: 43 us at 1 RHS,
     // 78 us at 8; at 64 the entry-parallel lanes are gone and it loses to k_tri_local, 483 against 272 us)
     if (nrhs <= 8 && P->push_terms > 0 && ctx().opt.tri_push) {
@@ -2478,6 +2500,21 @@ extern "C" int csx_tri_components(csx_handle_t h, int32_t *ncomp) {
     TriPlan *P = (TriPlan *)get(h, K_TRIPLAN);
     if (!P || !ncomp) return CSX_EINVAL;
     *ncomp = P->comp_ok ? P->ncomp : 0;
+    return CSX_OK;
+}
+
+extern "C" int csx_tri_set_order(csx_handle_t h, int exact) {
+    TriPlan *P = (TriPlan *)get(h, K_TRIPLAN);
+    if (!P) return CSX_EINVAL;
+    P->rounding_equal = exact == 0;
+    return CSX_OK;
+}
+
+extern "C" int csx_tri_order_info(csx_handle_t h, int32_t *matrix_cores, double *growth) {
+    TriPlan *P = (TriPlan *)get(h, K_TRIPLAN);
+    if (!P) return CSX_EINVAL;
+    if (matrix_cores) *matrix_cores = (P->rounding_equal && P->rag) ? 1 : 0;
+    if (growth) *growth = P->rag_growth;
     return CSX_OK;
 }
 

@@ -175,6 +175,16 @@ int csx_multiply(csx_handle_t A, csx_handle_t B, csx_handle_t *out);
 int csx_tri_analyse(csx_handle_t T, int kind, csx_handle_t *plan);
 int csx_tri_info(csx_handle_t plan, int32_t *n, int32_t *levels, int32_t *sequential);
 int csx_tri_solve(csx_handle_t plan, csx_handle_t X, int32_t nrhs);
+/* The order of a plan's solves.  exact = 1 (the default of every plan): the reference's operations in the reference's order,
+ * bit-identical to cs_lsolve / cs_ltsolve / cs_usolve / cs_utsolve (csparse.py:1330-1365, :2368-2385, :2460-2475).  exact = 0
+ * (round 5): equal to rounding (x[] within 1e-10).  It changes the solve of a factor that falls into many small independent
+ * components of at most 80 rows with more than 8 right-hand sides: every component is made dense in sweep order, padded to a
+ * multiple of 16 and solved as a blocked substitution on the matrix cores (16 x 16 tiles, explicit inverses of the diagonal
+ * tiles, built at the first such solve) -- unless || |inv(T_ii)| |T_ii| ||_inf of a diagonal tile exceeds 1e3, then the exact
+ * kernels stay.  Every other plan shape solves exactly in either order.  csx_tri_order_info: whether the matrix-core form is in
+ * use (after the first solve in that order) and the guard's measure; either pointer may be NULL. */
+int csx_tri_set_order(csx_handle_t plan, int exact);
+int csx_tri_order_info(csx_handle_t plan, int32_t *matrix_cores, double *growth);
 /* After the first solve: the number of connected components of the dependency graph when the plan solves
  * them one wave each (many components of <= 256 rows: block-diagonal factors), 0 when it level-schedules. */
 int csx_tri_components(csx_handle_t plan, int32_t *ncomp);
@@ -243,7 +253,10 @@ int csx_cholsol_factor_info(int32_t *path, double *analysis_ms, double *numeric_
 /* *path, for the plan's current order (csx_cholsol_set_order): 0 = level-scheduled generic, 1 = fused per-tree
  * kernel (X tile in LDS; the only forest path of the default, exact order), 2 = dense-block FMA substitution,
  * 3 = dense blocks as a blocked TRSM on the matrix cores (fp64 MFMA; blocks of 16/32/64 whose block inverses
- * are benign); 2 and 3 only in the rounding-equal order */
+ * are benign); 4 = supernodal schedule of a big elimination tree (csx_cholsol_sn_info); 5 = a forest of small trees that are not
+ * equal dense blocks (cliques of unequal sizes, small sparse trees, at most 80 columns each) made dense tree by tree, bucketed by
+ * size class (16 / 32 / 48 / 64 / 80) and solved on the matrix cores (round 5; guard: || |inv(T_ii)| |T_ii| ||_inf <= 1e3 for every
+ * diagonal tile); 2 - 5 only in the rounding-equal order */
 int csx_cholsol_info(csx_handle_t plan, int32_t *path, int32_t *ntrees, int32_t *max_nodes);
 int csx_cholsol_solve(csx_handle_t plan, csx_handle_t B, int32_t nrhs);
 /* exact = 1 (the default of every plan): every right-hand side is solved in the reference's operation order,
