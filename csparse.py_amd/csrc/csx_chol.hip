@@ -2287,7 +2287,7 @@ static int cholsol_build_ragged(CholPlan *P) {
     if (P->rag_tried || !P->local || P->dense_bs || !P->f_idx || P->max_nodes > RAG_MAX_ROWS) return CSX_OK;
     P->rag_tried = true;
     RaggedMfma *R = nullptr;
-    CSX_TRY(ragged_build(P->trees, P->ntrees, P->max_nodes, P->f_ptr, P->f_idx, P->f_val, P->diagk, false, &R));
+    CSX_TRY(ragged_build(P->trees, P->ntrees, P->max_nodes, P->tree_nodes, P->f_ptr, P->f_idx, P->f_val, P->diagk, false, &R));
     if (!R) return CSX_OK;
     P->mfma_growth = R->growth;
     if (R->growth <= RAG_GROWTH_LIMIT) P->rag = R;     // (a NaN fails the comparison: the fused per-tree kernel stays)
@@ -2484,7 +2484,7 @@ static int cholsol_solve(CholPlan *P, double *B, int32_t nrhs) {
             return CSX_OK;
         }
         if (P->relaxed && P->rag && ctx().opt.cholsol_dense_blocks)    // trees of any shape, rounding-equal order: on the matrix cores
-            return ragged_solve(P->rag, P->trees, P->tree_nodes, P->perm, false, 2, B, nrhs);
+            return ragged_solve(P->rag, P->tree_nodes, P->perm, false, 2, B, nrhs);
         const size_t per_wave = (size_t)P->max_nodes * 64 * sizeof(double);
         const int waves = tile_waves_per_workgroup(per_wave, CH_WAVES);
         const int32_t chunks = (nrhs + 63) / 64;

@@ -14,6 +14,7 @@ constexpr double RAG_GROWTH_LIMIT = 1e3;   // || |inv(T_ii)| |T_ii| ||_inf of a 
 struct RaggedMfma {
     int32_t ntrees = 0;
     int32_t *list = nullptr;                     // device [ntrees]: component ids, ordered by size class (stable)
+    void *desc = nullptr;                        // device [ntrees] int4 {first, count, base row or -1, id} in that order: what a solve reads
     int32_t cls_start[RAG_CLASSES + 1] = {0};    // class c (components of 16 c + 1 .. 16 (c + 1) rows): list[cls_start[c] .. cls_start[c + 1])
     size_t cls_frag[RAG_CLASSES + 1] = {0};      // first double of class c's fragments
     double *frag = nullptr;
@@ -24,13 +25,12 @@ struct RaggedMfma {
 // dense in POSITION order -- position sp of a component is its row sp (forward sweeps) or count - 1 - sp (backward sweeps) --
 // zero where the pattern has none, the identity on the padding, cut into 16 x 16 tiles: off-diagonal tiles negated, diagonal
 // tiles inverted, in k_cholsol_mfma's fragment order.  *out = nullptr when a component has more than RAG_MAX_ROWS rows.
-int ragged_build(const Tree *trees, int32_t ntrees, int32_t max_rows, const int32_t *ptr, const int32_t *idx, const double *val,
-                 const double *diag, bool reverse, RaggedMfma **out);
+int ragged_build(const Tree *trees, int32_t ntrees, int32_t max_rows, const int32_t *nodes, const int32_t *ptr, const int32_t *idx,
+                 const double *val, const double *diag, bool reverse, RaggedMfma **out);
 // X (n-by-nrhs, row-major) <- the sweep applied to every component: a blocked substitution in position order on the matrix cores.
 // passes = 1: that sweep; passes = 2: then the TRANSPOSED system backwards (cs_cholsol's L then L', the fragments read transposed).
 // perm (or null): row j of the components is row perm[j] of X.
-int ragged_solve(const RaggedMfma *R, const Tree *trees, const int32_t *nodes, const int32_t *perm, bool reverse, int passes, double *X,
-                 int32_t nrhs);
+int ragged_solve(const RaggedMfma *R, const int32_t *nodes, const int32_t *perm, bool reverse, int passes, double *X, int32_t nrhs);
 void ragged_free(RaggedMfma *R);
 
 }  // namespace csx

@@ -38,6 +38,26 @@ __global__ __launch_bounds__(256) void k_rag_class(const Tree *__restrict__ tree
     id[t] = (uint32_t)t;
 }
 
+// What a solve needs to know of the component in slot q of the class-ordered list, in ONE 16-byte load: {first, count, base, id}.
+// base >= 0: the component's rows are the consecutive rows base, base + 1, ... of X (blocks of a block-diagonal matrix: every
+// forest this path was made for) and a lane computes its rows; base = -1: it looks them up in the node list.  (The first version
+// went list -> trees -> nodes -> X: three dependent memory round trips in front of the first byte of X, 3.39 ms for 128
+// right-hand sides on 5M rows of cliques of 8 .. 64 columns; with the descriptor and computed rows: see profiles/r05_ablation.md.)
+__global__ __launch_bounds__(256) void k_rag_desc(const int32_t *__restrict__ list, int32_t ntrees, const Tree *__restrict__ trees,
+                                                  const int32_t *__restrict__ nodes, int4 *__restrict__ desc) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= ntrees) return;
+    const int32_t t = list[q];
+    const Tree tr = trees[t];
+    int32_t base = tr.count > 0 ? nodes[tr.first] : 0;
+    for (int32_t a = 1; a < tr.count; a++)
+        if (nodes[tr.first + a] != base + a) {
+            base = -1;
+            break;
+        }
+    desc[q] = make_int4(tr.first, tr.count, base, t);
+}
+
 // one wave per component: the dense position-order matrix in LDS, the inverses of its diagonal tiles, the fragments, the guard
 template <int NB>
 __global__ __launch_bounds__(64) void k_rag_frags(const int32_t *__restrict__ list, const Tree *__restrict__ trees,
@@ -118,8 +138,8 @@ __global__ __launch_bounds__(64) void k_rag_frags(const int32_t *__restrict__ li
 // col (+ 16 c) of the chunk -- the f64 accumulator layout, which is also the B-operand layout of k-step r: a finished tile feeds
 // the next product from its registers.  Positions past the component's rows are padding: zero in X, the identity in T.
 template <int NB, int PASSES>
-__global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void k_rag_mfma(const int32_t *__restrict__ list, int32_t ncls,
-                                                                     const Tree *__restrict__ trees, const int32_t *__restrict__ nodes,
+__global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void k_rag_mfma(const int4 *__restrict__ desc, int32_t ncls,
+                                                                     const int32_t *__restrict__ nodes,
                                                                      const int32_t *__restrict__ perm, const double *__restrict__ frag,
                                                                      int reverse, double *B, int32_t nrhs, int32_t chunks) {
     const int lane = threadIdx.x & 63;
@@ -127,22 +147,19 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void k_rag_mfma(const int32
     const int64_t task = (int64_t)blockIdx.x * 4 + w;
     if (task >= (int64_t)ncls * chunks) return;
     const int32_t q = (int32_t)(task / chunks), h = (int32_t)(task % chunks);
-    const int32_t t = list[q];
-    const int32_t first = trees[t].first, count = trees[t].count;
+    const int4 ds = desc[q];
+    const int32_t first = __builtin_amdgcn_readfirstlane(ds.x), count = __builtin_amdgcn_readfirstlane(ds.y);
+    const int32_t base = __builtin_amdgcn_readfirstlane(ds.z);
     const int col = lane & 15, rq = lane >> 4;
-    int32_t row[NB][4];      // row of X, -1: padding
-#pragma unroll
-    for (int i = 0; i < NB; i++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int p = 16 * i + rq + 4 * r;
-            int32_t jr = -1;
-            if (p < count) {
-                jr = nodes[first + (reverse ? count - 1 - p : p)];
-                if (perm) jr = perm[jr];
-            }
-            row[i][r] = jr;
-        }
+    // X moves through a BUFFER RESOURCE when the component's rows are consecutive rows of X (base >= 0: blocks of a block-diagonal
+    // matrix): scalar base = the component's first row, size = its rows, a lane's 32-bit byte offset = its position's row and
+    // right-hand sides.  A padding position lies past the size: the hardware's range check returns zero for its load and drops its
+    // store -- no predicate, no branch, no access.  (Tried first: a predicate per load -- the compiler gave every load its own
+    // exec-masked basic block, 234 branches in the 64-row kernel: 3.31 ms for 128 right-hand sides on 5M rows of cliques of
+    // 8 .. 64 columns; padding positions loading the last row and zeroing afterwards: 4.36 ms, the dummy loads cost what real ones
+    // do; this form: profiles/r05_ablation.md.)  Rows that are not consecutive, or permuted (cs_cholsol with a fill-reducing
+    // order), are looked up and go through predicated global accesses.
+    const bool consecutive = base >= 0 && !perm && (int64_t)(RAG_MAX_ROWS + 16) * nrhs * 8 < (1ll << 31);      // uniform (offsets of padding positions must not wrap back into range)
     rg_f64x4 X[NB][4];
     bool live[4];
     int32_t cidx[4];
@@ -156,25 +173,69 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void k_rag_mfma(const int32
     // neighbours 32 c' + 2 col, + 1 of a row and gives them to column chunks 2 c' and 2 c' + 1 (which right-hand side a
     // (chunk, column) pair stands for is free)
     const bool wide = (nrhs & 1) == 0 && h * 64 + 64 <= nrhs && (reinterpret_cast<uintptr_t>(B) & 15) == 0;   // uniform
-    if (wide) {
+    typedef unsigned int rg_u32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned int rg_u32x2 __attribute__((ext_vector_type(2)));
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(B + (consecutive ? (int64_t)base * nrhs : 0), 0, consecutive ? count * nrhs * 8 : 0, 0x00020000);
+    // byte offset of position p's row inside the component (padding: past the size, also when the order is reversed)
+    auto pos_off = [&](int i, int r) -> uint32_t {
+        const int p = 16 * i + rq + 4 * r;
+        return (uint32_t)(reverse ? count - 1 - p : p) * (uint32_t)(nrhs * 8);
+    };
+    auto row_of = [&](int i, int r, bool *ok) -> int64_t {       // the general case: look the row up
+        const int p = 16 * i + rq + 4 * r;
+        *ok = p < count;
+        if (!*ok) return 0;
+        int32_t jr = nodes[first + (reverse ? count - 1 - p : p)];
+        if (perm) jr = perm[jr];
+        return (int64_t)jr * nrhs;
+    };
+    if (consecutive && wide) {
+        const uint32_t coff = (uint32_t)(h * 64 + 2 * col) * 8u;
 #pragma unroll
         for (int i = 0; i < NB; i++)
 #pragma unroll
             for (int cp = 0; cp < 2; cp++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    rg_f64x2 v = rg_f64x2{0.0, 0.0};
-                    if (row[i][r] >= 0) v = *reinterpret_cast<const rg_f64x2 *>(B + (int64_t)row[i][r] * nrhs + h * 64 + 32 * cp + 2 * col);
+                    const rg_u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs, pos_off(i, r) + coff, 32 * cp * 8, 0);
+                    const rg_f64x2 v = __builtin_bit_cast(rg_f64x2, u);
                     X[i][2 * cp][r] = v.x;
                     X[i][2 * cp + 1][r] = v.y;
                 }
-    } else {
+    } else if (consecutive) {
 #pragma unroll
         for (int i = 0; i < NB; i++)
 #pragma unroll
             for (int c = 0; c < 4; c++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) X[i][c][r] = row[i][r] >= 0 ? B[(int64_t)row[i][r] * nrhs + cidx[c]] : 0.0;
+                for (int r = 0; r < 4; r++)
+                    X[i][c][r] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, pos_off(i, r) + (uint32_t)cidx[c] * 8u, 0, 0));
+    } else if (wide) {
+#pragma unroll
+        for (int i = 0; i < NB; i++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                bool ok;
+                const int64_t ro = row_of(i, r, &ok);
+#pragma unroll
+                for (int cp = 0; cp < 2; cp++) {
+                    rg_f64x2 v = rg_f64x2{0.0, 0.0};
+                    if (ok) v = *reinterpret_cast<const rg_f64x2 *>(B + ro + h * 64 + 32 * cp + 2 * col);
+                    X[i][2 * cp][r] = v.x;
+                    X[i][2 * cp + 1][r] = v.y;
+                }
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NB; i++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                bool ok;
+                const int64_t ro = row_of(i, r, &ok);
+#pragma unroll
+                for (int c = 0; c < 4; c++) X[i][c][r] = ok ? B[ro + cidx[c]] : 0.0;
+            }
     }
     const double *F = frag + (size_t)q * rag_frags<NB>() * 64 + lane;
     int f = 0;
@@ -228,39 +289,74 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void k_rag_mfma(const int32
             for (int c = 0; c < 4; c++) X[i][c] = Y[c];
         }
     }
-    if (wide) {
+    if (consecutive && wide) {
+        const uint32_t coff = (uint32_t)(h * 64 + 2 * col) * 8u;
 #pragma unroll
         for (int i = 0; i < NB; i++)
 #pragma unroll
             for (int cp = 0; cp < 2; cp++)
 #pragma unroll
-                for (int r = 0; r < 4; r++)
-                    if (row[i][r] >= 0) {
-                        rg_f64x2 v;
-                        v.x = X[i][2 * cp][r];
-                        v.y = X[i][2 * cp + 1][r];
-                        *reinterpret_cast<rg_f64x2 *>(B + (int64_t)row[i][r] * nrhs + h * 64 + 32 * cp + 2 * col) = v;
-                    }
+                for (int r = 0; r < 4; r++) {
+                    rg_f64x2 v;
+                    v.x = X[i][2 * cp][r];
+                    v.y = X[i][2 * cp + 1][r];
+                    // (the constant goes into the LANE offset, not the instruction's scalar offset: a 16-byte buffer store whose
+                    // soffset is an SGPR gets no wait states from the compiler before a vector instruction overwrites its data
+                    // registers -- GCNHazardRecognizer::createsVALUHazard exempts MUBUF stores with a register soffset -- and on this
+                    // chip the store then took the NEW low dword of its first register in about one block in a hundred: solutions
+                    // wrong in the 7th digit, in columns 56 .. 63 of a chunk only, differently from run to run)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(rg_u32x4, v), rs, pos_off(i, r) + coff + 32u * cp * 8u, 0, 0);
+                }
+        return;
+    }
+    if (consecutive) {
+#pragma unroll
+        for (int i = 0; i < NB; i++)
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const double xv = X[i][c][r];      // (a bit_cast of the vector ELEMENT expression itself reads element 0 of the vector)
+                    // a right-hand side past the block: an offset the range check refuses (0xfffffff8, not 0xffffffff: the access
+                    // is two dwords, each checked on its own, and the second one's offset would wrap to 3)
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(rg_u32x2, xv), rs,
+                                                          live[c] ? pos_off(i, r) + (uint32_t)cidx[c] * 8u : 0xfffffff8u, 0, 0);
+                }
         return;
     }
 #pragma unroll
     for (int i = 0; i < NB; i++)
 #pragma unroll
-        for (int c = 0; c < 4; c++)
+        for (int r = 0; r < 4; r++) {
+            bool ok;
+            const int64_t ro = row_of(i, r, &ok);
+            if (!ok) continue;
+            if (wide) {
 #pragma unroll
-            for (int r = 0; r < 4; r++)
-                if (live[c] && row[i][r] >= 0) B[(int64_t)row[i][r] * nrhs + cidx[c]] = X[i][c][r];
+                for (int cp = 0; cp < 2; cp++) {
+                    rg_f64x2 v;
+                    v.x = X[i][2 * cp][r];
+                    v.y = X[i][2 * cp + 1][r];
+                    *reinterpret_cast<rg_f64x2 *>(B + ro + h * 64 + 32 * cp + 2 * col) = v;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+                    if (live[c]) B[ro + cidx[c]] = X[i][c][r];
+            }
+        }
 }
 
 void ragged_free(RaggedMfma *R) {
     if (!R) return;
+    dfree(R->desc);
     dfree(R->list);
     dfree(R->frag);
     delete R;
 }
 
-int ragged_build(const Tree *trees, int32_t ntrees, int32_t max_rows, const int32_t *ptr, const int32_t *idx, const double *val,
-                 const double *diag, bool reverse, RaggedMfma **out) {
+int ragged_build(const Tree *trees, int32_t ntrees, int32_t max_rows, const int32_t *nodes, const int32_t *ptr, const int32_t *idx,
+                 const double *val, const double *diag, bool reverse, RaggedMfma **out) {
     *out = nullptr;
     if (ntrees <= 0 || max_rows > RAG_MAX_ROWS) return CSX_OK;
     hipStream_t s = ctx().stream;
@@ -284,6 +380,9 @@ int ragged_build(const Tree *trees, int32_t ntrees, int32_t max_rows, const int3
     CSX_LAUNCH_CHECK();
     CSX_TRY(stable_sort_by_key(key, id, nullptr, ntrees, RAG_CLASSES, skey, (uint32_t *)R->list, nullptr));
     CSX_TRY(boundaries_from_sorted(skey, ntrees, RAG_CLASSES, bounds));
+    CSX_TRY(dalloc((int4 **)&R->desc, (size_t)ntrees));
+    hipLaunchKernelGGL(k_rag_desc, dim3((unsigned)((ntrees + 255) / 256)), dim3(256), 0, s, R->list, ntrees, trees, nodes, (int4 *)R->desc);
+    CSX_LAUNCH_CHECK();
     CSX_HIP(hipMemcpyAsync(R->cls_start, bounds, sizeof R->cls_start, hipMemcpyDeviceToHost, s));
     CSX_HIP(hipStreamSynchronize(s));
     size_t total = 0;
@@ -320,8 +419,7 @@ int ragged_build(const Tree *trees, int32_t ntrees, int32_t max_rows, const int3
     return CSX_OK;
 }
 
-int ragged_solve(const RaggedMfma *R, const Tree *trees, const int32_t *nodes, const int32_t *perm, bool reverse, int passes, double *X,
-                 int32_t nrhs) {
+int ragged_solve(const RaggedMfma *R, const int32_t *nodes, const int32_t *perm, bool reverse, int passes, double *X, int32_t nrhs) {
     hipStream_t s = ctx().stream;
     const int32_t chunks = (nrhs + 63) / 64;
     const int rev = reverse ? 1 : 0;
@@ -330,10 +428,10 @@ int ragged_solve(const RaggedMfma *R, const Tree *trees, const int32_t *nodes, c
         if (cnt <= 0) continue;
         const int64_t tasks = (int64_t)cnt * chunks;
         const dim3 grid((unsigned)((tasks + 3) / 4));
-        const int32_t *lst = R->list + R->cls_start[c];
+        const int4 *dsc = (const int4 *)R->desc + R->cls_start[c];
         const double *fr = R->frag + R->cls_frag[c];
 #define CSX_RS(NB, PS) \
-    hipLaunchKernelGGL((k_rag_mfma<NB, PS>), grid, dim3(256), 0, s, lst, cnt, trees, nodes, perm, fr, rev, X, nrhs, chunks)
+    hipLaunchKernelGGL((k_rag_mfma<NB, PS>), grid, dim3(256), 0, s, dsc, cnt, nodes, perm, fr, rev, X, nrhs, chunks)
 #define CSX_RSP(NB)                \
     if (passes == 2) CSX_RS(NB, 2); \
     else CSX_RS(NB, 1)

@@ -1703,14 +1703,14 @@ static int solve_components(TriPlan *P, double *X, int32_t nrhs) {
         if (!P->rag_tried) {
             P->rag_tried = true;
             RaggedMfma *R = nullptr;
-            CSX_TRY(ragged_build(P->comps, P->ncomp, P->comp_max, P->prog_ptr, P->prog_idx, P->prog_val, P->prog_diag, !P->forward, &R));
+            CSX_TRY(ragged_build(P->comps, P->ncomp, P->comp_max, P->comp_nodes, P->prog_ptr, P->prog_idx, P->prog_val, P->prog_diag, !P->forward, &R));
             if (R) {
                 P->rag_growth = R->growth;
                 if (R->growth <= RAG_GROWTH_LIMIT) P->rag = R;     // (a NaN fails the comparison)
                 else ragged_free(R);
             }
         }
-        if (P->rag) return ragged_solve(P->rag, P->comps, P->comp_nodes, nullptr, !P->forward, 1, X, nrhs);
+        if (P->rag) return ragged_solve(P->rag, P->comp_nodes, nullptr, !P->forward, 1, X, nrhs);
     }
     // L, U with up to 8 right-hand sides: one wave per component, column-push form (W, L + U pair: 43 us at 1 RHS,
     // 78 us at 8; at 64 the entry-parallel lanes are gone and it loses to k_tri_local, 483 against 272 us)

@@ -128,3 +128,30 @@ def rhs(n, nrhs, col0=0):
     i = np.arange(n, dtype=np.float64)[:, None]
     r = np.arange(nrhs, dtype=np.float64)[None, :]
     return 1.0 + (i + col0 + r) / float(n)
+
+
+def ragged_cliques(n_want, lo, hi, seed):
+    """Block-diagonal SPD matrix whose dense blocks have sizes drawn uniformly from [lo, hi], about n_want rows (full symmetric
+    storage, columns ascending): a forest of cliques of UNEQUAL sizes (north_star's "batches of independent matrices").
+    Block b = R R' / s + s I.  Returns n, Ap, Ai, Ax, sizes."""
+    rng = np.random.default_rng(seed)
+    sizes = rng.integers(lo, hi + 1, max(1, int(n_want / ((lo + hi) / 2.0))))
+    start = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    n = int(start[-1])
+    Ap = np.concatenate([[0], np.cumsum(np.repeat(sizes, sizes))]).astype(np.int64)
+    nnz = int(Ap[-1])
+    assert nnz < 2 ** 31
+    Ai = np.empty(nnz, np.int32)
+    Ax = np.empty(nnz, np.float64)
+    for s in range(lo, hi + 1):
+        blk = np.nonzero(sizes == s)[0]
+        if len(blk) == 0:
+            continue
+        R = rng.uniform(-1.0, 1.0, (len(blk), s, s))
+        B = R @ np.transpose(R, (0, 2, 1)) / s
+        B[:, np.arange(s), np.arange(s)] += s
+        c0 = start[blk]
+        pos = (Ap[c0][:, None, None] + (np.arange(s) * s)[None, :, None] + np.arange(s)[None, None, :]).reshape(-1)   # [block][col][row]
+        Ai[pos] = (c0[:, None, None] + np.zeros((1, s, 1), np.int64) + np.arange(s)[None, None, :]).reshape(-1).astype(np.int32)
+        Ax[pos] = np.transpose(B, (0, 2, 1)).reshape(-1)
+    return n, Ap.astype(np.int32), Ai, Ax, sizes

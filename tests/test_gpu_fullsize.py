@@ -319,3 +319,43 @@ def test_multiply_1m_identity(cs, lib, draw):
     assert np.max(np.abs(a - c) / np.abs(a)) < 1e-12
     for h in (hA, hB, hC, hone):
         _csx.free(h)
+
+
+def test_forest_of_unequal_cliques_at_1m_rows_rounding_equal_equals_exact_everywhere(cs, lib):
+    """csx_trimfma.hip at scale: a forest of 28 000 cliques of 8 .. 64 columns (1M rows), 128 right-hand sides: EVERY entry of the
+    rounding-equal solve (path 5: trees made dense by size class on the matrix cores) within 1e-12 of the exact order's, and two
+    runs of it bit-identical.  (This size is what it takes: a store hazard -- a 16-byte buffer store with a scalar offset whose data
+    registers the next vector instruction overwrites, which the compiler does not pad -- corrupted the seventh digit of about one
+    block in a hundred at 1M and 5M rows and never at the few thousand rows of tests/test_gpu_trimfma.py.)"""
+    import _csx
+    import synth
+    n, Ap, Ai, Ax, sizes = synth.ragged_cliques(1000000, 8, 64, 20240605)
+    k = 128
+    hA = _csx.new_handle()
+    _csx.check(lib.csx_csc_upload(n, n, _csx.pi(Ap), _csx.pi(Ai), _csx.pd(Ax), hA))
+    hL, plan = _csx.new_handle(), _csx.new_handle()
+    _csx.check(lib.csx_cholsol_factor(hA, 0, hL, plan))
+    path = C.c_int32(-1)
+    _csx.check(lib.csx_cholsol_info(plan, path, None, None))
+    assert path.value == 5
+    sols = []
+    for exact in (1, 0, 0):
+        _csx.check(lib.csx_cholsol_set_order(plan, exact))
+        hB = _csx.new_handle()
+        _csx.check(lib.csx_gen_rhs(n, k, 0, hB))
+        _csx.check(lib.csx_cholsol_solve(plan, hB, k))
+        x = np.empty(n * k)
+        _csx.check(lib.csx_vec_download(hB, _csx.pd(x), n * k))
+        sols.append(x)
+        _csx.free(hB)
+    assert sols[1].tobytes() == sols[2].tobytes()
+    assert float(np.max(np.abs(sols[1] - sols[0]) / np.abs(sols[0]))) <= 1e-12
+    # and the answer is a solution: A x = b for three columns (A symmetric, full storage)
+    import scipy.sparse as sp
+    A = sp.csc_matrix((Ax, Ai, Ap), shape=(n, n))
+    X = sols[1].reshape(n, k)
+    for r in (0, 77, k - 1):
+        b = 1.0 + (np.arange(n) + r) / float(n)
+        assert float(np.max(np.abs(A @ X[:, r] - b))) <= 1e-12 * 64.0
+    for h in (plan, hL, hA):
+        _csx.free(h)
