@@ -374,6 +374,10 @@ def main():
                          "(max relative error %.3e)" % parity_err)
     del ya, ye
 
+    try:
+        rccl_ranks = comm.info()
+    except Exception as e:                                # reported, never fatal
+        rccl_ranks = {"error": "%s: %s" % (type(e).__name__, e)}
     key_bytes = _csx.C.c_int(0)
     _csx.check(lib.csx_gaxpy_plan_info(hA, None, None, key_bytes), "plan_info")
     shape, shape_ms = _csx.C.c_int(-1), (_csx.C.c_double * 4)()
@@ -384,6 +388,9 @@ def main():
         "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(wall / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        # what the exchange transport itself says (csx_comm_info of the communicator libcsx made, and a sum of ones over it):
+        # at N > 1 "uses_rccl" must be true and "ranks_counted" == n_gpus
+        "rccl_ranks": rccl_ranks,
         "config": {"workload": "cs_gaxpy y += A x on G-rand: %d x %d CSC, %s, int32 indices, fp64 values; one "
                                "independent matrix per GPU" % (n, n, gen_words[args.gen]), "row_draw": args.gen,
                    "n": n, "nnz": nnz, "kernel": "gaxpy_" + chosen, "plan_key_bytes": key_bytes.value,
@@ -542,12 +549,17 @@ def exchange_preflight(args, lib, cs, comm, barrier, deadline, out):
         res["running"] = name
         deadline.checkpoint(out)
         t0 = time.perf_counter()
+        err = None
         try:
             ok = fn()
-            ok = bool(comm.sum(1.0 if ok else 0.0) == world)      # every rank's check
-            res["legs"][name] = {"ok": ok, "s": round(time.perf_counter() - t0, 4)}
         except Exception as e:                                    # reported, never fatal
-            res["legs"][name] = {"ok": False, "error": "%s: %s" % (type(e).__name__, e)}
+            ok, err = False, "%s: %s" % (type(e).__name__, e)
+        # EVERY rank takes part in the vote, also the one whose fn() raised: a rank that skipped it would enter the next
+        # leg's collectives one step ahead of the others
+        ok = bool(comm.sum(1.0 if ok else 0.0) == world)
+        res["legs"][name] = {"ok": ok, "s": round(time.perf_counter() - t0, 4)}
+        if err:
+            res["legs"][name]["error"] = err
         res["running"] = None
         deadline.checkpoint(out)
 
@@ -905,6 +917,12 @@ def cholsol_section(args, lib, cs, comm, hB, nb, bs, barrier, max_over_ranks, pr
                              "frac_whole_call": round(chol_bytes / t_factor / 1e9 / HBM_PEAK_GBS, 4),
                              "traffic": (measured_traffic("k_chol_clique", n=n) or {}).get("bytes")},
            "end_to_end_solves_per_s_per_gpu": round(k / (t_factor + ms * 1e-3), 1),
+           # BASELINE config 5 as stated: 1 024 right-hand sides on 8 GPUs = 128 per GPU, ONE batch; every rank factors for itself
+           # (csx_cholsol_factor, no exchange: DESIGN 5), its block generated in place; whole-job figures with the slowest rank's times
+           "config5_as_stated": (lambda tf: {"total_rhs": k * world, "rhs_per_gpu": k, "gpus": world,
+                                             "factor_s_slowest_rank": round(tf, 5), "batch_ms_slowest_rank": round(ms, 4),
+                                             "end_to_end_solves_per_s_whole_job": round(k * world / (tf + ms * 1e-3), 1),
+                                             "solve_phase_solves_per_s_whole_job": round(k * world / (ms * 1e-3), 1)})(max_over_ranks(t_factor)),
            "end_to_end_note": "cs_schol + cs_chol + plan + ONE batch of %d right-hand sides (the solve phase alone: solves_per_s)" % k,
            "exact_order": {"ms_per_batch": round(ms_exact, 4), "solves_per_s_per_gpu": round(k / (ms_exact * 1e-3), 1),
                            "note": "default order of every plan: bit-identical to cs_lsolve + cs_ltsolve"}}

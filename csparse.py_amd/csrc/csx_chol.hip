@@ -1069,6 +1069,11 @@ struct CholPlan {
     // the trees made dense and bucketed by size class, solved on the matrix cores (csx_trimfma.hip); null: not built / refused
     RaggedMfma *rag = nullptr;
     bool rag_tried = false;
+    // csx_cholsol_factor on such a forest in the rounding-equal order: the plan holds the block list and `rag` (built straight from
+    // L's columns) and nothing else; a solve the matrix cores do not take (the exact order, the guard's refusal) goes to `full`,
+    // the general plan of the same factor, made the first time it is needed
+    bool lite = false;
+    CholPlan *full = nullptr;
     bool mfma_tried = false;  // fragments were built, or refused by the growth guard
     double mfma_growth = 0.0; // max|inv(L_ii)| max|L| over the forest (the guard's measure)
     // big trees, rounding-equal order: supernodal schedule (csx_snsolve.hip), built the first time the plan is relaxed
@@ -1083,6 +1088,7 @@ void free_cholplan(CholPlan *P) {
     if (P->g_exec) (void)hipGraphExecDestroy(P->g_exec);
     free_snplan(P->sn);
     ragged_free(P->rag);
+    free_cholplan(P->full);
     free_triplan(P->fwd);
     free_triplan(P->bwd);
     dfree(P->perm);
@@ -2362,6 +2368,12 @@ static int cholsol_solve(CholPlan *P, double *B, int32_t nrhs) {
     hipStream_t s = ctx().stream;
     const int32_t n = P->n;
     if (n == 0 || nrhs == 0) return CSX_OK;
+    if (P->lite) {
+        if (P->relaxed && P->rag && ctx().opt.cholsol_dense_blocks) return ragged_solve(P->rag, P->tree_nodes, nullptr, false, 2, B, nrhs);
+        if (!P->full) CSX_TRY(cholsol_plan(P->L, nullptr, &P->full));
+        P->full->relaxed = false;          // (what `full` is for: the exact order, or the order the guard left)
+        return cholsol_solve(P->full, B, nrhs);
+    }
     const int32_t *Gp = nullptr, *Gi = nullptr;
     const double *Gx = nullptr, *Gd = nullptr;
     if (!P->clique) tri_gather_arrays(P->fwd, &Gp, &Gi, &Gx, &Gd);
@@ -2705,6 +2717,30 @@ static int cholsol_factor_device(csx_handle_t hA, Csc *A, bool exact, Csc *L, Ch
                     P->frag_f = nullptr;
                 }
                 g_factor_path = 3;
+            } else if (!exact && ctx().opt.cholsol_dense_blocks && !(F.min_bs == bs && bs == 8 && !F.sparse)) {
+                // a forest of UNEQUAL cliques or of small sparse trees, rounding-equal order: the block list from the forest's
+                // starts, the matrix-core operands straight from L's columns -- no general plan unless a solve needs one
+                P = new CholPlan();
+                *Pout = P;
+                P->n = n;
+                P->L = L;
+                P->lite = true;
+                P->local = true;
+                P->relaxed = true;
+                P->ntrees = F.nblocks;
+                P->max_nodes = bs;
+                CSX_TRY(dalloc(&P->trees, (size_t)F.nblocks));
+                CSX_TRY(dalloc(&P->tree_nodes, (size_t)n));
+                CSX_TRY(ragged_blocks(F.start, F.nblocks, n, P->trees, P->tree_nodes));
+                P->rag_tried = true;
+                RaggedMfma *R = nullptr;
+                CSX_TRY(ragged_build(P->trees, P->ntrees, bs, P->tree_nodes, nullptr, nullptr, nullptr, nullptr, false, &R, L));
+                if (R) {
+                    P->mfma_growth = R->growth;
+                    if (R->growth <= RAG_GROWTH_LIMIT) P->rag = R;
+                    else ragged_free(R);
+                }
+                g_factor_path = F.sparse ? 2 : 1;
             } else {
                 if (!F.sparse && F.min_bs == bs && (bs == 8 || bs == 16 || bs == 32 || bs == 64) && ctx().opt.cholsol_dense_blocks) {
                     // equal dense blocks (the forest's record says so: no k_clique_factor_shape over L.i): the programs straight from L.x
@@ -2798,6 +2834,11 @@ extern "C" int csx_cholsol_info(csx_handle_t h, int32_t *local, int32_t *ntrees,
     if (!P) return CSX_EINVAL;
     // 0 level-scheduled, 1 fused in LDS, 2 dense blocks (substitution), 3 dense blocks on the matrix cores, 4 supernodal schedule,
     // 5 small trees of any shape made dense by size class on the matrix cores (csx_trimfma.hip)
+    if (P->lite && !(P->relaxed && P->rag)) {   // the general plan answers (made now if it has to be)
+        if (!P->full) CSX_TRY(cholsol_plan(P->L, nullptr, &P->full));
+        P->full->relaxed = false;
+        P = P->full;
+    }
     if (local) *local = P->local ? (P->dense_bs ? (P->relaxed && P->frag_f ? 3 : 2) : (P->relaxed && P->rag ? 5 : 1)) : (P->relaxed && P->sn && sn_usable(P->sn) ? 4 : 0);
     if (ntrees) *ntrees = P->ntrees;
     if (max_nodes) *max_nodes = P->max_nodes;

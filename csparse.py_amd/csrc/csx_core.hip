@@ -161,7 +161,8 @@ int dmalloc(void **p, size_t bytes) {
         // driver cost tens of milliseconds (30 ms for the 2 GB of a 5M-row factor inside its first csx_chol when the pool
         // happened to hold nothing of that size), and a block that idles in the cache serves nobody
         auto it = g_pool.idle.lower_bound(want);
-        const size_t most = want >= ((size_t)64 << 20) ? 3 * want : want + want / 4;
+        // (the slack of a big block is capped in absolute terms: a 2 GB factor must not pin a 6 GB block for its lifetime)
+        const size_t most = want >= ((size_t)64 << 20) ? std::min(3 * want, want + ((size_t)1 << 30)) : want + want / 4;
         if (it != g_pool.idle.end() && it->first <= most) {
             *p = it->second.p;
             g_pool.cached -= it->first;
@@ -310,22 +311,40 @@ int csx_init(int device) {
     hipDeviceProp_t prop;
     CSX_HIP(hipGetDeviceProperties(&prop, device));
     c.cus = prop.multiProcessorCount;
-    CSX_HIP(hipStreamCreateWithFlags(&c.own_stream, hipStreamNonBlocking));
+    // every exit below that is not the last one gives back what was made so far (streams, events, the warm-up block)
+    int *d_warm = nullptr;
+    auto undo = [&](hipError_t e, const char *what) {
+        set_error("csx_init: %s -> %s", what, hipGetErrorString(e));
+        if (d_warm) (void)hipFree(d_warm);
+        if (c.ev0) (void)hipEventDestroy(c.ev0);
+        if (c.ev1) (void)hipEventDestroy(c.ev1);
+        if (c.side) (void)hipStreamDestroy(c.side);
+        if (c.own_stream) (void)hipStreamDestroy(c.own_stream);
+        c = Context();
+        return CSX_ERUNTIME;
+    };
+#define CSX_INIT_STEP(call)                           \
+    do {                                              \
+        const hipError_t _e = (call);                 \
+        if (_e != hipSuccess) return undo(_e, #call); \
+    } while (0)
+    CSX_INIT_STEP(hipStreamCreateWithFlags(&c.own_stream, hipStreamNonBlocking));
     c.stream = c.own_stream;
-    CSX_HIP(hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking));
+    CSX_INIT_STEP(hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking));
     {
         // the first LARGE copy from pageable memory on a stream sets up its copy path (6 ms seen inside the first csx_chol)
         std::vector<int> warm((size_t)1 << 20, 0);
-        int *d_warm = nullptr;
-        CSX_HIP(hipMalloc(&d_warm, warm.size() * sizeof(int)));
-        CSX_HIP(hipMemcpyAsync(d_warm, warm.data(), warm.size() * sizeof(int), hipMemcpyHostToDevice, c.side));
+        CSX_INIT_STEP(hipMalloc(&d_warm, warm.size() * sizeof(int)));
+        CSX_INIT_STEP(hipMemcpyAsync(d_warm, warm.data(), warm.size() * sizeof(int), hipMemcpyHostToDevice, c.side));
         hipLaunchKernelGGL(k_warm, dim3(1), dim3(64), 0, c.side, d_warm);      // (and a stream's first kernel makes its queue)
-        CSX_HIP(hipMemcpyAsync(warm.data(), d_warm, warm.size() * sizeof(int), hipMemcpyDeviceToHost, c.side));
-        CSX_HIP(hipStreamSynchronize(c.side));
-        CSX_HIP(hipFree(d_warm));
+        CSX_INIT_STEP(hipMemcpyAsync(warm.data(), d_warm, warm.size() * sizeof(int), hipMemcpyDeviceToHost, c.side));
+        CSX_INIT_STEP(hipStreamSynchronize(c.side));
+        CSX_INIT_STEP(hipFree(d_warm));
+        d_warm = nullptr;
     }
-    CSX_HIP(hipEventCreate(&c.ev0));
-    CSX_HIP(hipEventCreate(&c.ev1));
+    CSX_INIT_STEP(hipEventCreate(&c.ev0));
+    CSX_INIT_STEP(hipEventCreate(&c.ev1));
+#undef CSX_INIT_STEP
     c.device = device;
     c.ready = true;
     return CSX_OK;

@@ -25,8 +25,12 @@ struct RaggedMfma {
 // dense in POSITION order -- position sp of a component is its row sp (forward sweeps) or count - 1 - sp (backward sweeps) --
 // zero where the pattern has none, the identity on the padding, cut into 16 x 16 tiles: off-diagonal tiles negated, diagonal
 // tiles inverted, in k_cholsol_mfma's fragment order.  *out = nullptr when a component has more than RAG_MAX_ROWS rows.
+// from_factor (or null): the components are blocks of consecutive columns of this Cholesky-shaped factor (trees[b] = {first column,
+// columns}, nodes the identity) and the dense triangles are read from its columns instead of from sweep programs (ptr .. diag unused).
 int ragged_build(const Tree *trees, int32_t ntrees, int32_t max_rows, const int32_t *nodes, const int32_t *ptr, const int32_t *idx,
-                 const double *val, const double *diag, bool reverse, RaggedMfma **out);
+                 const double *val, const double *diag, bool reverse, RaggedMfma **out, const Csc *from_factor = nullptr);
+// trees[b] = {start[b], start[b + 1] - start[b]}, nodes = the identity (n entries): the block list of such a factor
+int ragged_blocks(const int32_t *start, int32_t nblocks, int32_t n, Tree *trees, int32_t *nodes);
 // X (n-by-nrhs, row-major) <- the sweep applied to every component: a blocked substitution in position order on the matrix cores.
 // passes = 1: that sweep; passes = 2: then the TRANSPOSED system backwards (cs_cholsol's L then L', the fragments read transposed).
 // perm (or null): row j of the components is row perm[j] of X.

@@ -134,6 +134,95 @@ __global__ __launch_bounds__(64) void k_rag_frags(const int32_t *__restrict__ li
     }
 }
 
+// The same fragments straight from a Cholesky-shaped factor L whose components are BLOCKS of consecutive columns closed under
+// their rows (a forest of cliques or of small trees as csx_cholclique.hip recognises it): component = columns [first, first + count),
+// element (r, c) of its dense triangle = L(first + r, first + c).  No solve plan in between (csx_cholsol_factor: the general plan of
+// such a factor -- two triangular analyses, partition, packing -- took 12 ms at 5M rows in front of a 2.8 ms solve).
+template <int NB>
+__global__ __launch_bounds__(64) void k_rag_frags_csc(const int32_t *__restrict__ list, const Tree *__restrict__ trees,
+                                                      const int32_t *__restrict__ Lp, const int32_t *__restrict__ Li,
+                                                      const double *__restrict__ Lx, double *__restrict__ frag,
+                                                      unsigned long long *cond_bits) {
+    constexpr int BS = 16 * NB;
+    __shared__ double M[BS][BS + 1];
+    __shared__ double W[NB][16][17];
+    __shared__ int32_t cp[BS + 1];
+    const int lane = threadIdx.x;
+    const int32_t t = list[blockIdx.x], first = trees[t].first, count = trees[t].count;
+    for (int e = lane; e < BS * (BS + 1); e += 64) (&M[0][0])[e] = 0.0;
+    for (int c = lane; c <= count; c += 64) cp[c] = Lp[first + c];
+    __syncthreads();
+    for (int sp = count + lane; sp < BS; sp += 64) M[sp][sp] = 1.0;
+    const int32_t tb = cp[0], te = cp[count];
+    for (int32_t q = tb + lane; q < te; q += 64) {
+        int lo = 0, hi = count;                 // the column of entry q: largest c with cp[c] <= q
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (cp[mid] <= q) lo = mid;
+            else hi = mid;
+        }
+        const int32_t r = Li[q] - first;
+        if (r >= lo && r < count) atomicAdd(&M[r][lo], Lx[q]);
+    }
+    __syncthreads();
+    double wmax = 0.0;
+    {
+        const int blk = lane >> 4, col = lane & 15;
+        for (int b0 = 0; b0 < NB; b0 += 4) {
+            const int b = b0 + blk;
+            if (b < NB) {
+                double wcol[16];
+                tile_inverse_column(&M[16 * b][16 * b], BS + 1, col, wcol);
+#pragma unroll
+                for (int r = 0; r < 16; r++) W[b][r][col] = wcol[r];
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const int r = lane & 15, cg = lane >> 4;
+        for (int b = 0; b < NB; b++) {
+            double s = 0.0;
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                for (int k = 0; k < 16; k++) s += fabs(W[b][r][k]) * fabs(M[16 * b + k][16 * b + 4 * cg + c]);
+            s += __shfl_xor(s, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            wmax = fmax(wmax, s);
+        }
+    }
+    const int m = lane & 15, kq = lane >> 4;
+    double *F = frag + (size_t)blockIdx.x * rag_frags<NB>() * 64 + lane;
+    int f = 0;
+    for (int i = 0; i < NB; i++) {
+        for (int j = 0; j < i; j++)
+            for (int sx = 0; sx < 4; sx++) F[64 * f++] = -M[16 * i + m][16 * j + 4 * sx + kq];
+        for (int sx = 0; sx < 4; sx++) F[64 * f++] = W[i][m][4 * sx + kq];
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) wmax = fmax(wmax, __shfl_xor(wmax, d, 64));
+    if (lane == 0) {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(wmax != wmax ? __longlong_as_double(0x7ff8000000000000ll) : wmax);
+        if (!(bits <= *(volatile unsigned long long *)cond_bits)) atomicMax(cond_bits, bits);
+    }
+}
+
+// the plan's block list from the forest's block starts: component b = columns [start[b], start[b + 1]), the identity node list
+__global__ __launch_bounds__(256) void k_rag_blocks(const int32_t *__restrict__ start, int32_t nblocks, int32_t n, Tree *__restrict__ trees,
+                                                    int32_t *__restrict__ nodes) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < nblocks) trees[q] = Tree{start[q], start[q + 1] - start[q]};
+    if (q < n) nodes[q] = (int32_t)q;
+}
+
+int ragged_blocks(const int32_t *start, int32_t nblocks, int32_t n, Tree *trees, int32_t *nodes) {
+    const int64_t m = std::max<int64_t>(nblocks, n);
+    if (m <= 0) return CSX_OK;
+    hipLaunchKernelGGL(k_rag_blocks, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx().stream, start, nblocks, n, trees, nodes);
+    CSX_LAUNCH_CHECK();
+    return CSX_OK;
+}
+
 // One wave = one component x 64 right-hand sides.  Lane (rq, col): rows 16 i + rq + 4 r of the position order, right-hand sides
 // col (+ 16 c) of the chunk -- the f64 accumulator layout, which is also the B-operand layout of k-step r: a finished tile feeds
 // the next product from its registers.  Positions past the component's rows are padding: zero in X, the identity in T.
@@ -356,7 +445,7 @@ void ragged_free(RaggedMfma *R) {
 }
 
 int ragged_build(const Tree *trees, int32_t ntrees, int32_t max_rows, const int32_t *nodes, const int32_t *ptr, const int32_t *idx,
-                 const double *val, const double *diag, bool reverse, RaggedMfma **out) {
+                 const double *val, const double *diag, bool reverse, RaggedMfma **out, const Csc *from_factor) {
     *out = nullptr;
     if (ntrees <= 0 || max_rows > RAG_MAX_ROWS) return CSX_OK;
     hipStream_t s = ctx().stream;
@@ -398,8 +487,12 @@ int ragged_build(const Tree *trees, int32_t ntrees, int32_t max_rows, const int3
         if (cnt <= 0) continue;
         const int32_t *lst = R->list + R->cls_start[c];
         double *fr = R->frag + R->cls_frag[c];
-#define CSX_RF(NB) \
-    hipLaunchKernelGGL(k_rag_frags<NB>, dim3((unsigned)cnt), dim3(64), 0, s, lst, trees, ptr, idx, val, diag, reverse ? 1 : 0, fr, cond)
+#define CSX_RF(NB)                                                                                                                   \
+    if (from_factor)                                                                                                                \
+        hipLaunchKernelGGL(k_rag_frags_csc<NB>, dim3((unsigned)cnt), dim3(64), 0, s, lst, trees, from_factor->p, from_factor->i,    \
+                           from_factor->x, fr, cond);                                                                               \
+    else                                                                                                                            \
+        hipLaunchKernelGGL(k_rag_frags<NB>, dim3((unsigned)cnt), dim3(64), 0, s, lst, trees, ptr, idx, val, diag, reverse ? 1 : 0, fr, cond)
         switch (c) {
             case 0: CSX_RF(1); break;
             case 1: CSX_RF(2); break;

@@ -204,6 +204,18 @@ class Comm(object):
                 raise ValueError("shard.Comm: unknown backend %r" % backend)
             self.backend = "rccl (libcsx)" if backend == "csx" else backend
 
+    def info(self):
+        """What the transport itself reports: {"backend", "world", "rank", "uses_rccl", "ranks_counted"} -- world / rank / uses_rccl
+        from csx_comm_info (the communicator libcsx made), ranks_counted = a sum of ones over that transport."""
+        d = {"backend": self.backend, "world": self.world, "rank": self.rank, "uses_rccl": False}
+        if self.csx is not None:
+            C = self._csx.C
+            r, w, u = C.c_int(-1), C.c_int(-1), C.c_int(0)
+            self._csx.check(self.csx.csx_comm_info(r, w, u), "csx_comm_info")
+            d.update(world=w.value, rank=r.value, uses_rccl=bool(u.value))
+        d["ranks_counted"] = int(round(self.sum(1.0)))
+        return d
+
     # ---- control plane -------------------------------------------------------------------------------------------
 
     def barrier(self, sync=None):
