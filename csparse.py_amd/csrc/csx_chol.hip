@@ -727,7 +727,7 @@ static int chol_device(const Csc *A, const int32_t *parent, const int32_t *cp, c
             }
             lap("allocations");
             if (st == CSX_OK) (void)hipEventRecord(ev_a, s);
-            if (st == CSX_OK) st = chol_clique_numeric(A, F, L, d_notspd);
+            if (st == CSX_OK) st = chol_clique_numeric(A, F, L, d_notspd, nullptr, !ctx().opt.chol_exact);
             if (st == CSX_OK) (void)hipEventRecord(ev_b, s);
             lap("block kernel");
             if (st == CSX_OK) st = clique_matches_run(&cmp);
@@ -2686,7 +2686,7 @@ static int cholsol_factor_device(csx_handle_t hA, Csc *A, bool exact, Csc *L, Ch
                 return CSX_ERUNTIME;
             }
             (void)hipEventRecord(ev_a, s);
-            int st = chol_clique_numeric(A, F, L, d_flags, emit ? &em : nullptr);
+            int st = chol_clique_numeric(A, F, L, d_flags, emit ? &em : nullptr, !ctx().opt.chol_exact);
             (void)hipEventRecord(ev_b, s);
             int h[4] = {0, 0, 0, 0};
             if (hipMemcpyAsync(h, d_flags, sizeof h, hipMemcpyDeviceToHost, s) != hipSuccess) st = st == CSX_OK ? CSX_ERUNTIME : st;

@@ -53,7 +53,8 @@ struct CliqueEmit {
     int32_t *tree_nodes = nullptr;        // [n]        the identity node list
 };
 // values and row indices of L (L->p = F.cp already in place, L->i / L->x allocated); blocks of at most 64 columns
-int chol_clique_numeric(const Csc *A, const CliqueForest &F, Csc *L, int *d_notspd, const CliqueEmit *emit = nullptr);
+// relaxed ("chol.exact" = 0): fused multiply-adds and reciprocal square roots -- L.x equal to the exact kernel's to rounding
+int chol_clique_numeric(const Csc *A, const CliqueForest &F, Csc *L, int *d_notspd, const CliqueEmit *emit = nullptr, bool relaxed = false);
 constexpr int clique_frags_per_block(int nb16) { return (nb16 * (nb16 - 1) / 2 + nb16) * 4; }
 
 // Column `col` of the inverse of a 16 x 16 lower-triangular tile T (element (r, q) at T[r * ld + q]): w[r] = inv(T)(r, col), zero

@@ -489,7 +489,22 @@ constexpr int CQ_TILE = CQ_CH * CQ_LD + 2;                 // the staging tile +
 constexpr int CQ_TILE_EMIT = 8 * 64 + 4 * CQ_DIAG;         // colbuf + four diagonal tiles (>= CQ_TILE)
 static_assert(CQ_TILE_EMIT >= CQ_TILE, "the staging tile must fit");
 
-template <int PARTS, bool SMALL, bool DENSE, bool SPARSE, bool EMIT>
+// RELAXED ("chol.exact" = 0, opt-in): the same elimination with what bit-identity forbids -- every update one fused multiply-add
+// instead of a multiply and a subtraction (4 032 -> 2 016 vector instructions per 64-column block), the pivot column scaled by a
+// reciprocal square root refined to full precision (v_rsq_f64 + two Newton steps, ~12 instructions; L(j,j) = d * rsqrt(d) corrected
+// once) instead of an IEEE square root and an IEEE division per column (~35 instructions each, 64 of each per block).  L.x then
+// equals the exact kernel's to rounding (1e-13 normwise tested), which is what BASELINE.json's north_star asks of x[].
+__device__ __forceinline__ double cq_rsqrt(double d) {
+    double y = __builtin_amdgcn_rsq(d);                 // ~2^-26 relative
+#pragma unroll
+    for (int it = 0; it < 2; it++) {                    // y <- y + y (1 - d y^2) / 2
+        const double e = __builtin_fma(-d * y, y, 1.0);
+        y = __builtin_fma(0.5 * y, e, y);
+    }
+    return y;
+}
+
+template <int PARTS, bool SMALL, bool DENSE, bool SPARSE, bool EMIT, bool RELAXED = false>
 __global__ __launch_bounds__(64 * CQ_WAVES, 3) void k_chol_clique(const int32_t *__restrict__ start, int32_t nblocks, int32_t n, int32_t nnz,
                                                                  const int32_t *__restrict__ Ap, const int32_t *__restrict__ Ai,
                                                                  const double *__restrict__ Ax, const int32_t *__restrict__ Lp,
@@ -626,8 +641,17 @@ __global__ __launch_bounds__(64 * CQ_WAVES, 3) void k_chol_clique(const int32_t 
                 const double d = cq_bcast(a[jw], g);    // (the pivot through LDS instead -- a store by its lane, a broadcast read --
                                                         // saves 7 ns of issue and costs an LDS round trip on the chain: no gain, 1.72 ms either way)
                 if (d <= 0.0 && lane == 0) atomicMin(notspd, c0 + g);   // csparse.py:612
-                const double ljj = sqrt(d);
-                const double l = a[jw] / ljj;
+                double ljj, l;
+                if (RELAXED) {
+                    const double y = cq_rsqrt(d);
+                    double sq = d * y;                                   // sqrt(d), corrected once: s + (d - s^2) y / 2
+                    sq = __builtin_fma(__builtin_fma(-sq, sq, d), 0.5 * y, sq);
+                    ljj = sq;
+                    l = a[jw] * y;
+                } else {
+                    ljj = sqrt(d);
+                    l = a[jw] / ljj;
+                }
                 a[jw] = lane == g ? ljj : l;
                 colbuf[jw * 64 + lane] = a[jw];
                 cq_wave_sync_lds();
@@ -637,8 +661,12 @@ __global__ __launch_bounds__(64 * CQ_WAVES, 3) void k_chol_clique(const int32_t 
                     for (int cw = jw + 1; cw < 8; cw++) sc[cw] = colbuf[jw * 64 + J + cw];
 #pragma unroll
                     for (int cw = jw + 1; cw < 8; cw++) {
-                        const double pr = a[jw] * sc[cw];
-                        a[cw] = a[cw] - pr;
+                        if (RELAXED) {
+                            a[cw] = __builtin_fma(-a[jw], sc[cw], a[cw]);
+                        } else {
+                            const double pr = a[jw] * sc[cw];
+                            a[cw] = a[cw] - pr;
+                        }
                     }
                 }
             }
@@ -654,10 +682,15 @@ __global__ __launch_bounds__(64 * CQ_WAVES, 3) void k_chol_clique(const int32_t 
                     const double *src = colbuf + jw * 64 + J + 8 * gq;
 #pragma unroll
                     for (int cc = 0; cc < 8; cc++) sc[cc] = (PARTS & 8) ? a[(jw + cc) & 63] : src[cc];
+                    if (RELAXED) {
 #pragma unroll
-                    for (int cc = 0; cc < 8; cc++) pr[cc] = a[jw] * sc[cc];
+                        for (int cc = 0; cc < 8; cc++) a[8 * gq + cc] = __builtin_fma(-a[jw], sc[cc], a[8 * gq + cc]);
+                    } else {
 #pragma unroll
-                    for (int cc = 0; cc < 8; cc++) a[8 * gq + cc] = a[8 * gq + cc] - pr[cc];
+                        for (int cc = 0; cc < 8; cc++) pr[cc] = a[jw] * sc[cc];
+#pragma unroll
+                        for (int cc = 0; cc < 8; cc++) a[8 * gq + cc] = a[8 * gq + cc] - pr[cc];
+                    }
                 }
             }
         }
@@ -729,7 +762,7 @@ __global__ __launch_bounds__(64 * CQ_WAVES, 3) void k_chol_clique(const int32_t 
     }
 }
 
-int chol_clique_numeric(const Csc *A, const CliqueForest &F, Csc *L, int *d_notspd, const CliqueEmit *emit) {
+int chol_clique_numeric(const Csc *A, const CliqueForest &F, Csc *L, int *d_notspd, const CliqueEmit *emit, bool relaxed) {
     hipStream_t s = ctx().stream;
     if (F.nblocks == 0 || A->nnz == 0) return CSX_OK;
     const dim3 grid((unsigned)((F.nblocks + CQ_WAVES - 1) / CQ_WAVES));
@@ -758,6 +791,30 @@ int chol_clique_numeric(const Csc *A, const CliqueForest &F, Csc *L, int *d_nots
         CSX_CQ_GO(PARTS, true, false, false, false);                                                                            \
     else                                                                                                                        \
         CSX_CQ_GO(PARTS, false, false, false, false)
+    if (relaxed && A->nnz < (1 << 29)) {      // "chol.exact" = 0: the rounding-equal arithmetic (the common shapes; others stay exact)
+        if (emit && F.dense_in_front) {
+            hipLaunchKernelGGL((k_chol_clique<7, true, true, false, true, true>), grid, dim3(64 * CQ_WAVES), 0, s, F.start, F.nblocks, A->n,
+                               A->nnz, A->p, A->i, A->x, L->p, L->i, L->x, d_notspd, F.colmask, em);
+            CSX_LAUNCH_CHECK();
+            return CSX_OK;
+        }
+        if (emit) {
+            hipLaunchKernelGGL((k_chol_clique<7, true, false, false, true, true>), grid, dim3(64 * CQ_WAVES), 0, s, F.start, F.nblocks, A->n,
+                               A->nnz, A->p, A->i, A->x, L->p, L->i, L->x, d_notspd, F.colmask, em);
+            CSX_LAUNCH_CHECK();
+            return CSX_OK;
+        }
+        if (!F.sparse) {
+            if (F.dense_in_front)
+                hipLaunchKernelGGL((k_chol_clique<7, true, true, false, false, true>), grid, dim3(64 * CQ_WAVES), 0, s, F.start, F.nblocks,
+                                   A->n, A->nnz, A->p, A->i, A->x, L->p, L->i, L->x, d_notspd, F.colmask, em);
+            else
+                hipLaunchKernelGGL((k_chol_clique<7, true, false, false, false, true>), grid, dim3(64 * CQ_WAVES), 0, s, F.start, F.nblocks,
+                                   A->n, A->nnz, A->p, A->i, A->x, L->p, L->i, L->x, d_notspd, F.colmask, em);
+            CSX_LAUNCH_CHECK();
+            return CSX_OK;
+        }
+    }
     int parts = 7;
 #ifdef CSX_ABLATION
     if (const char *e = ablation_env("CSX_CQ_PARTS")) parts = atoi(e);

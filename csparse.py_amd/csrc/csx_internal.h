@@ -135,6 +135,9 @@ struct Options {
     int chol_forest = 1;          // ... and forests of small SPARSE trees on consecutive columns (blocks of <= 64 columns closed under
                                   // their upper entries): symbolic analysis on 64-bit row masks in registers, the block kernel with
                                   // a compacted store (needs chol.clique)
+    int chol_exact = 1;           // cs_chol on forests of dense blocks: 1 = the reference's operations in the reference's order, L.x
+                                  // bit-identical (default); 0 = fused multiply-adds and refined reciprocal square roots in the block
+                                  // kernel: L.x equal to rounding, 1.5x the rate (opt-in; BASELINE grants x[] 1e-10)
     int chol_clique = 1;          // cs_schol / cs_chol / cholsol plan: forests of cliques on consecutive columns recognised from
                                   // A (or L) itself and handled without the general pattern machine (csx_cholclique.hip)
     int cholsol_dense_blocks = 1; // cholsol: dense-block kernels (false: the fused per-tree kernel)

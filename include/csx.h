@@ -96,7 +96,9 @@ int csx_mem_info(int64_t *cached_bytes, int64_t *live_bytes, int64_t *device_fre
  * -- block-diagonal matrices with dense blocks -- from the matrix itself and skip the general pattern machine; 0 = the
  * general path), "chol.forest" (default 1: where that rule fails, csx_schol / csx_chol look for blocks of <= 64 consecutive
  * columns closed under their upper entries -- forests of small sparse trees -- and analyse / factor a block in one wave;
- * 0 = the general path for them).  Unknown name: CSX_EINVAL. */
+ * 0 = the general path for them).  Round 5: "chol.exact" (default 1: cs_chol's block kernel keeps the reference's operations and
+ * their order, L.x bit-identical; 0, opt-in: fused multiply-adds and refined reciprocal square roots in that kernel -- forests of
+ * dense blocks only -- L.x equal to rounding, about 1.5x the rate).  Unknown name: CSX_EINVAL. */
 int csx_set_option(const char *name, int value);
 int csx_get_option(const char *name, int *value);   /* the value in force (after csx_set_option's normalisation) */
 int csx_timer_start(void);                /* hipEvent on the context's stream */

@@ -240,3 +240,51 @@ def test_python_surface_goes_through_the_one_call(cs):
     dBe = cs.dvec(B)
     assert Fe.solve(dBe) is True
     assert dBe.numpy()[:, 0].tobytes() == ref.tobytes()
+
+
+@pytest.mark.parametrize("bs, density", [(64, 1.0), (32, 1.0), (16, 1.0), (64, 0.5), (8, 1.0)])
+def test_rounding_equal_block_kernel(cs, bs, density):
+    """"chol.exact" = 0 (opt-in): the block kernel with fused multiply-adds and refined reciprocal square roots.  L.p / L.i as
+    always, L.x within 1e-13 (normwise) and 1e-12 (componentwise, entries above 1e-6 of the largest) of the default kernel's --
+    which is bit-identical to the oracle -- through csx_chol and through csx_cholsol_factor; the solutions of the plan it made
+    within 1e-10 of cs_lsolve + cs_ltsolve on the exact factor; a non-positive pivot still reported."""
+    import _csx
+    lib = _csx.lib()
+    n, Ap, Ai, Ax = _blocks([bs] * 57, 31, density)
+    A = cs.cs_pin(_host_cs(cs, n, n, Ap, Ai, Ax))
+    parent, cp = CO.schol(n, Ap, Ai)
+    Lp, Li, Lx = CO.chol(n, Ap, Ai, Ax, parent, cp)
+    S = cs.cs_schol(0, A)
+    with _csx.option("chol.exact", 0):
+        N = cs.cs_chol(A, S)
+        st, hL, plan, path = _fused(A, False)
+        assert st == _csx.OK
+    gp, gi, gx = _arr(N.L)
+    fp, fi, fx = _download(hL)
+    for p_, i_, x_ in ((gp, gi, gx), (fp, fi, fx)):
+        assert p_.tolist() == Lp.tolist() and i_.tolist() == Li.tolist()
+        assert x_.tobytes() != Lx.tobytes()                              # it really is other arithmetic
+        assert TOL.normwise(x_, Lx) <= 1e-13
+        big = np.abs(Lx) > 1e-6 * np.abs(Lx).max()
+        assert TOL.componentwise(x_[big], Lx[big]) <= 1e-12
+    assert gx.tobytes() == fx.tobytes()                                  # one kernel behind both entries
+    k = 70
+    B = synth.rhs(n, k, 3)
+    X = _solve(plan, B)
+    for r in (0, 31, k - 1):
+        y = CO.lsolve(n, Lp, Li, Lx, B[:, r])
+        ref = CO.ltsolve(n, Lp, Li, Lx, y)
+        assert TOL.componentwise(X[:, r], ref, TOL.cholsolve_terms(n, Lp, Li, Lx, y, ref)) <= TOL.X_RTOL
+    # the default is untouched by the option having been used
+    N1 = cs.cs_chol(A, S)
+    assert _arr(N1.L)[2].tobytes() == Lx.tobytes()
+    # not positive definite
+    c = 5 * bs + bs // 2
+    Ax2 = Ax.copy()
+    Ax2[Ap[c] + int(np.nonzero(Ai[Ap[c]:Ap[c + 1]] == c)[0][0])] = -2.0
+    A2 = cs.cs_pin(_host_cs(cs, n, n, Ap, Ai, Ax2))
+    with _csx.option("chol.exact", 0):
+        assert cs.cs_chol(A2, S) is None
+        assert _fused(A2, False)[0] == _csx.ENOTSPD
+    for h in (plan, hL):
+        _csx.free(h)

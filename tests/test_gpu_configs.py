@@ -89,7 +89,7 @@ def test_config3_lusol_on_W_full_size(cs):
     assert np.asarray(bl).tobytes() == ref_x.tobytes()
     # the batched form (factor once; permute, L, U, permute on the device): 70 right-hand sides, scaled copies of b, every column
     # against the plain-C oracle's solves on the same factors
-    F = cs.lusol_factor(A, 0, 1.0)
+    F = cs.lusol_factor(A, 0, 1.0, exact=True)
     scales = 1.0 + 0.5 * np.arange(70)
     dB = cs.dvec(np.ascontiguousarray(b[:, None] * scales[None, :]))
     assert F.solve(dB) is True
@@ -104,6 +104,15 @@ def test_config3_lusol_on_W_full_size(cs):
         want = CO.usolve(n, fUp.astype(np.int32), fUi.astype(np.int32), fUx,
                          CO.lsolve(n, fLp.astype(np.int32), fLi.astype(np.int32), fLx, pbr))
         assert Xb[:, r].tobytes() == want.tobytes(), r
+    # the default of lusol_factor solves a device block in the rounding-equal order (round 5: W's components dense on the matrix
+    # cores, tests/test_gpu_trimfma.py): the same columns within BASELINE's 1e-10
+    Fd = cs.lusol_factor(A, 0, 1.0)
+    dBd = cs.dvec(np.ascontiguousarray(b[:, None] * scales[None, :]))
+    assert Fd.solve(dBd) is True
+    Xd = dBd.numpy().reshape(n, 70)
+    assert all(v["matrix_cores"] for v in Fd.info().values())
+    for r in (0, 33, 69):
+        assert np.max(np.abs(Xd[:, r] - Xb[:, r]) / np.abs(Xb[:, r])) <= 1e-10, r
     res = CO.gaxpy(n, n, Ap, Ai, Ax, ref_x, -b)
     norm1 = float(np.max(np.add.reduceat(np.abs(Ax), Ap[:-1])))
     assert np.max(np.abs(res)) <= 1e-12 * (norm1 * np.max(np.abs(ref_x)) + np.max(np.abs(b)))
