@@ -762,6 +762,170 @@ __global__ __launch_bounds__(64 * CQ_WAVES, 3) void k_chol_clique(const int32_t 
     }
 }
 
+// ---- values, rounding-equal, on the matrix cores ("chol.exact" = 0; equal dense blocks of 16 / 32 / 48 / 64 columns) --------------
+// A blocked right-looking Cholesky of one block per wave on 16 x 16 tiles, written for the UPPER factor U = L' so that every tile
+// lives in the accumulator layout of v_mfma_f64_16x16x4_f64 (lane (c = l & 15, rq = l >> 4), register r <-> element (rq + 4 r, c))
+// from the load to the store and never changes it: for 16 x 16 matrices P, Q the product P Q is four matrix instructions whose
+// A operand is the accumulator form of P' and whose B operand is the accumulator form of Q, register by register.  Step k:
+//   diagonal tile  T_kk = U_kk' U_kk and V_kk = inv(U_kk): forward elimination of [T_kk | I] by rows, lane = COLUMN (16 lanes the
+//                  tile's, 16 the identity's), registers = rows: row j is scaled by a refined reciprocal square root of its pivot,
+//                  written to LDS -- it is a finished row of [U_kk | inv(U_kk')] -- and every later row takes its multiple off, the
+//                  multiplier read back from that LDS row (the tile is symmetric: the multiplier of row i is the row's own entry i);
+//   panel          U_ki = inv(U_kk') T_ki   (i > k):  A operand V_kk, B operand T_ki;
+//   trailing part  T_ij -= U_ki' U_kj   (k < i <= j): A operand -U_ki, B operand U_kj.
+// What the kernel writes: L.x (column j of L is row j of U: for one register four columns of L, 16 consecutive rows each); with
+// EMIT the matrix-core solve's fragments, which ARE the negated panel tiles and the V tiles register by register, lane by lane --
+// 512 contiguous bytes per store; without EMIT the row indices.  64 matrix instructions and about 2 400 vector instructions per
+// 64-column block where the bit-identical kernel issues about 11 000 (csparse.py:598-617 is the arithmetic being regrouped).
+constexpr int CM_WAVES = 4;
+constexpr int CM_RS = 34;           // doubles per LDS row of [U | inv(U')] (32 used)
+constexpr int CM_TS = 17;           // doubles per LDS row of the transposed diagonal tile
+
+template <int NB, bool EMIT>
+__global__ __launch_bounds__(64 * CM_WAVES, 2) void k_chol_block_mfma(const int32_t *__restrict__ start, int32_t nblocks,
+                                                                     const int32_t *__restrict__ Ap, const double *__restrict__ Ax,
+                                                                     const int32_t *__restrict__ Lp, int32_t *__restrict__ Li,
+                                                                     double *__restrict__ Lx, int *notspd, CliqueEmit em) {
+    typedef double f4 __attribute__((ext_vector_type(4)));
+    constexpr int BS = 16 * NB;
+    __shared__ __attribute__((aligned(16))) double s_rows[CM_WAVES][16 * CM_RS];
+    __shared__ double s_tile[CM_WAVES][16 * CM_TS];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t t = (int64_t)blockIdx.x * CM_WAVES + w;
+    if (t >= nblocks) return;      // no workgroup barrier below
+    const int32_t c0 = __builtin_amdgcn_readfirstlane(start[t]);
+    const int c = lane & 15, rq = lane >> 4;
+    double *rows = s_rows[w], *tt = s_tile[w];
+    // ---- load: tile (k, i), k <= i: element (16 k + rq + 4 r, 16 i + c) of the upper triangle = entry (that row) of column 16 i + c
+    // (every upper part is rows c0 .. column, one each, stored in front: k_clique_min's "dense in front") ----
+    f4 T[NB][NB];
+    {
+        const int64_t a0 = Ap[c0];
+        const __amdgpu_buffer_rsrc_t rx = cq_rsrc(Ax + a0, (int)((int64_t)Ap[c0 + BS] - a0) * 8);
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+            const uint32_t colo = (uint32_t)(Ap[c0 + 16 * i + c] - a0);
+#pragma unroll
+            for (int k = 0; k <= i; k++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int row = 16 * k + rq + 4 * r;
+                    // (below the diagonal of a diagonal tile: past the upper part of the column -- not read, zero)
+                    const bool up = k < i || rq + 4 * r <= c;
+                    T[k][i][r] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rx, up ? (colo + row) * 8u : 0xfffffff8u, 0, 0));
+                }
+        }
+    }
+    const int64_t lbase = Lp[c0];
+    const __amdgpu_buffer_rsrc_t rl = cq_rsrc(Lx + lbase, (BS * (BS + 1) / 2) * 8);
+    const __amdgpu_buffer_rsrc_t ri = cq_rsrc(Li + (EMIT ? 0 : lbase), EMIT ? 0 : (BS * (BS + 1) / 2) * 4);
+    double *frag = nullptr;
+    if (EMIT) {
+        frag = em.frag + (size_t)t * (size_t)(clique_frags_per_block(NB) * 64) + lane;
+        if (lane < BS) em.tree_nodes[c0 + lane] = c0 + lane;
+        if (lane == 0) em.trees[t] = Tree{c0, BS};
+    }
+    double lmax = 0.0, wmax = 0.0;
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+        // ---- the diagonal tile: to lane = column, registers = rows (its upper part is what T holds: the rest by symmetry) ----
+        __builtin_amdgcn_sched_barrier(0);      // (the phases of a step are kept apart: interleaved across steps by the scheduler, the
+                                                // tile factor's sixteen rows sat on top of every other live tile and the kernel spilled)
+#pragma unroll
+        for (int r = 0; r < 4; r++) tt[(rq + 4 * r) * CM_TS + c] = T[k][k][r];
+        cq_wave_sync_lds();
+        double a[16];
+        if (lane < 16) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) a[i] = tt[min(i, c) * CM_TS + max(i, c)];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; i++) a[i] = (lane - 16) == i ? 1.0 : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const double d = cq_bcast(a[j], j);
+            if (d <= 0.0 && lane == 0) atomicMin(notspd, c0 + 16 * k + j);   // csparse.py:612
+            const double y = cq_rsqrt(d);
+            double tv = a[j] * y;                                    // row j of [U | inv(U')], finished
+            if (lane < j) tv = 0.0;                                  // (left of the diagonal: eliminated)
+            if (lane < 32) rows[j * CM_RS + lane] = tv;
+            cq_wave_sync_lds();
+#pragma unroll
+            for (int i = j + 1; i < 16; i++) a[i] = __builtin_fma(-rows[j * CM_RS + i], tv, a[i]);
+        }
+        // back to the accumulator layout: U_kk (zero below its diagonal) and V = inv(U_kk) = the transpose of the right half
+        __builtin_amdgcn_sched_barrier(0);
+        f4 U, V;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = rq + 4 * r;
+            U[r] = row <= c ? rows[row * CM_RS + c] : 0.0;
+            V[r] = rows[c * CM_RS + 16 + row];
+            lmax = fmax(lmax, fabs(U[r]));
+            wmax = fmax(wmax, fabs(V[r]));
+        }
+        cq_wave_sync_lds();      // (the next tile's rows go to the same place)
+        T[k][k] = U;
+        if (EMIT) {
+#pragma unroll
+            for (int sx = 0; sx < 4; sx++) frag[(size_t)(((k * (k + 1) / 2 + k) * 4 + sx) * 64)] = V[sx];
+        }
+        // ---- panel: U_ki = inv(U_kk') T_ki; its negative is the A operand of the updates and, with EMIT, the solve's fragment ----
+        f4 NU[NB];
+#pragma unroll
+        for (int i = k + 1; i < NB; i++) {
+            f4 D = f4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int sx = 0; sx < 4; sx++) D = __builtin_amdgcn_mfma_f64_16x16x4f64(V[sx], T[k][i][sx], D, 0, 0, 0);
+            T[k][i] = D;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                NU[i][r] = -D[r];
+                lmax = fmax(lmax, fabs(D[r]));
+            }
+            if (EMIT) {
+#pragma unroll
+                for (int sx = 0; sx < 4; sx++) frag[(size_t)(((i * (i + 1) / 2 + k) * 4 + sx) * 64)] = NU[i][sx];
+            }
+        }
+        // ---- trailing part ----
+#pragma unroll
+        for (int i = k + 1; i < NB; i++)
+#pragma unroll
+            for (int j = i; j < NB; j++)
+#pragma unroll
+                for (int sx = 0; sx < 4; sx++) T[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(NU[i][sx], T[k][j][sx], T[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- store row block k of U = column block k of L: register r of tile (k, i) is L(16 i + c, J), J = 16 k + rq + 4 r ----
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int J = 16 * k + rq + 4 * r;
+            const int colbase = J * BS - J * (J - 1) / 2 - J;          // entry (I, J) of the packed block: colbase + I
+#pragma unroll
+            for (int i = k; i < NB; i++) {
+                const int I = 16 * i + c;
+                const bool in = I >= J;
+                const double xv = T[k][i][r];
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(cq_u32x2, xv), rl, in ? (uint32_t)(colbase + I) * 8u : 0xfffffff8u, 0, 0);
+                if (!EMIT) __builtin_amdgcn_raw_buffer_store_b32((unsigned int)(c0 + I), ri, in ? (uint32_t)(colbase + I) * 4u : 0xfffffffcu, 0, 0);
+            }
+        }
+    }
+    if (EMIT) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            lmax = fmax(lmax, __shfl_xor(lmax, d, 64));
+            wmax = fmax(wmax, __shfl_xor(wmax, d, 64));
+        }
+        if (lane == 0) {
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(lmax * wmax);
+            if (!(bits <= *(volatile unsigned long long *)em.cond_bits)) atomicMax(em.cond_bits, bits);
+        }
+    }
+}
+
 int chol_clique_numeric(const Csc *A, const CliqueForest &F, Csc *L, int *d_notspd, const CliqueEmit *emit, bool relaxed) {
     hipStream_t s = ctx().stream;
     if (F.nblocks == 0 || A->nnz == 0) return CSX_OK;
@@ -791,6 +955,26 @@ int chol_clique_numeric(const Csc *A, const CliqueForest &F, Csc *L, int *d_nots
         CSX_CQ_GO(PARTS, true, false, false, false);                                                                            \
     else                                                                                                                        \
         CSX_CQ_GO(PARTS, false, false, false, false)
+    if (relaxed && !F.sparse && F.dense_in_front && F.min_bs == F.max_bs && F.max_bs % 16 == 0 && ctx().opt.chol_exact == 0) {
+        // equal dense blocks of 16 / 32 / 48 / 64 columns: the blocked factorisation on the matrix cores
+        const dim3 g2((unsigned)((F.nblocks + CM_WAVES - 1) / CM_WAVES));
+#define CSX_CM(NB)                                                                                                                        \
+    if (emit)                                                                                                                             \
+        hipLaunchKernelGGL((k_chol_block_mfma<NB, true>), g2, dim3(64 * CM_WAVES), 0, s, F.start, F.nblocks, A->p, A->x, L->p, L->i, L->x, \
+                           d_notspd, em);                                                                                                 \
+    else                                                                                                                                  \
+        hipLaunchKernelGGL((k_chol_block_mfma<NB, false>), g2, dim3(64 * CM_WAVES), 0, s, F.start, F.nblocks, A->p, A->x, L->p, L->i, L->x, \
+                           d_notspd, em)
+        switch (F.max_bs / 16) {
+            case 1: CSX_CM(1); break;
+            case 2: CSX_CM(2); break;
+            case 3: CSX_CM(3); break;
+            default: CSX_CM(4); break;
+        }
+#undef CSX_CM
+        CSX_LAUNCH_CHECK();
+        return CSX_OK;
+    }
     if (relaxed && A->nnz < (1 << 29)) {      // "chol.exact" = 0: the rounding-equal arithmetic (the common shapes; others stay exact)
         if (emit && F.dense_in_front) {
             hipLaunchKernelGGL((k_chol_clique<7, true, true, false, true, true>), grid, dim3(64 * CQ_WAVES), 0, s, F.start, F.nblocks, A->n,

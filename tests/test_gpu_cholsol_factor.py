@@ -288,3 +288,59 @@ def test_rounding_equal_block_kernel(cs, bs, density):
         assert _fused(A2, False)[0] == _csx.ENOTSPD
     for h in (plan, hL):
         _csx.free(h)
+
+
+def test_matrix_core_block_kernel_at_1m_rows(cs):
+    """"chol.exact" = 0 on G-spd's shape at a fifth of its size (15 625 dense blocks of 64 columns): csx_cholsol_factor's L.x within
+    1e-13 normwise of the default (bit-identical) kernel's, the fragments it wrote give the solutions of the default's plan to
+    1e-12, A x = b holds, and two runs are bit-identical (stores through buffer resources, a kernel of 64 matrix instructions per
+    block: checked at a size where every CU holds several blocks at once)."""
+    import _csx
+    lib = _csx.lib()
+    nb, bs, k = 15625, 64, 64
+    n = nb * bs
+    hA = _csx.new_handle()
+    _csx.check(lib.csx_gen_gspd(nb, bs, 20240606, hA))
+    hL0, plan0 = _csx.new_handle(), _csx.new_handle()
+    _csx.check(lib.csx_cholsol_factor(hA, 0, hL0, plan0))
+    outs = []
+    with _csx.option("chol.exact", 0):
+        for rep in range(2):
+            hL, plan = _csx.new_handle(), _csx.new_handle()
+            _csx.check(lib.csx_cholsol_factor(hA, 0, hL, plan))
+            outs.append((hL, plan))
+    import csparse
+    def lx(h):
+        m_, n_, z, hv = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int()
+        _csx.check(lib.csx_csc_info(h, m_, n_, z, hv))
+        x = np.empty(z.value)
+        _csx.check(lib.csx_csc_download(h, None, None, _csx.pd(x)))
+        return x
+    x0, x1, x2 = lx(hL0), lx(outs[0][0]), lx(outs[1][0])
+    assert x1.tobytes() == x2.tobytes() and x1.tobytes() != x0.tobytes()
+    assert TOL.normwise(x1, x0) <= 1e-13
+    sols = []
+    for pl in (plan0, outs[0][1], outs[1][1]):
+        hB = _csx.new_handle()
+        _csx.check(lib.csx_gen_rhs(n, k, 0, hB))
+        _csx.check(lib.csx_cholsol_solve(pl, hB, k))
+        a = np.empty(n * k)
+        _csx.check(lib.csx_vec_download(hB, _csx.pd(a), n * k))
+        sols.append(a)
+        _csx.free(hB)
+    assert sols[1].tobytes() == sols[2].tobytes()
+    assert float(np.max(np.abs(sols[1] - sols[0]) / np.abs(sols[0]))) <= 1e-12
+    g = C.c_double(0.0), C.c_double(0.0)
+    _csx.check(lib.csx_cholsol_growth(plan0, g[0]))
+    _csx.check(lib.csx_cholsol_growth(outs[0][1], g[1]))
+    assert abs(g[1].value - g[0].value) <= 1e-10 * g[0].value
+    # A x = b on three columns (synth.gspd is the host twin of csx_gen_gspd)
+    Ap, Ai, Ax = synth.gspd(nb, bs, 20240606)
+    import scipy.sparse as sp
+    A = sp.csc_matrix((Ax, Ai, Ap), shape=(n, n))
+    X = sols[1].reshape(n, k)
+    for r in (0, 31, k - 1):
+        b = 1.0 + (np.arange(n) + r) / float(n)
+        assert float(np.max(np.abs(A @ X[:, r] - b))) <= 1e-12 * 128.0
+    for h in (plan0, hL0, outs[0][1], outs[0][0], outs[1][1], outs[1][0], hA):
+        _csx.free(h)
