@@ -294,6 +294,24 @@ def config3():
         ms_c = timed(run_c, 5)
         chain["nrhs_%d" % k] = {"ms_lsolve_plus_usolve": round(ms_c, 3),
                                 "bit_identical_to_c_oracle": bool(all(gotc[:, r].tobytes() == ref_c.tobytes() for r in (0, k - 1)))}
+    # one HOST right-hand side (the list call of the drop-in module) with "tri.host_chains" = 1 (opt-in): the reference's loop on
+    # the host inside libcsx for such a chain, same bits; beside it the same list call on the device (the default)
+    def list_pair():
+        xl = pbc.copy()
+        cs.cs_lsolve(Lc, xl)
+        cs.cs_usolve(Uc, xl)
+        return xl
+    for name, val in (("device_default", 0), ("host_chains_option", 1)):
+        cs.cs_option("tri.host_chains", val)
+        try:
+            got_l = list_pair()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                list_pair()
+            chain["list_call_ms_" + name] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
+            chain["list_call_bit_identical_" + name] = bool(got_l.tobytes() == ref_c.tobytes())
+        finally:
+            cs.cs_option("tri.host_chains", 0)
     lv = {}
     for nm, M, kind in (("L", Lc, cs.TRI_L), ("U", Uc, cs.TRI_U)):
         n_, lev, seq = _csx.C.c_int32(), _csx.C.c_int32(), _csx.C.c_int32()
@@ -539,6 +557,25 @@ def cholsol_connected(grid=300):
                     _csx.check(_csx.lib().csx_cholsol_graph_info(F.plan_handle, cap, cap_ms))
                     if cap.value:
                         r["graph_capture_ms_%s_k%d" % ("exact" if exact else "rounding_equal", k)] = round(cap_ms.value, 3)
+            if order == 0:
+                # the list call with "tri.host_chains" = 1 (opt-in): the whole solve sequence on the host for a chain, same bits
+                Fl = cs.cholsol_factor(A, 0, exact=True)
+                for name, val in (("device_default", 0), ("host_chains_option", 1)):
+                    cs.cs_option("tri.host_chains", val)
+                    try:
+                        xl = b.copy()
+                        Fl.solve(xl)
+                        t0 = time.perf_counter()
+                        for _ in range(3):
+                            xl = b.copy()
+                            Fl.solve(xl)
+                        r["list_solve_ms_" + name] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
+                        if val == 0:
+                            x_dev = xl.copy()
+                        else:
+                            r["list_solve_host_equals_device_bits"] = bool(xl.tobytes() == x_dev.tobytes())
+                    finally:
+                        cs.cs_option("tri.host_chains", 0)
             res["order_%d" % order] = r
         if cpu and not SKIP_CPU:
             t0 = time.perf_counter()

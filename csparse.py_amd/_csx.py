@@ -72,6 +72,8 @@ _PROTOS = {
     "csx_tri_info": [H, _i32p, _i32p, _i32p],
     "csx_tri_solve": [H, H, C.c_int32],
     "csx_tri_set_order": [H, C.c_int],
+    "csx_tri_solve_list": [H, _f64p, C.POINTER(C.c_int)],
+    "csx_cholsol_solve_list": [H, _f64p, C.POINTER(C.c_int)],
     "csx_tri_order_info": [H, _i32p, _f64p],
     "csx_tri_components": [H, _i32p],
     "csx_permute_vec": [H, H, H, C.c_int32, C.c_int32, C.c_int],

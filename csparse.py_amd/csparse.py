@@ -729,6 +729,16 @@ def _trisolve(T, x, kind):
         raise TypeError("'NoneType' object is not subscriptable")
     if T.m != T.n:
         raise IndexError("list index out of range")
+    if _HOST_CHAINS[0] and not isinstance(x, dvec):
+        # "tri.host_chains" (opt-in, cs_option): one host right-hand side on a chain-like factor -- the reference's loop on the
+        # host inside libcsx, same bits (csx_tri_solve_list); anything else falls through to the device
+        buf = _csx.f64(x[:T.n])
+        taken = _csx.C.c_int(0)
+        with _Resident(T) as dT:
+            _csx.check(_csx.lib().csx_tri_solve_list(_plan(dT, kind), _csx.pd(buf), taken), "csx_tri_solve_list")
+        if taken.value:
+            x[:T.n] = buf.tolist() if isinstance(x, list) else buf
+            return True
     dx, xhost = _vec_in(x, T.n, "x")
     nrhs = dx.k
     with _Resident(T) as dT:
@@ -736,6 +746,29 @@ def _trisolve(T, x, kind):
         _csx.check(_csx.lib().csx_tri_solve(plan, dx.handle, nrhs), "csx_tri_solve")
     _write_back(xhost, dx, T.n * nrhs)
     return True
+
+
+_HOST_CHAINS = [False]
+
+
+def cs_option(name, value):
+    """csx_set_option from the drop-in module (DESIGN.md lists the names).  "tri.host_chains" = 1 additionally lets the list-level
+    cs_lsolve / cs_ltsolve / cs_usolve / cs_utsolve / cs_cholsol / cholsol_factor(...).solve(list) try the host loop first."""
+    _csx.check(_csx.lib().csx_set_option(name.encode(), int(value)), "csx_set_option")
+    if name == "tri.host_chains":
+        _HOST_CHAINS[0] = bool(value)
+
+
+def _cholsol_list_on_host(plan, b, n):
+    """cs_cholsol's solve sequence for a LIST b by csx_cholsol_solve_list ("tri.host_chains"); True when it was taken"""
+    if not _HOST_CHAINS[0] or isinstance(b, dvec):
+        return False
+    buf = _csx.f64(b[:n])
+    taken = _csx.C.c_int(0)
+    _csx.check(_csx.lib().csx_cholsol_solve_list(plan, _csx.pd(buf), taken), "csx_cholsol_solve_list")
+    if taken.value:
+        b[:n] = buf.tolist() if isinstance(b, list) else buf
+    return bool(taken.value)
 
 
 def cs_lsolve(L, x):
@@ -1049,8 +1082,10 @@ def cs_cholsol(order, A, b):
         if fused is None:
             return False
         L, plan = fused
-        db, bhost = _vec_in(b, n, "b")
         try:
+            if _cholsol_list_on_host(plan, b, n):
+                return True
+            db, bhost = _vec_in(b, n, "b")
             _csx.check(_csx.lib().csx_cholsol_solve(plan, db.handle, db.k), "csx_cholsol_solve")
         finally:
             _csx.free(plan)
@@ -1060,15 +1095,17 @@ def cs_cholsol(order, A, b):
     N = cs_chol(A, S) if S is not None else None
     if S is None or N is None:
         return False
-    db, bhost = _vec_in(b, n, "b")
     pinv = None if S.pinv is None else _csx.i32(S.pinv)
     plan = _csx.new_handle()
     with _Resident(N.L) as dL:
         _csx.check(_csx.lib().csx_cholsol_plan(dL.handle, _csx.pi(pinv), plan), "csx_cholsol_plan")
-    try:
-        _csx.check(_csx.lib().csx_cholsol_solve(plan, db.handle, db.k), "csx_cholsol_solve")
-    finally:
-        _csx.free(plan)
+        try:
+            if _cholsol_list_on_host(plan, b, n):
+                return True
+            db, bhost = _vec_in(b, n, "b")
+            _csx.check(_csx.lib().csx_cholsol_solve(plan, db.handle, db.k), "csx_cholsol_solve")
+        finally:
+            _csx.free(plan)
     _write_back(bhost, db, n * db.k)
     return True
 
@@ -1213,6 +1250,8 @@ def cholsol_factor(A, order=0, exact=None):
             the root's block is overwritten.  Every column has the bits of the unsharded solve."""
             if comm is not None and comm.world > 1:
                 return self._solve_sharded(b, comm, nrhs)
+            if not isinstance(b, dvec) and (exact is None or exact) and _cholsol_list_on_host(self._plan_for(False), b, n):
+                return True
             db, bhost = _vec_in(b, n, "b")
             _csx.check(_csx.lib().csx_cholsol_solve(self._plan_for(isinstance(b, dvec)), db.handle, db.k), "csx_cholsol_solve")
             _write_back(bhost, db, n * db.k)

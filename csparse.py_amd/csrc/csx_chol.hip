@@ -53,6 +53,7 @@ int chol_symbolic_device(const Csc *A, const int32_t *parent, const int32_t *cp,
 // csx_trisolve.hip
 struct TriPlan;
 int tri_solve_raw(TriPlan *P, double *X, int32_t nrhs, bool relaxed);
+int tri_solve_host_raw(TriPlan *P, double *x, bool *taken);
 int tri_analyse_raw(const Csc *T, int kind, TriPlan **out);
 void tri_set_mate(TriPlan *P, TriPlan *mate);
 void tri_set_level_hint(TriPlan *P, std::vector<int32_t> &&level);
@@ -2877,6 +2878,39 @@ extern "C" int csx_cholsol_sn_info(csx_handle_t h, int32_t *supernodes, int32_t 
     if (max_width) *max_width = c;
     if (matrix_cores) *matrix_cores = mc;
     if (growth) *growth = g;
+    return CSX_OK;
+}
+
+// "tri.host_chains" (opt-in): the solve phase of cs_cholsol (csparse.py:640-643) for ONE host right-hand side when L is a chain:
+// x = P b, L \ x, L' \ x, b = P' x with the reference's loops on the host (csx_tri_solve_list's rule, applied to both sweeps)
+extern "C" int csx_cholsol_solve_list(csx_handle_t h, double *b, int *taken) {
+    CSX_TRY(require_ready());
+    CholPlan *P = (CholPlan *)get(h, K_CHOLPLAN);
+    if (!P || !b || !taken) return CSX_EINVAL;
+    *taken = 0;
+    if (!ctx().opt.tri_host_chains || P->local || P->lite || !P->fwd || !P->bwd || P->n == 0) return CSX_OK;
+    const int32_t n = P->n;
+    std::vector<double> x((size_t)n);
+    std::vector<int32_t> perm;
+    if (P->perm) {
+        perm.resize((size_t)n);
+        CSX_HIP(hipMemcpyAsync(perm.data(), P->perm, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx().stream));
+        CSX_HIP(hipStreamSynchronize(ctx().stream));
+        for (int32_t j = 0; j < n; j++) x[(size_t)j] = b[perm[(size_t)j]];      // x = P b  (cs_ipvec, csparse.py:640)
+    } else {
+        std::memcpy(x.data(), b, (size_t)n * sizeof(double));
+    }
+    bool t1 = false, t2 = false;
+    CSX_TRY(tri_solve_host_raw(P->fwd, x.data(), &t1));
+    if (!t1) return CSX_OK;                       // no chain: nothing was changed, the caller goes to the device
+    CSX_TRY(tri_solve_host_raw(P->bwd, x.data(), &t2));
+    if (!t2) return CSX_ERUNTIME;                 // (both sweeps share one level structure: cannot happen)
+    if (P->perm) {
+        for (int32_t j = 0; j < n; j++) b[perm[(size_t)j]] = x[(size_t)j];      // b = P' x  (cs_pvec, csparse.py:643)
+    } else {
+        std::memcpy(b, x.data(), (size_t)n * sizeof(double));
+    }
+    *taken = 1;
     return CSX_OK;
 }
 

@@ -591,6 +591,7 @@ const OptSlot kOptSlots[] = {
     {"lu.etree", &Options::lu_etree, 5},                 {"tri.graph", &Options::tri_graph, 6},
     {"sort.short_keys", &Options::sort_short_keys, 0},   {"chol.clique", &Options::chol_clique, 0},
     {"chol.forest", &Options::chol_forest, 0},           {"chol.exact", &Options::chol_exact, 0},
+    {"tri.host_chains", &Options::tri_host_chains, 0},
                     {"cholsol.exact_variant", &Options::cholsol_exact_variant, 4},
 };
 int normalise(int kind, int value) {

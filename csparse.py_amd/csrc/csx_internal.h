@@ -151,6 +151,8 @@ struct Options {
     int tri_row_waves = 1;        // level-scheduled solves: a wave per row for few right-hand sides and long rows
     int tri_levels_where = 0;         // level analysis: 0 = device for big factors, host for small; 1 = host; 2 = device
     int sort_short_keys = 1;          // cs_transpose: 16-bit keys between the radix passes where the matrix allows (0: always 32-bit)
+    int tri_host_chains = 0;          // ONE host right-hand side on a chain-like factor (levels > n / 4, < 5e7 entries): 1 = the reference's
+                                      // loop on the host (same bits), a case the device loses 10 - 40x; 0 (default) = the device, always
     int tri_graph = 2;                // supernodal solves: replay the launches of a solve as a hipGraph while the block of right-hand
                                       // sides stays in place: 0 never, 1 always, 2 when a solve is more than 256 launches and the
                                       // block has been the block of the two solves before it too (the third consecutive solve captures)

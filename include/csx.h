@@ -98,7 +98,9 @@ int csx_mem_info(int64_t *cached_bytes, int64_t *live_bytes, int64_t *device_fre
  * columns closed under their upper entries -- forests of small sparse trees -- and analyse / factor a block in one wave;
  * 0 = the general path for them).  Round 5: "chol.exact" (default 1: cs_chol's block kernel keeps the reference's operations and
  * their order, L.x bit-identical; 0, opt-in: fused multiply-adds and refined reciprocal square roots in that kernel -- forests of
- * dense blocks only -- L.x equal to rounding, about 1.5x the rate).  Unknown name: CSX_EINVAL. */
+ * dense blocks only -- L.x equal to rounding; equal blocks of 16 / 32 / 48 / 64 columns are then factored on the matrix cores, 1.8x
+ * the rate), "tri.host_chains" (default 0; 1: csx_tri_solve_list / csx_cholsol_solve_list take one host right-hand side on a
+ * chain-like factor to the host).  Unknown name: CSX_EINVAL. */
 int csx_set_option(const char *name, int value);
 int csx_get_option(const char *name, int *value);   /* the value in force (after csx_set_option's normalisation) */
 int csx_timer_start(void);                /* hipEvent on the context's stream */
@@ -185,6 +187,13 @@ int csx_tri_solve(csx_handle_t plan, csx_handle_t X, int32_t nrhs);
  * tiles, built at the first such solve) -- unless || |inv(T_ii)| |T_ii| ||_inf of a diagonal tile exceeds 1e3, then the exact
  * kernels stay.  Every other plan shape solves exactly in either order.  csx_tri_order_info: whether the matrix-core form is in
  * use (after the first solve in that order) and the guard's measure; either pointer may be NULL. */
+/* "tri.host_chains" = 1 (csx_set_option; opt-in, default 0): ONE right-hand side in host memory on a factor whose dependency graph
+ * is a chain (more than n / 4 levels, fewer than 5e7 entries) is solved by the reference's own loop on the host, on a copy of the
+ * factor the plan downloads once -- the same operations in the same order, the same bits, 10 - 40x sooner than one dependent
+ * subtraction per term on the device.  *taken = 0: the option is off or the factor is no chain: x untouched, call csx_tri_solve.
+ * csx_cholsol_solve_list: the same for cs_cholsol's whole solve sequence (csparse.py:640-643) on b[n]. */
+int csx_tri_solve_list(csx_handle_t plan, double *x, int *taken);
+int csx_cholsol_solve_list(csx_handle_t plan, double *b, int *taken);
 int csx_tri_set_order(csx_handle_t plan, int exact);
 int csx_tri_order_info(csx_handle_t plan, int32_t *matrix_cores, double *growth);
 /* After the first solve: the number of connected components of the dependency graph when the plan solves
