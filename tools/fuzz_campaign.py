@@ -91,6 +91,9 @@ while time.time() < t_end:
     if seed % 7 == 1:  # forests of cliques (csx_cholclique.hip): block-diagonal, random block sizes and densities, entries of
         sizes = rng.integers(1, int(rng.choice([9, 33, 65, 90])), size=int(rng.choice([1, 40, 600]))).tolist()   # the lower part shuffled,
         dens = float(rng.choice([1.0, 0.5, 0.15]))                 # now and then a duplicate or a block of more than 64 columns (the
+        if rng.random() < 0.3:                                     # round 5: EQUAL blocks of 8 .. 64 columns now and then (the fused
+            sizes = [int(rng.choice([8, 16, 32, 48, 64]))] * int(rng.choice([1, 40, 600]))   # factor -> plan path, the matrix-core kernels)
+            dens = float(rng.choice([1.0, 1.0, 0.5]))
         n = int(sum(sizes))                                        # general path must take over): schol, chol bit for bit, cholsol
         cols_i, cols_x, a = [], [], 0
         for bsz in sizes:
@@ -141,6 +144,31 @@ while time.time() < t_end:
         for r in sorted({0, k - 1}):
             z = CO.ltsolve(n, gLp, gLi, gLx, CO.lsolve(n, gLp, gLi, gLx, B[:, r]))
             assert Xn[:, r].tobytes() == z.tobytes(), ("clique cholsol", seed, n, k, r)
+        # round 5: the one-call factor (csx_cholsol_factor) in the order blocks are solved in -- matrix cores where the forest allows
+        # (equal blocks: operands written by the block kernel; unequal blocks / small trees: dense by size class) -- and the same with
+        # "chol.exact" = 0 (fused multiply-adds / the blocked factorisation on the matrix cores): x[] within 1e-10, L.x within 1e-13
+        kk = max(k, int(rng.choice([9, 70])))
+        B2 = rng.uniform(-1, 1, size=(n, kk))
+        Z = np.stack([CO.ltsolve(n, gLp, gLi, gLx, CO.lsolve(n, gLp, gLi, gLx, B2[:, r])) for r in sorted({0, kk - 1})], axis=1)
+        scale = np.maximum(np.abs(Z), 1e-3 * np.max(np.abs(Z)))
+        for opt in (1, 0):
+            with _csx.option("chol.exact", opt):
+                F2 = cs.cholsol_factor(A)
+                fpath = _csx.C.c_int32(-1)
+                _csx.check(_csx.lib().csx_cholsol_factor_info(fpath, None, None, None))
+                X2 = cs.dvec(B2)
+                assert F2.solve(X2) is True
+                X2n = X2.numpy().reshape(n, kk)[:, sorted({0, kk - 1})]
+                err = float(np.max(np.abs(X2n - Z) / scale))
+                assert err <= 1e-10, ("one-call cholsol", seed, n, kk, opt, fpath.value, err)
+                lx2 = np.asarray(F2.L.x[:lnz])
+                if opt == 1 and path.value == 1:
+                    assert lx2.tobytes() == Lx.tobytes(), ("one-call L.x", seed, n)
+                else:
+                    assert float(np.max(np.abs(lx2 - Lx))) <= 1e-13 * max(1.0, float(np.max(np.abs(Lx)))), ("one-call L.x rounding", seed, n, opt)
+                assert F2.L.p == Lp.tolist() and F2.L.i[:lnz] == Li.tolist(), ("one-call pattern", seed, n, opt)
+                key = "factor_path_%d_%s" % (fpath.value, "mc" if F2.info()["matrix_cores"] else "sub")
+                counts[key] = counts.get(key, 0) + 1
         counts["clique_cholesky"] = counts.get("clique_cholesky", 0) + 1
         continue
     if seed % 7 == 5:  # order 1 (nested dissection) on grids with random holes: supernodes as dense trapezoids, level hints from
@@ -262,6 +290,24 @@ while time.time() < t_end:
             Xk = dB.numpy().reshape(n, 3)
             for r in range(3):
                 assert Xk[:, r].tobytes() == ofn(n, Tp, Ti, Tx, B[:, r]).tobytes(), ("trisolve block", seed, fn.__name__, n, shape, r)
+            # round 5: the rounding-equal order of the same plan (csx_tri_set_order; matrix cores when the factor falls into
+            # many small components -- shape 2 with small blocks): 20 right-hand sides against the oracle, then exact again
+            B20 = rng.uniform(-1, 1, size=(n, 20))
+            plan = M._dev.plans[{cs.cs_lsolve: cs.TRI_L, cs.cs_ltsolve: cs.TRI_LT, cs.cs_usolve: cs.TRI_U, cs.cs_utsolve: cs.TRI_UT}[fn]]
+            _csx.check(_csx.lib().csx_tri_set_order(plan, 0))
+            try:
+                d20 = cs.dvec(B20)
+                _csx.check(_csx.lib().csx_tri_solve(plan, d20.handle, 20))
+                mc = _csx.C.c_int32(0)
+                _csx.check(_csx.lib().csx_tri_order_info(plan, mc, None))
+            finally:
+                _csx.check(_csx.lib().csx_tri_set_order(plan, 1))
+            X20 = d20.numpy().reshape(n, 20)
+            for r in (0, 19):
+                z = ofn(n, Tp, Ti, Tx, B20[:, r])
+                err = float(np.max(np.abs(X20[:, r] - z))) / max(float(np.max(np.abs(z))), 1e-300)
+                assert err <= 1e-11, ("trisolve rounding-equal", seed, fn.__name__, n, shape, mc.value, err)
+            counts["tri_rounding_equal_mc%d" % mc.value] = counts.get("tri_rounding_equal_mc%d" % mc.value, 0) + 1
         counts["trisolve"] += 1
         continue
     if kind == 4:      # cs_schol + cs_chol + cs_cholsol on random SPD matrices: banded, block-diagonal, scattered

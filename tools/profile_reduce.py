@@ -59,8 +59,14 @@ def main(out, tag):
                      "n_gpus": b["n_gpus"], "step_ms_hip_events_in_traced_run": b["roofline"]["step_ms_hip_events"]})
         if "cholsol" in b:
             meta["nrhs_per_gpu"] = b["cholsol"]["nrhs_per_gpu"]
-    except Exception as e:  # not a bench.py run: the figures stand on their own
-        meta["note"] = "no bench line: %s" % e
+    except Exception:  # not a bench.py run (a tools/time_*.py script, a bench_configs.py section): say what was run instead
+        try:
+            with open(os.path.join(out, "trace.stdout")) as f:
+                lines = [l for l in f.read().splitlines() if l.strip()]
+            meta["run"] = "not a bench.py headline run; last line of the traced command's output follows"
+            meta["last_output_line"] = lines[-1][:400] if lines else ""
+        except OSError:
+            meta["run"] = "output of the traced command not kept"
     with open(os.path.join(out, tag + "_traffic.json"), "w") as fjs:
         json.dump({"_meta": meta, "kernels": traffic}, fjs, indent=1, sort_keys=True)
 
