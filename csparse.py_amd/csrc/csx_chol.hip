@@ -2618,7 +2618,7 @@ namespace csx {
 static int g_factor_path = -1;
 static double g_factor_ms[3] = {0.0, 0.0, 0.0};   // analysis / numeric kernel (HIP events) / whole call (host clock)
 
-static int cholsol_factor_device(csx_handle_t hA, Csc *A, bool exact, Csc *L, CholPlan **Pout) {
+static int cholsol_factor_device(csx_handle_t hA, Csc *A, bool exact, Csc *L, CholPlan **Pout) {   // (A->clique may be replaced)
     hipStream_t s = ctx().stream;
     const int32_t n = A->n;
     const auto t_call = std::chrono::steady_clock::now();
@@ -2651,12 +2651,15 @@ static int cholsol_factor_device(csx_handle_t hA, Csc *A, bool exact, Csc *L, Ch
             L->m = L->n = n;
             L->nnz = (int32_t)F.lnz;
             L->owns = true;
-            if (cached) {
-                CSX_TRY(dalloc(&L->p, (size_t)n + 1));
-                CSX_HIP(hipMemcpyAsync(L->p, F.cp, ((size_t)n + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
-            } else {
-                L->p = F.cp;          // L takes the forest's column pointers
-                F.cp = nullptr;
+            // L gets a copy of the forest's column pointers; the finding itself (tree, counts, block list: pattern only) stays on the
+            // matrix for the next factorisation of it -- a refactorisation loop pays for the analysis once, like csx_schol followed by
+            // many csx_chol (csx_csc_invalidate drops it with every other cached plan)
+            CSX_TRY(dalloc(&L->p, (size_t)n + 1));
+            CSX_HIP(hipMemcpyAsync(L->p, F.cp, ((size_t)n + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+            if (!cached) {
+                free_clique_cache(A->clique);
+                A->clique = new CliqueForest(F);
+                release.on = false;   // the matrix owns the arrays now
             }
             CSX_TRY(dalloc(&L->x, (size_t)L->nnz));
             if (!emit) CSX_TRY(dalloc(&L->i, (size_t)L->nnz));
