@@ -560,7 +560,7 @@ def cholsol_connected(grid=300):
             if order == 0:
                 # the list call with "tri.host_chains" = 1 (opt-in): the whole solve sequence on the host for a chain, same bits
                 Fl = cs.cholsol_factor(A, 0, exact=True)
-                for name, val in (("device_default", 0), ("host_chains_option", 1)):
+                for how, val in (("device_default", 0), ("host_chains_option", 1)):
                     cs.cs_option("tri.host_chains", val)
                     try:
                         xl = b.copy()
@@ -569,7 +569,7 @@ def cholsol_connected(grid=300):
                         for _ in range(3):
                             xl = b.copy()
                             Fl.solve(xl)
-                        r["list_solve_ms_" + name] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
+                        r["list_solve_ms_" + how] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
                         if val == 0:
                             x_dev = xl.copy()
                         else:
