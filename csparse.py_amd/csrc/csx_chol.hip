@@ -1074,7 +1074,18 @@ struct CholPlan {
     // L's columns) and nothing else; a solve the matrix cores do not take (the exact order, the guard's refusal) goes to `full`,
     // the general plan of the same factor, made the first time it is needed
     bool lite = false;
+    bool lite_cliques = false;   // ... and every block is a CLIQUE (dense): the exact order can take the padded size classes below
     CholPlan *full = nullptr;
+    // exact order on a forest of cliques of UNEQUAL sizes (round 5): the blocks bucketed by size class 8 / 16 / 32 / 64, every block
+    // padded at its end with the identity up to its class, the register-resident exact kernel (k_cholsol_dense_exact_dpp) run
+    // per class on programs cut out of L.x -- the padding changes no bit (see the kernel)
+    struct ExactClass {
+        int32_t count = 0;
+        Tree *trees = nullptr;
+        int32_t *nodes = nullptr, *f_ptr = nullptr, *b_ptr = nullptr;
+        double *f_val = nullptr, *dense_b = nullptr, *diagk = nullptr, *diagb = nullptr;
+    } xc[4];
+    bool xc_built = false;
     bool mfma_tried = false;  // fragments were built, or refused by the growth guard
     double mfma_growth = 0.0; // max|inv(L_ii)| max|L| over the forest (the guard's measure)
     // big trees, rounding-equal order: supernodal schedule (csx_snsolve.hip), built the first time the plan is relaxed
@@ -1090,6 +1101,16 @@ void free_cholplan(CholPlan *P) {
     free_snplan(P->sn);
     ragged_free(P->rag);
     free_cholplan(P->full);
+    for (auto &c : P->xc) {
+        dfree(c.trees);
+        dfree(c.nodes);
+        dfree(c.f_ptr);
+        dfree(c.b_ptr);
+        dfree(c.f_val);
+        dfree(c.dense_b);
+        dfree(c.diagk);
+        dfree(c.diagb);
+    }
     free_triplan(P->fwd);
     free_triplan(P->bwd);
     dfree(P->perm);
@@ -1694,16 +1715,19 @@ __global__ __launch_bounds__(256, 3) void k_cholsol_dense_exact_dpp(const Tree *
     const bool live = valid && rhs < nrhs;
     const int32_t rhs_ld = rhs < nrhs ? rhs : nrhs - 1;
     double *M = s_m[slot], *DG = s_m[slot] + NT;            // DG overlaps the DMA overrun and is written after it
-    int32_t jrow = 0;
+    // (a node of -1 is PADDING: a block of fewer than BS columns padded at its end with the identity -- cholsol_exact_classes.
+    // Its unknown starts as +0.0, stays +0.0 through both sweeps and is never stored; the zero coefficients that link it to the
+    // real rows come last in every real row's backward sum and subtract (+0.0) (+0.0) = +0.0: no bit of a real unknown changes.)
+    int32_t jrow = -1;
     if (lane < BS) {
         jrow = nodes[first + lane];
-        if (perm) jrow = perm[jrow];
+        if (perm && jrow >= 0) jrow = perm[jrow];
     }
     double x[BS];
 #pragma unroll
     for (int a = 0; a < BS; a++) {
         const int32_t row = __builtin_amdgcn_readlane(jrow, a);
-        x[a] = B[(int64_t)row * nrhs + rhs_ld];
+        x[a] = row >= 0 ? B[(int64_t)row * nrhs + rhs_ld] : 0.0;
     }
     auto run_pass = [&](auto pass_tag) {
         constexpr int pass = decltype(pass_tag)::value;
@@ -1728,7 +1752,7 @@ __global__ __launch_bounds__(256, 3) void k_cholsol_dense_exact_dpp(const Tree *
 #pragma unroll
     for (int a = 0; a < BS; a++) {
         const int32_t row = __builtin_amdgcn_readlane(jrow, a);
-        if (live) B[(int64_t)row * nrhs + rhs] = x[a];
+        if (live && row >= 0) B[(int64_t)row * nrhs + rhs] = x[a];
     }
 }
 // (Round 4 tried the L values as SCALAR operands: a lane is a right-hand side, so an L value is the same for the whole wave,
@@ -2291,10 +2315,13 @@ constexpr double MFMA_GROWTH_LIMIT = 1e3;
 
 // forests of small trees of any shape (max_nodes <= 80): the trees' forward programs made dense, bucketed by size, on the matrix cores
 static int cholsol_build_ragged(CholPlan *P) {
-    if (P->rag_tried || !P->local || P->dense_bs || !P->f_idx || P->max_nodes > RAG_MAX_ROWS) return CSX_OK;
+    if (P->rag_tried || !P->local || P->dense_bs || (!P->f_idx && !P->lite) || P->max_nodes > RAG_MAX_ROWS) return CSX_OK;
     P->rag_tried = true;
     RaggedMfma *R = nullptr;
-    CSX_TRY(ragged_build(P->trees, P->ntrees, P->max_nodes, P->tree_nodes, P->f_ptr, P->f_idx, P->f_val, P->diagk, false, &R));
+    if (P->lite)      // (csx_cholsol_factor's plan of a forest on consecutive columns: straight from L's columns)
+        CSX_TRY(ragged_build(P->trees, P->ntrees, P->max_nodes, P->tree_nodes, nullptr, nullptr, nullptr, nullptr, false, &R, P->L));
+    else
+        CSX_TRY(ragged_build(P->trees, P->ntrees, P->max_nodes, P->tree_nodes, P->f_ptr, P->f_idx, P->f_val, P->diagk, false, &R));
     if (!R) return CSX_OK;
     P->mfma_growth = R->growth;
     if (R->growth <= RAG_GROWTH_LIMIT) P->rag = R;     // (a NaN fails the comparison: the fused per-tree kernel stays)
@@ -2365,10 +2392,162 @@ static int cholsol_build_sn(CholPlan *P) {
     return st;
 }
 
+// ---- exact order on forests of cliques of unequal sizes: padded size classes ------------------------------------------------
+__global__ __launch_bounds__(256) void k_xc_class(const Tree *__restrict__ trees, int32_t ntrees, uint32_t *__restrict__ key,
+                                                  uint32_t *__restrict__ id) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ntrees) return;
+    const int32_t c = trees[t].count;
+    key[t] = c <= 8 ? 0u : c <= 16 ? 1u : c <= 32 ? 2u : 3u;
+    id[t] = (uint32_t)t;
+}
+
+// k_clique_plan for a block of bs <= BS columns padded at its END with the identity up to BS: slot q of the class holds block
+// list[q]; f_val = rows of the strictly lower triangle, row-major; dense_b = for sweep position sp (row BS - 1 - sp) the column
+// below the diagonal reversed; the diagonals in both orders; the node list with -1 for the padding
+template <int BS>
+__global__ __launch_bounds__(256) void k_xc_plan(const uint32_t *__restrict__ list, const Tree *__restrict__ blocks,
+                                                 const int32_t *__restrict__ Lp, const double *__restrict__ Lx, Tree *trees,
+                                                 int32_t *nodes, int32_t *f_ptr, int32_t *b_ptr, double *f_val, double *dense_b,
+                                                 double *diagk, double *diagb, int32_t count) {
+    constexpr int NT = BS * (BS - 1) / 2;
+    __shared__ double tri[BS * (BS + 1) / 2];
+    const int32_t q = blockIdx.x;
+    const Tree blk = blocks[list[q]];
+    const int32_t c0 = blk.first, bs = blk.count;
+    const int64_t base = Lp[c0];
+    const int nent = bs * (bs + 1) / 2;
+    for (int e = threadIdx.x; e < nent; e += 256) tri[e] = Lx[base + e];
+    __syncthreads();
+    // element (r, c), r >= c, of the padded block
+    auto Lpad = [&](int r, int c) -> double {
+        if (r < bs) return tri[c * bs - c * (c - 1) / 2 + r - c];       // (then c < bs too)
+        return r == c ? 1.0 : 0.0;
+    };
+    const int64_t po = (int64_t)q * NT;
+    for (int idx = threadIdx.x; idx < BS * BS; idx += 256) {
+        const int a = idx / BS, c = idx % BS;
+        if (c < a) {
+            f_val[po + a * (a - 1) / 2 + c] = Lpad(a, c);
+            dense_b[po + a * (a - 1) / 2 + c] = Lpad(BS - 1 - c, BS - 1 - a);
+        }
+    }
+    if (threadIdx.x < BS) {
+        const int a = threadIdx.x;
+        const double d = Lpad(a, a);
+        diagk[q * BS + a] = d;
+        diagb[q * BS + BS - 1 - a] = d;
+        f_ptr[q * BS + a] = (int32_t)(po + a * (a - 1) / 2);
+        b_ptr[q * BS + a] = (int32_t)(po + a * (a - 1) / 2);
+        nodes[q * BS + a] = a < bs ? c0 + a : -1;
+    }
+    if (threadIdx.x == 0) {
+        trees[q] = Tree{q * BS, BS};
+        if (q == count - 1) f_ptr[count * BS] = b_ptr[count * BS] = (int32_t)(po + NT);
+    }
+}
+
+static int cholsol_exact_classes_build(CholPlan *P) {
+    if (P->xc_built) return CSX_OK;
+    hipStream_t s = ctx().stream;
+    const int32_t nt = P->ntrees;
+    DevScope tmp;
+    uint32_t *key = nullptr, *id = nullptr, *skey = nullptr, *list = nullptr;
+    int32_t *bounds = nullptr;
+    CSX_TRY(tmp.alloc(&key, (size_t)nt));
+    CSX_TRY(tmp.alloc(&id, (size_t)nt));
+    CSX_TRY(tmp.alloc(&skey, (size_t)nt));
+    CSX_TRY(tmp.alloc(&list, (size_t)nt));
+    CSX_TRY(tmp.alloc(&bounds, 5));
+    hipLaunchKernelGGL(k_xc_class, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, P->trees, nt, key, id);
+    CSX_LAUNCH_CHECK();
+    CSX_TRY(stable_sort_by_key(key, id, nullptr, nt, 4, skey, list, nullptr));
+    CSX_TRY(boundaries_from_sorted(skey, nt, 4, bounds));
+    int32_t hb[5] = {0, 0, 0, 0, 0};
+    CSX_HIP(hipMemcpyAsync(hb, bounds, sizeof hb, hipMemcpyDeviceToHost, s));
+    CSX_HIP(hipStreamSynchronize(s));
+    static const int kBS[4] = {8, 16, 32, 64};
+    for (int c = 0; c < 4; c++) {
+        CholPlan::ExactClass &X = P->xc[c];
+        X.count = hb[c + 1] - hb[c];
+        if (X.count <= 0) continue;
+        const int BS = kBS[c];
+        const size_t rows = (size_t)X.count * BS, terms = (size_t)X.count * (BS * (BS - 1) / 2);
+        if (terms > 0x7fffffffull) return CSX_OK;            // (32-bit program offsets: the general plan takes over; nothing built is used)
+        CSX_TRY(dalloc(&X.trees, (size_t)X.count));
+        CSX_TRY(dalloc(&X.nodes, rows));
+        CSX_TRY(dalloc(&X.f_ptr, rows + 1));
+        CSX_TRY(dalloc(&X.b_ptr, rows + 1));
+        CSX_TRY(dalloc(&X.diagk, rows));
+        CSX_TRY(dalloc(&X.diagb, rows));
+        CSX_TRY(dalloc(&X.f_val, terms + 128));
+        CSX_TRY(dalloc(&X.dense_b, terms + 128));
+#define CSX_XCP(B_)                                                                                                                \
+    hipLaunchKernelGGL(k_xc_plan<B_>, dim3((unsigned)X.count), dim3(256), 0, s, list + hb[c], P->trees, P->L->p, P->L->x, X.trees, \
+                       X.nodes, X.f_ptr, X.b_ptr, X.f_val, X.dense_b, X.diagk, X.diagb, X.count)
+        switch (BS) {
+            case 8: CSX_XCP(8); break;
+            case 16: CSX_XCP(16); break;
+            case 32: CSX_XCP(32); break;
+            default: CSX_XCP(64); break;
+        }
+#undef CSX_XCP
+        CSX_LAUNCH_CHECK();
+    }
+    CSX_HIP(hipStreamSynchronize(s));       // (list is a temporary of this function)
+    P->xc_built = true;
+    return CSX_OK;
+}
+
+static int launch_exact_dpp(int BS, const Tree *trees, int32_t ntrees, const int32_t *nodes, const int32_t *perm, const int32_t *f_ptr,
+                            const double *f_val, const int32_t *b_ptr, const double *dense_b, const double *diagk, const double *diagb,
+                            double *B, int32_t nrhs, bool mix) {
+    hipStream_t s = ctx().stream;
+    const int32_t chunks = (nrhs + 63) / 64;
+    const int share = chunks % 4 == 0 ? 1 : chunks % 2 == 0 ? 2 : 4;
+    const int64_t groups = ((int64_t)ntrees + share - 1) / share * (chunks / (4 / share));
+    const dim3 grid((unsigned)groups);
+#define CSX_DPP_X(BS_, SH, MX)                                                                                                     \
+    hipLaunchKernelGGL((k_cholsol_dense_exact_dpp<BS_, SH, MX>), grid, dim3(256), 0, s, trees, ntrees, nodes, perm, f_ptr, f_val, \
+                       b_ptr, dense_b, diagk, diagb, B, nrhs, chunks)
+#define CSX_DPP_S(BS_, MX)                      \
+    if (share == 1) CSX_DPP_X(BS_, 1, MX);      \
+    else if (share == 2) CSX_DPP_X(BS_, 2, MX); \
+    else CSX_DPP_X(BS_, 4, MX)
+#define CSX_DPP_V(BS_)               \
+    if (mix) { CSX_DPP_S(BS_, 1); }  \
+    else { CSX_DPP_S(BS_, 0); }
+    switch (BS) {
+        case 8: CSX_DPP_V(8); break;
+        case 16: CSX_DPP_V(16); break;
+        case 32: CSX_DPP_V(32); break;
+        default: CSX_DPP_V(64); break;
+    }
+#undef CSX_DPP_V
+#undef CSX_DPP_S
+#undef CSX_DPP_X
+    CSX_LAUNCH_CHECK();
+    return CSX_OK;
+}
+
 static int cholsol_solve(CholPlan *P, double *B, int32_t nrhs) {
     hipStream_t s = ctx().stream;
     const int32_t n = P->n;
     if (n == 0 || nrhs == 0) return CSX_OK;
+    if (P->lite && P->lite_cliques && !(P->relaxed && P->rag) && ctx().opt.cholsol_dense_blocks) {
+        // the exact order on cliques of unequal sizes: size classes padded with the identity, the register-resident exact kernel
+        CSX_TRY(cholsol_exact_classes_build(P));
+        if (P->xc_built) {
+            static const int kBS[4] = {8, 16, 32, 64};
+            for (int c = 0; c < 4; c++) {
+                const CholPlan::ExactClass &X = P->xc[c];
+                if (X.count > 0)
+                    CSX_TRY(launch_exact_dpp(kBS[c], X.trees, X.count, X.nodes, nullptr, X.f_ptr, X.f_val, X.b_ptr, X.dense_b, X.diagk,
+                                             X.diagb, B, nrhs, true));
+            }
+            return CSX_OK;
+        }
+    }
     if (P->lite) {
         if (P->relaxed && P->rag && ctx().opt.cholsol_dense_blocks) return ragged_solve(P->rag, P->tree_nodes, nullptr, false, 2, B, nrhs);
         if (!P->full) CSX_TRY(cholsol_plan(P->L, nullptr, &P->full));
@@ -2406,31 +2585,8 @@ static int cholsol_solve(CholPlan *P, double *B, int32_t nrhs) {
             if (variant >= 5) {
                 // the L values by DPP row broadcast: one right-hand side per lane; waves that solve the same block share its
                 // LDS copy (as many as divide the number of 64-wide chunks of right-hand sides)
-                const int32_t chunks = (nrhs + 63) / 64;
-                const int share = chunks % 4 == 0 ? 1 : chunks % 2 == 0 ? 2 : 4;
-                const int64_t groups = ((int64_t)P->ntrees + share - 1) / share * (chunks / (4 / share));
-                const dim3 grid((unsigned)groups);
-#define CSX_DPP_X(BS, SH, MX)                                                                                                          \
-    hipLaunchKernelGGL((k_cholsol_dense_exact_dpp<BS, SH, MX>), grid, dim3(256), 0, s, P->trees, P->ntrees, P->tree_nodes, P->perm, \
-                       P->f_ptr, P->f_val, P->b_ptr, P->dense_b, P->diagk, P->diagb, B, nrhs, chunks)
-#define CSX_DPP_S(BS, MX)                      \
-    if (share == 1) CSX_DPP_X(BS, 1, MX);      \
-    else if (share == 2) CSX_DPP_X(BS, 2, MX); \
-    else CSX_DPP_X(BS, 4, MX)
-#define CSX_DPP_V(BS)                          \
-    if (variant == 5) { CSX_DPP_S(BS, 1); }    \
-    else { CSX_DPP_S(BS, 0); }
-                switch (P->dense_bs) {
-                    case 8: CSX_DPP_V(8); break;
-                    case 16: CSX_DPP_V(16); break;
-                    case 32: CSX_DPP_V(32); break;
-                    default: CSX_DPP_V(64); break;
-                }
-#undef CSX_DPP_V
-#undef CSX_DPP_S
-#undef CSX_DPP_X
-                CSX_LAUNCH_CHECK();
-                return CSX_OK;
+                return launch_exact_dpp(P->dense_bs, P->trees, P->ntrees, P->tree_nodes, P->perm, P->f_ptr, P->f_val, P->b_ptr, P->dense_b,
+                                        P->diagk, P->diagb, B, nrhs, variant == 5);
             }
             if (P->dense_bs == 64 && variant > 2) variant -= 2;
             if (nrhs <= 64 && variant > 2) variant -= 2;
@@ -2721,29 +2877,26 @@ static int cholsol_factor_device(csx_handle_t hA, Csc *A, bool exact, Csc *L, Ch
                     P->frag_f = nullptr;
                 }
                 g_factor_path = 3;
-            } else if (!exact && ctx().opt.cholsol_dense_blocks && !(F.min_bs == bs && bs == 8 && !F.sparse)) {
-                // a forest of UNEQUAL cliques or of small sparse trees, rounding-equal order: the block list from the forest's
-                // starts, the matrix-core operands straight from L's columns -- no general plan unless a solve needs one
+            } else if (ctx().opt.cholsol_dense_blocks && (!exact || !F.sparse) &&
+                       !(!F.sparse && F.min_bs == bs && (bs == 8 || bs == 16 || bs == 32 || bs == 64))) {
+                // a forest of UNEQUAL cliques (either order) or of small sparse trees (rounding-equal order): the plan is the block
+                // list from the forest's starts; the matrix-core operands come straight from L's columns (now, or when the order is
+                // switched), the exact order of cliques runs on padded size classes cut out of L.x at the first such solve
+                // (cholsol_exact_classes_build) -- no general plan unless a solve needs one
                 P = new CholPlan();
                 *Pout = P;
                 P->n = n;
                 P->L = L;
                 P->lite = true;
+                P->lite_cliques = !F.sparse;
                 P->local = true;
-                P->relaxed = true;
+                P->relaxed = !exact;
                 P->ntrees = F.nblocks;
                 P->max_nodes = bs;
                 CSX_TRY(dalloc(&P->trees, (size_t)F.nblocks));
                 CSX_TRY(dalloc(&P->tree_nodes, (size_t)n));
                 CSX_TRY(ragged_blocks(F.start, F.nblocks, n, P->trees, P->tree_nodes));
-                P->rag_tried = true;
-                RaggedMfma *R = nullptr;
-                CSX_TRY(ragged_build(P->trees, P->ntrees, bs, P->tree_nodes, nullptr, nullptr, nullptr, nullptr, false, &R, L));
-                if (R) {
-                    P->mfma_growth = R->growth;
-                    if (R->growth <= RAG_GROWTH_LIMIT) P->rag = R;
-                    else ragged_free(R);
-                }
+                if (!exact) CSX_TRY(cholsol_build_ragged(P));
                 g_factor_path = F.sparse ? 2 : 1;
             } else {
                 if (!F.sparse && F.min_bs == bs && (bs == 8 || bs == 16 || bs == 32 || bs == 64) && ctx().opt.cholsol_dense_blocks) {
@@ -2838,6 +2991,12 @@ extern "C" int csx_cholsol_info(csx_handle_t h, int32_t *local, int32_t *ntrees,
     if (!P) return CSX_EINVAL;
     // 0 level-scheduled, 1 fused in LDS, 2 dense blocks (substitution), 3 dense blocks on the matrix cores, 4 supernodal schedule,
     // 5 small trees of any shape made dense by size class on the matrix cores (csx_trimfma.hip)
+    if (P->lite && P->lite_cliques && !(P->relaxed && P->rag) && ctx().opt.cholsol_dense_blocks) {
+        if (local) *local = 2;               // dense-block substitution (padded size classes), the exact order
+        if (ntrees) *ntrees = P->ntrees;
+        if (max_nodes) *max_nodes = P->max_nodes;
+        return CSX_OK;
+    }
     if (P->lite && !(P->relaxed && P->rag)) {   // the general plan answers (made now if it has to be)
         if (!P->full) CSX_TRY(cholsol_plan(P->L, nullptr, &P->full));
         P->full->relaxed = false;

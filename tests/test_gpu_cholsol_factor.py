@@ -99,7 +99,15 @@ def test_one_call_equals_the_three_calls(cs, case, exact):
     if want_path == 3 and exact:
         want_path = 1                 # the exact order needs the substitution programs: block kernel, then the plan from L.x
     assert path == want_path
-    assert _info(plan) == _info(plan0)
+
+    def same_info(in_exact_order):
+        if case == "unequal" and in_exact_order:
+            # the one call's plan solves cliques of unequal sizes exactly by PADDED SIZE CLASSES on the register-resident kernel
+            # (path 2); the three calls' general plan by the fused per-tree kernel (path 1): same trees, same bits (below)
+            assert _info(plan) == (2,) + _info(plan0)[1:] and _info(plan0)[0] == 1
+        else:
+            assert _info(plan) == _info(plan0)
+    same_info(exact)
     k = 70
     B = synth.rhs(n, k, 5)
     X0 = _solve(plan0, B)
@@ -117,7 +125,7 @@ def test_one_call_equals_the_three_calls(cs, case, exact):
     # the other order on the same plans
     for pl in (plan0, plan):
         _csx.check(lib.csx_cholsol_set_order(pl, 0 if exact else 1))
-    assert _info(plan) == _info(plan0)
+    same_info(not exact)
     Y0, Y = _solve(plan0, B), _solve(plan, B)
     assert Y.tobytes() == Y0.tobytes()
     # exact order: cs_lsolve + cs_ltsolve on this L (csparse.py:640-643), bit for bit; rounding-equal: 1e-10 componentwise

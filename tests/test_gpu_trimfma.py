@@ -238,3 +238,36 @@ def test_cholsol_forests_of_small_trees_on_the_matrix_cores(cs, shape):
         dB1 = cs.dvec(B)
         assert F.solve(dB1) is True
         assert dB1.numpy().reshape(n, k)[:, 35].tobytes() == ref.tobytes()
+
+
+@pytest.mark.parametrize("k", [1, 70, 128, 200])
+def test_exact_order_on_unequal_cliques_by_padded_size_classes(cs, k):
+    """The exact order on a forest of cliques of 1 .. 64 columns (csx_cholsol_factor's plan): blocks bucketed by size class
+    8 / 16 / 32 / 64 and padded at their end with the identity, the register-resident exact kernel per class.  The padding changes
+    no bit: every column equals cs_lsolve + cs_ltsolve on the same L (the oracle's loops), for 1, 70, 128 and 200 right-hand sides
+    (every sharing mode of the kernel), zeros and negative zeros in the right-hand side included."""
+    import _csx
+    rng = np.random.default_rng(11)
+    sizes = list(rng.integers(1, 65, 200)) + [64, 1, 8, 9, 16, 17, 32, 33]
+    n, Ap, Ai, Ax = _blocks(sizes, 23)
+    A = cs.cs_pin(_host_cs(cs, n, n, Ap, Ai, Ax))
+    F = cs.cholsol_factor(A, exact=True)
+    path = C.c_int32(-1)
+    _csx.check(_csx.lib().csx_cholsol_info(F.plan_handle, path, None, None))
+    gLp, gLi, gLx = (np.asarray(v) for v in (F.L.p, F.L.i, F.L.x))
+    gLp, gLi = gLp.astype(np.int32), gLi.astype(np.int32)
+    gLi, gLx = gLi[:gLp[n]], gLx[:gLp[n]]
+    B = synth.rhs(n, k, 2) if k > 1 else synth.rhs(n, 1, 2)
+    B = B.reshape(n, -1).copy()
+    B[::7, 0] = 0.0
+    B[3::11, -1] = -0.0
+    dB = cs.dvec(B if k > 1 else B[:, 0].copy())
+    assert F.solve(dB) is True
+    X = dB.numpy().reshape(n, -1)
+    for r in sorted({0, k // 2, k - 1}):
+        ref = CO.ltsolve(n, gLp, gLi, gLx, CO.lsolve(n, gLp, gLi, gLx, B[:, r]))
+        assert X[:, r].tobytes() == ref.tobytes(), r
+    with _csx.option("cholsol.dense_blocks", 0):            # the fused per-tree kernel (the general plan) on the same solver
+        dB1 = cs.dvec(B if k > 1 else B[:, 0].copy())
+        assert F.solve(dB1) is True
+        assert dB1.numpy().tobytes() == dB.numpy().tobytes()
