@@ -1717,7 +1717,9 @@ __global__ __launch_bounds__(256, 3) void k_cholsol_dense_exact_dpp(const Tree *
     double *M = s_m[slot], *DG = s_m[slot] + NT;            // DG overlaps the DMA overrun and is written after it
     // (a node of -1 is PADDING: a block of fewer than BS columns padded at its end with the identity -- cholsol_exact_classes.
     // Its unknown starts as +0.0, stays +0.0 through both sweeps and is never stored; the zero coefficients that link it to the
-    // real rows come last in every real row's backward sum and subtract (+0.0) (+0.0) = +0.0: no bit of a real unknown changes.)
+    // real rows come last in every real row's backward sum and subtract (+0.0) (+0.0) = +0.0: no bit of a real unknown changes --
+    // for FINITE data: an infinity among a block's unknowns turns the padding into NaN (0 x inf) and the block's other non-finite
+    // values with it, where the reference keeps some of them as infinities; a clique's unknowns are all non-finite then either way.)
     int32_t jrow = -1;
     if (lane < BS) {
         jrow = nodes[first + lane];
