@@ -2820,7 +2820,8 @@ static int cholsol_factor_device(csx_handle_t hA, Csc *A, bool exact, Csc *L, Ch
                 release.on = false;   // the matrix owns the arrays now
             }
             CSX_TRY(dalloc(&L->x, (size_t)L->nnz));
-            if (!emit) CSX_TRY(dalloc(&L->i, (size_t)L->nnz));
+            // (L.i: allocated below, once it is known whether the kernel writes it -- with the emission it does not: rows j, j + 1, ...
+            // in every column of a clique, Csc::rows_pending)
             CholPlan *P = nullptr;
             CliqueEmit em;
             DevScope tmp;
@@ -2828,6 +2829,44 @@ static int cholsol_factor_device(csx_handle_t hA, Csc *A, bool exact, Csc *L, Ch
             CSX_TRY(tmp.alloc(&d_flags, 4));
             CSX_HIP(hipMemsetAsync(d_flags, 0x7f, sizeof(int), s));
             CSX_HIP(hipMemsetAsync(d_flags + 2, 0, 2 * sizeof(int), s));
+            // cliques of UNEQUAL sizes, rounding-equal order: the block kernel writes the matrix-core operands of csx_trimfma.hip's
+            // size classes itself (the class-ordered list, descriptors and fragment storage are made first: the kernel needs to know
+            // where each block's fragments go)
+            const bool emit_ragged = !emit && !exact && !F.sparse && ctx().opt.cholsol_dense_blocks &&
+                                     !(F.min_bs == bs && (bs == 8 || bs == 16 || bs == 32 || bs == 64));
+            RaggedMfma *Rg = nullptr;
+            int64_t *frag_off = nullptr;
+            struct RagGuard {
+                RaggedMfma *&R;
+                int64_t *&off;
+                ~RagGuard() {
+                    ragged_free(R);
+                    dfree(off);
+                }
+            } rag_guard{Rg, frag_off};
+            if (emit_ragged) {
+                P = new CholPlan();
+                *Pout = P;
+                P->n = n;
+                P->L = L;
+                P->lite = true;
+                P->lite_cliques = true;
+                P->local = true;
+                P->relaxed = true;
+                P->ntrees = F.nblocks;
+                P->max_nodes = bs;
+                CSX_TRY(dalloc(&P->trees, (size_t)F.nblocks));
+                CSX_TRY(dalloc(&P->tree_nodes, (size_t)n));
+                CSX_TRY(ragged_blocks(F.start, F.nblocks, n, P->trees, P->tree_nodes));
+                CSX_TRY(ragged_prepare_emit(P->trees, P->ntrees, bs, P->tree_nodes, &Rg, &frag_off));
+                if (Rg) {
+                    em.frag = Rg->frag;
+                    em.frag_off = frag_off;
+                    em.cond_bits = (unsigned long long *)(d_flags + 2);
+                }
+            }
+            const bool emit_any = emit || (emit_ragged && Rg);
+            if (!emit_any) CSX_TRY(dalloc(&L->i, (size_t)L->nnz));
             if (emit) {
                 P = new CholPlan();
                 *Pout = P;            // (the caller frees it on any error)
@@ -2848,7 +2887,7 @@ static int cholsol_factor_device(csx_handle_t hA, Csc *A, bool exact, Csc *L, Ch
                 return CSX_ERUNTIME;
             }
             (void)hipEventRecord(ev_a, s);
-            int st = chol_clique_numeric(A, F, L, d_flags, emit ? &em : nullptr, !ctx().opt.chol_exact);
+            int st = chol_clique_numeric(A, F, L, d_flags, emit_any ? &em : nullptr, !ctx().opt.chol_exact);
             (void)hipEventRecord(ev_b, s);
             int h[4] = {0, 0, 0, 0};
             if (hipMemcpyAsync(h, d_flags, sizeof h, hipMemcpyDeviceToHost, s) != hipSuccess) st = st == CSX_OK ? CSX_ERUNTIME : st;
@@ -2879,6 +2918,23 @@ static int cholsol_factor_device(csx_handle_t hA, Csc *A, bool exact, Csc *L, Ch
                     P->frag_f = nullptr;
                 }
                 g_factor_path = 3;
+            } else if (emit_ragged) {
+                // the plan was made before the kernel ran (above); its matrix-core operands are in place
+                if (Rg) {
+                    L->rows_pending = L->i == nullptr;
+                    double growth = 0.0;
+                    std::memcpy(&growth, h + 2, sizeof growth);
+                    Rg->growth = growth;
+                    P->mfma_growth = growth;
+                    P->rag_tried = true;
+                    if (growth <= MFMA_GROWTH_LIMIT) {       // (max|L| max|W| of a block, the equal-block path's measure; a NaN fails)
+                        P->rag = Rg;
+                        Rg = nullptr;
+                    }
+                } else if (!L->i) {
+                    L->rows_pending = true;
+                }
+                g_factor_path = 1;
             } else if (ctx().opt.cholsol_dense_blocks && (!exact || !F.sparse) &&
                        !(!F.sparse && F.min_bs == bs && (bs == 8 || bs == 16 || bs == 32 || bs == 64))) {
                 // a forest of UNEQUAL cliques (either order) or of small sparse trees (rounding-equal order): the plan is the block

@@ -49,8 +49,11 @@ struct Tree;
 struct CliqueEmit {
     double *frag = nullptr;               // [nblocks * frags_per_block(bs / 16) * 64]
     unsigned long long *cond_bits = nullptr;   // ordered bits of the largest max|L| max|W| of a block (zeroed by the caller)
-    Tree *trees = nullptr;                // [nblocks]  {first column, columns}
+    Tree *trees = nullptr;                // [nblocks]  {first column, columns}   (null: the caller has made the block list)
     int32_t *tree_nodes = nullptr;        // [n]        the identity node list
+    const int64_t *frag_off = nullptr;    // blocks of UNEQUAL sizes: frag_off[t] = first double of block t's fragments (csx_trimfma.h:
+                                          // ragged_prepare_emit); a block of bs columns then takes ceil(bs / 16) tiles a side, its last
+                                          // tile row / column padded with the identity.  null: equal blocks, block t at t * per_block
 };
 // values and row indices of L (L->p = F.cp already in place, L->i / L->x allocated); blocks of at most 64 columns
 // relaxed ("chol.exact" = 0): fused multiply-adds and reciprocal square roots -- L.x equal to the exact kernel's to rounding

@@ -626,10 +626,21 @@ __global__ __launch_bounds__(64 * CQ_WAVES, 3) void k_chol_clique(const int32_t 
     double *em_diag = tile + 8 * 64;                                   // EMIT: the diagonal tiles, beside colbuf
     double *em_frag = nullptr;
     double em_lmax = 0.0;
+    const int em_rows = EMIT ? 16 * ((bs + 15) >> 4) : 0;               // EMIT: the block's rows padded to whole tiles
     if (EMIT) {
-        em_frag = em.frag + (size_t)t * (size_t)(clique_frags_per_block(bs >> 4) * 64);
-        if (lane < bs) em.tree_nodes[c0 + lane] = c0 + lane;
-        if (lane == 0) em.trees[t] = Tree{c0, bs};
+        em_frag = em.frag + (em.frag_off ? (size_t)em.frag_off[t] : (size_t)t * (size_t)(clique_frags_per_block(bs >> 4) * 64));
+        if (em.trees) {
+            if (lane < bs) em.tree_nodes[c0 + lane] = c0 + lane;
+            if (lane == 0) em.trees[t] = Tree{c0, bs};
+        }
+        if (bs & 15) {      // a block that does not fill its last tile: the diagonal tiles start as the identity (the padding's part stays)
+#pragma unroll
+            for (int e = 0; e < (4 * CQ_DIAG + 63) / 64; e++) {
+                const int q = e * 64 + lane;
+                if (q < 4 * CQ_DIAG) em_diag[q] = ((q % CQ_DIAG) / 17 == (q % CQ_DIAG) % 17) ? 1.0 : 0.0;
+            }
+            cq_wave_sync_lds();
+        }
     }
     double *colbuf = tile;   // [8][64]   (s_setprio around the phases -- loading waves first, or factoring waves first -- 1.61-1.65 ms: no gain)
 #pragma unroll 1
@@ -719,14 +730,15 @@ __global__ __launch_bounds__(64 * CQ_WAVES, 3) void k_chol_clique(const int32_t 
             // (tile (ti, tj), k-step sx) holds element (m, 4 sx + kq) at position 16 kq + m: for one column 16 lanes write 128
             // contiguous bytes.  (Above the diagonal a[] is +0.0: nothing of it is read.)
             const int tj = J >> 4, ti = lane >> 4, m = lane & 15;
-            if (ti > tj && lane < bs) {
+            if (ti > tj && lane < em_rows) {        // (rows past the block, in its last tile row: a[] is zero there -- the padding)
                 double *dst = em_frag + (size_t)(((ti * (ti + 1) / 2 + tj) * 4 + ((J & 8) >> 2)) * 64 + m);
 #pragma unroll
-                for (int jw = 0; jw < 8; jw++) dst[(jw >> 2) * 64 + (jw & 3) * 16] = -a[jw];
-            } else if (ti == tj) {
+                for (int jw = 0; jw < 8; jw++) dst[(jw >> 2) * 64 + (jw & 3) * 16] = J + jw < bs ? -a[jw] : 0.0;
+            } else if (ti == tj && lane < bs) {
                 double *dd = em_diag + ti * CQ_DIAG + m * 17 + (J & 8);
 #pragma unroll
-                for (int jw = 0; jw < 8; jw++) dd[jw] = a[jw];
+                for (int jw = 0; jw < 8; jw++)
+                    if (J + jw < bs) dd[jw] = a[jw];
             }
 #pragma unroll
             for (int jw = 0; jw < 8; jw++) em_lmax = fmax(em_lmax, fabs(a[jw]));
@@ -931,8 +943,10 @@ int chol_clique_numeric(const Csc *A, const CliqueForest &F, Csc *L, int *d_nots
     if (F.nblocks == 0 || A->nnz == 0) return CSX_OK;
     const dim3 grid((unsigned)((F.nblocks + CQ_WAVES - 1) / CQ_WAVES));
     if (emit) {
-        // what k_cholsol_mfma can take: equal dense blocks of 16 / 32 / 64 columns
-        if (F.sparse || F.min_bs != F.max_bs || (F.max_bs != 16 && F.max_bs != 32 && F.max_bs != 64)) return CSX_EINVAL;
+        // what k_cholsol_mfma can take: equal dense blocks of 16 / 32 / 64 columns; with frag_off (csx_trimfma.hip's size classes):
+        // dense blocks of any sizes up to 64
+        if (F.sparse) return CSX_EINVAL;
+        if (!emit->frag_off && (F.min_bs != F.max_bs || (F.max_bs != 16 && F.max_bs != 32 && F.max_bs != 64))) return CSX_EINVAL;
     }
     const CliqueEmit em = emit ? *emit : CliqueEmit();
 #define CSX_CQ_GO(PARTS, SMALL, DENSE, SPARSE, EMIT)                                                                                  \
@@ -955,7 +969,8 @@ int chol_clique_numeric(const Csc *A, const CliqueForest &F, Csc *L, int *d_nots
         CSX_CQ_GO(PARTS, true, false, false, false);                                                                            \
     else                                                                                                                        \
         CSX_CQ_GO(PARTS, false, false, false, false)
-    if (relaxed && !F.sparse && F.dense_in_front && F.min_bs == F.max_bs && F.max_bs % 16 == 0 && ctx().opt.chol_exact == 0) {
+    if (relaxed && !F.sparse && F.dense_in_front && F.min_bs == F.max_bs && F.max_bs % 16 == 0 && ctx().opt.chol_exact == 0 &&
+        !(emit && emit->frag_off)) {
         // equal dense blocks of 16 / 32 / 48 / 64 columns: the blocked factorisation on the matrix cores
         const dim3 g2((unsigned)((F.nblocks + CM_WAVES - 1) / CM_WAVES));
 #define CSX_CM(NB)                                                                                                                        \

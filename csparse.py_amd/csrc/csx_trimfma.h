@@ -29,6 +29,10 @@ struct RaggedMfma {
 // columns}, nodes the identity) and the dense triangles are read from its columns instead of from sweep programs (ptr .. diag unused).
 int ragged_build(const Tree *trees, int32_t ntrees, int32_t max_rows, const int32_t *nodes, const int32_t *ptr, const int32_t *idx,
                  const double *val, const double *diag, bool reverse, RaggedMfma **out, const Csc *from_factor = nullptr);
+// For a producer that writes the fragments itself (k_chol_clique with CliqueEmit::frag_off: cs_chol of a forest of cliques of unequal
+// sizes): the class-ordered list, descriptors and fragment storage, and frag_off[t] = the first double of component t's fragments
+// (device array the caller frees; layout per component as above, its class = ceil(rows / 16) tiles).  R->growth is the caller's to set.
+int ragged_prepare_emit(const Tree *trees, int32_t ntrees, int32_t max_rows, const int32_t *nodes, RaggedMfma **out, int64_t **frag_off);
 // trees[b] = {start[b], start[b + 1] - start[b]}, nodes = the identity (n entries): the block list of such a factor
 int ragged_blocks(const int32_t *start, int32_t nblocks, int32_t n, Tree *trees, int32_t *nodes);
 // X (n-by-nrhs, row-major) <- the sweep applied to every component: a blocked substitution in position order on the matrix cores.

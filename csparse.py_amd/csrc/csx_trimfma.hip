@@ -444,26 +444,17 @@ void ragged_free(RaggedMfma *R) {
     delete R;
 }
 
-int ragged_build(const Tree *trees, int32_t ntrees, int32_t max_rows, const int32_t *nodes, const int32_t *ptr, const int32_t *idx,
-                 const double *val, const double *diag, bool reverse, RaggedMfma **out, const Csc *from_factor) {
-    *out = nullptr;
-    if (ntrees <= 0 || max_rows > RAG_MAX_ROWS) return CSX_OK;
+// the class-ordered list, the descriptors and room for the fragments (not yet written)
+static int ragged_skeleton(const Tree *trees, int32_t ntrees, const int32_t *nodes, RaggedMfma *R) {
     hipStream_t s = ctx().stream;
-    RaggedMfma *R = new RaggedMfma();
-    struct Guard {
-        RaggedMfma *R;
-        ~Guard() { ragged_free(R); }
-    } guard{R};
     R->ntrees = ntrees;
     DevScope tmp;
     uint32_t *key = nullptr, *id = nullptr, *skey = nullptr;
     int32_t *bounds = nullptr;
-    unsigned long long *cond = nullptr;
     CSX_TRY(tmp.alloc(&key, (size_t)ntrees));
     CSX_TRY(tmp.alloc(&id, (size_t)ntrees));
     CSX_TRY(tmp.alloc(&skey, (size_t)ntrees));
     CSX_TRY(tmp.alloc(&bounds, RAG_CLASSES + 1));
-    CSX_TRY(tmp.alloc(&cond, 1));
     CSX_TRY(dalloc(&R->list, (size_t)ntrees));
     hipLaunchKernelGGL(k_rag_class, dim3((unsigned)((ntrees + 255) / 256)), dim3(256), 0, s, trees, ntrees, key, id);
     CSX_LAUNCH_CHECK();
@@ -481,6 +472,65 @@ int ragged_build(const Tree *trees, int32_t ntrees, int32_t max_rows, const int3
     }
     R->cls_frag[RAG_CLASSES] = total;
     CSX_TRY(dalloc(&R->frag, total));
+    return CSX_OK;
+}
+
+// frag_off[t] = where component t's fragments start (doubles from R->frag): its class's base + its slot in the class
+struct RagBases {
+    int32_t start[RAG_CLASSES + 1];
+    int64_t frag[RAG_CLASSES + 1];
+};
+__global__ __launch_bounds__(256) void k_rag_fragoff(const int32_t *__restrict__ list, int32_t ntrees, RagBases b, int64_t *__restrict__ off) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= ntrees) return;
+    int c = 0;
+    while (c + 1 < RAG_CLASSES && q >= b.start[c + 1]) c++;
+    const int nb = c + 1;
+    off[list[q]] = b.frag[c] + (q - b.start[c]) * (int64_t)((nb * (nb - 1) / 2 + nb) * 4 * 64);
+}
+
+int ragged_prepare_emit(const Tree *trees, int32_t ntrees, int32_t max_rows, const int32_t *nodes, RaggedMfma **out, int64_t **frag_off) {
+    *out = nullptr;
+    *frag_off = nullptr;
+    if (ntrees <= 0 || max_rows > RAG_MAX_ROWS) return CSX_OK;
+    RaggedMfma *R = new RaggedMfma();
+    struct Guard {
+        RaggedMfma *R;
+        ~Guard() { ragged_free(R); }
+    } guard{R};
+    CSX_TRY(ragged_skeleton(trees, ntrees, nodes, R));
+    int64_t *off = nullptr;
+    CSX_TRY(dalloc(&off, (size_t)ntrees));
+    RagBases b;
+    for (int c = 0; c <= RAG_CLASSES; c++) {
+        b.start[c] = R->cls_start[c];
+        b.frag[c] = (int64_t)R->cls_frag[c];
+    }
+    hipLaunchKernelGGL(k_rag_fragoff, dim3((unsigned)((ntrees + 255) / 256)), dim3(256), 0, ctx().stream, R->list, ntrees, b, off);
+    if (hipGetLastError() != hipSuccess) {
+        dfree(off);
+        return CSX_ERUNTIME;
+    }
+    guard.R = nullptr;
+    *out = R;
+    *frag_off = off;
+    return CSX_OK;
+}
+
+int ragged_build(const Tree *trees, int32_t ntrees, int32_t max_rows, const int32_t *nodes, const int32_t *ptr, const int32_t *idx,
+                 const double *val, const double *diag, bool reverse, RaggedMfma **out, const Csc *from_factor) {
+    *out = nullptr;
+    if (ntrees <= 0 || max_rows > RAG_MAX_ROWS) return CSX_OK;
+    hipStream_t s = ctx().stream;
+    RaggedMfma *R = new RaggedMfma();
+    struct Guard {
+        RaggedMfma *R;
+        ~Guard() { ragged_free(R); }
+    } guard{R};
+    CSX_TRY(ragged_skeleton(trees, ntrees, nodes, R));
+    DevScope tmp;
+    unsigned long long *cond = nullptr;
+    CSX_TRY(tmp.alloc(&cond, 1));
     CSX_HIP(hipMemsetAsync(cond, 0, sizeof(unsigned long long), s));
     for (int c = 0; c < RAG_CLASSES; c++) {
         const int32_t cnt = R->cls_start[c + 1] - R->cls_start[c];
