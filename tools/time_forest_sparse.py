@@ -33,6 +33,17 @@ Ax = np.tile(bx, nb)
 hA = _csx.new_handle()
 _csx.check(lib.csx_csc_upload(n, n, _csx.pi(Ap), _csx.pi(Ai), _csx.pd(Ax), hA))
 print("n %d nnz %d blocks %d of %d" % (n, len(Ai), nb, bs), flush=True)
+for rep in range(reps):          # round 5: the same as ONE call (csx_cholsol_factor, rounding-equal order: block list + fragments from L's columns)
+    hLf, planf = _csx.new_handle(), _csx.new_handle()
+    _csx.check(lib.csx_csc_invalidate(hA))
+    _csx.sync()
+    t0 = time.perf_counter()
+    _csx.check(lib.csx_cholsol_factor(hA, 0, hLf, planf), "cholsol_factor")
+    _csx.sync()
+    print("csx_cholsol_factor (one call) %.2f ms" % (1e3 * (time.perf_counter() - t0)), flush=True)
+    _csx.free(planf)
+    _csx.free(hLf)
+_csx.check(lib.csx_csc_invalidate(hA))
 for rep in range(reps):
     parent, cp = np.empty(n, np.int32), np.empty(n + 1, np.int32)
     t0 = time.perf_counter()
