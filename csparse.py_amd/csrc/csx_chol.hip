@@ -2863,6 +2863,8 @@ static int cholsol_factor_device(csx_handle_t hA, Csc *A, bool exact, Csc *L, Ch
                     em.frag = Rg->frag;
                     em.frag_off = frag_off;
                     em.cond_bits = (unsigned long long *)(d_flags + 2);
+                    em.list = Rg->list;
+                    for (int c = 0; c <= RAG_CLASSES; c++) em.cls_start[c] = Rg->cls_start[c];
                 }
             }
             const bool emit_any = emit || (emit_ragged && Rg);

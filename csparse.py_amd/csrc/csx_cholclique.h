@@ -54,6 +54,8 @@ struct CliqueEmit {
     const int64_t *frag_off = nullptr;    // blocks of UNEQUAL sizes: frag_off[t] = first double of block t's fragments (csx_trimfma.h:
                                           // ragged_prepare_emit); a block of bs columns then takes ceil(bs / 16) tiles a side, its last
                                           // tile row / column padded with the identity.  null: equal blocks, block t at t * per_block
+    const int32_t *list = nullptr;        // with frag_off: the blocks ordered by size class (ceil(bs / 16) - 1), class c at
+    int32_t cls_start[6] = {0, 0, 0, 0, 0, 0};   // list[cls_start[c] .. cls_start[c + 1]): what the matrix-core block kernel launches by
 };
 // values and row indices of L (L->p = F.cp already in place, L->i / L->x allocated); blocks of at most 64 columns
 // relaxed ("chol.exact" = 0): fused multiply-adds and reciprocal square roots -- L.x equal to the exact kernel's to rounding

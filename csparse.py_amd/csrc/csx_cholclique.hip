@@ -793,20 +793,26 @@ constexpr int CM_WAVES = 4;
 constexpr int CM_RS = 34;           // doubles per LDS row of [U | inv(U')] (32 used)
 constexpr int CM_TS = 17;           // doubles per LDS row of the transposed diagonal tile
 
-template <int NB, bool EMIT>
+// RAGGED (blocks of UNEQUAL sizes, launched per size class with `list`): a block of bs columns, 16 (NB - 1) < bs <= 16 NB, is factored
+// as a block of 16 NB columns whose last rows / columns are the identity: loads past the block return zero (the range check), the
+// padded diagonal is set to one, the stores and the pivot test stop at bs, the fragments go to frag_off[t] (csx_trimfma.h's layout).
+template <int NB, bool EMIT, bool RAGGED = false>
 __global__ __launch_bounds__(64 * CM_WAVES, 2) void k_chol_block_mfma(const int32_t *__restrict__ start, int32_t nblocks,
                                                                      const int32_t *__restrict__ Ap, const double *__restrict__ Ax,
                                                                      const int32_t *__restrict__ Lp, int32_t *__restrict__ Li,
-                                                                     double *__restrict__ Lx, int *notspd, CliqueEmit em) {
+                                                                     double *__restrict__ Lx, int *notspd, CliqueEmit em,
+                                                                     const int32_t *__restrict__ list) {
     typedef double f4 __attribute__((ext_vector_type(4)));
     constexpr int BS = 16 * NB;
     __shared__ __attribute__((aligned(16))) double s_rows[CM_WAVES][16 * CM_RS];
     __shared__ double s_tile[CM_WAVES][16 * CM_TS];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t t = (int64_t)blockIdx.x * CM_WAVES + w;
-    if (t >= nblocks) return;      // no workgroup barrier below
+    const int64_t q = (int64_t)blockIdx.x * CM_WAVES + w;
+    if (q >= nblocks) return;      // no workgroup barrier below
+    const int64_t t = RAGGED ? (int64_t)__builtin_amdgcn_readfirstlane(list[q]) : q;
     const int32_t c0 = __builtin_amdgcn_readfirstlane(start[t]);
+    const int32_t bs = RAGGED ? __builtin_amdgcn_readfirstlane(start[t + 1]) - c0 : BS;
     const int c = lane & 15, rq = lane >> 4;
     double *rows = s_rows[w], *tt = s_tile[w];
     // ---- load: tile (k, i), k <= i: element (16 k + rq + 4 r, 16 i + c) of the upper triangle = entry (that row) of column 16 i + c
@@ -814,29 +820,33 @@ __global__ __launch_bounds__(64 * CM_WAVES, 2) void k_chol_block_mfma(const int3
     f4 T[NB][NB];
     {
         const int64_t a0 = Ap[c0];
-        const __amdgpu_buffer_rsrc_t rx = cq_rsrc(Ax + a0, (int)((int64_t)Ap[c0 + BS] - a0) * 8);
+        const __amdgpu_buffer_rsrc_t rx = cq_rsrc(Ax + a0, (int)((int64_t)Ap[c0 + bs] - a0) * 8);
 #pragma unroll
         for (int i = 0; i < NB; i++) {
-            const uint32_t colo = (uint32_t)(Ap[c0 + 16 * i + c] - a0);
+            const bool col_in = !RAGGED || 16 * i + c < bs;                  // (a column of the padding has no entries)
+            const uint32_t colo = col_in ? (uint32_t)(Ap[c0 + 16 * i + c] - a0) : 0u;
 #pragma unroll
             for (int k = 0; k <= i; k++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int row = 16 * k + rq + 4 * r;
                     // (below the diagonal of a diagonal tile: past the upper part of the column -- not read, zero)
-                    const bool up = k < i || rq + 4 * r <= c;
+                    const bool up = (k < i || rq + 4 * r <= c) && col_in;
                     T[k][i][r] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rx, up ? (colo + row) * 8u : 0xfffffff8u, 0, 0));
+                    if (RAGGED && k == i && k == NB - 1 && rq + 4 * r == c && 16 * i + c >= bs) T[k][i][r] = 1.0;   // the padding's diagonal
                 }
         }
     }
     const int64_t lbase = Lp[c0];
-    const __amdgpu_buffer_rsrc_t rl = cq_rsrc(Lx + lbase, (BS * (BS + 1) / 2) * 8);
-    const __amdgpu_buffer_rsrc_t ri = cq_rsrc(Li + (EMIT ? 0 : lbase), EMIT ? 0 : (BS * (BS + 1) / 2) * 4);
+    const __amdgpu_buffer_rsrc_t rl = cq_rsrc(Lx + lbase, (bs * (bs + 1) / 2) * 8);
+    const __amdgpu_buffer_rsrc_t ri = cq_rsrc(Li + (EMIT ? 0 : lbase), EMIT ? 0 : (bs * (bs + 1) / 2) * 4);
     double *frag = nullptr;
     if (EMIT) {
-        frag = em.frag + (size_t)t * (size_t)(clique_frags_per_block(NB) * 64) + lane;
-        if (lane < BS) em.tree_nodes[c0 + lane] = c0 + lane;
-        if (lane == 0) em.trees[t] = Tree{c0, BS};
+        frag = em.frag + (em.frag_off ? (size_t)em.frag_off[t] : (size_t)t * (size_t)(clique_frags_per_block(NB) * 64)) + lane;
+        if (em.trees) {
+            if (lane < bs) em.tree_nodes[c0 + lane] = c0 + lane;
+            if (lane == 0) em.trees[t] = Tree{c0, bs};
+        }
     }
     double lmax = 0.0, wmax = 0.0;
 #pragma unroll
@@ -858,7 +868,7 @@ __global__ __launch_bounds__(64 * CM_WAVES, 2) void k_chol_block_mfma(const int3
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             const double d = cq_bcast(a[j], j);
-            if (d <= 0.0 && lane == 0) atomicMin(notspd, c0 + 16 * k + j);   // csparse.py:612
+            if (d <= 0.0 && lane == 0 && 16 * k + j < bs) atomicMin(notspd, c0 + 16 * k + j);   // csparse.py:612
             const double y = cq_rsqrt(d);
             double tv = a[j] * y;                                    // row j of [U | inv(U')], finished
             if (lane < j) tv = 0.0;                                  // (left of the diagonal: eliminated)
@@ -914,11 +924,11 @@ __global__ __launch_bounds__(64 * CM_WAVES, 2) void k_chol_block_mfma(const int3
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int J = 16 * k + rq + 4 * r;
-            const int colbase = J * BS - J * (J - 1) / 2 - J;          // entry (I, J) of the packed block: colbase + I
+            const int colbase = J * bs - J * (J - 1) / 2 - J;          // entry (I, J) of the packed block: colbase + I
 #pragma unroll
             for (int i = k; i < NB; i++) {
                 const int I = 16 * i + c;
-                const bool in = I >= J;
+                const bool in = I >= J && (!RAGGED || I < bs);         // (J <= I < bs)
                 const double xv = T[k][i][r];
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(cq_u32x2, xv), rl, in ? (uint32_t)(colbase + I) * 8u : 0xfffffff8u, 0, 0);
                 if (!EMIT) __builtin_amdgcn_raw_buffer_store_b32((unsigned int)(c0 + I), ri, in ? (uint32_t)(colbase + I) * 4u : 0xfffffffcu, 0, 0);
@@ -976,10 +986,10 @@ int chol_clique_numeric(const Csc *A, const CliqueForest &F, Csc *L, int *d_nots
 #define CSX_CM(NB)                                                                                                                        \
     if (emit)                                                                                                                             \
         hipLaunchKernelGGL((k_chol_block_mfma<NB, true>), g2, dim3(64 * CM_WAVES), 0, s, F.start, F.nblocks, A->p, A->x, L->p, L->i, L->x, \
-                           d_notspd, em);                                                                                                 \
+                           d_notspd, em, nullptr);                                                                                        \
     else                                                                                                                                  \
         hipLaunchKernelGGL((k_chol_block_mfma<NB, false>), g2, dim3(64 * CM_WAVES), 0, s, F.start, F.nblocks, A->p, A->x, L->p, L->i, L->x, \
-                           d_notspd, em)
+                           d_notspd, em, nullptr)
         switch (F.max_bs / 16) {
             case 1: CSX_CM(1); break;
             case 2: CSX_CM(2); break;
@@ -988,6 +998,27 @@ int chol_clique_numeric(const Csc *A, const CliqueForest &F, Csc *L, int *d_nots
         }
 #undef CSX_CM
         CSX_LAUNCH_CHECK();
+        return CSX_OK;
+    }
+    if (relaxed && !F.sparse && F.dense_in_front && ctx().opt.chol_exact == 0 && emit && emit->frag_off && emit->list) {
+        // dense blocks of UNEQUAL sizes (csx_cholsol_factor's size classes): the same kernel per class, padded with the identity
+        for (int c = 0; c < 4; c++) {
+            const int32_t cnt = emit->cls_start[c + 1] - emit->cls_start[c];
+            if (cnt <= 0) continue;
+            const dim3 g3((unsigned)((cnt + CM_WAVES - 1) / CM_WAVES));
+            const int32_t *lst = emit->list + emit->cls_start[c];
+#define CSX_CMR(NB)                                                                                                                    \
+    hipLaunchKernelGGL((k_chol_block_mfma<NB, true, true>), g3, dim3(64 * CM_WAVES), 0, s, F.start, cnt, A->p, A->x, L->p, L->i, L->x, \
+                       d_notspd, em, lst)
+            switch (c) {
+                case 0: CSX_CMR(1); break;
+                case 1: CSX_CMR(2); break;
+                case 2: CSX_CMR(3); break;
+                default: CSX_CMR(4); break;
+            }
+#undef CSX_CMR
+            CSX_LAUNCH_CHECK();
+        }
         return CSX_OK;
     }
     if (relaxed && A->nnz < (1 << 29)) {      // "chol.exact" = 0: the rounding-equal arithmetic (the common shapes; others stay exact)

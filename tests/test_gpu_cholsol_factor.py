@@ -352,3 +352,48 @@ def test_matrix_core_block_kernel_at_1m_rows(cs):
         assert float(np.max(np.abs(A @ X[:, r] - b))) <= 1e-12 * 128.0
     for h in (plan0, hL0, outs[0][1], outs[0][0], outs[1][1], outs[1][0], hA):
         _csx.free(h)
+
+
+def test_matrix_core_block_kernel_on_unequal_cliques(cs):
+    """"chol.exact" = 0 through csx_cholsol_factor on dense blocks of 1 .. 64 columns: the blocked factorisation per size class
+    (a block padded with the identity to whole tiles), the size-class fragments written by it.  L.p / L.i the oracle's, L.x within
+    1e-13 normwise, the plan on the matrix cores (path 5), solutions within 1e-10 of cs_lsolve + cs_ltsolve on the oracle's L;
+    the exact order on the same plan bit-identical on ITS L; a non-positive pivot in a padded block reported."""
+    import _csx
+    lib = _csx.lib()
+    rng = np.random.default_rng(17)
+    sizes = list(rng.integers(1, 65, 220)) + [64, 1, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63]
+    n, Ap, Ai, Ax = _blocks(sizes, 41)
+    A = cs.cs_pin(_host_cs(cs, n, n, Ap, Ai, Ax))
+    parent, cp = CO.schol(n, Ap, Ai)
+    Lp, Li, Lx = CO.chol(n, Ap, Ai, Ax, parent, cp)
+    with _csx.option("chol.exact", 0):
+        st, hL, plan, path = _fused(A, False)
+    assert st == _csx.OK and path == 1
+    assert _info(plan)[0] == 5
+    k = 70
+    B = synth.rhs(n, k, 6)
+    X = _solve(plan, B)
+    fp, fi, fx = _download(hL)
+    assert fp.tolist() == Lp.tolist() and fi.tolist() == Li.tolist()
+    assert fx.tobytes() != Lx.tobytes() and TOL.normwise(fx, Lx) <= 1e-13
+    big = np.abs(Lx) > 1e-6 * np.abs(Lx).max()
+    assert TOL.componentwise(fx[big], Lx[big]) <= 1e-12
+    for r in (0, 35, k - 1):
+        y = CO.lsolve(n, Lp, Li, Lx, B[:, r])
+        ref = CO.ltsolve(n, Lp, Li, Lx, y)
+        assert TOL.componentwise(X[:, r], ref, TOL.cholsolve_terms(n, Lp, Li, Lx, y, ref)) <= TOL.X_RTOL
+    _csx.check(lib.csx_cholsol_set_order(plan, 1))
+    Xe = _solve(plan, B)
+    for r in (0, k - 1):
+        assert Xe[:, r].tobytes() == CO.ltsolve(n, fp, fi, fx, CO.lsolve(n, fp, fi, fx, B[:, r])).tobytes()
+    # not positive definite, in a block that does not fill its last tile
+    b = int(np.argmax(np.asarray(sizes) == 49))
+    c = int(sum(sizes[:b])) + 40
+    Ax2 = Ax.copy()
+    Ax2[Ap[c] + int(np.nonzero(Ai[Ap[c]:Ap[c + 1]] == c)[0][0])] = -5.0
+    A2 = cs.cs_pin(_host_cs(cs, n, n, Ap, Ai, Ax2))
+    with _csx.option("chol.exact", 0):
+        assert _fused(A2, False)[0] == _csx.ENOTSPD
+    for h in (plan, hL):
+        _csx.free(h)

@@ -2,7 +2,7 @@
 in general): block-diagonal SPD, block sizes drawn uniformly from [lo, hi], about n rows.  csx_cholsol_factor (one call), then
 the solve of 128 right-hand sides in the exact order (fused per-tree kernel) and in the rounding-equal order (csx_trimfma.hip:
 trees made dense by size class on the matrix cores), each column of a sample against the other order.
-usage: time_ragged_cliques.py [n] [lo] [hi] [nrhs]"""
+usage: time_ragged_cliques.py [n] [lo] [hi] [nrhs] [chol.exact 1/0]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "csparse.py_amd"))
@@ -15,6 +15,7 @@ n_want = int(sys.argv[1]) if len(sys.argv) > 1 else 5000000
 lo = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 hi = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 k = int(sys.argv[4]) if len(sys.argv) > 4 else 128
+_csx.check(lib.csx_set_option(b"chol.exact", int(sys.argv[5]) if len(sys.argv) > 5 else 1))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import synth
 t0 = time.perf_counter()
