@@ -1153,7 +1153,7 @@ def cholsol_factor(A, order=0, exact=None):
       supernodal schedule.  (G-spd, 128 right-hand sides: 2.4 ms against 4.8; bcsstk16: 0.4 ms against 6.6.)
     exact=True: every solve, blocks too, bit-identical to the reference's order.   exact=False: every solve rounding-equal.
     cs_cholsol, the reference's own driver, is always exact."""
-    if not CS_CSC(A):
+    if not CS_CSC(A) or A.m != A.n:
         return None
     first_plan = None
     if order == 0 and A.m == A.n and _meta(A)[1]:

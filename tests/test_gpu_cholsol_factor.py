@@ -397,3 +397,39 @@ def test_matrix_core_block_kernel_on_unequal_cliques(cs):
         assert _fused(A2, False)[0] == _csx.ENOTSPD
     for h in (plan, hL):
         _csx.free(h)
+
+
+def test_edge_shapes_through_the_one_call(cs):
+    """n = 0, n = 1, a diagonal matrix (every block one column), a matrix with no entries, a rectangular one, a missing diagonal:
+    the drop-in's conventions (True / False / None) and the reference's arithmetic on each."""
+    E = cs.cs_spalloc(0, 0, 0, True, False)
+    E.p = [0]
+    assert cs.cs_cholsol(0, E, []) is True
+    F0 = cs.cholsol_factor(E)
+    assert F0 is not None and F0.solve([]) is True
+    one = cs.cs_spalloc(1, 1, 1, True, False)
+    one.p, one.i, one.x = [0, 1], [0], [4.0]
+    b = [6.0]
+    assert cs.cs_cholsol(0, one, b) is True and b == [1.5]
+    F1 = cs.cholsol_factor(one)
+    assert F1.L.p == [0, 1] and F1.L.i[:1] == [0] and F1.L.x[:1] == [2.0]
+    n = 300
+    D = cs.cs_spalloc(n, n, n, True, False)
+    D.p, D.i, D.x = list(range(n + 1)), list(range(n)), [float(2 + (j % 5)) for j in range(n)]
+    rhs = [float(1 + j) for j in range(n)]
+    want = [(rhs[j] / (D.x[j] ** 0.5)) / (D.x[j] ** 0.5) for j in range(n)]          # cs_lsolve then cs_ltsolve on L = sqrt(D)
+    x = list(rhs)
+    assert cs.cs_cholsol(0, D, x) is True and x == want
+    FD = cs.cholsol_factor(D)
+    Bk = cs.dvec(np.repeat(np.asarray(rhs)[:, None], 20, axis=1))
+    assert FD.solve(Bk) is True
+    assert np.max(np.abs(Bk.numpy().reshape(n, 20)[:, 7] - np.asarray(want)) / np.asarray(want)) <= 1e-14
+    Z = cs.cs_spalloc(5, 5, 1, True, False)          # no entries at all: the first pivot is 0 -> not positive definite
+    Z.p, Z.i, Z.x = [0] * 6, [0], [0.0]
+    assert cs.cs_cholsol(0, Z, [1.0] * 5) is False and cs.cholsol_factor(Z) is None
+    R = cs.cs_spalloc(3, 2, 2, True, False)
+    R.p, R.i, R.x = [0, 1, 2], [0, 1], [1.0, 1.0]
+    assert cs.cholsol_factor(R) is None
+    M = cs.cs_spalloc(3, 3, 4, True, False)          # column 1 has no diagonal entry
+    M.p, M.i, M.x = [0, 1, 2, 4], [0, 0, 1, 2], [4.0, 1.0, 1.0, 9.0]
+    assert cs.cs_cholsol(0, M, [1.0, 1.0, 1.0]) is False
