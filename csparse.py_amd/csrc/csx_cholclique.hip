@@ -52,19 +52,42 @@ __device__ __forceinline__ int4 cq_load4(const int32_t *__restrict__ idx, int32_
     return v;
 }
 
+// (round 5: CQ_MIN_COLS consecutive columns to a group of 16 lanes, the first 64 entries of all of them requested before any is looked
+// at: with one column per group a wave had ONE 1 KB load in flight in front of ~60 instructions of shuffles -- 2.9 TB/s, 0.44 ms of the
+// 2.5 ms factor call at 5M columns)
+constexpr int CQ_MIN_COLS = 4;
 __global__ __launch_bounds__(256) void k_clique_min(int32_t n, int32_t nnz, const int32_t *__restrict__ Ap,
                                                     const int32_t *__restrict__ Ai, int32_t *__restrict__ u, int *flags) {
     const int t = threadIdx.x & 15;
-    const int64_t k64 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    const int32_t k = (int32_t)(k64 < n ? k64 : n - 1);          // the spare groups of the last wave repeat column n - 1
-    const int32_t b = Ap[k], e = Ap[k + 1];
+    const int64_t g64 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    int32_t kk[CQ_MIN_COLS], bb[CQ_MIN_COLS], ee[CQ_MIN_COLS];
+    int4 first4[CQ_MIN_COLS];
+#pragma unroll
+    for (int q = 0; q < CQ_MIN_COLS; q++) {
+        const int64_t k64 = g64 * CQ_MIN_COLS + q;
+        kk[q] = (int32_t)(k64 < n ? k64 : n - 1);                // the spare groups / columns of the last wave repeat column n - 1
+        bb[q] = Ap[kk[q]];
+        ee[q] = Ap[kk[q] + 1];
+    }
+#pragma unroll
+    for (int q = 0; q < CQ_MIN_COLS; q++) {
+        const int32_t p = (bb[q] & ~3) + 4 * t;
+        first4[q] = make_int4(0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff);
+        if (p < ee[q]) first4[q] = cq_load4(Ai, p, nnz);
+    }
+#pragma unroll
+    for (int q = 0; q < CQ_MIN_COLS; q++) {
+    const int64_t k64 = g64 * CQ_MIN_COLS + q;
+    const int32_t k = kk[q];
+    const int32_t b = bb[q], e = ee[q];
     int32_t mn = k, run = -1;          // smallest upper row; largest upper row of the steps before
     int32_t nup = 0, lastpos = -1;     // upper entries of this lane; position (in the column) of its last one
     bool bad = false;
     for (int32_t p0 = b & ~3; p0 < e; p0 += 64) {
         const int32_t p = p0 + 4 * t;
         int4 v = make_int4(0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff);
-        if (p < e) v = cq_load4(Ai, p, nnz);
+        if (p0 == (b & ~3)) v = first4[q];
+        else if (p < e) v = cq_load4(Ai, p, nnz);
         const int32_t r[4] = {v.x, v.y, v.z, v.w};
         int32_t lmax = -1, first = 0x7fffffff;   // of this lane's upper entries
 #pragma unroll
@@ -103,6 +126,7 @@ __global__ __launch_bounds__(256) void k_clique_min(int32_t n, int32_t nnz, cons
     // the column IS row u[k] + t, and the block kernel need not read the row indices at all
     if (nup != k - mn + 1 || lastpos != nup - 1) cq_raise(&flags[3]);
     if (t == 0 && k64 < n) u[k] = mn;
+    }
 }
 
 // thread per column: the rule above (flags[1] |= broken), block starts, parent, the last column of every block
@@ -292,7 +316,7 @@ int clique_forest(const Csc *A, CliqueForest *F, bool *ok) {
     // waited after the rule, after the block count and after lnz).  A matrix that fails the rule has paid for two scans and the counts
     // in vain (0.2 ms at 5M columns) and goes on to the second rule below.
     hipLaunchKernelGGL(k_cq_init, dim3(1), dim3(64), 0, s, flags);
-    hipLaunchKernelGGL(k_clique_min, dim3(blocks_for((int64_t)n * 16)), dim3(256), 0, s, n, A->nnz, A->p, A->i, u, flags);
+    hipLaunchKernelGGL(k_clique_min, dim3(blocks_for(((int64_t)n + CQ_MIN_COLS - 1) / CQ_MIN_COLS * 16)), dim3(256), 0, s, n, A->nnz, A->p, A->i, u, flags);
     hipLaunchKernelGGL(k_clique_mark, dim3(blocks_for(n)), dim3(256), 0, s, n, u, is_start, F->parent, end_of, flags);
     CSX_TRY(scan_exclusive_i32(is_start, block_id, n, nullptr));
     hipLaunchKernelGGL(k_clique_counts, dim3(std::min(blocks_for(n), 1024u)), dim3(256), 0, s, n, u, is_start, block_id, end_of, count,
