@@ -1057,7 +1057,12 @@ struct CholPlan {
     int32_t *rev_pos = nullptr;
     int dense_bs = 0;  // > 0: every tree is a dense lower-triangular block of this size on contiguous rows
     double *dense_b = nullptr;  // dense only: backward program with every row reversed (sweep-position order)
-    double *frag_f = nullptr;   // dense, block size 16/32/64: MFMA fragments (k_mfma_frags); the backward sweep reads them transposed
+    // dense, block size 16/32/64, the matrix cores' operands: the inverses W_ii of the diagonal tiles as A fragments (NB tiles of 256
+    // doubles per block; the backward sweep reads them transposed) -- and the off-diagonal tiles, which are L's own numbers and are
+    // read where they lie: in L.x (a plan on consecutive columns of L: `clique`), or in `lcopy`, the blocks' packed columns copied
+    // out of the programs (a plan the general analysis made: it never assumed an order of the rows inside a column of L)
+    double *frag_f = nullptr;
+    double *lcopy = nullptr;
     // exact (default): every right-hand side is solved in the reference's operation order -- substitution
     // kernels, level walker in source order: bit-identical to cs_lsolve + cs_ltsolve.  !exact
     // (csx_cholsol_set_order(plan, 0)): results equal to rounding; dense 16/32/64 blocks go to the matrix cores
@@ -1129,6 +1134,7 @@ void free_cholplan(CholPlan *P) {
     dfree(P->rev_pos);
     dfree(P->dense_b);
     dfree(P->frag_f);
+    dfree(P->lcopy);
     delete P;
 }
 
@@ -1784,14 +1790,13 @@ __global__ __launch_bounds__(256, 3) void k_cholsol_dense_exact_dpp(const Tree *
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2w __attribute__((ext_vector_type(2)));
 
-template <int NB>
-constexpr int mfma_frags() { return (NB * (NB - 1) / 2 + NB) * 4; }
-
-// one wave per tree: fragments of -L_ij / W_ii (forward) and -L_ji' / W_ii' (backward) in use order
+// one wave per tree: the A fragments of W_ii = inv(L_ii) (tile i of the block at Wt + (t NB + i) 256: k-step sx, lane (m, kq) holds
+// W_ii[m][4 sx + kq]) and, when `lcopy` is given, the block's packed columns (diagonal first, rows ascending: L.x's own layout, block
+// t at t BS (BS + 1) / 2), both from the plan's forward programs
 template <int NB>
 __global__ __launch_bounds__(64) void k_mfma_frags(const Tree *__restrict__ trees, const int32_t *__restrict__ f_ptr,
                                                    const double *__restrict__ f_val, const double *__restrict__ diagk,
-                                                   double *__restrict__ frag_f, unsigned long long *cond_bits) {
+                                                   double *__restrict__ Wt, double *__restrict__ lcopy, unsigned long long *cond_bits) {
     constexpr int BS = 16 * NB;
     __shared__ double Ls[BS][BS + 1];
     __shared__ double W[NB][16][17];
@@ -1833,16 +1838,14 @@ __global__ __launch_bounds__(64) void k_mfma_frags(const Tree *__restrict__ tree
     }
     __syncthreads();
     const int m = lane & 15, kq = lane >> 4;
-    double *F = frag_f + (size_t)t * mfma_frags<NB>() * 64 + lane;
-    int f = 0;
-    for (int i = 0; i < NB; i++) {
-        for (int j = 0; j < i; j++)
-            for (int sx = 0; sx < 4; sx++) F[64 * f++] = -Ls[16 * i + m][16 * j + 4 * sx + kq];
-        for (int sx = 0; sx < 4; sx++) F[64 * f++] = W[i][m][4 * sx + kq];
+    double *F = Wt + (size_t)t * (NB * 256) + lane;
+    for (int i = 0; i < NB; i++)
+        for (int sx = 0; sx < 4; sx++) F[(i * 4 + sx) * 64] = W[i][m][4 * sx + kq];
+    if (lcopy) {
+        double *C = lcopy + (size_t)t * (BS * (BS + 1) / 2);
+        for (int c = 0; c < BS; c++)                       // column c: rows c .. BS - 1, contiguous
+            if (lane >= c && lane < BS) C[c * BS - c * (c - 1) / 2 + lane - c] = Ls[lane][c];
     }
-    // (The backward sweep needs the TRANSPOSED tiles -L_ji' and W_ii' as A fragments.  They are the same 256 numbers
-    // per tile: k_cholsol_mfma reads them out of these fragments with the roles of lane and k-step exchanged, instead
-    // of a second, transposed copy -- half the fragment bytes, 1.5 GB less traffic per batch at 5M rows.)
     // largest |W| |L| over the forest, as ordered bits of a non-negative double
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
@@ -1852,11 +1855,19 @@ __global__ __launch_bounds__(64) void k_mfma_frags(const Tree *__restrict__ tree
     if (lane == 0) atomicMax(cond_bits, (unsigned long long)__double_as_longlong(lmax * wmax));
 }
 
+// The solve.  Off-diagonal operands are read where the factorisation left them (round 5; until then a second, re-arranged and negated
+// copy of them was written beside L.x -- 1 GB per factorisation at 5M rows, a fifth of csx_cholsol_factor's traffic): the A fragment
+// of -L_ij for lane (m, kq), k-step sx, is -L(16 i + m, 16 j + 4 sx + kq) -- in the packed columns the 16 lanes of one kq read 128
+// contiguous bytes of one column, the four kq four neighbouring columns; the backward sweep's -L_ji' takes L(16 j + 4 sx + kq, 16 i + m):
+// lane m its own column, the four kq four consecutive rows of it.  Lv: the packed columns, block t at Lp[its first column] (L.x
+// itself) or, without Lp, at t BS (BS + 1) / 2 (the plan's copy).  The sign is flipped in the register.
 template <int NB>
 __global__ __launch_bounds__(256, 2) void k_cholsol_mfma(const Tree *__restrict__ trees, int32_t ntrees,
                                                       const int32_t *__restrict__ nodes, const int32_t *__restrict__ perm,
-                                                      const double *__restrict__ frag_f, double *B, int32_t nrhs,
+                                                      const int32_t *__restrict__ Lp, const double *__restrict__ Lv,
+                                                      const double *__restrict__ Wt, double *B, int32_t nrhs,
                                                       int32_t chunks) {
+    constexpr int BS = 16 * NB;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t task = (int64_t)blockIdx.x * 4 + w;
@@ -1907,20 +1918,20 @@ __global__ __launch_bounds__(256, 2) void k_cholsol_mfma(const Tree *__restrict_
 #pragma unroll
                 for (int r = 0; r < 4; r++) X[i][c][r] = B[roff[i][r] + cidx[c]];
     }
-    const double *F = frag_f + (size_t)t * mfma_frags<NB>() * 64 + lane;
+    // entry (R, C), R >= C, of the block's packed columns: C BS - C (C - 1) / 2 + R - C
+    const double *Lb = Lv + (Lp ? (size_t)Lp[nodes[first]] : (size_t)t * (BS * (BS + 1) / 2));
+    auto col_at = [](int C) { return C * BS - C * (C - 1) / 2 - C; };
+    const double *F = Wt + (size_t)t * (NB * 256) + lane;
     // Transposed read of a stored tile: the A fragment of tile' for (lane = (m, kq), k-step sx) is element (4 sx + kq, m)
-    // of the tile, which the forward layout keeps in k-step m >> 2 at lane (m & 3) * 16 + 4 sx + kq.  tile_at(a, b):
-    // tiles of block row a come in the order (a, 0) .. (a, a - 1), W_a.
-    const double *Ft = frag_f + (size_t)t * mfma_frags<NB>() * 64 + (size_t)(col >> 2) * 64 + (col & 3) * 16 + rq;
-    auto tile_at = [](int a, int b) { return (a * (a + 1) / 2 + b) * 4; };   // first of the tile's four fragments
-    int f = 0;
+    // of the tile, which the forward layout keeps in k-step m >> 2 at lane (m & 3) * 16 + 4 sx + kq.
+    const double *Ft = Wt + (size_t)t * (NB * 256) + (size_t)(col >> 2) * 64 + (col & 3) * 16 + rq;
 #pragma unroll
     for (int i = 0; i < NB; i++) {
 #pragma unroll
         for (int j = 0; j < i; j++)
 #pragma unroll
             for (int sx = 0; sx < 4; sx++) {
-                const double a = F[64 * f++];
+                const double a = -Lb[col_at(16 * j + 4 * sx + rq) + 16 * i + col];
 #pragma unroll
                 for (int c = 0; c < 4; c++) X[i][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[j][c][sx], X[i][c], 0, 0, 0);
             }
@@ -1929,7 +1940,7 @@ __global__ __launch_bounds__(256, 2) void k_cholsol_mfma(const Tree *__restrict_
         for (int c = 0; c < 4; c++) Y[c] = f64x4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int sx = 0; sx < 4; sx++) {
-            const double a = F[64 * f++];
+            const double a = F[(i * 4 + sx) * 64];
 #pragma unroll
             for (int c = 0; c < 4; c++) Y[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[i][c][sx], Y[c], 0, 0, 0);
         }
@@ -1942,7 +1953,7 @@ __global__ __launch_bounds__(256, 2) void k_cholsol_mfma(const Tree *__restrict_
         for (int j = i + 1; j < NB; j++)
 #pragma unroll
             for (int sx = 0; sx < 4; sx++) {
-                const double a = Ft[(size_t)tile_at(j, i) * 64 + 4 * sx];   // -L_ji' from the stored -L_ji
+                const double a = -Lb[col_at(16 * i + col) + 16 * j + 4 * sx + rq];   // -L_ji'
 #pragma unroll
                 for (int c = 0; c < 4; c++) X[i][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[j][c][sx], X[i][c], 0, 0, 0);
             }
@@ -1951,7 +1962,7 @@ __global__ __launch_bounds__(256, 2) void k_cholsol_mfma(const Tree *__restrict_
         for (int c = 0; c < 4; c++) Y[c] = f64x4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int sx = 0; sx < 4; sx++) {
-            const double a = Ft[(size_t)tile_at(i, i) * 64 + 4 * sx];       // W_ii' from the stored W_ii
+            const double a = Ft[(size_t)(i * 4) * 64 + 4 * sx];                      // W_ii' from the stored W_ii
 #pragma unroll
             for (int c = 0; c < 4; c++) Y[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[i][c][sx], Y[c], 0, 0, 0);
         }
@@ -2337,20 +2348,22 @@ static int cholsol_build_mfma(CholPlan *P) {
     P->mfma_tried = true;
     hipStream_t s = ctx().stream;
     const int nb16 = P->dense_bs / 16;
-    const size_t nfrag = (size_t)(nb16 * (nb16 - 1) / 2 + nb16) * 4;
+    const int32_t bs = P->dense_bs;
     unsigned long long *cond = nullptr, hcond = 0;
-    double *ff = nullptr;
+    double *ff = nullptr, *lc = nullptr;
     int st = dalloc(&cond, 1);
-    if (st == CSX_OK) st = dalloc(&ff, (size_t)P->ntrees * nfrag * 64);
+    if (st == CSX_OK) st = dalloc(&ff, (size_t)P->ntrees * nb16 * 256);
+    // (a plan on consecutive columns of L reads the off-diagonal tiles in L.x; the general analysis' plan gets a packed copy)
+    if (st == CSX_OK && !P->clique) st = dalloc(&lc, (size_t)P->ntrees * (bs * (bs + 1) / 2));
     if (st == CSX_OK && hipMemsetAsync(cond, 0, sizeof(unsigned long long), s) != hipSuccess) st = CSX_ERUNTIME;
     if (st == CSX_OK) {
         const dim3 g((unsigned)P->ntrees);
         if (nb16 == 1)
-            hipLaunchKernelGGL(k_mfma_frags<1>, g, dim3(64), 0, s, P->trees, P->f_ptr, P->f_val, P->diagk, ff, cond);
+            hipLaunchKernelGGL(k_mfma_frags<1>, g, dim3(64), 0, s, P->trees, P->f_ptr, P->f_val, P->diagk, ff, lc, cond);
         else if (nb16 == 2)
-            hipLaunchKernelGGL(k_mfma_frags<2>, g, dim3(64), 0, s, P->trees, P->f_ptr, P->f_val, P->diagk, ff, cond);
+            hipLaunchKernelGGL(k_mfma_frags<2>, g, dim3(64), 0, s, P->trees, P->f_ptr, P->f_val, P->diagk, ff, lc, cond);
         else
-            hipLaunchKernelGGL(k_mfma_frags<4>, g, dim3(64), 0, s, P->trees, P->f_ptr, P->f_val, P->diagk, ff, cond);
+            hipLaunchKernelGGL(k_mfma_frags<4>, g, dim3(64), 0, s, P->trees, P->f_ptr, P->f_val, P->diagk, ff, lc, cond);
         if (hipGetLastError() != hipSuccess ||
             hipMemcpyAsync(&hcond, cond, sizeof hcond, hipMemcpyDeviceToHost, s) != hipSuccess ||
             hipStreamSynchronize(s) != hipSuccess)
@@ -2362,8 +2375,10 @@ static int cholsol_build_mfma(CholPlan *P) {
     P->mfma_growth = growth;
     if (st == CSX_OK && growth <= MFMA_GROWTH_LIMIT) {   // (a NaN fails the comparison: substitution stays)
         P->frag_f = ff;
+        P->lcopy = lc;
     } else {
         dfree(ff);
+        dfree(lc);
     }
     return st;
 }
@@ -2624,18 +2639,20 @@ static int cholsol_solve(CholPlan *P, double *B, int32_t nrhs) {
             const int64_t tasks = (int64_t)P->ntrees * chunks;
             const dim3 grid((unsigned)((tasks + 3) / 4));
             if (P->frag_f) {
+                const int32_t *lp = P->lcopy ? nullptr : P->L->p;
+                const double *lv = P->lcopy ? P->lcopy : P->L->x;
                 switch (P->dense_bs) {
                     case 16:
                         hipLaunchKernelGGL(k_cholsol_mfma<1>, grid, dim3(256), 0, s, P->trees, P->ntrees, P->tree_nodes,
-                                           P->perm, P->frag_f, B, nrhs, chunks);
+                                           P->perm, lp, lv, P->frag_f, B, nrhs, chunks);
                         break;
                     case 32:
                         hipLaunchKernelGGL(k_cholsol_mfma<2>, grid, dim3(256), 0, s, P->trees, P->ntrees, P->tree_nodes,
-                                           P->perm, P->frag_f, B, nrhs, chunks);
+                                           P->perm, lp, lv, P->frag_f, B, nrhs, chunks);
                         break;
                     default:
                         hipLaunchKernelGGL(k_cholsol_mfma<4>, grid, dim3(256), 0, s, P->trees, P->ntrees, P->tree_nodes,
-                                           P->perm, P->frag_f, B, nrhs, chunks);
+                                           P->perm, lp, lv, P->frag_f, B, nrhs, chunks);
                         break;
                 }
                 CSX_LAUNCH_CHECK();
@@ -2874,8 +2891,7 @@ static int cholsol_factor_device(csx_handle_t hA, Csc *A, bool exact, Csc *L, Ch
                 *Pout = P;            // (the caller frees it on any error)
                 P->n = n;
                 P->L = L;
-                const size_t per_block = (size_t)clique_frags_per_block(bs / 16) * 64;
-                CSX_TRY(dalloc(&P->frag_f, (size_t)F.nblocks * per_block));
+                CSX_TRY(dalloc(&P->frag_f, (size_t)F.nblocks * (size_t)(bs / 16) * 256));   // the W tiles; the rest is L.x
                 CSX_TRY(dalloc(&P->trees, (size_t)F.nblocks));
                 CSX_TRY(dalloc(&P->tree_nodes, (size_t)n));
                 em.frag = P->frag_f;

@@ -41,19 +41,20 @@ int clique_matches_begin(const CliqueForest &F, const int32_t *parent, const int
 int clique_matches_run(CliqueCompare *c);
 int clique_matches_end(CliqueCompare *c, bool *same);
 // What the block kernel can write BESIDE L.x while it has a finished block in registers (csx_cholsol_factor: factor -> plan in one
-// kernel instead of k_clique_factor_shape + k_clique_plan + k_mfma_frags reading L back): the matrix-core solve's operands for a forest
-// of EQUAL dense blocks of 16 / 32 / 64 columns -- per block the tiles -L_ij and W_ii = inv(L_ii) in k_cholsol_mfma's fragment order --
-// the guard's measure max|L| max|W| over the forest, and the plan's block list.  With `emit`, L.i is NOT written (L->i may be null:
-// Csc::rows_pending).
+// kernel instead of k_clique_factor_shape + k_clique_plan + k_mfma_frags reading L back): what the matrix-core solve needs beyond L.x
+// for a forest of EQUAL dense blocks of 16 / 32 / 64 columns -- per block the inverses W_ii = inv(L_ii) of its diagonal tiles as A
+// fragments (k_cholsol_mfma reads the off-diagonal tiles in L.x itself) -- the guard's measure max|L| max|W| over the forest, and the
+// plan's block list.  With `emit`, L.i is NOT written (L->i may be null: Csc::rows_pending).
 struct Tree;
 struct CliqueEmit {
-    double *frag = nullptr;               // [nblocks * frags_per_block(bs / 16) * 64]
+    double *frag = nullptr;               // equal blocks: [nblocks * (bs / 16) * 256], tile i of block t at (t bs / 16 + i) * 256
     unsigned long long *cond_bits = nullptr;   // ordered bits of the largest max|L| max|W| of a block (zeroed by the caller)
     Tree *trees = nullptr;                // [nblocks]  {first column, columns}   (null: the caller has made the block list)
     int32_t *tree_nodes = nullptr;        // [n]        the identity node list
     const int64_t *frag_off = nullptr;    // blocks of UNEQUAL sizes: frag_off[t] = first double of block t's fragments (csx_trimfma.h:
                                           // ragged_prepare_emit); a block of bs columns then takes ceil(bs / 16) tiles a side, its last
-                                          // tile row / column padded with the identity.  null: equal blocks, block t at t * per_block
+                                          // tile row / column padded with the identity, and its fragments are ALL its tiles (-L_ij
+                                          // and W_ii, clique_frags_per_block of them).  null: equal blocks
     const int32_t *list = nullptr;        // with frag_off: the blocks ordered by size class (ceil(bs / 16) - 1), class c at
     int32_t cls_start[6] = {0, 0, 0, 0, 0, 0};   // list[cls_start[c] .. cls_start[c + 1]): what the matrix-core block kernel launches by
 };

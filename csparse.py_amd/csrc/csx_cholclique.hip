@@ -503,11 +503,12 @@ __device__ __forceinline__ double cq_bcast(double v, int src) {
 // PARTS: 1 load, 2 factor, 4 store -- 7 is the kernel; the others exist in the ablation build only (what each phase costs)
 // SPARSE: the blocks are small trees (CliqueForest::sparse).  The arithmetic is the dense block's -- an entry outside L's
 // pattern is a zero that stays zero -- and only the store differs: column g keeps the rows of its mask, compacted.
-// EMIT (csx_cholsol_factor on a forest of EQUAL blocks of 16 / 32 / 64 columns): the kernel also writes what the matrix-core solve
-// reads -- the block's tiles -L_ij (as a panel of eight columns is finished: the lanes of tile row i hold them) and W_ii = inv(L_ii)
-// (the diagonal tiles are kept in LDS as their panels finish; after the last panel lane (tile, column) inverts its column, the
-// arithmetic of k_mfma_frags) in k_cholsol_mfma's fragment order, the guard's measure and the plan's block list -- and does NOT
-// write L.i (rows j, j + 1, ... in every column: csc_fill_rows makes them from L.p when somebody asks).  L.x is written as always.
+// EMIT (csx_cholsol_factor): the kernel also writes what the matrix-core solve reads beside L.x -- W_ii = inv(L_ii) (the diagonal
+// tiles are kept in LDS as their panels finish; after the last panel lane (tile, column) inverts its column, the arithmetic of
+// k_mfma_frags), the guard's measure and the plan's block list -- and does NOT write L.i (rows j, j + 1, ... in every column:
+// csc_fill_rows makes them from L.p when somebody asks).  L.x is written as always; for EQUAL blocks of 16 / 32 / 64 columns that is
+// all (k_cholsol_mfma reads the off-diagonal tiles where they lie); blocks of unequal sizes (em.frag_off) also get their padded tiles
+// -L_ij as fragments (as a panel of eight columns is finished: the lanes of tile row i hold them), csx_trimfma.h's layout.
 constexpr int CQ_DIAG = 16 * 17;      // doubles per kept diagonal tile (odd stride)
 constexpr int CQ_TILE = CQ_CH * CQ_LD + 2;                 // the staging tile + the spare slot rejected entries go to
 constexpr int CQ_TILE_EMIT = 8 * 64 + 4 * CQ_DIAG;         // colbuf + four diagonal tiles (>= CQ_TILE)
@@ -652,7 +653,9 @@ __global__ __launch_bounds__(64 * CQ_WAVES, 3) void k_chol_clique(const int32_t 
     double em_lmax = 0.0;
     const int em_rows = EMIT ? 16 * ((bs + 15) >> 4) : 0;               // EMIT: the block's rows padded to whole tiles
     if (EMIT) {
-        em_frag = em.frag + (em.frag_off ? (size_t)em.frag_off[t] : (size_t)t * (size_t)(clique_frags_per_block(bs >> 4) * 64));
+        // equal blocks (no frag_off): the W tiles only, NB of them per block -- k_cholsol_mfma reads the off-diagonal tiles in L.x;
+        // unequal blocks: csx_trimfma.h's layout, padded off-diagonal tiles included
+        em_frag = em.frag + (em.frag_off ? (size_t)em.frag_off[t] : (size_t)t * (size_t)((bs >> 4) * 256));
         if (em.trees) {
             if (lane < bs) em.tree_nodes[c0 + lane] = c0 + lane;
             if (lane == 0) em.trees[t] = Tree{c0, bs};
@@ -754,7 +757,7 @@ __global__ __launch_bounds__(64 * CQ_WAVES, 3) void k_chol_clique(const int32_t 
             // (tile (ti, tj), k-step sx) holds element (m, 4 sx + kq) at position 16 kq + m: for one column 16 lanes write 128
             // contiguous bytes.  (Above the diagonal a[] is +0.0: nothing of it is read.)
             const int tj = J >> 4, ti = lane >> 4, m = lane & 15;
-            if (ti > tj && lane < em_rows) {        // (rows past the block, in its last tile row: a[] is zero there -- the padding)
+            if (ti > tj && lane < em_rows && em.frag_off) {   // (rows past the block, in its last tile row: a[] is zero there -- the padding)
                 double *dst = em_frag + (size_t)(((ti * (ti + 1) / 2 + tj) * 4 + ((J & 8) >> 2)) * 64 + m);
 #pragma unroll
                 for (int jw = 0; jw < 8; jw++) dst[(jw >> 2) * 64 + (jw & 3) * 16] = J + jw < bs ? -a[jw] : 0.0;
@@ -779,7 +782,7 @@ __global__ __launch_bounds__(64 * CQ_WAVES, 3) void k_chol_clique(const int32_t 
             tile_inverse_column(em_diag + blk * CQ_DIAG, 17, col, wcol);
             // fragment (tile (blk, blk), k-step col >> 2), positions 16 (col & 3) + r: this lane's sixteen values are contiguous
             typedef double d2 __attribute__((ext_vector_type(2)));
-            d2 *dst = (d2 *)(em_frag + (size_t)(((blk * (blk + 1) / 2 + blk) * 4 + (col >> 2)) * 64 + (col & 3) * 16));
+            d2 *dst = (d2 *)(em_frag + (size_t)(((em.frag_off ? blk * (blk + 1) / 2 + blk : blk) * 4 + (col >> 2)) * 64 + (col & 3) * 16));
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 dst[r >> 1] = d2{wcol[r], wcol[r + 1]};
@@ -866,7 +869,7 @@ __global__ __launch_bounds__(64 * CM_WAVES, 2) void k_chol_block_mfma(const int3
     const __amdgpu_buffer_rsrc_t ri = cq_rsrc(Li + (EMIT ? 0 : lbase), EMIT ? 0 : (bs * (bs + 1) / 2) * 4);
     double *frag = nullptr;
     if (EMIT) {
-        frag = em.frag + (em.frag_off ? (size_t)em.frag_off[t] : (size_t)t * (size_t)(clique_frags_per_block(NB) * 64)) + lane;
+        frag = em.frag + (em.frag_off ? (size_t)em.frag_off[t] : (size_t)t * (size_t)(NB * 256)) + lane;   // (equal blocks: the V tiles only)
         if (em.trees) {
             if (lane < bs) em.tree_nodes[c0 + lane] = c0 + lane;
             if (lane == 0) em.trees[t] = Tree{c0, bs};
@@ -916,7 +919,7 @@ __global__ __launch_bounds__(64 * CM_WAVES, 2) void k_chol_block_mfma(const int3
         T[k][k] = U;
         if (EMIT) {
 #pragma unroll
-            for (int sx = 0; sx < 4; sx++) frag[(size_t)(((k * (k + 1) / 2 + k) * 4 + sx) * 64)] = V[sx];
+            for (int sx = 0; sx < 4; sx++) frag[(size_t)(((RAGGED ? k * (k + 1) / 2 + k : k) * 4 + sx) * 64)] = V[sx];
         }
         // ---- panel: U_ki = inv(U_kk') T_ki; its negative is the A operand of the updates and, with EMIT, the solve's fragment ----
         f4 NU[NB];
@@ -931,7 +934,7 @@ __global__ __launch_bounds__(64 * CM_WAVES, 2) void k_chol_block_mfma(const int3
                 NU[i][r] = -D[r];
                 lmax = fmax(lmax, fabs(D[r]));
             }
-            if (EMIT) {
+            if (EMIT && RAGGED) {
 #pragma unroll
                 for (int sx = 0; sx < 4; sx++) frag[(size_t)(((i * (i + 1) / 2 + k) * 4 + sx) * 64)] = NU[i][sx];
             }
