@@ -1857,22 +1857,30 @@ __global__ __launch_bounds__(64) void k_mfma_frags(const Tree *__restrict__ tree
 
 // The solve.  Off-diagonal operands are read where the factorisation left them (round 5; until then a second, re-arranged and negated
 // copy of them was written beside L.x -- 1 GB per factorisation at 5M rows, a fifth of csx_cholsol_factor's traffic): the A fragment
-// of -L_ij for lane (m, kq), k-step sx, is -L(16 i + m, 16 j + 4 sx + kq) -- in the packed columns the 16 lanes of one kq read 128
-// contiguous bytes of one column, the four kq four neighbouring columns; the backward sweep's -L_ji' takes L(16 j + 4 sx + kq, 16 i + m):
-// lane m its own column, the four kq four consecutive rows of it.  Lv: the packed columns, block t at Lp[its first column] (L.x
-// itself) or, without Lp, at t BS (BS + 1) / 2 (the plan's copy).  The sign is flipped in the register.
-template <int NB>
+// of -L_ij for lane (m, kq), k-step sx, is -L(16 i + m, 16 j + 4 sx + kq), the backward sweep's -L_ji' takes L(16 j + 4 sx + kq,
+// 16 i + m); the sign is flipped in the register.  In the packed columns neither is a run of 512 aligned bytes (straight from memory
+// the forward operand touches eight lines an instruction instead of four and the solve lost 5 %), so the block's packed columns --
+// one contiguous, 16-byte aligned piece of L.x: block t at t BS (BS + 1) / 2 -- are copied to LDS once by the waves that solve it
+// (global_load_lds, 1 KB an instruction, every line of the block requested once per workgroup instead of twice per wave), and both
+// sweeps take their operands there.  SHARE blocks per workgroup, 4 / SHARE waves (chunks of 64 right-hand sides) per block -- the
+// host picks the SHARE whose waves-per-block divides the number of chunks.  Lv: L.x itself (a plan on all the columns of L, equal
+// blocks) or the plan's packed copy.
+template <int NB, int SHARE>
 __global__ __launch_bounds__(256, 2) void k_cholsol_mfma(const Tree *__restrict__ trees, int32_t ntrees,
                                                       const int32_t *__restrict__ nodes, const int32_t *__restrict__ perm,
-                                                      const int32_t *__restrict__ Lp, const double *__restrict__ Lv,
-                                                      const double *__restrict__ Wt, double *B, int32_t nrhs,
-                                                      int32_t chunks) {
-    constexpr int BS = 16 * NB;
+                                                      const double *__restrict__ Lv, const double *__restrict__ Wt, double *B,
+                                                      int32_t nrhs, int32_t chunks) {
+    constexpr int BS = 16 * NB, NENT = BS * (BS + 1) / 2, WPT = 4 / SHARE;
+    constexpr int LSZ = (NENT + 127) / 128 * 128;            // whole copy instructions (128 doubles each)
+    __shared__ __attribute__((aligned(16))) double s_l[SHARE][LSZ];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t task = (int64_t)blockIdx.x * 4 + w;
-    if (task >= (int64_t)ntrees * chunks) return;
-    const int32_t t = (int32_t)(task / chunks), h = (int32_t)(task % chunks);
+    const int slot = w / WPT, sub = w % WPT;
+    const int32_t cgroups = chunks / WPT;
+    const int32_t tg = (int32_t)(blockIdx.x / cgroups), cg = (int32_t)(blockIdx.x % cgroups);
+    const int32_t t_raw = tg * SHARE + slot, h = cg * WPT + sub;
+    const bool valid = t_raw < ntrees;                      // a wave past the last block still copies and meets the barrier
+    const int32_t t = valid ? t_raw : ntrees - 1;
     const int32_t first = trees[t].first;
     const int col = lane & 15, rq = lane >> 4;
     // rows of B this lane touches: local row 16 i + rq + 4 r
@@ -1891,8 +1899,8 @@ __global__ __launch_bounds__(256, 2) void k_cholsol_mfma(const Tree *__restrict_
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         const int32_t rhs = h * 64 + 16 * c + col;
-        live[c] = rhs < nrhs;
-        cidx[c] = live[c] ? rhs : nrhs - 1;   // clamped: loaded, never stored
+        live[c] = valid && rhs < nrhs;
+        cidx[c] = rhs < nrhs ? rhs : nrhs - 1;   // clamped: loaded, never stored
     }
     // A chunk that is wholly inside the block (and an even nrhs: 16-byte alignment) is moved 16 bytes per lane: the
     // right-hand sides are independent, so which one a (c, col) pair stands for is free -- lane (rq, col) takes the
@@ -1918,8 +1926,20 @@ __global__ __launch_bounds__(256, 2) void k_cholsol_mfma(const Tree *__restrict_
 #pragma unroll
                 for (int r = 0; r < 4; r++) X[i][c][r] = B[roff[i][r] + cidx[c]];
     }
-    // entry (R, C), R >= C, of the block's packed columns: C BS - C (C - 1) / 2 + R - C
-    const double *Lb = Lv + (Lp ? (size_t)Lp[nodes[first]] : (size_t)t * (BS * (BS + 1) / 2));
+    // the block's packed columns to LDS, this wave's share of the copy instructions (a lane past the block's end repeats its start)
+    {
+        const double *Lb = Lv + (size_t)t * NENT;
+#pragma unroll
+        for (int k = 0; k < LSZ / 128; k++)
+            if (k % WPT == sub) {
+                const int e = k * 128 + 2 * lane;
+                __builtin_amdgcn_global_load_lds((csx_gptr)(Lb + (e < NENT ? e : 0)), (csx_lptr)(s_l[slot] + k * 128), 16, 0, 0);
+            }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // entry (R, C), R >= C, of the packed columns: C BS - C (C - 1) / 2 + R - C
+    const double *Ls = s_l[slot];
     auto col_at = [](int C) { return C * BS - C * (C - 1) / 2 - C; };
     const double *F = Wt + (size_t)t * (NB * 256) + lane;
     // Transposed read of a stored tile: the A fragment of tile' for (lane = (m, kq), k-step sx) is element (4 sx + kq, m)
@@ -1931,7 +1951,7 @@ __global__ __launch_bounds__(256, 2) void k_cholsol_mfma(const Tree *__restrict_
         for (int j = 0; j < i; j++)
 #pragma unroll
             for (int sx = 0; sx < 4; sx++) {
-                const double a = -Lb[col_at(16 * j + 4 * sx + rq) + 16 * i + col];
+                const double a = -Ls[col_at(16 * j + 4 * sx + rq) + 16 * i + col];
 #pragma unroll
                 for (int c = 0; c < 4; c++) X[i][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[j][c][sx], X[i][c], 0, 0, 0);
             }
@@ -1953,7 +1973,7 @@ __global__ __launch_bounds__(256, 2) void k_cholsol_mfma(const Tree *__restrict_
         for (int j = i + 1; j < NB; j++)
 #pragma unroll
             for (int sx = 0; sx < 4; sx++) {
-                const double a = -Lb[col_at(16 * i + col) + 16 * j + 4 * sx + rq];   // -L_ji'
+                const double a = -Ls[col_at(16 * i + col) + 16 * j + 4 * sx + rq];   // -L_ji'
 #pragma unroll
                 for (int c = 0; c < 4; c++) X[i][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[j][c][sx], X[i][c], 0, 0, 0);
             }
@@ -1969,6 +1989,7 @@ __global__ __launch_bounds__(256, 2) void k_cholsol_mfma(const Tree *__restrict_
 #pragma unroll
         for (int c = 0; c < 4; c++) X[i][c] = Y[c];
     }
+    if (!valid) return;
     if (wide) {
 #pragma unroll
         for (int i = 0; i < NB; i++)
@@ -2639,22 +2660,23 @@ static int cholsol_solve(CholPlan *P, double *B, int32_t nrhs) {
             const int64_t tasks = (int64_t)P->ntrees * chunks;
             const dim3 grid((unsigned)((tasks + 3) / 4));
             if (P->frag_f) {
-                const int32_t *lp = P->lcopy ? nullptr : P->L->p;
+                // (equal dense blocks on ALL the columns of L -- `clique` -- lie in L.x as they do in a copy: block t at t bs (bs + 1) / 2)
                 const double *lv = P->lcopy ? P->lcopy : P->L->x;
+                const int share = chunks % 4 == 0 ? 1 : chunks % 2 == 0 ? 2 : 4;
+                const dim3 g2((unsigned)(((int64_t)P->ntrees + share - 1) / share * (chunks / (4 / share))));
+#define CSX_MF_X(NB_, SH) \
+    hipLaunchKernelGGL((k_cholsol_mfma<NB_, SH>), g2, dim3(256), 0, s, P->trees, P->ntrees, P->tree_nodes, P->perm, lv, P->frag_f, B, nrhs, chunks)
+#define CSX_MF(NB_)                       \
+    if (share == 1) CSX_MF_X(NB_, 1);     \
+    else if (share == 2) CSX_MF_X(NB_, 2); \
+    else CSX_MF_X(NB_, 4)
                 switch (P->dense_bs) {
-                    case 16:
-                        hipLaunchKernelGGL(k_cholsol_mfma<1>, grid, dim3(256), 0, s, P->trees, P->ntrees, P->tree_nodes,
-                                           P->perm, lp, lv, P->frag_f, B, nrhs, chunks);
-                        break;
-                    case 32:
-                        hipLaunchKernelGGL(k_cholsol_mfma<2>, grid, dim3(256), 0, s, P->trees, P->ntrees, P->tree_nodes,
-                                           P->perm, lp, lv, P->frag_f, B, nrhs, chunks);
-                        break;
-                    default:
-                        hipLaunchKernelGGL(k_cholsol_mfma<4>, grid, dim3(256), 0, s, P->trees, P->ntrees, P->tree_nodes,
-                                           P->perm, lp, lv, P->frag_f, B, nrhs, chunks);
-                        break;
+                    case 16: CSX_MF(1); break;
+                    case 32: CSX_MF(2); break;
+                    default: CSX_MF(4); break;
                 }
+#undef CSX_MF
+#undef CSX_MF_X
                 CSX_LAUNCH_CHECK();
                 return CSX_OK;
             }
