@@ -1872,7 +1872,9 @@ __global__ __launch_bounds__(256, 2) void k_cholsol_mfma(const Tree *__restrict_
                                                       int32_t nrhs, int32_t chunks) {
     constexpr int BS = 16 * NB, NENT = BS * (BS + 1) / 2, WPT = 4 / SHARE;
     constexpr int LSZ = (NENT + 127) / 128 * 128;            // whole copy instructions (128 doubles each)
+    constexpr bool WLDS = SHARE <= 2;                        // the W tiles too (2 KB a tile), where two workgroups still fit a CU
     __shared__ __attribute__((aligned(16))) double s_l[SHARE][LSZ];
+    __shared__ __attribute__((aligned(16))) double s_w[WLDS ? SHARE : 1][WLDS ? NB * 256 : 2];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int slot = w / WPT, sub = w % WPT;
@@ -1914,7 +1916,8 @@ __global__ __launch_bounds__(256, 2) void k_cholsol_mfma(const Tree *__restrict_
             for (int cp = 0; cp < 2; cp++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const f64x2w v = *reinterpret_cast<const f64x2w *>(B + roff[i][r] + h * 64 + 32 * cp + 2 * col);
+                    // (B goes through once per batch, 10 GB of it at 5M rows x 128: the caches are told not to keep it)
+                    const f64x2w v = __builtin_nontemporal_load(reinterpret_cast<const f64x2w *>(B + roff[i][r] + h * 64 + 32 * cp + 2 * col));
                     X[i][2 * cp][r] = v.x;
                     X[i][2 * cp + 1][r] = v.y;
                 }
@@ -1935,16 +1938,24 @@ __global__ __launch_bounds__(256, 2) void k_cholsol_mfma(const Tree *__restrict_
                 const int e = k * 128 + 2 * lane;
                 __builtin_amdgcn_global_load_lds((csx_gptr)(Lb + (e < NENT ? e : 0)), (csx_lptr)(s_l[slot] + k * 128), 16, 0, 0);
             }
+        if (WLDS) {
+            const double *Wb = Wt + (size_t)t * (NB * 256);
+#pragma unroll
+            for (int k = 0; k < NB * 2; k++)
+                if ((k + LSZ / 128) % WPT == sub)
+                    __builtin_amdgcn_global_load_lds((csx_gptr)(Wb + k * 128 + 2 * lane), (csx_lptr)(s_w[WLDS ? slot : 0] + k * 128), 16, 0, 0);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // entry (R, C), R >= C, of the packed columns: C BS - C (C - 1) / 2 + R - C
     const double *Ls = s_l[slot];
     auto col_at = [](int C) { return C * BS - C * (C - 1) / 2 - C; };
-    const double *F = Wt + (size_t)t * (NB * 256) + lane;
+    const double *Wb = WLDS ? s_w[WLDS ? slot : 0] : Wt + (size_t)t * (NB * 256);
+    const double *F = Wb + lane;
     // Transposed read of a stored tile: the A fragment of tile' for (lane = (m, kq), k-step sx) is element (4 sx + kq, m)
     // of the tile, which the forward layout keeps in k-step m >> 2 at lane (m & 3) * 16 + 4 sx + kq.
-    const double *Ft = Wt + (size_t)t * (NB * 256) + (size_t)(col >> 2) * 64 + (col & 3) * 16 + rq;
+    const double *Ft = Wb + (col >> 2) * 64 + (col & 3) * 16 + rq;
 #pragma unroll
     for (int i = 0; i < NB; i++) {
 #pragma unroll
@@ -2000,7 +2011,7 @@ __global__ __launch_bounds__(256, 2) void k_cholsol_mfma(const Tree *__restrict_
                     f64x2w v;
                     v.x = X[i][2 * cp][r];
                     v.y = X[i][2 * cp + 1][r];
-                    *reinterpret_cast<f64x2w *>(B + roff[i][r] + h * 64 + 32 * cp + 2 * col) = v;
+                    __builtin_nontemporal_store(v, reinterpret_cast<f64x2w *>(B + roff[i][r] + h * 64 + 32 * cp + 2 * col));
                 }
         return;
     }
