@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void k_rag_class(const Tree *__restrict__ tree
 // went list -> trees -> nodes -> X: three dependent memory round trips in front of the first byte of X, 3.39 ms for 128
 // right-hand sides on 5M rows of cliques of 8 .. 64 columns; with the descriptor and computed rows: see profiles/r05_ablation.md.)
 __global__ __launch_bounds__(256) void k_rag_desc(const int32_t *__restrict__ list, int32_t ntrees, const Tree *__restrict__ trees,
-                                                  const int32_t *__restrict__ nodes, int4 *__restrict__ desc) {
+                                                  const int32_t *__restrict__ nodes, int4 *__restrict__ desc, int32_t *scattered) {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= ntrees) return;
     const int32_t t = list[q];
@@ -55,6 +55,7 @@ __global__ __launch_bounds__(256) void k_rag_desc(const int32_t *__restrict__ li
             base = -1;
             break;
         }
+    if (base < 0) *scattered = 1;
     desc[q] = make_int4(tr.first, tr.count, base, t);
 }
 
@@ -226,16 +227,42 @@ int ragged_blocks(const int32_t *start, int32_t nblocks, int32_t n, Tree *trees,
 // One wave = one component x 64 right-hand sides.  Lane (rq, col): rows 16 i + rq + 4 r of the position order, right-hand sides
 // col (+ 16 c) of the chunk -- the f64 accumulator layout, which is also the B-operand layout of k-step r: a finished tile feeds
 // the next product from its registers.  Positions past the component's rows are padding: zero in X, the identity in T.
-template <int NB, int PASSES>
+// SHARE > 0: the component's fragments go to LDS first (global_load_lds, every line once per workgroup; the backward sweep's
+// transposed reads, 8 bytes out of each of sixteen lines an instruction straight from memory, then cost LDS cycles instead of cache
+// lines -- what took k_cholsol_mfma from 2.37 to 2.07 ms): SHARE components per workgroup, 4 / SHARE waves (chunks of 64
+// right-hand sides) per component; the host picks the SHARE whose waves-per-component divides the number of chunks, or 0 (every
+// wave reads its fragments from memory, as before round 5's last week) where the copies would not leave two workgroups to a CU.
+typedef __attribute__((address_space(1))) const void *rg_gptr;
+typedef __attribute__((address_space(3))) void *rg_lptr;
+// FAST: the host vouches that every component is consecutive rows of X, unpermuted, and every chunk is 64 whole right-hand sides
+// at a 16-byte aligned X: only the buffer-resource path is compiled.  (With the four ways of moving X in one kernel the paths meet
+// in register moves that wait for the loads one by one, in front of everything that could overlap with them.)
+template <int NB, int PASSES, int SHARE, bool FAST>
 __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void k_rag_mfma(const int4 *__restrict__ desc, int32_t ncls,
                                                                      const int32_t *__restrict__ nodes,
                                                                      const int32_t *__restrict__ perm, const double *__restrict__ frag,
                                                                      int reverse, double *B, int32_t nrhs, int32_t chunks) {
+    constexpr int FSZ = rag_frags<NB>() * 64;               // doubles per component
+    constexpr int WPT = SHARE ? 4 / SHARE : 1;
+    __shared__ __attribute__((aligned(16))) double s_f[SHARE ? SHARE : 1][SHARE ? FSZ : 2];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t task = (int64_t)blockIdx.x * 4 + w;
-    if (task >= (int64_t)ncls * chunks) return;
-    const int32_t q = (int32_t)(task / chunks), h = (int32_t)(task % chunks);
+    const int slot = SHARE ? w / WPT : 0, sub = SHARE ? w % WPT : 0;
+    int32_t q, h;
+    bool valid = true;
+    if (SHARE) {
+        const int32_t cgroups = chunks / WPT;
+        const int32_t qg = (int32_t)(blockIdx.x / cgroups), cg = (int32_t)(blockIdx.x % cgroups);
+        const int32_t q_raw = qg * SHARE + slot;
+        valid = q_raw < ncls;                                // a wave past the last component still copies and meets the barrier
+        q = valid ? q_raw : ncls - 1;
+        h = cg * WPT + sub;
+    } else {
+        const int64_t task = (int64_t)blockIdx.x * 4 + w;
+        if (task >= (int64_t)ncls * chunks) return;
+        q = (int32_t)(task / chunks);
+        h = (int32_t)(task % chunks);
+    }
     const int4 ds = desc[q];
     const int32_t first = __builtin_amdgcn_readfirstlane(ds.x), count = __builtin_amdgcn_readfirstlane(ds.y);
     const int32_t base = __builtin_amdgcn_readfirstlane(ds.z);
@@ -248,7 +275,15 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void k_rag_mfma(const int4 
     // 8 .. 64 columns; padding positions loading the last row and zeroing afterwards: 4.36 ms, the dummy loads cost what real ones
     // do; this form: profiles/r05_ablation.md.)  Rows that are not consecutive, or permuted (cs_cholsol with a fill-reducing
     // order), are looked up and go through predicated global accesses.
-    const bool consecutive = base >= 0 && !perm && (int64_t)(RAG_MAX_ROWS + 16) * nrhs * 8 < (1ll << 31);      // uniform (offsets of padding positions must not wrap back into range)
+    const bool consecutive = FAST || (base >= 0 && !perm && (int64_t)(RAG_MAX_ROWS + 16) * nrhs * 8 < (1ll << 31));      // uniform (offsets of padding positions must not wrap back into range)
+    // (the copy of the fragments is requested FIRST: it depends on nothing, and behind the loads of X it waited for them -- the paths
+    // that load X meet in register moves that wait for every load in turn)
+    if (SHARE && !FAST) {
+        const double *src = frag + (size_t)q * FSZ;
+#pragma unroll
+        for (int k = 0; k < FSZ / 128; k++)
+            if (k % WPT == sub) __builtin_amdgcn_global_load_lds((rg_gptr)(src + k * 128 + 2 * lane), (rg_lptr)(s_f[slot] + k * 128), 16, 0, 0);
+    }
     rg_f64x4 X[NB][4];
     bool live[4];
     int32_t cidx[4];
@@ -261,7 +296,7 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void k_rag_mfma(const int4 
     // a chunk wholly inside the block (and an even nrhs: 16-byte alignment) moves 16 bytes per lane: lane (rq, col) takes the
     // neighbours 32 c' + 2 col, + 1 of a row and gives them to column chunks 2 c' and 2 c' + 1 (which right-hand side a
     // (chunk, column) pair stands for is free)
-    const bool wide = (nrhs & 1) == 0 && h * 64 + 64 <= nrhs && (reinterpret_cast<uintptr_t>(B) & 15) == 0;   // uniform
+    const bool wide = FAST || ((nrhs & 1) == 0 && h * 64 + 64 <= nrhs && (reinterpret_cast<uintptr_t>(B) & 15) == 0);   // uniform
     typedef unsigned int rg_u32x4 __attribute__((ext_vector_type(4)));
     typedef unsigned int rg_u32x2 __attribute__((ext_vector_type(2)));
     const __amdgpu_buffer_rsrc_t rs =
@@ -287,7 +322,7 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void k_rag_mfma(const int4 
             for (int cp = 0; cp < 2; cp++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const rg_u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs, pos_off(i, r) + coff, 32 * cp * 8, 0);
+                    const rg_u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs, pos_off(i, r) + coff, 32 * cp * 8, 2);   // (aux 2 = nt: X goes through once)
                     const rg_f64x2 v = __builtin_bit_cast(rg_f64x2, u);
                     X[i][2 * cp][r] = v.x;
                     X[i][2 * cp + 1][r] = v.y;
@@ -326,7 +361,18 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void k_rag_mfma(const int4 
                 for (int c = 0; c < 4; c++) X[i][c][r] = ok ? B[ro + cidx[c]] : 0.0;
             }
     }
-    const double *F = frag + (size_t)q * rag_frags<NB>() * 64 + lane;
+    if (SHARE && FAST) {   // (one way of loading X: behind its loads, where the same copy costs k_cholsol_mfma less)
+        const double *src = frag + (size_t)q * FSZ;
+#pragma unroll
+        for (int k = 0; k < FSZ / 128; k++)
+            if (k % WPT == sub) __builtin_amdgcn_global_load_lds((rg_gptr)(src + k * 128 + 2 * lane), (rg_lptr)(s_f[slot] + k * 128), 16, 0, 0);
+    }
+    if (SHARE) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    const double *Fb = SHARE ? s_f[slot] : frag + (size_t)q * FSZ;
+    const double *F = Fb + lane;
     int f = 0;
 #pragma unroll
     for (int i = 0; i < NB; i++) {
@@ -353,7 +399,7 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void k_rag_mfma(const int4 
     if (PASSES == 2) {
         // the transposed system, backwards: the A fragment of tile' for (lane = (m, kq), k-step sx) is element (4 sx + kq, m) of
         // the tile, which the forward layout keeps in k-step m >> 2 at lane (m & 3) * 16 + 4 sx + kq (k_cholsol_mfma)
-        const double *Ft = frag + (size_t)q * rag_frags<NB>() * 64 + (size_t)(col >> 2) * 64 + (col & 3) * 16 + rq;
+        const double *Ft = Fb + (col >> 2) * 64 + (col & 3) * 16 + rq;
         auto tile_at = [](int a, int b) { return (a * (a + 1) / 2 + b) * 4; };
 #pragma unroll
         for (int i = NB - 1; i >= 0; i--) {
@@ -378,6 +424,7 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void k_rag_mfma(const int4 
             for (int c = 0; c < 4; c++) X[i][c] = Y[c];
         }
     }
+    if (!valid) return;
     if (consecutive && wide) {
         const uint32_t coff = (uint32_t)(h * 64 + 2 * col) * 8u;
 #pragma unroll
@@ -394,7 +441,7 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void k_rag_mfma(const int4 
                     // registers -- GCNHazardRecognizer::createsVALUHazard exempts MUBUF stores with a register soffset -- and on this
                     // chip the store then took the NEW low dword of its first register in about one block in a hundred: solutions
                     // wrong in the 7th digit, in columns 56 .. 63 of a chunk only, differently from run to run)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(rg_u32x4, v), rs, pos_off(i, r) + coff + 32u * cp * 8u, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(rg_u32x4, v), rs, pos_off(i, r) + coff + 32u * cp * 8u, 0, 2);
                 }
         return;
     }
@@ -454,17 +501,22 @@ static int ragged_skeleton(const Tree *trees, int32_t ntrees, const int32_t *nod
     CSX_TRY(tmp.alloc(&key, (size_t)ntrees));
     CSX_TRY(tmp.alloc(&id, (size_t)ntrees));
     CSX_TRY(tmp.alloc(&skey, (size_t)ntrees));
-    CSX_TRY(tmp.alloc(&bounds, RAG_CLASSES + 1));
+    CSX_TRY(tmp.alloc(&bounds, RAG_CLASSES + 2));             // (+ 1: the "a component's rows are not consecutive" flag)
+    CSX_HIP(hipMemsetAsync(bounds + RAG_CLASSES + 1, 0, sizeof(int32_t), s));
     CSX_TRY(dalloc(&R->list, (size_t)ntrees));
     hipLaunchKernelGGL(k_rag_class, dim3((unsigned)((ntrees + 255) / 256)), dim3(256), 0, s, trees, ntrees, key, id);
     CSX_LAUNCH_CHECK();
     CSX_TRY(stable_sort_by_key(key, id, nullptr, ntrees, RAG_CLASSES, skey, (uint32_t *)R->list, nullptr));
     CSX_TRY(boundaries_from_sorted(skey, ntrees, RAG_CLASSES, bounds));
     CSX_TRY(dalloc((int4 **)&R->desc, (size_t)ntrees));
-    hipLaunchKernelGGL(k_rag_desc, dim3((unsigned)((ntrees + 255) / 256)), dim3(256), 0, s, R->list, ntrees, trees, nodes, (int4 *)R->desc);
+    hipLaunchKernelGGL(k_rag_desc, dim3((unsigned)((ntrees + 255) / 256)), dim3(256), 0, s, R->list, ntrees, trees, nodes, (int4 *)R->desc,
+                       bounds + RAG_CLASSES + 1);
     CSX_LAUNCH_CHECK();
-    CSX_HIP(hipMemcpyAsync(R->cls_start, bounds, sizeof R->cls_start, hipMemcpyDeviceToHost, s));
+    int32_t hb[RAG_CLASSES + 2];
+    CSX_HIP(hipMemcpyAsync(hb, bounds, sizeof hb, hipMemcpyDeviceToHost, s));
     CSX_HIP(hipStreamSynchronize(s));
+    for (int c = 0; c <= RAG_CLASSES; c++) R->cls_start[c] = hb[c];
+    R->all_consecutive = hb[RAG_CLASSES + 1] == 0;
     size_t total = 0;
     for (int c = 0; c < RAG_CLASSES; c++) {
         R->cls_frag[c] = total;
@@ -566,18 +618,30 @@ int ragged_solve(const RaggedMfma *R, const int32_t *nodes, const int32_t *perm,
     hipStream_t s = ctx().stream;
     const int32_t chunks = (nrhs + 63) / 64;
     const int rev = reverse ? 1 : 0;
+    const bool fast = R->all_consecutive && !perm && nrhs % 64 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 &&
+                      (int64_t)(RAG_MAX_ROWS + 16) * nrhs * 8 < (1ll << 31);
     for (int c = 0; c < RAG_CLASSES; c++) {
         const int32_t cnt = R->cls_start[c + 1] - R->cls_start[c];
         if (cnt <= 0) continue;
         const int64_t tasks = (int64_t)cnt * chunks;
-        const dim3 grid((unsigned)((tasks + 3) / 4));
         const int4 *dsc = (const int4 *)R->desc + R->cls_start[c];
         const double *fr = R->frag + R->cls_frag[c];
-#define CSX_RS(NB, PS) \
-    hipLaunchKernelGGL((k_rag_mfma<NB, PS>), grid, dim3(256), 0, s, dsc, cnt, nodes, perm, fr, rev, X, nrhs, chunks)
-#define CSX_RSP(NB)                \
-    if (passes == 2) CSX_RS(NB, 2); \
-    else CSX_RS(NB, 1)
+        // fragments through LDS, shared by the waves of a component (see the kernel); classes of 64 / 80 rows (20 / 30 KB a component)
+        // with an odd number of chunks keep the direct reads: four private copies would leave one workgroup to a CU
+        int share = chunks % 4 == 0 ? 1 : chunks % 2 == 0 ? 2 : 4;
+        if (share == 4 && c >= 3) share = 0;
+        const dim3 grid(share ? (unsigned)(((int64_t)cnt + share - 1) / share * (chunks / (4 / share))) : (unsigned)((tasks + 3) / 4));
+#define CSX_RS(NB, PS, SH)                                                                                                            \
+    if (fast) hipLaunchKernelGGL((k_rag_mfma<NB, PS, SH, true>), grid, dim3(256), 0, s, dsc, cnt, nodes, perm, fr, rev, X, nrhs, chunks); \
+    else hipLaunchKernelGGL((k_rag_mfma<NB, PS, SH, false>), grid, dim3(256), 0, s, dsc, cnt, nodes, perm, fr, rev, X, nrhs, chunks)
+#define CSX_RSS(NB, PS)                       \
+    if (share == 1) { CSX_RS(NB, PS, 1); }      \
+    else if (share == 2) { CSX_RS(NB, PS, 2); } \
+    else if (share == 4) { CSX_RS(NB, PS, 4); } \
+    else { CSX_RS(NB, PS, 0); }
+#define CSX_RSP(NB)                    \
+    if (passes == 2) { CSX_RSS(NB, 2); } \
+    else { CSX_RSS(NB, 1); }
         switch (c) {
             case 0: CSX_RSP(1); break;
             case 1: CSX_RSP(2); break;
@@ -585,6 +649,7 @@ int ragged_solve(const RaggedMfma *R, const int32_t *nodes, const int32_t *perm,
             case 3: CSX_RSP(4); break;
             default: CSX_RSP(5); break;
         }
+#undef CSX_RSS
 #undef CSX_RSP
 #undef CSX_RS
         CSX_LAUNCH_CHECK();
