@@ -77,6 +77,7 @@ _PROTOS = {
     "csx_tri_order_info": [H, _i32p, _f64p],
     "csx_tri_components": [H, _i32p],
     "csx_permute_vec": [H, H, H, C.c_int32, C.c_int32, C.c_int],
+    "csx_lusol_solve": [H, H, H, H, H, H, C.c_int32, C.POINTER(C.c_int)],
     "csx_schol_host": [C.c_int32, _i32p, _i32p, _i32p, _i32p],
     "csx_counts_host": [C.c_int32, C.c_int32, _i32p, _i32p, _i32p, _i32p, C.c_int, _i32p],
     "csx_chol": [H, _i32p, _i32p, _i32p, C.POINTER(H)],

@@ -1401,18 +1401,21 @@ def lusol_factor(A, order=0, tol=1.0, exact=None):
             self._fin = weakref.finalize(self, lambda hs: [_csx.free(h) for h in hs if h is not None], [keep_p, keep_q])
 
         def _block(self, blk, in_exact_order=True):
+            # x(pinv) = b, L x = x, U x = x, b(q) = x (csparse.py:1470-1473) as ONE library call: in the rounding-equal order on
+            # forests of small components the two permutations ride on the two sweeps (csx_lusol_solve)
             lib = _csx.lib()
             x = dvec(n, blk.k)
-            _csx.check(lib.csx_permute_vec(hp, blk.handle, x.handle, n, blk.k, 1), "csx_permute_vec")     # x(pinv) = b
-            for M, kind in ((L, TRI_L), (U, TRI_U)):
-                with _Resident(M) as dM:
-                    plan = _plan(dM, kind)       # (shared with the list-level cs_lsolve / cs_usolve on this factor: the order is set per solve)
-                    try:
+            with _Resident(L) as dL, _Resident(U) as dU:
+                pl, pu = _plan(dL, TRI_L), _plan(dU, TRI_U)      # (shared with the list-level cs_lsolve / cs_usolve on this factor: the order is set per solve)
+                fused = _csx.C.c_int(0)
+                try:
+                    for plan in (pl, pu):
                         _csx.check(lib.csx_tri_set_order(plan, 1 if in_exact_order else 0), "csx_tri_set_order")
-                        _csx.check(lib.csx_tri_solve(plan, x.handle, blk.k), "csx_tri_solve")
-                    finally:
-                        lib.csx_tri_set_order(plan, 1)
-            _csx.check(lib.csx_permute_vec(hq, x.handle, blk.handle, n, blk.k, 1), "csx_permute_vec")     # b(q) = x
+                    _csx.check(lib.csx_lusol_solve(pl, pu, hp, hq, blk.handle, x.handle, blk.k, _csx.C.byref(fused)), "csx_lusol_solve")
+                finally:
+                    lib.csx_tri_set_order(pl, 1)
+                    lib.csx_tri_set_order(pu, 1)
+            self.last_fused = bool(fused.value)
             return blk
 
         def info(self):

@@ -234,14 +234,24 @@ int ragged_blocks(const int32_t *start, int32_t nblocks, int32_t n, Tree *trees,
 // wave reads its fragments from memory, as before round 5's last week) where the copies would not leave two workgroups to a CU.
 typedef __attribute__((address_space(1))) const void *rg_gptr;
 typedef __attribute__((address_space(3))) void *rg_lptr;
-// FAST: the host vouches that every component is consecutive rows of X, unpermuted, and every chunk is 64 whole right-hand sides
-// at a 16-byte aligned X: only the buffer-resource path is compiled.  (With the four ways of moving X in one kernel the paths meet
-// in register moves that wait for the loads one by one, in front of everything that could overlap with them.)
-template <int NB, int PASSES, int SHARE, bool FAST>
+// MODE -- how X moves (the arithmetic is the same):
+//   0  anything: rows looked up (nodes, then load_rows / store_rows when given), or the buffer-resource path when the component is
+//      consecutive unpermuted rows; partial chunks of right-hand sides; decided at run time, four paths in one kernel
+//   1  the host vouches that every component is consecutive rows, unpermuted, and every chunk is 64 whole right-hand sides at 16-byte
+//      aligned blocks: only the buffer-resource path is compiled.  (With the four ways of moving X in one kernel the paths meet in
+//      register moves that wait for the loads one by one, in front of everything that could overlap with them.)
+//   2  as 1, but the LOAD gathers: position p of a component takes row load_rows[base + p] of Bsrc (cs_lusol's x = P b fused into the
+//      sweep over L: csparse.py:1470, cs_ipvec); one resource over all of Bsrc, a padding position's offset past its end
+//   3  as 1, but the STORE scatters: position p goes to row store_rows[base + p] of Bdst (cs_lusol's b = Q x fused into the sweep over U)
+// Bsrc / Bdst: the block read / the block written (the same block for an in-place solve).
+template <int NB, int PASSES, int SHARE, int MODE>
 __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void k_rag_mfma(const int4 *__restrict__ desc, int32_t ncls,
                                                                      const int32_t *__restrict__ nodes,
-                                                                     const int32_t *__restrict__ perm, const double *__restrict__ frag,
-                                                                     int reverse, double *B, int32_t nrhs, int32_t chunks) {
+                                                                     const int32_t *__restrict__ load_rows,
+                                                                     const int32_t *__restrict__ store_rows,
+                                                                     const double *__restrict__ frag, int reverse, const double *Bsrc,
+                                                                     double *Bdst, int32_t nrhs, int32_t chunks, int32_t n_rows) {
+    constexpr bool FAST = MODE != 0;
     constexpr int FSZ = rag_frags<NB>() * 64;               // doubles per component
     constexpr int WPT = SHARE ? 4 / SHARE : 1;
     __shared__ __attribute__((aligned(16))) double s_f[SHARE ? SHARE : 1][SHARE ? FSZ : 2];
@@ -275,15 +285,15 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void k_rag_mfma(const int4 
     // 8 .. 64 columns; padding positions loading the last row and zeroing afterwards: 4.36 ms, the dummy loads cost what real ones
     // do; this form: profiles/r05_ablation.md.)  Rows that are not consecutive, or permuted (cs_cholsol with a fill-reducing
     // order), are looked up and go through predicated global accesses.
-    const bool consecutive = FAST || (base >= 0 && !perm && (int64_t)(RAG_MAX_ROWS + 16) * nrhs * 8 < (1ll << 31));      // uniform (offsets of padding positions must not wrap back into range)
-    // (the copy of the fragments is requested FIRST: it depends on nothing, and behind the loads of X it waited for them -- the paths
-    // that load X meet in register moves that wait for every load in turn)
+    // (MODE 0: the copy of the fragments is requested FIRST -- it depends on nothing, and behind the loads of X it waited for them:
+    // the paths that load X meet in register moves that wait for every load in turn)
     if (SHARE && !FAST) {
         const double *src = frag + (size_t)q * FSZ;
 #pragma unroll
         for (int k = 0; k < FSZ / 128; k++)
             if (k % WPT == sub) __builtin_amdgcn_global_load_lds((rg_gptr)(src + k * 128 + 2 * lane), (rg_lptr)(s_f[slot] + k * 128), 16, 0, 0);
     }
+    const bool consecutive = FAST || (base >= 0 && !load_rows && !store_rows && (int64_t)(RAG_MAX_ROWS + 16) * nrhs * 8 < (1ll << 31));      // uniform (offsets of padding positions must not wrap back into range)
     rg_f64x4 X[NB][4];
     bool live[4];
     int32_t cidx[4];
@@ -296,24 +306,50 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void k_rag_mfma(const int4 
     // a chunk wholly inside the block (and an even nrhs: 16-byte alignment) moves 16 bytes per lane: lane (rq, col) takes the
     // neighbours 32 c' + 2 col, + 1 of a row and gives them to column chunks 2 c' and 2 c' + 1 (which right-hand side a
     // (chunk, column) pair stands for is free)
-    const bool wide = FAST || ((nrhs & 1) == 0 && h * 64 + 64 <= nrhs && (reinterpret_cast<uintptr_t>(B) & 15) == 0);   // uniform
+    const bool wide = FAST || ((nrhs & 1) == 0 && h * 64 + 64 <= nrhs && ((reinterpret_cast<uintptr_t>(Bsrc) | reinterpret_cast<uintptr_t>(Bdst)) & 15) == 0);   // uniform
     typedef unsigned int rg_u32x4 __attribute__((ext_vector_type(4)));
     typedef unsigned int rg_u32x2 __attribute__((ext_vector_type(2)));
-    const __amdgpu_buffer_rsrc_t rs =
-        __builtin_amdgcn_make_buffer_rsrc(B + (consecutive ? (int64_t)base * nrhs : 0), 0, consecutive ? count * nrhs * 8 : 0, 0x00020000);
+    // the component's rows as a resource of the block read and of the block written (MODE 2 / 3: the WHOLE block on the permuted side)
+    const __amdgpu_buffer_rsrc_t rs_ld =
+        MODE == 2 ? __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(Bsrc), 0, (int32_t)((uint32_t)n_rows * (uint32_t)nrhs * 8u), 0x00020000)
+                  : __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(Bsrc) + (consecutive ? (int64_t)base * nrhs : 0), 0, consecutive ? count * nrhs * 8 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_st =
+        MODE == 3 ? __builtin_amdgcn_make_buffer_rsrc(Bdst, 0, (int32_t)((uint32_t)n_rows * (uint32_t)nrhs * 8u), 0x00020000)
+                  : __builtin_amdgcn_make_buffer_rsrc(Bdst + (consecutive ? (int64_t)base * nrhs : 0), 0, consecutive ? count * nrhs * 8 : 0, 0x00020000);
     // byte offset of position p's row inside the component (padding: past the size, also when the order is reversed)
     auto pos_off = [&](int i, int r) -> uint32_t {
         const int p = 16 * i + rq + 4 * r;
         return (uint32_t)(reverse ? count - 1 - p : p) * (uint32_t)(nrhs * 8);
     };
-    auto row_of = [&](int i, int r, bool *ok) -> int64_t {       // the general case: look the row up
+    // MODE 2 / 3: byte offset of the permuted row of position p in the whole block (padding: an offset the range check refuses)
+    auto perm_off = [&](const int32_t *rows, int i, int r) -> uint32_t {
+        const int p = 16 * i + rq + 4 * r;
+        const int pc = p < count ? p : count - 1;
+        const int32_t row = rows[base + (reverse ? count - 1 - pc : pc)];
+        return p < count ? (uint32_t)row * (uint32_t)(nrhs * 8) : 0xc0000000u;    // (the host keeps the block under 3 GB for these modes)
+    };
+    auto row_of = [&](int i, int r, bool *ok) -> int32_t {       // the general case: look the row up
         const int p = 16 * i + rq + 4 * r;
         *ok = p < count;
         if (!*ok) return 0;
-        int32_t jr = nodes[first + (reverse ? count - 1 - p : p)];
-        if (perm) jr = perm[jr];
-        return (int64_t)jr * nrhs;
+        return nodes[first + (reverse ? count - 1 - p : p)];
     };
+    if (MODE == 2) {
+        const uint32_t coff = (uint32_t)(h * 64 + 2 * col) * 8u;
+#pragma unroll
+        for (int i = 0; i < NB; i++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const uint32_t ro = perm_off(load_rows, i, r) + coff;
+#pragma unroll
+                for (int cp = 0; cp < 2; cp++) {
+                    const rg_u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs_ld, ro, 32 * cp * 8, 2);
+                    const rg_f64x2 v = __builtin_bit_cast(rg_f64x2, u);
+                    X[i][2 * cp][r] = v.x;
+                    X[i][2 * cp + 1][r] = v.y;
+                }
+            }
+    } else
     if (consecutive && wide) {
         const uint32_t coff = (uint32_t)(h * 64 + 2 * col) * 8u;
 #pragma unroll
@@ -322,7 +358,7 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void k_rag_mfma(const int4 
             for (int cp = 0; cp < 2; cp++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const rg_u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs, pos_off(i, r) + coff, 32 * cp * 8, 2);   // (aux 2 = nt: X goes through once)
+                    const rg_u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs_ld, pos_off(i, r) + coff, 32 * cp * 8, 2);   // (aux 2 = nt: X goes through once)
                     const rg_f64x2 v = __builtin_bit_cast(rg_f64x2, u);
                     X[i][2 * cp][r] = v.x;
                     X[i][2 * cp + 1][r] = v.y;
@@ -334,18 +370,20 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void k_rag_mfma(const int4 
             for (int c = 0; c < 4; c++)
 #pragma unroll
                 for (int r = 0; r < 4; r++)
-                    X[i][c][r] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, pos_off(i, r) + (uint32_t)cidx[c] * 8u, 0, 0));
+                    X[i][c][r] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs_ld, pos_off(i, r) + (uint32_t)cidx[c] * 8u, 0, 0));
     } else if (wide) {
 #pragma unroll
         for (int i = 0; i < NB; i++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 bool ok;
-                const int64_t ro = row_of(i, r, &ok);
+                int32_t jr = row_of(i, r, &ok);
+                if (ok && load_rows) jr = load_rows[jr];
+                const int64_t ro = (int64_t)jr * nrhs;
 #pragma unroll
                 for (int cp = 0; cp < 2; cp++) {
                     rg_f64x2 v = rg_f64x2{0.0, 0.0};
-                    if (ok) v = *reinterpret_cast<const rg_f64x2 *>(B + ro + h * 64 + 32 * cp + 2 * col);
+                    if (ok) v = *reinterpret_cast<const rg_f64x2 *>(Bsrc + ro + h * 64 + 32 * cp + 2 * col);
                     X[i][2 * cp][r] = v.x;
                     X[i][2 * cp + 1][r] = v.y;
                 }
@@ -356,9 +394,11 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void k_rag_mfma(const int4 
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 bool ok;
-                const int64_t ro = row_of(i, r, &ok);
+                int32_t jr = row_of(i, r, &ok);
+                if (ok && load_rows) jr = load_rows[jr];
+                const int64_t ro = (int64_t)jr * nrhs;
 #pragma unroll
-                for (int c = 0; c < 4; c++) X[i][c][r] = ok ? B[ro + cidx[c]] : 0.0;
+                for (int c = 0; c < 4; c++) X[i][c][r] = ok ? Bsrc[ro + cidx[c]] : 0.0;
             }
     }
     if (SHARE && FAST) {   // (one way of loading X: behind its loads, where the same copy costs k_cholsol_mfma less)
@@ -425,6 +465,23 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void k_rag_mfma(const int4 
         }
     }
     if (!valid) return;
+    if (MODE == 3) {
+        const uint32_t coff = (uint32_t)(h * 64 + 2 * col) * 8u;
+#pragma unroll
+        for (int i = 0; i < NB; i++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const uint32_t ro = perm_off(store_rows, i, r) + coff;
+#pragma unroll
+                for (int cp = 0; cp < 2; cp++) {
+                    rg_f64x2 v;
+                    v.x = X[i][2 * cp][r];
+                    v.y = X[i][2 * cp + 1][r];
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(rg_u32x4, v), rs_st, ro + 32u * cp * 8u, 0, 2);   // (soffset 0: see below)
+                }
+            }
+        return;
+    }
     if (consecutive && wide) {
         const uint32_t coff = (uint32_t)(h * 64 + 2 * col) * 8u;
 #pragma unroll
@@ -441,7 +498,7 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void k_rag_mfma(const int4 
                     // registers -- GCNHazardRecognizer::createsVALUHazard exempts MUBUF stores with a register soffset -- and on this
                     // chip the store then took the NEW low dword of its first register in about one block in a hundred: solutions
                     // wrong in the 7th digit, in columns 56 .. 63 of a chunk only, differently from run to run)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(rg_u32x4, v), rs, pos_off(i, r) + coff + 32u * cp * 8u, 0, 2);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(rg_u32x4, v), rs_st, pos_off(i, r) + coff + 32u * cp * 8u, 0, 2);
                 }
         return;
     }
@@ -455,7 +512,7 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void k_rag_mfma(const int4 
                     const double xv = X[i][c][r];      // (a bit_cast of the vector ELEMENT expression itself reads element 0 of the vector)
                     // a right-hand side past the block: an offset the range check refuses (0xfffffff8, not 0xffffffff: the access
                     // is two dwords, each checked on its own, and the second one's offset would wrap to 3)
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(rg_u32x2, xv), rs,
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(rg_u32x2, xv), rs_st,
                                                           live[c] ? pos_off(i, r) + (uint32_t)cidx[c] * 8u : 0xfffffff8u, 0, 0);
                 }
         return;
@@ -465,20 +522,22 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void k_rag_mfma(const int4 
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             bool ok;
-            const int64_t ro = row_of(i, r, &ok);
+            int32_t jr = row_of(i, r, &ok);
             if (!ok) continue;
+            if (store_rows) jr = store_rows[jr];
+            const int64_t ro = (int64_t)jr * nrhs;
             if (wide) {
 #pragma unroll
                 for (int cp = 0; cp < 2; cp++) {
                     rg_f64x2 v;
                     v.x = X[i][2 * cp][r];
                     v.y = X[i][2 * cp + 1][r];
-                    *reinterpret_cast<rg_f64x2 *>(B + ro + h * 64 + 32 * cp + 2 * col) = v;
+                    *reinterpret_cast<rg_f64x2 *>(Bdst + ro + h * 64 + 32 * cp + 2 * col) = v;
                 }
             } else {
 #pragma unroll
                 for (int c = 0; c < 4; c++)
-                    if (live[c]) B[ro + cidx[c]] = X[i][c][r];
+                    if (live[c]) Bdst[ro + cidx[c]] = X[i][c][r];
             }
         }
 }
@@ -615,11 +674,21 @@ int ragged_build(const Tree *trees, int32_t ntrees, int32_t max_rows, const int3
 }
 
 int ragged_solve(const RaggedMfma *R, const int32_t *nodes, const int32_t *perm, bool reverse, int passes, double *X, int32_t nrhs) {
+    return ragged_solve_io(R, nodes, perm, perm, reverse, passes, X, X, nrhs, 0);
+}
+
+int ragged_solve_io(const RaggedMfma *R, const int32_t *nodes, const int32_t *load_rows, const int32_t *store_rows, bool reverse, int passes,
+                    const double *src, double *dst, int32_t nrhs, int32_t n_rows) {
     hipStream_t s = ctx().stream;
     const int32_t chunks = (nrhs + 63) / 64;
     const int rev = reverse ? 1 : 0;
-    const bool fast = R->all_consecutive && !perm && nrhs % 64 == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 &&
-                      (int64_t)(RAG_MAX_ROWS + 16) * nrhs * 8 < (1ll << 31);
+    const bool whole = R->all_consecutive && nrhs % 64 == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0 &&
+                       (int64_t)(RAG_MAX_ROWS + 16) * nrhs * 8 < (1ll << 31);
+    const bool small_block = (int64_t)n_rows * nrhs * 8 < 0xc0000000ll && n_rows > 0;
+    int mode = 0;
+    if (whole && !load_rows && !store_rows) mode = 1;
+    else if (whole && load_rows && !store_rows && passes == 1 && small_block) mode = 2;
+    else if (whole && !load_rows && store_rows && passes == 1 && small_block) mode = 3;
     for (int c = 0; c < RAG_CLASSES; c++) {
         const int32_t cnt = R->cls_start[c + 1] - R->cls_start[c];
         if (cnt <= 0) continue;
@@ -631,17 +700,25 @@ int ragged_solve(const RaggedMfma *R, const int32_t *nodes, const int32_t *perm,
         int share = chunks % 4 == 0 ? 1 : chunks % 2 == 0 ? 2 : 4;
         if (share == 4 && c >= 3) share = 0;
         const dim3 grid(share ? (unsigned)(((int64_t)cnt + share - 1) / share * (chunks / (4 / share))) : (unsigned)((tasks + 3) / 4));
-#define CSX_RS(NB, PS, SH)                                                                                                            \
-    if (fast) hipLaunchKernelGGL((k_rag_mfma<NB, PS, SH, true>), grid, dim3(256), 0, s, dsc, cnt, nodes, perm, fr, rev, X, nrhs, chunks); \
-    else hipLaunchKernelGGL((k_rag_mfma<NB, PS, SH, false>), grid, dim3(256), 0, s, dsc, cnt, nodes, perm, fr, rev, X, nrhs, chunks)
-#define CSX_RSS(NB, PS)                       \
-    if (share == 1) { CSX_RS(NB, PS, 1); }      \
-    else if (share == 2) { CSX_RS(NB, PS, 2); } \
-    else if (share == 4) { CSX_RS(NB, PS, 4); } \
-    else { CSX_RS(NB, PS, 0); }
-#define CSX_RSP(NB)                    \
-    if (passes == 2) { CSX_RSS(NB, 2); } \
-    else { CSX_RSS(NB, 1); }
+#define CSX_RK(NB, PS, SH, MD)                                                                                                          \
+    hipLaunchKernelGGL((k_rag_mfma<NB, PS, SH, MD>), grid, dim3(256), 0, s, dsc, cnt, nodes, load_rows, store_rows, fr, rev, src, dst, \
+                       nrhs, chunks, n_rows)
+#define CSX_RS1(NB, SH)                              \
+    if (mode == 1) CSX_RK(NB, 1, SH, 1);             \
+    else if (mode == 2) CSX_RK(NB, 1, SH, 2);        \
+    else if (mode == 3) CSX_RK(NB, 1, SH, 3);        \
+    else CSX_RK(NB, 1, SH, 0)
+#define CSX_RS2(NB, SH)                  \
+    if (mode == 1) CSX_RK(NB, 2, SH, 1); \
+    else CSX_RK(NB, 2, SH, 0)
+#define CSX_RSS(NB, SH)                      \
+    if (passes == 2) { CSX_RS2(NB, SH); }    \
+    else { CSX_RS1(NB, SH); }
+#define CSX_RSP(NB)                            \
+    if (share == 1) { CSX_RSS(NB, 1); }        \
+    else if (share == 2) { CSX_RSS(NB, 2); }   \
+    else if (share == 4) { CSX_RSS(NB, 4); }   \
+    else { CSX_RSS(NB, 0); }
         switch (c) {
             case 0: CSX_RSP(1); break;
             case 1: CSX_RSP(2); break;
@@ -649,9 +726,11 @@ int ragged_solve(const RaggedMfma *R, const int32_t *nodes, const int32_t *perm,
             case 3: CSX_RSP(4); break;
             default: CSX_RSP(5); break;
         }
-#undef CSX_RSS
 #undef CSX_RSP
-#undef CSX_RS
+#undef CSX_RSS
+#undef CSX_RS2
+#undef CSX_RS1
+#undef CSX_RK
         CSX_LAUNCH_CHECK();
     }
     return CSX_OK;

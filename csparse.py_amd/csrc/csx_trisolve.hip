@@ -1699,20 +1699,25 @@ static int analyse_components(TriPlan *P) {
     return CSX_OK;
 }
 
+// the components made dense for the matrix cores, the first time the rounding-equal order asks (P->rag stays null when the guard refuses)
+static int components_ragged(TriPlan *P) {
+    if (P->rag_tried) return CSX_OK;
+    P->rag_tried = true;
+    RaggedMfma *R = nullptr;
+    CSX_TRY(ragged_build(P->comps, P->ncomp, P->comp_max, P->comp_nodes, P->prog_ptr, P->prog_idx, P->prog_val, P->prog_diag, !P->forward, &R));
+    if (R) {
+        P->rag_growth = R->growth;
+        if (R->growth <= RAG_GROWTH_LIMIT) P->rag = R;     // (a NaN fails the comparison)
+        else ragged_free(R);
+    }
+    return CSX_OK;
+}
+
 static int solve_components(TriPlan *P, double *X, int32_t nrhs) {
     hipStream_t s = ctx().stream;
     if (P->rounding_equal && nrhs > 8) {
         // the caller granted rounding (csx_tri_set_order): dense components on the matrix cores, one sweep in position order
-        if (!P->rag_tried) {
-            P->rag_tried = true;
-            RaggedMfma *R = nullptr;
-            CSX_TRY(ragged_build(P->comps, P->ncomp, P->comp_max, P->comp_nodes, P->prog_ptr, P->prog_idx, P->prog_val, P->prog_diag, !P->forward, &R));
-            if (R) {
-                P->rag_growth = R->growth;
-                if (R->growth <= RAG_GROWTH_LIMIT) P->rag = R;     // (a NaN fails the comparison)
-                else ragged_free(R);
-            }
-        }
+        CSX_TRY(components_ragged(P));
         if (P->rag) return ragged_solve(P->rag, P->comp_nodes, nullptr, !P->forward, 1, X, nrhs);
     }
     // L, U with up to 8 right-hand sides: one wave per component, column-push form (W, L + U pair: 43 us at 1 RHS,
@@ -2637,6 +2642,65 @@ extern "C" int csx_permute_vec(csx_handle_t hp, csx_handle_t hb, csx_handle_t hx
     if (total == 0) return CSX_OK;
     hipLaunchKernelGGL(k_permute, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx().stream,
                        p ? (const int32_t *)p->d : nullptr, (const double *)b->d, (double *)x->d, n, nrhs, inverse);
+    CSX_LAUNCH_CHECK();
+    return CSX_OK;
+}
+
+__global__ __launch_bounds__(256) void k_invert_perm(const int32_t *__restrict__ p, int32_t n, int32_t *__restrict__ inv) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) inv[p[k]] = (int32_t)k;
+}
+
+// cs_lusol's solve phase for a block of right-hand sides (csparse.py:1470-1473): x = P b (cs_ipvec with pinv), L x = x, U x = x,
+// b = Q x (cs_ipvec with q), B overwritten with the solutions.  When both factors are forests of small components in the
+// rounding-equal order (csx_tri_set_order) the permutations are FUSED into the sweeps: the sweep over L gathers its rows out of B
+// through the inverse of pinv and leaves x in `work`, the sweep over U reads `work` and scatters through q into B -- four passes over
+// the block instead of eight ("on device must be fused into the batched solve").  Otherwise: the four steps, one
+// after the other, exactly what csx_permute_vec + csx_tri_solve + csx_tri_solve + csx_permute_vec do.  *fused says which.
+extern "C" int csx_lusol_solve(csx_handle_t hL, csx_handle_t hU, csx_handle_t hpinv, csx_handle_t hq, csx_handle_t hB,
+                               csx_handle_t hWork, int32_t nrhs, int *fused) {
+    CSX_TRY(require_ready());
+    TriPlan *PL = (TriPlan *)get(hL, K_TRIPLAN), *PU = (TriPlan *)get(hU, K_TRIPLAN);
+    Vec *B = vec(hB), *W = vec(hWork);
+    Vec *pv = hpinv ? ivec(hpinv) : nullptr, *qv = hq ? ivec(hq) : nullptr;
+    if (fused) *fused = 0;
+    if (!PL || !PU || !B || !W || nrhs < 0 || PL->n != PU->n || B->d == W->d) return CSX_EINVAL;
+    const int32_t n = PL->n;
+    if ((hpinv && (!pv || pv->len < n)) || (hq && (!qv || qv->len < n))) return CSX_EINVAL;
+    if (B->len < (int64_t)n * nrhs || W->len < (int64_t)n * nrhs) return CSX_EINVAL;
+    if (n == 0 || nrhs == 0) return CSX_OK;
+    if (PL->zero_pivot || PU->zero_pivot) return CSX_EZEROPIVOT;
+    hipStream_t s = ctx().stream;
+    const int32_t *pinv = pv ? (const int32_t *)pv->d : nullptr, *q = qv ? (const int32_t *)qv->d : nullptr;
+    double *b = (double *)B->d, *x = (double *)W->d;
+    const int64_t total = (int64_t)n * nrhs;
+    if (ctx().opt.tri_components && PL->rounding_equal && PU->rounding_equal && nrhs > 8) {
+        CSX_TRY(analyse_components(PL));
+        CSX_TRY(analyse_components(PU));
+        if (PL->comp_ok && PU->comp_ok) {
+            CSX_TRY(components_ragged(PL));
+            CSX_TRY(components_ragged(PU));
+        }
+        if (PL->comp_ok && PU->comp_ok && PL->rag && PU->rag) {
+            DevScope tmp;
+            int32_t *invp = nullptr;
+            if (pinv) {
+                CSX_TRY(tmp.alloc(&invp, (size_t)n));
+                hipLaunchKernelGGL(k_invert_perm, dim3((unsigned)(((int64_t)n + 255) / 256)), dim3(256), 0, s, pinv, n, invp);
+                CSX_LAUNCH_CHECK();
+            }
+            CSX_TRY(ragged_solve_io(PL->rag, PL->comp_nodes, invp, nullptr, !PL->forward, 1, b, x, nrhs, n));
+            CSX_TRY(ragged_solve_io(PU->rag, PU->comp_nodes, nullptr, q, !PU->forward, 1, x, b, nrhs, n));
+            if (fused) *fused = 1;
+            return CSX_OK;
+        }
+    }
+    hipLaunchKernelGGL(k_permute, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, pinv, (const double *)b, x, n, nrhs, 1);
+    CSX_LAUNCH_CHECK();
+    static const bool relaxed_env = ablation_env("CSX_TRI_RELAXED") != nullptr;   // experiments only
+    CSX_TRY(tri_solve_raw(PL, x, nrhs, relaxed_env));
+    CSX_TRY(tri_solve_raw(PU, x, nrhs, relaxed_env));
+    hipLaunchKernelGGL(k_permute, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, q, (const double *)x, b, n, nrhs, 1);
     CSX_LAUNCH_CHECK();
     return CSX_OK;
 }

@@ -204,6 +204,13 @@ int csx_tri_components(csx_handle_t plan, int32_t *ncomp);
  * inverse != 0: x[p[k], :] = b[k, :] (ipvec); else x[k, :] = b[p[k], :] (pvec).
  * p == 0 is the identity permutation. */
 int csx_permute_vec(csx_handle_t p, csx_handle_t b, csx_handle_t x, int32_t n, int32_t nrhs, int inverse);
+/* The solve phase of cs_lusol for an n-by-nrhs block, csparse.py:1470-1473 (cs_ipvec(pinv), cs_lsolve, cs_usolve, cs_ipvec(q)):
+ * b overwritten with the solutions; planL / planU: csx_tri_analyse plans of L (CSX_TRI_L) and U (CSX_TRI_U); pinv, q: int vectors
+ * or 0 (identity); work: another n-by-nrhs block.  Each plan solves in the order csx_tri_set_order gave it.  When both are
+ * in the rounding-equal order and both factors are forests of small components, the two permutations are fused into the two
+ * sweeps (four passes over the block instead of eight): *fused = 1.  Otherwise the four steps run one after the other. */
+int csx_lusol_solve(csx_handle_t planL, csx_handle_t planU, csx_handle_t pinv, csx_handle_t q, csx_handle_t b, csx_handle_t work,
+                    int32_t nrhs, int *fused);
 
 /* cs_schol (natural order), csparse.py:2051-2072: host C++ symbolic analysis of
  * the upper triangle of a host CSC pattern.  parent[n], cp[n+1]. */

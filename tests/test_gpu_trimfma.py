@@ -271,3 +271,97 @@ def test_exact_order_on_unequal_cliques_by_padded_size_classes(cs, k):
         dB1 = cs.dvec(B if k > 1 else B[:, 0].copy())
         assert F.solve(dB1) is True
         assert dB1.numpy().tobytes() == dB.numpy().tobytes()
+
+
+@pytest.mark.parametrize("nrhs", [9, 70, 128, 192])
+@pytest.mark.parametrize("perms", ["both", "pinv_only", "q_only", "none"])
+def test_lusol_solve_fuses_the_permutations_into_the_sweeps(cs, nrhs, perms):
+    """csx_lusol_solve (cs_lusol's solve phase, csparse.py:1470-1473) on block-triangular L and U with permutations that move rows
+    across the whole block: in the rounding-equal order on forests of small components the sweep over L gathers through pinv and
+    the sweep over U scatters through q (whole chunks of 64 right-hand sides: the buffer-resource gather / scatter; other counts: row
+    look-ups) -- every column BIT-identical to the four separate calls it replaces (the arithmetic is the same, only the data
+    movement differs), and those inside BASELINE's 1e-10 of the oracle; in the exact order the four steps run as before, bits of the
+    reference."""
+    import _csx
+    lib = _csx.lib()
+    rng = np.random.default_rng(nrhs * 7 + len(perms))
+    sizes = [67, 1, 5, 80, 64, 2, 17, 33, 48]
+
+    def linked(lower):
+        # every column linked to its neighbour inside the block: a block is ONE component on consecutive rows
+        cols_i, cols_x, Ap, base = [], [], [0], 0
+        for b in range(260):
+            m = sizes[b % len(sizes)]
+            for c in range(m):
+                cand = np.arange(c + 2, m) if lower else np.arange(0, c - 1)
+                pick = cand[rng.random(len(cand)) < 0.2]
+                rng.shuffle(pick)
+                link = [c + 1] if lower and c + 1 < m else ([c - 1] if not lower and c >= 1 else [])
+                d = rng.uniform(1.0, 2.0) * (1 if rng.random() < 0.5 else -1)
+                off_r = link + pick.tolist()
+                off_v = rng.uniform(-0.5, 0.5, len(link)).tolist() + rng.uniform(-0.1, 0.1, len(pick)).tolist()
+                rows = ([c] + off_r) if lower else (off_r + [c])
+                vals = ([d] + off_v) if lower else (off_v + [d])
+                cols_i.append(np.asarray(rows, np.int32) + base)
+                cols_x.append(np.asarray(vals))
+                Ap.append(Ap[-1] + len(rows))
+            base += m
+        return base, np.asarray(Ap, np.int32), np.concatenate(cols_i).astype(np.int32), np.concatenate(cols_x)
+    n, Lp, Li, Lx = linked(True)
+    n2, Up, Ui, Ux = linked(False)
+    assert n2 == n
+    L = cs.cs_pin(_host_cs(cs, n, n, Lp, Li, Lx))
+    U = cs.cs_pin(_host_cs(cs, n, n, Up, Ui, Ux))
+    pinv = rng.permutation(n).astype(np.int32) if perms in ("both", "pinv_only") else None
+    q = rng.permutation(n).astype(np.int32) if perms in ("both", "q_only") else None
+    B = synth.rhs(n, nrhs, 3)
+
+    def oracle(col):
+        pb = np.empty(n)
+        pb[pinv if pinv is not None else np.arange(n)] = col
+        y = CO.lsolve(n, Lp, Li, Lx, pb)
+        x = CO.usolve(n, Up, Ui, Ux, y)
+        out = np.empty(n)
+        out[q if q is not None else np.arange(n)] = x
+        return y, x, out
+
+    X = cs.dvec(B[:, :1].copy())
+    assert cs.cs_lsolve(L, X) is True and cs.cs_usolve(U, X) is True        # makes the two plans
+    pl, pu = L._dev.plans[KINDS["lsolve"]], U._dev.plans[KINDS["usolve"]]
+
+    def ivec(p):
+        if p is None:
+            return _csx.H(0)
+        h = _csx.new_handle()
+        _csx.check(lib.csx_ivec_upload(_csx.pi(p), n, h))
+        return h
+    hp, hq = ivec(pinv), ivec(q)
+    try:
+        results = {}
+        for exact in (1, 0):
+            for plan in (pl, pu):
+                _csx.check(lib.csx_tri_set_order(plan, exact))
+            b, w = cs.dvec(B), cs.dvec(n, nrhs)
+            fused = C.c_int(-1)
+            _csx.check(lib.csx_lusol_solve(pl, pu, hp, hq, b.handle, w.handle, nrhs, C.byref(fused)))
+            assert fused.value == (1 if exact == 0 and nrhs > 8 else 0)
+            results[exact] = b.numpy().reshape(n, nrhs).copy()
+            # the four calls it replaces, same orders
+            b2, x2 = cs.dvec(B), cs.dvec(n, nrhs)
+            _csx.check(lib.csx_permute_vec(hp, b2.handle, x2.handle, n, nrhs, 1))
+            _csx.check(lib.csx_tri_solve(pl, x2.handle, nrhs))
+            _csx.check(lib.csx_tri_solve(pu, x2.handle, nrhs))
+            _csx.check(lib.csx_permute_vec(hq, x2.handle, b2.handle, n, nrhs, 1))
+            assert b2.numpy().tobytes() == results[exact].tobytes(), (exact, "fused and separate calls differ")
+        for r in sorted({0, nrhs // 2, nrhs - 1}):
+            y, x, want = oracle(B[:, r])
+            assert results[1][:, r].tobytes() == want.tobytes()
+            terms = np.empty(n)
+            terms[q if q is not None else np.arange(n)] = _terms(n, Up, Ui, Ux, x, y, "usolve")
+            assert TOL.componentwise(results[0][:, r], want, terms) <= TOL.X_RTOL
+    finally:
+        for plan in (pl, pu):
+            lib.csx_tri_set_order(plan, 1)
+        for h in (hp, hq):
+            if h.value:
+                _csx.free(h)
