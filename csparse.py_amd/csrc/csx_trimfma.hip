@@ -244,8 +244,10 @@ typedef __attribute__((address_space(3))) void *rg_lptr;
 //      sweep over L: csparse.py:1470, cs_ipvec); one resource over all of Bsrc, a padding position's offset past its end
 //   3  as 1, but the STORE scatters: position p goes to row store_rows[base + p] of Bdst (cs_lusol's b = Q x fused into the sweep over U)
 // Bsrc / Bdst: the block read / the block written (the same block for an in-place solve).
-template <int NB, int PASSES, int SHARE, int MODE>
-__global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void k_rag_mfma(const int4 *__restrict__ desc, int32_t ncls,
+// CT: tiles of 16 right-hand sides a wave takes (a chunk is 16 CT right-hand sides): 4, or 2 for the class of 80 rows -- 5 x 4 tiles of
+// unknowns are 320 registers, one wave to a SIMD and nothing to hide a load behind; 5 x 2 leave room for three.
+template <int NB, int PASSES, int SHARE, int MODE, int CT>
+__global__ __launch_bounds__(256, 2) void k_rag_mfma(const int4 *__restrict__ desc, int32_t ncls,
                                                                      const int32_t *__restrict__ nodes,
                                                                      const int32_t *__restrict__ load_rows,
                                                                      const int32_t *__restrict__ store_rows,
@@ -294,19 +296,19 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void k_rag_mfma(const int4 
             if (k % WPT == sub) __builtin_amdgcn_global_load_lds((rg_gptr)(src + k * 128 + 2 * lane), (rg_lptr)(s_f[slot] + k * 128), 16, 0, 0);
     }
     const bool consecutive = FAST || (base >= 0 && !load_rows && !store_rows && (int64_t)(RAG_MAX_ROWS + 16) * nrhs * 8 < (1ll << 31));      // uniform (offsets of padding positions must not wrap back into range)
-    rg_f64x4 X[NB][4];
-    bool live[4];
-    int32_t cidx[4];
+    rg_f64x4 X[NB][CT];
+    bool live[CT];
+    int32_t cidx[CT];
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
-        const int32_t rhs = h * 64 + 16 * c + col;
+    for (int c = 0; c < CT; c++) {
+        const int32_t rhs = h * (16 * CT) + 16 * c + col;
         live[c] = rhs < nrhs;
         cidx[c] = live[c] ? rhs : nrhs - 1;   // clamped: loaded, never stored
     }
     // a chunk wholly inside the block (and an even nrhs: 16-byte alignment) moves 16 bytes per lane: lane (rq, col) takes the
     // neighbours 32 c' + 2 col, + 1 of a row and gives them to column chunks 2 c' and 2 c' + 1 (which right-hand side a
     // (chunk, column) pair stands for is free)
-    const bool wide = FAST || ((nrhs & 1) == 0 && h * 64 + 64 <= nrhs && ((reinterpret_cast<uintptr_t>(Bsrc) | reinterpret_cast<uintptr_t>(Bdst)) & 15) == 0);   // uniform
+    const bool wide = FAST || ((nrhs & 1) == 0 && h * (16 * CT) + 16 * CT <= nrhs && ((reinterpret_cast<uintptr_t>(Bsrc) | reinterpret_cast<uintptr_t>(Bdst)) & 15) == 0);   // uniform
     typedef unsigned int rg_u32x4 __attribute__((ext_vector_type(4)));
     typedef unsigned int rg_u32x2 __attribute__((ext_vector_type(2)));
     // the component's rows as a resource of the block read and of the block written (MODE 2 / 3: the WHOLE block on the permuted side)
@@ -335,14 +337,14 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void k_rag_mfma(const int4 
         return nodes[first + (reverse ? count - 1 - p : p)];
     };
     if (MODE == 2) {
-        const uint32_t coff = (uint32_t)(h * 64 + 2 * col) * 8u;
+        const uint32_t coff = (uint32_t)(h * (16 * CT) + 2 * col) * 8u;
 #pragma unroll
         for (int i = 0; i < NB; i++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const uint32_t ro = perm_off(load_rows, i, r) + coff;
 #pragma unroll
-                for (int cp = 0; cp < 2; cp++) {
+                for (int cp = 0; cp < CT / 2; cp++) {
                     const rg_u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs_ld, ro, 32 * cp * 8, 2);
                     const rg_f64x2 v = __builtin_bit_cast(rg_f64x2, u);
                     X[i][2 * cp][r] = v.x;
@@ -351,11 +353,11 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void k_rag_mfma(const int4 
             }
     } else
     if (consecutive && wide) {
-        const uint32_t coff = (uint32_t)(h * 64 + 2 * col) * 8u;
+        const uint32_t coff = (uint32_t)(h * (16 * CT) + 2 * col) * 8u;
 #pragma unroll
         for (int i = 0; i < NB; i++)
 #pragma unroll
-            for (int cp = 0; cp < 2; cp++)
+            for (int cp = 0; cp < CT / 2; cp++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const rg_u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs_ld, pos_off(i, r) + coff, 32 * cp * 8, 2);   // (aux 2 = nt: X goes through once)
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void k_rag_mfma(const int4 
 #pragma unroll
         for (int i = 0; i < NB; i++)
 #pragma unroll
-            for (int c = 0; c < 4; c++)
+            for (int c = 0; c < CT; c++)
 #pragma unroll
                 for (int r = 0; r < 4; r++)
                     X[i][c][r] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs_ld, pos_off(i, r) + (uint32_t)cidx[c] * 8u, 0, 0));
@@ -381,9 +383,9 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void k_rag_mfma(const int4 
                 if (ok && load_rows) jr = load_rows[jr];
                 const int64_t ro = (int64_t)jr * nrhs;
 #pragma unroll
-                for (int cp = 0; cp < 2; cp++) {
+                for (int cp = 0; cp < CT / 2; cp++) {
                     rg_f64x2 v = rg_f64x2{0.0, 0.0};
-                    if (ok) v = *reinterpret_cast<const rg_f64x2 *>(Bsrc + ro + h * 64 + 32 * cp + 2 * col);
+                    if (ok) v = *reinterpret_cast<const rg_f64x2 *>(Bsrc + ro + h * (16 * CT) + 32 * cp + 2 * col);
                     X[i][2 * cp][r] = v.x;
                     X[i][2 * cp + 1][r] = v.y;
                 }
@@ -398,7 +400,7 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void k_rag_mfma(const int4 
                 if (ok && load_rows) jr = load_rows[jr];
                 const int64_t ro = (int64_t)jr * nrhs;
 #pragma unroll
-                for (int c = 0; c < 4; c++) X[i][c][r] = ok ? Bsrc[ro + cidx[c]] : 0.0;
+                for (int c = 0; c < CT; c++) X[i][c][r] = ok ? Bsrc[ro + cidx[c]] : 0.0;
             }
     }
     if (SHARE && FAST) {   // (one way of loading X: behind its loads, where the same copy costs k_cholsol_mfma less)
@@ -422,19 +424,19 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void k_rag_mfma(const int4 
             for (int sx = 0; sx < 4; sx++) {
                 const double a = F[64 * f++];
 #pragma unroll
-                for (int c = 0; c < 4; c++) X[i][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[j][c][sx], X[i][c], 0, 0, 0);
+                for (int c = 0; c < CT; c++) X[i][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[j][c][sx], X[i][c], 0, 0, 0);
             }
-        rg_f64x4 Y[4];
+        rg_f64x4 Y[CT];
 #pragma unroll
-        for (int c = 0; c < 4; c++) Y[c] = rg_f64x4{0.0, 0.0, 0.0, 0.0};
+        for (int c = 0; c < CT; c++) Y[c] = rg_f64x4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int sx = 0; sx < 4; sx++) {
             const double a = F[64 * f++];
 #pragma unroll
-            for (int c = 0; c < 4; c++) Y[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[i][c][sx], Y[c], 0, 0, 0);
+            for (int c = 0; c < CT; c++) Y[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[i][c][sx], Y[c], 0, 0, 0);
         }
 #pragma unroll
-        for (int c = 0; c < 4; c++) X[i][c] = Y[c];
+        for (int c = 0; c < CT; c++) X[i][c] = Y[c];
     }
     if (PASSES == 2) {
         // the transposed system, backwards: the A fragment of tile' for (lane = (m, kq), k-step sx) is element (4 sx + kq, m) of
@@ -449,31 +451,31 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void k_rag_mfma(const int4 
                 for (int sx = 0; sx < 4; sx++) {
                     const double a = Ft[(size_t)tile_at(j, i) * 64 + 4 * sx];
 #pragma unroll
-                    for (int c = 0; c < 4; c++) X[i][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[j][c][sx], X[i][c], 0, 0, 0);
+                    for (int c = 0; c < CT; c++) X[i][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[j][c][sx], X[i][c], 0, 0, 0);
                 }
-            rg_f64x4 Y[4];
+            rg_f64x4 Y[CT];
 #pragma unroll
-            for (int c = 0; c < 4; c++) Y[c] = rg_f64x4{0.0, 0.0, 0.0, 0.0};
+            for (int c = 0; c < CT; c++) Y[c] = rg_f64x4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int sx = 0; sx < 4; sx++) {
                 const double a = Ft[(size_t)tile_at(i, i) * 64 + 4 * sx];
 #pragma unroll
-                for (int c = 0; c < 4; c++) Y[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[i][c][sx], Y[c], 0, 0, 0);
+                for (int c = 0; c < CT; c++) Y[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[i][c][sx], Y[c], 0, 0, 0);
             }
 #pragma unroll
-            for (int c = 0; c < 4; c++) X[i][c] = Y[c];
+            for (int c = 0; c < CT; c++) X[i][c] = Y[c];
         }
     }
     if (!valid) return;
     if (MODE == 3) {
-        const uint32_t coff = (uint32_t)(h * 64 + 2 * col) * 8u;
+        const uint32_t coff = (uint32_t)(h * (16 * CT) + 2 * col) * 8u;
 #pragma unroll
         for (int i = 0; i < NB; i++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const uint32_t ro = perm_off(store_rows, i, r) + coff;
 #pragma unroll
-                for (int cp = 0; cp < 2; cp++) {
+                for (int cp = 0; cp < CT / 2; cp++) {
                     rg_f64x2 v;
                     v.x = X[i][2 * cp][r];
                     v.y = X[i][2 * cp + 1][r];
@@ -483,11 +485,11 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void k_rag_mfma(const int4 
         return;
     }
     if (consecutive && wide) {
-        const uint32_t coff = (uint32_t)(h * 64 + 2 * col) * 8u;
+        const uint32_t coff = (uint32_t)(h * (16 * CT) + 2 * col) * 8u;
 #pragma unroll
         for (int i = 0; i < NB; i++)
 #pragma unroll
-            for (int cp = 0; cp < 2; cp++)
+            for (int cp = 0; cp < CT / 2; cp++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     rg_f64x2 v;
@@ -506,7 +508,7 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void k_rag_mfma(const int4 
 #pragma unroll
         for (int i = 0; i < NB; i++)
 #pragma unroll
-            for (int c = 0; c < 4; c++)
+            for (int c = 0; c < CT; c++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const double xv = X[i][c][r];      // (a bit_cast of the vector ELEMENT expression itself reads element 0 of the vector)
@@ -528,15 +530,15 @@ __global__ __launch_bounds__(256, (NB <= 4 ? 2 : 1)) void k_rag_mfma(const int4 
             const int64_t ro = (int64_t)jr * nrhs;
             if (wide) {
 #pragma unroll
-                for (int cp = 0; cp < 2; cp++) {
+                for (int cp = 0; cp < CT / 2; cp++) {
                     rg_f64x2 v;
                     v.x = X[i][2 * cp][r];
                     v.y = X[i][2 * cp + 1][r];
-                    *reinterpret_cast<rg_f64x2 *>(Bdst + ro + h * 64 + 32 * cp + 2 * col) = v;
+                    *reinterpret_cast<rg_f64x2 *>(Bdst + ro + h * (16 * CT) + 32 * cp + 2 * col) = v;
                 }
             } else {
 #pragma unroll
-                for (int c = 0; c < 4; c++)
+                for (int c = 0; c < CT; c++)
                     if (live[c]) Bdst[ro + cidx[c]] = X[i][c][r];
             }
         }
@@ -680,7 +682,6 @@ int ragged_solve(const RaggedMfma *R, const int32_t *nodes, const int32_t *perm,
 int ragged_solve_io(const RaggedMfma *R, const int32_t *nodes, const int32_t *load_rows, const int32_t *store_rows, bool reverse, int passes,
                     const double *src, double *dst, int32_t nrhs, int32_t n_rows) {
     hipStream_t s = ctx().stream;
-    const int32_t chunks = (nrhs + 63) / 64;
     const int rev = reverse ? 1 : 0;
     const bool whole = R->all_consecutive && nrhs % 64 == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0 &&
                        (int64_t)(RAG_MAX_ROWS + 16) * nrhs * 8 < (1ll << 31);
@@ -692,6 +693,8 @@ int ragged_solve_io(const RaggedMfma *R, const int32_t *nodes, const int32_t *lo
     for (int c = 0; c < RAG_CLASSES; c++) {
         const int32_t cnt = R->cls_start[c + 1] - R->cls_start[c];
         if (cnt <= 0) continue;
+        const int ct = c >= 4 ? 2 : 4;                          // tiles of 16 right-hand sides to a wave (see the kernel)
+        const int32_t chunks = (nrhs + 16 * ct - 1) / (16 * ct);
         const int64_t tasks = (int64_t)cnt * chunks;
         const int4 *dsc = (const int4 *)R->desc + R->cls_start[c];
         const double *fr = R->frag + R->cls_frag[c];
@@ -701,7 +704,7 @@ int ragged_solve_io(const RaggedMfma *R, const int32_t *nodes, const int32_t *lo
         if (share == 4 && c >= 3) share = 0;
         const dim3 grid(share ? (unsigned)(((int64_t)cnt + share - 1) / share * (chunks / (4 / share))) : (unsigned)((tasks + 3) / 4));
 #define CSX_RK(NB, PS, SH, MD)                                                                                                          \
-    hipLaunchKernelGGL((k_rag_mfma<NB, PS, SH, MD>), grid, dim3(256), 0, s, dsc, cnt, nodes, load_rows, store_rows, fr, rev, src, dst, \
+    hipLaunchKernelGGL((k_rag_mfma<NB, PS, SH, MD, (NB >= 5 ? 2 : 4)>), grid, dim3(256), 0, s, dsc, cnt, nodes, load_rows, store_rows, fr, rev, src, dst, \
                        nrhs, chunks, n_rows)
 #define CSX_RS1(NB, SH)                              \
     if (mode == 1) CSX_RK(NB, 1, SH, 1);             \
