@@ -1735,7 +1735,7 @@ __global__ __launch_bounds__(256, 3) void k_cholsol_dense_exact_dpp(const Tree *
 #pragma unroll
     for (int a = 0; a < BS; a++) {
         const int32_t row = __builtin_amdgcn_readlane(jrow, a);
-        x[a] = row >= 0 ? B[(int64_t)row * nrhs + rhs_ld] : 0.0;
+        x[a] = row >= 0 ? __builtin_nontemporal_load(B + (int64_t)row * nrhs + rhs_ld) : 0.0;   // (B goes through once per batch)
     }
     auto run_pass = [&](auto pass_tag) {
         constexpr int pass = decltype(pass_tag)::value;
@@ -1760,7 +1760,7 @@ __global__ __launch_bounds__(256, 3) void k_cholsol_dense_exact_dpp(const Tree *
 #pragma unroll
     for (int a = 0; a < BS; a++) {
         const int32_t row = __builtin_amdgcn_readlane(jrow, a);
-        if (live && row >= 0) B[(int64_t)row * nrhs + rhs] = x[a];
+        if (live && row >= 0) __builtin_nontemporal_store(x[a], B + (int64_t)row * nrhs + rhs);
     }
 }
 // (Round 4 tried the L values as SCALAR operands: a lane is a right-hand side, so an L value is the same for the whole wave,

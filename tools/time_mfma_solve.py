@@ -1,6 +1,6 @@
 """The matrix-core solve of config 5 alone (csx_cholsol_factor's plan, rounding-equal order): median and minimum of `sets` timings of
 `reps` back-to-back batches, HIP events on the library's stream.  For A/B runs of two builds in one gpurun call (CSX_LIB).
-usage: time_mfma_solve.py [nblocks] [bs] [nrhs] [sets] [reps]"""
+usage: time_mfma_solve.py [nblocks] [bs] [nrhs] [sets] [reps] [exact order 0/1]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "csparse.py_amd"))
@@ -13,11 +13,13 @@ bs = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 k = int(sys.argv[3]) if len(sys.argv) > 3 else 128
 sets = int(sys.argv[4]) if len(sys.argv) > 4 else 7
 reps = int(sys.argv[5]) if len(sys.argv) > 5 else 10
+exact = int(sys.argv[6]) if len(sys.argv) > 6 else 0
 n = nb * bs
 hA = _csx.new_handle()
 _csx.check(lib.csx_gen_gspd(nb, bs, 20240606, hA))
 hL, plan = _csx.new_handle(), _csx.new_handle()
 _csx.check(lib.csx_cholsol_factor(hA, 0, hL, plan), "cholsol_factor")
+_csx.check(lib.csx_cholsol_set_order(plan, exact))
 hB = _csx.new_handle()
 _csx.check(lib.csx_gen_rhs(n, k, 0, hB))
 for _ in range(3):
