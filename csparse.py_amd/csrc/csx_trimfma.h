@@ -19,7 +19,7 @@ struct RaggedMfma {
     size_t cls_frag[RAG_CLASSES + 1] = {0};      // first double of class c's fragments
     double *frag = nullptr;
     double growth = 0.0;                         // the guard's measure over all diagonal tiles
-    bool all_consecutive = false;                // every component is consecutive rows of X (every desc base >= 0)
+    bool cls_consecutive[RAG_CLASSES] = {false}; // every component of the class is consecutive rows of X (every desc base >= 0)
 };
 
 // The components' packed sweep programs (csx_sweep.h: per sweep position the terms (local row * 64, value), the diagonal) made

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void k_rag_desc(const int32_t *__restrict__ li
             base = -1;
             break;
         }
-    if (base < 0) *scattered = 1;
+    if (base < 0) scattered[min(max((tr.count + 15) / 16 - 1, 0), RAG_CLASSES - 1)] = 1;     // (its size class: k_rag_class's rule)
     desc[q] = make_int4(tr.first, tr.count, base, t);
 }
 
@@ -562,8 +562,8 @@ static int ragged_skeleton(const Tree *trees, int32_t ntrees, const int32_t *nod
     CSX_TRY(tmp.alloc(&key, (size_t)ntrees));
     CSX_TRY(tmp.alloc(&id, (size_t)ntrees));
     CSX_TRY(tmp.alloc(&skey, (size_t)ntrees));
-    CSX_TRY(tmp.alloc(&bounds, RAG_CLASSES + 2));             // (+ 1: the "a component's rows are not consecutive" flag)
-    CSX_HIP(hipMemsetAsync(bounds + RAG_CLASSES + 1, 0, sizeof(int32_t), s));
+    CSX_TRY(tmp.alloc(&bounds, 2 * RAG_CLASSES + 1));         // (+ per class: "a component's rows are not consecutive")
+    CSX_HIP(hipMemsetAsync(bounds + RAG_CLASSES + 1, 0, RAG_CLASSES * sizeof(int32_t), s));
     CSX_TRY(dalloc(&R->list, (size_t)ntrees));
     hipLaunchKernelGGL(k_rag_class, dim3((unsigned)((ntrees + 255) / 256)), dim3(256), 0, s, trees, ntrees, key, id);
     CSX_LAUNCH_CHECK();
@@ -573,11 +573,11 @@ static int ragged_skeleton(const Tree *trees, int32_t ntrees, const int32_t *nod
     hipLaunchKernelGGL(k_rag_desc, dim3((unsigned)((ntrees + 255) / 256)), dim3(256), 0, s, R->list, ntrees, trees, nodes, (int4 *)R->desc,
                        bounds + RAG_CLASSES + 1);
     CSX_LAUNCH_CHECK();
-    int32_t hb[RAG_CLASSES + 2];
+    int32_t hb[2 * RAG_CLASSES + 1];
     CSX_HIP(hipMemcpyAsync(hb, bounds, sizeof hb, hipMemcpyDeviceToHost, s));
     CSX_HIP(hipStreamSynchronize(s));
     for (int c = 0; c <= RAG_CLASSES; c++) R->cls_start[c] = hb[c];
-    R->all_consecutive = hb[RAG_CLASSES + 1] == 0;
+    for (int c = 0; c < RAG_CLASSES; c++) R->cls_consecutive[c] = hb[RAG_CLASSES + 1 + c] == 0;
     size_t total = 0;
     for (int c = 0; c < RAG_CLASSES; c++) {
         R->cls_frag[c] = total;
@@ -683,16 +683,17 @@ int ragged_solve_io(const RaggedMfma *R, const int32_t *nodes, const int32_t *lo
                     const double *src, double *dst, int32_t nrhs, int32_t n_rows) {
     hipStream_t s = ctx().stream;
     const int rev = reverse ? 1 : 0;
-    const bool whole = R->all_consecutive && nrhs % 64 == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0 &&
+    const bool whole_rhs = nrhs % 64 == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0 &&
                        (int64_t)(RAG_MAX_ROWS + 16) * nrhs * 8 < (1ll << 31);
     const bool small_block = (int64_t)n_rows * nrhs * 8 < 0xc0000000ll && n_rows > 0;
-    int mode = 0;
-    if (whole && !load_rows && !store_rows) mode = 1;
-    else if (whole && load_rows && !store_rows && passes == 1 && small_block) mode = 2;
-    else if (whole && !load_rows && store_rows && passes == 1 && small_block) mode = 3;
     for (int c = 0; c < RAG_CLASSES; c++) {
         const int32_t cnt = R->cls_start[c + 1] - R->cls_start[c];
         if (cnt <= 0) continue;
+        const bool whole = whole_rhs && R->cls_consecutive[c];
+        int mode = 0;
+        if (whole && !load_rows && !store_rows) mode = 1;
+        else if (whole && load_rows && !store_rows && passes == 1 && small_block) mode = 2;
+        else if (whole && !load_rows && store_rows && passes == 1 && small_block) mode = 3;
         const int ct = c >= 4 ? 2 : 4;                          // tiles of 16 right-hand sides to a wave (see the kernel)
         const int32_t chunks = (nrhs + 16 * ct - 1) / (16 * ct);
         const int64_t tasks = (int64_t)cnt * chunks;
