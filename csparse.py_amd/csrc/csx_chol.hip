@@ -2598,7 +2598,7 @@ static int cholsol_solve(CholPlan *P, double *B, int32_t nrhs) {
         }
     }
     if (P->lite) {
-        if (P->relaxed && P->rag && ctx().opt.cholsol_dense_blocks) return ragged_solve(P->rag, P->tree_nodes, nullptr, false, 2, B, nrhs);
+        if (P->relaxed && P->rag && ctx().opt.cholsol_dense_blocks) return ragged_solve(P->rag, P->tree_nodes, nullptr, false, 2, B, nrhs, P->n);
         if (!P->full) CSX_TRY(cholsol_plan(P->L, nullptr, &P->full));
         P->full->relaxed = false;          // (what `full` is for: the exact order, or the order the guard left)
         return cholsol_solve(P->full, B, nrhs);
@@ -2705,7 +2705,7 @@ static int cholsol_solve(CholPlan *P, double *B, int32_t nrhs) {
             return CSX_OK;
         }
         if (P->relaxed && P->rag && ctx().opt.cholsol_dense_blocks)    // trees of any shape, rounding-equal order: on the matrix cores
-            return ragged_solve(P->rag, P->tree_nodes, P->perm, false, 2, B, nrhs);
+            return ragged_solve(P->rag, P->tree_nodes, P->perm, false, 2, B, nrhs, P->n);
         const size_t per_wave = (size_t)P->max_nodes * 64 * sizeof(double);
         const int waves = tile_waves_per_workgroup(per_wave, CH_WAVES);
         const int32_t chunks = (nrhs + 63) / 64;

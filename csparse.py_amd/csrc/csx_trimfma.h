@@ -39,7 +39,8 @@ int ragged_blocks(const int32_t *start, int32_t nblocks, int32_t n, Tree *trees,
 // X (n-by-nrhs, row-major) <- the sweep applied to every component: a blocked substitution in position order on the matrix cores.
 // passes = 1: that sweep; passes = 2: then the TRANSPOSED system backwards (cs_cholsol's L then L', the fragments read transposed).
 // perm (or null): row j of the components is row perm[j] of X.
-int ragged_solve(const RaggedMfma *R, const int32_t *nodes, const int32_t *perm, bool reverse, int passes, double *X, int32_t nrhs);
+int ragged_solve(const RaggedMfma *R, const int32_t *nodes, const int32_t *perm, bool reverse, int passes, double *X, int32_t nrhs,
+                 int32_t n_rows = 0);
 // The same from one block into another (src == dst: in place), with a row permutation on either side: position p of a component
 // (node j = nodes[first + p]) is read from row load_rows[j] of src (null: row j) and written to row store_rows[j] of dst (null: row j).
 // n_rows: rows of the blocks (the fused permutations of cs_lusol address a whole block through one 32-bit resource; 0: unknown).

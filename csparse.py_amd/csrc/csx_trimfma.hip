@@ -243,6 +243,9 @@ typedef __attribute__((address_space(3))) void *rg_lptr;
 //   2  as 1, but the LOAD gathers: position p of a component takes row load_rows[base + p] of Bsrc (cs_lusol's x = P b fused into the
 //      sweep over L: csparse.py:1470, cs_ipvec); one resource over all of Bsrc, a padding position's offset past its end
 //   3  as 1, but the STORE scatters: position p goes to row store_rows[base + p] of Bdst (cs_lusol's b = Q x fused into the sweep over U)
+//   4  whole chunks, rows LOOKED UP on both sides (nodes, then load_rows / store_rows when given: components that are not consecutive
+//      rows, cs_cholsol with a fill-reducing order): one resource over each whole block, a position's two byte offsets computed once
+//      and kept (a padding position's past the end) -- the look-ups of MODE 0 without its branches and without its four paths
 // Bsrc / Bdst: the block read / the block written (the same block for an in-place solve).
 // CT: tiles of 16 right-hand sides a wave takes (a chunk is 16 CT right-hand sides): 4, or 2 for the class of 80 rows -- 5 x 4 tiles of
 // unknowns are 320 registers, one wave to a SIMD and nothing to hide a load behind; 5 x 2 leave room for three.
@@ -313,10 +316,10 @@ __global__ __launch_bounds__(256, 2) void k_rag_mfma(const int4 *__restrict__ de
     typedef unsigned int rg_u32x2 __attribute__((ext_vector_type(2)));
     // the component's rows as a resource of the block read and of the block written (MODE 2 / 3: the WHOLE block on the permuted side)
     const __amdgpu_buffer_rsrc_t rs_ld =
-        MODE == 2 ? __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(Bsrc), 0, (int32_t)((uint32_t)n_rows * (uint32_t)nrhs * 8u), 0x00020000)
+        (MODE == 2 || MODE == 4) ? __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(Bsrc), 0, (int32_t)((uint32_t)n_rows * (uint32_t)nrhs * 8u), 0x00020000)
                   : __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(Bsrc) + (consecutive ? (int64_t)base * nrhs : 0), 0, consecutive ? count * nrhs * 8 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_st =
-        MODE == 3 ? __builtin_amdgcn_make_buffer_rsrc(Bdst, 0, (int32_t)((uint32_t)n_rows * (uint32_t)nrhs * 8u), 0x00020000)
+        (MODE == 3 || MODE == 4) ? __builtin_amdgcn_make_buffer_rsrc(Bdst, 0, (int32_t)((uint32_t)n_rows * (uint32_t)nrhs * 8u), 0x00020000)
                   : __builtin_amdgcn_make_buffer_rsrc(Bdst + (consecutive ? (int64_t)base * nrhs : 0), 0, consecutive ? count * nrhs * 8 : 0, 0x00020000);
     // byte offset of position p's row inside the component (padding: past the size, also when the order is reversed)
     auto pos_off = [&](int i, int r) -> uint32_t {
@@ -336,13 +339,29 @@ __global__ __launch_bounds__(256, 2) void k_rag_mfma(const int4 *__restrict__ de
         if (!*ok) return 0;
         return nodes[first + (reverse ? count - 1 - p : p)];
     };
-    if (MODE == 2) {
+    uint32_t off_ld[MODE == 4 ? NB : 1][4], off_st[MODE == 4 ? NB : 1][4];      // MODE 4: the looked-up rows' byte offsets
+    if (MODE == 4) {
+#pragma unroll
+        for (int i = 0; i < NB; i++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int p = 16 * i + rq + 4 * r;
+                const bool ok = p < count;
+                const int pc = ok ? p : count - 1;
+                const int32_t j = nodes[first + (reverse ? count - 1 - pc : pc)];
+                const int32_t jl = load_rows ? load_rows[j] : j;
+                const int32_t js = store_rows == load_rows ? jl : (store_rows ? store_rows[j] : j);
+                off_ld[MODE == 4 ? i : 0][r] = ok ? (uint32_t)jl * (uint32_t)(nrhs * 8) : 0xc0000000u;
+                off_st[MODE == 4 ? i : 0][r] = ok ? (uint32_t)js * (uint32_t)(nrhs * 8) : 0xc0000000u;
+            }
+    }
+    if (MODE == 2 || MODE == 4) {
         const uint32_t coff = (uint32_t)(h * (16 * CT) + 2 * col) * 8u;
 #pragma unroll
         for (int i = 0; i < NB; i++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const uint32_t ro = perm_off(load_rows, i, r) + coff;
+                const uint32_t ro = (MODE == 4 ? off_ld[MODE == 4 ? i : 0][r] : perm_off(load_rows, i, r)) + coff;
 #pragma unroll
                 for (int cp = 0; cp < CT / 2; cp++) {
                     const rg_u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rs_ld, ro, 32 * cp * 8, 2);
@@ -467,13 +486,13 @@ __global__ __launch_bounds__(256, 2) void k_rag_mfma(const int4 *__restrict__ de
         }
     }
     if (!valid) return;
-    if (MODE == 3) {
+    if (MODE == 3 || MODE == 4) {
         const uint32_t coff = (uint32_t)(h * (16 * CT) + 2 * col) * 8u;
 #pragma unroll
         for (int i = 0; i < NB; i++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const uint32_t ro = perm_off(store_rows, i, r) + coff;
+                const uint32_t ro = (MODE == 4 ? off_st[MODE == 4 ? i : 0][r] : perm_off(store_rows, i, r)) + coff;
 #pragma unroll
                 for (int cp = 0; cp < CT / 2; cp++) {
                     rg_f64x2 v;
@@ -675,8 +694,9 @@ int ragged_build(const Tree *trees, int32_t ntrees, int32_t max_rows, const int3
     return CSX_OK;
 }
 
-int ragged_solve(const RaggedMfma *R, const int32_t *nodes, const int32_t *perm, bool reverse, int passes, double *X, int32_t nrhs) {
-    return ragged_solve_io(R, nodes, perm, perm, reverse, passes, X, X, nrhs, 0);
+int ragged_solve(const RaggedMfma *R, const int32_t *nodes, const int32_t *perm, bool reverse, int passes, double *X, int32_t nrhs,
+                 int32_t n_rows) {
+    return ragged_solve_io(R, nodes, perm, perm, reverse, passes, X, X, nrhs, n_rows);
 }
 
 int ragged_solve_io(const RaggedMfma *R, const int32_t *nodes, const int32_t *load_rows, const int32_t *store_rows, bool reverse, int passes,
@@ -694,6 +714,7 @@ int ragged_solve_io(const RaggedMfma *R, const int32_t *nodes, const int32_t *lo
         if (whole && !load_rows && !store_rows) mode = 1;
         else if (whole && load_rows && !store_rows && passes == 1 && small_block) mode = 2;
         else if (whole && !load_rows && store_rows && passes == 1 && small_block) mode = 3;
+        else if (whole_rhs && small_block) mode = 4;
         const int ct = c >= 4 ? 2 : 4;                          // tiles of 16 right-hand sides to a wave (see the kernel)
         const int32_t chunks = (nrhs + 16 * ct - 1) / (16 * ct);
         const int64_t tasks = (int64_t)cnt * chunks;
@@ -711,9 +732,11 @@ int ragged_solve_io(const RaggedMfma *R, const int32_t *nodes, const int32_t *lo
     if (mode == 1) CSX_RK(NB, 1, SH, 1);             \
     else if (mode == 2) CSX_RK(NB, 1, SH, 2);        \
     else if (mode == 3) CSX_RK(NB, 1, SH, 3);        \
+    else if (mode == 4) CSX_RK(NB, 1, SH, 4);        \
     else CSX_RK(NB, 1, SH, 0)
-#define CSX_RS2(NB, SH)                  \
-    if (mode == 1) CSX_RK(NB, 2, SH, 1); \
+#define CSX_RS2(NB, SH)                       \
+    if (mode == 1) CSX_RK(NB, 2, SH, 1);      \
+    else if (mode == 4) CSX_RK(NB, 2, SH, 4); \
     else CSX_RK(NB, 2, SH, 0)
 #define CSX_RSS(NB, SH)                      \
     if (passes == 2) { CSX_RS2(NB, SH); }    \

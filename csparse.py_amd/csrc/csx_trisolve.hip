@@ -1718,7 +1718,7 @@ static int solve_components(TriPlan *P, double *X, int32_t nrhs) {
     if (P->rounding_equal && nrhs > 8) {
         // the caller granted rounding (csx_tri_set_order): dense components on the matrix cores, one sweep in position order
         CSX_TRY(components_ragged(P));
-        if (P->rag) return ragged_solve(P->rag, P->comp_nodes, nullptr, !P->forward, 1, X, nrhs);
+        if (P->rag) return ragged_solve(P->rag, P->comp_nodes, nullptr, !P->forward, 1, X, nrhs, P->n);
     }
     // L, U with up to 8 right-hand sides: one wave per component, column-push form (W, L + U pair: 43 us at 1 RHS,
     // 78 us at 8; at 64 the entry-parallel lanes are gone and it loses to k_tri_local, 483 against 272 us)

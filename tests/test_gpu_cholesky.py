@@ -179,6 +179,46 @@ def test_gspd_factor_and_batched_solve(cs, nblocks, bs, k):
     assert np.asarray(b).tobytes() == refs[0].tobytes()
 
 
+@pytest.mark.parametrize("nblocks,bs,k", [(40, 64, 128), (25, 16, 70), (7, 32, 192)])
+def test_matrix_core_solve_reads_L_or_the_plans_copy_same_bits(cs, nblocks, bs, k):
+    """k_cholsol_mfma takes the off-diagonal tiles out of L.x itself (a plan on all the columns of L: csx_cholsol_factor's, or the
+    three calls' when the factor is recognised as equal blocks) or out of the packed copy a plan of the GENERAL analysis keeps
+    ("chol.clique" = 0 takes the recognition away): three routes to the same operands, the same solution bits."""
+    import _csx
+    lib = _csx.lib()
+    Ap, Ai, Ax = synth.gspd(nblocks, bs, 20240613)
+    n = nblocks * bs
+    A = cs.cs_pin(_host_cs(cs, n, n, Ap, Ai, Ax))
+    B = synth.rhs(n, k, 1)
+    F = cs.cholsol_factor(A, exact=False)                  # one call: the block kernel wrote the W tiles, the rest is L.x
+    assert F.info()["matrix_cores"] is True
+    d0 = cs.dvec(B)
+    assert F.solve(d0) is True
+    X0 = d0.numpy().copy()
+    S = cs.cs_schol(0, A)
+    N = cs.cs_chol(A, S)
+    outs = {}
+    for name, clique in (("recognised", 1), ("general", 0)):
+        with _csx.option("chol.clique", clique):
+            plan = _csx.new_handle()
+            with cs._Resident(N.L) as dL:
+                _csx.check(lib.csx_cholsol_plan(dL.handle, None, plan))
+                _csx.check(lib.csx_cholsol_set_order(plan, 0))
+                a, b, c = _csx.C.c_int32(), _csx.C.c_int32(), _csx.C.c_int32()
+                _csx.check(lib.csx_cholsol_info(plan, a, b, c))
+                assert a.value == 3, (name, a.value)          # dense blocks on the matrix cores
+                dB = cs.dvec(B)
+                _csx.check(lib.csx_cholsol_solve(plan, dB.handle, k))
+                outs[name] = dB.numpy().copy()
+                _csx.free(plan)
+    assert outs["recognised"].tobytes() == X0.tobytes()
+    assert outs["general"].tobytes() == X0.tobytes()
+    gLp, gLi, gLx = _arr(N.L)
+    for r in (0, k - 1):
+        ref = CO.ltsolve(n, gLp, gLi, gLx, CO.lsolve(n, gLp, gLi, gLx, B[:, r]))
+        assert TOL.normwise(X0.reshape(n, k)[:, r], ref) <= 1e-13
+
+
 @pytest.mark.parametrize("bs", [16, 64])
 @pytest.mark.parametrize("spread", [1.0, 30.0, 300.0, 800.0, 3000.0, 1e5])
 def test_matrix_core_solve_below_and_above_the_growth_guard(cs, bs, spread):

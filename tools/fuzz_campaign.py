@@ -278,10 +278,12 @@ while time.time() < t_end:
             Tp = np.zeros(n + 1, np.int32); Tp[1:] = np.cumsum([len(c) for c in cols_i])
             tri[lower] = (Tp, np.concatenate(cols_i).astype(np.int32), np.concatenate(cols_x))
         B = rng.uniform(-1, 1, size=(n, 3))
+        pinned = {}
         for fn, ofn, lower in ((cs.cs_lsolve, CO.lsolve, True), (cs.cs_ltsolve, CO.ltsolve, True),
                                (cs.cs_usolve, CO.usolve, False), (cs.cs_utsolve, CO.utsolve, False)):
             Tp, Ti, Tx = tri[lower]
             M = cs.cs_pin(host(cs, n, n, Tp, Ti, Tx))
+            pinned[fn] = M
             b = B[:, 0].tolist()
             assert fn(M, b) is True
             assert np.asarray(b).tobytes() == ofn(n, Tp, Ti, Tx, B[:, 0]).tobytes(), ("trisolve list", seed, fn.__name__, n, shape)
@@ -308,6 +310,57 @@ while time.time() < t_end:
                 err = float(np.max(np.abs(X20[:, r] - z))) / max(float(np.max(np.abs(z))), 1e-300)
                 assert err <= 1e-11, ("trisolve rounding-equal", seed, fn.__name__, n, shape, mc.value, err)
             counts["tri_rounding_equal_mc%d" % mc.value] = counts.get("tri_rounding_equal_mc%d" % mc.value, 0) + 1
+        # round 5, late: cs_lusol's solve phase as one call (csx_lusol_solve) on this L and U with random permutations, both orders:
+        # the same bits as the four calls it replaces (permutations fused into the sweeps or not), the exact order the oracle's bits
+        lib = _csx.lib()
+        pl, pu = pinned[cs.cs_lsolve]._dev.plans[cs.TRI_L], pinned[cs.cs_usolve]._dev.plans[cs.TRI_U]
+        k = int(rng.choice([9, 20, 64, 100, 128]))
+        Bk = rng.uniform(-1, 1, size=(n, k))
+        perms = []
+        for want in (rng.random() < 0.8, rng.random() < 0.8):
+            perms.append(rng.permutation(n).astype(np.int32) if want else None)
+        hs = []
+        for pp in perms:
+            if pp is None:
+                hs.append(_csx.H(0))
+            else:
+                h = _csx.new_handle()
+                _csx.check(lib.csx_ivec_upload(_csx.pi(pp), n, h))
+                hs.append(h)
+        try:
+            for exact in (1, 0):
+                for plan in (pl, pu):
+                    _csx.check(lib.csx_tri_set_order(plan, exact))
+                b1, w1 = cs.dvec(Bk), cs.dvec(n, k)
+                fused = _csx.C.c_int(-1)
+                _csx.check(lib.csx_lusol_solve(pl, pu, hs[0], hs[1], b1.handle, w1.handle, k, _csx.C.byref(fused)))
+                got = b1.numpy().reshape(n, k).copy()
+                b2, x2 = cs.dvec(Bk), cs.dvec(n, k)
+                _csx.check(lib.csx_permute_vec(hs[0], b2.handle, x2.handle, n, k, 1))
+                _csx.check(lib.csx_tri_solve(pl, x2.handle, k))
+                _csx.check(lib.csx_tri_solve(pu, x2.handle, k))
+                _csx.check(lib.csx_permute_vec(hs[1], x2.handle, b2.handle, n, k, 1))
+                assert b2.numpy().tobytes() == got.tobytes(), ("lusol_solve against the four calls", seed, n, shape, k, exact, fused.value)
+                ident = np.arange(n)
+                for r in (0, k - 1):
+                    pb = np.empty(n)
+                    pb[perms[0] if perms[0] is not None else ident] = Bk[:, r]
+                    z = CO.usolve(n, *tri[False], CO.lsolve(n, *tri[True], pb))
+                    want = np.empty(n)
+                    want[perms[1] if perms[1] is not None else ident] = z
+                    if exact:
+                        assert got[:, r].tobytes() == want.tobytes(), ("lusol_solve exact", seed, n, shape, k, r)
+                    else:
+                        err = float(np.max(np.abs(got[:, r] - want))) / max(float(np.max(np.abs(want))), 1e-300)
+                        assert err <= 1e-11, ("lusol_solve rounding-equal", seed, n, shape, k, r, fused.value, err)
+                key = "lusol_solve_%s_fused%d" % ("exact" if exact else "rounding", fused.value)
+                counts[key] = counts.get(key, 0) + 1
+        finally:
+            for plan in (pl, pu):
+                lib.csx_tri_set_order(plan, 1)
+            for h in hs:
+                if h.value:
+                    _csx.free(h)
         counts["trisolve"] += 1
         continue
     if kind == 4:      # cs_schol + cs_chol + cs_cholsol on random SPD matrices: banded, block-diagonal, scattered
