@@ -2648,7 +2648,7 @@ extern "C" int csx_permute_vec(csx_handle_t hp, csx_handle_t hb, csx_handle_t hx
 
 __global__ __launch_bounds__(256) void k_invert_perm(const int32_t *__restrict__ p, int32_t n, int32_t *__restrict__ inv) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n) inv[p[k]] = (int32_t)k;
+    if (k < n && (uint32_t)p[k] < (uint32_t)n) inv[p[k]] = (int32_t)k;      // (an entry out of range is the caller's error: no write outside)
 }
 
 // cs_lusol's solve phase for a block of right-hand sides (csparse.py:1470-1473): x = P b (cs_ipvec with pinv), L x = x, U x = x,
@@ -2686,6 +2686,7 @@ extern "C" int csx_lusol_solve(csx_handle_t hL, csx_handle_t hU, csx_handle_t hp
             int32_t *invp = nullptr;
             if (pinv) {
                 CSX_TRY(tmp.alloc(&invp, (size_t)n));
+                CSX_HIP(hipMemsetAsync(invp, 0, (size_t)n * sizeof(int32_t), s));      // (not a permutation: rows never named read row 0)
                 hipLaunchKernelGGL(k_invert_perm, dim3((unsigned)(((int64_t)n + 255) / 256)), dim3(256), 0, s, pinv, n, invp);
                 CSX_LAUNCH_CHECK();
             }
