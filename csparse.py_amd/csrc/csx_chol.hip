@@ -1546,45 +1546,67 @@ __device__ __forceinline__ double dpp_row_bcast(const double v) {
     return __longlong_as_double(__builtin_amdgcn_mov_dpp(__double_as_longlong(v), 0x150 + K, 0xf, 0xf, true));
 }
 
+// Where the pass finds L.  PACKED = false: the plan's PROGRAMS -- the strictly lower triangle row-major in sweep order (term E of
+// sweep row SP at SP (SP - 1) / 2 + E; the backward pass reads the row-reversed copy with the same indices), the diagonals in an
+// array of their own.  PACKED = true (round 5): the block's packed COLUMNS as they lie in L.x -- entry (R, C), R >= C, at
+// C BS - C (C - 1) / 2 + R - C -- one copy for both passes and no programs at all: forward, sweep row SP is matrix row SP and term
+// E its column E; backward, sweep row SP is COLUMN BS - 1 - SP and term E its row BS - 1 - E.
+template <int BS>
+constexpr int xl_col(int C) { return C * BS - C * (C - 1) / 2 - C; }                 // entry (R, C) at xl_col(C) + R
+template <int BS, bool BACKWARD, bool PACKED>
+constexpr int xl_term(int SP, int E) {                                               // wave-uniform index of term E of sweep row SP
+    return !PACKED ? SP * (SP - 1) / 2 + E : (!BACKWARD ? xl_col<BS>(E) + SP : xl_col<BS>(BS - 1 - SP) + BS - 1 - E);
+}
+template <int BS, bool BACKWARD, bool PACKED>
+constexpr int xl_diag(int SP) {                                                      // index of sweep row SP's diagonal (PACKED: in the copy)
+    return !PACKED ? SP : (!BACKWARD ? xl_col<BS>(SP) + SP : xl_col<BS>(BS - 1 - SP) + BS - 1 - SP);
+}
+// the 16 lanes of a DPP row read terms 16 G .. 16 G + 15 of sweep row NS: lane k at lb[G] + xl_group(NS, G), lb = the lane's part
+// (programs: + k; packed forward: the start of column 16 G + k; packed backward: - k, the rows of one column descending)
+template <int BS, bool BACKWARD, bool PACKED>
+constexpr int xl_group(int NS, int G) {
+    return !PACKED ? NS * (NS - 1) / 2 + 16 * G : (!BACKWARD ? NS : xl_col<BS>(BS - 1 - NS) + BS - 1 - 16 * G);
+}
+
 // term E of sweep row SP; the L values of a group of 16 terms die with the group's last term, and the same group of the
 // NEXT row is requested there: four values live instead of eight (168 VGPRs is three waves per SIMD at blocks of 64)
-template <int BS, bool BACKWARD, int MIX, int SP, int E>
-__device__ __forceinline__ void dense_exact_term_dpp(const double (&x)[BS], const double *Ml, const double *Mu, const double (&lv)[4],
+template <int BS, bool BACKWARD, int MIX, bool PACKED, int SP, int E>
+__device__ __forceinline__ void dense_exact_term_dpp(const double (&x)[BS], const double *M, const int (&lb)[4], const double (&lv)[4],
                                                      double (&nxt)[4], double &acc) {
     constexpr int G = E >> 4, NS = SP + 1;
     // One term in four takes its L value by a broadcast LDS read instead: two VALU instructions instead of three, on the LDS
     // path the DPP form left idle.  Measured at blocks of 64 (ms per 128 right-hand sides): none 4.81, one in four 4.59, two
     // in four 4.93 -- at half the terms the return path (4 clk per broadcast value and CU) is 80 % busy and its latency shows.
     constexpr bool via_lds = (E & 3) < MIX;
-    const double lb = via_lds ? Mu[SP * (SP - 1) / 2 + E] : dpp_row_bcast<(E & 15)>(lv[G]);
-    const double t = lb * x[BACKWARD ? BS - 1 - E : E];
+    const double lbv = via_lds ? M[xl_term<BS, BACKWARD, PACKED>(SP, E)] : dpp_row_bcast<(E & 15)>(lv[G]);
+    const double t = lbv * x[BACKWARD ? BS - 1 - E : E];
     acc = acc - t;
     constexpr bool last_of_group = BACKWARD ? (E & 15) == 0 : ((E & 15) == 15 || E == SP - 1);
-    if constexpr (last_of_group && NS < BS) nxt[G] = Ml[NS * (NS - 1) / 2 + 16 * G];
+    if constexpr (last_of_group && NS < BS) nxt[G] = M[lb[G] + xl_group<BS, BACKWARD, PACKED>(NS, G)];
     // a row's products are independent of each other: left alone the scheduler forms dozens of them ahead of the
     // subtraction chain and spills; four at a time is ahead enough
     if constexpr ((E & 3) == (BACKWARD ? 0 : 3) || last_of_group) __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int BS, bool BACKWARD, int MIX, int SP, int... I>
-__device__ __forceinline__ void dense_exact_terms_dpp(const double (&x)[BS], const double *Ml, const double *Mu, const double (&lv)[4],
+template <int BS, bool BACKWARD, int MIX, bool PACKED, int SP, int... I>
+__device__ __forceinline__ void dense_exact_terms_dpp(const double (&x)[BS], const double *M, const int (&lb)[4], const double (&lv)[4],
                                                       double (&nxt)[4], double &acc, std::integer_sequence<int, I...>) {
     // the reference's order: ascending columns forward, descending (in sweep numbering) backward
-    (dense_exact_term_dpp<BS, BACKWARD, MIX, SP, (BACKWARD ? SP - 1 - I : I)>(x, Ml, Mu, lv, nxt, acc), ...);
+    (dense_exact_term_dpp<BS, BACKWARD, MIX, PACKED, SP, (BACKWARD ? SP - 1 - I : I)>(x, M, lb, lv, nxt, acc), ...);
 }
 
-// sweep row SP: cur = its L values (lane l: entry 16 g + (l & 15) of the packed row), dv its diagonal; requests row SP + 1
-template <int BS, bool BACKWARD, int MIX, int SP>
-__device__ __forceinline__ void dense_exact_row_dpp(double (&x)[BS], const double *Ml, const double *Mu, const double *D, const double (&cur)[4],
+// sweep row SP: cur = its L values (lane l: entry 16 g + (l & 15) of the row's terms), dv its diagonal; requests row SP + 1
+template <int BS, bool BACKWARD, int MIX, bool PACKED, int SP>
+__device__ __forceinline__ void dense_exact_row_dpp(double (&x)[BS], const double *M, const int (&lb)[4], const double *D, const double (&cur)[4],
                                                     double (&nxt)[4], const double dv, double &dnext) {
     constexpr int NS = SP + 1;
     if constexpr (NS < BS) {
         // a group the next row has and this one has not (its first term is this row's unknown)
-        if constexpr ((NS + 15) / 16 > (SP + 15) / 16) nxt[(SP + 15) / 16] = Ml[NS * (NS - 1) / 2 + 16 * ((SP + 15) / 16)];
-        dnext = D[NS];
+        if constexpr ((NS + 15) / 16 > (SP + 15) / 16) nxt[(SP + 15) / 16] = M[lb[(SP + 15) / 16] + xl_group<BS, BACKWARD, PACKED>(NS, (SP + 15) / 16)];
+        dnext = D[xl_diag<BS, BACKWARD, PACKED>(NS)];
     }
     double acc = x[BACKWARD ? BS - 1 - SP : SP];
-    dense_exact_terms_dpp<BS, BACKWARD, MIX, SP>(x, Ml, Mu, cur, nxt, acc, std::make_integer_sequence<int, SP>{});
+    dense_exact_terms_dpp<BS, BACKWARD, MIX, PACKED, SP>(x, M, lb, cur, nxt, acc, std::make_integer_sequence<int, SP>{});
     double xr = acc / dv;
     // the row's arithmetic is pure: nothing but its data dependences holds it in place, and the instruction selector sank
     // whole rows of it behind the moves of later rows (256 VGPRs and spills at blocks of 16).  An empty volatile asm that
@@ -1594,17 +1616,24 @@ __device__ __forceinline__ void dense_exact_row_dpp(double (&x)[BS], const doubl
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int BS, bool BACKWARD, int MIX, int... SP>
-__device__ __forceinline__ void dense_exact_rows_dpp(double (&x)[BS], const double *Ml, const double *Mu, const double *D,
+template <int BS, bool BACKWARD, int MIX, bool PACKED, int... SP>
+__device__ __forceinline__ void dense_exact_rows_dpp(double (&x)[BS], const double *M, const int (&lb)[4], const double *D,
                                                      std::integer_sequence<int, SP...>) {
     double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};   // L values of the even / odd sweep rows
-    double da = D[0], db = 1.0;                                         // and their diagonals
-    (dense_exact_row_dpp<BS, BACKWARD, MIX, SP>(x, Ml, Mu, D, (SP & 1) ? b : a, (SP & 1) ? a : b, (SP & 1) ? db : da, (SP & 1) ? da : db), ...);
+    double da = D[xl_diag<BS, BACKWARD, PACKED>(0)], db = 1.0;           // and their diagonals
+    (dense_exact_row_dpp<BS, BACKWARD, MIX, PACKED, SP>(x, M, lb, D, (SP & 1) ? b : a, (SP & 1) ? a : b, (SP & 1) ? db : da, (SP & 1) ? da : db), ...);
 }
 
-template <int BS, bool BACKWARD, int MIX>
+template <int BS, bool BACKWARD, int MIX, bool PACKED>
 __device__ __forceinline__ void dense_exact_pass_dpp(double (&x)[BS], const double *M, const double *D, const int lane) {
-    dense_exact_rows_dpp<BS, BACKWARD, MIX>(x, M + (lane & 15), M, D, std::make_integer_sequence<int, BS>{});
+    const int k = lane & 15;
+    int lb[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const int c = 16 * g + k < BS ? 16 * g + k : BS - 1;          // (lanes past the block's columns: any address inside the copy)
+        lb[g] = !PACKED ? k : (!BACKWARD ? c * BS - c * (c - 1) / 2 - c : -k);
+    }
+    dense_exact_rows_dpp<BS, BACKWARD, MIX, PACKED>(x, M, lb, D, std::make_integer_sequence<int, BS>{});
 }
 
 // second launch-bound argument = waves per SIMD the register allocation must leave room for: without it the
@@ -1697,15 +1726,17 @@ __global__ __launch_bounds__(256, (RING || R == 2 ? 1 : 2)) void k_cholsol_dense
 // (16.6 KB) does not if every wave stages its own (4 x 16.6 KB per workgroup: two workgroups per CU).  Waves of a
 // workgroup that solve the SAME block for different right-hand sides share one copy: SHARE = blocks per workgroup
 // (4, 2 or 1), 4 / SHARE waves per block, each staging its share of the DMA; two workgroup barriers per pass.
-template <int BS, int SHARE, int MIX>
+// PACKED (round 5; a plan on all the columns of L, equal blocks): f_val = L.x itself, block t at t BS (BS + 1) / 2 -- the block's
+// packed columns are copied ONCE and serve both passes (see xl_term); no programs, no diagonal arrays: the other pointers are unused.
+template <int BS, int SHARE, int MIX, bool PACKED>
 __global__ __launch_bounds__(256, 3) void k_cholsol_dense_exact_dpp(const Tree *__restrict__ trees, int32_t ntrees,
                                                                     const int32_t *__restrict__ nodes, const int32_t *__restrict__ perm,
                                                                     const int32_t *__restrict__ f_ptr, const double *__restrict__ f_val,
                                                                     const int32_t *__restrict__ b_ptr, const double *__restrict__ b_val,
                                                                     const double *__restrict__ diagf, const double *__restrict__ diagb,
                                                                     double *B, int32_t nrhs, int32_t chunks) {
-    constexpr int NT = BS * (BS - 1) / 2;
-    constexpr int MSZ = ((NT + 127) / 128 * 128 > NT + BS) ? (NT + 127) / 128 * 128 : NT + BS;
+    constexpr int NT = BS * (BS - 1) / 2, NENT = BS * (BS + 1) / 2;
+    constexpr int MSZ = PACKED ? (NENT + 127) / 128 * 128 : (((NT + 127) / 128 * 128 > NT + BS) ? (NT + 127) / 128 * 128 : NT + BS);
     constexpr int WPT = 4 / SHARE;                          // waves per block
     __shared__ __attribute__((aligned(16))) double s_m[SHARE][MSZ];
     const int lane = threadIdx.x & 63;
@@ -1720,7 +1751,7 @@ __global__ __launch_bounds__(256, 3) void k_cholsol_dense_exact_dpp(const Tree *
     const int32_t rhs = h * 64 + lane;
     const bool live = valid && rhs < nrhs;
     const int32_t rhs_ld = rhs < nrhs ? rhs : nrhs - 1;
-    double *M = s_m[slot], *DG = s_m[slot] + NT;            // DG overlaps the DMA overrun and is written after it
+    double *M = s_m[slot], *DG = PACKED ? s_m[slot] : s_m[slot] + NT;   // (programs: DG overlaps the DMA overrun and is written after it)
     // (a node of -1 is PADDING: a block of fewer than BS columns padded at its end with the identity -- cholsol_exact_classes.
     // Its unknown starts as +0.0, stays +0.0 through both sweeps and is never stored; the zero coefficients that link it to the
     // real rows come last in every real row's backward sum and subtract (+0.0) (+0.0) = +0.0: no bit of a real unknown changes --
@@ -1739,21 +1770,29 @@ __global__ __launch_bounds__(256, 3) void k_cholsol_dense_exact_dpp(const Tree *
     }
     auto run_pass = [&](auto pass_tag) {
         constexpr int pass = decltype(pass_tag)::value;
-        const int32_t *ptr = pass ? b_ptr : f_ptr;
-        const double *val = pass ? b_val : f_val;           // b_val here is the row-reversed dense copy
-        const double *dg = pass ? diagb : diagf;
-        const int32_t base = ptr[first];
-        const double dv = lane < BS ? dg[first + lane] : 1.0;
-        if (pass) __syncthreads();                          // every wave of the block is done with the forward copy
+        if (!PACKED || pass == 0) {
+            const int32_t *ptr = pass ? b_ptr : f_ptr;
+            const double *val = pass ? b_val : f_val;           // b_val here is the row-reversed dense copy
+            const double *dg = pass ? diagb : diagf;
+            const int64_t base = PACKED ? (int64_t)t * NENT : (int64_t)ptr[first];
+            const double dv = (!PACKED && lane < BS) ? dg[first + lane] : 1.0;
+            if (pass) __syncthreads();                          // every wave of the block is done with the forward copy
 #pragma unroll
-        for (int k = 0; k < (NT + 127) / 128; k++)
-            if (k % WPT == sub)
-                __builtin_amdgcn_global_load_lds((csx_gptr)(val + base + k * 128 + 2 * lane), (csx_lptr)(M + k * 128), 16, 0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                    // all shares of the copy have landed
-        if (sub == 0 && lane < BS) DG[lane] = dv;           // behind the DMA overrun of the last chunk
-        __syncthreads();
-        dense_exact_pass_dpp<BS, pass == 1, MIX>(x, M, DG, lane);
+            for (int k = 0; k < (PACKED ? MSZ / 128 : (NT + 127) / 128); k++)
+                if (k % WPT == sub) {
+                    const int e = k * 128 + 2 * lane;
+                    // (programs: the overrun of the last chunk reads the next block's -- the arrays are padded by 128; packed: a lane
+                    // past the block's end repeats its start)
+                    __builtin_amdgcn_global_load_lds((csx_gptr)(val + base + (PACKED && e >= NENT ? 0 : e)), (csx_lptr)(M + k * 128), 16, 0, 0);
+                }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                    // all shares of the copy have landed
+            if (!PACKED) {
+                if (sub == 0 && lane < BS) DG[lane] = dv;       // behind the DMA overrun of the last chunk
+                __syncthreads();
+            }
+        }
+        dense_exact_pass_dpp<BS, pass == 1, MIX, PACKED>(x, M, DG, lane);
     };
     run_pass(std::integral_constant<int, 0>{});
     run_pass(std::integral_constant<int, 1>{});
@@ -2550,22 +2589,25 @@ static int cholsol_exact_classes_build(CholPlan *P) {
 
 static int launch_exact_dpp(int BS, const Tree *trees, int32_t ntrees, const int32_t *nodes, const int32_t *perm, const int32_t *f_ptr,
                             const double *f_val, const int32_t *b_ptr, const double *dense_b, const double *diagk, const double *diagb,
-                            double *B, int32_t nrhs, bool mix) {
+                            double *B, int32_t nrhs, bool mix, const double *packed_lx = nullptr) {
+    // packed_lx (with mix): L.x of a factor that is nothing but these equal blocks, block t at t BS (BS + 1) / 2 -- no programs needed
     hipStream_t s = ctx().stream;
     const int32_t chunks = (nrhs + 63) / 64;
     const int share = chunks % 4 == 0 ? 1 : chunks % 2 == 0 ? 2 : 4;
     const int64_t groups = ((int64_t)ntrees + share - 1) / share * (chunks / (4 / share));
     const dim3 grid((unsigned)groups);
-#define CSX_DPP_X(BS_, SH, MX)                                                                                                     \
-    hipLaunchKernelGGL((k_cholsol_dense_exact_dpp<BS_, SH, MX>), grid, dim3(256), 0, s, trees, ntrees, nodes, perm, f_ptr, f_val, \
+    if (packed_lx) f_val = packed_lx;
+#define CSX_DPP_X(BS_, SH, MX, PK)                                                                                                     \
+    hipLaunchKernelGGL((k_cholsol_dense_exact_dpp<BS_, SH, MX, PK>), grid, dim3(256), 0, s, trees, ntrees, nodes, perm, f_ptr, f_val, \
                        b_ptr, dense_b, diagk, diagb, B, nrhs, chunks)
-#define CSX_DPP_S(BS_, MX)                      \
-    if (share == 1) CSX_DPP_X(BS_, 1, MX);      \
-    else if (share == 2) CSX_DPP_X(BS_, 2, MX); \
-    else CSX_DPP_X(BS_, 4, MX)
-#define CSX_DPP_V(BS_)               \
-    if (mix) { CSX_DPP_S(BS_, 1); }  \
-    else { CSX_DPP_S(BS_, 0); }
+#define CSX_DPP_S(BS_, MX, PK)                      \
+    if (share == 1) CSX_DPP_X(BS_, 1, MX, PK);      \
+    else if (share == 2) CSX_DPP_X(BS_, 2, MX, PK); \
+    else CSX_DPP_X(BS_, 4, MX, PK)
+#define CSX_DPP_V(BS_)                                \
+    if (mix && packed_lx) { CSX_DPP_S(BS_, 1, true); } \
+    else if (mix) { CSX_DPP_S(BS_, 1, false); }        \
+    else { CSX_DPP_S(BS_, 0, false); }
     switch (BS) {
         case 8: CSX_DPP_V(8); break;
         case 16: CSX_DPP_V(16); break;
@@ -2611,8 +2653,12 @@ static int cholsol_solve(CholPlan *P, double *B, int32_t nrhs) {
         if (P->clique) {
             // a plan csx_cholsol_factor made holds the matrix-core operands only (written by the block kernel beside L.x); what the
             // substitution kernels read is cut out of L.x the first time one of them is asked for
+            // ... unless the kernel asked for takes L.x as it is: the matrix cores (W tiles beside it), and -- round 5 -- the
+            // default exact kernel, which copies the block's packed columns to LDS once for both passes
             const bool cores = P->dense_bs && P->relaxed && P->frag_f && ctx().opt.cholsol_dense_blocks;
-            if (!cores && !P->f_val) CSX_TRY(cholsol_plan_clique(P, P->dense_bs));
+            const int wantv = ctx().opt.cholsol_exact_variant;
+            const bool packed_exact = P->dense_bs && !P->relaxed && ctx().opt.cholsol_dense_blocks && !(wantv >= 1 && wantv <= 6 && wantv != 5);
+            if (!cores && !packed_exact && !P->f_val) CSX_TRY(cholsol_plan_clique(P, P->dense_bs));
             if (P->clique_zero_pivot) return CSX_EZEROPIVOT;
             if (!ctx().opt.cholsol_dense_blocks) CSX_TRY(cholsol_clique_local(P));
         } else {
@@ -2634,8 +2680,9 @@ static int cholsol_solve(CholPlan *P, double *B, int32_t nrhs) {
             if (variant >= 5) {
                 // the L values by DPP row broadcast: one right-hand side per lane; waves that solve the same block share its
                 // LDS copy (as many as divide the number of 64-wide chunks of right-hand sides)
+                // (a plan on all the columns of L -- `clique` -- hands the kernel L.x itself)
                 return launch_exact_dpp(P->dense_bs, P->trees, P->ntrees, P->tree_nodes, P->perm, P->f_ptr, P->f_val, P->b_ptr, P->dense_b,
-                                        P->diagk, P->diagb, B, nrhs, variant == 5);
+                                        P->diagk, P->diagb, B, nrhs, variant == 5, P->clique && variant == 5 ? P->L->x : nullptr);
             }
             if (P->dense_bs == 64 && variant > 2) variant -= 2;
             if (nrhs <= 64 && variant > 2) variant -= 2;
