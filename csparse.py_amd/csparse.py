@@ -1159,8 +1159,8 @@ def cholsol_factor(A, order=0, exact=None):
     if order == 0 and A.m == A.n and _meta(A)[1]:
         # natural order: analysis, factorisation and plan in ONE library call, S never leaving the device (csx_cholsol_factor:
         # round 4's flow handed 40 MB of parent / cp to the host, back again, and re-read L twice to re-arrange it).  The plan
-        # starts in the order blocks are solved in unless every solve is to be exact; a list switches it (a flag, and the
-        # substitution programs cut out of L.x at that moment).
+        # starts in the order blocks are solved in unless every solve is to be exact; a list switches it (a flag: the exact
+        # kernel of a forest of equal blocks reads L.x itself).
         fused = _cholsol_factor_fused(A, exact is True)
         if fused is None:
             return None
