@@ -80,6 +80,31 @@ __global__ __launch_bounds__(256) void k_clique_min(int32_t n, int32_t nnz, cons
     const int64_t k64 = g64 * CQ_MIN_COLS + q;
     const int32_t k = kk[q];
     const int32_t b = bb[q], e = ee[q];
+    // The column every forest this path was made for consists of: at most 64 entries (with the alignment slack: one step), the
+    // first one row r0 <= k, entry t = row r0 + t up to row k, everything after it below the diagonal.  Sixteen lanes agree on that
+    // with four comparisons each, one broadcast and four shuffles; the general rule below (prefix maxima over the lanes, counts,
+    // positions: ~60 instructions a step) is for the columns that are anything else.  Same u[k], no flag raised: what the rule
+    // below finds for such a column.
+    if (e - (b & ~3) <= 64 && e > b) {
+        const int4 v = first4[q];
+        const int32_t r[4] = {v.x, v.y, v.z, v.w};
+        const int sl = b & 3;                                   // lane 0's element holding the column's first entry
+        const int32_t rs = sl == 0 ? r[0] : sl == 1 ? r[1] : sl == 2 ? r[2] : r[3];
+        const int32_t r0 = __shfl(rs, 0, 16);
+        bool fits = r0 >= 0 && r0 <= k;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int32_t pos = 4 * t + c - sl;                 // position in the column
+            if (pos >= 0 && pos < e - b) fits = fits && (pos <= k - r0 ? r[c] == r0 + pos : r[c] > k);
+        }
+        int ok = fits ? 1 : 0;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) ok &= __shfl_xor(ok, o, 16);
+        if (ok && e - b >= k - r0 + 1) {                         // (uniform over the 16 lanes; the upper part is all there)
+            if (t == 0 && k64 < n) u[k] = r0;
+            continue;
+        }
+    }
     int32_t mn = k, run = -1;          // smallest upper row; largest upper row of the steps before
     int32_t nup = 0, lastpos = -1;     // upper entries of this lane; position (in the column) of its last one
     bool bad = false;
