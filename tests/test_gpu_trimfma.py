@@ -365,3 +365,31 @@ def test_lusol_solve_fuses_the_permutations_into_the_sweeps(cs, nrhs, perms):
         for h in (hp, hq):
             if h.value:
                 _csx.free(h)
+
+
+@pytest.mark.parametrize("order", [0, 1])
+def test_whole_chunks_and_partial_chunks_of_right_hand_sides_give_the_same_bits(cs, order):
+    """k_rag_mfma moves X in one of five ways (MODE: run-time paths; consecutive rows through a buffer resource; gather; scatter;
+    looked-up rows through whole-block resources) chosen by the host from the number of right-hand sides, the rows of the components
+    and the permutation -- the arithmetic of a right-hand side is the same in all of them: a batch of 128 (whole chunks: MODE 1 in
+    the natural order, MODE 4 under a fill-reducing permutation) and a batch of 70 (MODE 0) agree bit for bit on the columns they
+    share, and both are inside the budget against the oracle."""
+    rng = np.random.default_rng(11)
+    sizes = list(rng.integers(1, 65, 200)) + [64, 33, 48, 17]
+    n, Ap, Ai, Ax = _blocks(sizes, 23)
+    A = cs.cs_pin(_host_cs(cs, n, n, Ap, Ai, Ax))
+    F = cs.cholsol_factor(A, order=order, exact=False)
+    assert F.info()["matrix_cores"]
+    B = synth.rhs(n, 128, 5)
+    d128, d70 = cs.dvec(B), cs.dvec(np.ascontiguousarray(B[:, :70]))
+    assert F.solve(d128) is True and F.solve(d70) is True
+    X128, X70 = d128.numpy().reshape(n, 128), d70.numpy().reshape(n, 70)
+    assert X128[:, :70].tobytes() == X70.tobytes()
+    Fe = cs.cholsol_factor(A, order=order, exact=True)
+    de = cs.dvec(np.ascontiguousarray(B[:, :3]))
+    assert Fe.solve(de) is True
+    Xe = de.numpy().reshape(n, 3)
+    for r in range(3):
+        assert TOL.normwise(X128[:, r], Xe[:, r]) <= 1e-12
+        R = CO.gaxpy(n, n, Ap, Ai, Ax, X128[:, r], -B[:, r])
+        assert np.max(np.abs(R)) <= 1e-11 * np.max(np.abs(B[:, r])) * 64
