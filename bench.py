@@ -889,6 +889,35 @@ def cholsol_section(args, lib, cs, comm, hB, nb, bs, barrier, max_over_ranks, pr
         del parent, cp
     except Exception as e:                                # a comparison figure: never take the section down
         sep["error"] = "%s: %s" % (type(e).__name__, e)
+    # the reference's own driver is exact throughout -- cs_cholsol(order, A, b): the same one call with exact = 1 (no W tiles; the
+    # plan is the block list, the exact kernel reads L.x itself), whole pipeline each time (analysis dropped), then ONE batch
+    exact_flow = {}
+    try:
+        ef_ms, es_ms = [], []
+        for rep in range(3):
+            hLe, plane = _csx.new_handle(), _csx.new_handle()
+            _csx.check(lib.csx_csc_invalidate(hB), "csc_invalidate")
+            _csx.sync()
+            t0 = time.perf_counter()
+            _csx.check(lib.csx_cholsol_factor(hB, 1, hLe, plane), "cholsol_factor")
+            _csx.sync()
+            ef_ms.append((time.perf_counter() - t0) * 1e3)
+            hRe = _csx.new_handle()
+            _csx.check(lib.csx_gen_rhs(n, k, rank * k, hRe), "gen_rhs")
+            _csx.sync()
+            t0 = time.perf_counter()
+            _csx.check(lib.csx_cholsol_solve(plane, hRe, k), "cholsol_solve")
+            _csx.sync()
+            es_ms.append((time.perf_counter() - t0) * 1e3)
+            _csx.free(hRe)
+            _csx.free(plane)
+            _csx.free(hLe)
+        tf_e, ts_e = sorted(ef_ms)[1], sorted(es_ms)[1]
+        exact_flow = {"factor_calls_ms": [round(v, 3) for v in ef_ms], "first_batch_ms": [round(v, 3) for v in es_ms],
+                      "end_to_end_solves_per_s_per_gpu": round(k / ((tf_e + ts_e) * 1e-3), 1),
+                      "note": "csx_cholsol_factor(exact = 1) + ONE batch of %d, medians of three; every bit the reference's" % k}
+    except Exception as e:                                # a comparison figure: never take the section down
+        exact_flow = {"error": "%s: %s" % (type(e).__name__, e)}
     # exact (default) order first: bit-identical to cs_lsolve + cs_ltsolve, substitution kernels
     hR0 = _csx.new_handle()
     _csx.check(lib.csx_gen_rhs(n, k, rank * k, hR0), "gen_rhs")
@@ -959,8 +988,8 @@ def cholsol_section(args, lib, cs, comm, hB, nb, bs, barrier, max_over_ranks, pr
                              "achieved": round(chol_bytes / (chol_kernel_ms.value * 1e-3) / 1e9, 2) if chol_kernel_ms.value > 0 else None,
                              "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(chol_bytes / (chol_kernel_ms.value * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if chol_kernel_ms.value > 0 else None,
-                             "note": "inside csx_cholsol_factor the kernel writes the matrix-core solve's operands (1.6 GB) beside "
-                                     "L.x and leaves L.i to be made on demand; algorithmic bytes stay SURVEY 8d's 12 nnz(triu A) + 12 lnz",
+                             "note": "inside csx_cholsol_factor the kernel writes the inverses of the diagonal tiles (0.64 GB: all the matrix-core "
+                                     "solve needs beyond L.x) and leaves L.i to be made on demand; algorithmic bytes stay SURVEY 8d's 12 nnz(triu A) + 12 lnz",
                              "factor_call_ms": round(t_factor * 1e3, 3),
                              "frac_whole_call": round(chol_bytes / t_factor / 1e9 / HBM_PEAK_GBS, 4),
                              "traffic": (measured_traffic("k_chol_clique", n=n) or {}).get("bytes"),
@@ -976,7 +1005,8 @@ def cholsol_section(args, lib, cs, comm, hB, nb, bs, barrier, max_over_ranks, pr
                                              "solve_phase_solves_per_s_whole_job": round(k * world / (ms * 1e-3), 1)})(max_over_ranks(t_factor)),
            "end_to_end_note": "cs_schol + cs_chol + plan + ONE batch of %d right-hand sides (the solve phase alone: solves_per_s)" % k,
            "exact_order": {"ms_per_batch": round(ms_exact, 4), "solves_per_s_per_gpu": round(k / (ms_exact * 1e-3), 1),
-                           "note": "default order of every plan: bit-identical to cs_lsolve + cs_ltsolve"}}
+                           "note": "default order of every plan: bit-identical to cs_lsolve + cs_ltsolve",
+                           "one_batch_end_to_end": exact_flow}}
     if rank == 0 and world == 1 and not args.skip_cpu:
         out["cpu_baseline"] = cpu_baseline_cholsol(args.cpu_chol_blocks, bs, args.cpu_seconds, lnz)
     bad = [name for name in ("factor_broadcast", "rhs_scatter", "solution_gather")

@@ -2416,6 +2416,7 @@ static int cholsol_build_ragged(CholPlan *P) {
 static int cholsol_build_mfma(CholPlan *P) {
     if (!P->dense_bs) return cholsol_build_ragged(P);
     if (P->mfma_tried || P->dense_bs < 16) return CSX_OK;
+    if (P->clique && !P->f_val) CSX_TRY(cholsol_plan_clique(P, P->dense_bs));   // (a plan that has been the block list so far: k_mfma_frags reads programs)
     P->mfma_tried = true;
     hipStream_t s = ctx().stream;
     const int nb16 = P->dense_bs / 16;
@@ -3061,7 +3062,21 @@ static int cholsol_factor_device(csx_handle_t hA, Csc *A, bool exact, Csc *L, Ch
                     *Pout = P;
                     P->n = n;
                     P->L = L;
-                    CSX_TRY(cholsol_plan_clique(P, bs));
+                    if (exact) {
+                        // every solve in the reference's order: the default exact kernel reads L.x itself (k_cholsol_dense_exact_dpp<PACKED>),
+                        // so the plan is the block list; programs are cut out of L.x only if another kernel is asked for (cholsol_solve)
+                        CSX_TRY(dalloc(&P->trees, (size_t)F.nblocks));
+                        CSX_TRY(dalloc(&P->tree_nodes, (size_t)n));
+                        CSX_TRY(ragged_blocks(F.start, F.nblocks, n, P->trees, P->tree_nodes));
+                        P->clique = true;
+                        P->clique_zero_pivot = false;      // every pivot is a square root of a positive number
+                        P->ntrees = F.nblocks;
+                        P->max_nodes = bs;
+                        P->local = true;
+                        P->dense_bs = bs;
+                    } else {
+                        CSX_TRY(cholsol_plan_clique(P, bs));
+                    }
                 } else {
                     CSX_TRY(cholsol_plan(L, nullptr, Pout));
                     P = *Pout;
