@@ -540,9 +540,13 @@ __global__ __launch_bounds__(64 * TL_WAVES_MAX) void k_tri_local(const Tree *__r
                                                                  const int32_t *__restrict__ prog_ptr,
                                                                  const int32_t *__restrict__ prog_idx,
                                                                  const double *__restrict__ prog_val,
-                                                                 const double *__restrict__ prog_diag, double *B,
-                                                                 int32_t nrhs, int32_t chunks, int32_t max_nodes,
-                                                                 int32_t waves_per_wg) {
+                                                                 const double *__restrict__ prog_diag, const double *Bsrc,
+                                                                 double *B, const int32_t *__restrict__ load_rows,
+                                                                 const int32_t *__restrict__ store_rows, int32_t nrhs,
+                                                                 int32_t chunks, int32_t max_nodes, int32_t waves_per_wg) {
+    // Bsrc / load_rows, B / store_rows: row j of the system is read from row load_rows[j] of Bsrc and written to row store_rows[j] of
+    // B (null: row j; Bsrc == B: in place) -- cs_lusol's two permutations ride on its two sweeps (csx_lusol_solve), the order of
+    // the arithmetic is untouched
     extern __shared__ __attribute__((aligned(16))) double xt[];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -557,13 +561,14 @@ __global__ __launch_bounds__(64 * TL_WAVES_MAX) void k_tri_local(const Tree *__r
     double *X = xt + (size_t)w * max_nodes * 64;
     for (int32_t c0 = 0; c0 < tr.count; c0 += 64) {
         const int32_t crow = min(64, tr.count - c0);
-        const int32_t jrow = lane < crow ? nodes[tr.first + c0 + lane] : 0;
+        int32_t jrow = lane < crow ? nodes[tr.first + c0 + lane] : 0;
+        if (load_rows && lane < crow) jrow = load_rows[jrow];
         for (int32_t r0 = 0; r0 < crow; r0 += 16) {
             double tmp[16];
 #pragma unroll
             for (int u = 0; u < 16; u++) {
                 const int32_t row = __builtin_amdgcn_readlane(jrow, min(r0 + u, crow - 1));
-                tmp[u] = B[(int64_t)row * nrhs + rl];
+                tmp[u] = Bsrc[(int64_t)row * nrhs + rl];
             }
 #pragma unroll
             for (int u = 0; u < 16; u++)
@@ -573,7 +578,8 @@ __global__ __launch_bounds__(64 * TL_WAVES_MAX) void k_tri_local(const Tree *__r
     sweep<FORWARD>(tr, prog_ptr, prog_idx, prog_val, prog_diag, X, lane);
     for (int32_t c0 = 0; c0 < tr.count; c0 += 64) {
         const int32_t crow = min(64, tr.count - c0);
-        const int32_t jrow = lane < crow ? nodes[tr.first + c0 + lane] : 0;
+        int32_t jrow = lane < crow ? nodes[tr.first + c0 + lane] : 0;
+        if (store_rows && lane < crow) jrow = store_rows[jrow];
         for (int32_t r = 0; r < crow; r++) {
             const int32_t row = __builtin_amdgcn_readlane(jrow, r);
             if (live) B[(int64_t)row * nrhs + rhs] = X[(c0 + r) * 64 + lane];
@@ -1713,8 +1719,18 @@ static int components_ragged(TriPlan *P) {
     return CSX_OK;
 }
 
-static int solve_components(TriPlan *P, double *X, int32_t nrhs) {
+// io (csx_lusol_solve, exact order): the block read and its row map, the row map of the block written (X); honoured by the kernel
+// of MANY right-hand sides only -- *io_taken says whether (false: nothing was launched, the caller runs the separate steps)
+struct TriIO {
+    const double *src;
+    const int32_t *load_rows, *store_rows;
+};
+static int solve_components(TriPlan *P, double *X, int32_t nrhs, const TriIO *io = nullptr, bool *io_taken = nullptr) {
     hipStream_t s = ctx().stream;
+    if (io) {
+        *io_taken = false;
+        if ((P->rounding_equal && nrhs > 8) || nrhs <= 32) return CSX_OK;      // (other kernels' territory)
+    }
     if (P->rounding_equal && nrhs > 8) {
         // the caller granted rounding (csx_tri_set_order): dense components on the matrix cores, one sweep in position order
         CSX_TRY(components_ragged(P));
@@ -1796,14 +1812,17 @@ static int solve_components(TriPlan *P, double *X, int32_t nrhs) {
         CSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tri_local<true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
         hipLaunchKernelGGL(k_tri_local<true>, grid, dim3(64 * waves), lds, s, P->comps, P->ncomp, P->comp_nodes,
-                           P->prog_ptr, P->prog_idx, P->prog_val, P->prog_diag, X, nrhs, chunks, P->comp_max, waves);
+                           P->prog_ptr, P->prog_idx, P->prog_val, P->prog_diag, io ? io->src : (const double *)X, X,
+                           io ? io->load_rows : nullptr, io ? io->store_rows : nullptr, nrhs, chunks, P->comp_max, waves);
     } else {
         CSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tri_local<false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
         hipLaunchKernelGGL(k_tri_local<false>, grid, dim3(64 * waves), lds, s, P->comps, P->ncomp, P->comp_nodes,
-                           P->prog_ptr, P->prog_idx, P->prog_val, P->prog_diag, X, nrhs, chunks, P->comp_max, waves);
+                           P->prog_ptr, P->prog_idx, P->prog_val, P->prog_diag, io ? io->src : (const double *)X, X,
+                           io ? io->load_rows : nullptr, io ? io->store_rows : nullptr, nrhs, chunks, P->comp_max, waves);
     }
     CSX_LAUNCH_CHECK();
+    if (io) *io_taken = true;
     return CSX_OK;
 }
 
@@ -2694,6 +2713,32 @@ extern "C" int csx_lusol_solve(csx_handle_t hL, csx_handle_t hU, csx_handle_t hp
             CSX_TRY(ragged_solve_io(PU->rag, PU->comp_nodes, nullptr, q, !PU->forward, 1, x, b, nrhs, n));
             if (fused) *fused = 1;
             return CSX_OK;
+        }
+    }
+    if (ctx().opt.tri_components && !PL->rounding_equal && !PU->rounding_equal && nrhs > 32) {
+        // the exact order on forests of small components: the same fusion through the in-LDS sweeps (k_tri_local reads and writes a
+        // component's rows through the row maps); the arithmetic and its order are those of the separate steps, bit for bit
+        CSX_TRY(analyse_components(PL));
+        CSX_TRY(analyse_components(PU));
+        if (PL->comp_ok && PU->comp_ok) {
+            DevScope tmp;
+            int32_t *invp = nullptr;
+            if (pinv) {
+                CSX_TRY(tmp.alloc(&invp, (size_t)n));
+                CSX_HIP(hipMemsetAsync(invp, 0, (size_t)n * sizeof(int32_t), s));
+                hipLaunchKernelGGL(k_invert_perm, dim3((unsigned)(((int64_t)n + 255) / 256)), dim3(256), 0, s, pinv, n, invp);
+                CSX_LAUNCH_CHECK();
+            }
+            bool took = false;
+            const TriIO ioL{b, invp, nullptr};
+            CSX_TRY(solve_components(PL, x, nrhs, &ioL, &took));
+            if (took) {
+                const TriIO ioU{x, nullptr, q};
+                CSX_TRY(solve_components(PU, b, nrhs, &ioU, &took));     // (same plan shape, same nrhs: taken too)
+                if (!took) return CSX_ERUNTIME;
+                if (fused) *fused = 1;
+                return CSX_OK;
+            }
         }
     }
     hipLaunchKernelGGL(k_permute, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, pinv, (const double *)b, x, n, nrhs, 1);
