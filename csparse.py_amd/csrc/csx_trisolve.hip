@@ -2735,8 +2735,14 @@ extern "C" int csx_lusol_solve(csx_handle_t hL, csx_handle_t hU, csx_handle_t hp
             if (took) {
                 const TriIO ioU{x, nullptr, q};
                 CSX_TRY(solve_components(PU, b, nrhs, &ioU, &took));     // (same plan shape, same nrhs: taken too)
-                if (!took) return CSX_ERUNTIME;
-                if (fused) *fused = 1;
+                if (took) {
+                    if (fused) *fused = 1;
+                    return CSX_OK;
+                }
+                // (not taken after all: x holds L's solution of the permuted block -- finish with the separate steps)
+                CSX_TRY(tri_solve_raw(PU, x, nrhs, false));
+                hipLaunchKernelGGL(k_permute, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, q, (const double *)x, b, n, nrhs, 1);
+                CSX_LAUNCH_CHECK();
                 return CSX_OK;
             }
         }
