@@ -1089,7 +1089,7 @@ struct CholPlan {
         Tree *trees = nullptr;
         int32_t *nodes = nullptr, *f_ptr = nullptr, *b_ptr = nullptr;
         double *f_val = nullptr, *dense_b = nullptr, *diagk = nullptr, *diagb = nullptr;
-    } xc[4];
+    } xc[5];
     bool xc_built = false;
     bool mfma_tried = false;  // fragments were built, or refused by the growth guard
     double mfma_growth = 0.0; // max|inv(L_ii)| max|L| over the forest (the guard's measure)
@@ -2487,7 +2487,7 @@ __global__ __launch_bounds__(256) void k_xc_class(const Tree *__restrict__ trees
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ntrees) return;
     const int32_t c = trees[t].count;
-    key[t] = c <= 8 ? 0u : c <= 16 ? 1u : c <= 32 ? 2u : 3u;
+    key[t] = c <= 8 ? 0u : c <= 16 ? 1u : c <= 32 ? 2u : c <= 48 ? 3u : 4u;
     id[t] = (uint32_t)t;
 }
 
@@ -2547,16 +2547,17 @@ static int cholsol_exact_classes_build(CholPlan *P) {
     CSX_TRY(tmp.alloc(&id, (size_t)nt));
     CSX_TRY(tmp.alloc(&skey, (size_t)nt));
     CSX_TRY(tmp.alloc(&list, (size_t)nt));
-    CSX_TRY(tmp.alloc(&bounds, 5));
+    CSX_TRY(tmp.alloc(&bounds, 6));
     hipLaunchKernelGGL(k_xc_class, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, P->trees, nt, key, id);
     CSX_LAUNCH_CHECK();
-    CSX_TRY(stable_sort_by_key(key, id, nullptr, nt, 4, skey, list, nullptr));
-    CSX_TRY(boundaries_from_sorted(skey, nt, 4, bounds));
-    int32_t hb[5] = {0, 0, 0, 0, 0};
+    CSX_TRY(stable_sort_by_key(key, id, nullptr, nt, 5, skey, list, nullptr));
+    CSX_TRY(boundaries_from_sorted(skey, nt, 5, bounds));
+    int32_t hb[6] = {0, 0, 0, 0, 0, 0};
     CSX_HIP(hipMemcpyAsync(hb, bounds, sizeof hb, hipMemcpyDeviceToHost, s));
     CSX_HIP(hipStreamSynchronize(s));
-    static const int kBS[4] = {8, 16, 32, 64};
-    for (int c = 0; c < 4; c++) {
+    // (a class of 48 since late in round 5: a block of 33 .. 48 columns padded to 64 did 1.8 times the terms it does padded to 48)
+    static const int kBS[5] = {8, 16, 32, 48, 64};
+    for (int c = 0; c < 5; c++) {
         CholPlan::ExactClass &X = P->xc[c];
         X.count = hb[c + 1] - hb[c];
         if (X.count <= 0) continue;
@@ -2578,6 +2579,7 @@ static int cholsol_exact_classes_build(CholPlan *P) {
             case 8: CSX_XCP(8); break;
             case 16: CSX_XCP(16); break;
             case 32: CSX_XCP(32); break;
+            case 48: CSX_XCP(48); break;
             default: CSX_XCP(64); break;
         }
 #undef CSX_XCP
@@ -2613,6 +2615,7 @@ static int launch_exact_dpp(int BS, const Tree *trees, int32_t ntrees, const int
         case 8: CSX_DPP_V(8); break;
         case 16: CSX_DPP_V(16); break;
         case 32: CSX_DPP_V(32); break;
+        case 48: { CSX_DPP_S(48, 1, false); } break;      // (the padded size classes only: programs, the default mix)
         default: CSX_DPP_V(64); break;
     }
 #undef CSX_DPP_V
@@ -2630,8 +2633,8 @@ static int cholsol_solve(CholPlan *P, double *B, int32_t nrhs) {
         // the exact order on cliques of unequal sizes: size classes padded with the identity, the register-resident exact kernel
         CSX_TRY(cholsol_exact_classes_build(P));
         if (P->xc_built) {
-            static const int kBS[4] = {8, 16, 32, 64};
-            for (int c = 0; c < 4; c++) {
+            static const int kBS[5] = {8, 16, 32, 48, 64};
+            for (int c = 0; c < 5; c++) {
                 const CholPlan::ExactClass &X = P->xc[c];
                 if (X.count > 0)
                     CSX_TRY(launch_exact_dpp(kBS[c], X.trees, X.count, X.nodes, nullptr, X.f_ptr, X.f_val, X.b_ptr, X.dense_b, X.diagk,
