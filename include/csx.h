@@ -251,7 +251,9 @@ int csx_chol_info(int32_t *path, double *numeric_ms);
 /* The solve phase of cs_cholsol, csparse.py:640-643, for nrhs right-hand sides:
  * B (n-by-nrhs, row-major) is overwritten with the solutions.  The plan of a factor that is a forest of equal dense
  * blocks of 8 / 16 / 32 / 64 columns (recognised from L itself, also from an L that came over the wire or from the host)
- * is cut straight out of L.x; any other factor gets two triangular-solve analyses and the forest partition. */
+ * is the block list: the default exact kernel and the matrix-core kernel read the blocks' packed columns in L.x itself (round 5);
+ * any other factor gets two triangular-solve analyses and the forest partition.  The plan BORROWS L's arrays either way (lazy
+ * builds read them too): free the plan before L. */
 int csx_cholsol_plan(csx_handle_t L, const int32_t *pinv /* host, or NULL */, csx_handle_t *plan);
 /* cs_cholsol's factor sequence in natural order -- S = cs_schol(0, A); N = cs_chol(A, S), csparse.py:636-639 -- and the solve
  * plan of csparse.py:640-643 in ONE call, the symbolic analysis never leaving the device (round 5; replaces csx_schol's 40 MB of
