@@ -1048,6 +1048,7 @@ struct CholPlan {
     bool local = false;
     int32_t ntrees = 0, max_nodes = 0;
     Tree *trees = nullptr;
+    Tree *trees_by_size = nullptr;   // the same list biggest first: what k_cholsol_local launches by (trees_biggest_first), made at its first launch
     int32_t *tree_nodes = nullptr, *local_id = nullptr;
     // per-tree solve programs, indexed by position k in tree_nodes (row a of tree t: k = first + a):
     // forward terms [f_ptr[k], f_ptr[k+1]) and backward terms [b_ptr[k], b_ptr[k+1]) as
@@ -1121,6 +1122,7 @@ void free_cholplan(CholPlan *P) {
     dfree(P->perm);
     dfree(P->scratch);
     dfree(P->trees);
+    dfree(P->trees_by_size);
     dfree(P->tree_nodes);
     dfree(P->local_id);
     dfree(P->f_ptr);
@@ -2764,8 +2766,9 @@ static int cholsol_solve(CholPlan *P, double *B, int32_t nrhs) {
         const size_t lds = per_wave * (size_t)waves;
         CSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cholsol_local),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+        if (!P->trees_by_size) CSX_TRY(trees_biggest_first(P->trees, P->ntrees, P->max_nodes, &P->trees_by_size));
         hipLaunchKernelGGL(k_cholsol_local, dim3((unsigned)((tasks + waves - 1) / waves)), dim3(64 * waves), lds, s,
-                           P->trees, P->ntrees, P->tree_nodes, P->perm, P->f_ptr, P->f_idx, P->f_val, P->b_ptr, P->b_idx,
+                           P->trees_by_size, P->ntrees, P->tree_nodes, P->perm, P->f_ptr, P->f_idx, P->f_val, P->b_ptr, P->b_idx,
                            P->b_val, P->diagk, P->diagb, B, nrhs, chunks, P->max_nodes, waves);
         CSX_LAUNCH_CHECK();
         return CSX_OK;

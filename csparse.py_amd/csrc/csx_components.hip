@@ -163,4 +163,45 @@ int group_by_root(int32_t n, const int32_t *root, uint32_t *nodes, int32_t *comp
     return CSX_OK;
 }
 
+__global__ __launch_bounds__(256) void k_comp_size_key(const Tree *__restrict__ comps, int32_t ncomp, int32_t maxc, uint32_t *__restrict__ key,
+                                                       uint32_t *__restrict__ id) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= ncomp) return;
+    key[q] = (uint32_t)(maxc - comps[q].count);       // biggest first
+    id[q] = (uint32_t)q;
+}
+__global__ __launch_bounds__(256) void k_comp_gather(const Tree *__restrict__ comps, const uint32_t *__restrict__ list, int32_t ncomp,
+                                                     Tree *__restrict__ out) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < ncomp) out[q] = comps[list[q]];
+}
+
+
+int trees_biggest_first(const Tree *trees, int32_t ntrees, int32_t max_count, Tree **out) {
+    *out = nullptr;
+    if (ntrees <= 0) return CSX_OK;
+    hipStream_t s = ctx().stream;
+    DevScope tmp;
+    uint32_t *key = nullptr, *id = nullptr, *list = nullptr;
+    CSX_TRY(tmp.alloc(&key, (size_t)ntrees));
+    CSX_TRY(tmp.alloc(&id, (size_t)ntrees));
+    CSX_TRY(tmp.alloc(&list, (size_t)ntrees));
+    Tree *o = nullptr;
+    CSX_TRY(dalloc(&o, (size_t)ntrees));
+    const unsigned g = (unsigned)((ntrees + 255) / 256);
+    hipLaunchKernelGGL(k_comp_size_key, dim3(g), dim3(256), 0, s, trees, ntrees, max_count, key, id);
+    int st = hipGetLastError() == hipSuccess ? CSX_OK : CSX_ERUNTIME;
+    if (st == CSX_OK) st = stable_sort_by_key(key, id, nullptr, ntrees, (uint32_t)max_count + 1, nullptr, list, nullptr);
+    if (st == CSX_OK) {
+        hipLaunchKernelGGL(k_comp_gather, dim3(g), dim3(256), 0, s, trees, list, ntrees, o);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) st = CSX_ERUNTIME;     // (list is a temporary)
+    }
+    if (st != CSX_OK) {
+        dfree(o);
+        return st;
+    }
+    *out = o;
+    return CSX_OK;
+}
+
 }  // namespace csx

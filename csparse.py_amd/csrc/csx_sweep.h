@@ -25,6 +25,11 @@ int group_by_root(int32_t n, const int32_t *root, uint32_t *nodes, int32_t *comp
 // A wave of the fused sweeps owns an X tile of `per_wave` bytes of LDS.  Waves per workgroup (1 .. maxw) that put the most
 // waves on a CU (160 KB of LDS); of equal choices the smallest workgroup (the last round of a launch fills better).  W's
 // 67-row components (34 KB a wave): 1 x 4 workgroups instead of 3 x 1 -- the old rule capped a workgroup at 128 KB.
+// a copy of a component list ordered biggest first (stable; counts in [0, max_count]): the order single-wave-per-component kernels launch
+// by -- workgroups go to the XCDs and shader engines in a fixed rotation, so a periodic pattern of big and small components in launch
+// order becomes an imbalance between engines (csx_trisolve.hip: analyse_components)
+int trees_biggest_first(const Tree *trees, int32_t ntrees, int32_t max_count, Tree **out);
+
 inline int tile_waves_per_workgroup(size_t per_wave, int maxw) {
     const size_t cu = 160 * 1024 - 1024;
     int best = 1;

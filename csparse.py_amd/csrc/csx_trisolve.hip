@@ -71,6 +71,7 @@ struct TriPlan {
     bool comp_tried = false, comp_ok = false;
     int32_t ncomp = 0, comp_max = 0;
     Tree *comps = nullptr;           // [ncomp] (first, count) into comp_nodes
+    Tree *comps_by_size = nullptr;   // the same list, biggest first (stable): what the many-right-hand-side sweeps launch by
     int32_t *comp_nodes = nullptr;   // [n] rows grouped by component, ascending inside one
     int32_t *prog_ptr = nullptr, *prog_idx = nullptr;   // per sweep position: terms (local row * 64, value)
     double *prog_val = nullptr, *prog_diag = nullptr;
@@ -114,6 +115,7 @@ void free_triplan(TriPlan *t) {
     dfree(t->level_of);
     dfree(t->resume);
     dfree(t->comps);
+    dfree(t->comps_by_size);
     dfree(t->comp_nodes);
     dfree(t->prog_ptr);
     dfree(t->prog_idx);
@@ -1700,6 +1702,12 @@ static int analyse_components(TriPlan *P) {
             break;
         }
     }
+    // The sweeps of many right-hand sides (k_tri_local) launch one single-wave workgroup per (component, chunk).  Workgroups are dealt
+    // to the XCDs and their shader engines in a fixed rotation, so a PERIODIC pattern of work in launch order lands on the hardware as
+    // an imbalance: W's U is a 65-row component and a singleton per block -- sixteen big workgroups, sixteen tiny ones, and so on: half
+    // of the engines got the big ones and its sweep took exactly twice its L's (2.30 against 1.14 ms), with or without the singletons'
+    // work.  Biggest first (stable): 1.28 ms.
+    CSX_TRY(trees_biggest_first(comps, P->ncomp, maxc, &P->comps_by_size));
     CSX_HIP(hipStreamSynchronize(s));
     P->comp_ok = true;
     return CSX_OK;
@@ -1811,13 +1819,13 @@ static int solve_components(TriPlan *P, double *X, int32_t nrhs, const TriIO *io
     if (P->forward) {
         CSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tri_local<true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-        hipLaunchKernelGGL(k_tri_local<true>, grid, dim3(64 * waves), lds, s, P->comps, P->ncomp, P->comp_nodes,
+        hipLaunchKernelGGL(k_tri_local<true>, grid, dim3(64 * waves), lds, s, P->comps_by_size, P->ncomp, P->comp_nodes,
                            P->prog_ptr, P->prog_idx, P->prog_val, P->prog_diag, io ? io->src : (const double *)X, X,
                            io ? io->load_rows : nullptr, io ? io->store_rows : nullptr, nrhs, chunks, P->comp_max, waves);
     } else {
         CSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_tri_local<false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
-        hipLaunchKernelGGL(k_tri_local<false>, grid, dim3(64 * waves), lds, s, P->comps, P->ncomp, P->comp_nodes,
+        hipLaunchKernelGGL(k_tri_local<false>, grid, dim3(64 * waves), lds, s, P->comps_by_size, P->ncomp, P->comp_nodes,
                            P->prog_ptr, P->prog_idx, P->prog_val, P->prog_diag, io ? io->src : (const double *)X, X,
                            io ? io->load_rows : nullptr, io ? io->store_rows : nullptr, nrhs, chunks, P->comp_max, waves);
     }
