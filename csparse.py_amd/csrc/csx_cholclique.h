@@ -22,6 +22,8 @@ struct CliqueForest {
     int32_t *cp = nullptr;       // device [n + 1]: column pointers of L (csparse.py:2069-2071)
     int32_t *start = nullptr;    // device [nblocks + 1]: first column of every block, then n
     unsigned long long *colmask = nullptr;   // device [n], sparse only: the rows of column k of L as bits (bit r = row start + r)
+    int32_t *order = nullptr;    // device [nblocks], blocks of UNEQUAL sizes only: the blocks biggest first (stable) -- the order the
+                                 // block kernel takes them in, so that the four waves of a workgroup hold blocks of like size
 };
 
 void free_clique(CliqueForest *F);
@@ -55,6 +57,7 @@ struct CliqueEmit {
                                           // ragged_prepare_emit); a block of bs columns then takes ceil(bs / 16) tiles a side, its last
                                           // tile row / column padded with the identity, and its fragments are ALL its tiles (-L_ij
                                           // and W_ii, clique_frags_per_block of them).  null: equal blocks
+    const int32_t *order = nullptr;       // the blocks biggest first (CliqueForest::order; null: matrix order) -- set by chol_clique_numeric
     const int32_t *list = nullptr;        // with frag_off: the blocks ordered by size class (ceil(bs / 16) - 1), class c at
     int32_t cls_start[6] = {0, 0, 0, 0, 0, 0};   // list[cls_start[c] .. cls_start[c + 1]): what the matrix-core block kernel launches by
 };
