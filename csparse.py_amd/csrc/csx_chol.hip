@@ -2428,7 +2428,8 @@ static int cholsol_build_mfma(CholPlan *P) {
     int st = dalloc(&cond, 1);
     if (st == CSX_OK) st = dalloc(&ff, (size_t)P->ntrees * nb16 * 256);
     // (a plan on consecutive columns of L reads the off-diagonal tiles in L.x; the general analysis' plan gets a packed copy)
-    if (st == CSX_OK && !P->clique) st = dalloc(&lc, (size_t)P->ntrees * (bs * (bs + 1) / 2));
+    // (... or whose L.x is not 16-byte aligned -- a wrapped pointer: the copies to LDS move 16 bytes a lane)
+    if (st == CSX_OK && (!P->clique || (reinterpret_cast<uintptr_t>(P->L->x) & 15) != 0)) st = dalloc(&lc, (size_t)P->ntrees * (bs * (bs + 1) / 2));
     if (st == CSX_OK && hipMemsetAsync(cond, 0, sizeof(unsigned long long), s) != hipSuccess) st = CSX_ERUNTIME;
     if (st == CSX_OK) {
         const dim3 g((unsigned)P->ntrees);
@@ -2663,7 +2664,8 @@ static int cholsol_solve(CholPlan *P, double *B, int32_t nrhs) {
             // default exact kernel, which copies the block's packed columns to LDS once for both passes
             const bool cores = P->dense_bs && P->relaxed && P->frag_f && ctx().opt.cholsol_dense_blocks;
             const int wantv = ctx().opt.cholsol_exact_variant;
-            const bool packed_exact = P->dense_bs && !P->relaxed && ctx().opt.cholsol_dense_blocks && !(wantv >= 1 && wantv <= 6 && wantv != 5);
+            const bool lx_aligned = (reinterpret_cast<uintptr_t>(P->L->x) & 15) == 0;      // (the copies to LDS move 16 bytes a lane)
+            const bool packed_exact = P->dense_bs && !P->relaxed && ctx().opt.cholsol_dense_blocks && !(wantv >= 1 && wantv <= 6 && wantv != 5) && lx_aligned;
             if (!cores && !packed_exact && !P->f_val) CSX_TRY(cholsol_plan_clique(P, P->dense_bs));
             if (P->clique_zero_pivot) return CSX_EZEROPIVOT;
             if (!ctx().opt.cholsol_dense_blocks) CSX_TRY(cholsol_clique_local(P));
@@ -2688,7 +2690,8 @@ static int cholsol_solve(CholPlan *P, double *B, int32_t nrhs) {
                 // LDS copy (as many as divide the number of 64-wide chunks of right-hand sides)
                 // (a plan on all the columns of L -- `clique` -- hands the kernel L.x itself)
                 return launch_exact_dpp(P->dense_bs, P->trees, P->ntrees, P->tree_nodes, P->perm, P->f_ptr, P->f_val, P->b_ptr, P->dense_b,
-                                        P->diagk, P->diagb, B, nrhs, variant == 5, P->clique && variant == 5 ? P->L->x : nullptr);
+                                        P->diagk, P->diagb, B, nrhs, variant == 5,
+                                        P->clique && variant == 5 && (reinterpret_cast<uintptr_t>(P->L->x) & 15) == 0 ? P->L->x : nullptr);
             }
             if (P->dense_bs == 64 && variant > 2) variant -= 2;
             if (nrhs <= 64 && variant > 2) variant -= 2;
