@@ -867,7 +867,8 @@ __global__ __launch_bounds__(64 * CQ_WAVES, 3) void k_chol_clique(const int32_t 
 //   panel          U_ki = inv(U_kk') T_ki   (i > k):  A operand V_kk, B operand T_ki;
 //   trailing part  T_ij -= U_ki' U_kj   (k < i <= j): A operand -U_ki, B operand U_kj.
 // What the kernel writes: L.x (column j of L is row j of U: for one register four columns of L, 16 consecutive rows each); with
-// EMIT the matrix-core solve's fragments, which ARE the negated panel tiles and the V tiles register by register, lane by lane --
+// EMIT what the matrix-core solve reads beside L.x -- the V tiles (the inverses of the diagonal tiles) register by register, lane by lane;
+// for blocks of unequal sizes (RAGGED) also their negated panel tiles, the fragments of csx_trimfma.h --
 // 512 contiguous bytes per store; without EMIT the row indices.  64 matrix instructions and about 2 400 vector instructions per
 // 64-column block where the bit-identical kernel issues about 11 000 (csparse.py:598-617 is the arithmetic being regrouped).
 constexpr int CM_WAVES = 4;

@@ -25,7 +25,7 @@ struct RaggedMfma {
 // The components' packed sweep programs (csx_sweep.h: per sweep position the terms (local row * 64, value), the diagonal) made
 // dense in POSITION order -- position sp of a component is its row sp (forward sweeps) or count - 1 - sp (backward sweeps) --
 // zero where the pattern has none, the identity on the padding, cut into 16 x 16 tiles: off-diagonal tiles negated, diagonal
-// tiles inverted, in k_cholsol_mfma's fragment order.  *out = nullptr when a component has more than RAG_MAX_ROWS rows.
+// tiles inverted, fragment by fragment in use order (tile (a, b), b < a, then the inverse of diagonal tile a; 4 fragments of 64 doubles a tile).  *out = nullptr when a component has more than RAG_MAX_ROWS rows.
 // from_factor (or null): the components are blocks of consecutive columns of this Cholesky-shaped factor (trees[b] = {first column,
 // columns}, nodes the identity) and the dense triangles are read from its columns instead of from sweep programs (ptr .. diag unused).
 int ragged_build(const Tree *trees, int32_t ntrees, int32_t max_rows, const int32_t *nodes, const int32_t *ptr, const int32_t *idx,
