@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void k_comp_size_key(const Tree *__restrict__ 
                                                        uint32_t *__restrict__ id) {
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= ncomp) return;
-    key[q] = (uint32_t)(maxc - comps[q].count);       // biggest first
+    key[q] = (uint32_t)min(max(maxc - comps[q].count, 0), maxc);       // biggest first (clamped: a count outside [0, maxc] must not leave the key range)
     id[q] = (uint32_t)q;
 }
 __global__ __launch_bounds__(256) void k_comp_gather(const Tree *__restrict__ comps, const uint32_t *__restrict__ list, int32_t ncomp,
