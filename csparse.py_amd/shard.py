@@ -145,8 +145,12 @@ class Rendezvous(object):
         while time.time() < deadline:
             for port in self._candidates():
                 try:
-                    with socket.create_connection((self.addr, port), timeout=2.0) as sk:
-                        sk.settimeout(10.0)
+                    left = deadline - time.time()
+                    if left <= 0:
+                        break
+                    # (a stranger that accepts and says nothing must not hold this rank past its deadline: the waits are cut to what is left)
+                    with socket.create_connection((self.addr, port), timeout=min(2.0, max(0.2, left))) as sk:
+                        sk.settimeout(min(10.0, max(0.2, left)))
                         self._send(sk, _MAGIC + self.token)
                         ans = self._recv(sk)
                         if ans[:4] == _MAGIC:
